@@ -1,0 +1,122 @@
+/*
+ * include/gaba.h -- C-ABI of the MI355X-native banded-extension library (libminialign_amd.so).
+ *
+ * Drop-in surface for the reference's libgaba header (/root/reference/gaba.h): the structs below keep the
+ * reference's sizes and field order (gaba.h:81-98 params 40 B, :151-155 section 16 B, :169-178 fill 64 B,
+ * :183-188 pos pair, :193-200 segment 32 B; sizes asserted at gaba.c:220-224), status codes are gaba.h:45-51.
+ *
+ * The GPU entry point is *batched*: one wavefront per job runs the reference's call sequence
+ *   gaba_dp_fill_root (gaba.c:2110) -> gaba_dp_fill* (gaba.c:2161) -> gaba_dp_search_max (gaba.c:2776)
+ *   -> gaba_dp_trace (gaba.c:3372)
+ * exactly as minialign's mm_extend_core drives it (minialign.c:4075-4112), on sequences resident in HBM
+ * (2-bit packed + N mask).  The per-call scalar API of gaba.h:245-371 (one fill per call on host pointers)
+ * maps onto a 1-job batch; see INTEGRATION.md for the binding a maintainer would add.
+ *
+ * All functions return NULL / a negative value (and print the reason to stderr) when no gfx950 device is
+ * usable: there is no CPU fallback in this library.
+ */
+#ifndef MINIALIGN_AMD_GABA_H
+#define MINIALIGN_AMD_GABA_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum gaba_status {                 /* gaba.h:45-51 */
+	GABA_CONT = 0, GABA_UPDATE_A = 0x000f, GABA_UPDATE_B = 0x00f0, GABA_TERM = 0x8000, GABA_OOM = 0x0400
+};
+
+struct gaba_params_s {             /* gaba.h:81-98 */
+	int8_t score_matrix[16];
+	int8_t gi, ge, gfa, gfb;
+	int8_t xdrop;
+	uint8_t filter_thresh;
+	void *reserved;
+	uint64_t _pad;
+};
+typedef struct gaba_params_s gaba_params_t;
+
+struct gaba_fill_s {               /* gaba.h:169-178 */
+	uint32_t aid, bid;
+	uint32_t ascnt, bscnt;
+	uint64_t apos, bpos;
+	int64_t max;
+	uint32_t status;
+	uint32_t reserved[5];
+};
+typedef struct gaba_fill_s gaba_fill_t;
+
+struct gaba_pos_pair_s {           /* gaba.h:183-188 */
+	uint32_t aid, bid;
+	uint32_t apos, bpos;
+	uint64_t plen;
+};
+typedef struct gaba_pos_pair_s gaba_pos_pair_t;
+
+struct gaba_segment_s {            /* gaba.h:193-200 */
+	uint32_t aid, bid;
+	uint32_t apos, bpos;
+	uint32_t alen, blen;
+	uint64_t ppos;
+};
+typedef struct gaba_segment_s gaba_path_section_t;
+
+typedef struct gaba_context_s gaba_t;          /* gaba.h:117 */
+typedef struct gaba_arena_s gaba_arena_t;      /* a set of sequences resident in HBM */
+
+/* gaba_init (gaba.h:245, gaba_wrap.h:245-295): validates the scores exactly as gaba_init_check_score
+ * (gaba.c:3614-3640) and uploads the score vectors and the three root blocks (64/32/16 cells). */
+gaba_t *gaba_init(gaba_params_t const *params);
+void gaba_clean(gaba_t *ctx);                  /* gaba.h:252 */
+
+/* upload `n` bases (one byte per base: A,C,G,T = 0..3, N = 4 -- minialign.c:214-220) as 2-bit + N-mask */
+gaba_arena_t *gaba_arena_upload(uint8_t const *bases, uint64_t n);
+void gaba_arena_free(gaba_arena_t *ar);
+
+/* one extension job: the arguments of gaba_dp_fill_root (gaba.c:2110) with host pointers replaced by
+ * arena offsets; rev = 1 selects the mirrored (reverse-complement) view (gaba.h:151-155 gaba_mirror) */
+typedef struct {
+	uint64_t a_off; uint32_t alen, apos;
+	uint64_t b_off; uint32_t blen, bpos;
+	uint8_t arev, brev;
+	uint8_t bw_idx;                /* 0: 64 cells, 1: 32, 2: 16 (gaba_wrap.h:57) */
+	uint8_t do_trace;
+} gaba_job_t;
+
+typedef struct {
+	int64_t max; uint32_t status; uint32_t aid, bid, ascnt, bscnt; uint64_t apos, bpos;
+} gaba_xfill_t;
+
+typedef struct {
+	uint32_t n_fill, max_fill_idx;
+	gaba_xfill_t fill[8];          /* every gaba_fill_t the call sequence produced */
+	uint32_t p_aid, p_bid, p_apos, p_bpos; uint64_t p_plen;    /* gaba_dp_search_max on the max fill */
+	int32_t traced;                /* 0: not requested, 1: ok, -1: path left the band (reference returns NULL) */
+	int64_t score; double identity;
+	uint32_t agcnt, bgcnt, dcnt, slen, plen;
+	struct gaba_segment_s seg[16];
+	uint32_t n_path_words;
+} gaba_xresult_t;
+
+/*
+ * Run `n` jobs.  results[n]; paths: n * path_stride words (job i's path bits start at paths + i * path_stride,
+ * bit k = k-th step from the root, 1 = b-advance, as gaba_alignment_s.path, gaba.h:219).
+ * Returns 0, or a negative error (-2: a job ran out of device workspace, -3: path_stride too small).
+ */
+int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const *b,
+	gaba_job_t const *jobs, uint32_t n, gaba_xresult_t *results, uint32_t *paths, uint32_t path_stride);
+
+/* CIGAR printers over a path (gaba.h:393-420, gaba_parse.h:247-263); host side, operate on host memory.
+ * `path` must be preceded by the two header words {plen, 0x40000000} as in gaba_alignment_s (gaba.h:217). */
+uint64_t gaba_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
+uint64_t gaba_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
+
+/* last kernel time of gaba_dp_extend_batch in milliseconds (HIP events on the launch stream) and work counters */
+typedef struct { double kernel_ms; uint64_t vectors, blocks, trace_steps; } gaba_batch_stats_t;
+void gaba_last_stats(gaba_t *ctx, gaba_batch_stats_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,910 @@
+/*
+ * gaba_device.hpp -- CDNA4 (gfx950) device-side adaptive banded Smith-Waterman-Gotoh extension.
+ *
+ * One wavefront = one band: lane l holds cell l of the current anti-diagonal (W = 64 fills the wave,
+ * W = 32 / 16 use the low lanes).  Difference vectors dh/dv/de/df, the running delta / drop and the
+ * 16-bit middle delta live in VGPRs; the two lane shifts of the recurrence are single DPP moves
+ * (wave_shr:1 / wave_shl:1); the band-steering accumulator, X-drop test and all section bookkeeping
+ * run on the scalar unit.  Traceback masks are accumulated per lane over the 32 vectors of a block
+ * (one bit per vector) and written as one coalesced 1 KiB store per block -- a transposed layout of the
+ * reference's per-vector lane masks, so no ballots are needed in the hot loop.
+ *
+ * Replaces (reference, behaviour only): gaba.c:735-2203 (fill), :2604-2817 (max search),
+ * :2820-3407 (trace), and the arch/x86_64_{sse41,avx2} vector shim it is written on.  Results
+ * (fill max/status/positions, max position, path bits, segments, gap counts, identity) are
+ * bit-identical to the reference; the int8 wrap / saturation points are called out inline.
+ *
+ * Integer add/max/compare and lane shifts only: no MFMA (this is not a contraction).
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gaba {
+
+constexpr int BLK = 32;
+constexpr int MIN_BULK_BLOCKS = 32;              /* gaba.c:186 */
+constexpr int INIT_FETCH_POS = -1;               /* gaba.c:194-195 */
+enum : int { CONT = 0, ZERO = 0x01, TERM = 0x80, STAT_MASK = 0x81, HEAD = 0x20, MERGE = 0x40, ROOT = 0x60 };   /* gaba.c:678-690 */
+enum : uint32_t { UPDATE_A = 0x000f, UPDATE_B = 0x00f0, STATUS_TERM = 0x8000 };                            /* gaba.h:45-51 */
+enum : int { MODEL_AFFINE = 1, MODEL_COMBINED = 2 };
+constexpr uint32_t NIL = 0xffffffffu;
+
+/* ---- sequence arenas: 2-bit packed bases (16 per u32) + 1-bit N mask (32 per u32) ---- */
+struct SeqArena {
+	const uint32_t *pk;
+	const uint32_t *nm;
+};
+/* a section: gaba_section_t (gaba.h:151-155) with the mirrored-pointer trick replaced by a flag */
+struct Sec {
+	uint32_t id, len;
+	uint64_t off;        /* first base of the section in its arena */
+	uint32_t arena;      /* 0: a-side arena (reference), 1: b-side arena (reads), 2: 96 x N tail (minialign.c:4512-4519) */
+	uint32_t rev;        /* 1: mirrored (reverse-complement) */
+};
+
+/* ---- per-job state in HBM (offsets are relative to the wave's slab) ---- */
+struct Fill {            /* gaba_fill_s, gaba.h:169-178 */
+	uint32_t aid, bid, ascnt, bscnt;
+	uint64_t apos, bpos;
+	int64_t max;
+	uint32_t status;
+	uint32_t reserved[5];
+};
+struct Tail {            /* gaba_joint_tail_s, gaba.c:351-366 */
+	uint8_t ch[64];
+	int8_t xd[64];
+	int16_t md[64];
+	int16_t mdrop; uint16_t istat; uint32_t pridx;
+	uint32_t ridx[2], adv[2];
+	uint32_t tail;       /* previous tail (slab offset) or NIL */
+	uint32_t last;       /* _last_block(tail) */
+	int32_t W; uint32_t _pad;
+	Sec sec[2];          /* the sections this fill ran on (replaces atptr / btptr) */
+	Fill f;
+};
+static_assert(sizeof(Tail) == 256 + 8 + 16 + 16 + 48 + 64, "tail layout");
+struct BlkMisc {         /* tail of gaba_block_s, gaba.c:311-314; `link` overlays max_mask for head blocks (gaba.c:321) */
+	int8_t acc, xstat, acnt, bcnt;
+	uint32_t dir_mask;
+	union { uint64_t max_mask; uint32_t link; };
+};
+struct Blk {             /* gaba_block_s, gaba.c:308-315: 1296 B */
+	uint32_t m[4][64];   /* h, v, e, f; lane-major, bit (31 - k) = vector k of the block */
+	uint32_t diff[64];   /* dh | dv << 8 | de << 16 | df << 24 per lane */
+	BlkMisc s;
+};
+static_assert(sizeof(Blk) == 1296, "block layout");
+
+struct PosPair { uint32_t aid, bid, apos, bpos; uint64_t plen; };        /* gaba.h:183-188 */
+struct Segment { uint32_t aid, bid, apos, bpos, alen, blen; uint64_t ppos; };   /* gaba.h:193-200 */
+
+/* scoring constants (uniform; from gaba_init, gaba.c:3644-3680, 3811-3830) */
+struct Consts {
+	int32_t model;
+	uint32_t sb[4];      /* 16 x int8 substitution scores (+2(gi+ge) bias) */
+	int32_t adjh, adjv, ofsh, ofsv, gfh, gfv;
+	int32_t tx;
+	int32_t gi, ge, gfa, gfb;
+	double imx, xmx;
+};
+constexpr uint32_t ROOT_STRIDE = sizeof(Blk) + sizeof(Tail);            /* [blk][tail] x {64, 32, 16} at the head of each slab */
+constexpr uint32_t SLAB_HEAD = 3 * ROOT_STRIDE;
+
+/* ---- wave primitives ---- */
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int sext8(int x) { return __builtin_amdgcn_sbfe(x, 0, 8); }
+__device__ __forceinline__ int sext16(int x) { return __builtin_amdgcn_sbfe(x, 0, 16); }
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int rdfirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t rdfirst64(uint64_t v)
+{
+	return ((uint64_t)(uint32_t)rdfirst((int)(v >> 32)) << 32) | (uint32_t)rdfirst((int)v);
+}
+/* lane i <- lane i - 1, lane 0 <- fill  (_bsl_n, v64i8.h:152) */
+__device__ __forceinline__ int shift_up(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+/* lane i <- lane i + 1, lane 63 <- fill (_bsr_n, v64i8.h:164) */
+__device__ __forceinline__ int shift_dn(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+
+/* ---- sequence fetch (gaba.c:846-1119): value of the k-th base of a section as seen by the band ---- */
+__device__ __forceinline__ uint32_t fetch_code(const SeqArena *ar, const Sec &s, uint32_t i)
+{
+	if(s.arena == 2) { return 4; }
+	uint64_t p = s.off + (s.rev ? (uint64_t)(s.len - 1 - i) : (uint64_t)i);
+	const SeqArena &A = ar[s.arena];
+	uint32_t c = (A.pk[p >> 4] >> (2 * (p & 15))) & 3;
+	uint32_t n = (A.nm[p >> 5] >> (p & 31)) & 1;
+	c = s.rev ? 3 - c : c;                      /* comp_mask_a / compshift_mask_b, gaba.c:852-866 */
+	return n ? 4 : c;
+}
+__device__ __forceinline__ uint32_t enc_b(uint32_t c) { return c == 4 ? 2 : c << 2; }    /* shift_mask_b, gaba.c:856-859 */
+
+/* ---- the band, in registers ---- */
+struct Band {
+	int dh, dv, de, df;      /* int8 semantics, sign-extended */
+	int delta, drop;         /* int8: wrapping add / saturating sub (gaba.c:1649-1650) */
+	int ach, bch;            /* sequence windows: lane 0 = newest a base, lane W-1 = newest b base (gaba.c:806-809) */
+	uint32_t mh, mv, me, mf; /* per-lane traceback bits of the current block, newest vector in bit 0 */
+};
+
+/* uniform per-fill work area (gaba_reader_work_s, gaba.c:407-432) */
+struct Work {
+	int W;
+	uint32_t rlim[2], id[2];
+	Sec sec[2];
+	uint32_t pridx; int32_t ofsd;
+	uint32_t rem[2], sridx[2];
+	uint32_t tail;           /* previous tail */
+	uint32_t acnt, bcnt;     /* consumed in the current block */
+	uint32_t la_cnt;         /* valid look-ahead lengths are implied by the caller */
+	uint32_t dmask; int32_t dacc;
+	uint32_t nblk;           /* blocks written so far in this fill, head included */
+	uint32_t blk0;           /* slab offset of the head block of this fill */
+};
+
+struct Ctx {                 /* everything a device routine needs */
+	const Consts *c;
+	const SeqArena *ar;
+	uint8_t *slab;           /* this wave's arena */
+	uint32_t top, cap;       /* bump pointer / capacity (bytes) */
+	int lane;
+	int err;                 /* sticky: 1 = slab exhausted */
+	uint32_t n_vec, n_blk, n_tr;   /* work counters (uniform): DP vectors, blocks stored, traceback steps */
+};
+
+__device__ __forceinline__ Blk *blk_at(Ctx &x, uint32_t off) { return (Blk *)(x.slab + off); }
+__device__ __forceinline__ Tail *tail_at(Ctx &x, uint32_t off) { return (Tail *)(x.slab + off); }
+__device__ __forceinline__ uint32_t root_blk(int bw_idx) { return (uint32_t)bw_idx * ROOT_STRIDE; }
+__device__ __forceinline__ uint32_t root_tail(int bw_idx) { return (uint32_t)bw_idx * ROOT_STRIDE + (uint32_t)sizeof(Blk); }
+
+__device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
+{
+	uint32_t off = x.top;
+	bytes = (bytes + 15u) & ~15u;
+	if(off + bytes > x.cap) { x.err = 1; return SLAB_HEAD; }      /* keep running inside bounds; the job is reported as failed */
+	x.top = off + bytes;
+	return off;
+}
+
+/* substitution score lookup: _shuf_n(sb, a | b) (gaba.c:1605, 1616) */
+__device__ __forceinline__ int score_of(const Consts &c, int ab)
+{
+	int idx = ab & 15;
+	uint32_t w = (idx & 8) ? ((idx & 4) ? c.sb[3] : c.sb[2]) : ((idx & 4) ? c.sb[1] : c.sb[0]);
+	return sext8((int)(w >> ((idx & 3) * 8)));
+}
+
+/*
+ * one anti-diagonal (gaba.c:1576-1699).  `down` is wave-uniform.  new_base: the base entering the window.
+ * Returns t (the per-lane score increment fed to delta / drop / direction).
+ */
+__device__ __forceinline__ int fill_vector(const Consts &c, Band &b, int W, bool down, int new_base, bool lane_top)
+{
+	if(!down) {
+		b.ach = shift_up(b.ach, new_base);
+		b.dh = shift_up(b.dh, 0);
+		b.df = shift_up(b.df, 0);
+	} else {
+		int nb = shift_dn(b.bch, new_base), nv = shift_dn(b.dv, 0), ne = shift_dn(b.de, 0);
+		if(W != 64) {                              /* the top lane of a narrow band takes the fill values */
+			nb = lane_top ? new_base : nb; nv = lane_top ? 0 : nv; ne = lane_top ? 0 : ne;
+		}
+		b.bch = nb; b.dv = nv; b.de = ne;
+	}
+	int s = score_of(c, b.ach | b.bch);
+	int dh = b.dh, dv = b.dv, de = b.de, df = b.df, t;
+	uint32_t bh, bv, be, bf;
+	if(c.model == MODEL_COMBINED) {                /* gaba.c:1604-1640 */
+		int dfh = sext8(dv + c.gfh), dfv = sext8(c.gfv - dh);
+		int ss = max(max(de, df), dfh);
+		t = max(max(s, dfv), ss);
+		bool gfh = t == dfh, gh = t == de, gfv = t == dfv, gv = t == df;
+		bh = gfh | gh; gh = gh & !gfh;
+		bv = gfv | gv; gv = gv & !gfv;
+		de = sext8(de + c.adjh);
+		int te = max(de, t);
+		be = gh | (te == t);
+		de = sext8(te + dh);
+		dh = sext8(dh + t);
+		df = sext8(df + c.adjv);
+		int tf = max(df, t);
+		bf = gv | (tf == t);
+		df = sext8(tf - dv);
+	} else {                                       /* AFFINE, gaba.c:1576-1602 */
+		t = max(df, max(de, s));
+		bh = t == de; bv = t == df;
+		de = sext8(de + c.adjh);
+		int te = max(de, t);
+		be = te == t;
+		de = sext8(te + dh);
+		dh = sext8(dh + t);
+		df = sext8(df + c.adjv);
+		int tf = max(df, t);
+		bf = tf == t;
+		df = sext8(tf - dv);
+	}
+	int t2 = sext8(dv - t);
+	b.dv = dh; b.dh = t2; b.de = de; b.df = df;
+	b.mh = (b.mh << 1) | bh; b.mv = (b.mv << 1) | bv; b.me = (b.me << 1) | be; b.mf = (b.mf << 1) | bf;
+	/* _fill_update_delta (gaba.c:1647-1655): uses the new dh / dv */
+	int tt = !down ? sext8(c.ofsh - t2) : sext8(c.ofsv + dh);
+	b.delta = sext8(b.delta + tt);
+	b.drop = min(127, max(-128, b.drop - tt));     /* _subs_n */
+	return tt;
+}
+
+/* ---- fill state shared by the block routines ---- */
+struct FillState {
+	Band b;
+	int xd;                  /* w.r.xd[lane] */
+	int md;                  /* w.r.md[lane], int16 */
+	int look;                /* look-ahead bases: lanes 0..31 = next a bases, lanes 32..63 = next b bases (b already enc_b'd) */
+};
+
+/* _fill_load_context (gaba.c:1527-1552): diff vectors come from the previous block */
+__device__ __forceinline__ void load_context(Ctx &x, Work &w, FillState &f, uint32_t prev_off)
+{
+	const Blk *p = blk_at(x, prev_off);
+	uint32_t d = p->diff[x.lane];
+	f.b.dh = sext8((int)d); f.b.dv = sext8((int)(d >> 8)); f.b.de = sext8((int)(d >> 16)); f.b.df = sext8((int)(d >> 24));
+	f.b.delta = 0; f.b.drop = f.xd;
+	f.b.mh = f.b.mv = f.b.me = f.b.mf = 0;
+	w.dmask = 0; w.dacc = rdfirst((int)p->s.acc);
+	w.acnt = 0; w.bcnt = 0;
+}
+
+/* fill_fetch_core (gaba.c:1125-1144): the windows are already in registers; load the look-ahead */
+__device__ __forceinline__ void fetch_look(Ctx &x, Work &w, FillState &f, uint32_t alen, uint32_t blen)
+{
+	int l = x.lane;
+	bool isb = l >= 32;
+	uint32_t k = (uint32_t)(l & 31);
+	const Sec &s = w.sec[isb ? 1 : 0];
+	uint32_t len = isb ? blen : alen;
+	uint32_t pos = s.len - w.rem[isb ? 1 : 0] + k;                 /* tptr - rem + k */
+	uint32_t c = 0;
+	if(k < len) { c = fetch_code(x.ar, s, pos); c = isb ? enc_b(c) : c; }
+	f.look = (int)c;
+}
+
+/* _fill_store_context (gaba.c:1734-1778) */
+__device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uint32_t blk_off, uint32_t cnt)
+{
+	const Consts &c = *x.c;
+	Blk *p = blk_at(x, blk_off);
+	int l = x.lane, W = w.W;
+	Band &b = f.b;
+	/* left-align the per-lane bit columns: vector k of the block -> bit (31 - k) */
+	uint32_t sh = cnt == 0 ? 0 : (uint32_t)(BLK - cnt);
+	bool act = l < W;
+	p->m[0][l] = act ? b.mh << sh : 0; p->m[1][l] = act ? b.mv << sh : 0;
+	p->m[2][l] = act ? b.me << sh : 0; p->m[3][l] = act ? b.mf << sh : 0;
+	p->diff[l] = (uint32_t)(b.dh & 0xff) | ((uint32_t)(b.dv & 0xff) << 8) | ((uint32_t)(b.de & 0xff) << 16) | ((uint32_t)(b.df & 0xff) << 24);
+
+	int drop_c = rdlane(b.drop, W / 2), cofs = rdlane(b.delta, W / 2);
+	int xstat = (c.tx - drop_c) & TERM;
+	int prev_drop = f.xd;
+	bool upd = act && (sext8(b.drop + b.delta) > prev_drop);
+	uint64_t max_mask = __ballot(upd);
+	if(l == 0) {
+		p->s.acc = (int8_t)w.dacc; p->s.xstat = (int8_t)xstat;
+		p->s.acnt = (int8_t)w.acnt; p->s.bcnt = (int8_t)w.bcnt;
+		p->s.dir_mask = w.dmask;
+		p->s.max_mask = max_mask;
+	}
+	w.ofsd += cofs; w.rem[0] -= w.acnt; w.rem[1] -= w.bcnt;
+	/* middle delta with overflow / underflow rescue (int16, gaba.c:1752-1761) */
+	int md = f.md;
+	md = sext16(md + b.delta);
+	int ov = sext8(~sext8(b.drop + b.delta) & (b.drop & b.delta));
+	md = sext16(md + (0x0100 & ov));
+	int uv = sext8(min(127, max(-128, b.delta - 0x40)) | b.drop);
+	md = sext16(md + (0x0100 & uv));
+	md = sext16(md - (cofs + 0x0100));
+	f.md = md; f.xd = b.drop;
+}
+
+/* one block of up to BLK vectors.  bounded = per-vector sequence-end tests (fill_cap_seq_bounded, gaba.c:1925-1975).
+ * Returns the number of vectors filled. */
+__device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool bounded)
+{
+	const Consts &c = *x.c;
+	int W = w.W;
+	bool lane_top = x.lane == W - 1;
+	uint32_t alen = BLK, blen = BLK;
+	if(bounded) { alen = min(w.rem[0], (uint32_t)BLK); blen = min(w.rem[1], (uint32_t)BLK); }
+	fetch_look(x, w, f, alen, blen);
+	load_context(x, w, f, prev_off);
+	int64_t arem = w.rem[0], brem = w.rem[1], prem = w.pridx;
+	uint32_t k = 0;
+	for(; k < BLK; k++) {
+		w.dmask = (w.dmask << 1) | (uint32_t)(w.dacc < 0);         /* _dir_fetch, gaba.c:753 */
+		bool down = w.dmask & 1;
+		if(bounded) {                                               /* _fill_cap_test_idx, gaba.c:1800-1809 */
+			int64_t ta = arem - (int64_t)(w.acnt + (down ? 0 : 1)), tb = brem - (int64_t)(w.bcnt + (down ? 1 : 0));
+			if((ta | tb | (ta + tb + prem)) < 0) { w.dmask >>= 1; break; }
+		}
+		int nb = down ? rdlane(f.look, 32 + (int)w.bcnt) : rdlane(f.look, (int)w.acnt);
+		if(down) { w.bcnt++; } else { w.acnt++; }
+		int t = fill_vector(c, f.b, W, down, nb, lane_top);
+		w.dacc += rdlane(t, 0) - rdlane(t, W - 1);                  /* _dir_update, gaba.c:761 */
+	}
+	w.pridx -= k;
+	x.n_vec += k; x.n_blk += 1;
+	if(k != 0 && k != BLK) { w.dmask <<= (BLK - k); }              /* _dir_adjust_remainder, gaba.c:769 */
+	store_context(x, w, f, blk_off, k);
+	return k;
+}
+
+/* ---- section / tail plumbing ---- */
+/* fill_load_section (gaba.c:1269-1308); breakpoint masks are always zero in minialign's call pattern */
+__device__ __forceinline__ void load_section(Ctx &x, Work &w, uint32_t tail_off, const Sec &a, const Sec &b, uint32_t pridx)
+{
+	const Tail *t = tail_at(x, tail_off);
+	for(int k = 0; k < 2; k++) {
+		const Sec &s = k ? b : a;
+		uint32_t tr = (uint32_t)rdfirst((int)t->ridx[k]);
+		uint32_t ridx = tr == 0 ? s.len : tr;
+		w.rlim[k] = 0; w.id[k] = s.id; w.sec[k] = s;
+		w.rem[k] = ridx; w.sridx[k] = ridx;
+	}
+	w.pridx = pridx; w.ofsd = 0; w.tail = tail_off;
+}
+
+/* fill_load_vectors (gaba.c:1376-1399) + fill_create_phantom (gaba.c:1315-1333) */
+__device__ __forceinline__ void load_vectors(Ctx &x, Work &w, FillState &f, uint32_t tail_off)
+{
+	const Tail *t = tail_at(x, tail_off);
+	int l = x.lane;
+	w.W = rdfirst(t->W);
+	int ch = t->ch[l];
+	f.b.ach = ch & 0x0f; f.b.bch = (ch >> 4) & 0x0f;
+	f.xd = t->xd[l]; f.md = t->md[l];
+	uint32_t prev = (uint32_t)rdfirst((int)t->last);
+	/* head ("phantom") block: copies diff / acc, marks HEAD, links to the previous block */
+	uint32_t off = slab_alloc(x, sizeof(Blk));
+	Blk *h = blk_at(x, off); const Blk *p = blk_at(x, prev);
+	h->diff[l] = p->diff[l];
+	if(l == 0) {
+		h->s.acc = p->s.acc; h->s.xstat = (int8_t)((p->s.xstat & ROOT) | HEAD);
+		h->s.acnt = 0; h->s.bcnt = 0; h->s.dir_mask = 0; h->s.max_mask = 0; h->s.link = prev;
+	}
+	w.blk0 = off; w.nblk = 1;
+}
+
+/* fill_init_fetch (gaba.c:1168-1210): slide the windows by the prefetched bases without computing vectors.
+ * Returns bpos after the fetch. */
+__device__ __forceinline__ int64_t init_fetch(Ctx &x, Work &w, FillState &f, int64_t apos, int64_t bpos)
+{
+	int32_t irem[2] = { (int32_t)(INIT_FETCH_POS - (int32_t)apos), (int32_t)(INIT_FETCH_POS - (int32_t)bpos) };
+	int32_t srem[2] = { (int32_t)w.rem[0], (int32_t)w.rem[1] };
+	int32_t len[2];
+	len[0] = min(min(irem[0], srem[0]), (srem[1] - irem[1]) + (1 + irem[0]));
+	len[1] = min(min(irem[1], srem[1]), (srem[0] - irem[0]) + (0 + irem[1]));
+	fetch_look(x, w, f, (uint32_t)len[0], (uint32_t)len[1]);
+	int W = w.W; bool lane_top = x.lane == W - 1;
+	for(int k = 0; k < len[0]; k++) { f.b.ach = shift_up(f.b.ach, rdlane(f.look, k)); }
+	for(int k = 0; k < len[1]; k++) {
+		int nb = rdlane(f.look, 32 + k);
+		int v = shift_dn(f.b.bch, nb);
+		f.b.bch = (W != 64 && lane_top) ? nb : v;
+	}
+	Blk *h = blk_at(x, w.blk0);
+	if(x.lane == 0) { h->s.acnt = (int8_t)len[0]; h->s.bcnt = (int8_t)len[1]; }
+	w.rem[0] = (uint32_t)(srem[0] - len[0]); w.rem[1] = (uint32_t)(srem[1] - len[1]);
+	/* the head block's (acnt, bcnt) are consumed by the first real block's fetch (gaba.c:1827): already applied here */
+	return bpos + len[1];
+}
+
+/* fill_create_tail (gaba.c:1406-1499) */
+__device__ __forceinline__ uint32_t create_tail(Ctx &x, Work &w, FillState &f, uint32_t last_blk, uint32_t last_cnt_nonzero, int xstat)
+{
+	uint32_t off = slab_alloc(x, sizeof(Tail));
+	Tail *t = tail_at(x, off);
+	const Tail *prev = tail_at(x, w.tail);
+	int l = x.lane, W = w.W;
+	/* fill_save_vectors: windows after the last consumed bases are exactly the register windows */
+	t->ch[l] = (uint8_t)(f.b.ach | (f.b.bch << 4));
+	t->xd[l] = (int8_t)f.xd; t->md[l] = (int16_t)f.md;
+	int v = (l < W) ? sext16(f.md + f.xd) : -32768;
+	for(int o = 32; o > 0; o >>= 1) { v = max(v, __shfl_xor(v, o)); }           /* _hmax_w */
+	int mdrop = rdfirst(v);
+	uint32_t ridx[2], adv[2];
+	for(int k = 0; k < 2; k++) { ridx[k] = w.rem[k] + w.rlim[k]; adv[k] = w.sridx[k] - ridx[k]; }
+	int64_t pmax = (int64_t)rdfirst64((uint64_t)prev->f.max); int pmdrop = rdfirst((int)prev->mdrop);
+	if(l == 0) {
+		t->mdrop = (int16_t)mdrop; t->istat = 0; t->pridx = w.pridx;
+		t->ridx[0] = ridx[0]; t->ridx[1] = ridx[1]; t->adv[0] = adv[0]; t->adv[1] = adv[1];
+		t->tail = w.tail; t->last = last_blk; t->W = W; t->_pad = 0;
+		t->sec[0] = w.sec[0]; t->sec[1] = w.sec[1];
+		t->f.aid = w.id[0]; t->f.bid = w.id[1];
+		t->f.ascnt = prev->f.ascnt + (ridx[0] == 0); t->f.bscnt = prev->f.bscnt + (ridx[1] == 0);
+		t->f.apos = prev->f.apos + (uint64_t)(int64_t)(int32_t)adv[0];
+		t->f.bpos = prev->f.bpos + (uint64_t)(int64_t)(int32_t)adv[1];
+		t->f.max = (pmax - pmdrop) + w.ofsd + mdrop;
+		t->f.status = (((uint32_t)xstat & (TERM | CONT)) << 8) | (ridx[0] == 0 ? UPDATE_A : 0) | (ridx[1] == 0 ? UPDATE_B : 0);
+		for(int k = 0; k < 5; k++) { t->f.reserved[k] = 0; }
+	}
+	(void)last_cnt_nonzero;
+	return off;
+}
+
+/* fill_section_seq_bounded / fill_seq_bounded (gaba.c:2027-2099): bulk blocks while >= 32 bases remain on both
+ * sides, then a per-vector bounded cap.  Returns the tail offset. */
+__device__ __forceinline__ uint32_t fill_body(Ctx &x, Work &w, FillState &f, bool run_blocks)
+{
+	uint32_t last = w.blk0;                        /* last block written */
+	int xstat = (int)(int8_t)rdfirst((int)blk_at(x, w.blk0)->s.xstat);
+	uint32_t head_cnt_nz = 0;
+	if(!run_blocks) {
+		/* still in the init-fetch state: the tail follows the head directly (gaba.c:2145-2147) */
+		const Blk *h = blk_at(x, w.blk0);
+		head_cnt_nz = (uint32_t)((rdfirst((int)h->s.acnt) | rdfirst((int)h->s.bcnt)) != 0);
+		uint32_t lb = head_cnt_nz ? w.blk0 : (uint32_t)rdfirst((int)h->s.link);
+		return create_tail(x, w, f, lb, head_cnt_nz, xstat);
+	}
+	/* the bulk / bounded-bulk distinction of the reference only selects where bounds are tested */
+	while(true) {
+		bool can_bulk = w.rem[0] >= (uint32_t)BLK && w.rem[1] >= (uint32_t)BLK && w.pridx >= (uint32_t)BLK;
+		if(xstat < 0 && last != w.blk0) { break; }                  /* TERM */
+		if((xstat & STAT_MASK) != CONT) { break; }
+		if(!can_bulk) { break; }
+		uint32_t off = slab_alloc(x, sizeof(Blk));
+		if(x.err) { break; }
+		fill_block(x, w, f, last, off, false);
+		last = off; w.nblk++;
+		xstat = (int)(int8_t)((x.c->tx - rdlane(f.xd, w.W / 2)) & TERM);
+	}
+	if((xstat & STAT_MASK) == CONT && !x.err) {
+		/* fill_cap_seq_bounded (gaba.c:1925-1975) */
+		while(xstat >= 0) {
+			uint32_t off = slab_alloc(x, sizeof(Blk));
+			if(x.err) { break; }
+			uint32_t k = fill_block(x, w, f, last, off, true);
+			xstat = (int)(int8_t)((x.c->tx - rdlane(f.xd, w.W / 2)) & TERM);
+			if(k != 0) { last = off; w.nblk++; } else { x.top = off; }   /* squash the empty block (gaba.c:1492) */
+			if(k != BLK) { break; }
+		}
+	}
+	return create_tail(x, w, f, last, 1, xstat);
+}
+
+/* gaba_dp_fill_root (gaba.c:2110-2154) */
+__device__ __forceinline__ uint32_t dp_fill_root(Ctx &x, int bw_idx, const Sec &a, uint32_t apos, const Sec &b, uint32_t bpos, uint32_t pridx)
+{
+	Work w; FillState f;
+	uint32_t rt = root_tail(bw_idx);
+	const Tail *root = tail_at(x, rt);
+	/* fill_create_bridge (gaba.c:1339-1370) */
+	uint32_t bo = slab_alloc(x, sizeof(Tail));
+	Tail *br = tail_at(x, bo);
+	int l = x.lane;
+	br->ch[l] = root->ch[l]; br->xd[l] = root->xd[l]; br->md[l] = root->md[l];
+	if(l == 0) {
+		br->mdrop = root->mdrop; br->istat = (uint16_t)(root->istat | 1); br->pridx = root->pridx;
+		br->ridx[0] = a.len - apos; br->ridx[1] = b.len - bpos; br->adv[0] = apos; br->adv[1] = bpos;
+		br->tail = rt; br->last = NIL; br->W = root->W; br->_pad = 0;
+		br->sec[0] = a; br->sec[1] = b;
+		br->f = root->f; br->f.aid = a.id; br->f.bid = b.id;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	load_section(x, w, bo, a, b, pridx == 0 ? 0xffffffffu : pridx);
+	load_vectors(x, w, f, rt);
+	int64_t rap = (int64_t)rdfirst64(root->f.apos), rbp = (int64_t)rdfirst64(root->f.bpos);
+	bool run = !(init_fetch(x, w, f, rap, rbp) < INIT_FETCH_POS);
+	return fill_body(x, w, f, run);
+}
+
+/* gaba_dp_fill (gaba.c:2161-2203) */
+__device__ __forceinline__ uint32_t dp_fill(Ctx &x, uint32_t prev_tail, const Sec &a, const Sec &b, uint32_t pridx)
+{
+	Work w; FillState f;
+	const Tail *t = tail_at(x, prev_tail);
+	load_section(x, w, prev_tail, a, b, pridx == 0 ? (uint32_t)rdfirst((int)t->pridx) : pridx);
+	load_vectors(x, w, f, prev_tail);
+	int64_t tap = (int64_t)rdfirst64(t->f.apos), tbp = (int64_t)rdfirst64(t->f.bpos);
+	bool run = true;
+	if(tbp < INIT_FETCH_POS) { run = !(init_fetch(x, w, f, tap, tbp) < INIT_FETCH_POS); }
+	return fill_body(x, w, f, run);
+}
+
+/* ---- max search (gaba.c:2604-2817) ---- */
+struct Leaf {
+	uint32_t blk;            /* block holding the max cell */
+	uint32_t p, q;
+	int32_t gidx[2], sgidx[2];
+	uint32_t ofs[2], id[2];
+	uint32_t tl[2];
+	uint32_t state;
+	uint32_t icnt[2], ecnt[2], fcnt[2];
+};
+
+/* previous block of `off` inside a fill is simply off - sizeof(Blk) (blocks of one fill are contiguous) */
+__device__ __forceinline__ uint32_t skip_heads(Ctx &x, uint32_t off)
+{
+	while(off != NIL && (rdfirst((int)blk_at(x, off)->s.xstat) & HEAD)) { off = (uint32_t)rdfirst((int)blk_at(x, off)->s.link); }
+	return off;
+}
+
+/* leaf_search (gaba.c:2708-2770): returns plen, fills lf.{blk,p,q,gidx,sgidx} */
+__device__ __forceinline__ uint64_t leaf_search(Ctx &x, uint32_t tail_off, Leaf &lf)
+{
+	const Consts &c = *x.c;
+	const Tail *t = tail_at(x, tail_off);
+	int l = x.lane, W = rdfirst(t->W);
+	bool act = l < W;
+	/* leaf_load_max_mask (gaba.c:2609-2631) */
+	int mdrop = rdfirst((int)t->mdrop);
+	uint64_t max_mask = __ballot(act && (sext16((int)t->md[l] + (int)t->xd[l]) == mdrop));
+	int32_t ridx[2] = { rdfirst((int)t->ridx[0]), rdfirst((int)t->ridx[1]) };
+	uint32_t b = (uint32_t)rdfirst((int)t->last) + (uint32_t)sizeof(Blk);
+	while(true) {
+		b -= (uint32_t)sizeof(Blk);
+		int xs = rdfirst((int)blk_at(x, b)->s.xstat);
+		if((xs & ROOT) == ROOT) { return 0; }
+		b = skip_heads(x, b);
+		const Blk *pb = blk_at(x, b);
+		ridx[0] += rdfirst((int)pb->s.acnt); ridx[1] += rdfirst((int)pb->s.bcnt);
+		uint64_t mm = rdfirst64(pb->s.max_mask);
+		if((max_mask & ~mm) == 0) { break; }
+		max_mask &= ~mm;
+	}
+	/* fill_restore_fetch (gaba.c:1217-1264): rebuild the sequence windows at the head of block b */
+	const Tail *pt = tail_at(x, (uint32_t)rdfirst((int)t->tail));
+	Work w; FillState f;
+	w.W = W;
+	int32_t ofs[2], len[2], cridx[2];
+	for(int k = 0; k < 2; k++) {
+		int32_t sridx = (int32_t)(rdfirst((int)t->ridx[k]) + rdfirst((int)t->adv[k]));
+		int32_t dridx = ridx[k] + W;
+		cridx[k] = min(dridx, sridx);
+		ofs[k] = dridx - cridx[k];
+		len[k] = min(cridx[k], W + BLK - ofs[k]);
+		w.sec[k] = t->sec[k];
+		w.sec[k].id = (uint32_t)rdfirst((int)w.sec[k].id); w.sec[k].len = (uint32_t)rdfirst((int)w.sec[k].len);
+		w.sec[k].off = rdfirst64(w.sec[k].off); w.sec[k].arena = (uint32_t)rdfirst((int)w.sec[k].arena); w.sec[k].rev = (uint32_t)rdfirst((int)w.sec[k].rev);
+	}
+	{
+		/* a window: lanes >= W - ofs come from the previous tail's window, the rest from the stream (t = W - ofs - 1 - lane) */
+		int pch = pt->ch[(l - (W - ofs[0])) & 63] & 0x0f;
+		int tt = W - ofs[0] - 1 - l;
+		uint32_t base = w.sec[0].len - (uint32_t)cridx[0];
+		int sv = (act && tt >= 0 && tt < len[0]) ? (int)fetch_code(x.ar, w.sec[0], base + (uint32_t)tt) : 0;
+		f.b.ach = (l >= W - ofs[0]) ? pch : sv;
+		/* b window: lanes < ofs come from the previous tail's top lanes, the rest from the stream (t = lane - ofs) */
+		int pcb = (pt->ch[(W - ofs[1] + l) & 63] >> 4) & 0x0f;
+		int tb = l - ofs[1];
+		uint32_t bbase = w.sec[1].len - (uint32_t)cridx[1];
+		int bv = (act && tb >= 0 && tb < len[1]) ? (int)enc_b(fetch_code(x.ar, w.sec[1], bbase + (uint32_t)tb)) : 0;
+		f.b.bch = (l < ofs[1]) ? pcb : bv;
+		/* look-ahead: a stream t = W - ofs + k, b stream t = W - ofs + k */
+		bool isb = l >= 32; int k = l & 31;
+		int ts = W - ofs[isb] + k;
+		uint32_t sb_ = isb ? bbase : base;
+		int lv = (ts < len[isb]) ? (int)fetch_code(x.ar, w.sec[isb], sb_ + (uint32_t)ts) : 0;
+		f.look = isb ? (int)enc_b((uint32_t)lv) : lv;
+		if(ts >= len[isb]) { f.look = 0; }
+	}
+	/* leaf_detect_pos (gaba.c:2663-2700): refill the block, recording cell-wise update masks */
+	const Blk *pb = blk_at(x, b);
+	int cnt = rdfirst((int)pb->s.acnt) + rdfirst((int)pb->s.bcnt);
+	f.xd = 0; f.md = 0;
+	load_context(x, w, f, b - (uint32_t)sizeof(Blk));
+	int mx = f.b.delta;
+	uint32_t upd = 0;          /* per-lane: bit (k) = updated at vector k */
+	bool lane_top = l == W - 1;
+	for(int k = 0; k < cnt; k++) {
+		w.dmask = (w.dmask << 1) | (uint32_t)(w.dacc < 0);
+		bool down = w.dmask & 1;
+		int nb = down ? rdlane(f.look, 32 + (int)w.bcnt) : rdlane(f.look, (int)w.acnt);
+		if(down) { w.bcnt++; } else { w.acnt++; }
+		int tv = fill_vector(c, f.b, W, down, nb, lane_top);
+		w.dacc += rdlane(tv, 0) - rdlane(tv, W - 1);
+		upd |= (uint32_t)(act && f.b.delta > mx) << k;
+		mx = max(mx, f.b.delta);
+	}
+	/* leaf_search_pos (gaba.c:2636-2652) */
+	int mi = cnt;
+	uint64_t mcur = 0;
+	while(mi > 0) {
+		mi--;
+		mcur = __ballot((upd >> mi) & 1);
+		if((max_mask & ~mcur) == 0) { break; }
+		max_mask &= ~mcur;
+	}
+	uint64_t hit = mcur & max_mask;
+	lf.p = (uint32_t)mi;
+	lf.q = hit == 0 ? 64u : (uint32_t)__builtin_ctzll(hit);
+	lf.blk = b;
+	int32_t fcnt = (int32_t)lf.p + 1;
+	uint32_t dir_mask = (uint32_t)rdfirst((int)pb->s.dir_mask) >> (BLK - fcnt);
+	int32_t pc = __builtin_popcount(dir_mask);
+	ridx[0] -= (fcnt - pc) - (1 + (int32_t)lf.q);
+	ridx[1] -= pc - (W - (int32_t)lf.q);
+	int32_t tr[2] = { rdfirst((int)t->ridx[0]), rdfirst((int)t->ridx[1]) };
+	for(int k = 0; k < 2; k++) { lf.gidx[k] = 1 - ridx[k] + tr[k]; lf.sgidx[k] = lf.gidx[k]; }
+	int32_t rem0 = ridx[0] - tr[0], rem1 = ridx[1] - tr[1];
+	uint64_t plen = rdfirst64(t->f.apos) + rdfirst64(t->f.bpos) + 2ull + (uint64_t)W - (uint64_t)(int64_t)rem1 - (uint64_t)(int64_t)rem0;
+	return plen;
+}
+
+/* gaba_dp_search_max (gaba.c:2776-2817) */
+__device__ __forceinline__ PosPair dp_search_max(Ctx &x, uint32_t tail_off, Leaf &lf)
+{
+	PosPair pos;
+	pos.plen = leaf_search(x, tail_off, lf);
+	const Tail *t = tail_at(x, tail_off);
+	int32_t gidx[2] = { lf.gidx[0], lf.gidx[1] }, acc[2] = { 0, 0 };
+	uint32_t id[2] = { (uint32_t)rdfirst((int)t->f.aid), (uint32_t)rdfirst((int)t->f.bid) };
+	uint32_t cur = tail_off;
+	while(true) {
+		const Tail *ct = tail_at(x, cur);
+		uint32_t prev = (uint32_t)rdfirst((int)ct->tail);
+		if(prev == NIL) { break; }
+		bool upd[2] = { 1 > gidx[0], 1 > gidx[1] };
+		if(!upd[0] && !upd[1]) { break; }
+		uint32_t nid[2] = { (uint32_t)rdfirst((int)ct->f.aid), (uint32_t)rdfirst((int)ct->f.bid) };
+		acc[0] += rdfirst((int)ct->adv[0]); acc[1] += rdfirst((int)ct->adv[1]);
+		cur = prev;
+		const Tail *pt = tail_at(x, cur);
+		for(int k = 0; k < 2; k++) {
+			bool m = upd[k] && (rdfirst((int)pt->ridx[k]) == 0);
+			if(m) { gidx[k] += acc[k]; id[k] = nid[k]; acc[k] = 0; }
+		}
+	}
+	pos.aid = id[0]; pos.bid = id[1]; pos.apos = (uint32_t)gidx[0]; pos.bpos = (uint32_t)gidx[1];
+	return pos;
+}
+
+/* ---- traceback (gaba.c:2820-3407) ---- */
+enum : uint32_t { TS_H = 1, TS_V = 2, TS_S = 4, ts_d = 3, ts_v0 = 2, ts_v1 = 6, ts_h0 = 1, ts_h1 = 5 };
+
+struct Trace {
+	int W, model;
+	uint32_t blk; int32_t p; uint32_t q, save, dir_mask; bool bulk;
+	int32_t gidx[2];
+	uint64_t ppos;
+	uint32_t *path;
+	bool oob;
+	/* this lane's mask words of the current block, and the 4 words of lane q (uniform) */
+	uint32_t lm[4];
+	uint32_t qh, qv, qe, qf; uint32_t qcur; uint32_t blk_loaded;
+	uint32_t pw; uint64_t pw_idx;   /* path word being assembled (uniform) */
+};
+
+__device__ __forceinline__ void trace_load_block(Ctx &x, Trace &t)
+{
+	const Blk *b = blk_at(x, t.blk);
+	int l = x.lane;
+	t.lm[0] = b->m[0][l]; t.lm[1] = b->m[1][l]; t.lm[2] = b->m[2][l]; t.lm[3] = b->m[3][l];
+	t.blk_loaded = t.blk; t.qcur = 0xffffffffu;
+}
+/* (mask->x.all >> q) & 1 with the x86 shift-count masking of the reference's word size (gaba.c:2931-2951) */
+__device__ __forceinline__ void trace_sel_q(Trace &t)
+{
+	if(t.qcur == t.q) { return; }
+	t.qcur = t.q;
+	uint32_t ql = (t.W == 64) ? (t.q & 63) : (t.q & 31);
+	bool dead = ql >= (uint32_t)t.W;
+	t.qh = dead ? 0 : (uint32_t)rdlane((int)t.lm[0], (int)ql); t.qv = dead ? 0 : (uint32_t)rdlane((int)t.lm[1], (int)ql);
+	t.qe = dead ? 0 : (uint32_t)rdlane((int)t.lm[2], (int)ql); t.qf = dead ? 0 : (uint32_t)rdlane((int)t.lm[3], (int)ql);
+}
+#define GABA_BIT(_w, _p)   ( ((_w) >> (31 - (_p))) & 1u )
+__device__ __forceinline__ bool t_diag_h(Trace &t) { trace_sel_q(t); return GABA_BIT(t.qh, t.p) == 0; }
+__device__ __forceinline__ bool t_diag_v(Trace &t) { trace_sel_q(t); return GABA_BIT(t.qv, t.p) == 0; }
+__device__ __forceinline__ bool t_gap_h(Trace &t) { trace_sel_q(t); return (t.model == MODEL_COMBINED ? GABA_BIT(~t.qh & t.qe, t.p) : GABA_BIT(t.qe, t.p)) == 0; }
+__device__ __forceinline__ bool t_gap_v(Trace &t) { trace_sel_q(t); return (t.model == MODEL_COMBINED ? GABA_BIT(~t.qv & t.qf, t.p) : GABA_BIT(t.qf, t.p)) == 0; }
+__device__ __forceinline__ bool t_fgap_h(Trace &t) { trace_sel_q(t); return t.model == MODEL_COMBINED ? GABA_BIT(t.qe, t.p) == 0 : false; }
+__device__ __forceinline__ bool t_fgap_v(Trace &t) { trace_sel_q(t); return t.model == MODEL_COMBINED ? GABA_BIT(t.qf, t.p) == 0 : false; }
+
+__device__ __forceinline__ uint32_t trace_head_cnt(int W) { return (uint32_t)(W / BLK + (W == 16)); }   /* gaba.c:3051 */
+
+/* _trace_test_bulk (gaba.c:3035-3046) */
+__device__ __forceinline__ bool trace_test_bulk(Ctx &x, Trace &t)
+{
+	const Blk *b = blk_at(x, t.blk);
+	int32_t ga = t.gidx[0] - rdfirst((int)b->s.acnt), gb = t.gidx[1] - rdfirst((int)b->s.bcnt);
+	if(!(t.W > ga) && !(t.W > gb)) { t.gidx[0] = ga; t.gidx[1] = gb; return true; }
+	return false;
+}
+/* _trace_reload_block / _trace_reload_tail (gaba.c:3000-3031) */
+__device__ __forceinline__ void trace_reload(Ctx &x, Trace &t)
+{
+	uint32_t b = skip_heads(x, t.blk - (uint32_t)sizeof(Blk));
+	if(b == NIL) { t.blk = NIL; t.p = -1; t.dir_mask = 0; return; }
+	const Blk *pb = blk_at(x, b);
+	int cnt = rdfirst((int)pb->s.acnt) + rdfirst((int)pb->s.bcnt);
+	t.p = cnt - 1; t.dir_mask = (uint32_t)rdfirst((int)pb->s.dir_mask) >> (BLK - cnt);
+	t.blk = b;
+	trace_load_block(x, t);
+}
+__device__ __forceinline__ void path_flush(Ctx &x, Trace &t)
+{
+	if(x.lane == 0) { t.path[t.pw_idx] = t.pw; }
+}
+/* _pop_vector (gaba.c:3114-3122) */
+__device__ __forceinline__ bool trace_pop(Ctx &x, Trace &t, int is_v)
+{
+	if(!t.bulk) { t.gidx[is_v]--; }
+	t.ppos--; x.n_tr++;
+	if((t.ppos >> 5) != t.pw_idx) { path_flush(x, t); t.pw_idx = t.ppos >> 5; t.pw = 0; }
+	t.pw |= (uint32_t)is_v << (t.ppos & 31);
+	t.q += (t.dir_mask & 1) - (uint32_t)is_v;
+	t.dir_mask >>= 1;
+	t.p--;
+	if(t.p >= 0) { return false; }
+	if(t.bulk) {
+		trace_reload(x, t);
+		if(!trace_test_bulk(x, t)) {
+			if(t.q >= (uint32_t)t.W) { t.oob = true; return true; }
+			t.gidx[1] += (int32_t)(t.q - t.save);
+			t.gidx[0] += (int32_t)(t.save - t.q);
+			t.save = trace_head_cnt(t.W);
+			t.bulk = false;
+		}
+	} else {
+		bool prev_head = (rdfirst((int)blk_at(x, t.blk - (uint32_t)sizeof(Blk))->s.xstat) & HEAD) != 0;
+		trace_reload(x, t);
+		if(!prev_head) {
+			t.save--;
+			if(t.save >= trace_head_cnt(t.W) && trace_test_bulk(x, t)) { t.save = t.q; t.bulk = true; }
+		}
+	}
+	return false;
+}
+
+/* trace_core (gaba.c:3111-3228) as an explicit state machine over the reference's labels */
+__device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
+{
+	enum { L_D_HEAD, L_D_MID, L_D_TAIL, L_H_HEAD, L_H_LOOP, L_H_TAIL, L_V_HEAD, L_V_LOOP, L_V_TAIL };
+	int lbl;
+	t.bulk = false; t.save = trace_head_cnt(t.W); t.oob = false;
+	t.blk = lf.blk; t.p = (int32_t)lf.p; t.q = lf.q;
+	t.dir_mask = (uint32_t)rdfirst((int)blk_at(x, t.blk)->s.dir_mask) >> (BLK - (t.p + 1));
+	t.gidx[0] = lf.gidx[0]; t.gidx[1] = lf.gidx[1];
+	if(t.blk_loaded != t.blk) { trace_load_block(x, t); }
+	t.qcur = 0xffffffffu;
+	switch(lf.state) {
+		case ts_d:  lbl = L_D_HEAD; break;
+		case ts_v0: lbl = L_V_HEAD; break;
+		case ts_v1: lbl = L_V_TAIL; break;
+		case ts_h0: lbl = L_H_HEAD; break;
+		case ts_h1: lbl = L_H_TAIL; break;
+		default: return;
+	}
+	while(true) {
+		if(t.blk == NIL) { break; }                 /* fell off the root: cannot happen on a consistent band */
+		if(lbl == L_D_HEAD) {
+			if(!t_diag_h(t)) { lbl = L_H_HEAD; continue; }
+			if(!t.bulk && (t.gidx[0] == 0 || t.gidx[1] == 0)) { lf.state = ts_d; break; }
+			if(trace_pop(x, t, 0)) { break; }
+			lbl = L_D_MID;
+		} else if(lbl == L_D_MID) {
+			if(trace_pop(x, t, 1)) { break; }
+			lbl = L_D_TAIL;
+		} else if(lbl == L_D_TAIL) {
+			lbl = !t_diag_v(t) ? L_V_HEAD : L_D_HEAD;
+		} else if(lbl == L_H_HEAD) {
+			if(t_fgap_h(t)) {
+				if(!t.bulk && t.gidx[0] == 0) { lf.state = ts_h0; break; }
+				lf.fcnt[0]++;
+				if(trace_pop(x, t, 0)) { break; }
+				lbl = L_D_HEAD;
+			} else { lf.icnt[0]++; lbl = L_H_LOOP; }
+		} else if(lbl == L_H_LOOP) {
+			if(!t.bulk && t.gidx[0] == 0) { lf.state = ts_h1; break; }
+			lf.ecnt[0]++;
+			if(trace_pop(x, t, 0)) { break; }
+			lbl = L_H_TAIL;
+		} else if(lbl == L_H_TAIL) {
+			lbl = t_gap_h(t) ? L_H_LOOP : L_D_HEAD;
+		} else if(lbl == L_V_HEAD) {
+			if(t_fgap_v(t)) {
+				if(!t.bulk && t.gidx[1] == 0) { lf.state = ts_v0; break; }
+				lf.fcnt[1]++;
+				if(trace_pop(x, t, 1)) { break; }
+				lbl = L_D_TAIL;
+			} else { lf.icnt[1]++; lbl = L_V_LOOP; }
+		} else if(lbl == L_V_LOOP) {
+			if(!t.bulk && t.gidx[1] == 0) { lf.state = ts_v1; break; }
+			lf.ecnt[1]++;
+			if(trace_pop(x, t, 1)) { break; }
+			lbl = L_V_TAIL;
+		} else { /* L_V_TAIL */
+			lbl = t_gap_v(t) ? L_V_LOOP : L_D_TAIL;
+		}
+	}
+	lf.blk = t.blk; lf.p = (uint32_t)t.p; lf.q = t.q;
+	lf.gidx[0] = t.gidx[0]; lf.gidx[1] = t.gidx[1];
+}
+
+/* trace_reload_section (gaba.c:2826-2860) */
+__device__ __forceinline__ void trace_reload_section(Ctx &x, Leaf &lf, int i)
+{
+	uint32_t tail = lf.tl[i], prev_tail = tail;
+	int32_t gidx = lf.gidx[i];
+	while(gidx <= 0) {
+		do {
+			const Tail *t = tail_at(x, tail);
+			gidx += rdfirst((int)t->istat) ? 0 : rdfirst((int)t->adv[i]);
+			prev_tail = tail; tail = (uint32_t)rdfirst((int)t->tail);
+		} while(rdfirst((int)tail_at(x, tail)->ridx[i]) != 0);
+	}
+	const Tail *pt = tail_at(x, prev_tail);
+	lf.tl[i] = tail;
+	lf.id[i] = (uint32_t)rdfirst((int)(i == 0 ? pt->f.aid : pt->f.bid));
+	lf.ofs[i] = rdfirst((int)pt->istat) ? (uint32_t)rdfirst((int)pt->adv[i]) : 0u;
+	lf.gidx[i] = gidx; lf.sgidx[i] = gidx;
+}
+
+struct AlnOut {              /* what gaba_alignment_s carries (gaba.h:205-220) */
+	int64_t score; double identity;
+	uint32_t agcnt, bgcnt, dcnt, slen, plen;
+	int32_t status;          /* 1: ok, -1: path left the band (reference returns NULL, gaba.c:3324) */
+};
+
+/*
+ * gaba_dp_trace (gaba.c:3372) -> trace_body (gaba.c:3299).  path: (plen + 31) / 32 + 2 words (zeroed here);
+ * seg: written in root-first order like aln->seg[]; max_seg bounds the array.
+ */
+__device__ __forceinline__ AlnOut dp_trace(Ctx &x, uint32_t tail_off, uint32_t *path, uint64_t path_cap_words, Segment *seg, uint32_t max_seg)
+{
+	const Consts &c = *x.c;
+	const Tail *tail = tail_at(x, tail_off);
+	Leaf lf;
+	AlnOut out; out.status = 1;
+	int64_t fbpos = (int64_t)rdfirst64(tail->f.bpos);
+	uint64_t plen = fbpos < INIT_FETCH_POS ? 0 : leaf_search(x, tail_off, lf);
+	uint64_t pn = (plen + 31) / 32 + 2;
+	if(pn > path_cap_words) { x.err = 2; out.status = -2; out.plen = (uint32_t)plen; return out; }
+	for(uint64_t i = (uint64_t)x.lane; i < pn; i += 64) { path[i] = 0; }
+	lf.tl[0] = tail_off; lf.tl[1] = tail_off;
+	lf.icnt[0] = lf.icnt[1] = lf.ecnt[0] = lf.ecnt[1] = lf.fcnt[0] = lf.fcnt[1] = 0;
+	lf.state = ts_d;
+	Trace t;
+	t.W = rdfirst(tail->W); t.model = c.model; t.path = path; t.ppos = plen;
+	t.blk_loaded = NIL; t.pw_idx = plen >> 5; t.pw = 1u << (plen & 31);            /* sentinel bit (gaba.c:3288) */
+	t.blk = NIL; t.p = 0; t.q = 0; t.save = 0; t.dir_mask = 0; t.bulk = false; t.oob = false; t.qcur = 0xffffffffu;
+	uint32_t slen = 0;
+	while(t.ppos > 0) {
+		if(lf.gidx[0] < (int32_t)((lf.state & TS_H) != 0)) { trace_reload_section(x, lf, 0); }
+		if(lf.gidx[1] < (int32_t)((lf.state & TS_V) != 0)) { trace_reload_section(x, lf, 1); }
+		trace_core(x, t, lf);
+		if(lf.q >= (uint32_t)t.W || t.blk == NIL) { out.status = -1; out.plen = (uint32_t)plen; return out; }
+		/* trace_push_segment (gaba.c:2865-2897); reversed into root-first order below */
+		if(slen < max_seg && x.lane == 0) {
+			Segment *s = &seg[slen];
+			s->aid = lf.id[0]; s->bid = lf.id[1];
+			s->apos = lf.ofs[0] + (uint32_t)lf.gidx[0]; s->bpos = lf.ofs[1] + (uint32_t)lf.gidx[1];
+			s->alen = (uint32_t)(lf.sgidx[0] - lf.gidx[0]); s->blen = (uint32_t)(lf.sgidx[1] - lf.gidx[1]);
+			s->ppos = t.ppos;
+		}
+		slen++;
+		lf.sgidx[0] = lf.gidx[0]; lf.sgidx[1] = lf.gidx[1];
+	}
+	path_flush(x, t);
+	if(slen > max_seg) { x.err = 3; }
+	/* reverse the segment array (the reference pushes with seg--) */
+	if(x.lane == 0) {
+		uint32_t n = min(slen, max_seg);
+		for(uint32_t i = 0; i < n / 2; i++) { Segment tmp = seg[i]; seg[i] = seg[n - 1 - i]; seg[n - 1 - i] = tmp; }
+	}
+	/* identity estimate (gaba.c:3334-3355); _mul_v2i32 = _mm_mul_epi32 multiplies lane 0 only (v2i32.h:106) */
+	int32_t gcnt0 = (int32_t)(lf.ecnt[0] + lf.fcnt[0]), gcnt1 = (int32_t)(lf.ecnt[1] + lf.fcnt[1]);
+	int64_t p1 = (int64_t)c.gi * (int64_t)(int32_t)lf.icnt[0], p2 = (int64_t)c.ge * (int64_t)(int32_t)lf.ecnt[0], p3 = (int64_t)c.gfa * (int64_t)(int32_t)lf.fcnt[0];
+	int32_t g0 = (int32_t)((uint32_t)p1 + (uint32_t)p2 + (uint32_t)p3);
+	int32_t g1 = (int32_t)((uint32_t)(p1 >> 32) + (uint32_t)(p2 >> 32) + (uint32_t)(p3 >> 32));
+	uint64_t dlen = (plen - (uint64_t)(int64_t)gcnt1 - (uint64_t)(int64_t)gcnt0) >> 1;
+	int64_t score = (int64_t)rdfirst64((uint64_t)tail->f.max);
+	int64_t dsc = score + g1 + g0;
+	out.score = score;
+	out.identity = dlen == 0 ? 0.0 : (((double)dsc / (double)dlen) * c.imx - c.xmx);
+	out.agcnt = (uint32_t)gcnt0; out.bgcnt = (uint32_t)gcnt1; out.dcnt = (uint32_t)dlen;
+	out.slen = slen; out.plen = (uint32_t)plen;
+	return out;
+}
+
+/* gaba_dp_flush (gaba.c:3969): reset the bump pointer behind the root blocks */
+__device__ __forceinline__ void dp_flush(Ctx &x) { x.top = SLAB_HEAD; }
+
+} /* namespace gaba */

@@ -102,3 +102,100 @@ def mutate(rng, seq, sub, ins, dele):
         if x > 1.0 - ins:
             out.append(int(r[k] * 4) & 3); k += 1
     return np.array(out, dtype=np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# product library (HIP): include/gaba.h through ctypes
+class Job(ctypes.Structure):
+    _fields_ = [('a_off', ctypes.c_uint64), ('alen', ctypes.c_uint32), ('apos', ctypes.c_uint32),
+                ('b_off', ctypes.c_uint64), ('blen', ctypes.c_uint32), ('bpos', ctypes.c_uint32),
+                ('arev', ctypes.c_uint8), ('brev', ctypes.c_uint8), ('bw_idx', ctypes.c_uint8), ('do_trace', ctypes.c_uint8)]
+
+class Params(ctypes.Structure):
+    _fields_ = [('sm', ctypes.c_int8 * 16), ('gi', ctypes.c_int8), ('ge', ctypes.c_int8), ('gfa', ctypes.c_int8),
+                ('gfb', ctypes.c_int8), ('xdrop', ctypes.c_int8), ('ft', ctypes.c_uint8), ('reserved', ctypes.c_void_p),
+                ('_pad', ctypes.c_uint64)]
+
+class BatchStats(ctypes.Structure):
+    _fields_ = [('kernel_ms', ctypes.c_double), ('vectors', ctypes.c_uint64), ('blocks', ctypes.c_uint64), ('trace_steps', ctypes.c_uint64)]
+
+def load_product():
+    """load libminialign_amd.so; raises if it was not built (no silent fallback)"""
+    p = os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')
+    if not os.path.exists(p):
+        raise RuntimeError('minialign_amd/libminialign_amd.so is missing: run __graft_entry__.build()')
+    L = ctypes.CDLL(p)
+    L.gaba_init.restype = ctypes.c_void_p
+    L.gaba_arena_upload.restype = ctypes.c_void_p
+    return L
+
+class Hip:
+    """batched driver over gaba_dp_extend_batch; jobs: list of (a, apos, arev, b, bpos, brev, bw_idx, trace)"""
+    def __init__(self, m, x, gi, ge, gfa, gfb, xdrop):
+        self.L = load_product()
+        p = Params(); p.sm = score_matrix(m, x); p.gi, p.ge, p.gfa, p.gfb, p.xdrop = gi, ge, gfa, gfb, xdrop
+        self.ctx = self.L.gaba_init(ctypes.byref(p))
+        if not self.ctx:
+            raise RuntimeError('gaba_init failed (no HIP device?)')
+
+    def extend_batch(self, jobs):
+        n = len(jobs)
+        aa, bb, J = [], [], (Job * n)()
+        ao = bo = 0; maxp = 0
+        for i, (a, apos, arev, b, bpos, brev, bw, tr) in enumerate(jobs):
+            a = np.ascontiguousarray(a, dtype=np.uint8); b = np.ascontiguousarray(b, dtype=np.uint8)
+            J[i].a_off, J[i].alen, J[i].apos = ao, len(a), apos
+            J[i].b_off, J[i].blen, J[i].bpos = bo, len(b), bpos
+            J[i].arev, J[i].brev, J[i].bw_idx, J[i].do_trace = int(arev), int(brev), bw, int(tr)
+            aa.append(a); bb.append(b); ao += len(a); bo += len(b)
+            maxp = max(maxp, len(a) + len(b) + 512)
+        A = np.concatenate(aa); B = np.concatenate(bb)
+        ha = self.L.gaba_arena_upload(A.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(A)))
+        hb = self.L.gaba_arena_upload(B.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(B)))
+        assert ha and hb
+        stride = maxp // 32 + 32
+        res = (XResult * n)(); paths = np.zeros(n * stride, dtype=np.uint32)
+        rc = self.L.gaba_dp_extend_batch(ctypes.c_void_p(self.ctx), ctypes.c_void_p(ha), ctypes.c_void_p(hb), J, n, res,
+                                         paths.ctypes.data_as(ctypes.c_void_p), stride)
+        self.L.gaba_arena_free(ctypes.c_void_p(ha)); self.L.gaba_arena_free(ctypes.c_void_p(hb))
+        assert rc == 0, 'gaba_dp_extend_batch rc=%d' % rc
+        return [res[i].as_dict(paths[i * stride:(i + 1) * stride]) for i in range(n)]
+
+    def stats(self):
+        s = BatchStats(); self.L.gaba_last_stats(ctypes.c_void_p(self.ctx), ctypes.byref(s)); return s
+
+
+def revcomp(s):
+    r = s[::-1].copy(); m = r < 4; r[m] = 3 - r[m]; return r
+
+def random_jobs(seed, n, max_len=6000, bw_choices=(0, 0, 0, 1, 2)):
+    """seeded random extension jobs covering the edge cases the reference's unit tests probe (gaba.c:5351-5765):
+    short / empty-ish inputs, tandem repeats, long indels, N runs, unequal lengths, start offsets, all strands"""
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for it in range(n):
+        mode = int(rng.integers(0, 6))
+        L = int(rng.integers(1, max_len)) if mode else int(rng.integers(1, 200))
+        a = rng.integers(0, 4, L, dtype=np.uint8)
+        if mode == 2:
+            u = rng.integers(0, 4, int(rng.integers(1, 40)), dtype=np.uint8); a = np.tile(u, L // len(u) + 1)[:L]
+        err = rng.uniform(0.0, 0.35)
+        b = mutate(rng, a, err * 0.1, err * 0.6, err * 0.3)
+        if len(b) == 0:
+            b = rng.integers(0, 4, 5, dtype=np.uint8)
+        if mode == 3:
+            k = int(rng.integers(0, len(b)))
+            b = np.concatenate([b[:k], rng.integers(0, 4, int(rng.integers(1, 120)), dtype=np.uint8), b[k:]])
+        if mode == 4 and len(a) > 10:
+            k = int(rng.integers(0, len(a) - 5)); a = a.copy(); a[k:k + int(rng.integers(1, 30))] = 4
+        if rng.random() < 0.3:
+            b = np.concatenate([b, rng.integers(0, 4, int(rng.integers(0, 300)), dtype=np.uint8)])
+        if rng.random() < 0.2:
+            a = np.concatenate([a, rng.integers(0, 4, int(rng.integers(0, 300)), dtype=np.uint8)])
+        apos = int(rng.integers(0, max(1, len(a) // 3))) if rng.random() < 0.7 else int(rng.integers(0, len(a)))
+        bpos = min(len(b) - 1, apos) if rng.random() < 0.8 else int(rng.integers(0, len(b)))
+        arev = bool(rng.random() < 0.4); brev = bool(rng.random() < 0.4)
+        aa = revcomp(a) if arev else a; bb = revcomp(b) if brev else b
+        bw = int(rng.choice(bw_choices))
+        jobs.append((aa, apos, arev, bb, bpos, brev, bw, 1))
+    return jobs
