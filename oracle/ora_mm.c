@@ -1,0 +1,1063 @@
+/*
+ * ora_mm.c -- TEST INFRASTRUCTURE (see ora_mm.h).  Plain-C restatement of the reference mapper
+ * (/root/reference/minialign.c 0.6.0-devel) from FASTA in to SAM out, single-threaded:
+ *   sketch (minialign.c:2349-2448)       index build / get (:2656-3040)     seed (:3420-3540)
+ *   chain (:3547-3725)                   extension driver (:3785-4173)      post-map (:4185-4398)
+ *   SAM (:5096-5426)                     ksort radix sorts (ksort.h:84-131) kh_t (:341-683)
+ * Quirks of the reference that are part of its observable output are reproduced and marked "QUIRK".
+ * Not restated: circular references (-c), all-versus-all, BAM / gz input, non-SAM printers, optional tags.
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <time.h>
+#include "ora_mm.h"
+
+#define MAX2(x, y)  ( (x) > (y) ? (x) : (y) )
+#define MIN2(x, y)  ( (x) < (y) ? (x) : (y) )
+typedef union { uint64_t u64[2]; uint32_t u32[4]; } v4u32_t;
+typedef union { uint64_t u64[1]; uint32_t u32[2]; } v2u32_t;
+
+/* double -> uint32 the way gcc/x86-64 does it (cvttsd2si r64, then truncate); out-of-range gives 0x8000000000000000 -> 0 */
+static inline uint32_t d2u32(double d) { if(!(d > -9.2e18 && d < 9.2e18)) { return 0; } return (uint32_t)(int64_t)d; }
+static inline uint32_t f2u32(float f) { if(!(f > -9.2e18f && f < 9.2e18f)) { return 0; } return (uint32_t)(int64_t)f; }
+
+/* ---- growable arrays ---- */
+#define vec_t(type)     struct { uint64_t n, m; type *a; }
+#define vec_reserve(type, v, s) { if((v).m < (uint64_t)(s)) { (v).m = MAX2(256, (uint64_t)(s) * 2); (v).a = (type *)realloc((v).a, sizeof(type) * (v).m); } }
+#define vec_push(type, v, x)    { vec_reserve(type, v, (v).n + 1); (v).a[(v).n++] = (x); }
+
+/* ---- ksort.h:84-131: in-place MSD radix sort + insertion sort, UNSTABLE; the exact permutation is part of the contract ---- */
+#define RS_MIN_SIZE 64
+#define RADIX_SORT(name, type_t, keyexpr, keybytes) \
+	typedef struct { type_t *b, *e; } rsb_##name##_t; \
+	static void rs_ins_##name(type_t *beg, type_t *end) { \
+		for(type_t *i = beg + 1; i < end; ++i) { \
+			if(keyexpr(*i) < keyexpr(*(i - 1))) { \
+				type_t *j, tmp = *i; \
+				for(j = i; j > beg && keyexpr(tmp) < keyexpr(*(j - 1)); --j) { *j = *(j - 1); } \
+				*j = tmp; \
+			} \
+		} \
+	} \
+	static void rs_sort_##name(type_t *beg, type_t *end, int n_bits, int s) { \
+		int size = 1 << n_bits, m = size - 1; \
+		rsb_##name##_t b[256], *be = b + size, *k; \
+		for(k = b; k != be; ++k) { k->b = k->e = beg; } \
+		for(type_t *i = beg; i != end; ++i) { ++b[keyexpr(*i) >> s & m].e; } \
+		for(k = b + 1; k != be; ++k) { k->e += (k - 1)->e - beg; k->b = (k - 1)->e; } \
+		for(k = b; k != be;) { \
+			if(k->b != k->e) { \
+				rsb_##name##_t *l; \
+				if((l = b + (keyexpr(*k->b) >> s & m)) != k) { \
+					type_t tmp = *k->b, swap; \
+					do { swap = tmp; tmp = *l->b; *l->b++ = swap; l = b + (keyexpr(tmp) >> s & m); } while(l != k); \
+					*k->b++ = tmp; \
+				} else { ++k->b; } \
+			} else { ++k; } \
+		} \
+		for(b->b = beg, k = b + 1; k != be; ++k) { k->b = (k - 1)->e; } \
+		if(s) { \
+			s = s > n_bits ? s - n_bits : 0; \
+			for(k = b; k != be; ++k) { \
+				if(k->e - k->b > RS_MIN_SIZE) { rs_sort_##name(k->b, k->e, n_bits, s); } \
+				else if(k->e - k->b > 1) { rs_ins_##name(k->b, k->e); } \
+			} \
+		} \
+	} \
+	static void radix_sort_##name(type_t *p, uint64_t l) { \
+		if(l <= RS_MIN_SIZE) { rs_ins_##name(p, p + l); } else { rs_sort_##name(p, p + l, 8, keybytes * 8 - 8); } \
+	}
+#define KEY128(a)   ( (a).u64[0] )
+#define KEY64(a)    ( (a).u32[0] )
+RADIX_SORT(128x, v4u32_t, KEY128, 8)        /* minialign.c:203-204 */
+RADIX_SORT(64x, v2u32_t, KEY64, 4)          /* minialign.c:205-206 */
+
+/* ---- options ---- */
+static void opt_apply(om_opt_t *o, char const *s)
+{
+	while(*s) {
+		while(*s == ' ') { s++; }
+		if(*s != '-') { break; }
+		char c = s[1]; s += 2;
+		char const *arg = s;
+		while(*s && *s != ' ') { s++; }
+		switch(c) {
+			case 'k': o->k = (uint32_t)atoi(arg); break;
+			case 'w': o->w = (uint32_t)atoi(arg); break;
+			case 'a': { int m = atoi(arg); for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 2)) { o->p.score_matrix[i] = (int8_t)m; } } break; }
+			case 'b': { int x = atoi(arg); for(int i = 0; i < 16; i++) { if((i & 3) != (i >> 2)) { o->p.score_matrix[i] = (int8_t)-x; } } break; }
+			case 'p': o->p.gi = (int8_t)atoi(arg); break;
+			case 'q': o->p.ge = (int8_t)atoi(arg); break;
+			case 'r': { o->p.gfa = o->p.gfb = (int8_t)atoi(arg); char const *cm = arg; while(cm < s && *cm != ',') { cm++; } if(cm < s) { o->p.gfb = (int8_t)atoi(cm + 1); } break; }
+			case 'Y': o->p.xdrop = (int8_t)atoi(arg); break;
+			case 's': o->min_score = (uint32_t)atoi(arg); break;
+			case 'm': o->min_ratio = (float)atof(arg); break;
+			default: break;
+		}
+	}
+}
+int om_opt_init(om_opt_t *o, char const *preset)
+{
+	memset(o, 0, sizeof(*o));
+	o->k = 15; o->w = 32; o->b = 14; o->n_frq = 3; o->frq[0] = 0.05f; o->frq[1] = 0.01f; o->frq[2] = 0.001f;
+	o->wlen = 7000; o->glen = 7000; o->min_score = 50; o->min_ratio = 0.3f;
+	for(int i = 0; i < 16; i++) { o->p.score_matrix[i] = (i & 3) == (i >> 2) ? 1 : -1; }
+	o->p.gi = 1; o->p.ge = 1; o->p.gfa = 0; o->p.gfb = 0; o->p.xdrop = 50;
+	int rc = 0;
+	if(preset && *preset) {
+		/* preset tree, minialign.c:5853-5878 (the paths used by BASELINE's configs) */
+		if(strcmp(preset, "pacbio") == 0 || strcmp(preset, "pacbio.clr") == 0) { opt_apply(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3"); }
+		else if(strcmp(preset, "pacbio.ccs") == 0) { opt_apply(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3"); opt_apply(o, "-b5 -p6 -p2"); }
+		else if(strncmp(preset, "ont", 3) == 0) {
+			opt_apply(o, "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3");
+			if(strcmp(preset, "ont.1d") == 0) { opt_apply(o, "-a2"); }
+			else if(strcmp(preset, "ont.1dsq") == 0 || strcmp(preset, "ont.2d") == 0) { opt_apply(o, "-a2 -b6 -r4,4"); }
+			else if(strcmp(preset, "ont") != 0) { rc = 1; }
+		} else { rc = 1; }
+	}
+	if(o->w >= 32) { o->w = (uint32_t)(int)(2.0 / 3.0 * o->k + .499); }   /* minialign.c:6111 */
+	return rc;
+}
+
+/* ---- FASTA / FASTQ (bseq_read_fasta, minialign.c:1996-2090; encoding minialign.c:223-229) ---- */
+static uint8_t const encaf[16] = { [('A' & 0xf)] = 0, [('C' & 0xf)] = 1, [('G' & 0xf)] = 2, [('T' & 0xf)] = 3, [('U' & 0xf)] = 3, [('N' & 0xf)] = 4 };
+om_seqs_t om_read_fasta(char const *fn)
+{
+	om_seqs_t r = { 0, 0 };
+	FILE *fp = fopen(fn, "r");
+	if(!fp) { return r; }
+	vec_t(om_seq_t) v = { 0, 0, 0 };
+	char *line = NULL; size_t cap = 0; ssize_t l;
+	int state = 0;          /* 0: expect header, 1: seq lines, 2: qual lines */
+	char delim = 0;
+	uint64_t scap = 0, qneed = 0, qgot = 0;
+	while((l = getline(&line, &cap, fp)) > 0) {
+		while(l > 0 && (line[l - 1] == '\n' || line[l - 1] == '\r')) { line[--l] = 0; }
+		if(state == 2) { qgot += (uint64_t)l; if(qgot >= qneed) { state = 0; } continue; }
+		if(delim == 0 && (line[0] == '>' || line[0] == '@')) { delim = line[0]; }
+		if(state != 2 && line[0] == delim && (state == 0 || delim == '>' || 1) && (state == 0 || delim == '>')) {
+			om_seq_t s; memset(&s, 0, sizeof(s));
+			char *p = line + 1; while(*p == ' ' || *p == '\t') { p++; }
+			char *e = p; while(*e && *e != ' ' && *e != '\t') { e++; }
+			s.l_name = (uint32_t)(e - p); s.name = strndup(p, s.l_name);
+			vec_push(om_seq_t, v, s); scap = 0; state = 1;
+			continue;
+		}
+		if(state == 1 && delim == '@' && line[0] == '+') { state = 2; qneed = v.a[v.n - 1].l_seq; qgot = 0; if(qneed == 0) { state = 0; } continue; }
+		if(state == 1) {
+			om_seq_t *s = &v.a[v.n - 1];
+			if(s->l_seq + (uint64_t)l + 1 > scap) { scap = (s->l_seq + (uint64_t)l + 1) * 2; s->seq = (uint8_t *)realloc(s->seq, scap); }
+			for(ssize_t i = 0; i < l; i++) { s->seq[s->l_seq++] = encaf[line[i] & 0x0f]; }
+		}
+	}
+	free(line); fclose(fp);
+	/* -L 1: sequences shorter than min_len = 1 are dropped (minialign.c:2077) */
+	uint64_t j = 0;
+	for(uint64_t i = 0; i < v.n; i++) { if(v.a[i].l_seq >= 1) { v.a[j++] = v.a[i]; } else { free(v.a[i].name); free(v.a[i].seq); } }
+	r.a = v.a; r.n = j;
+	return r;
+}
+void om_seqs_free(om_seqs_t *s)
+{
+	for(uint64_t i = 0; i < s->n; i++) { free(s->a[i].name); free(s->a[i].seq); free(s->a[i].qual); }
+	free(s->a); s->a = NULL; s->n = 0;
+}
+
+/* ---- sketch ---- */
+static uint32_t crc_tbl[256]; static int crc_init_done = 0;
+static void crc_init(void)
+{
+	for(uint32_t i = 0; i < 256; i++) { uint32_t c = i; for(int k = 0; k < 8; k++) { c = (c & 1) ? (c >> 1) ^ 0x82f63b78u : c >> 1; } crc_tbl[i] = c; }
+	crc_init_done = 1;
+}
+static inline uint64_t crc32c_u64(uint64_t crc, uint64_t v)     /* _mm_crc32_u64 */
+{
+	uint32_t c = (uint32_t)crc;
+	for(int i = 0; i < 8; i++) { c = crc_tbl[(c ^ (uint8_t)(v >> (8 * i))) & 0xff] ^ (c >> 8); }
+	return (uint64_t)c;
+}
+#define HASH64(k0, k1, mask)    ( (crc32c_u64((k1), (k1)) ^ (k0)) & (mask) )       /* minialign.c:2353 */
+
+uint64_t om_sketch(uint32_t w_, uint32_t k_, uint8_t const *seq, uint32_t len, uint64_t *out)
+{
+	if(!crc_init_done) { crc_init(); }
+	uint64_t r[64]; for(int i = 0; i < 64; i++) { r[i] = UINT64_MAX; }     /* QUIRK: the reference initialises r[0..32) only (minialign.c:2373); w < 16 keeps all reads inside */
+	uint64_t const kk = k_ - 1, shift1 = 2 * kk, mask = (1ULL << 2 * k_) - 1, w = w_;
+	uint64_t *q = out;
+	uint8_t const *p = seq, *t = seq + len;
+	uint64_t u = 0, k0 = 0, k1 = 0;
+	#define PUSH_KMER() { uint64_t c = *p++; k0 = (k0 << 2 | c) & mask; k1 = (k1 >> 2) | ((3ULL ^ c) << shift1); }
+	#define LOOP_CORE(_h) { \
+		PUSH_KMER(); \
+		uint64_t km = k0 < k1 ? k0 : k1, kx = k0 < k1 ? k1 : k0, m = k0 < k1 ? 0 : 0x80; \
+		uint64_t hh = HASH64(km, kx, mask) << 8 | i | m; f = MIN2(f, hh); uint64_t v = MIN2(f, r[i + 1]); \
+		if((v == hh) | (v - u)) { *q++ = v; } \
+		u = v; (_h) = hh; \
+	}
+	for(uint64_t i = 0; i < kk && p < t; i++) { PUSH_KMER(); }
+	while((int64_t)(t - p) >= (int64_t)w) {
+		for(uint64_t i = 0, f = UINT64_MAX; i < w; i++) { uint64_t h; LOOP_CORE(h); r[i] = h; }
+		for(uint64_t i = 0, rr = UINT64_MAX; i < w; i++) { rr = MIN2(rr, r[w - i - 1]); r[w - i - 1] = rr; }
+	}
+	uint64_t l = (uint64_t)(t - p);
+	if(l > 0) {
+		for(uint64_t i = 0, f = UINT64_MAX; i < l; i++) { uint64_t h; LOOP_CORE(h); r[w + i] = h + w; }
+		/* (the folded r[] is only needed by a following circular cap, minialign.c:2424-2433) */
+	}
+	#undef PUSH_KMER
+	#undef LOOP_CORE
+	return (uint64_t)(q - out);
+}
+
+/* ---- kh_t: 64 -> 64 ordered linear-probing hash (minialign.c:341-683), literal ---- */
+#define KH_SIZE     256
+#define KH_THRESH   0.4
+#define KH_INIT_VAL UINT64_MAX
+typedef struct { uint32_t mask, max, cnt, ub; v4u32_t *a; } kh_t;
+static void kh_init_static(kh_t *h, uint64_t size)
+{
+	size = 0x8000000000000000ULL >> (__builtin_clzll(size - 1) - 1);
+	size = MAX2(size, KH_SIZE);
+	h->mask = (uint32_t)(size - 1); h->max = (uint32_t)size; h->cnt = 0; h->ub = (uint32_t)(size * KH_THRESH);
+	h->a = (v4u32_t *)malloc(sizeof(v4u32_t) * size);
+	for(uint64_t i = 0; i < size; i++) { h->a[i].u64[0] = UINT64_MAX; h->a[i].u64[1] = KH_INIT_VAL; }
+}
+static void kh_clear(kh_t *h)
+{
+	h->mask = KH_SIZE - 1; h->cnt = 0; h->ub = (uint32_t)(KH_SIZE * KH_THRESH);
+	for(uint64_t i = 0; i < KH_SIZE; i++) { h->a[i].u64[0] = UINT64_MAX; h->a[i].u64[1] = KH_INIT_VAL; }
+}
+typedef struct { uint64_t idx, n; } kh_bidx_t;
+static kh_bidx_t kh_allocate(v4u32_t *a, uint64_t k, uint64_t v, uint64_t mask)
+{
+	#define POLL(_i, _b0, _k1) { \
+		int64_t _b = (int64_t)(_b0); \
+		while(1) { \
+			(_k1) = a[_i].u64[0]; \
+			if(_b <= (int64_t)((_k1) & mask) + (int64_t)((_k1) + 2 < 2)) { break; } \
+			_b -= (int64_t)(((_i) + 1) & (mask + 1)); \
+			(_i) = ((_i) + 1) & mask; \
+		} \
+	}
+	uint64_t i = k & mask, k0 = k, v0 = v, k1;
+	POLL(i, i, k1);
+	if(k0 == k1) { return (kh_bidx_t){ i, 0 }; }
+	uint64_t j = i;
+	a[i].u64[0] = k0;
+	while(k1 + 2 >= 2) {
+		uint64_t v1 = a[i].u64[1];
+		a[i].u64[1] = v0;
+		k0 = k1; v0 = v1;
+		i = (i + 1) & mask;
+		POLL(i, k0 & mask, k1);
+		a[i].u64[0] = k0;
+	}
+	a[i].u64[1] = v0;
+	return (kh_bidx_t){ j, 1 };
+	#undef POLL
+}
+static void kh_extend(kh_t *h)
+{
+	uint64_t prev_size = (uint64_t)h->mask + 1, size = 2 * prev_size, mask = size - 1;
+	h->mask = (uint32_t)mask; h->ub = (uint32_t)(size * KH_THRESH);
+	if(size > h->max) { h->a = (v4u32_t *)realloc(h->a, sizeof(v4u32_t) * size); h->max = (uint32_t)size; }
+	for(uint64_t i = 0; i < prev_size; i++) { h->a[i + prev_size].u64[0] = UINT64_MAX; h->a[i + prev_size].u64[1] = KH_INIT_VAL; }
+	for(uint64_t i = 0; i < size; i++) {
+		uint64_t k = h->a[i].u64[0];
+		if(k + 2 < 2 || (k & mask) == i) { continue; }
+		uint64_t v = h->a[i].u64[1];
+		h->a[i].u64[0] = UINT64_MAX - 1; h->a[i].u64[1] = KH_INIT_VAL;
+		kh_allocate(h->a, k, v, mask);
+	}
+}
+static uint64_t *kh_put_ptr(kh_t *h, uint64_t key, uint64_t extend)
+{
+	if(extend != 0 && h->cnt >= h->ub) { kh_extend(h); }
+	kh_bidx_t b = kh_allocate(h->a, key, KH_INIT_VAL, h->mask);
+	h->cnt += (uint32_t)b.n;
+	return &h->a[b.idx].u64[1];
+}
+
+/* ---- index (mm_idx_gen, minialign.c:2767-3040): same key -> value-list map and list order; the 2nd-stage
+ *      Robin-Hood probe order is unobservable, so each bucket keeps its (hrem-sorted) array + binary search ---- */
+typedef struct { uint64_t hrem; uint32_t pos, rid; } mini_t;     /* mm_mini_t, minialign.c:2661 */
+typedef struct {
+	uint64_t n_keys;
+	uint64_t *key;      /* hrem, ascending */
+	uint32_t *start;    /* n_keys + 1 offsets into val */
+	uint64_t *val;      /* pos | rid << 32, in post-sort order */
+} bkt_t;
+struct om_idx_s {
+	uint32_t b, w, k, n_occ; uint64_t mask;
+	uint32_t occ[16];
+	bkt_t *bkt;
+	om_seq_t const *s; uint32_t n_seq;
+};
+uint32_t om_idx_occ(om_idx_t const *mi, uint32_t i) { return mi->occ[i]; }
+
+static int cmp_u32(void const *a, void const *b) { uint32_t x = *(uint32_t const *)a, y = *(uint32_t const *)b; return x < y ? -1 : x > y; }
+
+om_idx_t *om_idx_build(om_opt_t const *o, om_seq_t const *ref, uint32_t n_ref)
+{
+	om_idx_t *mi = (om_idx_t *)calloc(1, sizeof(om_idx_t));
+	uint32_t b = MIN2(o->k * 2, o->b);
+	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq; mi->mask = (1ULL << b) - 1;
+	mi->s = ref; mi->n_seq = n_ref;
+	uint64_t nb = 1ULL << b;
+	typedef vec_t(mini_t) mini_v;
+	mini_v *arr = (mini_v *)calloc(nb, sizeof(mini_v));
+	/* mm_idx_worker + mm_idx_drain_intl (minialign.c:2790-2860): sketch every sequence, push in reference order */
+	for(uint32_t i = 0; i < n_ref; i++) {
+		uint64_t *m = (uint64_t *)malloc(sizeof(uint64_t) * (4 * (uint64_t)ref[i].l_seq / o->w + 512));
+		uint64_t n = om_sketch(o->w, o->k, ref[i].seq, ref[i].l_seq, m);
+		uint64_t w = o->w, base = (uint64_t)-(int64_t)w, v = w;
+		for(uint64_t j = 0; j < n; j++) {
+			uint64_t u = m[j] & 0x7f, fr = (m[j] >> 7) & 0x01, h = m[j] >> 8;
+			base += u <= v ? w : 0; v = u;
+			mini_t x = { h >> b, (uint32_t)(base + u), (uint32_t)((i << 1) + fr) };
+			vec_push(mini_t, arr[h & mi->mask], x);
+		}
+		free(m);
+	}
+	/* mm_idx_count_occ (minialign.c:2867-2900): per-bucket radix sort on hrem, occurrence histogram */
+	vec_t(uint32_t) cnt = { 0, 0, 0 };
+	for(uint64_t i = 0; i < nb; i++) {
+		if(arr[i].n == 0) { continue; }
+		radix_sort_128x((v4u32_t *)arr[i].a, arr[i].n);
+		uint32_t n = 1;
+		for(uint64_t j = 1; j < arr[i].n; j++) {
+			if(arr[i].a[j - 1].hrem != arr[i].a[j].hrem) { vec_push(uint32_t, cnt, n); n = 0; }
+			n++;
+		}
+		vec_push(uint32_t, cnt, n);
+	}
+	/* occ thresholds (minialign.c:2981-2986): k-th smallest count + 1 */
+	uint32_t *sorted = (uint32_t *)malloc(sizeof(uint32_t) * (cnt.n + 1));
+	memcpy(sorted, cnt.a, sizeof(uint32_t) * cnt.n);
+	qsort(sorted, cnt.n, sizeof(uint32_t), cmp_u32);
+	for(uint32_t i = 0; i < o->n_frq; i++) {
+		if(o->frq[i] <= 0.0) { mi->occ[i] = UINT32_MAX; continue; }
+		uint32_t kk = (uint32_t)((1.0 - o->frq[i]) * cnt.n);
+		mi->occ[i] = (cnt.n ? sorted[MIN2((uint64_t)kk, cnt.n - 1)] : 0) + 1;
+	}
+	free(sorted); free(cnt.a);
+	/* mm_idx_build_hash (minialign.c:2905-2944): keys with more than occ[n_occ - 1] hits are dropped */
+	uint64_t max_cnt = mi->occ[mi->n_occ - 1];
+	mi->bkt = (bkt_t *)calloc(nb, sizeof(bkt_t));
+	for(uint64_t i = 0; i < nb; i++) {
+		uint64_t n = arr[i].n;
+		if(n == 0) { continue; }
+		bkt_t *bk = &mi->bkt[i];
+		bk->key = (uint64_t *)malloc(sizeof(uint64_t) * n); bk->start = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1)); bk->val = (uint64_t *)malloc(sizeof(uint64_t) * n);
+		uint64_t nk = 0, nv = 0;
+		for(uint64_t j = 0; j < n;) {
+			uint64_t e = j + 1; while(e < n && arr[i].a[e].hrem == arr[i].a[j].hrem) { e++; }
+			/* QUIRK (minialign.c:2927-2931): when a key exceeds max_cnt the fill cursor `q` is not advanced, so every
+			 * later key of the same bucket (in hrem order) is measured from that stale cursor and dropped as well */
+			if(e - j > max_cnt) { break; }
+			bk->key[nk] = arr[i].a[j].hrem; bk->start[nk] = (uint32_t)nv; nk++;
+			for(uint64_t x = j; x < e; x++) { bk->val[nv++] = (uint64_t)arr[i].a[x].pos | ((uint64_t)arr[i].a[x].rid << 32); }
+			j = e;
+		}
+		bk->start[nk] = (uint32_t)nv; bk->n_keys = nk;
+		free(arr[i].a);
+	}
+	free(arr);
+	return mi;
+}
+void om_idx_free(om_idx_t *mi)
+{
+	if(!mi) { return; }
+	for(uint64_t i = 0; i < (1ULL << mi->b); i++) { free(mi->bkt[i].key); free(mi->bkt[i].start); free(mi->bkt[i].val); }
+	free(mi->bkt); free(mi);
+}
+uint64_t const *om_idx_get(om_idx_t const *mi, uint64_t minier, uint32_t *n)
+{
+	bkt_t const *b = &mi->bkt[minier & mi->mask];
+	uint64_t key = minier >> mi->b, lo = 0, hi = b->n_keys;
+	while(lo < hi) { uint64_t mid = (lo + hi) / 2; if(b->key[mid] < key) { lo = mid + 1; } else { hi = mid; } }
+	if(lo >= b->n_keys || b->key[lo] != key) { *n = 0; return NULL; }
+	*n = b->start[lo + 1] - b->start[lo];
+	return &b->val[b->start[lo]];
+}
+
+/* ---- mapper ---- */
+typedef struct { uint32_t qs, n; uint64_t const *p; } resc_t;                 /* mm_resc_t, minialign.c:3176 */
+typedef struct { uint32_t rsid, rid, lsid, cid; } leaf_t;                       /* mm_leaf_t, minialign.c:3190 */
+typedef struct { uint32_t plen, lid; } root_t;                                  /* mm_root_t, minialign.c:3202; aliased by mm_res_t { score, iid } */
+typedef struct { uint32_t apos, bpos; } pos_pair_t;
+typedef struct {                                                                /* mm_search_t, minialign.c:3218 */
+	pos_pair_t cp, tp;
+	uint32_t aid, bid;
+	uint32_t iid, eid, sid, rev;
+	int64_t prem; uint32_t pacc;
+	uint32_t crem, srem, narrow;
+	uint32_t min_score;
+} search_t;
+#define MM_CREM 50000
+#define MM_SREM 8
+#define BIN_N   2           /* mm_bin_t header occupies two pointer slots (minialign.c:3252-3257) */
+typedef struct { uint32_t n_aln, plen, lb, ub; } bin_hdr_t;
+
+struct om_align_s {
+	om_idx_t const *mi; om_opt_t o;
+	uint32_t twlen, tglen; float min_ratio; uint32_t min_score;
+	double mcoef, xcoef;
+	og_ctx_t *ctx; og_dp_t *dp;
+	uint32_t rid, qid, rlen, qlen;
+	uint8_t const *rseq, *qseq;
+	og_section_t r[2], q[3], t[2];
+	uint8_t tail[128];
+	vec_t(resc_t) resc; uint64_t presc;
+	vec_t(om_seed_t) seed; uint64_t n_seed;
+	vec_t(root_t) root;
+	vec_t(v2u32_t) next;
+	uint32_t n_res;
+	vec_t(uint64_t) bin;            /* slots: bin headers (2 slots) and alignment handles (index + 1 into alns) */
+	vec_t(og_alignment_t *) alns;   /* alignment table (the lmm arena of the reference) */
+	kh_t pos;
+	uint64_t cnt[8];
+};
+#define OFS(x)          ( (int32_t)0x40000000 - (int32_t)(x) )
+#define UD(x, y)        ( ((x) << 1) - (y) )
+#define VD(x, y)        ( ((y) << 1) - (x) )
+#define U_(x, y)        ( UD(x, y) + OFS(0) )
+#define V_(x, y)        ( VD(x, y) + OFS(0) )
+#define BARE(x)         ( (x) - OFS(0) )
+#define AS(p)           ( (int32_t)((BARE((p)->upos) << 1) + BARE((p)->vpos)) / 3 )
+#define BS(p)           ( (int32_t)((BARE((p)->vpos) << 1) + BARE((p)->upos)) / 3 )
+#define PS(p)           ( (p)->upos + (p)->vpos )
+#define SMASK(x)        ( ((int32_t)(x)) >> 31 )
+static inline uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
+#define KEY(x, y)       ( (uint64_t)(x) ^ ((uint64_t)(x) >> 29) ^ (uint64_t)(y) ^ bswap64((uint64_t)(y)) )   /* minialign.c:3362 */
+
+om_align_t *om_align_init(om_opt_t const *o, om_idx_t const *mi)
+{
+	om_align_t *a = (om_align_t *)calloc(1, sizeof(om_align_t));
+	a->mi = mi; a->o = *o;
+	a->twlen = (uint32_t)UD((int32_t)o->wlen, (int32_t)o->wlen); a->tglen = (uint32_t)UD((int32_t)o->glen, (int32_t)o->glen);
+	a->min_ratio = o->min_ratio; a->min_score = o->min_score;
+	/* QUIRK (minialign.c:4676-4681): both coefficients accumulate score_matrix[0] */
+	double mcoef = 0.0, xcoef = 0.0;
+	for(uint64_t i = 0; i < 16; i++) { if((i & 0x03) == (i >> 3)) { mcoef += o->p.score_matrix[0]; } else { xcoef += o->p.score_matrix[0]; } }
+	a->mcoef = mcoef / 4.0; a->xcoef = xcoef / 12.0;
+	a->ctx = og_init(&o->p);
+	if(a->ctx == NULL) { free(a); return NULL; }
+	a->dp = og_dp_init(a->ctx);
+	memset(a->tail, 4, 128);
+	a->t[0] = (og_section_t){ 0xfffffffe, 96, a->tail }; a->t[1] = a->t[0];
+	kh_init_static(&a->pos, 128);
+	return a;
+}
+void om_align_free(om_align_t *a)
+{
+	if(!a) { return; }
+	og_dp_clean(a->dp); og_clean(a->ctx);
+	free(a->resc.a); free(a->seed.a); free(a->root.a); free(a->next.a); free(a->bin.a); free(a->alns.a); free(a->pos.a);
+	free(a);
+}
+void om_counters(om_align_t const *a, uint64_t out[8]) { memcpy(out, a->cnt, sizeof(a->cnt)); }
+
+/* mm_expand, minialign.c:3420-3447 */
+static void mm_expand(om_align_t *self, uint32_t n, uint64_t const *r, uint32_t qs)
+{
+	if(n == 0) { return; }
+	vec_reserve(om_seed_t, self->seed, self->seed.n + n);
+	for(uint64_t i = 0; i < n; i++) {
+		uint32_t rid = (uint32_t)(r[i] >> 32);
+		if(rid < self->qid) { continue; }
+		uint32_t rs = (uint32_t)r[i];
+		uint32_t rmask = -(rid & 0x01);
+		int32_t _rs = (int32_t)(rs + (self->mi->k & rmask)), _qs = (int32_t)(qs ^ rmask);
+		self->seed.a[self->seed.n++] = (om_seed_t){ .upos = (uint32_t)U_(_rs, _qs), .vpos = (uint32_t)V_(_rs, _qs), .rid = rid >> 1, .lid = INT32_MAX };
+	}
+}
+/* mm_collect_seed, minialign.c:3454-3493 */
+static void mm_collect_seed(om_align_t *self)
+{
+	uint64_t *m = (uint64_t *)malloc(sizeof(uint64_t) * (4 * (uint64_t)self->qlen / self->mi->w + 512));
+	uint64_t nm = om_sketch(self->mi->w, self->mi->k, self->qseq, self->qlen, m);
+	vec_reserve(resc_t, self->resc, nm + 1);
+	uint64_t ns = 0;
+	uint32_t max_occ = self->mi->occ[self->mi->n_occ - 1], resc_occ = self->mi->occ[0];
+	uint64_t w = self->mi->w, base = (uint64_t)-(int64_t)w, v = w;
+	for(uint64_t j = 0; j < nm; j++) {
+		uint64_t u = m[j] & 0x7f, fr = (m[j] >> 7) & 0x01, h = m[j] >> 8;
+		base += u <= v ? w : 0; v = u;
+		uint32_t n;
+		uint64_t const *r = om_idx_get(self->mi, h, &n);
+		self->cnt[0]++;
+		if(n > max_occ) { continue; }
+		uint32_t pos = (uint32_t)((base + u + (self->mi->k & -fr)) ^ -fr);
+		if(n > resc_occ) { self->resc.a[ns++] = (resc_t){ .p = r, .qs = pos, .n = n }; continue; }
+		mm_expand(self, n, r, pos);
+	}
+	free(m);
+	self->resc.n = ns; self->presc = 0; self->root.n = 0;
+}
+/* mm_seed, minialign.c:3500-3541 */
+static uint64_t mm_seed(om_align_t *self, uint64_t cnt)
+{
+	if(cnt == 0) {
+		self->seed.n = 0; self->n_seed = 0;
+		mm_collect_seed(self);
+	} else {
+		if(cnt == 1) { radix_sort_128x((v4u32_t *)self->resc.a, self->resc.n); }     /* key = qs | n << 32 */
+		self->seed.n = self->n_seed;
+		for(uint64_t i = 0; i < self->seed.n; i++) { self->seed.a[i].lid = INT32_MAX; }
+		uint64_t p = self->presc, t = self->resc.n;
+		while(p < t && self->resc.a[p].n <= self->mi->occ[cnt]) { mm_expand(self, self->resc.a[p].n, self->resc.a[p].p, self->resc.a[p].qs); p++; }
+		self->presc = p;
+	}
+	self->n_seed = self->seed.n;
+	if(self->seed.n == 0) { return 0; }
+	om_seed_t sentinel = { .rid = INT32_MAX, .upos = (uint32_t)INT32_MIN, .vpos = (uint32_t)INT32_MIN, .lid = INT32_MAX };
+	vec_push(om_seed_t, self->seed, sentinel);
+	radix_sort_128x((v4u32_t *)self->seed.a, self->seed.n);
+	self->cnt[1] += self->seed.n;
+	return self->seed.n;
+}
+
+/* window arithmetic on (vpos, vpos, rid, upos) vectors, minialign.c:3366-3402, written out per element (signed 32-bit) */
+typedef struct { int32_t e[4]; } v4;     /* e[0] = upos, e[1] = rid, e[2] = vpos (vub side), e[3] = vpos (vlb side) */
+static inline v4 load_pv(om_seed_t const *p) { return (v4){ { (int32_t)p->upos, (int32_t)p->rid, (int32_t)p->vpos, (int32_t)p->vpos } }; }
+static inline v4 window(int32_t len) { return (v4){ { len, 0, len, 0 } }; }       /* _seta(0, len, 0, len): lane0 = len, 1 = 0, 2 = len, 3 = 0 */
+static inline v4 add4(v4 a, v4 b) { v4 r; for(int i = 0; i < 4; i++) { r.e[i] = (int32_t)((uint32_t)a.e[i] + (uint32_t)b.e[i]); } return r; }
+static inline v4 sub4(v4 a, v4 b) { v4 r; for(int i = 0; i < 4; i++) { r.e[i] = (int32_t)((uint32_t)a.e[i] - (uint32_t)b.e[i]); } return r; }
+/* _mask_v4i32(_gt_v4i32(d, u)): 4 bits per lane, lane 0 in the low nibble */
+static inline uint32_t inside_mask(v4 u, v4 d) { uint32_t m = 0; for(int i = 0; i < 4; i++) { if(d.e[i] > u.e[i]) { m |= 0xfu << (4 * i); } } return m; }
+#define INSIDE_WV(u, d)     ( inside_mask(u, d) == 0xf000 )
+#define INSIDE_UUB(u, d)    ( (inside_mask(u, d) & 0xff) == 0x00 )
+static inline v4 update_wv(v4 w, v4 f)       /* _update_wv, minialign.c:3380-3388 */
+{
+	v4 dv = sub4(w, f);
+	/* shuffle (3,0,1,2) -> lanes (dv2, dv1, dv0, dv3); keep lanes 0 and 2 */
+	v4 sv = { { dv.e[2], 0, dv.e[0], 0 } };
+	return sub4(w, sv);
+}
+static inline int32_t pdiff(v4 w, v4 f) { v4 dv = sub4(w, f); return (int32_t)((uint32_t)dv.e[0] + (uint32_t)dv.e[2]); }
+
+/* mm_chain_seeds, minialign.c:3547-3625 */
+static uint64_t mm_chain_seeds(om_align_t *self)
+{
+	om_seed_t *s = self->seed.a;
+	leaf_t *ls = (leaf_t *)self->seed.a;
+	root_t *c = self->root.a;
+	uint32_t ncid = 0, nlid = (uint32_t)self->n_seed + 1;
+	uint32_t nlsid = 0, tsid = (uint32_t)self->n_seed;
+	v4 tv = window((int32_t)self->twlen);
+	while(nlsid < tsid) {
+		uint32_t lid = nlid++;
+		ls[lid] = (leaf_t){ .rsid = nlsid, .lsid = nlsid, .rid = s[nlsid].rid, .cid = UINT32_MAX };
+		uint32_t plen = PS(&s[nlsid]), scnt = 1;
+		uint64_t nrsid = nlsid; nlsid = UINT32_MAX;
+		while(1) {
+			uint32_t rsid = (uint32_t)nrsid; nrsid = 0;
+			v4 wv = add4(load_pv(&s[rsid]), tv);
+			for(uint32_t sid = rsid + 1; ; sid++) {
+				v4 fv = load_pv(&s[sid]);
+				if(!INSIDE_WV(wv, fv)) {
+					nlsid = MIN2(nlsid, sid);
+					if(INSIDE_UUB(wv, fv)) { continue; }
+					break;
+				}
+				wv = update_wv(wv, fv);
+				int64_t di = (int64_t)(((uint64_t)(int64_t)pdiff(wv, fv) << 32) | sid);
+				nrsid = (uint64_t)MAX2((int64_t)nrsid, di);
+			}
+			if(nrsid == 0) { nrsid = rsid; break; }
+			if(s[(uint32_t)nrsid].lid != INT32_MAX) { nrsid = (uint32_t)nrsid; break; }
+			s[(uint32_t)nrsid].lid = lid; scnt++;
+			if(nlsid <= nrsid) { nlsid = UINT32_MAX; }            /* QUIRK: compares against the full 64-bit (pdiff << 32 | sid) value */
+		}
+		if(nrsid == ls[lid].lsid) { continue; }
+		uint32_t cid = UINT32_MAX;
+		if(s[nrsid].lid < lid) {
+			nrsid = ls[s[nrsid].lid].rsid;
+			cid = ls[s[nrsid].lid].cid;
+		}
+		if(cid == UINT32_MAX) { cid = ncid++; c[cid] = (root_t){ .lid = lid, .plen = (uint32_t)OFS(0) }; }
+		ls[lid].cid = cid; ls[lid].rsid = (uint32_t)nrsid;
+		plen = (uint32_t)OFS((uint32_t)d2u32((1.0 - 1.0 / (double)scnt) * (double)(uint32_t)(PS(&s[nrsid]) - plen)));
+		if(plen < c[cid].plen) { c[cid] = (root_t){ .plen = plen, .lid = lid }; }
+	}
+	self->root.n = ncid; self->seed.n = nlid;
+	return ncid;
+}
+/* mm_chain, minialign.c:3702-3721 (mm_circularize is a no-op without circular references) */
+static uint64_t mm_chain(om_align_t *self)
+{
+	vec_reserve(om_seed_t, self->seed, self->seed.n + self->seed.n);
+	vec_reserve(root_t, self->root, self->seed.n);
+	vec_reserve(v2u32_t, self->next, self->seed.n);
+	self->root.n = 0; self->next.n = 0;
+	if(mm_chain_seeds(self) == 0) { return 0; }
+	radix_sort_64x((v2u32_t *)self->root.a, self->root.n);
+	self->cnt[2] += self->root.n;
+	return self->root.n;
+}
+
+/* sections: _sec_fw / _sec_rv, minialign.c:3727-3736 */
+static void init_ref(om_align_t *self, uint32_t rid)
+{
+	om_seq_t const *ref = &self->mi->s[rid];
+	self->rid = rid; self->rlen = ref->l_seq; self->rseq = ref->seq;
+	self->r[0] = (og_section_t){ rid << 1, ref->l_seq, ref->seq };
+	self->r[1] = (og_section_t){ (rid << 1) + 1, ref->l_seq, og_mirror(ref->seq, ref->l_seq) };
+}
+static void init_query(om_align_t *self, uint32_t l_seq, uint8_t const *seq)
+{
+	self->qid = 0; self->qlen = l_seq; self->qseq = seq;
+	self->q[0] = (og_section_t){ 0, l_seq, seq };
+	self->q[1] = (og_section_t){ 1, l_seq, og_mirror(seq, l_seq) };
+	self->q[2] = self->q[0];
+}
+
+static bin_hdr_t *bin_at(om_align_t *self, uint64_t iid) { return (bin_hdr_t *)&self->bin.a[iid]; }
+static og_alignment_t *aln_of(om_align_t *self, uint64_t slot) { return self->alns.a[self->bin.a[slot] - 1]; }
+
+/* mm_finish_root, minialign.c:3795-3813 */
+static uint64_t mm_finish_root(om_align_t *self, search_t *st)
+{
+	root_t *r = self->root.a;
+	bin_hdr_t *bin = bin_at(self, st->iid);
+	if(bin->n_aln == 0 || r[st->eid].plen > (uint32_t)OFS(self->min_score)) {
+		self->bin.n = st->iid; self->n_res--; st->crem--;
+	} else {
+		st->crem = st->crem != 0 ? MM_CREM : 0;
+	}
+	return st->crem == 0;
+}
+/* mm_search_load_pos, minialign.c:3818-3834 */
+static pos_pair_t mm_search_load_pos(om_align_t *self, om_seed_t const *p, uint32_t *rev)
+{
+	*rev = BS(p) < 0;
+	pos_pair_t cp = { .apos = (uint32_t)AS(p), .bpos = (uint32_t)(BS(p) + (SMASK(BS(p)) & (int32_t)self->qlen)) };
+	if(cp.apos >= self->rlen || cp.bpos >= self->qlen) {
+		cp.apos -= MIN2(cp.apos, self->mi->k);
+		cp.bpos -= MIN2(cp.bpos, self->mi->k);
+	}
+	return cp;
+}
+/* mm_search_load_root, minialign.c:3839-3883 */
+static uint64_t mm_search_load_root(om_align_t *self, search_t *st, uint32_t cid)
+{
+	om_seed_t const *s = self->seed.a; leaf_t const *ls = (leaf_t const *)self->seed.a;
+	uint32_t lid = self->root.a[cid].lid;
+	uint32_t plen = (uint32_t)OFS(self->root.a[cid].plen);
+	if(plen * self->mcoef < 2.0 * self->min_score) { return 1; }
+	self->next.n = 0;
+	/* open result bin: a header with lb = UINT32_MAX */
+	vec_reserve(uint64_t, self->bin, self->bin.n + BIN_N);
+	uint32_t iid = (uint32_t)self->bin.n;
+	/* QUIRK (build-dependent): the source initialises the header with .lb = UINT32_MAX through a type-punned
+	 * compound literal (minialign.c:3855); gcc -O3 drops that store (strict aliasing), so in the reference *as built*
+	 * every bin starts all-zero -- verified on oracle/_ref (204/204 bins end with lb == 0).  The built binary is the oracle. */
+	bin_hdr_t hdr = { .n_aln = 0, .plen = 0, .lb = 0, .ub = 0 };
+	memcpy(&self->bin.a[iid], &hdr, sizeof(hdr)); self->bin.n += BIN_N;
+	root_t *r = self->root.a;
+	uint32_t eid = self->n_res++;
+	r[eid] = (root_t){ .plen = (uint32_t)OFS(0), .lid = iid };      /* mm_res_t { score, iid } aliases the root array */
+	uint32_t rsid = ls[lid].rsid;
+	om_seed_t const *p = &s[rsid];
+	/* QUIRK: mm_search_load_pos runs before mm_init_ref, i.e. with the rlen of the previously loaded reference
+	 * (0 for the very first chain of the run): the state is carried across chains *and reads* (minialign.c:3864,3873) */
+	pos_pair_t cp = mm_search_load_pos(self, p, &st->rev);
+	st->cp = cp; st->tp = cp;
+	st->aid = p->rid; st->bid = self->qid;
+	st->iid = iid; st->eid = eid; st->sid = rsid;
+	st->prem = plen; st->pacc = 0;
+	st->srem = MM_SREM; st->narrow = 0;
+	init_ref(self, st->aid);
+	return 0;
+}
+/* mm_search_load_next, minialign.c:3888-3946 */
+static uint64_t mm_search_load_next(om_align_t *self, search_t *st)
+{
+	if(st->srem == 0) { return 0; }
+	st->srem--;
+	om_seed_t const *s = self->seed.a;
+	v2u32_t *n = self->next.a;
+	uint64_t ncnt = self->next.n, ofs = 2 * (uint64_t)self->tglen;
+	v4 tv = window((int32_t)self->tglen), ev = window(128);
+	int32_t fa = (int32_t)st->cp.apos, fb = (int32_t)(st->cp.bpos - (st->rev ? self->qlen : 0));
+	v4 fv = { { (int32_t)U_(fa, fb), (int32_t)st->aid, (int32_t)V_(fa, fb), (int32_t)V_(fa, fb) } };   /* _posv_v4i32 */
+	uint64_t plim = ofs - st->pacc;
+	if(st->pacc > ofs) { ncnt = 0; }
+	for(uint64_t i = 0; i < ncnt; i++) {
+		if(n[i].u32[0] >= plim) { ncnt = i; break; }
+		n[i].u32[0] += st->pacc;
+	}
+	uint64_t sid = st->sid;
+	for(uint64_t rcnt = 2 * (uint64_t)st->srem; sid > 0 && rcnt > 0; sid--) {
+		v4 wv = add4(load_pv(&s[sid - 1]), tv);
+		v4 zv = add4(load_pv(&s[sid - 1]), ev);
+		if(!INSIDE_UUB(wv, fv)) { break; }
+		if(!INSIDE_WV(wv, fv) || INSIDE_WV(zv, fv)) { continue; }
+		n[ncnt++] = (v2u32_t){ .u32 = { (uint32_t)pdiff(wv, fv), (uint32_t)(sid - 1) } }; rcnt--;
+	}
+	st->sid = (uint32_t)sid;
+	self->next.n = ncnt;
+	if(ncnt == 0) { st->pacc = 0; st->srem = 0; return 0; }
+	radix_sort_64x(n, ncnt);
+	uint32_t nsid = n[--self->next.n].u32[1];
+	st->pacc = (uint32_t)(ofs - n[self->next.n].u32[0]);
+	st->cp = mm_search_load_pos(self, &s[nsid], &st->rev);
+	return st->srem;
+}
+/* mm_search_test_dup, minialign.c:3953-3982 */
+static uint64_t mm_search_test_dup(om_align_t *self, search_t *st, og_pos_pair_t const *cp)
+{
+	uint64_t k = KEY((uint64_t)cp->apos | ((uint64_t)cp->bpos << 32), (uint64_t)st->aid | ((uint64_t)st->bid << 32));
+	uint64_t *t = kh_put_ptr(&self->pos, k, 1);
+	uint64_t prev = *t;
+	int32_t pa = MAX2(1, MIN2((int32_t)cp->apos, (int32_t)self->rlen)), pb = MAX2(1, MIN2((int32_t)cp->bpos, (int32_t)self->qlen));
+	st->tp.apos = (uint32_t)pa; st->tp.bpos = (uint32_t)pb;
+	*t = (uint64_t)st->eid | ((uint64_t)UINT32_MAX << 32);
+	if(prev == KH_INIT_VAL) { return 0; }
+	uint32_t eid = (uint32_t)*t;                 /* QUIRK: reads the slot *after* overwriting it, so eid == st->eid always */
+	root_t *r = self->root.a;
+	if(eid != st->eid && cp->plen < bin_at(self, r[eid].lid)->plen) {
+		st->srem = 0;
+	} else {
+		st->narrow = MIN2(st->narrow + 1, 2);
+	}
+	return 1;
+}
+/* mm_search_record (+ mm_update_pos), minialign.c:3987-4067 */
+static uint64_t mm_search_record(om_align_t *self, search_t *st, og_alignment_t *a)
+{
+	og_segment_t const *sl = &a->seg[a->slen - 1], *s0 = &a->seg[0];
+	uint32_t p[4];
+	p[0] = self->rlen - (sl->apos + sl->alen); p[1] = self->qlen - (sl->bpos + sl->blen);
+	p[2] = self->rlen - s0->apos;               p[3] = self->qlen - s0->bpos;
+	st->cp.apos = p[0]; st->cp.bpos = p[1];
+	st->prem -= a->plen; st->pacc = a->plen;
+
+	uint64_t id = (uint64_t)st->aid | ((uint64_t)st->bid << 32);
+	uint64_t hk = KEY((uint64_t)p[0] | ((uint64_t)p[1] << 32), id), tk = KEY((uint64_t)p[2] | ((uint64_t)p[3] << 32), id);
+	/* QUIRK: h is taken before the second insert, which may shift table entries under it (minialign.c:4027-4029);
+	 * both are plain pointers into the same array here too, so the aliasing is reproduced literally */
+	uint64_t *h = kh_put_ptr(&self->pos, hk, 1);
+	uint64_t *t = kh_put_ptr(&self->pos, tk, 0);
+	uint64_t new = (uint32_t)(*h >> 32) == UINT32_MAX;
+	vec_push(og_alignment_t *, self->alns, a);
+	uint64_t handle = self->alns.n;              /* index + 1 */
+	uint32_t nid;
+	if(new) { vec_reserve(uint64_t, self->bin, self->bin.n + 1); nid = (uint32_t)self->bin.n; self->bin.a[self->bin.n++] = handle; }
+	else { nid = (uint32_t)(*h >> 32); }
+	root_t *r = self->root.a;
+	bin_hdr_t *bin = bin_at(self, st->iid);
+	uint32_t ovl = MAX2(bin->lb, p[1]) - MIN2(bin->ub, p[3]) - p[1] + p[3];
+	r[st->eid].plen -= (uint32_t)(a->score + (int64_t)d2u32((double)(uint32_t)(ovl * 2) * a->identity));
+	bin->n_aln += (uint32_t)new;
+	bin->plen += a->plen;
+	bin->lb = MIN2(bin->lb, p[1]);
+	bin->ub = MAX2(bin->ub, p[3]);
+	og_alignment_t *b0 = aln_of(self, nid);
+	if(b0->score > a->score) {
+		*t = (uint64_t)st->eid | ((uint64_t)UINT32_MAX << 32);
+	} else {
+		if(b0 != a) { self->bin.a[nid] = handle; }
+		*h = *t = (uint64_t)st->eid | ((uint64_t)nid << 32);
+	}
+	st->srem = MM_SREM; st->narrow = 0;
+	{
+		float cand = (float)a->score * self->min_ratio, cur = (float)st->min_score;
+		st->min_score = f2u32(cur > cand ? cur : cand);
+	}
+	return (new && st->prem > 0) ? 0 : 1;
+}
+/* mm_extend_core, minialign.c:4075-4112 */
+static og_fill_t const *mm_extend_core(om_align_t *self, int bw_idx, og_section_t const *a, og_section_t const *at, og_section_t const *b, og_section_t const *bt, pos_pair_t s)
+{
+	if(getenv("OM_DEBUG")) { fprintf(stderr, "fill_root bw(%d) a(%u,%u) apos(%u) b(%u,%u) bpos(%u) rlen(%u) qlen(%u)\n", bw_idx, a->id, a->len, s.apos, b->id, b->len, s.bpos, self->rlen, self->qlen); }
+	og_fill_t const *f = og_dp_fill_root(self->dp, bw_idx, a, s.apos, b, s.bpos, 0);
+	og_fill_t const *m = f;
+	uint32_t flag = OG_TERM;
+	self->cnt[3]++;
+	while((flag & f->status) == 0) {
+		if(f->status & OG_UPDATE_A) { a = at; }
+		if(f->status & OG_UPDATE_B) { b = bt; }
+		flag |= f->status & (OG_UPDATE_A | OG_UPDATE_B);
+		f = og_dp_fill(self->dp, f, a, b, 0);
+		m = f->max > m->max ? f : m;
+	}
+	return m;
+}
+/* mm_extend, minialign.c:4118-4173 */
+static uint64_t mm_extend(om_align_t *self)
+{
+	search_t st; memset(&st, 0, sizeof(st)); st.crem = MM_CREM; st.min_score = self->min_score;
+	for(uint64_t k = 0; k < self->root.n; k++) {
+		if(mm_search_load_root(self, &st, (uint32_t)k)) { if(getenv("OM_DEBUG")) fprintf(stderr, "chain %lu: plen too short, break\n", k); break; }
+		if(getenv("OM_DEBUG")) fprintf(stderr, "chain %lu/%lu: prem %ld aid %u cp(%u,%u) rev %u\n", k, self->root.n, st.prem, st.aid, st.cp.apos, st.cp.bpos, st.rev);
+		for(; st.srem > 0 && st.prem > 0; mm_search_load_next(self, &st)) {
+			og_dp_flush(self->dp);
+			/* QUIRK (minialign.c:4123): _dp(x) ignores its argument, every call uses dp[st.narrow] */
+			og_fill_t const *f = mm_extend_core(self, (int)st.narrow, &self->r[0], &self->t[0], &self->q[st.rev], &self->t[0], st.cp);
+			if(getenv("OM_DEBUG")) fprintf(stderr, "  down max %ld\n", f->max);
+			if(f->max == 0) { continue; }
+			og_pos_pair_t const *pp = og_dp_search_max(self->dp, f);
+			if(mm_search_test_dup(self, &st, pp) != 0) { if(getenv("OM_DEBUG")) fprintf(stderr, "  dup\n"); continue; }
+			pos_pair_t up = { .apos = self->r[0].len - st.tp.apos, .bpos = self->q[0].len - st.tp.bpos };
+			f = mm_extend_core(self, (int)st.narrow, &self->r[1], &self->t[0], &self->q[1 - st.rev], &self->t[0], up);
+			og_alignment_t *a = NULL;
+			if(getenv("OM_DEBUG")) fprintf(stderr, "  up max %ld (from %u,%u)\n", f->max, up.apos, up.bpos);
+			if(f->max < (int64_t)self->min_score || (a = og_dp_trace(self->dp, f)) == NULL) { continue; }
+			self->cnt[4]++;
+			if(mm_search_record(self, &st, a)) { break; }
+		}
+		if(getenv("OM_DEBUG")) fprintf(stderr, "  finish: n_aln %u score %d min_score %u\n", bin_at(self, st.iid)->n_aln, OFS(self->root.a[st.eid].plen), self->min_score);
+		if(mm_finish_root(self, &st)) { break; }
+	}
+	return self->n_res;
+}
+
+/* ---- post-map (minialign.c:4175-4398) ---- */
+#define MAPQ_DEC    4
+#define MAPQ_COEF   ( 1 << MAPQ_DEC )
+#define CLIP(x)     MAX2(0, MIN2((uint32_t)d2u32(x), 60 * MAPQ_COEF))
+/* mm_prune_regs, minialign.c:4185-4208 */
+static uint64_t mm_prune_regs(om_align_t *self)
+{
+	root_t *res = self->root.a;
+	uint64_t q = self->n_res;
+	uint32_t min = (uint32_t)OFS(f2u32((float)OFS(res[0].plen) * self->min_ratio));
+	while(res[--q].plen > min) { }
+	self->n_res = (uint32_t)(q + 1);
+	return q + 1;
+}
+/* mm_collect_supp, minialign.c:4214-4264 */
+static uint64_t mm_collect_supp(om_align_t *self, uint32_t n_res, root_t *res)
+{
+	#define SWAP_RES(x, y)  { root_t _tmp = res[x]; res[x] = res[y]; res[y] = _tmp; }
+	uint64_t p, q;
+	for(p = 1, q = n_res; p < q; p++) {
+		uint64_t max = 0;
+		for(uint64_t i = p; i < q; i++) {
+			bin_hdr_t *s = bin_at(self, res[i].lid);
+			int64_t lb = s->lb, ub = s->ub, span = ub - lb;
+			int covered = 0;
+			for(uint64_t j = 0; j < p; j++) {
+				bin_hdr_t *t = bin_at(self, res[j].lid);
+				if((int64_t)t->ub < ub) { lb = MAX2(lb, (int64_t)t->ub); } else { ub = MIN2(ub, (int64_t)t->lb); }
+				if(1.2 * (double)(ub - lb) < (double)span) { q--; SWAP_RES(i, q); i--; covered = 1; break; }
+			}
+			if(covered) { continue; }
+			max = MAX2(max, ((uint64_t)(2 * (ub - lb) - span) << 32) | i);
+		}
+		if(max & 0xffffffff) { SWAP_RES(p, max & 0xffffffff); }
+	}
+	p = MIN2(p, q);
+	#undef SWAP_RES
+	return p;
+}
+/* mm_post_map, minialign.c:4270-4326 */
+static uint64_t mm_post_map(om_align_t *self)
+{
+	root_t *res = self->root.a;
+	uint64_t p = mm_collect_supp(self, self->n_res, res);
+	int64_t usc = 0, lsc = INT64_MAX, tsc = 0;
+	for(uint64_t i = p; i < self->n_res; i++) {
+		usc = MAX2(usc, (int64_t)OFS(res[i].plen));
+		lsc = MIN2(lsc, (int64_t)OFS(res[i].plen));
+		tsc += OFS(res[i].plen);
+	}
+	lsc = (lsc == INT32_MAX) ? 0 : lsc;          /* QUIRK: compares an INT64_MAX-initialised value with INT32_MAX */
+	double tpc = 1.0, x = self->xcoef, mx = self->mcoef + self->xcoef;
+	for(uint64_t i = 0; i < p; i++) {
+		uint32_t score = (uint32_t)OFS(res[i].plen);
+		bin_hdr_t *bin = bin_at(self, res[i].lid);
+		double pid = 0.0; uint64_t len = 0;
+		for(uint64_t j = 0; j < bin->n_aln; j++) {
+			og_alignment_t *al = aln_of(self, res[i].lid + BIN_N + j);
+			len += al->plen; pid += (double)al->plen * al->identity;
+		}
+		pid /= (double)len;
+		double ec = 2.0 / (pid * mx - x);
+		double ulen = ec * (double)MAX2((int64_t)score - usc, 0), pe = 1.0 / (ulen * ulen + 1);
+		bin->plen = CLIP(-10.0 * MAPQ_COEF * log10(pe));
+		tpc *= 1.0 - pe;
+	}
+	double tpe = MIN2(1.0 - tpc, 1.0);
+	for(uint64_t i = p; i < self->n_res; i++) {
+		bin_hdr_t *bin = bin_at(self, res[i].lid);
+		bin->plen = CLIP(-10.0 * MAPQ_COEF * log10(1.0 - tpe * (double)(int64_t)((int64_t)res[i].plen - lsc + 1) / (double)tsc));
+	}
+	return p;
+}
+
+static void tbuf_clear(om_align_t *self)
+{
+	self->resc.n = 0; self->presc = 0; self->seed.n = 0; self->n_seed = 0; self->root.n = 0; self->next.n = 0;
+	self->n_res = 0; self->bin.n = 0; self->alns.n = 0;
+	kh_clear(&self->pos);
+}
+
+/* mm_align_seq, minialign.c:4427-4474 */
+om_reg_t *om_align_seq(om_align_t *self, uint32_t l_seq, uint8_t const *seq)
+{
+	if(l_seq < self->mi->k || l_seq * self->mcoef < (double)self->min_score) { return NULL; }
+	tbuf_clear(self);
+	init_query(self, l_seq, seq);
+	for(uint64_t i = 0; i < self->mi->n_occ; i++) {
+		if(mm_seed(self, i) == 0) { continue; }
+		if(mm_chain(self) == 0) { continue; }
+		if(mm_extend(self) > 0) { break; }
+	}
+	if(self->n_res == 0) {
+		for(uint64_t i = 0; i < self->alns.n; i++) { og_aln_free(self->alns.a[i]); }
+		return NULL;
+	}
+	radix_sort_64x((v2u32_t *)self->root.a, self->n_res);
+	uint32_t n_all = (uint32_t)mm_prune_regs(self);
+	uint32_t n_uniq = (uint32_t)mm_post_map(self);
+	/* mm_pack_reg, minialign.c:4364-4397 */
+	om_reg_t *reg = (om_reg_t *)calloc(1, sizeof(om_reg_t));
+	reg->aln = (om_aln_t *)calloc(self->bin.n + 1, sizeof(om_aln_t));
+	uint8_t *used = (uint8_t *)calloc(self->alns.n + 1, 1);
+	uint32_t np = 0;
+	root_t *res = self->root.a;
+	for(uint64_t i = 0; i < n_all; i++) {
+		bin_hdr_t *bin = bin_at(self, res[i].lid);
+		for(uint64_t j = 0; j < bin->n_aln; j++) {
+			uint64_t h = self->bin.a[res[i].lid + BIN_N + j];
+			reg->aln[np].aid = (uint32_t)i; reg->aln[np].mapq = bin->plen; reg->aln[np].a = self->alns.a[h - 1];
+			used[h - 1] = 1; np++;
+		}
+		if(i == n_uniq - 1) { reg->n_uniq = np; }
+	}
+	reg->n_all = np;
+	for(uint64_t i = 0; i < self->alns.n; i++) { if(!used[i]) { og_aln_free(self->alns.a[i]); } }
+	free(used);
+	return reg;
+}
+void om_reg_free(om_reg_t *r)
+{
+	if(!r) { return; }
+	for(uint32_t i = 0; i < r->n_all; i++) { og_aln_free(r->aln[i].a); }
+	free(r->aln); free(r);
+}
+
+/* stage taps */
+uint64_t om_stage_seed(om_align_t *self, uint32_t l_seq, uint8_t const *seq, uint64_t iter, om_seed_t const **seeds)
+{
+	tbuf_clear(self); init_query(self, l_seq, seq);
+	uint64_t n = 0;
+	for(uint64_t i = 0; i <= iter; i++) { n = mm_seed(self, i); }
+	*seeds = self->seed.a;
+	return n;
+}
+uint64_t om_stage_chain(om_align_t *self, uint64_t const **roots)
+{
+	uint64_t n = mm_chain(self);
+	*roots = (uint64_t const *)self->root.a;
+	return n;
+}
+
+/* ---- SAM (minialign.c:5096-5426), default tag set ---- */
+void om_sam_header(FILE *fp, om_opt_t const *o, om_seq_t const *ref, uint32_t n_ref)
+{
+	fputs("@HD\tVN:1.0\tSO:unsorted\n", fp);
+	for(uint32_t i = 0; i < n_ref; i++) { fprintf(fp, "@SQ\tSN:%.*s\tLN:%u\n", (int)ref[i].l_name, ref[i].name, ref[i].l_seq); }
+	fprintf(fp, "@PG\tID:minialign\tPN:minialign\tVN:%s\tCL:%s\n", "0.6.0-devel", o->arg_line ? o->arg_line : "");
+}
+static void put_seq(FILE *fp, uint8_t const *s, uint32_t n, int rev)
+{
+	for(uint32_t i = 0; i < n; i++) {
+		uint8_t c = rev ? s[n - 1 - i] : s[i];
+		fputc(rev ? "TGCAN\0\0\0\0\0\0\0\0\0\0\0"[c & 15] : "ACGTN\0\0\0\0\0\0\0\0\0\0\0"[c & 15], fp);    /* decaf / decar, minialign.c:231-232 */
+	}
+}
+/* mm_print_sam_mapped_core, minialign.c:5147-5198 */
+static void sam_core(FILE *fp, om_seq_t const *r, om_seq_t const *q, og_segment_t const *s, uint32_t const *path, uint32_t flag, uint32_t mapq)
+{
+	uint32_t rid = s->aid >> 1;
+	uint32_t rs = r[rid].l_seq - s->apos - s->alen;
+	uint32_t hl = q->l_seq - s->bpos - s->blen, tl = s->bpos;
+	uint32_t qs = (flag & 0x900) ? hl : 0;
+	uint32_t qe = q->l_seq - ((flag & 0x900) ? tl : 0);
+	fprintf(fp, "%.*s\t%u\t%.*s\t%u\t%u\t", (int)q->l_name, q->name, flag | ((~s->bid & 0x01) << 4), (int)r[rid].l_name, r[rid].name, rs + 1, mapq >> MAPQ_DEC);
+	if(hl) { fprintf(fp, "%u%c", hl, (flag & 0x900) ? 'H' : 'S'); }
+	uint64_t plen = (uint64_t)s->alen + s->blen;
+	char *buf = (char *)malloc(plen * 3 + 64);
+	og_dump_cigar_reverse(buf, plen * 3 + 64, path, s->ppos, plen);
+	fputs(buf, fp); free(buf);
+	if(tl) { fprintf(fp, "%u%c", tl, (flag & 0x900) ? 'H' : 'S'); }
+	fputs("\t*\t0\t0\t", fp);
+	if(s->bid & 0x01) { put_seq(fp, &q->seq[qs], qe - qs, 0); }
+	else { put_seq(fp, &q->seq[q->l_seq - qe], qe - qs, 1); }
+	fputc('\t', fp);
+	fputc('*', fp);          /* qualities are dropped unless -Q (minialign.c:5186, 5964) */
+}
+/* mm_print_sam_mapped, minialign.c:5390-5426 (+ mm_print_sam_unmapped :5127) */
+void om_sam_record(FILE *fp, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg)
+{
+	if(reg == NULL) {
+		fprintf(fp, "%.*s\t4\t*\t0\t0\t*\t*\t0\t0\t", (int)q->l_name, q->name);
+		put_seq(fp, q->seq, q->l_seq, 0);
+		fputs("\t*\n", fp);
+		return;
+	}
+	uint64_t n = reg->n_all;
+	uint32_t flag = 0;
+	for(uint64_t i = 0; i < n; i++) {
+		if(i >= reg->n_uniq) { flag = 0x100; }
+		om_aln_t const *a = &reg->aln[i];
+		for(uint64_t j = a->a->slen; j > 0; j--) {
+			sam_core(fp, ref, q, &a->a->seg[j - 1], a->a->path, flag, a->mapq);
+			if(i == 0 && j == a->a->slen) { flag = 0x800; }
+			fputc('\n', fp);
+		}
+		flag = 0x800;
+	}
+}
+
+/* ---- whole program ---- */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *out, char const *arg_line, double *map_seconds, uint64_t *bases)
+{
+	om_opt_t o;
+	if(om_opt_init(&o, preset)) { return 1; }
+	o.arg_line = arg_line;
+	om_seqs_t ref = om_read_fasta(ref_fn);
+	if(ref.n == 0) { return 2; }
+	om_idx_t *mi = om_idx_build(&o, ref.a, (uint32_t)ref.n);
+	om_align_t *al = om_align_init(&o, mi);
+	if(al == NULL) { return 3; }
+	om_seqs_t qs = om_read_fasta(query_fn);
+	om_sam_header(out, &o, ref.a, (uint32_t)ref.n);
+	double t0 = now_s(), tmap = 0; uint64_t nb = 0;
+	for(uint64_t i = 0; i < qs.n; i++) {
+		double t1 = now_s();
+		om_reg_t *reg = om_align_seq(al, qs.a[i].l_seq, qs.a[i].seq);
+		tmap += now_s() - t1; nb += qs.a[i].l_seq;
+		om_sam_record(out, ref.a, &qs.a[i], reg);
+		om_reg_free(reg);
+	}
+	(void)t0;
+	if(map_seconds) { *map_seconds = tmap; }
+	if(bases) { *bases = nb; }
+	om_align_free(al); om_idx_free(mi); om_seqs_free(&qs); om_seqs_free(&ref);
+	return 0;
+}
+
+/* test tap: same record as mm_ref_shim.c:mmref_align */
+uint32_t om_align_dump(om_align_t *self, uint8_t const *seq, uint32_t len, int64_t *out, uint32_t max)
+{
+	om_reg_t *reg = om_align_seq(self, len, seq);
+	if(reg == NULL) { return 0; }
+	uint32_t k = 0, n = reg->n_all;
+	for(uint32_t i = 0; i < reg->n_all && k + 12 <= max; i++) {
+		om_aln_t const *a = &reg->aln[i];
+		out[k++] = a->aid; out[k++] = a->mapq; out[k++] = a->a->score; out[k++] = a->a->plen; out[k++] = a->a->slen;
+		out[k++] = a->a->seg[0].aid; out[k++] = a->a->seg[0].bid; out[k++] = a->a->seg[0].apos; out[k++] = a->a->seg[0].bpos;
+		out[k++] = a->a->seg[0].alen; out[k++] = a->a->seg[0].blen; out[k++] = (int64_t)(i < reg->n_uniq);
+	}
+	om_reg_free(reg);
+	return n;
+}

@@ -1,0 +1,83 @@
+/*
+ * ora_mm.h -- TEST INFRASTRUCTURE.  CPU restatement (plain C) of the reference's mapper:
+ * minimizer sketch, index build + lookup, seed collection, array-based chaining, extension driver,
+ * post-map (prune / supplementary / MAPQ) and the SAM printer (/root/reference/minialign.c, ksort.h).
+ * Builds on ora_gaba.c for the DP.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may use it; the product never does.
+ *
+ * Parity status: PINNED -- byte-identical SAM against the compiled reference (oracle/_ref/minialign) on the
+ * seeded synthetic sets of tests/ (tests/test_oracle_mm.py), and against committed golden SAM in tests/golden/.
+ */
+#ifndef ORA_MM_H
+#define ORA_MM_H
+#include <stdint.h>
+#include <stdio.h>
+#include "ora_gaba.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+	/* indexing, minialign.c:6146-6149 */
+	uint32_t k, w, b, n_frq; float frq[16];
+	/* mapping, minialign.c:6151-6160 */
+	uint32_t wlen, glen, min_score; float min_ratio;
+	og_params_t p;
+	char const *arg_line;       /* @PG CL: text */
+} om_opt_t;
+
+/* defaults (minialign.c:6141-6162) followed by a preset string such as "pacbio" or "ont.1dsq" (minialign.c:5846-5900);
+ * returns nonzero on unknown preset */
+int om_opt_init(om_opt_t *o, char const *preset);
+
+typedef struct {
+	char *name; uint32_t l_name;
+	uint8_t *seq; uint32_t l_seq;       /* 0..4 per base, minialign.c:214-229 */
+	char *qual;                         /* NULL unless kept */
+} om_seq_t;
+typedef struct { om_seq_t *a; uint64_t n; } om_seqs_t;
+om_seqs_t om_read_fasta(char const *fn);        /* FASTA / FASTQ, plain text (bseq_read_fasta, minialign.c:1996) */
+void om_seqs_free(om_seqs_t *s);
+
+typedef struct om_idx_s om_idx_t;
+om_idx_t *om_idx_build(om_opt_t const *o, om_seq_t const *ref, uint32_t n_ref);     /* mm_idx_gen, minialign.c:2951 */
+void om_idx_free(om_idx_t *mi);
+uint32_t om_idx_occ(om_idx_t const *mi, uint32_t i);
+/* mm_idx_get, minialign.c:2728: returns the (pos, rid) list of a minimizer; values are u64 = pos | rid << 32 */
+uint64_t const *om_idx_get(om_idx_t const *mi, uint64_t minier, uint32_t *n);
+
+/* mm_sketch, minialign.c:2410: appends the minimizer words (cap excluded) to out (must hold 4 * len / w + 256); returns count */
+uint64_t om_sketch(uint32_t w, uint32_t k, uint8_t const *seq, uint32_t len, uint64_t *out);
+
+typedef struct om_align_s om_align_t;
+om_align_t *om_align_init(om_opt_t const *o, om_idx_t const *mi);       /* mm_align_init + mm_tbuf_init, minialign.c:4671, 4499 */
+void om_align_free(om_align_t *a);
+
+typedef struct {
+	uint32_t aid, mapq;                 /* mm_aln_t, minialign.c:3260 */
+	og_alignment_t *a;
+} om_aln_t;
+typedef struct {
+	uint32_t n_all, n_uniq;             /* mm_reg_t, minialign.c:3264 */
+	om_aln_t *aln;
+} om_reg_t;
+om_reg_t *om_align_seq(om_align_t *a, uint32_t l_seq, uint8_t const *seq);    /* mm_align_seq, minialign.c:4427; NULL = unmapped */
+void om_reg_free(om_reg_t *r);
+
+/* stage taps for the parity tests (valid after om_align_seq / om_stage_* on the same context) */
+typedef struct { uint32_t upos, rid, vpos, lid; } om_seed_t;
+uint64_t om_stage_seed(om_align_t *a, uint32_t l_seq, uint8_t const *seq, uint64_t iter, om_seed_t const **seeds);   /* mm_seed(i), minialign.c:3500 (i = 0..iter run in order) */
+uint64_t om_stage_chain(om_align_t *a, uint64_t const **roots);       /* mm_chain, minialign.c:3702; roots[i] = plen | lid << 32 */
+void om_counters(om_align_t const *a, uint64_t out[8]);               /* work counters: fills, vectors, ... */
+
+/* SAM (minialign.c:5096-5426); default tag set (none) */
+void om_sam_header(FILE *fp, om_opt_t const *o, om_seq_t const *ref, uint32_t n_ref);
+void om_sam_record(FILE *fp, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg);
+
+/* whole program: `minialign -x<preset> ref.fa reads.fa > out` (minialign.c:6365-6447) */
+int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *out, char const *arg_line, double *map_seconds, uint64_t *bases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,53 @@
+"""CPU tests (no GPU) for the mapper-level oracle (oracle/ora_mm.c): byte-identical SAM against the committed golden SAM of
+the compiled reference, per-stage vectors (sketch / sorted seeds / chain roots) against committed digests, and -- when
+oracle/_ref is present -- live comparison with the reference binary and its stage harness."""
+import gzip, hashlib, json, os, subprocess, tempfile
+import numpy as np, pytest
+import mmlib as M
+from golden.make_mm_golden import make_inputs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+META = json.load(open(os.path.join(HERE, 'golden', 'mm_golden.json')))
+
+@pytest.fixture(scope='module')
+def workdir():
+    with tempfile.TemporaryDirectory() as d:
+        yield d
+
+def _strip_pg(sam):
+    return b''.join(l for l in sam.splitlines(True) if not l.startswith(b'@PG'))
+
+@pytest.mark.parametrize('s', META['sets'], ids=[s['name'] for s in META['sets']])
+def test_oracle_sam_matches_golden(s, workdir):
+    ref, rd = make_inputs(s, workdir)
+    assert hashlib.md5(open(ref, 'rb').read()).hexdigest() == s['ref_md5'], 'generator stream changed'
+    assert hashlib.md5(open(rd, 'rb').read()).hexdigest() == s['reads_md5']
+    got = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign'), '-x' + s['preset'], ref, rd],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+    want = gzip.open(os.path.join(HERE, 'golden', s['name'] + '.sam.gz')).read()
+    assert hashlib.md5(want).hexdigest() == s['sam_md5']
+    assert got == want
+
+@pytest.mark.parametrize('s', META['sets'], ids=[s['name'] for s in META['sets']])
+def test_oracle_stages_match_golden(s, workdir):
+    ref, rd = make_inputs(s, workdir)
+    o = M.OracleMM(s['preset'], M.read_fasta(ref))
+    assert o.occ() == s['occ']
+    reads = dict(M.read_fasta(rd))
+    for st in s['stages']:
+        q = reads[st['read']]
+        sk = o.sketch(q)
+        assert len(sk) == st['sketch_n'] and [int(x) for x in sk[:8]] == st['sketch_head']
+        assert hashlib.md5(sk.tobytes()).hexdigest() == st['sketch_md5']
+        sd = o.seed(q)
+        assert len(sd) == st['seed_n'] and hashlib.md5(sd.tobytes()).hexdigest() == st['seed_md5']
+        assert [int(x) for x in o.chain()] == st['chain']
+
+@pytest.mark.skipif(not M.RefMM.available(), reason='oracle/_ref not built (needs /root/reference)')
+def test_oracle_vs_live_reference_multicontig(workdir):
+    """a fresh set with many contigs: exercises the rlen state carried across reads (minialign.c:3864)"""
+    s = dict(name='live_mc', preset='pacbio', genome=(201, 300000, 25, 0.05), reads=(202, 0.5, 'pacbio', 'fa', 3000, 1000))
+    ref, rd = make_inputs(s, workdir)
+    a = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', '_ref', 'minialign'), '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+    b = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign'), '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+    assert a == b

@@ -1,0 +1,126 @@
+/*
+ * gensim.c -- seeded synthetic data generator (repo's own): a reference genome with planted
+ * interspersed / tandem repeats and N runs, and PBSIM-CLR-like or ONT-like reads sampled from it.
+ * Own PRNG (xoshiro256** seeded by splitmix64) so that streams are identical on every box.
+ *
+ *   gensim genome <seed> <total_len> <n_contigs> <repeat_frac> > ref.fa
+ *   gensim reads  <seed> ref.fa <depth> <pacbio|ont> [fq] [len_mean len_sd] > reads.fa
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <math.h>
+
+static uint64_t s[4];
+static uint64_t splitmix(uint64_t *x) { uint64_t z = (*x += 0x9e3779b97f4a7c15ULL); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); }
+static void seed_rng(uint64_t sd) { for(int i = 0; i < 4; i++) s[i] = splitmix(&sd); }
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline uint64_t rnd(void) { uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; }
+static inline double unif(void) { return (double)(rnd() >> 11) * (1.0 / 9007199254740992.0); }
+static inline uint64_t below(uint64_t n) { return (uint64_t)(unif() * (double)n); }
+static double gauss(void) { double u = unif(), v = unif(); if(u < 1e-300) u = 1e-300; return sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v); }
+
+static void put_fasta(FILE *fp, char const *name, char const *seq, uint64_t len)
+{
+	fprintf(fp, ">%s\n", name);
+	for(uint64_t i = 0; i < len; i += 80) { fwrite(seq + i, 1, len - i < 80 ? len - i : 80, fp); fputc('\n', fp); }
+}
+
+static int main_genome(int argc, char **argv)
+{
+	if(argc < 6) return 1;
+	seed_rng(strtoull(argv[2], 0, 0));
+	uint64_t total = strtoull(argv[3], 0, 0); int nc = atoi(argv[4]); double rf = atof(argv[5]);
+	char *g = malloc(total + 1);
+	for(uint64_t i = 0; i < total; i++) g[i] = "ACGT"[rnd() >> 62];
+	/* contig boundaries: geometric-ish sizes */
+	uint64_t *cs = malloc(sizeof(uint64_t) * (nc + 1)); double *wts = malloc(sizeof(double) * nc), ws = 0;
+	for(int i = 0; i < nc; i++) { wts[i] = 0.2 + unif(); ws += wts[i]; }
+	cs[0] = 0; for(int i = 0; i < nc; i++) { cs[i + 1] = cs[i] + (uint64_t)(wts[i] / ws * total); } cs[nc] = total;
+	/* planted interspersed repeats: families of 300 bp .. 6 kb elements, copies at 80-99 % identity */
+	uint64_t planted = 0, target = (uint64_t)(rf * total);
+	while(planted < target) {
+		uint64_t el = 300 + below(5700); if(el * 4 > total) el = total / 8 + 1;
+		uint64_t src = below(total - el); int copies = 2 + (int)below(60);
+		for(int c = 0; c < copies && planted < target; c++) {
+			uint64_t dst = below(total - el); double id = 0.80 + 0.19 * unif();
+			for(uint64_t i = 0; i < el; i++) { char ch = g[src + i]; if(unif() > id) ch = "ACGT"[rnd() >> 62]; g[dst + i] = ch; }
+			planted += el;
+		}
+	}
+	/* tandem arrays */
+	for(int t = 0; t < (int)(rf * 200) + 1 && total > 10000; t++) {
+		uint64_t ul = 2 + below(60), n = 5 + below(80), pos = below(total - ul * n - 1);
+		for(uint64_t i = ul; i < ul * n; i++) g[pos + i] = g[pos + (i % ul)];
+	}
+	/* N runs */
+	for(int t = 0; t < (int)(total / 2000000) + 1 && total > 100000; t++) { uint64_t pos = below(total - 2000), l = 10 + below(500); memset(g + pos, 'N', l); }
+	for(int i = 0; i < nc; i++) { char name[64]; sprintf(name, "ctg%04d len=%lu", i, (unsigned long)(cs[i + 1] - cs[i])); put_fasta(stdout, name, g + cs[i], cs[i + 1] - cs[i]); }
+	return 0;
+}
+
+typedef struct { char *name; char *seq; uint64_t len; } ctg_t;
+static ctg_t *load_fasta(char const *fn, int *n)
+{
+	FILE *fp = fopen(fn, "r"); if(!fp) { perror(fn); exit(1); }
+	ctg_t *c = NULL; int nc = 0; size_t cap = 0; char *line = NULL; size_t lcap = 0; ssize_t l;
+	while((l = getline(&line, &lcap, fp)) > 0) {
+		while(l > 0 && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
+		if(line[0] == '>') { c = realloc(c, sizeof(ctg_t) * (nc + 1)); char *sp = strpbrk(line + 1, " \t"); if(sp) *sp = 0; c[nc].name = strdup(line + 1); c[nc].seq = NULL; c[nc].len = 0; cap = 0; nc++; }
+		else if(nc) { ctg_t *t = &c[nc - 1]; if(t->len + l + 1 > cap) { cap = (t->len + l + 1) * 2; t->seq = realloc(t->seq, cap); } memcpy(t->seq + t->len, line, l); t->len += l; }
+	}
+	fclose(fp); *n = nc; return c;
+}
+static char comp(char c) { switch(c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+
+static int main_reads(int argc, char **argv)
+{
+	if(argc < 6) return 1;
+	seed_rng(strtoull(argv[2], 0, 0));
+	int nc; ctg_t *c = load_fasta(argv[3], &nc);
+	double depth = atof(argv[4]); int ont = strcmp(argv[5], "ont") == 0; int fq = argc > 6 && strcmp(argv[6], "fq") == 0;
+	double lm = argc > 8 ? atof(argv[7]) : 20000.0, lsd = argc > 8 ? atof(argv[8]) : 2000.0;
+	uint64_t total = 0; for(int i = 0; i < nc; i++) total += c[i].len;
+	uint64_t want = (uint64_t)(depth * total), made = 0, id = 0;
+	char *buf = malloc(4 * 1000000 + 16), *qb = malloc(4 * 1000000 + 16);
+	while(made < want) {
+		double len_d; 
+		if(ont) { len_d = exp(log(8000.0) + 0.9 * gauss()); } else { len_d = lm + lsd * gauss(); }
+		if(len_d < 1000) len_d = 1000; if(len_d > 900000) len_d = 900000;
+		uint64_t len = (uint64_t)len_d;
+		/* pick a contig proportional to length */
+		uint64_t p = below(total); int ci = 0; while(p >= c[ci].len) { p -= c[ci].len; ci++; }
+		if(len > c[ci].len) len = c[ci].len;
+		if(p + len > c[ci].len) p = c[ci].len - len;
+		double acc = ont ? 0.90 + 0.05 * gauss() : 0.88 + 0.07 * gauss();
+		if(acc < 0.6) acc = 0.6; if(acc > 0.99) acc = 0.99;
+		double e = 1.0 - acc, ps, pi, pd;
+		if(ont) { ps = e * 0.4; pi = e * 0.2; pd = e * 0.4; } else { ps = e * 0.10; pi = e * 0.60; pd = e * 0.30; }
+		int rev = rnd() >> 63;
+		uint64_t n = 0;
+		for(uint64_t i = 0; i < len; i++) {
+			char ch = rev ? comp(c[ci].seq[p + len - 1 - i]) : c[ci].seq[p + i];
+			double x = unif();
+			double pdl = pd; if(ont && i > 0 && n > 0 && buf[n - 1] == ch) pdl = pd * 2.0;   /* homopolymer-biased deletions */
+			if(x < pdl) continue;
+			if(x < pdl + ps) { char m; do { m = "ACGT"[rnd() >> 62]; } while(m == ch); buf[n++] = m; }
+			else { buf[n++] = ch; }
+			while(unif() < pi && n < 3900000) { buf[n++] = "ACGT"[rnd() >> 62]; }
+		}
+		buf[n] = 0;
+		char name[128]; sprintf(name, "r%lu_%s_%lu_%lu_%c_%.3f", (unsigned long)id, c[ci].name, (unsigned long)p, (unsigned long)(p + len), rev ? '-' : '+', acc);
+		if(fq) { for(uint64_t i = 0; i < n; i++) qb[i] = (char)('!' + 5 + below(20)); qb[n] = 0; printf("@%s\n%s\n+\n%s\n", name, buf, qb); }
+		else { printf(">%s\n%s\n", name, buf); }
+		made += n; id++;
+	}
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	if(argc > 1 && strcmp(argv[1], "genome") == 0) return main_genome(argc, argv);
+	if(argc > 1 && strcmp(argv[1], "reads") == 0) return main_reads(argc, argv);
+	fprintf(stderr, "usage: gensim genome <seed> <total_len> <n_contigs> <repeat_frac> | gensim reads <seed> ref.fa <depth> <pacbio|ont> [fq|fa] [len_mean len_sd]\n");
+	return 1;
+}
