@@ -1,0 +1,79 @@
+/*
+ * include/minialign.h -- C-ABI of the MI355X-native mapper (libminialign_amd.so): the `mm_*` entry points.
+ *
+ * In the reference every mapper function is `static` inside minialign.c; the contract below exports the same
+ * call sequence main_align (minialign.c:6365-6447) performs, with the same names and argument meaning:
+ *
+ *   mm_opt_init / mm_opt_parse   <- mm_opt_init, mm_opt_parse_argv, presets   (minialign.c:6138, 5771, 5846)
+ *   mm_idx_gen / mm_idx_destroy  <- mm_idx_gen, mm_idx_destroy                 (minialign.c:2951, 2703)
+ *   mm_align_init / _destroy     <- mm_align_init, mm_align_destroy            (minialign.c:4671, 4650)
+ *   mm_align_file                <- mm_align_file + mm_print_sam_*             (minialign.c:4725, 5096-5426)
+ *   mm_main                      <- main                                       (minialign.c:6451)
+ *
+ * What runs where: sketch + index lookup + seed expansion, seed sort + chaining and the banded extension
+ * (fill / max search / traceback) run as HIP kernels on gfx950 (minialign_amd/csrc/mm_device.hpp,
+ * gaba_device.hpp); FASTA parsing, index construction, post-map (prune / supplementary / MAPQ) and SAM
+ * formatting are host C++.  No CPU fallback exists for the device stages: without a HIP device the calls
+ * fail (NULL / non-zero) and say so on stderr.
+ */
+#ifndef MINIALIGN_AMD_MINIALIGN_H
+#define MINIALIGN_AMD_MINIALIGN_H
+#include <stdint.h>
+#include <stdio.h>
+#include "gaba.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mm_opt_s mm_opt_t;
+typedef struct mm_idx_s mm_idx_t;
+typedef struct mm_align_s mm_align_t;
+
+/* options: defaults of minialign.c:6141-6162; mm_opt_parse applies "-x preset" strings and the single-letter
+ * options used by the benchmark command lines (-k -w -a -b -p -q -r -Y -s -m -t). Returns 0 on success. */
+mm_opt_t *mm_opt_init(void);
+int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char const **files, int max_files, int *n_files);
+void mm_opt_destroy(mm_opt_t *o);
+
+/* index over a FASTA file (host build; value-list order and occurrence thresholds as the reference) */
+mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta);
+void mm_idx_destroy(mm_idx_t *mi);
+uint32_t mm_idx_n_seq(mm_idx_t const *mi);
+uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i);
+/* mm_idx_get (minialign.c:2728) on the host copy: writes up to max values (pos | rid << 32), returns the count */
+uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t max);
+
+/* device context: uploads the reference (2-bit + N mask) and the flattened index, builds the DP constants */
+mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi);
+void mm_align_destroy(mm_align_t *a);
+/* maps every read of a FASTA / FASTQ file and prints SAM records (no header) to `out`; returns 0 on success */
+int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out);
+void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line);
+
+/* in-memory batch entry (used by bench.py and the parity tests): reads are given as one byte per base (0..4),
+ * concatenated, with per-read lengths; SAM text for the batch is appended to *sam (malloc'd / realloc'd by the
+ * library, free with free()).  names may be NULL (then "r<i>"). */
+int mm_align_batch(mm_align_t *a, uint8_t const *bases, uint32_t const *lens, char const *const *names, uint32_t n_reads,
+	char **sam, uint64_t *sam_len);
+
+/* stage taps for the parity tests: run the device sketch / seed / chain stages for ONE read and copy the results */
+uint64_t mm_stage_sketch(mm_align_t *a, uint8_t const *seq, uint32_t len, uint64_t *qpos_n_ref, uint64_t max);   /* per minimizer: qs | n << 32 */
+uint64_t mm_stage_seed_chain(mm_align_t *a, uint8_t const *seq, uint32_t len, uint32_t rounds, uint32_t *seeds, uint64_t max_seeds,
+	uint64_t *roots, uint64_t max_roots, uint64_t *n_roots);
+
+/* timing / work counters of everything run since the last reset */
+typedef struct {
+	double k1_ms, k2_ms, k3_ms;             /* summed kernel times (HIP events on the launch stream) */
+	uint64_t k1_launches, k2_launches, k3_launches;
+	uint64_t reads, bases, minimizers, seeds, fills, vectors, blocks, traces, trace_steps, reruns;
+	double host_post_ms, host_sam_ms, wall_ms;
+} mm_stats_t;
+void mm_stats(mm_align_t *a, mm_stats_t *out, int reset);
+
+/* the command-line program: `minialign [-x preset] [opts] ref.fa reads.{fa,fq} > out.sam` */
+int mm_main(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -16,21 +16,7 @@
 
 using namespace gaba;
 
-#define HIP_OK(_e, _ret) do { hipError_t _r = (_e); if(_r != hipSuccess) { \
-	fprintf(stderr, "[minialign_amd] HIP error %s at %s:%d\n", hipGetErrorString(_r), __FILE__, __LINE__); return _ret; } } while(0)
-
-struct gaba_arena_s { uint32_t *pk, *nm; uint64_t n; };
-
-struct gaba_context_s {
-	Consts hc;
-	Consts *dc;
-	uint8_t *droots;              /* 3 x (Blk + Tail) */
-	uint8_t *slabs; uint64_t slab_bytes; uint32_t n_waves;
-	uint32_t *counter; uint64_t *dstats;
-	hipStream_t stream;
-	hipEvent_t ev0, ev1;
-	gaba_batch_stats_t last;
-};
+#include "gaba_host.hpp"
 
 struct DevJob { Sec a, b; uint32_t apos, bpos, bw_idx, do_trace; };
 

@@ -847,16 +847,20 @@ struct AlnOut {              /* what gaba_alignment_s carries (gaba.h:205-220) *
  * gaba_dp_trace (gaba.c:3372) -> trace_body (gaba.c:3299).  path: (plen + 31) / 32 + 2 words (zeroed here);
  * seg: written in root-first order like aln->seg[]; max_seg bounds the array.
  */
-__device__ __forceinline__ AlnOut dp_trace(Ctx &x, uint32_t tail_off, uint32_t *path, uint64_t path_cap_words, Segment *seg, uint32_t max_seg)
+/* phase 1: locate the max cell, return the path length (0 when the fill never left the init-fetch state) */
+__device__ __forceinline__ uint64_t dp_trace_begin(Ctx &x, uint32_t tail_off, Leaf &lf)
+{
+	const Tail *tail = tail_at(x, tail_off);
+	int64_t fbpos = (int64_t)rdfirst64(tail->f.bpos);
+	return fbpos < INIT_FETCH_POS ? 0 : leaf_search(x, tail_off, lf);
+}
+/* phase 2: walk back; path must hold (plen + 31) / 32 + 2 words */
+__device__ __forceinline__ AlnOut dp_trace_finish(Ctx &x, uint32_t tail_off, Leaf &lf, uint64_t plen, uint32_t *path, Segment *seg, uint32_t max_seg)
 {
 	const Consts &c = *x.c;
 	const Tail *tail = tail_at(x, tail_off);
-	Leaf lf;
 	AlnOut out; out.status = 1;
-	int64_t fbpos = (int64_t)rdfirst64(tail->f.bpos);
-	uint64_t plen = fbpos < INIT_FETCH_POS ? 0 : leaf_search(x, tail_off, lf);
 	uint64_t pn = (plen + 31) / 32 + 2;
-	if(pn > path_cap_words) { x.err = 2; out.status = -2; out.plen = (uint32_t)plen; return out; }
 	for(uint64_t i = (uint64_t)x.lane; i < pn; i += 64) { path[i] = 0; }
 	lf.tl[0] = tail_off; lf.tl[1] = tail_off;
 	lf.icnt[0] = lf.icnt[1] = lf.ecnt[0] = lf.ecnt[1] = lf.fcnt[0] = lf.fcnt[1] = 0;
@@ -902,6 +906,14 @@ __device__ __forceinline__ AlnOut dp_trace(Ctx &x, uint32_t tail_off, uint32_t *
 	out.agcnt = (uint32_t)gcnt0; out.bgcnt = (uint32_t)gcnt1; out.dcnt = (uint32_t)dlen;
 	out.slen = slen; out.plen = (uint32_t)plen;
 	return out;
+}
+
+__device__ __forceinline__ AlnOut dp_trace(Ctx &x, uint32_t tail_off, uint32_t *path, uint64_t path_cap_words, Segment *seg, uint32_t max_seg)
+{
+	Leaf lf;
+	uint64_t plen = dp_trace_begin(x, tail_off, lf);
+	if((plen + 31) / 32 + 2 > path_cap_words) { x.err = 2; AlnOut o; o.status = -2; o.plen = (uint32_t)plen; return o; }
+	return dp_trace_finish(x, tail_off, lf, plen, path, seg, max_seg);
 }
 
 /* gaba_dp_flush (gaba.c:3969): reset the bump pointer behind the root blocks */

@@ -1,0 +1,848 @@
+/*
+ * mm_device.hpp -- CDNA4 (gfx950) kernels for the seed-and-extend mapper hot path.
+ *
+ *   K1  mm_sketch_seed_kernel   one wavefront per read: lanes = k-mer positions over 2-bit packed sequence;
+ *                               sliding-window minimum by lane shuffles; ordered compaction by ballot;
+ *                               index probe (open-addressing table in HBM); seed expansion.
+ *                               (reference behaviour: mm_sketch minialign.c:2410, mm_idx_get :2728,
+ *                               mm_collect_seed :3454, mm_expand :3420)
+ *   K2  mm_sort_chain_kernel    one lane per read: the reference's in-place MSD radix / insertion sort
+ *                               reproduced step by step (ksort.h:84-131 -- its *unstable* permutation is part of
+ *                               the observable result), then greedy window chaining (mm_chain_seeds :3547) and
+ *                               the chain-length sort.
+ *   K3  mm_extend_kernel        one wavefront per read: the extension state machine (mm_extend :4118 and
+ *                               mm_search_* :3785-4067) driving the banded DP of gaba_device.hpp, with the
+ *                               per-read position hash (kh_t :341-683) kept literally, slot for slot.
+ *
+ * Host code (mm_host.hip) owns parsing, index construction, post-map / MAPQ and SAM.
+ */
+#pragma once
+#include "gaba_device.hpp"
+
+namespace mm {
+
+using gaba::rdfirst; using gaba::rdfirst64; using gaba::rdlane; using gaba::lane_id;
+
+/* ---- index in HBM: one open-addressing table keyed by the minimizer value ---- */
+struct IdxSlot { uint64_t key; uint64_t val; };      /* key = minimizer + 1 (0 = empty); val: bit 63 clear -> single hit (pos | rid << 32),
+                                                       set -> (offset << 24 | count) into the value array */
+struct DevIndex {
+	const IdxSlot *slot; uint64_t mask;                /* table size - 1 */
+	const uint64_t *val;                               /* multi-hit lists: pos | rid << 32, in the reference's list order */
+	const uint32_t *seq_len;                           /* per reference sequence */
+	const uint64_t *seq_off;                           /* first base of each reference sequence in the a-side arena */
+	uint32_t n_seq, k, w, n_occ;
+	uint32_t occ[4];
+};
+__device__ __forceinline__ uint64_t idx_hash(uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; }
+
+/* ---- per-read records ---- */
+struct ReadIn {
+	uint64_t q_off;            /* first base in the b-side arena */
+	uint32_t qlen;
+	uint32_t rlen_in;          /* reference-length state carried in from the previous read (minialign.c:3864 reads it before mm_init_ref) */
+};
+struct MinRec { uint32_t qs, n; uint64_t ref; };      /* one looked-up minimizer: query pos (strand folded), #hits, inline hit or list offset */
+struct Seed { uint32_t upos, rid, vpos, lid; };       /* mm_seed_t, minialign.c:3187 (leaf view: rsid, rid, lsid, cid -- :3190) */
+struct Root { uint32_t plen, lid; };                  /* mm_root_t :3202, aliased by mm_res_t { score, iid } :3232 */
+struct Resc { uint32_t qs, n; uint64_t ref; };        /* mm_resc_t :3176 */
+
+struct ReadState {
+	/* regions (element offsets into the shared pools) */
+	uint64_t min_off; uint32_t min_cap, n_min;        /* MinRec pool */
+	uint64_t seed_off; uint32_t seed_cap;             /* Seed pool: seeds, sentinel, leaves */
+	uint32_t seed_n, n_seed;                          /* seed.n, self->n_seed */
+	uint64_t resc_off; uint32_t n_resc, presc;        /* Resc pool */
+	uint64_t root_off; uint32_t root_cap, n_root;     /* Root pool (also the result array) */
+	uint32_t n_res;
+	uint32_t rlen;                                    /* self->rlen carried across chains / rounds / reads */
+	uint32_t rid_last;                                /* last reference loaded by mm_init_ref, NIL if none */
+	uint32_t apos0, cond0;                            /* first mm_search_load_pos of the read: unadjusted apos and (bpos >= qlen) */
+	uint32_t pred_rid;                                /* after chaining: reference of the last chain passing the length test */
+	uint32_t done;                                    /* 1: finished (mapped or exhausted rounds) */
+	uint32_t err;                                     /* sticky error flags */
+	uint32_t kh_mask, kh_cnt, kh_ub, _pad0;            /* kh_t state of the per-read position hash (persists across rounds) */
+	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
+	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
+};
+enum : uint32_t { ERR_SEED_CAP = 1, ERR_DP_SLAB = 2, ERR_PATH_CAP = 4, ERR_SEG_CAP = 8, ERR_KH_CAP = 16, ERR_BIN_CAP = 32, ERR_ALN_CAP = 64, ERR_NEXT_CAP = 128, ERR_STACK = 256 };
+
+/* coordinate transforms, minialign.c:3340-3362 */
+__device__ __forceinline__ int32_t OFS(int32_t x) { return (int32_t)0x40000000 - x; }
+__device__ __forceinline__ uint32_t U_(int32_t x, int32_t y) { return (uint32_t)(((x << 1) - y) + OFS(0)); }
+__device__ __forceinline__ uint32_t V_(int32_t x, int32_t y) { return (uint32_t)(((y << 1) - x) + OFS(0)); }
+__device__ __forceinline__ int32_t AS(const Seed &p) { return (int32_t)(((p.upos - (uint32_t)OFS(0)) << 1) + (p.vpos - (uint32_t)OFS(0))) / 3; }
+__device__ __forceinline__ int32_t BS(const Seed &p) { return (int32_t)(((p.vpos - (uint32_t)OFS(0)) << 1) + (p.upos - (uint32_t)OFS(0))) / 3; }
+
+/* =====================================================================================================
+ * K1: sketch + lookup + expand
+ * ===================================================================================================== */
+__device__ __forceinline__ uint32_t crc32c_u64(uint32_t crc, uint64_t v)        /* _mm_crc32_u64; only reached for k > 16 */
+{
+	for(int i = 0; i < 64; i++) { uint32_t b = (crc ^ (uint32_t)(v >> i)) & 1u; crc = (crc >> 1) ^ (b ? 0x82f63b78u : 0u); }
+	return crc;
+}
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d)
+{
+	return ((uint64_t)(uint32_t)__shfl_up((int)(v >> 32), d) << 32) | (uint32_t)__shfl_up((int)v, d);
+}
+
+struct K1Args {
+	DevIndex idx; gaba::SeqArena qar;
+	const ReadIn *in; ReadState *st; uint32_t n_reads;
+	MinRec *min_pool;
+	Seed *seed_pool; uint64_t seed_pool_cap; unsigned long long *seed_top;
+	Resc *resc_pool; uint64_t resc_pool_cap; unsigned long long *resc_top;
+	Root *root_pool; uint64_t root_pool_cap; unsigned long long *root_top;
+	uint32_t *counter;
+	unsigned long long *stats;     /* [0] minimizers probed, [1] seeds */
+	const uint32_t *work;          /* read indices to process (n_reads entries) */
+};
+
+/* code (0..3, 4 = N) of base p of the read */
+__device__ __forceinline__ uint32_t q_code(const gaba::SeqArena &ar, uint64_t p)
+{
+	uint32_t c = (ar.pk[p >> 4] >> (2 * (p & 15))) & 3;
+	uint32_t n = (ar.nm[p >> 5] >> (p & 31)) & 1;
+	return n ? 4 : c;
+}
+
+__global__ void __launch_bounds__(256) mm_sketch_seed_kernel(K1Args a)
+{
+	const int lane = lane_id();
+	const DevIndex &ix = a.idx;
+	const uint32_t k = ix.k, w = ix.w;
+	const uint64_t kmask = (1ull << 2 * k) - 1;
+	const uint32_t max_occ = ix.occ[ix.n_occ - 1], resc_occ = ix.occ[0];
+	unsigned long long n_probe = 0, n_seedtot = 0;
+	while(true) {
+		uint32_t r = 0;
+		if(lane == 0) { r = atomicAdd(a.counter, 1u); }
+		r = (uint32_t)rdfirst((int)r);
+		if(r >= a.n_reads) { break; }
+		r = (uint32_t)rdfirst((int)a.work[r]);
+		ReadState *st = &a.st[r];
+		const uint64_t q_off = rdfirst64(a.in[r].q_off);
+		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
+		MinRec *rec = a.min_pool + rdfirst64(st->min_off);
+		const uint32_t min_cap = (uint32_t)rdfirst((int)st->min_cap);
+		uint32_t n_rec = 0;            /* uniform */
+		uint32_t n_seed = 0, n_resc = 0, n_resc_hits = 0;
+
+		/* pass 1: minimizers in order, probe the index, keep (qs, n, ref) records */
+		uint64_t h_prev = ~0ull;       /* h of the previous 64 positions (lane i = position base - 64 + i) */
+		uint64_t v_last = 0;           /* v of the last position of the previous chunk: u of the reference, initial cap value 0 (minialign.c:2412) */
+		for(uint32_t base = 0; base < qlen; base += 64) {
+			uint32_t p = base + (uint32_t)lane;
+			uint64_t h = ~0ull;
+			if(p >= k - 1 && p < qlen) {
+				/* forward / reverse k-mers ending at p.  N is pushed as 4 (minialign.c:2391-2392): it ORs into the neighbouring
+				 * 2-bit slots, and k1 is never masked, so the recurrence is replayed over the k + 1 bases that can still
+				 * influence the registers at p (one base before the window leaves one bit behind in k1) */
+				uint64_t k0 = 0, k1 = 0;
+				uint32_t start = p >= k ? p - k : 0;
+				for(uint32_t j = start; j <= p; j++) {
+					uint64_t c = q_code(a.qar, q_off + j);
+					k0 = (k0 << 2 | c) & kmask;
+					k1 = (k1 >> 2) | ((3ull ^ c) << (2 * (k - 1)));
+				}
+				uint64_t km = k0 < k1 ? k0 : k1, kx = k0 < k1 ? k1 : k0, m = k0 < k1 ? 0 : 0x80;
+				/* hash64 (minialign.c:2353): a CRC32C seeded with the low word of its own input is zero unless the high word is set */
+				uint64_t crc = (kx >> 32) ? (uint64_t)crc32c_u64((uint32_t)kx, kx) : 0ull;
+				uint64_t hv = (crc ^ km) & kmask;
+				uint32_t i = (p - (k - 1)) % w;
+				h = hv << 8 | i | m;
+			}
+			/* window minimum over the last w positions (forward-min of the current block + backward-min of the previous one,
+			 * minialign.c:2394-2421, is the minimum over [p - w + 1, p]) */
+			uint64_t v = h;
+			for(uint32_t j = 1; j < w; j++) {
+				int src_lane = lane - (int)j;
+				uint64_t from_cur = ((uint64_t)(uint32_t)__shfl((int)(h >> 32), src_lane & 63) << 32) | (uint32_t)__shfl((int)h, src_lane & 63);
+				uint64_t from_prev = ((uint64_t)(uint32_t)__shfl((int)(h_prev >> 32), src_lane & 63) << 32) | (uint32_t)__shfl((int)h_prev, src_lane & 63);
+				uint64_t src = src_lane >= 0 ? from_cur : from_prev;
+				v = src < v ? src : v;
+			}
+			uint64_t vp = shfl_up64(v, 1);
+			uint64_t v63 = ((uint64_t)(uint32_t)rdlane((int)(v >> 32), 63) << 32) | (uint32_t)rdlane((int)v, 63);
+			if(lane == 0) { vp = v_last; }
+			if(p == k - 1) { vp = 0; }                       /* u of the first evaluated position is the initial cap value 0 (minialign.c:2412) */
+			bool valid = p >= k - 1 && p < qlen;
+			bool emit = valid && ((v == h) || (v != vp));
+			/* last valid lane's v feeds the next chunk */
+			v_last = v63;
+			h_prev = h;
+			uint64_t em = __ballot(emit);
+			uint32_t my = (uint32_t)__popcll(em & ((1ull << lane) - 1));
+			if(emit) {
+				uint32_t iv = (uint32_t)(v & 0x7f), ip = (p - (k - 1)) % w;
+				uint32_t qpos = (p - (k - 1)) - ((ip + w - iv) % w);          /* = base + u of the reference's decoder (minialign.c:3471-3475) */
+				uint64_t fr = (v >> 7) & 1, hh = v >> 8;
+				/* mm_idx_get: probe */
+				uint64_t s = idx_hash(hh) & ix.mask; uint32_t n = 0; uint64_t ref = 0;
+				while(true) {
+					IdxSlot sl = ix.slot[s];
+					if(sl.key == 0) { break; }
+					if(sl.key == hh + 1) { if((int64_t)sl.val >= 0) { n = 1; ref = sl.val; } else { n = (uint32_t)(sl.val & 0xffffff); ref = sl.val; } break; }
+					s = (s + 1) & ix.mask;
+				}
+				uint32_t pos = (uint32_t)((qpos + (k & (uint32_t)-(int32_t)fr)) ^ (uint32_t)-(int32_t)fr);   /* minialign.c:3482 */
+				uint32_t slot_i = n_rec + my;
+				if(slot_i < min_cap) { rec[slot_i] = MinRec{ pos, n > max_occ ? 0u : n, ref }; }
+			}
+			n_rec += (uint32_t)__popcll(em);
+			n_probe += (unsigned long long)__popcll(em);
+		}
+		if(n_rec > min_cap) { n_rec = min_cap; if(lane == 0) { st->err |= ERR_SEED_CAP; } }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		/* totals */
+		for(uint32_t i = (uint32_t)lane; i < n_rec + 63 - ((n_rec + 63) % 64); i += 64) {
+			uint32_t n = i < n_rec ? rec[i].n : 0;
+			uint32_t s_ = (n != 0 && n <= resc_occ) ? n : 0, rr = n > resc_occ ? 1u : 0u, rh = n > resc_occ ? n : 0;
+			for(int o = 32; o > 0; o >>= 1) { s_ += (uint32_t)__shfl_xor((int)s_, o); rr += (uint32_t)__shfl_xor((int)rr, o); rh += (uint32_t)__shfl_xor((int)rh, o); }
+			n_seed += s_; n_resc += rr; n_resc_hits += rh;
+		}
+		n_seed = (uint32_t)rdfirst((int)n_seed); n_resc = (uint32_t)rdfirst((int)n_resc); n_resc_hits = (uint32_t)rdfirst((int)n_resc_hits);
+		/* claim space: seeds + sentinel + leaves, doubled as the reference reserves (minialign.c:3709) */
+		uint32_t seed_cap = 2 * (n_seed + n_resc_hits + 2);
+		uint32_t root_cap = n_seed + n_resc_hits + 2;
+		unsigned long long so = 0, ro = 0, to = 0;
+		if(lane == 0) { so = atomicAdd(a.seed_top, (unsigned long long)seed_cap); ro = atomicAdd(a.resc_top, (unsigned long long)n_resc + 1); to = atomicAdd(a.root_top, (unsigned long long)root_cap); }
+		so = rdfirst64(so); ro = rdfirst64(ro); to = rdfirst64(to);
+		bool ok = so + seed_cap <= a.seed_pool_cap && ro + n_resc + 1 <= a.resc_pool_cap && to + root_cap <= a.root_pool_cap;
+		if(!ok) { if(lane == 0) { st->err |= ERR_SEED_CAP; st->done = 1; st->seed_n = 0; st->n_seed = 0; st->n_resc = 0; } continue; }
+		Seed *seed = a.seed_pool + so; Resc *resc = a.resc_pool + ro;
+		/* pass 2: expand in order (mm_expand, minialign.c:3420-3447) */
+		uint32_t sp = 0, rp = 0;
+		for(uint32_t base = 0; base < n_rec; base += 64) {
+			uint32_t i = base + (uint32_t)lane;
+			MinRec m = i < n_rec ? rec[i] : MinRec{ 0, 0, 0 };
+			uint32_t ns = (m.n != 0 && m.n <= resc_occ) ? m.n : 0, nr = m.n > resc_occ ? 1u : 0u;
+			/* exclusive prefix sums across the wave */
+			uint32_t ps = ns, pr = nr;
+			for(int o = 1; o < 64; o <<= 1) { uint32_t x = (uint32_t)__shfl_up((int)ps, o), y = (uint32_t)__shfl_up((int)pr, o); if(lane >= o) { ps += x; pr += y; } }
+			uint32_t tot_s = (uint32_t)rdlane((int)ps, 63), tot_r = (uint32_t)rdlane((int)pr, 63);
+			ps -= ns; pr -= nr;
+			if(nr) { resc[rp + pr] = Resc{ m.qs, m.n, m.ref }; }
+			for(uint32_t j = 0; j < ns; j++) {
+				uint64_t hit = (int64_t)m.ref >= 0 ? m.ref : ix.val[((m.ref & 0x7fffffffffffffffull) >> 24) + j];
+				uint32_t rid = (uint32_t)(hit >> 32), rs = (uint32_t)hit;
+				uint32_t rmask = (uint32_t)-(int32_t)(rid & 1);
+				int32_t _rs = (int32_t)(rs + (k & rmask)), _qs = (int32_t)(m.qs ^ rmask);
+				seed[sp + ps + j] = Seed{ U_(_rs, _qs), rid >> 1, V_(_rs, _qs), 0x7fffffffu };
+			}
+			sp += tot_s; rp += tot_r;
+		}
+		n_seedtot += n_seed;
+		if(lane == 0) {
+			st->n_min = n_rec;
+			st->seed_off = so; st->seed_cap = seed_cap; st->seed_n = n_seed; st->n_seed = 0;
+			st->resc_off = ro; st->n_resc = n_resc; st->presc = 0;
+			st->root_off = to; st->root_cap = root_cap; st->n_root = 0; st->n_res = 0;
+		}
+	}
+	if(lane == 0) { atomicAdd(&a.stats[0], n_probe); atomicAdd(&a.stats[1], n_seedtot); }
+}
+
+/* =====================================================================================================
+ * K2: seed sort + chaining, one lane per read (serial by nature; 64 reads per wavefront)
+ * ===================================================================================================== */
+struct K2Args {
+	DevIndex idx;
+	ReadState *st; const uint32_t *work; uint32_t n_work;     /* indices of the reads taking part in this round */
+	uint32_t round;
+	Seed *seed_pool; Resc *resc_pool; Root *root_pool;
+	uint32_t *rs_scratch; uint32_t rs_stride;                 /* per-lane scratch: 512 bucket words + range stack */
+	uint32_t twlen; double mcoef; uint32_t min_score;
+};
+
+/* ---- ksort.h:84-131 restated over 16-byte records with a 64-bit key (first 8 bytes) ---- */
+struct U128 { uint64_t k, v; };
+__device__ __forceinline__ void ins_sort_128(U128 *beg, U128 *end)
+{
+	for(U128 *i = beg + 1; i < end; ++i) {
+		if(i->k < (i - 1)->k) {
+			U128 *j, tmp = *i;
+			for(j = i; j > beg && tmp.k < (j - 1)->k; --j) { *j = *(j - 1); }
+			*j = tmp;
+		}
+	}
+}
+/*
+ * radix_sort_128x: MSD, 8 bits per level starting at bit 56, in-place cycle-leader permutation (UNSTABLE) with
+ * insertion sort for buckets of <= 64.  The recursion order of sibling buckets is irrelevant (disjoint ranges), so an
+ * explicit stack of pending ranges replaces it; one 256-entry bucket table lives in the per-lane scratch.
+ * Returns false if the scratch stack overflowed.
+ */
+__device__ inline bool radix_sort_128(U128 *p, uint32_t l, uint32_t *scratch, uint32_t scratch_words)
+{
+	if(l <= 64) { ins_sort_128(p, p + l); return true; }
+	uint32_t *bb = scratch, *be = scratch + 256;             /* bucket begin / end (element indices relative to p) */
+	uint32_t *stack = scratch + 512; uint32_t cap = (scratch_words - 512) / 3, sp = 0;
+	stack[0] = 0; stack[1] = l; stack[2] = 56; sp = 1;
+	while(sp > 0) {
+		sp--;
+		uint32_t beg = stack[3 * sp], end = stack[3 * sp + 1]; int s = (int)stack[3 * sp + 2];
+		for(int k = 0; k < 256; k++) { bb[k] = be[k] = beg; }
+		for(uint32_t i = beg; i != end; ++i) { ++be[(p[i].k >> s) & 255]; }
+		for(int k = 1; k < 256; k++) { be[k] += be[k - 1] - beg; bb[k] = be[k - 1]; }
+		for(int k = 0; k < 256;) {
+			if(bb[k] != be[k]) {
+				int l_ = (int)((p[bb[k]].k >> s) & 255);
+				if(l_ != k) {
+					U128 tmp = p[bb[k]], swap;
+					do { swap = tmp; tmp = p[bb[l_]]; p[bb[l_]++] = swap; l_ = (int)((tmp.k >> s) & 255); } while(l_ != k);
+					p[bb[k]++] = tmp;
+				} else { ++bb[k]; }
+			} else { ++k; }
+		}
+		bb[0] = beg; for(int k = 1; k < 256; k++) { bb[k] = be[k - 1]; }
+		if(s) {
+			int ns = s > 8 ? s - 8 : 0;
+			for(int k = 0; k < 256; k++) {
+				uint32_t n = be[k] - bb[k];
+				if(n > 64) { if(sp >= cap) { return false; } stack[3 * sp] = bb[k]; stack[3 * sp + 1] = be[k]; stack[3 * sp + 2] = (uint32_t)ns; sp++; }
+				else if(n > 1) { ins_sort_128(p + bb[k], p + be[k]); }
+			}
+		}
+	}
+	return true;
+}
+/* radix_sort_64x (key = low 32 bits of an 8-byte record): same algorithm, 4 key bytes */
+struct U64R { uint32_t k, v; };
+__device__ __forceinline__ void ins_sort_64(U64R *beg, U64R *end)
+{
+	for(U64R *i = beg + 1; i < end; ++i) {
+		if(i->k < (i - 1)->k) {
+			U64R *j, tmp = *i;
+			for(j = i; j > beg && tmp.k < (j - 1)->k; --j) { *j = *(j - 1); }
+			*j = tmp;
+		}
+	}
+}
+__device__ inline bool radix_sort_64(U64R *p, uint32_t l, uint32_t *scratch, uint32_t scratch_words)
+{
+	if(l <= 64) { ins_sort_64(p, p + l); return true; }
+	uint32_t *bb = scratch, *be = scratch + 256;
+	uint32_t *stack = scratch + 512; uint32_t cap = (scratch_words - 512) / 3, sp = 0;
+	stack[0] = 0; stack[1] = l; stack[2] = 24; sp = 1;
+	while(sp > 0) {
+		sp--;
+		uint32_t beg = stack[3 * sp], end = stack[3 * sp + 1]; int s = (int)stack[3 * sp + 2];
+		for(int k = 0; k < 256; k++) { bb[k] = be[k] = beg; }
+		for(uint32_t i = beg; i != end; ++i) { ++be[(p[i].k >> s) & 255]; }
+		for(int k = 1; k < 256; k++) { be[k] += be[k - 1] - beg; bb[k] = be[k - 1]; }
+		for(int k = 0; k < 256;) {
+			if(bb[k] != be[k]) {
+				int l_ = (int)((p[bb[k]].k >> s) & 255);
+				if(l_ != k) {
+					U64R tmp = p[bb[k]], swap;
+					do { swap = tmp; tmp = p[bb[l_]]; p[bb[l_]++] = swap; l_ = (int)((tmp.k >> s) & 255); } while(l_ != k);
+					p[bb[k]++] = tmp;
+				} else { ++bb[k]; }
+			} else { ++k; }
+		}
+		bb[0] = beg; for(int k = 1; k < 256; k++) { bb[k] = be[k - 1]; }
+		if(s) {
+			int ns = s > 8 ? s - 8 : 0;
+			for(int k = 0; k < 256; k++) {
+				uint32_t n = be[k] - bb[k];
+				if(n > 64) { if(sp >= cap) { return false; } stack[3 * sp] = bb[k]; stack[3 * sp + 1] = be[k]; stack[3 * sp + 2] = (uint32_t)ns; sp++; }
+				else if(n > 1) { ins_sort_64(p + bb[k], p + be[k]); }
+			}
+		}
+	}
+	return true;
+}
+
+/* window vectors of the reference's v4i32 code (minialign.c:3366-3402): e0 = upos, e1 = rid, e2 = e3 = vpos */
+struct V4 { int32_t e0, e1, e2, e3; };
+__device__ __forceinline__ V4 load_pv(const Seed &s) { return V4{ (int32_t)s.upos, (int32_t)s.rid, (int32_t)s.vpos, (int32_t)s.vpos }; }
+__device__ __forceinline__ V4 add_win(V4 a, int32_t len) { return V4{ (int32_t)((uint32_t)a.e0 + (uint32_t)len), a.e1, (int32_t)((uint32_t)a.e2 + (uint32_t)len), a.e3 }; }
+/* _inside_wv: (v > vlb, v <= vub, rid <= rid, u <= uub) <=> gt-mask == 0xf000 */
+__device__ __forceinline__ bool inside_wv(const V4 &u, const V4 &d) { return !(d.e0 > u.e0) && !(d.e1 > u.e1) && !(d.e2 > u.e2) && (d.e3 > u.e3); }
+__device__ __forceinline__ bool inside_uub(const V4 &u, const V4 &d) { return !(d.e0 > u.e0) && !(d.e1 > u.e1); }
+__device__ __forceinline__ V4 update_wv(V4 w, const V4 &f)
+{
+	uint32_t d0 = (uint32_t)w.e0 - (uint32_t)f.e0, d2 = (uint32_t)w.e2 - (uint32_t)f.e2;
+	w.e0 = (int32_t)((uint32_t)w.e0 - d2); w.e2 = (int32_t)((uint32_t)w.e2 - d0);
+	return w;
+}
+__device__ __forceinline__ int32_t pdiff(const V4 &w, const V4 &f) { return (int32_t)(((uint32_t)w.e0 - (uint32_t)f.e0) + ((uint32_t)w.e2 - (uint32_t)f.e2)); }
+/* double -> uint32 as the reference's x86-64 build does it (cvttsd2si r64 + truncation) */
+__device__ __forceinline__ uint32_t d2u32(double d) { if(!(d > -9.2e18 && d < 9.2e18)) { return 0; } return (uint32_t)(long long)d; }
+__device__ __forceinline__ uint32_t f2u32(float f) { if(!(f > -9.2e18f && f < 9.2e18f)) { return 0; } return (uint32_t)(long long)f; }
+
+__global__ void __launch_bounds__(64) mm_sort_chain_kernel(K2Args a)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if(t >= a.n_work) { return; }
+	ReadState *st = &a.st[a.work[t]];
+	uint32_t *scratch = a.rs_scratch + (uint64_t)t * a.rs_stride;
+	Seed *s = a.seed_pool + st->seed_off;
+	Root *c = a.root_pool + st->root_off;
+	const DevIndex &ix = a.idx;
+
+	/* mm_seed for round >= 1 (minialign.c:3509-3526): rescued minimizers join the (already sorted) seed array */
+	uint32_t seed_n = st->seed_n;
+	if(a.round > 0) {
+		Resc *resc = a.resc_pool + st->resc_off;
+		if(a.round == 1) { if(!radix_sort_128((U128 *)resc, st->n_resc, scratch, a.rs_stride)) { st->err |= ERR_STACK; } }    /* key = qs | n << 32 */
+		seed_n = st->n_seed;
+		for(uint32_t i = 0; i < seed_n; i++) { s[i].lid = 0x7fffffffu; }
+		uint32_t p = st->presc, e = st->n_resc;
+		while(p < e && resc[p].n <= ix.occ[a.round]) {
+			Resc m = resc[p];
+			for(uint32_t j = 0; j < m.n; j++) {
+				uint64_t hit = (int64_t)m.ref >= 0 ? m.ref : ix.val[((m.ref & 0x7fffffffffffffffull) >> 24) + j];
+				uint32_t rid = (uint32_t)(hit >> 32), rs = (uint32_t)hit;
+				uint32_t rmask = (uint32_t)-(int32_t)(rid & 1);
+				int32_t _rs = (int32_t)(rs + (ix.k & rmask)), _qs = (int32_t)(m.qs ^ rmask);
+				if(seed_n + 2 < st->seed_cap / 2) { s[seed_n++] = Seed{ U_(_rs, _qs), rid >> 1, V_(_rs, _qs), 0x7fffffffu }; } else { st->err |= ERR_SEED_CAP; }
+			}
+			p++;
+		}
+		st->presc = p;
+	}
+	st->n_seed = seed_n; st->n_root = 0; st->pred_rid = gaba::NIL;
+	if(seed_n == 0) { st->seed_n = 0; return; }
+	/* sentinel + sort (minialign.c:3531-3535) */
+	s[seed_n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu };
+	uint32_t n_all = seed_n + 1;
+	if(!radix_sort_128((U128 *)s, n_all, scratch, a.rs_stride)) { st->err |= ERR_STACK; }
+
+	/* mm_chain_seeds (minialign.c:3547-3625) */
+	Seed *ls = s;                                   /* leaf view of the same array */
+	uint32_t ncid = 0, nlid = seed_n + 1, nlsid = 0, tsid = seed_n;
+	const int32_t tw = (int32_t)a.twlen;
+	while(nlsid < tsid) {
+		uint32_t lid = nlid++;
+		ls[lid] = Seed{ nlsid, s[nlsid].rid, nlsid, 0xffffffffu };        /* { rsid, rid, lsid, cid } */
+		uint32_t plen = s[nlsid].upos + s[nlsid].vpos, scnt = 1;
+		uint64_t nrsid = nlsid; nlsid = 0xffffffffu;
+		while(true) {
+			uint32_t rsid = (uint32_t)nrsid; nrsid = 0;
+			V4 wv = add_win(load_pv(s[rsid]), tw);
+			for(uint32_t sid = rsid + 1; ; sid++) {
+				V4 fv = load_pv(s[sid]);
+				if(!inside_wv(wv, fv)) {
+					nlsid = nlsid < sid ? nlsid : sid;
+					if(inside_uub(wv, fv)) { continue; }
+					break;
+				}
+				wv = update_wv(wv, fv);
+				int64_t di = (int64_t)(((uint64_t)(int64_t)pdiff(wv, fv) << 32) | sid);
+				nrsid = (uint64_t)((int64_t)nrsid > di ? (int64_t)nrsid : di);
+			}
+			if(nrsid == 0) { nrsid = rsid; break; }
+			if(s[(uint32_t)nrsid].lid != 0x7fffffffu) { nrsid = (uint32_t)nrsid; break; }
+			s[(uint32_t)nrsid].lid = lid; scnt++;
+			if((uint64_t)nlsid <= nrsid) { nlsid = 0xffffffffu; }     /* the reference compares with the full (pdiff << 32 | sid) value */
+		}
+		if(nrsid == ls[lid].vpos /* lsid */) { continue; }
+		uint32_t cid = 0xffffffffu;
+		if(s[nrsid].lid < lid) {
+			nrsid = ls[s[nrsid].lid].upos /* rsid */;
+			cid = ls[s[nrsid].lid].lid /* cid */;
+		}
+		if(cid == 0xffffffffu) { cid = ncid++; c[cid] = Root{ (uint32_t)OFS(0), lid }; }
+		ls[lid].lid = cid; ls[lid].upos = (uint32_t)nrsid;
+		plen = (uint32_t)OFS((int32_t)d2u32((1.0 - 1.0 / (double)scnt) * (double)(uint32_t)((s[nrsid].upos + s[nrsid].vpos) - plen)));
+		if(plen < c[cid].plen) { c[cid] = Root{ plen, lid }; }
+	}
+	st->seed_n = nlid; st->n_root = ncid;
+	if(ncid == 0) { return; }
+	if(!radix_sort_64((U64R *)c, ncid, scratch, a.rs_stride)) { st->err |= ERR_STACK; }      /* longest first (minialign.c:3719) */
+	/* prediction for the carried reference-length state: the last chain that passes the length test of
+	 * mm_search_load_root (minialign.c:3849) is the last one mm_init_ref sees, unless the extension loop stops early */
+	uint32_t pred = gaba::NIL;
+	for(uint32_t kq = 0; kq < ncid; kq++) {
+		uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
+		if(pl * a.mcoef < 2.0 * a.min_score) { break; }
+		pred = s[ls[c[kq].lid].upos].rid;
+	}
+	st->pred_rid = pred;
+}
+
+/* =====================================================================================================
+ * K3: extension driver, one wavefront per read
+ * ===================================================================================================== */
+struct KhSlot { uint64_t k, v; };
+struct AlnRec {                /* what the host needs of a gaba_alignment_t (gaba.h:205-220) */
+	int64_t score; double identity;
+	uint32_t agcnt, bgcnt, dcnt, slen, plen;
+	uint32_t seg_off;          /* index into the segment pool */
+	uint64_t path_off;         /* word offset into the path pool; two header words {plen, 0x40000000} precede it (gaba.h:217) */
+};
+struct K3Args {
+	DevIndex idx; const gaba::Consts *gc; const uint8_t *roots; gaba::SeqArena ar_ref, ar_q;
+	const ReadIn *in; ReadState *st; const uint32_t *work; uint32_t n_work;
+	Seed *seed_pool; Root *root_pool;
+	uint8_t *slabs; uint64_t slab_bytes;                 /* DP workspace per wave */
+	KhSlot *kh_pool; uint32_t kh_cap;                    /* per read (work index) */
+	uint32_t round;
+	uint64_t *next_pool; uint32_t next_cap;              /* per wave: (pdiff, sid) */
+	uint64_t *bin_pool; uint64_t bin_pool_cap; unsigned long long *bin_top; uint32_t bin_cap_per_read;
+	AlnRec *aln_pool; uint64_t aln_pool_cap; unsigned long long *aln_top; uint32_t aln_cap_per_read;
+	gaba::Segment *seg_pool; uint64_t seg_pool_cap; unsigned long long *seg_top;
+	uint32_t *path_pool; uint64_t path_pool_cap; unsigned long long *path_top;
+	uint32_t tglen; double mcoef; float min_ratio; uint32_t min_score;
+	uint32_t *counter; unsigned long long *stats;        /* [2] fills, [3] vectors, [4] blocks, [5] traces, [6] trace steps */
+};
+
+/* the per-read position hash, kh_t (minialign.c:341-683), literal */
+struct Kh { KhSlot *a; uint32_t mask, cnt, ub, cap; };
+__device__ inline void kh_clear(Kh &h) { h.mask = 255; h.cnt = 0; h.ub = (uint32_t)(256 * 0.4); for(int i = 0; i < 256; i++) { h.a[i].k = ~0ull; h.a[i].v = ~0ull; } }
+__device__ inline uint64_t kh_allocate(KhSlot *a, uint64_t k, uint64_t v, uint64_t mask, uint32_t *is_new)
+{
+	#define KH_POLL(_i, _b0, _k1) { long long _b = (long long)(_b0); while(true) { (_k1) = a[_i].k; \
+		if(_b <= (long long)((_k1) & mask) + (long long)((_k1) + 2 < 2)) { break; } _b -= (long long)(((_i) + 1) & (mask + 1)); (_i) = ((_i) + 1) & mask; } }
+	uint64_t i = k & mask, k0 = k, v0 = v, k1;
+	KH_POLL(i, i, k1);
+	if(k0 == k1) { *is_new = 0; return i; }
+	uint64_t j = i;
+	a[i].k = k0;
+	while(k1 + 2 >= 2) {
+		uint64_t v1 = a[i].v; a[i].v = v0; k0 = k1; v0 = v1;
+		i = (i + 1) & mask;
+		KH_POLL(i, k0 & mask, k1);
+		a[i].k = k0;
+	}
+	a[i].v = v0;
+	*is_new = 1;
+	return j;
+	#undef KH_POLL
+}
+__device__ inline bool kh_extend(Kh &h)
+{
+	uint64_t prev = (uint64_t)h.mask + 1, size = 2 * prev, mask = size - 1;
+	if(size > h.cap) { return false; }
+	h.mask = (uint32_t)mask; h.ub = (uint32_t)(size * 0.4);
+	for(uint64_t i = 0; i < prev; i++) { h.a[i + prev].k = ~0ull; h.a[i + prev].v = ~0ull; }
+	for(uint64_t i = 0; i < size; i++) {
+		uint64_t k = h.a[i].k;
+		if(k + 2 < 2 || (k & mask) == i) { continue; }
+		uint64_t v = h.a[i].v;
+		h.a[i].k = ~0ull - 1; h.a[i].v = ~0ull;
+		uint32_t dummy; kh_allocate(h.a, k, v, mask, &dummy);
+	}
+	return true;
+}
+/* kh_put_ptr: returns the slot index whose value word the caller reads / writes */
+__device__ inline uint64_t kh_put(Kh &h, uint64_t key, bool extend, uint32_t *err)
+{
+	if(extend && h.cnt >= h.ub) { if(!kh_extend(h)) { *err |= ERR_KH_CAP; } }
+	uint32_t nw; uint64_t idx = kh_allocate(h.a, key, ~0ull, h.mask, &nw);
+	h.cnt += nw;
+	return idx;
+}
+__device__ __forceinline__ uint64_t mm_key(uint64_t x, uint64_t y) { return x ^ (x >> 29) ^ y ^ __builtin_bswap64(y); }    /* minialign.c:3362 */
+
+struct Search {                 /* mm_search_t, minialign.c:3218 */
+	uint32_t cp_a, cp_b, tp_a, tp_b;
+	uint32_t aid, bid, iid, eid, sid, rev;
+	int64_t prem; uint32_t pacc, crem, srem, narrow, min_score;
+};
+constexpr uint32_t MM_CREM = 50000, MM_SREM = 8;
+
+__global__ void __launch_bounds__(256) mm_extend_kernel(K3Args a)
+{
+	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
+	gaba::Ctx x;
+	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	const int lane = x.lane;
+	uint32_t wave = (uint32_t)rdfirst((int)(blockIdx.x * 4 + threadIdx.x / 64));
+	x.slab = a.slabs + (uint64_t)wave * a.slab_bytes; x.cap = (uint32_t)a.slab_bytes; x.top = gaba::SLAB_HEAD;
+	for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	Kh kh; kh.cap = a.kh_cap;
+	uint64_t *next = a.next_pool + (uint64_t)wave * a.next_cap;
+	const DevIndex &ix = a.idx;
+	const gaba::Sec tailsec = { 0xfffffffeu, 96, 0, 2, 0 };
+	unsigned long long n_fill = 0, n_trace = 0;
+
+	while(true) {
+		uint32_t wi = 0;
+		if(lane == 0) { wi = atomicAdd(a.counter, 1u); }
+		wi = (uint32_t)rdfirst((int)wi);
+		if(wi >= a.n_work) { break; }
+		const uint32_t r = (uint32_t)rdfirst((int)a.work[wi]);
+		ReadState *st = &a.st[r];
+		const uint32_t n_root = (uint32_t)rdfirst((int)st->n_root);
+		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
+		const uint64_t q_off = rdfirst64(a.in[r].q_off);
+		Seed *s = a.seed_pool + rdfirst64(st->seed_off);
+		Root *root = a.root_pool + rdfirst64(st->root_off);
+		uint32_t rlen = (uint32_t)rdfirst((int)st->rlen);
+		uint32_t err = 0, n_res = (uint32_t)rdfirst((int)st->n_res);
+		uint32_t rid_last = (uint32_t)rdfirst((int)st->rid_last);
+		uint32_t apos0 = (uint32_t)rdfirst((int)st->apos0), cond0 = (uint32_t)rdfirst((int)st->cond0);
+
+		/* per-read output regions */
+		uint64_t bin_off = rdfirst64(st->bin_off), aln_off = rdfirst64(st->aln_off);
+		uint32_t n_bin = (uint32_t)rdfirst((int)st->n_bin), n_aln = (uint32_t)rdfirst((int)st->n_aln);
+		if(bin_off == ~0ull) {
+			unsigned long long bo = 0, ao = 0;
+			if(lane == 0) { bo = atomicAdd(a.bin_top, (unsigned long long)a.bin_cap_per_read); ao = atomicAdd(a.aln_top, (unsigned long long)a.aln_cap_per_read); }
+			bin_off = rdfirst64(bo); aln_off = rdfirst64(ao); n_bin = 0; n_aln = 0;
+			if(bin_off + a.bin_cap_per_read > a.bin_pool_cap || aln_off + a.aln_cap_per_read > a.aln_pool_cap) { err |= ERR_BIN_CAP; bin_off = 0; aln_off = 0; }
+			/* first round of this read: mm_tbuf_clear (minialign.c:4402) */
+		}
+		uint64_t *bin = a.bin_pool + bin_off;
+		AlnRec *alns = a.aln_pool + aln_off;
+		/* the hash is cleared once per read (mm_tbuf_clear, minialign.c:4402) and shared by the rounds of that read */
+		kh.a = a.kh_pool + (uint64_t)r * a.kh_cap;
+		if(a.round == 0) { if(lane == 0) { kh_clear(kh); } }
+		else { kh.mask = (uint32_t)rdfirst((int)st->kh_mask); kh.cnt = (uint32_t)rdfirst((int)st->kh_cnt); kh.ub = (uint32_t)rdfirst((int)st->kh_ub); }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		x.err = 0;
+
+		Search sr;
+		sr.crem = MM_CREM; sr.min_score = a.min_score; sr.narrow = 0; sr.srem = 0; sr.prem = 0; sr.pacc = 0;
+		sr.cp_a = sr.cp_b = sr.tp_a = sr.tp_b = 0; sr.aid = sr.bid = sr.iid = sr.eid = sr.sid = sr.rev = 0;
+		uint32_t next_n = 0;
+		gaba::Sec rsec_f, rsec_r, qsec_f, qsec_r;
+		qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }; qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
+
+		#define LOAD_POS(_p, _cpa, _cpb, _rev) { \
+			int32_t _bs = BS(_p); (_rev) = _bs < 0; \
+			(_cpa) = (uint32_t)AS(_p); (_cpb) = (uint32_t)(_bs + ((_bs >> 31) & (int32_t)qlen)); \
+			if(first_pos) { apos0 = (_cpa); cond0 = (_cpb) >= qlen; first_pos = false; } \
+			if((_cpa) >= rlen || (_cpb) >= qlen) { (_cpa) -= min((_cpa), ix.k); (_cpb) -= min((_cpb), ix.k); } }
+		bool first_pos = apos0 == gaba::NIL;
+
+		for(uint32_t kq = 0; kq < n_root; kq++) {
+			/* mm_search_load_root (minialign.c:3839-3883) */
+			Root rt = root[kq];
+			uint32_t lid = (uint32_t)rdfirst((int)rt.lid);
+			uint32_t plen = (uint32_t)OFS((int32_t)rdfirst((int)rt.plen));
+			if(plen * a.mcoef < 2.0 * a.min_score) { break; }
+			next_n = 0;
+			if(n_bin + 2 > a.bin_cap_per_read) { err |= ERR_BIN_CAP; break; }
+			uint32_t iid = n_bin;
+			if(lane == 0) { bin[iid] = 0; bin[iid + 1] = 0; }        /* header {n_aln, plen, lb, ub}: all-zero as in the reference *as built*  */
+			n_bin += 2;
+			uint32_t eid = n_res++;
+			if(lane == 0) { root[eid] = Root{ (uint32_t)OFS(0), iid }; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			uint32_t rsid = (uint32_t)rdfirst((int)s[lid].upos);
+			Seed ps = s[rsid];
+			ps.upos = (uint32_t)rdfirst((int)ps.upos); ps.vpos = (uint32_t)rdfirst((int)ps.vpos); ps.rid = (uint32_t)rdfirst((int)ps.rid);
+			LOAD_POS(ps, sr.cp_a, sr.cp_b, sr.rev);
+			sr.tp_a = sr.cp_a; sr.tp_b = sr.cp_b;
+			sr.aid = ps.rid; sr.bid = 0; sr.iid = iid; sr.eid = eid; sr.sid = rsid;
+			sr.prem = plen; sr.pacc = 0; sr.srem = MM_SREM; sr.narrow = 0;
+			/* mm_init_ref */
+			rlen = (uint32_t)rdfirst((int)ix.seq_len[sr.aid]); rid_last = sr.aid;
+			uint64_t roff = rdfirst64(ix.seq_off[sr.aid]);
+			rsec_f = gaba::Sec{ sr.aid << 1, rlen, roff, 0, 0 }; rsec_r = gaba::Sec{ (sr.aid << 1) + 1, rlen, roff, 0, 1 };
+
+			bool first_iter = true;
+			while(true) {
+				if(!first_iter) {
+					/* mm_search_load_next (minialign.c:3888-3946) */
+					if(sr.srem == 0) { /* nothing */ }
+					else {
+						sr.srem--;
+						uint64_t ofs = 2ull * a.tglen;
+						int32_t fa = (int32_t)sr.cp_a, fb = (int32_t)(sr.cp_b - (sr.rev ? qlen : 0u));
+						V4 fv = V4{ (int32_t)U_(fa, fb), (int32_t)sr.aid, (int32_t)V_(fa, fb), (int32_t)V_(fa, fb) };
+						uint32_t ncnt = next_n;
+						uint64_t plim = ofs - sr.pacc;
+						if(sr.pacc > ofs) { ncnt = 0; }
+						/* serial section on lane 0 (short arrays) */
+						uint32_t sid_out = sr.sid;
+						if(lane == 0) {
+							for(uint32_t i = 0; i < ncnt; i++) {
+								uint32_t pd = (uint32_t)next[i];
+								if(pd >= plim) { ncnt = i; break; }
+								next[i] = (next[i] & 0xffffffff00000000ull) | (uint32_t)(pd + sr.pacc);
+							}
+							uint64_t sid = sr.sid;
+							for(uint64_t rcnt = 2ull * sr.srem; sid > 0 && rcnt > 0; sid--) {
+								V4 pv = load_pv(s[sid - 1]);
+								V4 wv = add_win(pv, (int32_t)a.tglen), zv = add_win(pv, 128);
+								if(!inside_uub(wv, fv)) { break; }
+								if(!inside_wv(wv, fv) || inside_wv(zv, fv)) { continue; }
+								if(ncnt < a.next_cap) { next[ncnt++] = (uint64_t)(uint32_t)pdiff(wv, fv) | ((uint64_t)(sid - 1) << 32); } else { err |= ERR_NEXT_CAP; }
+								rcnt--;
+							}
+							sid_out = (uint32_t)sid;
+							/* radix_sort_64x: arrays here are far below the 64-element insertion-sort threshold in practice */
+							if(ncnt <= 64) { ins_sort_64((U64R *)next, (U64R *)next + ncnt); } else { err |= ERR_NEXT_CAP; ins_sort_64((U64R *)next, (U64R *)next + ncnt); }
+						}
+						__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+						ncnt = (uint32_t)rdfirst((int)ncnt); sr.sid = (uint32_t)rdfirst((int)sid_out); err = (uint32_t)rdfirst((int)err);
+						next_n = ncnt;
+						if(ncnt == 0) { sr.pacc = 0; sr.srem = 0; }
+						else {
+							next_n = ncnt - 1;
+							uint64_t e = rdfirst64(next[next_n]);
+							uint32_t nsid = (uint32_t)(e >> 32);
+							sr.pacc = (uint32_t)(ofs - (uint32_t)e);
+							Seed ns = s[nsid];
+							ns.upos = (uint32_t)rdfirst((int)ns.upos); ns.vpos = (uint32_t)rdfirst((int)ns.vpos);
+							LOAD_POS(ns, sr.cp_a, sr.cp_b, sr.rev);
+						}
+					}
+				}
+				first_iter = false;
+				if(!(sr.srem > 0 && sr.prem > 0)) { break; }
+
+				/* one extension trial (minialign.c:4134-4166) */
+				gaba::dp_flush(x);
+				int bw = (int)sr.narrow;                     /* _dp(x) ignores its argument (minialign.c:4123) */
+				/* downward */
+				uint32_t f, m; int64_t mmax;
+				{
+					gaba::Sec ca = rsec_f, cb = sr.rev ? qsec_r : qsec_f;
+					f = gaba::dp_fill_root(x, bw, ca, sr.cp_a, cb, sr.cp_b, 0); m = f; n_fill++;
+					mmax = (int64_t)rdfirst64((uint64_t)gaba::tail_at(x, f)->f.max);
+					uint32_t flag = gaba::STATUS_TERM;
+					while(true) {
+						uint32_t stt = (uint32_t)rdfirst((int)gaba::tail_at(x, f)->f.status);
+						if((flag & stt) != 0 || x.err) { break; }
+						if(stt & gaba::UPDATE_A) { ca = tailsec; }
+						if(stt & gaba::UPDATE_B) { cb = tailsec; }
+						flag |= stt & (gaba::UPDATE_A | gaba::UPDATE_B);
+						f = gaba::dp_fill(x, f, ca, cb, 0);
+						int64_t fm = (int64_t)rdfirst64((uint64_t)gaba::tail_at(x, f)->f.max);
+						if(fm > mmax) { m = f; mmax = fm; }
+					}
+				}
+				if(x.err) { err |= ERR_DP_SLAB; break; }
+				if(mmax == 0) { continue; }
+				gaba::Leaf lf;
+				gaba::PosPair pp = gaba::dp_search_max(x, m, lf);
+				/* mm_search_test_dup (minialign.c:3953-3982) */
+				uint32_t dup = 0;
+				{
+					uint64_t key = mm_key((uint64_t)pp.apos | ((uint64_t)pp.bpos << 32), (uint64_t)sr.aid | ((uint64_t)sr.bid << 32));
+					uint64_t prev = 0;
+					if(lane == 0) {
+						uint64_t ti = kh_put(kh, key, true, &err);
+						prev = kh.a[ti].v;
+						kh.a[ti].v = (uint64_t)sr.eid | (0xffffffffull << 32);
+					}
+					prev = rdfirst64(prev); err = (uint32_t)rdfirst((int)err);
+					int32_t pa = max(1, min((int32_t)pp.apos, (int32_t)rlen)), pb = max(1, min((int32_t)pp.bpos, (int32_t)qlen));
+					sr.tp_a = (uint32_t)pa; sr.tp_b = (uint32_t)pb;
+					if(prev != ~0ull) {
+						/* the reference re-reads the slot it has just overwritten, so the "other chain" test never fires */
+						sr.narrow = min(sr.narrow + 1, 2u);
+						dup = 1;
+					}
+				}
+				if(dup) { continue; }
+				/* upward */
+				{
+					gaba::Sec ca = rsec_r, cb = sr.rev ? qsec_f : qsec_r;
+					uint32_t ua = rlen - sr.tp_a, ub = qlen - sr.tp_b;
+					f = gaba::dp_fill_root(x, bw, ca, ua, cb, ub, 0); m = f; n_fill++;
+					mmax = (int64_t)rdfirst64((uint64_t)gaba::tail_at(x, f)->f.max);
+					uint32_t flag = gaba::STATUS_TERM;
+					while(true) {
+						uint32_t stt = (uint32_t)rdfirst((int)gaba::tail_at(x, f)->f.status);
+						if((flag & stt) != 0 || x.err) { break; }
+						if(stt & gaba::UPDATE_A) { ca = tailsec; }
+						if(stt & gaba::UPDATE_B) { cb = tailsec; }
+						flag |= stt & (gaba::UPDATE_A | gaba::UPDATE_B);
+						f = gaba::dp_fill(x, f, ca, cb, 0);
+						int64_t fm = (int64_t)rdfirst64((uint64_t)gaba::tail_at(x, f)->f.max);
+						if(fm > mmax) { m = f; mmax = fm; }
+					}
+				}
+				if(x.err) { err |= ERR_DP_SLAB; break; }
+				if(mmax < (int64_t)a.min_score) { continue; }
+				/* trace into the output pools */
+				if(n_aln >= a.aln_cap_per_read) { err |= ERR_ALN_CAP; break; }
+				gaba::Leaf tlf;
+				uint64_t tplen = gaba::dp_trace_begin(x, m, tlf);
+				uint64_t need_words = (tplen + 31) / 32 + 2;
+				unsigned long long po = 0, so_ = 0;
+				if(lane == 0) { po = atomicAdd(a.path_top, (unsigned long long)need_words + 2); so_ = atomicAdd(a.seg_top, 8ull); }
+				po = rdfirst64(po); so_ = rdfirst64(so_);
+				if(po + need_words + 2 > a.path_pool_cap || so_ + 8 > a.seg_pool_cap) { err |= ERR_PATH_CAP; break; }
+				uint32_t *path = a.path_pool + po + 2;
+				gaba::AlnOut ao = gaba::dp_trace_finish(x, m, tlf, tplen, path, a.seg_pool + so_, 8);
+				n_trace++;
+				if(x.err) { err |= (x.err == 1 ? ERR_DP_SLAB : (x.err == 2 ? ERR_PATH_CAP : ERR_SEG_CAP)); break; }
+				if(ao.status != 1) { continue; }           /* NULL alignment: path left the band */
+				uint32_t ai = n_aln++;
+				if(lane == 0) {
+					a.path_pool[po] = ao.plen; a.path_pool[po + 1] = 0x40000000u;
+					AlnRec *ar_ = &alns[ai];
+					ar_->score = ao.score; ar_->identity = ao.identity; ar_->agcnt = ao.agcnt; ar_->bgcnt = ao.bgcnt; ar_->dcnt = ao.dcnt;
+					ar_->slen = ao.slen; ar_->plen = ao.plen; ar_->seg_off = (uint32_t)so_; ar_->path_off = po + 2;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				/* mm_search_record (minialign.c:4018-4067) */
+				const gaba::Segment *segs = a.seg_pool + so_;
+				gaba::Segment sl = segs[ao.slen - 1], s0 = segs[0];
+				uint32_t p0 = rlen - ((uint32_t)rdfirst((int)sl.apos) + (uint32_t)rdfirst((int)sl.alen)), p1 = qlen - ((uint32_t)rdfirst((int)sl.bpos) + (uint32_t)rdfirst((int)sl.blen));
+				uint32_t p2 = rlen - (uint32_t)rdfirst((int)s0.apos), p3 = qlen - (uint32_t)rdfirst((int)s0.bpos);
+				sr.cp_a = p0; sr.cp_b = p1;
+				sr.prem -= ao.plen; sr.pacc = ao.plen;
+				uint64_t id = (uint64_t)sr.aid | ((uint64_t)sr.bid << 32);
+				uint64_t hk = mm_key((uint64_t)p0 | ((uint64_t)p1 << 32), id), tk = mm_key((uint64_t)p2 | ((uint64_t)p3 << 32), id);
+				uint32_t isnew = 0;
+				if(lane == 0) {
+					/* h is taken before the second insert, which may shift entries under it (minialign.c:4027-4029): indices, literally */
+					uint64_t hi = kh_put(kh, hk, true, &err);
+					uint64_t ti = kh_put(kh, tk, false, &err);
+					isnew = (uint32_t)(kh.a[hi].v >> 32) == 0xffffffffu;
+					uint32_t nid;
+					if(isnew) { nid = n_bin; if(n_bin < a.bin_cap_per_read) { bin[n_bin] = (uint64_t)ai + 1; } else { err |= ERR_BIN_CAP; } }
+					else { nid = (uint32_t)(kh.a[hi].v >> 32); }
+					uint32_t *hdr = (uint32_t *)&bin[sr.iid];           /* { n_aln, plen, lb, ub } */
+					uint32_t lb = hdr[2], ubb = hdr[3];
+					uint32_t ovl = max(lb, p1) - min(ubb, p3) - p1 + p3;
+					Root *rr = &root[sr.eid];
+					rr->plen -= (uint32_t)(ao.score + (int64_t)d2u32((double)(uint32_t)(ovl * 2) * ao.identity));
+					hdr[0] += isnew; hdr[1] += ao.plen; hdr[2] = min(lb, p1); hdr[3] = max(ubb, p3);
+					uint32_t cur = nid < a.bin_cap_per_read ? (uint32_t)bin[nid] - 1 : ai;
+					int64_t bscore = alns[cur].score;
+					if(bscore > ao.score) {
+						kh.a[ti].v = (uint64_t)sr.eid | (0xffffffffull << 32);
+					} else {
+						if(cur != ai && nid < a.bin_cap_per_read) { bin[nid] = (uint64_t)ai + 1; }
+						uint64_t nv = (uint64_t)sr.eid | ((uint64_t)nid << 32);
+						kh.a[ti].v = nv; kh.a[hi].v = nv;              /* *h = *t = ... (t first, then h, as the chained assignment evaluates) */
+					}
+				}
+				isnew = (uint32_t)rdfirst((int)isnew); err = (uint32_t)rdfirst((int)err);
+				n_bin += isnew;
+				sr.srem = MM_SREM; sr.narrow = 0;
+				{
+					float cand = (float)ao.score * a.min_ratio, cur = (float)sr.min_score;
+					sr.min_score = f2u32(cur > cand ? cur : cand);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				if(!(isnew && sr.prem > 0)) { break; }
+			}
+			if(err & (ERR_DP_SLAB | ERR_PATH_CAP | ERR_ALN_CAP | ERR_SEG_CAP)) { break; }
+			/* mm_finish_root (minialign.c:3795-3813) */
+			{
+				uint32_t *hdr = (uint32_t *)&bin[sr.iid];
+				uint32_t bn = (uint32_t)rdfirst((int)hdr[0]); uint32_t sc = (uint32_t)rdfirst((int)root[sr.eid].plen);
+				if(bn == 0 || sc > (uint32_t)OFS((int32_t)a.min_score)) { n_bin = sr.iid; n_res--; sr.crem--; }
+				else { sr.crem = sr.crem != 0 ? MM_CREM : 0; }
+				if(sr.crem == 0) { break; }
+			}
+		}
+		#undef LOAD_POS
+		if(lane == 0) {
+			st->n_res = n_res; st->rlen = rlen; st->rid_last = rid_last; st->apos0 = apos0; st->cond0 = cond0;
+			st->n_bin = n_bin; st->bin_off = bin_off; st->n_aln = n_aln; st->aln_off = aln_off;
+			st->kh_mask = kh.mask; st->kh_cnt = kh.cnt; st->kh_ub = kh.ub;
+			st->err |= err;
+			if(n_res > 0) { st->done = 1; }
+		}
+	}
+	if(lane == 0) {
+		atomicAdd(&a.stats[2], n_fill); atomicAdd(&a.stats[3], (unsigned long long)x.n_vec); atomicAdd(&a.stats[4], (unsigned long long)x.n_blk);
+		atomicAdd(&a.stats[5], n_trace); atomicAdd(&a.stats[6], (unsigned long long)x.n_tr);
+	}
+}
+
+} /* namespace mm */

@@ -1,0 +1,834 @@
+/*
+ * mm_host.hip -- host side of include/minialign.h: options, FASTA/FASTQ reader, index construction,
+ * the GPU batch pipeline (K1 sketch/lookup/expand -> K2 sort/chain -> K3 extend, in occurrence-threshold rounds),
+ * post-map (prune / supplementary / MAPQ) and the SAM printer.
+ *
+ * Reference behaviour mirrored here (file:line in /root/reference):
+ *   options / presets   minialign.c:5846-5900, 6141-6162      reader        minialign.c:1996-2090, 214-229
+ *   index build         minialign.c:2767-3040, ksort.h:84-131  post-map      minialign.c:4185-4398
+ *   SAM                 minialign.c:5096-5426, gaba_parse.h:168-263
+ * The reference streams 512 KB batches through a pthread queue (minialign.c:4535-4732); here a batch is as
+ * many reads as fit the device pools, every device stage is one launch over the whole batch, and batches are
+ * drained strictly in input order.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <time.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "gaba_host.hpp"
+#include "mm_device.hpp"
+#include "../../include/minialign.h"
+
+using namespace mm;
+
+namespace {
+
+double now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+inline uint32_t h_d2u32(double d) { if(!(d > -9.2e18 && d < 9.2e18)) return 0; return (uint32_t)(int64_t)d; }
+inline uint32_t h_f2u32(float f) { if(!(f > -9.2e18f && f < 9.2e18f)) return 0; return (uint32_t)(int64_t)f; }
+inline int32_t h_ofs(int32_t x) { return (int32_t)0x40000000 - x; }
+
+/* ---------------------------------------------------------------------------------------------
+ * the reference's radix sort (ksort.h:84-131): in-place MSD radix on 8-bit digits, cycle-leader
+ * permutation (unstable), insertion sort below 65 elements.  Its exact permutation decides the order of
+ * hits inside an index value list and of equal-score results, so it is implemented, not substituted.
+ * --------------------------------------------------------------------------------------------- */
+template<typename T, typename K> struct KRadix {
+	static void insertion(T *beg, T *end, K key)
+	{
+		for(T *i = beg + 1; i < end; ++i) {
+			if(key(*i) < key(*(i - 1))) {
+				T tmp = *i, *j;
+				for(j = i; j > beg && key(tmp) < key(*(j - 1)); --j) *j = *(j - 1);
+				*j = tmp;
+			}
+		}
+	}
+	static void msd(T *beg, T *end, int s, K key)
+	{
+		struct B { T *b, *e; } b[256];
+		for(int k = 0; k < 256; k++) b[k].b = b[k].e = beg;
+		for(T *i = beg; i != end; ++i) ++b[(key(*i) >> s) & 255].e;
+		for(int k = 1; k < 256; k++) { b[k].e += b[k - 1].e - beg; b[k].b = b[k - 1].e; }
+		for(int k = 0; k < 256;) {
+			if(b[k].b != b[k].e) {
+				int l = (int)((key(*b[k].b) >> s) & 255);
+				if(l != k) {
+					T tmp = *b[k].b, swp;
+					do { swp = tmp; tmp = *b[l].b; *b[l].b++ = swp; l = (int)((key(tmp) >> s) & 255); } while(l != k);
+					*b[k].b++ = tmp;
+				} else ++b[k].b;
+			} else ++k;
+		}
+		b[0].b = beg; for(int k = 1; k < 256; k++) b[k].b = b[k - 1].e;
+		if(s) {
+			int ns = s > 8 ? s - 8 : 0;
+			for(int k = 0; k < 256; k++) {
+				if(b[k].e - b[k].b > 64) msd(b[k].b, b[k].e, ns, key);
+				else if(b[k].e - b[k].b > 1) insertion(b[k].b, b[k].e, key);
+			}
+		}
+	}
+	static void sort(T *p, size_t n, int key_bits, K key) { if(n <= 64) insertion(p, p + n, key); else msd(p, p + n, key_bits - 8, key); }
+};
+struct Mini { uint64_t hrem; uint32_t pos, rid; };
+struct ResEnt { uint32_t score, iid; };
+inline void sort_minis(Mini *p, size_t n) { auto key = [](const Mini &m) { return m.hrem; }; KRadix<Mini, decltype(key)>::sort(p, n, 64, key); }
+inline void sort_res(ResEnt *p, size_t n) { auto key = [](const ResEnt &m) { return m.score; }; KRadix<ResEnt, decltype(key)>::sort(p, n, 32, key); }
+
+/* ---------------------------------------------------------------------------------------------
+ * sequences
+ * --------------------------------------------------------------------------------------------- */
+struct HSeq { std::string name; std::vector<uint8_t> seq; };
+
+/* FASTA / FASTQ text; bases by the low-nibble table of minialign.c:223-229 (anything but ACGTUN -> A) */
+bool read_seq_file(const char *fn, std::vector<HSeq> &out)
+{
+	FILE *fp = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
+	if(!fp) return false;
+	uint8_t enc[16] = { 0 };
+	enc['A' & 15] = 0; enc['C' & 15] = 1; enc['G' & 15] = 2; enc['T' & 15] = 3; enc['U' & 15] = 3; enc['N' & 15] = 4;
+	std::vector<char> buf(1 << 22);
+	std::string line; line.reserve(1 << 16);
+	int state = 0; char delim = 0; uint64_t qneed = 0, qgot = 0;
+	auto handle = [&](const char *l, size_t n) {
+		while(n > 0 && (l[n - 1] == '\r')) n--;
+		if(state == 2) { qgot += n; if(qgot >= qneed) state = 0; return; }
+		if(n == 0) return;
+		if(delim == 0 && (l[0] == '>' || l[0] == '@')) delim = l[0];
+		if(l[0] == delim && (state == 0 || delim == '>')) {
+			size_t p = 1; while(p < n && (l[p] == ' ' || l[p] == '\t')) p++;
+			size_t e = p; while(e < n && l[e] != ' ' && l[e] != '\t') e++;
+			out.emplace_back(); out.back().name.assign(l + p, e - p); state = 1; return;
+		}
+		if(state == 1 && delim == '@' && l[0] == '+') { state = 2; qneed = out.back().seq.size(); qgot = 0; if(qneed == 0) state = 0; return; }
+		if(state == 1) { auto &s = out.back().seq; size_t o = s.size(); s.resize(o + n); for(size_t i = 0; i < n; i++) s[o + i] = enc[l[i] & 15]; }
+	};
+	size_t got;
+	while((got = fread(buf.data(), 1, buf.size(), fp)) > 0) {
+		size_t st_ = 0;
+		for(size_t i = 0; i < got; i++) {
+			if(buf[i] == '\n') {
+				if(line.empty()) handle(buf.data() + st_, i - st_);
+				else { line.append(buf.data() + st_, i - st_); handle(line.data(), line.size()); line.clear(); }
+				st_ = i + 1;
+			}
+		}
+		if(st_ < got) line.append(buf.data() + st_, got - st_);
+	}
+	if(!line.empty()) handle(line.data(), line.size());
+	if(fp != stdin) fclose(fp);
+	/* -L 1 (minialign.c:2077): empty records are dropped */
+	out.erase(std::remove_if(out.begin(), out.end(), [](const HSeq &s) { return s.seq.empty(); }), out.end());
+	return true;
+}
+
+void pack_bases(const uint8_t *b, uint64_t n, std::vector<uint32_t> &pk, std::vector<uint32_t> &nm, uint64_t at)
+{
+	for(uint64_t i = 0; i < n; i++) {
+		uint64_t p = at + i; uint32_t c = b[i];
+		if(c > 3) { nm[p >> 5] |= 1u << (p & 31); c = 0; }
+		pk[p >> 4] |= c << (2 * (p & 15));
+	}
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * minimizer sketch on the host (index construction only; reads are sketched on the device).
+ * Same emission rule as the device kernel: window minimum over the last w positions of
+ * h = hash << 8 | (pos mod w) | strand << 7, emitted when the current position is the minimum or the minimum changed.
+ * --------------------------------------------------------------------------------------------- */
+uint32_t h_crc32c(uint32_t crc, uint64_t v) { for(int i = 0; i < 64; i++) { uint32_t b = (crc ^ (uint32_t)(v >> i)) & 1u; crc = (crc >> 1) ^ (b ? 0x82f63b78u : 0u); } return crc; }
+struct HMin { uint64_t hash; uint32_t pos; uint32_t strand; };
+void sketch_host(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t w, std::vector<HMin> &out)
+{
+	const uint64_t mask = (1ull << 2 * k) - 1; const int sh = 2 * (k - 1);
+	std::vector<uint64_t> ring(w, ~0ull);        /* h of the last w positions */
+	uint64_t k0 = 0, k1 = 0, u = 0;
+	for(uint32_t p = 0; p < len; p++) {
+		uint64_t c = seq[p];
+		k0 = (k0 << 2 | c) & mask; k1 = (k1 >> 2) | ((3ull ^ c) << sh);
+		if(p + 1 < k) continue;
+		uint64_t km = k0 < k1 ? k0 : k1, kx = k0 < k1 ? k1 : k0, m = k0 < k1 ? 0 : 0x80;
+		uint64_t crc = (kx >> 32) ? (uint64_t)h_crc32c((uint32_t)kx, kx) : 0ull;
+		uint32_t i = (p - (k - 1)) % w;
+		uint64_t h = ((crc ^ km) & mask) << 8 | i | m;
+		ring[i] = h;
+		uint64_t v = ~0ull; for(uint32_t j = 0; j < w; j++) v = ring[j] < v ? ring[j] : v;
+		if(v == h || v != u) {
+			uint32_t iv = (uint32_t)(v & 0x7f);
+			out.push_back(HMin{ v >> 8, (p - (k - 1)) - ((i + w - iv) % w), (uint32_t)((v >> 7) & 1) });
+		}
+		u = v;
+	}
+}
+
+} /* anonymous */
+
+/* =============================================================================================
+ * options
+ * ============================================================================================= */
+struct mm_opt_s {
+	uint32_t k = 15, w = 32, b = 14, n_frq = 3; float frq[4] = { 0.05f, 0.01f, 0.001f, 0 };
+	uint32_t wlen = 7000, glen = 7000, min_score = 50; float min_ratio = 0.3f;
+	gaba_params_t p;
+	uint32_t nth = 1;
+	std::string arg_line;
+	mm_opt_s() { memset(&p, 0, sizeof(p)); for(int i = 0; i < 16; i++) p.score_matrix[i] = (i & 3) == (i >> 2) ? 1 : -1; p.gi = 1; p.ge = 1; p.xdrop = 50; }
+};
+namespace {
+int opt_one(mm_opt_t *o, char c, const char *arg);
+int opt_line(mm_opt_t *o, const char *s)
+{
+	while(*s) {
+		while(*s == ' ') s++;
+		if(*s != '-') break;
+		char c = s[1]; s += 2; std::string a; while(*s && *s != ' ') a.push_back(*s++);
+		if(opt_one(o, c, a.c_str())) return 1;
+	}
+	return 0;
+}
+int opt_preset(mm_opt_t *o, const char *name)     /* preset tree, minialign.c:5853-5878 */
+{
+	std::string n(name); std::vector<std::string> parts; size_t st_ = 0;
+	for(size_t i = 0; i <= n.size(); i++) if(i == n.size() || n[i] == '.' || n[i] == ':') { parts.push_back(n.substr(st_, i - st_)); st_ = i + 1; }
+	if(parts.empty()) return 1;
+	if(parts[0] == "pacbio") {
+		opt_line(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3");
+		if(parts.size() > 1) { if(parts[1] == "ccs") opt_line(o, "-b5 -p6 -p2"); else if(parts[1] != "clr") return 1; }
+		return 0;
+	}
+	if(parts[0] == "ont") {
+		opt_line(o, "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3");
+		for(size_t i = 1; i < parts.size(); i++) {
+			const std::string &q = parts[i];
+			if(q == "r7") opt_line(o, "-b4");
+			else if(q == "r9" || q == "1") {}
+			else if(q == "4" || q == "5") opt_line(o, "-a2");
+			else if(q == "1d" || q == "2d" || q == "1dsq") {
+				bool under_r = i > 1;              /* leaves directly under "ont" also set -a2 */
+				if(q == "1d") { if(!under_r) opt_line(o, "-a2"); }
+				else { opt_line(o, under_r ? "-b6 -r4,4" : "-a2 -b6 -r4,4"); }
+			} else return 1;
+		}
+		return 0;
+	}
+	if(parts[0] == "ava") { opt_line(o, "-k15 -w5 -a2 -b3 -p0 -q2 -Y50 -s30 -m0.05"); return 0; }
+	return 1;
+}
+int opt_one(mm_opt_t *o, char c, const char *arg)
+{
+	switch(c) {
+		case 'x': return opt_preset(o, arg);
+		case 'k': o->k = atoi(arg); return !(o->k > 1 && o->k < 32);
+		case 'w': o->w = atoi(arg); return !(o->w > 1 && o->w < 32);
+		case 'a': { int m = atoi(arg); for(int i = 0; i < 16; i++) if((i & 3) == (i >> 2)) o->p.score_matrix[i] = (int8_t)m; return !(m > 0 && m < 7); }
+		case 'b': { int x = atoi(arg); for(int i = 0; i < 16; i++) if((i & 3) != (i >> 2)) o->p.score_matrix[i] = (int8_t)-x; return !(x > 0 && x < 7); }
+		case 'p': o->p.gi = (int8_t)atoi(arg); return 0;
+		case 'q': o->p.ge = (int8_t)atoi(arg); return 0;
+		case 'r': { o->p.gfa = o->p.gfb = (int8_t)atoi(arg); const char *cm = strchr(arg, ','); if(cm) o->p.gfb = (int8_t)atoi(cm + 1); return 0; }
+		case 'Y': o->p.xdrop = (int8_t)atoi(arg); return 0;
+		case 's': o->min_score = atoi(arg); return 0;
+		case 'm': o->min_ratio = (float)atof(arg); return 0;
+		case 't': o->nth = atoi(arg); return 0;
+		case 'W': o->wlen = atoi(arg); return 0;
+		case 'G': o->glen = atoi(arg); return 0;
+		default: fprintf(stderr, "[minialign_amd] unsupported option -%c\n", c); return 1;
+	}
+}
+} /* anonymous */
+
+extern "C" mm_opt_t *mm_opt_init(void) { return new mm_opt_s(); }
+extern "C" void mm_opt_destroy(mm_opt_t *o) { delete o; }
+extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char const **files, int max_files, int *n_files)
+{
+	int nf = 0;
+	o->arg_line.clear();
+	for(int i = 0; i < argc; i++) { if(i) o->arg_line += ' '; o->arg_line += argv[i]; }    /* mm_join(argv, ' '), minialign.c:6163 */
+	for(int i = 1; i < argc; i++) {
+		const char *a = argv[i];
+		if(a[0] == '-' && a[1]) {
+			const char *arg = a + 2;
+			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWG", a[1])) arg = argv[++i];
+			if(opt_one(o, a[1], arg)) return 1;
+		} else if(nf < max_files) files[nf++] = a;
+	}
+	if(n_files) *n_files = nf;
+	if(o->w >= 32) o->w = (uint32_t)(int)(2.0 / 3.0 * o->k + .499);       /* minialign.c:6111 */
+	return 0;
+}
+
+/* =============================================================================================
+ * index (host): mm_idx_gen, minialign.c:2951-3040
+ * ============================================================================================= */
+struct mm_idx_s {
+	uint32_t b, w, k, n_occ; uint32_t occ[4];
+	std::vector<HSeq> seq;
+	/* flattened table, also what the device gets */
+	std::vector<IdxSlot> slot; uint64_t mask;
+	std::vector<uint64_t> val;
+	uint64_t n_keys = 0;
+};
+
+extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
+{
+	mm_idx_t *mi = new mm_idx_s();
+	if(!read_seq_file(ref_fasta, mi->seq) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); delete mi; return NULL; }
+	uint32_t b = std::min(o->k * 2, o->b);
+	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq;
+	const uint64_t nb = 1ull << b, bmask = nb - 1;
+	/* sketch every sequence and push (hrem, pos, rid) to its bucket in reference order (minialign.c:2790-2860) */
+	std::vector<std::vector<Mini>> bkt(nb);
+	std::vector<HMin> mins;
+	for(uint32_t i = 0; i < mi->seq.size(); i++) {
+		mins.clear();
+		sketch_host(mi->seq[i].seq.data(), (uint32_t)mi->seq[i].seq.size(), o->k, o->w, mins);
+		for(const HMin &m : mins) bkt[m.hash & bmask].push_back(Mini{ m.hash >> b, m.pos, (i << 1) + m.strand });
+	}
+	/* per-bucket sort on hrem + occurrence histogram (minialign.c:2867-2900) */
+	std::vector<uint32_t> cnt;
+	for(auto &v : bkt) {
+		if(v.empty()) continue;
+		sort_minis(v.data(), v.size());
+		uint32_t n = 1;
+		for(size_t j = 1; j < v.size(); j++) { if(v[j - 1].hrem != v[j].hrem) { cnt.push_back(n); n = 0; } n++; }
+		cnt.push_back(n);
+	}
+	/* thresholds: (1 - frq)-quantile of the per-key counts, + 1 (minialign.c:2981-2986) */
+	std::vector<uint32_t> sorted(cnt); std::sort(sorted.begin(), sorted.end());
+	for(uint32_t i = 0; i < o->n_frq; i++) {
+		if(o->frq[i] <= 0.0) { mi->occ[i] = UINT32_MAX; continue; }
+		uint32_t kk = (uint32_t)((1.0 - o->frq[i]) * cnt.size());
+		mi->occ[i] = (cnt.empty() ? 0 : sorted[std::min<size_t>(kk, cnt.size() - 1)]) + 1;
+	}
+	/* key -> value-list map (minialign.c:2905-2944).  The reference stops advancing its fill cursor at the first key of a
+	 * bucket that exceeds the last threshold, which silently drops every later key of that bucket: kept. */
+	const uint64_t max_cnt = mi->occ[mi->n_occ - 1];
+	uint64_t n_keys = 0, n_multi_vals = 0;
+	for(auto &v : bkt) {
+		for(size_t j = 0; j < v.size();) { size_t e = j + 1; while(e < v.size() && v[e].hrem == v[j].hrem) e++; if(e - j > max_cnt) break; n_keys++; if(e - j > 1) n_multi_vals += e - j; j = e; }
+	}
+	uint64_t tsize = 1024; while(tsize < n_keys * 2) tsize <<= 1;
+	mi->slot.assign(tsize, IdxSlot{ 0, 0 }); mi->mask = tsize - 1; mi->val.reserve(n_multi_vals + 1); mi->n_keys = n_keys;
+	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
+	for(uint64_t bi = 0; bi < nb; bi++) {
+		auto &v = bkt[bi];
+		for(size_t j = 0; j < v.size();) {
+			size_t e = j + 1; while(e < v.size() && v[e].hrem == v[j].hrem) e++;
+			if(e - j > max_cnt) break;
+			uint64_t minier = (v[j].hrem << b) | bi, value;
+			if(e - j == 1) value = (uint64_t)v[j].pos | ((uint64_t)v[j].rid << 32);
+			else { value = (1ull << 63) | ((uint64_t)mi->val.size() << 24) | (uint64_t)(e - j); for(size_t x = j; x < e; x++) mi->val.push_back((uint64_t)v[x].pos | ((uint64_t)v[x].rid << 32)); }
+			uint64_t s = hash(minier) & mi->mask;
+			while(mi->slot[s].key != 0) s = (s + 1) & mi->mask;
+			mi->slot[s] = IdxSlot{ minier + 1, value };
+			j = e;
+		}
+		std::vector<Mini>().swap(v);
+	}
+	if(mi->val.empty()) mi->val.push_back(0);
+	return mi;
+}
+extern "C" void mm_idx_destroy(mm_idx_t *mi) { delete mi; }
+extern "C" uint32_t mm_idx_n_seq(mm_idx_t const *mi) { return (uint32_t)mi->seq.size(); }
+extern "C" uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i) { return mi->occ[i]; }
+extern "C" uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t max)
+{
+	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
+	uint64_t s = hash(minier) & mi->mask;
+	while(mi->slot[s].key != 0) {
+		if(mi->slot[s].key == minier + 1) {
+			uint64_t v = mi->slot[s].val;
+			if((int64_t)v >= 0) { if(max) out[0] = v; return 1; }
+			uint32_t n = (uint32_t)(v & 0xffffff); uint64_t off = (v & 0x7fffffffffffffffull) >> 24;
+			for(uint32_t i = 0; i < n && i < max; i++) out[i] = mi->val[off + i];
+			return n;
+		}
+		s = (s + 1) & mi->mask;
+	}
+	return 0;
+}
+
+/* =============================================================================================
+ * device context + batch pipeline
+ * ============================================================================================= */
+template<typename T> struct DBuf {
+	T *p = nullptr; uint64_t n = 0;
+	bool ensure(uint64_t want) { if(want <= n) return true; if(p) (void)hipFree(p); p = nullptr; n = 0; if(hipMalloc(&p, want * sizeof(T)) != hipSuccess) { fprintf(stderr, "[minialign_amd] hipMalloc of %.1f MB failed\n", want * sizeof(T) / 1e6); return false; } n = want; return true; }
+	void release() { if(p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct mm_align_s {
+	mm_opt_s o; const mm_idx_s *mi;
+	gaba_t *gctx;
+	DevIndex dix; IdxSlot *d_slot = nullptr; uint64_t *d_val = nullptr; uint32_t *d_seq_len = nullptr; uint64_t *d_seq_off = nullptr;
+	gaba_arena_t *ref_ar = nullptr;
+	uint32_t twlen, tglen; double mcoef, xcoef;
+	hipStream_t stream; hipEvent_t ev0, ev1;
+	uint32_t n_waves = 0;
+	/* pools */
+	DBuf<uint32_t> q_pk, q_nm; DBuf<ReadIn> d_in; DBuf<ReadState> d_st; DBuf<uint32_t> d_work;
+	DBuf<MinRec> min_pool; DBuf<Seed> seed_pool; DBuf<Resc> resc_pool; DBuf<Root> root_pool;
+	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
+	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
+	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
+	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
+	mm_stats_t st; double t_wall0;
+	/* knobs (grown on overflow) */
+	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
+};
+
+namespace {
+
+
+struct BatchOut {                       /* host copies of what post-map / SAM need */
+	std::vector<ReadState> st; std::vector<Root> root; std::vector<uint64_t> bin; std::vector<AlnRec> aln;
+	std::vector<gaba::Segment> seg; std::vector<uint32_t> path;
+};
+
+#define CK(_e) do { hipError_t _r = (_e); if(_r != hipSuccess) { fprintf(stderr, "[minialign_amd] HIP error %s at %s:%d\n", hipGetErrorString(_r), __FILE__, __LINE__); return false; } } while(0)
+
+/* run K1..K3 over `work` (indices into the batch) with rlen_in already stored in d_st[].rlen */
+bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &work_in, bool run_k1, std::vector<ReadState> &hst,
+	const std::vector<uint32_t> *rlen_fixed, const std::vector<uint32_t> &qlens)
+{
+	std::vector<uint32_t> work(work_in);
+	if(work.empty()) return true;
+	unsigned long long *tops = a->d_tops.p;
+	float ms;
+	if(run_k1) {
+		CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
+		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
+		K1Args k1; k1.idx = a->dix; k1.qar = gaba::SeqArena{ a->q_pk.p, a->q_nm.p }; k1.in = a->d_in.p; k1.st = a->d_st.p; k1.n_reads = (uint32_t)work.size();
+		k1.min_pool = a->min_pool.p; k1.seed_pool = a->seed_pool.p; k1.seed_pool_cap = a->seed_pool.n; k1.seed_top = tops + 0;
+		k1.resc_pool = a->resc_pool.p; k1.resc_pool_cap = a->resc_pool.n; k1.resc_top = tops + 1;
+		k1.root_pool = a->root_pool.p; k1.root_pool_cap = a->root_pool.n; k1.root_top = tops + 2;
+		k1.counter = (uint32_t *)(tops + 16); k1.stats = tops + 8; k1.work = a->d_work.p;
+		uint32_t waves = std::min<uint32_t>(a->n_waves, (uint32_t)((work.size() + 3) & ~3ull));
+		CK(hipEventRecord(a->ev0, a->stream));
+		hipLaunchKernelGGL(mm_sketch_seed_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k1);
+		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
+		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k1_ms += ms; a->st.k1_launches++;
+	}
+	for(uint32_t round = 0; round < a->mi->n_occ && !work.empty(); round++) {
+		CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
+		K2Args k2; k2.idx = a->dix; k2.st = a->d_st.p; k2.work = a->d_work.p; k2.n_work = (uint32_t)work.size(); k2.round = round;
+		k2.seed_pool = a->seed_pool.p; k2.resc_pool = a->resc_pool.p; k2.root_pool = a->root_pool.p;
+		if(!a->rs_scratch.ensure((uint64_t)work.size() * a->rs_stride)) return false;
+		k2.rs_scratch = a->rs_scratch.p; k2.rs_stride = a->rs_stride; k2.twlen = a->twlen; k2.mcoef = a->mcoef; k2.min_score = a->o.min_score;
+		CK(hipEventRecord(a->ev0, a->stream));
+		hipLaunchKernelGGL(mm_sort_chain_kernel, dim3((uint32_t)((work.size() + 63) / 64)), dim3(64), 0, a->stream, k2);
+		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
+		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k2_ms += ms; a->st.k2_launches++;
+
+		if(round == 0) {
+			/* seed the carried reference-length state (see ReadIn.rlen_in): either given exactly (re-runs), or predicted from
+			 * the chain lists: read i starts with the length of the last reference read i - 1 loads */
+			CK(hipMemcpy(hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost));
+			if(rlen_fixed) { for(size_t i = 0; i < work.size(); i++) hst[work[i]].rlen = (*rlen_fixed)[i]; }
+			else {
+				uint32_t cur = a->rlen_carry;
+				for(uint32_t i = 0; i < n_reads; i++) {
+					hst[i].rlen = cur;
+					if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size();
+				}
+			}
+			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
+			CK(hipMemcpy(a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState), hipMemcpyHostToDevice));
+		}
+		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
+		K3Args k3; k3.idx = a->dix; k3.gc = a->gctx->dc; k3.roots = a->gctx->droots; k3.ar_ref = gaba::SeqArena{ a->ref_ar->pk, a->ref_ar->nm }; k3.ar_q = gaba::SeqArena{ a->q_pk.p, a->q_nm.p };
+		k3.in = a->d_in.p; k3.st = a->d_st.p; k3.work = a->d_work.p; k3.n_work = (uint32_t)work.size();
+		k3.seed_pool = a->seed_pool.p; k3.root_pool = a->root_pool.p; k3.slabs = a->slabs.p; k3.slab_bytes = a->slabs.n / a->n_waves;
+		k3.kh_pool = a->kh_pool.p; k3.kh_cap = a->kh_cap; k3.round = round; k3.next_pool = a->next_pool.p; k3.next_cap = a->next_cap;
+		k3.bin_pool = a->bin_pool.p; k3.bin_pool_cap = a->bin_pool.n; k3.bin_top = tops + 3; k3.bin_cap_per_read = a->bin_cap;
+		k3.aln_pool = a->aln_pool.p; k3.aln_pool_cap = a->aln_pool.n; k3.aln_top = tops + 4; k3.aln_cap_per_read = a->aln_cap;
+		k3.seg_pool = a->seg_pool.p; k3.seg_pool_cap = a->seg_pool.n; k3.seg_top = tops + 5;
+		k3.path_pool = a->path_pool.p; k3.path_pool_cap = a->path_pool.n; k3.path_top = tops + 6;
+		k3.tglen = a->tglen; k3.mcoef = a->mcoef; k3.min_ratio = a->o.min_ratio; k3.min_score = a->o.min_score;
+		k3.counter = (uint32_t *)(tops + 16); k3.stats = tops + 8;
+		uint32_t waves = std::min<uint32_t>(a->n_waves, (uint32_t)((work.size() + 3) & ~3ull));
+		CK(hipEventRecord(a->ev0, a->stream));
+		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k3);
+		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
+		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
+		/* next round: reads that still have no result (minialign.c:4444-4448) */
+		CK(hipMemcpy(hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost));
+		std::vector<uint32_t> nxt;
+		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u)) nxt.push_back(wi);
+		work.swap(nxt);
+	}
+	(void)qlens;
+	return true;
+}
+
+/* ---- post-map on the host (minialign.c:4185-4398) ---- */
+struct OutAln { uint32_t aln; uint32_t mapq; };
+struct OutReg { uint32_t n_all = 0, n_uniq = 0; std::vector<OutAln> aln; bool mapped = false; };
+inline uint32_t clip_mapq(double x) { uint32_t v = h_d2u32(x); return std::min<uint32_t>(v, 60 * 16); }
+
+void post_map(const mm_align_t *a, const ReadState &rs, Root *res, uint64_t *bin, const AlnRec *alns, OutReg &out)
+{
+	uint32_t n_res = rs.n_res;
+	out.mapped = n_res > 0;
+	if(!n_res) return;
+	sort_res((ResEnt *)res, n_res);                                       /* radix_sort_64x, minialign.c:4452 */
+	/* mm_prune_regs */
+	uint64_t q = n_res;
+	uint32_t minv = (uint32_t)h_ofs((int32_t)h_f2u32((float)h_ofs((int32_t)res[0].plen) * a->o.min_ratio));
+	while(res[--q].plen > minv) {}
+	n_res = (uint32_t)(q + 1);
+	uint32_t n_all = n_res;
+	auto hdr = [&](uint32_t iid) { return (uint32_t *)&bin[iid]; };        /* { n_aln, plen, lb, ub } */
+	/* mm_collect_supp */
+	uint64_t p, qq;
+	for(p = 1, qq = n_res; p < qq; p++) {
+		uint64_t mx = 0;
+		for(uint64_t i = p; i < qq; i++) {
+			uint32_t *s = hdr(res[i].lid);
+			int64_t lb = s[2], ub = s[3], span = ub - lb; bool covered = false;
+			for(uint64_t j = 0; j < p; j++) {
+				uint32_t *t = hdr(res[j].lid);
+				if((int64_t)t[3] < ub) lb = std::max<int64_t>(lb, t[3]); else ub = std::min<int64_t>(ub, t[2]);
+				if(1.2 * (double)(ub - lb) < (double)span) { qq--; std::swap(res[i], res[qq]); i--; covered = true; break; }
+			}
+			if(covered) continue;
+			mx = std::max<uint64_t>(mx, ((uint64_t)(2 * (ub - lb) - span) << 32) | i);
+		}
+		if(mx & 0xffffffff) std::swap(res[p], res[mx & 0xffffffff]);
+	}
+	p = std::min(p, qq);
+	/* mm_post_map */
+	int64_t usc = 0, lsc = INT64_MAX, tsc = 0;
+	for(uint64_t i = p; i < n_res; i++) { int64_t sc = h_ofs((int32_t)res[i].plen); usc = std::max(usc, sc); lsc = std::min(lsc, sc); tsc += sc; }
+	lsc = (lsc == INT32_MAX) ? 0 : lsc;
+	double tpc = 1.0, x = a->xcoef, mxc = a->mcoef + a->xcoef;
+	for(uint64_t i = 0; i < p; i++) {
+		uint32_t score = (uint32_t)h_ofs((int32_t)res[i].plen);
+		uint32_t *b = hdr(res[i].lid);
+		double pid = 0.0; uint64_t len = 0;
+		for(uint32_t j = 0; j < b[0]; j++) { const AlnRec &al = alns[bin[res[i].lid + 2 + j] - 1]; len += al.plen; pid += (double)al.plen * al.identity; }
+		pid /= (double)len;
+		double ec = 2.0 / (pid * mxc - x);
+		double ulen = ec * (double)std::max<int64_t>((int64_t)score - usc, 0), pe = 1.0 / (ulen * ulen + 1);
+		b[1] = clip_mapq(-10.0 * 16 * log10(pe));
+		tpc *= 1.0 - pe;
+	}
+	double tpe = std::min(1.0 - tpc, 1.0);
+	for(uint64_t i = p; i < n_res; i++) {
+		uint32_t *b = hdr(res[i].lid);
+		b[1] = clip_mapq(-10.0 * 16 * log10(1.0 - tpe * (double)(int64_t)((int64_t)res[i].plen - lsc + 1) / (double)tsc));
+	}
+	/* mm_pack_reg */
+	for(uint64_t i = 0; i < n_all; i++) {
+		uint32_t *b = hdr(res[i].lid);
+		for(uint32_t j = 0; j < b[0]; j++) out.aln.push_back(OutAln{ (uint32_t)(bin[res[i].lid + 2 + j] - 1), b[1] });
+		if(i == p - 1) out.n_uniq = (uint32_t)out.aln.size();
+	}
+	out.n_all = (uint32_t)out.aln.size();
+}
+
+/* ---- CIGAR from path bits (gaba_parse.h:168-221, reverse parser) ---- */
+inline uint64_t path_u64(const uint64_t *ptr, int64_t pos) { int64_t rem = pos & 63; return (ptr[pos >> 6] >> rem) | ((ptr[(pos >> 6) + 1] << (63 - rem)) << 1); }
+inline uint64_t lzc(uint64_t x) { return x ? (uint64_t)__builtin_clzll(x) : 64; }
+inline void put_num(std::string &s, uint64_t v) { char b[24]; int n = 0; if(!v) b[n++] = '0'; while(v) { b[n++] = (char)('0' + v % 10); v /= 10; } while(n) s.push_back(b[--n]); }
+void cigar_reverse(std::string &out, const uint32_t *path, uint64_t offset, uint64_t len)
+{
+	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
+	uint64_t ofs = (uint64_t)((int64_t)offset + (((uintptr_t)path & 4) ? 32 : 0) - 64), idx = len;
+	while((int64_t)idx > 0) {
+		uint64_t m = lzc(path_u64(p, (int64_t)(ofs + idx))), c = std::min(idx, m - (m > 0));
+		idx -= c; if(c) { put_num(out, c); out.push_back('D'); }
+		m = lzc(~path_u64(p, (int64_t)(ofs + idx))); c = std::min(idx, m);
+		idx -= c; if(c) { put_num(out, c); out.push_back('I'); }
+		uint64_t sidx = idx;
+		do { m = lzc(path_u64(p, (int64_t)(ofs + idx)) ^ 0x5555555555555555ull); c = std::min(idx, m) & ~1ull; idx -= c; } while(c == 64);
+		if((sidx - idx) >> 1) { put_num(out, (sidx - idx) >> 1); out.push_back('M'); }
+	}
+}
+
+/* ---- SAM (minialign.c:5127-5198, 5390-5426), default tag set ---- */
+void sam_seq(std::string &s, const uint8_t *q, uint32_t n, bool rev)
+{
+	static const char fw[] = "ACGTN\0\0\0\0\0\0\0\0\0\0\0", rv[] = "TGCAN\0\0\0\0\0\0\0\0\0\0\0";
+	size_t o = s.size(); s.resize(o + n);
+	if(!rev) for(uint32_t i = 0; i < n; i++) s[o + i] = fw[q[i] & 15];
+	else for(uint32_t i = 0; i < n; i++) s[o + i] = rv[q[n - 1 - i] & 15];
+}
+void sam_record(const mm_align_t *a, std::string &s, const char *qname, const uint8_t *qseq, uint32_t qlen, const OutReg &reg,
+	const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths)
+{
+	if(!reg.mapped || reg.n_all == 0) {
+		s += qname; s += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; sam_seq(s, qseq, qlen, false); s += "\t*\n";
+		return;
+	}
+	uint32_t flag = 0;
+	for(uint32_t i = 0; i < reg.n_all; i++) {
+		if(i >= reg.n_uniq) flag = 0x100;
+		const AlnRec &al = alns[reg.aln[i].aln];
+		for(uint32_t j = al.slen; j > 0; j--) {
+			const gaba::Segment &sg = segs[al.seg_off + j - 1];
+			const HSeq &r = a->mi->seq[sg.aid >> 1];
+			uint32_t rs = (uint32_t)r.seq.size() - sg.apos - sg.alen;
+			uint32_t hl = qlen - sg.bpos - sg.blen, tl = sg.bpos;
+			uint32_t qs = (flag & 0x900) ? hl : 0, qe = qlen - ((flag & 0x900) ? tl : 0);
+			s += qname; s.push_back('\t'); put_num(s, flag | ((~sg.bid & 1) << 4)); s.push_back('\t');
+			s += r.name; s.push_back('\t'); put_num(s, rs + 1); s.push_back('\t'); put_num(s, reg.aln[i].mapq >> 4); s.push_back('\t');
+			char clip = (flag & 0x900) ? 'H' : 'S';
+			if(hl) { put_num(s, hl); s.push_back(clip); }
+			cigar_reverse(s, paths + al.path_off, sg.ppos, (uint64_t)sg.alen + sg.blen);
+			if(tl) { put_num(s, tl); s.push_back(clip); }
+			s += "\t*\t0\t0\t";
+			if(sg.bid & 1) sam_seq(s, qseq + qs, qe - qs, false); else sam_seq(s, qseq + (qlen - qe), qe - qs, true);
+			s += "\t*";
+			if(i == 0 && j == al.slen) flag = 0x800;
+			s.push_back('\n');
+		}
+		flag = 0x800;
+	}
+}
+
+bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_qlen, uint64_t scale)
+{
+	bool ok = true;
+	ok &= a->d_in.ensure(n_reads); ok &= a->d_st.ensure(n_reads); ok &= a->d_work.ensure(n_reads);
+	ok &= a->q_pk.ensure(bases / 16 + 8); ok &= a->q_nm.ensure(bases / 32 + 8);
+	ok &= a->min_pool.ensure(bases / 2 + 64ull * n_reads + 1024);
+	ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
+	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
+	ok &= a->resc_pool.ensure(bases / 2 + 64ull * n_reads + 1024);
+	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
+	ok &= a->next_pool.ensure((uint64_t)a->n_waves * a->next_cap);
+	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap);
+	ok &= a->aln_pool.ensure(((uint64_t)n_reads + 2048) * a->aln_cap);
+	ok &= a->seg_pool.ensure((uint64_t)n_reads * a->aln_cap * 2 + 4096);
+	ok &= a->path_pool.ensure((bases / 4 + 1024ull * n_reads) * scale + (1ull << 20));
+	/* DP workspace: a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors */
+	uint64_t blocks = 2 * ((2ull * max_qlen + 8192) / 32 + 64);
+	uint64_t slab = (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull;
+	ok &= a->slabs.ensure(slab * a->n_waves);
+	if(ok && a->slabs.n != slab * a->n_waves) { /* keep the per-wave stride derived from the current allocation */ }
+	ok &= a->d_tops.ensure(32);
+	return ok;
+}
+
+} /* anonymous */
+
+extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
+{
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "[minialign_amd] mm_align_init: no HIP device available (the device stages have no CPU path)\n"); return NULL; }
+	mm_align_t *a = new mm_align_s();
+	a->o = *o; a->mi = mi;
+	a->gctx = gaba_init(&o->p);
+	if(!a->gctx) { fprintf(stderr, "[minialign_amd] mm_align_init: scoring parameters rejected\n"); delete a; return NULL; }
+	a->twlen = (uint32_t)(((int32_t)o->wlen << 1) - (int32_t)o->wlen); a->tglen = (uint32_t)(((int32_t)o->glen << 1) - (int32_t)o->glen);   /* _ud(wlen, wlen), minialign.c:4506 */
+	/* mcoef / xcoef: both accumulate score_matrix[0] in the reference (minialign.c:4676-4681); kept */
+	double mc = 0, xc = 0; for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 3)) mc += o->p.score_matrix[0]; else xc += o->p.score_matrix[0]; }
+	a->mcoef = mc / 4.0; a->xcoef = xc / 12.0;
+	if(hipStreamCreate(&a->stream) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) { delete a; return NULL; }
+	/* reference: one arena, per-sequence offsets */
+	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
+	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
+	std::vector<uint8_t> all(total + 64, 4);
+	for(size_t i = 0; i < mi->seq.size(); i++) memcpy(all.data() + off[i], mi->seq[i].seq.data(), mi->seq[i].seq.size());
+	a->ref_ar = gaba_arena_upload(all.data(), total + 64);
+	if(!a->ref_ar) { delete a; return NULL; }
+	bool ok = true;
+	ok &= hipMalloc(&a->d_slot, mi->slot.size() * sizeof(IdxSlot)) == hipSuccess;
+	ok &= hipMalloc(&a->d_val, mi->val.size() * 8) == hipSuccess;
+	ok &= hipMalloc(&a->d_seq_len, len.size() * 4) == hipSuccess && hipMalloc(&a->d_seq_off, off.size() * 8) == hipSuccess;
+	if(!ok) { fprintf(stderr, "[minialign_amd] mm_align_init: index upload failed\n"); delete a; return NULL; }
+	(void)hipMemcpy(a->d_slot, mi->slot.data(), mi->slot.size() * sizeof(IdxSlot), hipMemcpyHostToDevice);
+	(void)hipMemcpy(a->d_val, mi->val.data(), mi->val.size() * 8, hipMemcpyHostToDevice);
+	(void)hipMemcpy(a->d_seq_len, len.data(), len.size() * 4, hipMemcpyHostToDevice);
+	(void)hipMemcpy(a->d_seq_off, off.data(), off.size() * 8, hipMemcpyHostToDevice);
+	a->dix.slot = a->d_slot; a->dix.mask = mi->mask; a->dix.val = a->d_val; a->dix.seq_len = a->d_seq_len; a->dix.seq_off = a->d_seq_off;
+	a->dix.n_seq = (uint32_t)mi->seq.size(); a->dix.k = mi->k; a->dix.w = mi->w; a->dix.n_occ = mi->n_occ;
+	for(int i = 0; i < 4; i++) a->dix.occ[i] = i < (int)mi->n_occ ? mi->occ[i] : 0;
+	hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
+	a->n_waves = (uint32_t)prop.multiProcessorCount * 16;
+	memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms();
+	return a;
+}
+extern "C" void mm_align_destroy(mm_align_t *a)
+{
+	if(!a) return;
+	(void)hipFree(a->d_slot); (void)hipFree(a->d_val); (void)hipFree(a->d_seq_len); (void)hipFree(a->d_seq_off);
+	gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
+	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
+	a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release();
+	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
+	delete a;
+}
+extern "C" void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line)
+{
+	fputs("@HD\tVN:1.0\tSO:unsorted\n", out);
+	for(const HSeq &s : a->mi->seq) fprintf(out, "@SQ\tSN:%s\tLN:%u\n", s.name.c_str(), (uint32_t)s.seq.size());
+	fprintf(out, "@PG\tID:minialign\tPN:minialign\tVN:%s\tCL:%s\n", "0.6.0-devel", arg_line ? arg_line : "");
+}
+extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
+{
+	a->st.wall_ms = now_ms() - a->t_wall0;
+	if(out) *out = a->st;
+	if(reset) { memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms(); }
+}
+
+namespace {
+/* one batch: device pipeline + re-runs for the carried reference-length state + host post-map + SAM text */
+bool align_batch(mm_align_t *a, const uint8_t *bases, const uint32_t *lens, const char *const *names, uint32_t n_reads, std::string &sam, BatchOut *keep)
+{
+	if(n_reads == 0) return true;
+	uint64_t total = 0; uint32_t max_qlen = 0; std::vector<uint64_t> qoff(n_reads);
+	for(uint32_t i = 0; i < n_reads; i++) { qoff[i] = total; total += ((uint64_t)lens[i] + 63) & ~63ull; max_qlen = std::max(max_qlen, lens[i]); }
+	std::vector<uint64_t> hoff(n_reads); { uint64_t t = 0; for(uint32_t i = 0; i < n_reads; i++) { hoff[i] = t; t += lens[i]; } }
+	for(uint64_t scale = 1; scale <= 64; scale *= 4) {
+		if(!ensure_pools(a, n_reads, total + 64, max_qlen, scale)) return false;
+		/* upload reads */
+		std::vector<uint32_t> pk((total + 64) / 16 + 8, 0), nm((total + 64) / 32 + 8, 0);
+		std::vector<ReadIn> in(n_reads); std::vector<ReadState> hst(n_reads);
+		uint64_t moff = 0;
+		std::vector<uint32_t> work;
+		for(uint32_t i = 0; i < n_reads; i++) {
+			pack_bases(bases + hoff[i], lens[i], pk, nm, qoff[i]);
+			in[i] = ReadIn{ qoff[i], lens[i], 0 };
+			memset(&hst[i], 0, sizeof(ReadState));
+			hst[i].min_off = moff; hst[i].min_cap = lens[i] / 2 + 64; moff += hst[i].min_cap;
+			hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL;
+			/* unmappable reads are skipped outright (minialign.c:4434) */
+			if(!(lens[i] < a->mi->k || lens[i] * a->mcoef < (double)a->o.min_score)) work.push_back(i);
+		}
+		CK(hipMemcpy(a->q_pk.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(a->q_nm.p, nm.data(), nm.size() * 4, hipMemcpyHostToDevice));
+		CK(hipMemcpy(a->d_in.p, in.data(), n_reads * sizeof(ReadIn), hipMemcpyHostToDevice));
+		CK(hipMemcpy(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice));
+		CK(hipMemset(a->d_tops.p, 0, 32 * 8));
+		std::vector<uint32_t> qlens(lens, lens + n_reads);
+		if(!run_rounds(a, n_reads, work, true, hst, nullptr, qlens)) return false;
+
+		/* the carried reference length: verify the prediction read by read, re-run the reads it changes */
+		std::vector<uint32_t> used(n_reads); for(uint32_t i = 0; i < n_reads; i++) used[i] = 0;
+		{
+			/* what was used: recompute the same prediction chain */
+			uint32_t cur = a->rlen_carry;
+			for(uint32_t i = 0; i < n_reads; i++) { used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size(); }
+		}
+		bool overflow = false;
+		for(int iter = 0; iter < 64; iter++) {
+			std::vector<uint32_t> redo, redo_rlen;
+			uint32_t cur = a->rlen_carry;
+			for(uint32_t i = 0; i < n_reads; i++) {
+				if(hst[i].err) overflow = true;
+				uint32_t truth = cur;
+				if(truth != used[i] && hst[i].apos0 != gaba::NIL && !hst[i].cond0 && ((hst[i].apos0 >= used[i]) != (hst[i].apos0 >= truth))) { redo.push_back(i); redo_rlen.push_back(truth); }
+				/* rounds after the first start from the length the previous round left behind: same state variable */
+				uint32_t out = hst[i].rid_last != gaba::NIL ? (uint32_t)a->mi->seq[hst[i].rid_last].seq.size() : truth;
+				cur = out;
+			}
+			if(redo.empty() || overflow) break;
+			a->st.reruns += redo.size();
+			/* reset and re-run the affected reads from the sketch on */
+			for(size_t j = 0; j < redo.size(); j++) {
+				uint32_t i = redo[j]; uint64_t mo = hst[i].min_off; uint32_t mc = hst[i].min_cap;
+				memset(&hst[i], 0, sizeof(ReadState)); hst[i].min_off = mo; hst[i].min_cap = mc;
+				hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL;
+				used[i] = redo_rlen[j];
+			}
+			CK(hipMemcpy(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice));
+			if(!run_rounds(a, n_reads, redo, true, hst, &redo_rlen, qlens)) return false;
+		}
+		if(overflow) { a->bin_cap *= 2; a->aln_cap *= 2; a->kh_cap *= 4; a->next_cap *= 2; a->rs_stride = 512 + (a->rs_stride - 512) * 4; continue; }
+		{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
+
+		/* download results */
+		unsigned long long tops[32]; CK(hipMemcpy(tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
+		a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
+		a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += lens[i];
+		double t0 = now_ms();
+		std::vector<Root> root(std::max<uint64_t>(tops[2], 1)); std::vector<uint64_t> bin(std::max<uint64_t>(tops[3], 1)); std::vector<AlnRec> aln(std::max<uint64_t>(tops[4], 1));
+		std::vector<gaba::Segment> seg(std::max<uint64_t>(tops[5], 1)); std::vector<uint32_t> path(std::max<uint64_t>(tops[6], 2) + 8);
+		CK(hipMemcpy(root.data(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost));
+		CK(hipMemcpy(bin.data(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(aln.data(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost));
+		CK(hipMemcpy(seg.data(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost));
+		CK(hipMemcpy(path.data(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost));
+		/* post-map + SAM, in input order */
+		double t1 = now_ms();
+		char nbuf[32];
+		for(uint32_t i = 0; i < n_reads; i++) {
+			OutReg reg;
+			const ReadState &rs = hst[i];
+			const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.data();
+			if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
+			const char *nm_ = names ? names[i] : (snprintf(nbuf, sizeof(nbuf), "r%u", i), nbuf);
+			sam_record(a, sam, nm_, bases + hoff[i], lens[i], reg, alns, seg.data(), path.data());
+		}
+		a->st.host_post_ms += t1 - t0; a->st.host_sam_ms += now_ms() - t1;
+		(void)keep;
+		return true;
+	}
+	fprintf(stderr, "[minialign_amd] batch does not fit the device pools\n");
+	return false;
+}
+} /* anonymous */
+
+extern "C" int mm_align_batch(mm_align_t *a, uint8_t const *bases, uint32_t const *lens, char const *const *names, uint32_t n_reads, char **sam, uint64_t *sam_len)
+{
+	std::string s;
+	if(!align_batch(a, bases, lens, names, n_reads, s, nullptr)) return -1;
+	uint64_t old = *sam ? *sam_len : 0;
+	*sam = (char *)realloc(*sam, old + s.size() + 1);
+	memcpy(*sam + old, s.data(), s.size()); (*sam)[old + s.size()] = 0; *sam_len = old + s.size();
+	return 0;
+}
+
+extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
+{
+	std::vector<HSeq> reads;
+	if(!read_seq_file(reads_fn, reads)) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
+	/* batches: bounded by bases so that the device pools stay modest */
+	const uint64_t max_bases = 512ull << 20; const uint32_t max_reads = 1u << 17;
+	size_t i = 0;
+	while(i < reads.size()) {
+		size_t j = i; uint64_t nb = 0;
+		while(j < reads.size() && j - i < max_reads && (nb == 0 || nb + reads[j].seq.size() <= max_bases)) { nb += reads[j].seq.size(); j++; }
+		std::vector<uint8_t> cat; cat.reserve(nb); std::vector<uint32_t> lens; std::vector<const char *> names;
+		for(size_t r = i; r < j; r++) { cat.insert(cat.end(), reads[r].seq.begin(), reads[r].seq.end()); lens.push_back((uint32_t)reads[r].seq.size()); names.push_back(reads[r].name.c_str()); }
+		std::string sam;
+		if(!align_batch(a, cat.data(), lens.data(), names.data(), (uint32_t)(j - i), sam, nullptr)) return 1;
+		fwrite(sam.data(), 1, sam.size(), out);
+		i = j;
+	}
+	return 0;
+}
+
+extern "C" int mm_main(int argc, char **argv)
+{
+	mm_opt_t *o = mm_opt_init();
+	const char *files[8]; int nf = 0;
+	if(mm_opt_parse(o, argc, (char const *const *)argv, files, 8, &nf) || nf < 2) {
+		fprintf(stderr, "usage: minialign [-x preset] [-k -w -a -b -p -q -r -Y -s -m -t] ref.fa reads.{fa,fq} > out.sam\n");
+		mm_opt_destroy(o); return 1;
+	}
+	double t0 = now_ms();
+	mm_idx_t *mi = mm_idx_gen(o, files[0]);
+	if(!mi) { mm_opt_destroy(o); return 1; }
+	mm_align_t *a = mm_align_init(o, mi);
+	if(!a) { mm_idx_destroy(mi); mm_opt_destroy(o); return 1; }
+	fprintf(stderr, "[M::main_align::%.3f] loaded/built index for %u target sequence(s).\n", (now_ms() - t0) * 1e-3, mm_idx_n_seq(mi));
+	mm_print_sam_header(a, stdout, o->arg_line.c_str());
+	int rc = 0;
+	for(int i = 1; i < nf && rc == 0; i++) {
+		rc = mm_align_file(a, files[i], stdout);
+		fprintf(stderr, "[M::main_align::%.3f] finished mapping `%s' onto `%s'.\n", (now_ms() - t0) * 1e-3, files[i], files[0]);
+	}
+	mm_stats_t st; mm_stats(a, &st, 0);
+	fprintf(stderr, "[M::main] %lu reads, %lu bases; kernels: sketch %.1f ms, sort+chain %.1f ms, extend %.1f ms; host post-map %.1f ms, SAM %.1f ms; %lu re-run(s)\n",
+		(unsigned long)st.reads, (unsigned long)st.bases, st.k1_ms, st.k2_ms, st.k3_ms, st.host_post_ms, st.host_sam_ms, (unsigned long)st.reruns);
+	mm_align_destroy(a); mm_idx_destroy(mi); mm_opt_destroy(o);
+	return rc;
+}

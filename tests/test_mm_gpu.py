@@ -1,0 +1,53 @@
+"""GPU parity for the whole mapper path: SAM from the HIP pipeline (minialign_amd/minialign, i.e. mm_main in
+libminialign_amd.so) must be byte-identical to (1) the committed golden SAM of the compiled reference, (2) the CPU oracle,
+and (3) -- when it travelled with the snapshot -- the reference binary itself, on seeded synthetic sets."""
+import gzip, hashlib, json, os, subprocess, tempfile
+import pytest
+import mmlib as M
+from golden.make_mm_golden import make_inputs
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+META = json.load(open(os.path.join(HERE, 'golden', 'mm_golden.json')))
+CLI = os.path.join(M.ROOT, 'minialign_amd', 'minialign')
+
+def _strip_pg(sam):
+    return b''.join(l for l in sam.splitlines(True) if not l.startswith(b'@PG'))
+
+def _run(exe, preset, ref, rd):
+    r = subprocess.run([exe, '-x' + preset, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return _strip_pg(r.stdout)
+
+def _first_diff(a, b):
+    la, lb = a.split(b'\n'), b.split(b'\n')
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return 'line %d:\n  got  %r\n  want %r' % (i, x[:300], y[:300])
+    return 'lengths differ: %d vs %d lines' % (len(la), len(lb))
+
+@pytest.fixture(scope='module')
+def workdir():
+    with tempfile.TemporaryDirectory() as d:
+        yield d
+
+@pytest.mark.parametrize('s', META['sets'], ids=[s['name'] for s in META['sets']])
+def test_sam_matches_golden(s, workdir):
+    ref, rd = make_inputs(s, workdir)
+    got = _run(CLI, s['preset'], ref, rd)
+    want = gzip.open(os.path.join(HERE, 'golden', s['name'] + '.sam.gz')).read()
+    assert got == want, _first_diff(got, want)
+
+@pytest.mark.parametrize('s', [
+    dict(name='g_multi', preset='pacbio', genome=(301, 600000, 30, 0.10), reads=(302, 1.0, 'pacbio', 'fa', 4000, 1500)),
+    dict(name='g_rep', preset='pacbio', genome=(311, 250000, 2, 0.50), reads=(312, 1.0, 'pacbio', 'fa', 5000, 2000)),
+    dict(name='g_ont', preset='ont.1dsq', genome=(321, 500000, 6, 0.10), reads=(322, 1.0, 'ont', 'fa')),
+], ids=lambda s: s['name'])
+def test_sam_matches_oracle(s, workdir):
+    ref, rd = make_inputs(s, workdir)
+    got = _run(CLI, s['preset'], ref, rd)
+    want = _run(os.path.join(M.ROOT, 'oracle', 'ora_minialign'), s['preset'], ref, rd)
+    assert got == want, _first_diff(got, want)
+    refbin = os.path.join(M.ROOT, 'oracle', '_ref', 'minialign')
+    if os.path.exists(refbin):
+        assert got == _run(refbin, s['preset'], ref, rd)
