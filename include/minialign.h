@@ -56,10 +56,20 @@ void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line);
 int mm_align_batch(mm_align_t *a, uint8_t const *bases, uint32_t const *lens, char const *const *names, uint32_t n_reads,
 	char **sam, uint64_t *sam_len);
 
-/* stage taps for the parity tests: run the device sketch / seed / chain stages for ONE read and copy the results */
-uint64_t mm_stage_sketch(mm_align_t *a, uint8_t const *seq, uint32_t len, uint64_t *qpos_n_ref, uint64_t max);   /* per minimizer: qs | n << 32 */
-uint64_t mm_stage_seed_chain(mm_align_t *a, uint8_t const *seq, uint32_t len, uint32_t rounds, uint32_t *seeds, uint64_t max_seeds,
-	uint64_t *roots, uint64_t max_roots, uint64_t *n_roots);
+/* the same batch in three phases, so that callers can keep inputs resident in HBM and time the hot path alone:
+ * upload (parse-free H2D of 2-bit packed reads) -> run (K1 sketch/lookup/expand, K2 sort/chain, K3 extend, in rounds;
+ * results stay in HBM) -> finish (D2H, post-map, SAM text appended to *sam).  mm_batch_run may be repeated. */
+typedef struct mm_reads_s mm_reads_t;
+typedef struct mm_batch_s mm_batch_t;
+mm_reads_t *mm_reads_load(char const *fn);
+void mm_reads_free(mm_reads_t *r);
+uint32_t mm_reads_count(mm_reads_t const *r);
+uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t n);
+mm_batch_t *mm_batch_upload(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n);
+int mm_batch_run(mm_align_t *a, mm_batch_t *b);
+int mm_batch_finish(mm_align_t *a, mm_batch_t *b, char **sam, uint64_t *sam_len);
+void mm_batch_free(mm_batch_t *b);
+int mm_set_device(int dev);
 
 /* timing / work counters of everything run since the last reset */
 typedef struct {

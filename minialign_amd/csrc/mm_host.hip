@@ -679,131 +679,189 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 	if(reset) { memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms(); }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * a batch in three phases: upload (H2D of packed reads), run (the hot path: K1..K3 in rounds plus the re-runs the
+ * carried reference-length state asks for; results stay in HBM), finish (D2H, post-map, SAM text)
+ * --------------------------------------------------------------------------------------------- */
+struct mm_reads_s { std::vector<HSeq> r; uint64_t bases = 0; };
+struct Batch {
+	uint32_t n = 0; uint64_t total = 0; uint32_t max_qlen = 0;
+	std::vector<uint32_t> lens; std::vector<uint64_t> qoff; std::vector<const uint8_t *> seq; std::vector<std::string> names;
+	std::vector<uint32_t> pk, nm; std::vector<ReadIn> in; std::vector<ReadState> hst; std::vector<uint32_t> work;
+	uint64_t scale = 1; bool uploaded = false, ran = false;
+};
 namespace {
-/* one batch: device pipeline + re-runs for the carried reference-length state + host post-map + SAM text */
-bool align_batch(mm_align_t *a, const uint8_t *bases, const uint32_t *lens, const char *const *names, uint32_t n_reads, std::string &sam, BatchOut *keep)
+bool batch_upload(mm_align_t *a, Batch &b)
 {
-	if(n_reads == 0) return true;
-	uint64_t total = 0; uint32_t max_qlen = 0; std::vector<uint64_t> qoff(n_reads);
-	for(uint32_t i = 0; i < n_reads; i++) { qoff[i] = total; total += ((uint64_t)lens[i] + 63) & ~63ull; max_qlen = std::max(max_qlen, lens[i]); }
-	std::vector<uint64_t> hoff(n_reads); { uint64_t t = 0; for(uint32_t i = 0; i < n_reads; i++) { hoff[i] = t; t += lens[i]; } }
-	for(uint64_t scale = 1; scale <= 64; scale *= 4) {
-		if(!ensure_pools(a, n_reads, total + 64, max_qlen, scale)) return false;
-		/* upload reads */
-		std::vector<uint32_t> pk((total + 64) / 16 + 8, 0), nm((total + 64) / 32 + 8, 0);
-		std::vector<ReadIn> in(n_reads); std::vector<ReadState> hst(n_reads);
-		uint64_t moff = 0;
-		std::vector<uint32_t> work;
-		for(uint32_t i = 0; i < n_reads; i++) {
-			pack_bases(bases + hoff[i], lens[i], pk, nm, qoff[i]);
-			in[i] = ReadIn{ qoff[i], lens[i], 0 };
-			memset(&hst[i], 0, sizeof(ReadState));
-			hst[i].min_off = moff; hst[i].min_cap = lens[i] / 2 + 64; moff += hst[i].min_cap;
-			hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL;
-			/* unmappable reads are skipped outright (minialign.c:4434) */
-			if(!(lens[i] < a->mi->k || lens[i] * a->mcoef < (double)a->o.min_score)) work.push_back(i);
-		}
-		CK(hipMemcpy(a->q_pk.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(a->q_nm.p, nm.data(), nm.size() * 4, hipMemcpyHostToDevice));
-		CK(hipMemcpy(a->d_in.p, in.data(), n_reads * sizeof(ReadIn), hipMemcpyHostToDevice));
-		CK(hipMemcpy(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice));
-		CK(hipMemset(a->d_tops.p, 0, 32 * 8));
-		std::vector<uint32_t> qlens(lens, lens + n_reads);
-		if(!run_rounds(a, n_reads, work, true, hst, nullptr, qlens)) return false;
-
-		/* the carried reference length: verify the prediction read by read, re-run the reads it changes */
-		std::vector<uint32_t> used(n_reads); for(uint32_t i = 0; i < n_reads; i++) used[i] = 0;
-		{
-			/* what was used: recompute the same prediction chain */
-			uint32_t cur = a->rlen_carry;
-			for(uint32_t i = 0; i < n_reads; i++) { used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size(); }
-		}
-		bool overflow = false;
-		for(int iter = 0; iter < 64; iter++) {
-			std::vector<uint32_t> redo, redo_rlen;
-			uint32_t cur = a->rlen_carry;
-			for(uint32_t i = 0; i < n_reads; i++) {
-				if(hst[i].err) overflow = true;
-				uint32_t truth = cur;
-				if(truth != used[i] && hst[i].apos0 != gaba::NIL && !hst[i].cond0 && ((hst[i].apos0 >= used[i]) != (hst[i].apos0 >= truth))) { redo.push_back(i); redo_rlen.push_back(truth); }
-				/* rounds after the first start from the length the previous round left behind: same state variable */
-				uint32_t out = hst[i].rid_last != gaba::NIL ? (uint32_t)a->mi->seq[hst[i].rid_last].seq.size() : truth;
-				cur = out;
-			}
-			if(redo.empty() || overflow) break;
-			a->st.reruns += redo.size();
-			/* reset and re-run the affected reads from the sketch on */
-			for(size_t j = 0; j < redo.size(); j++) {
-				uint32_t i = redo[j]; uint64_t mo = hst[i].min_off; uint32_t mc = hst[i].min_cap;
-				memset(&hst[i], 0, sizeof(ReadState)); hst[i].min_off = mo; hst[i].min_cap = mc;
-				hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL;
-				used[i] = redo_rlen[j];
-			}
-			CK(hipMemcpy(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice));
-			if(!run_rounds(a, n_reads, redo, true, hst, &redo_rlen, qlens)) return false;
-		}
-		if(overflow) { a->bin_cap *= 2; a->aln_cap *= 2; a->kh_cap *= 4; a->next_cap *= 2; a->rs_stride = 512 + (a->rs_stride - 512) * 4; continue; }
-		{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
-
-		/* download results */
-		unsigned long long tops[32]; CK(hipMemcpy(tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
-		a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
-		a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += lens[i];
-		double t0 = now_ms();
-		std::vector<Root> root(std::max<uint64_t>(tops[2], 1)); std::vector<uint64_t> bin(std::max<uint64_t>(tops[3], 1)); std::vector<AlnRec> aln(std::max<uint64_t>(tops[4], 1));
-		std::vector<gaba::Segment> seg(std::max<uint64_t>(tops[5], 1)); std::vector<uint32_t> path(std::max<uint64_t>(tops[6], 2) + 8);
-		CK(hipMemcpy(root.data(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost));
-		CK(hipMemcpy(bin.data(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost));
-		CK(hipMemcpy(aln.data(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost));
-		CK(hipMemcpy(seg.data(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost));
-		CK(hipMemcpy(path.data(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost));
-		/* post-map + SAM, in input order */
-		double t1 = now_ms();
-		char nbuf[32];
-		for(uint32_t i = 0; i < n_reads; i++) {
-			OutReg reg;
-			const ReadState &rs = hst[i];
-			const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.data();
-			if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
-			const char *nm_ = names ? names[i] : (snprintf(nbuf, sizeof(nbuf), "r%u", i), nbuf);
-			sam_record(a, sam, nm_, bases + hoff[i], lens[i], reg, alns, seg.data(), path.data());
-		}
-		a->st.host_post_ms += t1 - t0; a->st.host_sam_ms += now_ms() - t1;
-		(void)keep;
-		return true;
+	if(!ensure_pools(a, b.n, b.total + 64, b.max_qlen, b.scale)) return false;
+	b.hst.assign(b.n, ReadState()); b.work.clear();
+	uint64_t moff = 0;
+	for(uint32_t i = 0; i < b.n; i++) {
+		memset(&b.hst[i], 0, sizeof(ReadState));
+		b.hst[i].min_off = moff; b.hst[i].min_cap = b.lens[i] / 2 + 64; moff += b.hst[i].min_cap;
+		b.hst[i].bin_off = ~0ull; b.hst[i].apos0 = gaba::NIL; b.hst[i].rid_last = gaba::NIL; b.hst[i].pred_rid = gaba::NIL;
+		/* unmappable reads are skipped outright (minialign.c:4434) */
+		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
 	}
-	fprintf(stderr, "[minialign_amd] batch does not fit the device pools\n");
-	return false;
+	CK(hipMemcpy(a->q_pk.p, b.pk.data(), b.pk.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(a->q_nm.p, b.nm.data(), b.nm.size() * 4, hipMemcpyHostToDevice));
+	CK(hipMemcpy(a->d_in.p, b.in.data(), b.n * sizeof(ReadIn), hipMemcpyHostToDevice));
+	CK(hipMemcpy(a->d_st.p, b.hst.data(), b.n * sizeof(ReadState), hipMemcpyHostToDevice));
+	CK(hipMemset(a->d_tops.p, 0, 32 * 8));
+	b.uploaded = true; b.ran = false;
+	return true;
+}
+bool batch_prepare(mm_align_t *a, Batch &b)
+{
+	b.n = (uint32_t)b.lens.size(); b.total = 0; b.max_qlen = 0; b.qoff.resize(b.n); b.in.resize(b.n);
+	for(uint32_t i = 0; i < b.n; i++) { b.qoff[i] = b.total; b.total += ((uint64_t)b.lens[i] + 63) & ~63ull; b.max_qlen = std::max(b.max_qlen, b.lens[i]); }
+	b.pk.assign((b.total + 64) / 16 + 8, 0); b.nm.assign((b.total + 64) / 32 + 8, 0);
+	for(uint32_t i = 0; i < b.n; i++) { pack_bases(b.seq[i], b.lens[i], b.pk, b.nm, b.qoff[i]); b.in[i] = ReadIn{ b.qoff[i], b.lens[i], 0 }; }
+	b.scale = 1;
+	return batch_upload(a, b);
+}
+/* the hot path over the uploaded batch; returns 0 ok, 1 device pools overflowed (caller grows and retries), -1 error */
+int batch_run_once(mm_align_t *a, Batch &b)
+{
+	const uint32_t n_reads = b.n;
+	std::vector<ReadState> &hst = b.hst;
+	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return -1;
+	/* the carried reference length: verify the prediction read by read, re-run the reads it changes */
+	std::vector<uint32_t> used(n_reads);
+	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size(); } }
+	bool overflow = false;
+	for(int iter = 0; iter < 64; iter++) {
+		std::vector<uint32_t> redo, redo_rlen;
+		uint32_t cur = a->rlen_carry;
+		for(uint32_t i = 0; i < n_reads; i++) {
+			if(hst[i].err) overflow = true;
+			uint32_t truth = cur;
+			if(truth != used[i] && hst[i].apos0 != gaba::NIL && !hst[i].cond0 && ((hst[i].apos0 >= used[i]) != (hst[i].apos0 >= truth))) { redo.push_back(i); redo_rlen.push_back(truth); }
+			cur = hst[i].rid_last != gaba::NIL ? (uint32_t)a->mi->seq[hst[i].rid_last].seq.size() : truth;
+		}
+		if(redo.empty() || overflow) break;
+		a->st.reruns += redo.size();
+		for(size_t j = 0; j < redo.size(); j++) {
+			uint32_t i = redo[j]; uint64_t mo = hst[i].min_off; uint32_t mc = hst[i].min_cap;
+			memset(&hst[i], 0, sizeof(ReadState)); hst[i].min_off = mo; hst[i].min_cap = mc;
+			hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL;
+			used[i] = redo_rlen[j];
+		}
+		if(hipMemcpy(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice) != hipSuccess) return -1;
+		if(!run_rounds(a, n_reads, redo, true, hst, &redo_rlen, b.lens)) return -1;
+	}
+	if(overflow) return 1;
+	b.ran = true;
+	return 0;
+}
+bool batch_run(mm_align_t *a, Batch &b)
+{
+	while(true) {
+		int rc = batch_run_once(a, b);
+		if(rc < 0) return false;
+		if(rc == 0) return true;
+		/* a pool or a per-read cap overflowed: grow and redo the batch */
+		if(b.scale >= 256) { fprintf(stderr, "[minialign_amd] batch does not fit the device pools\n"); return false; }
+		b.scale *= 4; a->bin_cap *= 2; a->aln_cap *= 2; a->kh_cap *= 4; a->next_cap *= 2; a->rs_stride = 512 + (a->rs_stride - 512) * 4;
+		fprintf(stderr, "[minialign_amd] device pools overflowed, retrying the batch with scale %lu\n", (unsigned long)b.scale);
+		if(!batch_upload(a, b)) return false;
+	}
+}
+bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
+{
+	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
+	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
+	unsigned long long tops[32]; CK(hipMemcpy(tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
+	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
+	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
+	double t0 = now_ms();
+	std::vector<Root> root(std::max<uint64_t>(tops[2], 1)); std::vector<uint64_t> bin(std::max<uint64_t>(tops[3], 1)); std::vector<AlnRec> aln(std::max<uint64_t>(tops[4], 1));
+	std::vector<gaba::Segment> seg(std::max<uint64_t>(tops[5], 1)); std::vector<uint32_t> path(std::max<uint64_t>(tops[6], 2) + 8);
+	CK(hipMemcpy(root.data(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost));
+	CK(hipMemcpy(bin.data(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost));
+	CK(hipMemcpy(aln.data(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost));
+	CK(hipMemcpy(seg.data(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost));
+	CK(hipMemcpy(path.data(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost));
+	double t1 = now_ms();
+	for(uint32_t i = 0; i < n_reads; i++) {
+		OutReg reg; const ReadState &rs = hst[i];
+		const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.data();
+		if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
+		sam_record(a, sam, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.data(), path.data());
+	}
+	a->st.host_post_ms += t1 - t0; a->st.host_sam_ms += now_ms() - t1;
+	return true;
 }
 } /* anonymous */
 
+
 extern "C" int mm_align_batch(mm_align_t *a, uint8_t const *bases, uint32_t const *lens, char const *const *names, uint32_t n_reads, char **sam, uint64_t *sam_len)
 {
+	Batch b; uint64_t off = 0; char nbuf[32];
+	for(uint32_t i = 0; i < n_reads; i++) {
+		b.lens.push_back(lens[i]); b.seq.push_back(bases + off); off += lens[i];
+		if(names) b.names.emplace_back(names[i]); else { snprintf(nbuf, sizeof(nbuf), "r%u", i); b.names.emplace_back(nbuf); }
+	}
 	std::string s;
-	if(!align_batch(a, bases, lens, names, n_reads, s, nullptr)) return -1;
+	if(n_reads && !(batch_prepare(a, b) && batch_run(a, b) && batch_finish(a, b, s))) return -1;
 	uint64_t old = *sam ? *sam_len : 0;
 	*sam = (char *)realloc(*sam, old + s.size() + 1);
 	memcpy(*sam + old, s.data(), s.size()); (*sam)[old + s.size()] = 0; *sam_len = old + s.size();
 	return 0;
 }
 
+/* phase-split entry points over a parsed read set (bench.py times mm_batch_run alone: inputs resident in HBM) */
+extern "C" mm_reads_t *mm_reads_load(char const *fn)
+{
+	mm_reads_t *r = new mm_reads_s();
+	if(!read_seq_file(fn, r->r)) { delete r; return NULL; }
+	for(const HSeq &s : r->r) r->bases += s.seq.size();
+	return r;
+}
+extern "C" void mm_reads_free(mm_reads_t *r) { delete r; }
+extern "C" uint32_t mm_reads_count(mm_reads_t const *r) { return (uint32_t)r->r.size(); }
+extern "C" uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t n) { uint64_t b = 0; for(uint32_t i = first; i < first + n && i < r->r.size(); i++) b += r->r[i].seq.size(); return b; }
+struct mm_batch_s { Batch b; };
+extern "C" mm_batch_t *mm_batch_upload(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n)
+{
+	mm_batch_t *h = new mm_batch_s();
+	for(uint32_t i = first; i < first + n && i < r->r.size(); i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); }
+	if(!batch_prepare(a, h->b)) { delete h; return NULL; }
+	return h;
+}
+extern "C" int mm_batch_run(mm_align_t *a, mm_batch_t *h)
+{
+	if(h->b.ran) { if(!batch_upload(a, h->b)) return -1; }        /* a second pass over the same batch starts from clean device state */
+	return batch_run(a, h->b) ? 0 : -1;
+}
+extern "C" int mm_batch_finish(mm_align_t *a, mm_batch_t *h, char **sam, uint64_t *sam_len)
+{
+	std::string s;
+	if(!batch_finish(a, h->b, s)) return -1;
+	if(sam) { uint64_t old = *sam ? *sam_len : 0; *sam = (char *)realloc(*sam, old + s.size() + 1); memcpy(*sam + old, s.data(), s.size()); (*sam)[old + s.size()] = 0; *sam_len = old + s.size(); }
+	return 0;
+}
+extern "C" void mm_batch_free(mm_batch_t *h) { delete h; }
+extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
+
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
-	std::vector<HSeq> reads;
-	if(!read_seq_file(reads_fn, reads)) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
-	/* batches: bounded by bases so that the device pools stay modest */
+	mm_reads_t *reads = mm_reads_load(reads_fn);
+	if(!reads) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
+	/* batches: bounded by bases so that the device pools stay modest; drained strictly in input order */
 	const uint64_t max_bases = 512ull << 20; const uint32_t max_reads = 1u << 17;
-	size_t i = 0;
-	while(i < reads.size()) {
-		size_t j = i; uint64_t nb = 0;
-		while(j < reads.size() && j - i < max_reads && (nb == 0 || nb + reads[j].seq.size() <= max_bases)) { nb += reads[j].seq.size(); j++; }
-		std::vector<uint8_t> cat; cat.reserve(nb); std::vector<uint32_t> lens; std::vector<const char *> names;
-		for(size_t r = i; r < j; r++) { cat.insert(cat.end(), reads[r].seq.begin(), reads[r].seq.end()); lens.push_back((uint32_t)reads[r].seq.size()); names.push_back(reads[r].name.c_str()); }
-		std::string sam;
-		if(!align_batch(a, cat.data(), lens.data(), names.data(), (uint32_t)(j - i), sam, nullptr)) return 1;
-		fwrite(sam.data(), 1, sam.size(), out);
+	uint32_t i = 0, n = mm_reads_count(reads); int rc = 0;
+	while(i < n && rc == 0) {
+		uint32_t j = i; uint64_t nb = 0;
+		while(j < n && j - i < max_reads && (nb == 0 || nb + reads->r[j].seq.size() <= max_bases)) { nb += reads->r[j].seq.size(); j++; }
+		mm_batch_t *h = mm_batch_upload(a, reads, i, j - i);
+		char *sam = NULL; uint64_t len = 0;
+		if(!h || mm_batch_run(a, h) || mm_batch_finish(a, h, &sam, &len)) rc = 1;
+		else fwrite(sam, 1, len, out);
+		free(sam); if(h) mm_batch_free(h);
 		i = j;
 	}
-	return 0;
+	mm_reads_free(reads);
+	return rc;
 }
 
 extern "C" int mm_main(int argc, char **argv)
