@@ -21,8 +21,8 @@ using namespace gaba;
 struct DevJob { Sec a, b; uint32_t apos, bpos, bw_idx, do_trace; };
 
 /* ---- kernel ---- */
-__global__ void __launch_bounds__(256)
-gaba_extend_batch_kernel(const Consts *c, const uint8_t *roots, SeqArena ar_a, SeqArena ar_b,
+__global__ void __launch_bounds__(256, 8)
+gaba_extend_batch_kernel(const Consts c, const uint8_t *roots, SeqArena ar_a, SeqArena ar_b,
 	const DevJob *jobs, uint32_t njobs, gaba_xresult_t *res, uint32_t *paths, uint32_t path_stride,
 	uint8_t *slabs, uint64_t slab_bytes, uint32_t *counter, uint64_t *stats, int *errs)
 {
@@ -260,7 +260,8 @@ int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const 
 	need = (need + 255) & ~255ull;
 	int dev = 0; hipDeviceProp_t prop;
 	HIP_OK(hipGetDevice(&dev), -1); HIP_OK(hipGetDeviceProperties(&prop, dev), -1);
-	uint32_t max_waves = (uint32_t)prop.multiProcessorCount * 16;          /* 4 workgroups x 4 waves per CU */
+	const char *wenv = getenv("MM_WAVES_PER_CU");
+	uint32_t max_waves = (uint32_t)prop.multiProcessorCount * (wenv ? (uint32_t)atoi(wenv) : 16u);          /* default: 4 workgroups x 4 waves per CU */
 	uint32_t waves = n < max_waves ? ((n + 3) & ~3u) : max_waves;
 	if(ctx->slab_bytes < need || ctx->n_waves < waves) {
 		if(ctx->slabs) hipFree(ctx->slabs);
@@ -279,7 +280,7 @@ int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const 
 	SeqArena sa{ a->pk, a->nm }, sb{ b->pk, b->nm };
 	HIP_OK(hipEventRecord(ctx->ev0, ctx->stream), -1);
 	hipLaunchKernelGGL(gaba_extend_batch_kernel, dim3(waves / 4), dim3(256), 0, ctx->stream,
-		ctx->dc, ctx->droots, sa, sb, djobs, n, dres, dpaths, path_stride, ctx->slabs, ctx->slab_bytes, ctx->counter, ctx->dstats, derr);
+		ctx->hc, ctx->droots, sa, sb, djobs, n, dres, dpaths, path_stride, ctx->slabs, ctx->slab_bytes, ctx->counter, ctx->dstats, derr);
 	HIP_OK(hipGetLastError(), -1);
 	HIP_OK(hipEventRecord(ctx->ev1, ctx->stream), -1);
 	std::vector<int> herr(n);
@@ -304,5 +305,47 @@ int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const 
 }
 
 void gaba_last_stats(gaba_t *ctx, gaba_batch_stats_t *out) { if(ctx && out) *out = ctx->last; }
+
+/* ---- CIGAR printers over a path (gaba_parse.h:147-263): run-length decode of the path bits; host side ---- */
+static inline uint64_t cg_u64(const uint64_t *ptr, int64_t pos) { int64_t rem = pos & 63; return (ptr[pos >> 6] >> rem) | ((ptr[(pos >> 6) + 1] << (63 - rem)) << 1); }
+static inline uint64_t cg_lz(uint64_t x) { return x ? (uint64_t)__builtin_clzll(x) : 64; }
+static inline uint64_t cg_tz(uint64_t x) { return x ? (uint64_t)__builtin_ctzll(x) : 64; }
+static inline char *cg_put(char *b, uint64_t n, char op) { char t[24]; int k = 0; if(!n) t[k++] = '0'; while(n) { t[k++] = (char)('0' + n % 10); n /= 10; } while(k) *b++ = t[--k]; *b++ = op; return b; }
+uint64_t gaba_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
+{
+	(void)buf_size;
+	char *b = buf;
+	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
+	uint64_t ofs = (uint64_t)((int64_t)offset + (((uintptr_t)path & 4) ? 32 : 0) - 64), idx = len;
+	while((int64_t)idx > 0) {
+		uint64_t m = cg_lz(cg_u64(p, (int64_t)(ofs + idx))), c = m - (m > 0); if(c > idx) c = idx;
+		idx -= c; if(c) b = cg_put(b, c, 'D');
+		m = cg_lz(~cg_u64(p, (int64_t)(ofs + idx))); c = m < idx ? m : idx;
+		idx -= c; if(c) b = cg_put(b, c, 'I');
+		uint64_t s0 = idx;
+		do { m = cg_lz(cg_u64(p, (int64_t)(ofs + idx)) ^ 0x5555555555555555ull); c = (m < idx ? m : idx) & ~1ull; idx -= c; } while(c == 64);
+		if((s0 - idx) >> 1) b = cg_put(b, (s0 - idx) >> 1, 'M');
+	}
+	*b = 0;
+	return (uint64_t)(b - buf);
+}
+uint64_t gaba_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
+{
+	(void)buf_size;
+	char *b = buf;
+	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
+	uint64_t lim = offset + (((uintptr_t)path & 4) ? 32 : 0) + len, ridx = len;
+	while((int64_t)ridx > 0) {
+		uint64_t m = cg_tz(~cg_u64(p, (int64_t)(lim - ridx))), c = m - (m > 0); if(c > ridx) c = ridx;
+		ridx -= c; if(c) b = cg_put(b, c, 'I');
+		m = cg_tz(cg_u64(p, (int64_t)(lim - ridx))); c = m < ridx ? m : ridx;
+		ridx -= c; if(c) b = cg_put(b, c, 'D');
+		uint64_t s0 = ridx;
+		do { m = cg_tz(cg_u64(p, (int64_t)(lim - ridx)) ^ 0x5555555555555555ull); c = (m < ridx ? m : ridx) & ~1ull; ridx -= c; } while(c == 64);
+		if((s0 - ridx) >> 1) b = cg_put(b, (s0 - ridx) >> 1, 'M');
+	}
+	*b = 0;
+	return (uint64_t)(b - buf);
+}
 
 } /* extern "C" */

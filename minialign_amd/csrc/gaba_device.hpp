@@ -143,7 +143,7 @@ struct Work {
 };
 
 struct Ctx {                 /* everything a device routine needs */
-	const Consts *c;
+	Consts c;                /* by value: lives in SGPRs, never re-loaded inside the DP loops */
 	const SeqArena *ar;
 	uint8_t *slab;           /* this wave's arena */
 	uint32_t top, cap;       /* bump pointer / capacity (bytes) */
@@ -166,18 +166,21 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 	return off;
 }
 
-/* substitution score lookup: _shuf_n(sb, a | b) (gaba.c:1605, 1616) */
+/* substitution score lookup: _shuf_n(sb, a | b) (gaba.c:1605, 1616): a 16-entry byte table held in four SGPRs, read with
+ * two v_perm_b32 (byte select) + one select on bit 3 -- no memory access */
 __device__ __forceinline__ int score_of(const Consts &c, int ab)
 {
-	int idx = ab & 15;
-	uint32_t w = (idx & 8) ? ((idx & 4) ? c.sb[3] : c.sb[2]) : ((idx & 4) ? c.sb[1] : c.sb[0]);
-	return sext8((int)(w >> ((idx & 3) * 8)));
+	uint32_t sel = (uint32_t)ab & 7u;
+	uint32_t lo = __builtin_amdgcn_perm(c.sb[1], c.sb[0], sel);
+	uint32_t hi = __builtin_amdgcn_perm(c.sb[3], c.sb[2], sel);
+	return sext8((int)((ab & 8) ? hi : lo));
 }
 
 /*
  * one anti-diagonal (gaba.c:1576-1699).  `down` is wave-uniform.  new_base: the base entering the window.
  * Returns t (the per-lane score increment fed to delta / drop / direction).
  */
+template<int MODEL>
 __device__ __forceinline__ int fill_vector(const Consts &c, Band &b, int W, bool down, int new_base, bool lane_top)
 {
 	if(!down) {
@@ -194,7 +197,7 @@ __device__ __forceinline__ int fill_vector(const Consts &c, Band &b, int W, bool
 	int s = score_of(c, b.ach | b.bch);
 	int dh = b.dh, dv = b.dv, de = b.de, df = b.df, t;
 	uint32_t bh, bv, be, bf;
-	if(c.model == MODEL_COMBINED) {                /* gaba.c:1604-1640 */
+	if(MODEL == MODEL_COMBINED) {                  /* gaba.c:1604-1640 */
 		int dfh = sext8(dv + c.gfh), dfv = sext8(c.gfv - dh);
 		int ss = max(max(de, df), dfh);
 		t = max(max(s, dfv), ss);
@@ -270,7 +273,7 @@ __device__ __forceinline__ void fetch_look(Ctx &x, Work &w, FillState &f, uint32
 /* _fill_store_context (gaba.c:1734-1778) */
 __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uint32_t blk_off, uint32_t cnt)
 {
-	const Consts &c = *x.c;
+	const Consts &c = x.c;
 	Blk *p = blk_at(x, blk_off);
 	int l = x.lane, W = w.W;
 	Band &b = f.b;
@@ -306,9 +309,10 @@ __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uin
 
 /* one block of up to BLK vectors.  bounded = per-vector sequence-end tests (fill_cap_seq_bounded, gaba.c:1925-1975).
  * Returns the number of vectors filled. */
-__device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool bounded)
+template<int MODEL>
+__device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool bounded)
 {
-	const Consts &c = *x.c;
+	const Consts &c = x.c;
 	int W = w.W;
 	bool lane_top = x.lane == W - 1;
 	uint32_t alen = BLK, blen = BLK;
@@ -324,9 +328,9 @@ __device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, ui
 			int64_t ta = arem - (int64_t)(w.acnt + (down ? 0 : 1)), tb = brem - (int64_t)(w.bcnt + (down ? 1 : 0));
 			if((ta | tb | (ta + tb + prem)) < 0) { w.dmask >>= 1; break; }
 		}
-		int nb = down ? rdlane(f.look, 32 + (int)w.bcnt) : rdlane(f.look, (int)w.acnt);
-		if(down) { w.bcnt++; } else { w.acnt++; }
-		int t = fill_vector(c, f.b, W, down, nb, lane_top);
+		int t;
+		if(down) { int nb = rdlane(f.look, 32 + (int)w.bcnt); w.bcnt++; t = fill_vector<MODEL>(c, f.b, W, true, nb, lane_top); }
+		else { int nb = rdlane(f.look, (int)w.acnt); w.acnt++; t = fill_vector<MODEL>(c, f.b, W, false, nb, lane_top); }
 		w.dacc += rdlane(t, 0) - rdlane(t, W - 1);                  /* _dir_update, gaba.c:761 */
 	}
 	w.pridx -= k;
@@ -334,6 +338,13 @@ __device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, ui
 	if(k != 0 && k != BLK) { w.dmask <<= (BLK - k); }              /* _dir_adjust_remainder, gaba.c:769 */
 	store_context(x, w, f, blk_off, k);
 	return k;
+}
+
+__device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool bounded)
+{
+	/* the gap model is fixed per context: pick the specialised 32-vector loop once per block */
+	if(x.c.model == MODEL_COMBINED) { return fill_block_t<MODEL_COMBINED>(x, w, f, prev_off, blk_off, bounded); }
+	return fill_block_t<MODEL_AFFINE>(x, w, f, prev_off, blk_off, bounded);
 }
 
 /* ---- section / tail plumbing ---- */
@@ -453,7 +464,7 @@ __device__ __forceinline__ uint32_t fill_body(Ctx &x, Work &w, FillState &f, boo
 		if(x.err) { break; }
 		fill_block(x, w, f, last, off, false);
 		last = off; w.nblk++;
-		xstat = (int)(int8_t)((x.c->tx - rdlane(f.xd, w.W / 2)) & TERM);
+		xstat = (int)(int8_t)((x.c.tx - rdlane(f.xd, w.W / 2)) & TERM);
 	}
 	if((xstat & STAT_MASK) == CONT && !x.err) {
 		/* fill_cap_seq_bounded (gaba.c:1925-1975) */
@@ -461,7 +472,7 @@ __device__ __forceinline__ uint32_t fill_body(Ctx &x, Work &w, FillState &f, boo
 			uint32_t off = slab_alloc(x, sizeof(Blk));
 			if(x.err) { break; }
 			uint32_t k = fill_block(x, w, f, last, off, true);
-			xstat = (int)(int8_t)((x.c->tx - rdlane(f.xd, w.W / 2)) & TERM);
+			xstat = (int)(int8_t)((x.c.tx - rdlane(f.xd, w.W / 2)) & TERM);
 			if(k != 0) { last = off; w.nblk++; } else { x.top = off; }   /* squash the empty block (gaba.c:1492) */
 			if(k != BLK) { break; }
 		}
@@ -529,7 +540,7 @@ __device__ __forceinline__ uint32_t skip_heads(Ctx &x, uint32_t off)
 /* leaf_search (gaba.c:2708-2770): returns plen, fills lf.{blk,p,q,gidx,sgidx} */
 __device__ __forceinline__ uint64_t leaf_search(Ctx &x, uint32_t tail_off, Leaf &lf)
 {
-	const Consts &c = *x.c;
+	const Consts &c = x.c;
 	const Tail *t = tail_at(x, tail_off);
 	int l = x.lane, W = rdfirst(t->W);
 	bool act = l < W;
@@ -596,9 +607,9 @@ __device__ __forceinline__ uint64_t leaf_search(Ctx &x, uint32_t tail_off, Leaf 
 	for(int k = 0; k < cnt; k++) {
 		w.dmask = (w.dmask << 1) | (uint32_t)(w.dacc < 0);
 		bool down = w.dmask & 1;
-		int nb = down ? rdlane(f.look, 32 + (int)w.bcnt) : rdlane(f.look, (int)w.acnt);
-		if(down) { w.bcnt++; } else { w.acnt++; }
-		int tv = fill_vector(c, f.b, W, down, nb, lane_top);
+		int tv;
+		if(down) { int nb = rdlane(f.look, 32 + (int)w.bcnt); w.bcnt++; tv = c.model == MODEL_COMBINED ? fill_vector<MODEL_COMBINED>(c, f.b, W, true, nb, lane_top) : fill_vector<MODEL_AFFINE>(c, f.b, W, true, nb, lane_top); }
+		else { int nb = rdlane(f.look, (int)w.acnt); w.acnt++; tv = c.model == MODEL_COMBINED ? fill_vector<MODEL_COMBINED>(c, f.b, W, false, nb, lane_top) : fill_vector<MODEL_AFFINE>(c, f.b, W, false, nb, lane_top); }
 		w.dacc += rdlane(tv, 0) - rdlane(tv, W - 1);
 		upd |= (uint32_t)(act && f.b.delta > mx) << k;
 		mx = max(mx, f.b.delta);
@@ -857,7 +868,7 @@ __device__ __forceinline__ uint64_t dp_trace_begin(Ctx &x, uint32_t tail_off, Le
 /* phase 2: walk back; path must hold (plen + 31) / 32 + 2 words */
 __device__ __forceinline__ AlnOut dp_trace_finish(Ctx &x, uint32_t tail_off, Leaf &lf, uint64_t plen, uint32_t *path, Segment *seg, uint32_t max_seg)
 {
-	const Consts &c = *x.c;
+	const Consts &c = x.c;
 	const Tail *tail = tail_at(x, tail_off);
 	AlnOut out; out.status = 1;
 	uint64_t pn = (plen + 31) / 32 + 2;

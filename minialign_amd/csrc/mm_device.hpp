@@ -475,7 +475,7 @@ struct AlnRec {                /* what the host needs of a gaba_alignment_t (gab
 	uint64_t path_off;         /* word offset into the path pool; two header words {plen, 0x40000000} precede it (gaba.h:217) */
 };
 struct K3Args {
-	DevIndex idx; const gaba::Consts *gc; const uint8_t *roots; gaba::SeqArena ar_ref, ar_q;
+	DevIndex idx; gaba::Consts gc; const uint8_t *roots; gaba::SeqArena ar_ref, ar_q;
 	const ReadIn *in; ReadState *st; const uint32_t *work; uint32_t n_work;
 	Seed *seed_pool; Root *root_pool;
 	uint8_t *slabs; uint64_t slab_bytes;                 /* DP workspace per wave */
@@ -545,7 +545,7 @@ struct Search {                 /* mm_search_t, minialign.c:3218 */
 };
 constexpr uint32_t MM_CREM = 50000, MM_SREM = 8;
 
-__global__ void __launch_bounds__(256) mm_extend_kernel(K3Args a)
+__global__ void __launch_bounds__(256, 6) mm_extend_kernel(K3Args a)
 {
 	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
 	gaba::Ctx x;

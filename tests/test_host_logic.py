@@ -1,0 +1,71 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol the headers declare; the multi-GPU host logic
+(sharding, ordered merge, carried-state chain, timing reduction) under a 2-process gloo group."""
+import ctypes, os, re, sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, 'include', header)).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    names = set()
+    for m in re.finditer(r'\b((?:gaba|mm)_[a-z0-9_]+)\s*\(', txt):
+        names.add(m.group(1))
+    return names
+
+def test_library_exports_every_declared_symbol():
+    lib = os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')
+    assert os.path.exists(lib), 'run __graft_entry__.build() first'
+    L = ctypes.CDLL(lib)          # loading needs no GPU; no compute entry point is called here
+    missing = [n for h in ('gaba.h', 'minialign.h') for n in sorted(_declared(h)) if not hasattr(L, n)]
+    assert not missing, 'declared in include/*.h but not exported: %r' % missing
+
+def test_shard_bounds_cover_everything_once():
+    from minialign_amd.shard import shard_bounds
+    for n in (0, 1, 7, 8, 1000, 22308):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from minialign_amd.shard import shard_bounds, merge_in_order, carry_chain, reduce_timing
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = shard_bounds(11, rank, world)
+    body = b''.join(b'read%d\n' % i for i in range(lo, hi))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, body)
+    merged = merge_in_order(gathered)
+    # rank 0's shard ends having loaded a 1234-long reference, rank 1's shard never loads one
+    start = carry_chain(dist, 1 if rank == 0 else 0, 1234 if rank == 0 else 0, initial=77)
+    sec, units = reduce_timing(dist, 1.0 + rank, 100 * (rank + 1))
+    dist.barrier(); dist.destroy_process_group()
+    q.put((rank, merged, start, sec, units))
+
+def test_two_process_gloo_group():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn'); q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps: p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps: p.join(60)
+    want = b''.join(b'read%d\n' % i for i in range(11))
+    assert res[0][1] == want and res[1][1] == want          # contiguous shards concatenate to input order
+    assert res[0][2] == 77 and res[1][2] == 1234            # rank 1 starts from what rank 0 ended with
+    assert res[0][3] == 2.0 and res[1][3] == 2.0            # MAX over ranks
+    assert res[0][4] == 300.0 and res[1][4] == 300.0        # SUM over ranks
+
+
+def test_product_cigar_known_answers():
+    """the product's host CIGAR printers against the reference's in-tree known answers (gaba.c:4297-4522), via test_oracle_gaba's table"""
+    from test_oracle_gaba import CIGAR_KAT_FW, CIGAR_KAT_RV, _cigar
+    L = ctypes.CDLL(os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so'))
+    for words, ofs, ln, want in CIGAR_KAT_FW:
+        assert _cigar(L, 'gaba_dump_cigar_forward', words, ofs, ln)[0] == want
+    for words, ofs, ln, want in CIGAR_KAT_RV:
+        assert _cigar(L, 'gaba_dump_cigar_reverse', words, ofs, ln)[0] == want
