@@ -464,6 +464,228 @@ __global__ void __launch_bounds__(64) mm_sort_chain_kernel(K2Args a)
 	st->pred_rid = pred;
 }
 
+/* -----------------------------------------------------------------------------------------------------
+ * K2a: the same stage, one *wavefront* per read with the seed / leaf array staged in LDS (first round only; reads whose
+ * arrays do not fit the LDS budget, and the rescue rounds, take the lane-per-read kernel above).
+ *   - radix levels whose digit is constant over the range are identity permutations and are skipped (one parallel
+ *     histogram decides); the cycle-leader permutation itself stays serial (lane 0, in LDS); the <= 64-element buckets
+ *     left by a level are insertion-sorted one bucket per lane (insertion sort is stable, so any order of buckets and any
+ *     stable method give the reference's result);
+ *   - the chaining sweep keeps the reference's sequential semantics but tests 64 candidate seeds per step.
+ * ----------------------------------------------------------------------------------------------------- */
+struct K2aArgs {
+	ReadState *st; const uint32_t *work; uint32_t n_work;
+	Seed *seed_pool; Root *root_pool;
+	uint32_t lds_seeds;               /* capacity of the LDS seed array (elements) */
+	uint32_t twlen; double mcoef; uint32_t min_score;
+};
+typedef __attribute__((address_space(3))) Seed LSeed;
+typedef __attribute__((address_space(3))) uint32_t LU32;
+
+__device__ __forceinline__ uint64_t lkey(const LSeed *p) { return (uint64_t)p->upos | ((uint64_t)p->rid << 32); }
+__device__ __forceinline__ Seed lds_ld(const LSeed *p) { Seed r; r.upos = p->upos; r.rid = p->rid; r.vpos = p->vpos; r.lid = p->lid; return r; }
+__device__ __forceinline__ void lds_st(LSeed *p, const Seed &v) { p->upos = v.upos; p->rid = v.rid; p->vpos = v.vpos; p->lid = v.lid; }
+__device__ __forceinline__ uint64_t lkey(const Seed *p) { return (uint64_t)p->upos | ((uint64_t)p->rid << 32); }
+__device__ __forceinline__ Seed lds_ld(const Seed *p) { return *p; }
+__device__ __forceinline__ void lds_st(Seed *p, const Seed &v) { *p = v; }
+template<typename S>
+__device__ __forceinline__ void lds_ins_sort(S *beg, S *end)
+{
+	for(S *i = beg + 1; i < end; ++i) {
+		uint64_t ki = lkey(i);
+		if(ki < lkey(i - 1)) {
+			Seed tmp = lds_ld(i); S *j;
+			for(j = i; j > beg && ki < lkey(j - 1); --j) { lds_st(j, lds_ld(j - 1)); }
+			lds_st(j, tmp);
+		}
+	}
+}
+
+/* sort + chain over a seed array that lives either in LDS (S = LSeed) or in HBM (S = Seed); returns false if the leaf area overflowed */
+template<typename S>
+__device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t seed_n, LU32 *cnt, LU32 *bb, LU32 *be, LU32 *stack,
+	Root *c, const K2aArgs &a, int lane, uint32_t &nlid_out, uint32_t &ncid_out)
+{
+	const uint32_t n_all = seed_n + 1;
+		/* ---- radix_sort_128x ---- */
+		if(n_all <= 64) { if(lane == 0) { lds_ins_sort(s, s + n_all); } }
+		else {
+			uint32_t sp = 1;
+			if(lane == 0) { stack[0] = 0; stack[1] = n_all; stack[2] = 56; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			while(sp > 0) {
+				sp--;
+				const uint32_t beg = (uint32_t)rdfirst((int)stack[3 * sp]), end = (uint32_t)rdfirst((int)stack[3 * sp + 1]); const int sh = rdfirst((int)stack[3 * sp + 2]);
+				for(int k = lane; k < 256; k += 64) { cnt[k] = 0; }
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				for(uint32_t i = beg + (uint32_t)lane; i < end; i += 64) { atomicAdd((uint32_t *)&cnt[(lkey(&s[i]) >> sh) & 255], 1u); }
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				/* a level whose elements all share the digit leaves the range untouched */
+				const uint32_t d0 = (uint32_t)((lkey(&s[beg]) >> sh) & 255);
+				const bool single = (uint32_t)rdfirst((int)cnt[d0]) == end - beg;
+				if(single) {
+					if(sh) { if(lane == 0) { stack[3 * sp] = beg; stack[3 * sp + 1] = end; stack[3 * sp + 2] = (uint32_t)(sh > 8 ? sh - 8 : 0); } sp++; }
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+					continue;
+				}
+				if(lane == 0) {
+					/* bucket bounds, then the in-place cycle-leader permutation (ksort.h:101-116) */
+					uint32_t acc = beg;
+					for(int k = 0; k < 256; k++) { bb[k] = acc; acc += cnt[k]; be[k] = acc; }
+					for(int k = 0; k < 256;) {
+						uint32_t b = bb[k];
+						if(b != be[k]) {
+							int l_ = (int)((lkey(&s[b]) >> sh) & 255);
+							if(l_ != k) {
+								Seed tmp = lds_ld(&s[b]), swp;
+								do { swp = tmp; uint32_t d = bb[l_]; tmp = lds_ld(&s[d]); lds_st(&s[d], swp); bb[l_] = d + 1;
+								     l_ = (int)((((uint64_t)tmp.upos | ((uint64_t)tmp.rid << 32)) >> sh) & 255); } while(l_ != k);
+								lds_st(&s[bb[k]], tmp); bb[k]++;
+							} else { bb[k] = b + 1; }
+						} else { ++k; }
+					}
+					uint32_t acc2 = beg;
+					for(int k = 0; k < 256; k++) { bb[k] = acc2; acc2 = be[k]; }
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				if(sh) {
+					const int ns = sh > 8 ? sh - 8 : 0;
+					/* large buckets go back on the stack (order of siblings is irrelevant), small ones are sorted one per lane */
+					if(lane == 0) {
+						for(int k = 0; k < 256; k++) { uint32_t n = be[k] - bb[k]; if(n > 64) { stack[3 * sp] = bb[k]; stack[3 * sp + 1] = be[k]; stack[3 * sp + 2] = (uint32_t)ns; sp++; } }
+					}
+					sp = (uint32_t)rdfirst((int)sp);
+					for(int k = lane; k < 256; k += 64) { uint32_t n = be[k] - bb[k]; if(n > 1 && n <= 64) { lds_ins_sort(s + bb[k], s + be[k]); } }
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+
+		/* ---- mm_chain_seeds (minialign.c:3547-3625) ---- */
+		uint32_t ncid = 0, nlid = seed_n + 1, nlsid = 0; const uint32_t tsid = seed_n;
+		const int32_t tw = (int32_t)a.twlen;
+		bool overflow = false;
+		while(nlsid < tsid) {
+			const uint32_t lid = nlid++;
+			if(lid >= cap) { overflow = true; break; }
+			const uint32_t l_rid = (uint32_t)rdfirst((int)s[nlsid].rid);
+			if(lane == 0) { lds_st(&s[lid], Seed{ nlsid, l_rid, nlsid, 0xffffffffu }); }
+			uint32_t plen = (uint32_t)rdfirst((int)(s[nlsid].upos + s[nlsid].vpos)), scnt = 1;
+			const uint32_t lsid0 = nlsid;
+			uint64_t nrsid = nlsid; nlsid = 0xffffffffu;
+			while(true) {
+				const uint32_t rsid = (uint32_t)nrsid; nrsid = 0;
+				Seed rs_ = lds_ld(&s[rsid]);
+				V4 wv = add_win(V4{ rdfirst((int)rs_.upos), rdfirst((int)rs_.rid), rdfirst((int)rs_.vpos), rdfirst((int)rs_.vpos) }, tw);
+				bool stop = false;
+				for(uint32_t base = rsid + 1; !stop; base += 64) {
+					const uint32_t sid = base + (uint32_t)lane;
+					const bool valid = sid <= tsid;                      /* the sentinel at tsid always ends the scan */
+					Seed cs = Seed{ 0, 0x7fffffffu, 0, 0 }; if(valid) { cs = lds_ld(&s[sid]); }
+					V4 fv = load_pv(cs);
+					uint64_t pending = __ballot(valid);
+					while(pending) {
+						const bool mine = (pending >> lane) & 1;
+						const bool in = mine && inside_wv(wv, fv);
+						const bool brk = mine && !in && !inside_uub(wv, fv);
+						const uint64_t m_in = __ballot(in), m_brk = __ballot(brk), m_out = __ballot(mine && !in);
+						const uint32_t f_in = m_in ? (uint32_t)__builtin_ctzll(m_in) : 64u, f_brk = m_brk ? (uint32_t)__builtin_ctzll(m_brk) : 64u;
+						const uint32_t lim = f_in < f_brk ? f_in : f_brk;
+						/* non-inside candidates met before the next event (the breaking one included) pull nlsid down */
+						const uint64_t below = lim >= 63 ? ~0ull : ((2ull << lim) - 1);
+						const uint64_t m_seen = m_out & below;
+						if(m_seen) { const uint32_t fs = base + (uint32_t)__builtin_ctzll(m_seen); nlsid = nlsid < fs ? nlsid : fs; }
+						if(f_brk < f_in) { stop = true; break; }
+						if(f_in == 64) { break; }                       /* nothing left in this chunk */
+						V4 af = V4{ rdlane(fv.e0, (int)f_in), rdlane(fv.e1, (int)f_in), rdlane(fv.e2, (int)f_in), rdlane(fv.e3, (int)f_in) };
+						wv = update_wv(wv, af);
+						const int64_t di = (int64_t)(((uint64_t)(int64_t)pdiff(wv, af) << 32) | (uint64_t)(base + f_in));
+						nrsid = (uint64_t)((int64_t)nrsid > di ? (int64_t)nrsid : di);
+						pending &= f_in >= 63 ? 0ull : ~((2ull << f_in) - 1);
+					}
+					if(!stop && base + 64 > tsid + 1) { stop = true; }       /* ran past the sentinel (cannot happen: the sentinel breaks) */
+				}
+				if(nrsid == 0) { nrsid = rsid; break; }
+				const uint32_t cand = (uint32_t)nrsid;
+				const uint32_t cl = (uint32_t)rdfirst((int)s[cand].lid);
+				if(cl != 0x7fffffffu) { nrsid = cand; break; }
+				if(lane == 0) { s[cand].lid = lid; }
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				scnt++;
+				if((uint64_t)nlsid <= nrsid) { nlsid = 0xffffffffu; }
+			}
+			if(nrsid == lsid0) { continue; }
+			uint32_t cid = 0xffffffffu;
+			const uint32_t hl = (uint32_t)rdfirst((int)s[nrsid].lid);
+			if(hl < lid) {
+				nrsid = (uint32_t)rdfirst((int)s[hl].upos);                       /* leaf.rsid */
+				cid = (uint32_t)rdfirst((int)s[(uint32_t)rdfirst((int)s[nrsid].lid)].lid);   /* leaf.cid */
+			}
+			bool fresh = false;
+			if(cid == 0xffffffffu) { cid = ncid++; fresh = true; }
+			const uint32_t eu = (uint32_t)rdfirst((int)(s[nrsid].upos + s[nrsid].vpos));
+			plen = (uint32_t)OFS((int32_t)d2u32((1.0 - 1.0 / (double)scnt) * (double)(uint32_t)(eu - plen)));
+			if(lane == 0) {
+				if(fresh) { c[cid] = Root{ (uint32_t)OFS(0), lid }; }
+				s[lid].lid = cid; s[lid].upos = (uint32_t)nrsid;
+				if(plen < c[cid].plen) { c[cid] = Root{ plen, lid }; }
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		}
+	nlid_out = nlid; ncid_out = ncid;
+	return !overflow;
+}
+
+__global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
+{
+	extern __shared__ uint8_t lds_raw[];
+	LSeed *ls = (LSeed *)lds_raw;
+	LU32 *cnt = (LU32 *)(ls + a.lds_seeds);         /* 256 counters */
+	LU32 *bb = cnt + 256, *be = bb + 256;             /* bucket begin / end */
+	LU32 *stack = be + 256;                           /* pending ranges: (beg, end, shift) x 256 */
+	const int lane = lane_id();
+	for(uint32_t wi = blockIdx.x; wi < a.n_work; wi += gridDim.x) {
+		ReadState *st = &a.st[a.work[wi]];
+		const uint32_t seed_n = (uint32_t)rdfirst((int)st->seed_n);
+		Seed *gs = a.seed_pool + rdfirst64(st->seed_off);
+		Root *c = a.root_pool + rdfirst64(st->root_off);
+		const uint32_t gcap = (uint32_t)rdfirst((int)st->seed_cap);
+		if(lane == 0) { st->n_seed = seed_n; st->n_root = 0; st->pred_rid = gaba::NIL; }
+		if(seed_n == 0) { continue; }
+		const bool fits = 2 * (seed_n + 1) <= a.lds_seeds;
+		uint32_t nlid = 0, ncid = 0; bool ok;
+		if(fits) {
+			for(uint32_t i = (uint32_t)lane; i < seed_n; i += 64) { lds_st(&ls[i], gs[i]); }
+			if(lane == 0) { lds_st(&ls[seed_n], Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }); }      /* sentinel, minialign.c:3531 */
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			ok = sort_chain_wave<LSeed>(ls, a.lds_seeds, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid);
+			if(ok) { for(uint32_t i = (uint32_t)lane; i < nlid; i += 64) { gs[i] = lds_ld(&ls[i]); } }
+		} else {
+			/* too large for LDS: same algorithm in place in HBM */
+			if(lane == 0) { gs[seed_n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			ok = sort_chain_wave<Seed>(gs, gcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid);
+		}
+		if(!ok) { if(lane == 0) { st->err |= ERR_SEED_CAP; } continue; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if(lane == 0) {
+			st->seed_n = nlid; st->n_root = ncid;
+			if(ncid) {
+				if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)cnt, 1536)) { st->err |= ERR_STACK; }              /* longest first (minialign.c:3719); LDS tables reused as scratch */
+				uint32_t pred = gaba::NIL;
+				for(uint32_t kq = 0; kq < ncid; kq++) {
+					uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
+					if(pl * a.mcoef < 2.0 * a.min_score) { break; }
+					pred = gs[gs[c[kq].lid].upos].rid;
+				}
+				st->pred_rid = pred;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+}
+
 /* =====================================================================================================
  * K3: extension driver, one wavefront per read
  * ===================================================================================================== */
@@ -545,7 +767,7 @@ struct Search {                 /* mm_search_t, minialign.c:3218 */
 };
 constexpr uint32_t MM_CREM = 50000, MM_SREM = 8;
 
-__global__ void __launch_bounds__(256, 6) mm_extend_kernel(K3Args a)
+__global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
 {
 	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
 	gaba::Ctx x;

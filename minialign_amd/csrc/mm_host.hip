@@ -418,11 +418,37 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
 		K2Args k2; k2.idx = a->dix; k2.st = a->d_st.p; k2.work = a->d_work.p; k2.n_work = (uint32_t)work.size(); k2.round = round;
 		k2.seed_pool = a->seed_pool.p; k2.resc_pool = a->resc_pool.p; k2.root_pool = a->root_pool.p;
-		if(!a->rs_scratch.ensure((uint64_t)work.size() * a->rs_stride)) return false;
-		k2.rs_scratch = a->rs_scratch.p; k2.rs_stride = a->rs_stride; k2.twlen = a->twlen; k2.mcoef = a->mcoef; k2.min_score = a->o.min_score;
+		k2.twlen = a->twlen; k2.mcoef = a->mcoef; k2.min_score = a->o.min_score;
+		auto launch_serial_k2 = [&](uint32_t n) -> bool {
+			if(!a->rs_scratch.ensure((uint64_t)n * a->rs_stride)) return false;
+			k2.rs_scratch = a->rs_scratch.p; k2.rs_stride = a->rs_stride; k2.n_work = n;
+			hipLaunchKernelGGL(mm_sort_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, a->stream, k2);
+			return hipGetLastError() == hipSuccess;
+		};
 		CK(hipEventRecord(a->ev0, a->stream));
-		hipLaunchKernelGGL(mm_sort_chain_kernel, dim3((uint32_t)((work.size() + 63) / 64)), dim3(64), 0, a->stream, k2);
-		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
+		if(round == 0) {
+			/* wave-per-read kernel with the seed array in LDS; reads that do not fit are flagged and fall through to the serial one */
+			const uint32_t lds_bytes = 80 * 1024, lds_seeds = (lds_bytes - 1536 * 4) / sizeof(Seed);
+			static bool attr_set = false;
+			if(!attr_set) { CK(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); attr_set = true; }
+			K2aArgs ka; ka.st = a->d_st.p; ka.work = a->d_work.p; ka.n_work = (uint32_t)work.size(); ka.seed_pool = a->seed_pool.p; ka.root_pool = a->root_pool.p;
+			ka.lds_seeds = lds_seeds; ka.twlen = a->twlen; ka.mcoef = a->mcoef; ka.min_score = a->o.min_score;
+			uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), a->n_waves);
+			hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(grid), dim3(64), lds_bytes, a->stream, ka);
+			CK(hipGetLastError());
+			CK(hipMemcpyAsync(hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost, a->stream));
+			CK(hipStreamSynchronize(a->stream));
+			std::vector<uint32_t> big; for(uint32_t wi : work) if(hst[wi].n_root == 0xffffffffu) big.push_back(wi);
+			if(!big.empty()) {
+				CK(hipMemcpyAsync(a->d_work.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, a->stream));
+				if(!launch_serial_k2((uint32_t)big.size())) return false;
+				CK(hipStreamSynchronize(a->stream));
+				CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
+			}
+		} else {
+			if(!launch_serial_k2((uint32_t)work.size())) return false;
+		}
+		CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k2_ms += ms; a->st.k2_launches++;
 
 		if(round == 0) {
