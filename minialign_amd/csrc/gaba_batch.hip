@@ -21,7 +21,7 @@ using namespace gaba;
 struct DevJob { Sec a, b; uint32_t apos, bpos, bw_idx, do_trace; };
 
 /* ---- kernel ---- */
-__global__ void __launch_bounds__(256, 8)
+__global__ void __launch_bounds__(256, 4)
 gaba_extend_batch_kernel(const Consts c, const uint8_t *roots, SeqArena ar_a, SeqArena ar_b,
 	const DevJob *jobs, uint32_t njobs, gaba_xresult_t *res, uint32_t *paths, uint32_t path_stride,
 	uint8_t *slabs, uint64_t slab_bytes, uint32_t *counter, uint64_t *stats, int *errs)

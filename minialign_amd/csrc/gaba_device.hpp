@@ -764,18 +764,25 @@ __device__ __forceinline__ bool trace_pop(Ctx &x, Trace &t, int is_v)
 	return false;
 }
 
-/* trace_core (gaba.c:3111-3228) as an explicit state machine over the reference's labels */
+/*
+ * trace_core (gaba.c:3111-3228).  Everything but the four mask columns is wave-uniform: state lives in locals, the mask
+ * words of lane q are re-read (4 x v_readlane) only when q moves, and the block reload is one shared site at the top of the
+ * dispatch loop.  Same entry points (labels), same tail / bulk mode switches, same exits as the reference.
+ */
 __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 {
 	enum { L_D_HEAD, L_D_MID, L_D_TAIL, L_H_HEAD, L_H_LOOP, L_H_TAIL, L_V_HEAD, L_V_LOOP, L_V_TAIL };
+	const int W = t.W; const bool comb = t.model == MODEL_COMBINED;
+	const uint32_t head_cnt = trace_head_cnt(W);
+	uint32_t blk = lf.blk; int32_t p = (int32_t)lf.p; uint32_t q = lf.q, save = head_cnt;
+	bool bulk = false; t.oob = false;
+	uint32_t dir = (uint32_t)rdfirst((int)blk_at(x, blk)->s.dir_mask) >> (BLK - (p + 1));
+	int32_t g0 = lf.gidx[0], g1 = lf.gidx[1];
+	uint32_t ppos = (uint32_t)t.ppos, pw = t.pw;
+	uint32_t icnt0 = lf.icnt[0], icnt1 = lf.icnt[1], ecnt0 = lf.ecnt[0], ecnt1 = lf.ecnt[1], fcnt0 = lf.fcnt[0], fcnt1 = lf.fcnt[1];
+	uint32_t state = lf.state, n_pop = 0;
 	int lbl;
-	t.bulk = false; t.save = trace_head_cnt(t.W); t.oob = false;
-	t.blk = lf.blk; t.p = (int32_t)lf.p; t.q = lf.q;
-	t.dir_mask = (uint32_t)rdfirst((int)blk_at(x, t.blk)->s.dir_mask) >> (BLK - (t.p + 1));
-	t.gidx[0] = lf.gidx[0]; t.gidx[1] = lf.gidx[1];
-	if(t.blk_loaded != t.blk) { trace_load_block(x, t); }
-	t.qcur = 0xffffffffu;
-	switch(lf.state) {
+	switch(state) {
 		case ts_d:  lbl = L_D_HEAD; break;
 		case ts_v0: lbl = L_V_HEAD; break;
 		case ts_v1: lbl = L_V_TAIL; break;
@@ -783,50 +790,95 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 		case ts_h1: lbl = L_H_TAIL; break;
 		default: return;
 	}
+	if(t.blk_loaded != blk) { t.blk = blk; trace_load_block(x, t); }
+	uint32_t qsel = 0xffffffffu, qh = 0, qv = 0, qe = 0, qf = 0;
+
+	#define TR_BIT(_w)      ( ((_w) >> (31 - p)) & 1u )
+	/* _pop_vector (gaba.c:3114-3122) without the reload */
+	#define TR_POP(_is_v) { \
+		if(!bulk) { if(_is_v) { g1--; } else { g0--; } } \
+		if((ppos & 31) == 0) { if(x.lane == 0) { t.path[ppos >> 5] = pw; } pw = 0; } \
+		ppos--; n_pop++; \
+		if(_is_v) { pw |= 1u << (ppos & 31); } \
+		q += (dir & 1) - (uint32_t)(_is_v); dir >>= 1; p--; }
+
 	while(true) {
-		if(t.blk == NIL) { break; }                 /* fell off the root: cannot happen on a consistent band */
+		if(p < 0) {
+			/* _trace_{bulk,tail}_load_n (gaba.c:3052-3089): step to the previous block, hopping over head blocks */
+			bool prev_head = (rdfirst((int)blk_at(x, blk - (uint32_t)sizeof(Blk))->s.xstat) & HEAD) != 0;
+			uint32_t nb = skip_heads(x, blk - (uint32_t)sizeof(Blk));
+			if(nb == NIL) { blk = NIL; break; }
+			const Blk *pb = blk_at(x, nb);
+			int ac = rdfirst((int)pb->s.acnt), bc = rdfirst((int)pb->s.bcnt);
+			p = ac + bc - 1; dir = (uint32_t)rdfirst((int)pb->s.dir_mask) >> (BLK - (ac + bc));
+			blk = nb; t.blk = nb; trace_load_block(x, t); qsel = 0xffffffffu;
+			bool can_bulk = !(W > g0 - ac) && !(W > g1 - bc);             /* _trace_test_bulk (gaba.c:3035-3046) */
+			if(bulk) {
+				if(can_bulk) { g0 -= ac; g1 -= bc; }
+				else { if(q >= (uint32_t)W) { t.oob = true; break; } g1 += (int32_t)(q - save); g0 += (int32_t)(save - q); save = head_cnt; bulk = false; }
+			} else if(!prev_head) {
+				save--;
+				if(save >= head_cnt && can_bulk) { g0 -= ac; g1 -= bc; save = q; bulk = true; }
+			}
+		}
+		if(qsel != q) {
+			/* (mask >> q) & 1 with the x86 shift-count masking of the reference's word size (gaba.c:2931-2951) */
+			qsel = q; uint32_t ql = (W == 64) ? (q & 63) : (q & 31); bool dead = ql >= (uint32_t)W;
+			qh = dead ? 0u : (uint32_t)rdlane((int)t.lm[0], (int)ql); qv = dead ? 0u : (uint32_t)rdlane((int)t.lm[1], (int)ql);
+			qe = dead ? 0u : (uint32_t)rdlane((int)t.lm[2], (int)ql); qf = dead ? 0u : (uint32_t)rdlane((int)t.lm[3], (int)ql);
+		}
 		if(lbl == L_D_HEAD) {
-			if(!t_diag_h(t)) { lbl = L_H_HEAD; continue; }
-			if(!t.bulk && (t.gidx[0] == 0 || t.gidx[1] == 0)) { lf.state = ts_d; break; }
-			if(trace_pop(x, t, 0)) { break; }
+			if(TR_BIT(qh)) { lbl = L_H_HEAD; continue; }
+			if(!bulk && (g0 == 0 || g1 == 0)) { state = ts_d; break; }
+			TR_POP(0);
 			lbl = L_D_MID;
+			if(p < 0) { continue; }
+			/* fast path: the second half of the diagonal needs no mask word (q may move, the tests come after) */
+			TR_POP(1);
+			lbl = L_D_TAIL;
 		} else if(lbl == L_D_MID) {
-			if(trace_pop(x, t, 1)) { break; }
+			TR_POP(1);
 			lbl = L_D_TAIL;
 		} else if(lbl == L_D_TAIL) {
-			lbl = !t_diag_v(t) ? L_V_HEAD : L_D_HEAD;
+			lbl = TR_BIT(qv) ? L_V_HEAD : L_D_HEAD;
 		} else if(lbl == L_H_HEAD) {
-			if(t_fgap_h(t)) {
-				if(!t.bulk && t.gidx[0] == 0) { lf.state = ts_h0; break; }
-				lf.fcnt[0]++;
-				if(trace_pop(x, t, 0)) { break; }
+			if(comb && TR_BIT(qe) == 0) {                               /* _trace_test_fgap_h */
+				if(!bulk && g0 == 0) { state = ts_h0; break; }
+				fcnt0++;
+				TR_POP(0);
 				lbl = L_D_HEAD;
-			} else { lf.icnt[0]++; lbl = L_H_LOOP; }
+			} else { icnt0++; lbl = L_H_LOOP; }
 		} else if(lbl == L_H_LOOP) {
-			if(!t.bulk && t.gidx[0] == 0) { lf.state = ts_h1; break; }
-			lf.ecnt[0]++;
-			if(trace_pop(x, t, 0)) { break; }
+			if(!bulk && g0 == 0) { state = ts_h1; break; }
+			ecnt0++;
+			TR_POP(0);
 			lbl = L_H_TAIL;
 		} else if(lbl == L_H_TAIL) {
-			lbl = t_gap_h(t) ? L_H_LOOP : L_D_HEAD;
+			lbl = ((comb ? TR_BIT(~qh & qe) : TR_BIT(qe)) == 0) ? L_H_LOOP : L_D_HEAD;     /* _trace_test_gap_h */
 		} else if(lbl == L_V_HEAD) {
-			if(t_fgap_v(t)) {
-				if(!t.bulk && t.gidx[1] == 0) { lf.state = ts_v0; break; }
-				lf.fcnt[1]++;
-				if(trace_pop(x, t, 1)) { break; }
+			if(comb && TR_BIT(qf) == 0) {
+				if(!bulk && g1 == 0) { state = ts_v0; break; }
+				fcnt1++;
+				TR_POP(1);
 				lbl = L_D_TAIL;
-			} else { lf.icnt[1]++; lbl = L_V_LOOP; }
+			} else { icnt1++; lbl = L_V_LOOP; }
 		} else if(lbl == L_V_LOOP) {
-			if(!t.bulk && t.gidx[1] == 0) { lf.state = ts_v1; break; }
-			lf.ecnt[1]++;
-			if(trace_pop(x, t, 1)) { break; }
+			if(!bulk && g1 == 0) { state = ts_v1; break; }
+			ecnt1++;
+			TR_POP(1);
 			lbl = L_V_TAIL;
 		} else { /* L_V_TAIL */
-			lbl = t_gap_v(t) ? L_V_LOOP : L_D_TAIL;
+			lbl = ((comb ? TR_BIT(~qv & qf) : TR_BIT(qf)) == 0) ? L_V_LOOP : L_D_TAIL;
 		}
 	}
-	lf.blk = t.blk; lf.p = (uint32_t)t.p; lf.q = t.q;
-	lf.gidx[0] = t.gidx[0]; lf.gidx[1] = t.gidx[1];
+	#undef TR_BIT
+	#undef TR_POP
+	lf.state = state;
+	lf.blk = blk; lf.p = (uint32_t)p; lf.q = q;
+	lf.gidx[0] = g0; lf.gidx[1] = g1;
+	lf.icnt[0] = icnt0; lf.icnt[1] = icnt1; lf.ecnt[0] = ecnt0; lf.ecnt[1] = ecnt1; lf.fcnt[0] = fcnt0; lf.fcnt[1] = fcnt1;
+	t.blk = blk; t.ppos = ppos; t.pw = pw; t.pw_idx = ppos >> 5;
+	x.n_tr += n_pop;
 }
 
 /* trace_reload_section (gaba.c:2826-2860) */
@@ -897,7 +949,7 @@ __device__ __forceinline__ AlnOut dp_trace_finish(Ctx &x, uint32_t tail_off, Lea
 		slen++;
 		lf.sgidx[0] = lf.gidx[0]; lf.sgidx[1] = lf.gidx[1];
 	}
-	path_flush(x, t);
+	if(x.lane == 0) { t.path[t.ppos >> 5] = t.pw; }
 	if(slen > max_seg) { x.err = 3; }
 	/* reverse the segment array (the reference pushes with seg--) */
 	if(x.lane == 0) {
