@@ -52,13 +52,13 @@ gaba_extend_batch_kernel(const Consts c, const uint8_t *roots, SeqArena ar_a, Se
 		x.err = 0;
 		dp_flush(x);
 
-		/* mm_extend_core call pattern (minialign.c:4075-4112) */
+		/* mm_extend_core call pattern (minialign.c:4075-4112), recording every fill */
 		Sec ca = sa, cb = sb;
-		uint32_t f = dp_fill_root(x, bw, ca, apos, cb, bpos, 0);
-		uint32_t m = f, nfill = 0, maxidx = 0;
-		int64_t mmax;
+		uint32_t f = NIL, m = NIL, nfill = 0, maxidx = 0;
+		int64_t mmax = 0;
 		uint32_t flag = STATUS_TERM;
 		while(true) {
+			f = dp_fill_any(x, f, bw, ca, apos, cb, bpos, 0);
 			const Tail *t = tail_at(x, f);
 			uint32_t st = (uint32_t)rdfirst((int)t->f.status);
 			int64_t fmax = (int64_t)rdfirst64((uint64_t)t->f.max);
@@ -67,13 +67,12 @@ gaba_extend_batch_kernel(const Consts c, const uint8_t *roots, SeqArena ar_a, Se
 				o->max = t->f.max; o->status = t->f.status; o->aid = t->f.aid; o->bid = t->f.bid;
 				o->ascnt = t->f.ascnt; o->bscnt = t->f.bscnt; o->apos = t->f.apos; o->bpos = t->f.bpos;
 			}
-			if(nfill == 0) { mmax = fmax; } else if(fmax > mmax) { m = f; mmax = fmax; maxidx = nfill; }
+			if(nfill == 0 || fmax > mmax) { m = f; mmax = fmax; maxidx = nfill; }
 			nfill++;
 			if((flag & st) != 0 || x.err) { break; }
 			if(st & UPDATE_A) { ca = tailsec; }
 			if(st & UPDATE_B) { cb = tailsec; }
 			flag |= st & (UPDATE_A | UPDATE_B);
-			f = dp_fill(x, f, ca, cb, 0);
 		}
 		Leaf lf;
 		PosPair pp = dp_search_max(x, m, lf);

@@ -309,8 +309,8 @@ __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uin
 
 /* one block of up to BLK vectors.  bounded = per-vector sequence-end tests (fill_cap_seq_bounded, gaba.c:1925-1975).
  * Returns the number of vectors filled. */
-template<int MODEL>
-__device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool bounded)
+template<int MODEL, bool bounded>
+__device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off)
 {
 	const Consts &c = x.c;
 	int W = w.W;
@@ -340,11 +340,12 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 	return k;
 }
 
-__device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool bounded)
+template<bool bounded>
+__device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off)
 {
 	/* the gap model is fixed per context: pick the specialised 32-vector loop once per block */
-	if(x.c.model == MODEL_COMBINED) { return fill_block_t<MODEL_COMBINED>(x, w, f, prev_off, blk_off, bounded); }
-	return fill_block_t<MODEL_AFFINE>(x, w, f, prev_off, blk_off, bounded);
+	if(x.c.model == MODEL_COMBINED) { return fill_block_t<MODEL_COMBINED, bounded>(x, w, f, prev_off, blk_off); }
+	return fill_block_t<MODEL_AFFINE, bounded>(x, w, f, prev_off, blk_off);
 }
 
 /* ---- section / tail plumbing ---- */
@@ -454,24 +455,23 @@ __device__ __forceinline__ uint32_t fill_body(Ctx &x, Work &w, FillState &f, boo
 		uint32_t lb = head_cnt_nz ? w.blk0 : (uint32_t)rdfirst((int)h->s.link);
 		return create_tail(x, w, f, lb, head_cnt_nz, xstat);
 	}
-	/* the bulk / bounded-bulk distinction of the reference only selects where bounds are tested */
-	while(true) {
+	/* bulk blocks while >= 32 bases remain on both sides (the reference's bulk / bounded-bulk variants only differ in where
+	 * bounds are tested) ... */
+	while((xstat & STAT_MASK) == CONT && !x.err) {
 		bool can_bulk = w.rem[0] >= (uint32_t)BLK && w.rem[1] >= (uint32_t)BLK && w.pridx >= (uint32_t)BLK;
-		if(xstat < 0 && last != w.blk0) { break; }                  /* TERM */
-		if((xstat & STAT_MASK) != CONT) { break; }
 		if(!can_bulk) { break; }
 		uint32_t off = slab_alloc(x, sizeof(Blk));
 		if(x.err) { break; }
-		fill_block(x, w, f, last, off, false);
+		fill_block<false>(x, w, f, last, off);
 		last = off; w.nblk++;
 		xstat = (int)(int8_t)((x.c.tx - rdlane(f.xd, w.W / 2)) & TERM);
 	}
-	if((xstat & STAT_MASK) == CONT && !x.err) {
-		/* fill_cap_seq_bounded (gaba.c:1925-1975) */
-		while(xstat >= 0) {
+	/* ... then the per-vector bounded cap (fill_cap_seq_bounded, gaba.c:1925-1975) */
+	if((xstat & STAT_MASK) == CONT) {
+		while(xstat >= 0 && !x.err) {
 			uint32_t off = slab_alloc(x, sizeof(Blk));
 			if(x.err) { break; }
-			uint32_t k = fill_block(x, w, f, last, off, true);
+			uint32_t k = fill_block<true>(x, w, f, last, off);
 			xstat = (int)(int8_t)((x.c.tx - rdlane(f.xd, w.W / 2)) & TERM);
 			if(k != 0) { last = off; w.nblk++; } else { x.top = off; }   /* squash the empty block (gaba.c:1492) */
 			if(k != BLK) { break; }
@@ -480,43 +480,67 @@ __device__ __forceinline__ uint32_t fill_body(Ctx &x, Work &w, FillState &f, boo
 	return create_tail(x, w, f, last, 1, xstat);
 }
 
-/* gaba_dp_fill_root (gaba.c:2110-2154) */
-__device__ __forceinline__ uint32_t dp_fill_root(Ctx &x, int bw_idx, const Sec &a, uint32_t apos, const Sec &b, uint32_t bpos, uint32_t pridx)
+/* gaba_dp_fill_root (gaba.c:2110-2154) when prev_tail == NIL, gaba_dp_fill (gaba.c:2161-2203) otherwise: one body so that
+ * callers that chain fills keep a single inlined copy of the block loop */
+__device__ __forceinline__ uint32_t dp_fill_any(Ctx &x, uint32_t prev_tail, int bw_idx, const Sec &a, uint32_t apos, const Sec &b, uint32_t bpos, uint32_t pridx)
 {
 	Work w; FillState f;
-	uint32_t rt = root_tail(bw_idx);
-	const Tail *root = tail_at(x, rt);
-	/* fill_create_bridge (gaba.c:1339-1370) */
-	uint32_t bo = slab_alloc(x, sizeof(Tail));
-	Tail *br = tail_at(x, bo);
-	int l = x.lane;
-	br->ch[l] = root->ch[l]; br->xd[l] = root->xd[l]; br->md[l] = root->md[l];
-	if(l == 0) {
-		br->mdrop = root->mdrop; br->istat = (uint16_t)(root->istat | 1); br->pridx = root->pridx;
-		br->ridx[0] = a.len - apos; br->ridx[1] = b.len - bpos; br->adv[0] = apos; br->adv[1] = bpos;
-		br->tail = rt; br->last = NIL; br->W = root->W; br->_pad = 0;
-		br->sec[0] = a; br->sec[1] = b;
-		br->f = root->f; br->f.aid = a.id; br->f.bid = b.id;
+	const bool is_root = prev_tail == NIL;
+	uint32_t src = prev_tail, vec_src = prev_tail;
+	if(is_root) {
+		uint32_t rt = root_tail(bw_idx);
+		const Tail *root = tail_at(x, rt);
+		/* fill_create_bridge (gaba.c:1339-1370) */
+		uint32_t bo = slab_alloc(x, sizeof(Tail));
+		Tail *br = tail_at(x, bo);
+		int l = x.lane;
+		br->ch[l] = root->ch[l]; br->xd[l] = root->xd[l]; br->md[l] = root->md[l];
+		if(l == 0) {
+			br->mdrop = root->mdrop; br->istat = (uint16_t)(root->istat | 1); br->pridx = root->pridx;
+			br->ridx[0] = a.len - apos; br->ridx[1] = b.len - bpos; br->adv[0] = apos; br->adv[1] = bpos;
+			br->tail = rt; br->last = NIL; br->W = root->W; br->_pad = 0;
+			br->sec[0] = a; br->sec[1] = b;
+			br->f = root->f; br->f.aid = a.id; br->f.bid = b.id;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		src = bo; vec_src = rt;
 	}
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	load_section(x, w, bo, a, b, pridx == 0 ? 0xffffffffu : pridx);
-	load_vectors(x, w, f, rt);
-	int64_t rap = (int64_t)rdfirst64(root->f.apos), rbp = (int64_t)rdfirst64(root->f.bpos);
-	bool run = !(init_fetch(x, w, f, rap, rbp) < INIT_FETCH_POS);
-	return fill_body(x, w, f, run);
-}
-
-/* gaba_dp_fill (gaba.c:2161-2203) */
-__device__ __forceinline__ uint32_t dp_fill(Ctx &x, uint32_t prev_tail, const Sec &a, const Sec &b, uint32_t pridx)
-{
-	Work w; FillState f;
-	const Tail *t = tail_at(x, prev_tail);
-	load_section(x, w, prev_tail, a, b, pridx == 0 ? (uint32_t)rdfirst((int)t->pridx) : pridx);
-	load_vectors(x, w, f, prev_tail);
+	const Tail *t = tail_at(x, vec_src);
+	uint32_t pr = pridx != 0 ? pridx : (is_root ? 0xffffffffu : (uint32_t)rdfirst((int)t->pridx));
+	load_section(x, w, src, a, b, pr);
+	load_vectors(x, w, f, vec_src);
 	int64_t tap = (int64_t)rdfirst64(t->f.apos), tbp = (int64_t)rdfirst64(t->f.bpos);
 	bool run = true;
-	if(tbp < INIT_FETCH_POS) { run = !(init_fetch(x, w, f, tap, tbp) < INIT_FETCH_POS); }
+	if(is_root || tbp < INIT_FETCH_POS) { run = !(init_fetch(x, w, f, tap, tbp) < INIT_FETCH_POS); }
 	return fill_body(x, w, f, run);
+}
+__device__ __forceinline__ uint32_t dp_fill_root(Ctx &x, int bw_idx, const Sec &a, uint32_t apos, const Sec &b, uint32_t bpos, uint32_t pridx)
+{
+	return dp_fill_any(x, NIL, bw_idx, a, apos, b, bpos, pridx);
+}
+__device__ __forceinline__ uint32_t dp_fill(Ctx &x, uint32_t prev_tail, const Sec &a, const Sec &b, uint32_t pridx)
+{
+	return dp_fill_any(x, prev_tail, 0, a, 0, b, 0, pridx);
+}
+
+/* mm_extend_core (minialign.c:4075-4112): fill_root, then continue into the tail sections until X-drop or until a side that
+ * was already updated asks again; returns the tail with the largest max */
+__device__ __forceinline__ uint32_t extend_core(Ctx &x, int bw_idx, Sec ca, uint32_t apos, Sec cb, uint32_t bpos, const Sec &tailsec, int64_t &mmax_out, uint32_t &n_fill)
+{
+	uint32_t f = NIL, m = NIL, flag = STATUS_TERM; int64_t mmax = 0;
+	while(true) {
+		f = dp_fill_any(x, f, bw_idx, ca, apos, cb, bpos, 0); n_fill++;
+		const Tail *t = tail_at(x, f);
+		uint32_t st = (uint32_t)rdfirst((int)t->f.status);
+		int64_t fm = (int64_t)rdfirst64((uint64_t)t->f.max);
+		if(m == NIL || fm > mmax) { m = f; mmax = fm; }
+		if((flag & st) != 0 || x.err) { break; }
+		if(st & UPDATE_A) { ca = tailsec; }
+		if(st & UPDATE_B) { cb = tailsec; }
+		flag |= st & (UPDATE_A | UPDATE_B);
+	}
+	mmax_out = mmax;
+	return m;
 }
 
 /* ---- max search (gaba.c:2604-2817) ---- */
@@ -639,11 +663,11 @@ __device__ __forceinline__ uint64_t leaf_search(Ctx &x, uint32_t tail_off, Leaf 
 	return plen;
 }
 
-/* gaba_dp_search_max (gaba.c:2776-2817) */
-__device__ __forceinline__ PosPair dp_search_max(Ctx &x, uint32_t tail_off, Leaf &lf)
+/* gaba_dp_search_max (gaba.c:2776-2817), second half: convert the leaf's grid indices to section ids / positions */
+__device__ __forceinline__ PosPair search_max_walk(Ctx &x, uint32_t tail_off, const Leaf &lf, uint64_t plen)
 {
 	PosPair pos;
-	pos.plen = leaf_search(x, tail_off, lf);
+	pos.plen = plen;
 	const Tail *t = tail_at(x, tail_off);
 	int32_t gidx[2] = { lf.gidx[0], lf.gidx[1] }, acc[2] = { 0, 0 };
 	uint32_t id[2] = { (uint32_t)rdfirst((int)t->f.aid), (uint32_t)rdfirst((int)t->f.bid) };
@@ -665,6 +689,11 @@ __device__ __forceinline__ PosPair dp_search_max(Ctx &x, uint32_t tail_off, Leaf
 	}
 	pos.aid = id[0]; pos.bid = id[1]; pos.apos = (uint32_t)gidx[0]; pos.bpos = (uint32_t)gidx[1];
 	return pos;
+}
+__device__ __forceinline__ PosPair dp_search_max(Ctx &x, uint32_t tail_off, Leaf &lf)
+{
+	uint64_t plen = leaf_search(x, tail_off, lf);
+	return search_max_walk(x, tail_off, lf, plen);
 }
 
 /* ---- traceback (gaba.c:2820-3407) ---- */

@@ -767,6 +767,63 @@ struct Search {                 /* mm_search_t, minialign.c:3218 */
 };
 constexpr uint32_t MM_CREM = 50000, MM_SREM = 8;
 
+/*
+ * The DP phases run as real (non-inlined) device functions from the extension driver: the driver keeps ~150 scalars of
+ * state (search state, four section descriptors, pool pointers), and letting them stay live across the DP loops makes the
+ * compiler spill SGPRs into VGPR lanes *inside* those loops.  Across a call they are saved once.  Arguments and results go
+ * by value; uniform values are re-scalarised on entry (arguments travel in VGPRs).
+ */
+struct DpIn {                 /* what a DP phase needs of the wave's context */
+	gaba::Consts c; gaba::SeqArena ar0, ar1; uint8_t *slab; uint32_t top, cap;
+};
+struct DpOut { uint32_t top; int err; uint32_t n_vec, n_blk, n_tr; };
+__device__ __forceinline__ void dp_ctx_open(gaba::Ctx &x, gaba::SeqArena *ar, const DpIn &in)
+{
+	const uint32_t *src = (const uint32_t *)&in.c; uint32_t *dst = (uint32_t *)&x.c;
+	for(uint32_t i = 0; i < sizeof(gaba::Consts) / 4; i++) { dst[i] = (uint32_t)rdfirst((int)src[i]); }
+	ar[0].pk = (const uint32_t *)rdfirst64((uint64_t)in.ar0.pk); ar[0].nm = (const uint32_t *)rdfirst64((uint64_t)in.ar0.nm);
+	ar[1].pk = (const uint32_t *)rdfirst64((uint64_t)in.ar1.pk); ar[1].nm = (const uint32_t *)rdfirst64((uint64_t)in.ar1.nm);
+	x.ar = ar; x.slab = (uint8_t *)rdfirst64((uint64_t)in.slab); x.top = (uint32_t)rdfirst((int)in.top); x.cap = (uint32_t)rdfirst((int)in.cap);
+	x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+}
+__device__ __forceinline__ gaba::Sec sec_uniform(const gaba::Sec &s)
+{
+	gaba::Sec r; r.id = (uint32_t)rdfirst((int)s.id); r.len = (uint32_t)rdfirst((int)s.len); r.off = rdfirst64(s.off);
+	r.arena = (uint32_t)rdfirst((int)s.arena); r.rev = (uint32_t)rdfirst((int)s.rev); return r;
+}
+struct ExtOut { DpOut d; uint32_t m; int64_t mmax; uint32_t n_fill; };
+__device__ __attribute__((noinline)) ExtOut k3_extend_core(DpIn in, int bw, gaba::Sec ca, uint32_t apos, gaba::Sec cb, uint32_t bpos)
+{
+	gaba::Ctx x; gaba::SeqArena ar[2]; dp_ctx_open(x, ar, in);
+	const gaba::Sec tailsec = { 0xfffffffeu, 96, 0, 2, 0 };
+	ExtOut o; o.n_fill = 0;
+	o.m = gaba::extend_core(x, rdfirst(bw), sec_uniform(ca), (uint32_t)rdfirst((int)apos), sec_uniform(cb), (uint32_t)rdfirst((int)bpos), tailsec, o.mmax, o.n_fill);
+	o.d = DpOut{ x.top, x.err, x.n_vec, x.n_blk, x.n_tr };
+	return o;
+}
+struct LeafOut { DpOut d; gaba::Leaf lf; uint64_t plen; gaba::PosPair pp; };
+__device__ __attribute__((noinline)) LeafOut k3_leaf_search(DpIn in, uint32_t tail, int want_pos)
+{
+	gaba::Ctx x; gaba::SeqArena ar[2]; dp_ctx_open(x, ar, in);
+	LeafOut o;
+	tail = (uint32_t)rdfirst((int)tail);
+	int64_t fbpos = (int64_t)rdfirst64(gaba::tail_at(x, tail)->f.bpos);
+	o.plen = (!want_pos && fbpos < gaba::INIT_FETCH_POS) ? 0 : gaba::leaf_search(x, tail, o.lf);
+	if(want_pos) { o.pp = gaba::search_max_walk(x, tail, o.lf, o.plen); }
+	o.d = DpOut{ x.top, x.err, x.n_vec, x.n_blk, x.n_tr };
+	return o;
+}
+struct TraceOut { DpOut d; gaba::AlnOut ao; };
+__device__ __attribute__((noinline)) TraceOut k3_trace(DpIn in, uint32_t tail, gaba::Leaf lf, uint64_t plen, uint32_t *path, gaba::Segment *seg)
+{
+	gaba::Ctx x; gaba::SeqArena ar[2]; dp_ctx_open(x, ar, in);
+	TraceOut o;
+	uint32_t *lfw = (uint32_t *)&lf; for(uint32_t i = 0; i < sizeof(gaba::Leaf) / 4; i++) { lfw[i] = (uint32_t)rdfirst((int)lfw[i]); }
+	o.ao = gaba::dp_trace_finish(x, (uint32_t)rdfirst((int)tail), lf, rdfirst64(plen), (uint32_t *)rdfirst64((uint64_t)path), (gaba::Segment *)rdfirst64((uint64_t)seg), 8);
+	o.d = DpOut{ x.top, x.err, x.n_vec, x.n_blk, x.n_tr };
+	return o;
+}
+
 __global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
 {
 	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
@@ -911,82 +968,62 @@ __global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
 				first_iter = false;
 				if(!(sr.srem > 0 && sr.prem > 0)) { break; }
 
-				/* one extension trial (minialign.c:4134-4166) */
+				/* one extension trial (minialign.c:4134-4166): pass 0 = downward extension + max search + duplicate test,
+				 * pass 1 = upward extension from the max + max search for the traceback.  One loop so that the DP code is
+				 * instantiated once. */
 				gaba::dp_flush(x);
-				int bw = (int)sr.narrow;                     /* _dp(x) ignores its argument (minialign.c:4123) */
-				/* downward */
-				uint32_t f, m; int64_t mmax;
-				{
-					gaba::Sec ca = rsec_f, cb = sr.rev ? qsec_r : qsec_f;
-					f = gaba::dp_fill_root(x, bw, ca, sr.cp_a, cb, sr.cp_b, 0); m = f; n_fill++;
-					mmax = (int64_t)rdfirst64((uint64_t)gaba::tail_at(x, f)->f.max);
-					uint32_t flag = gaba::STATUS_TERM;
-					while(true) {
-						uint32_t stt = (uint32_t)rdfirst((int)gaba::tail_at(x, f)->f.status);
-						if((flag & stt) != 0 || x.err) { break; }
-						if(stt & gaba::UPDATE_A) { ca = tailsec; }
-						if(stt & gaba::UPDATE_B) { cb = tailsec; }
-						flag |= stt & (gaba::UPDATE_A | gaba::UPDATE_B);
-						f = gaba::dp_fill(x, f, ca, cb, 0);
-						int64_t fm = (int64_t)rdfirst64((uint64_t)gaba::tail_at(x, f)->f.max);
-						if(fm > mmax) { m = f; mmax = fm; }
+				const int bw = (int)sr.narrow;               /* _dp(x) ignores its argument (minialign.c:4123) */
+				uint32_t m = gaba::NIL; int64_t mmax = 0; gaba::Leaf tlf; uint64_t tplen = 0;
+				bool skip = false;
+				for(int pass = 0; pass < 2 && !skip; pass++) {
+					gaba::Sec ca = pass == 0 ? rsec_f : rsec_r;
+					gaba::Sec cb = ((sr.rev != 0) == (pass == 0)) ? qsec_r : qsec_f;
+					uint32_t sa = pass == 0 ? sr.cp_a : rlen - sr.tp_a, sb = pass == 0 ? sr.cp_b : qlen - sr.tp_b;
+					DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
+					ExtOut eo = k3_extend_core(din, bw, ca, sa, cb, sb);
+					x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk);
+					m = (uint32_t)rdfirst((int)eo.m); mmax = (int64_t)rdfirst64((uint64_t)eo.mmax); n_fill += (uint32_t)rdfirst((int)eo.n_fill);
+					if(x.err) { skip = true; break; }
+					if(pass == 0 ? (mmax == 0) : (mmax < (int64_t)a.min_score)) { skip = true; break; }
+					/* leaf_search: for pass 0 this is gaba_dp_search_max, for pass 1 the head of gaba_dp_trace */
+					din.top = x.top;
+					LeafOut lo = k3_leaf_search(din, m, pass == 0);
+					tlf = lo.lf; tplen = rdfirst64(lo.plen);
+					if(pass == 0) {
+						gaba::PosPair pp = lo.pp;
+						pp.apos = (uint32_t)rdfirst((int)pp.apos); pp.bpos = (uint32_t)rdfirst((int)pp.bpos); pp.plen = rdfirst64(pp.plen);
+						/* mm_search_test_dup (minialign.c:3953-3982) */
+						uint64_t key = mm_key((uint64_t)pp.apos | ((uint64_t)pp.bpos << 32), (uint64_t)sr.aid | ((uint64_t)sr.bid << 32));
+						uint64_t prev = 0;
+						if(lane == 0) {
+							uint64_t ti = kh_put(kh, key, true, &err);
+							prev = kh.a[ti].v;
+							kh.a[ti].v = (uint64_t)sr.eid | (0xffffffffull << 32);
+						}
+						prev = rdfirst64(prev); err = (uint32_t)rdfirst((int)err);
+						int32_t pa = max(1, min((int32_t)pp.apos, (int32_t)rlen)), pb = max(1, min((int32_t)pp.bpos, (int32_t)qlen));
+						sr.tp_a = (uint32_t)pa; sr.tp_b = (uint32_t)pb;
+						if(prev != ~0ull) {
+							/* the reference re-reads the slot it has just overwritten, so the "other chain" test never fires */
+							sr.narrow = min(sr.narrow + 1, 2u);
+							skip = true;
+						}
 					}
 				}
 				if(x.err) { err |= ERR_DP_SLAB; break; }
-				if(mmax == 0) { continue; }
-				gaba::Leaf lf;
-				gaba::PosPair pp = gaba::dp_search_max(x, m, lf);
-				/* mm_search_test_dup (minialign.c:3953-3982) */
-				uint32_t dup = 0;
-				{
-					uint64_t key = mm_key((uint64_t)pp.apos | ((uint64_t)pp.bpos << 32), (uint64_t)sr.aid | ((uint64_t)sr.bid << 32));
-					uint64_t prev = 0;
-					if(lane == 0) {
-						uint64_t ti = kh_put(kh, key, true, &err);
-						prev = kh.a[ti].v;
-						kh.a[ti].v = (uint64_t)sr.eid | (0xffffffffull << 32);
-					}
-					prev = rdfirst64(prev); err = (uint32_t)rdfirst((int)err);
-					int32_t pa = max(1, min((int32_t)pp.apos, (int32_t)rlen)), pb = max(1, min((int32_t)pp.bpos, (int32_t)qlen));
-					sr.tp_a = (uint32_t)pa; sr.tp_b = (uint32_t)pb;
-					if(prev != ~0ull) {
-						/* the reference re-reads the slot it has just overwritten, so the "other chain" test never fires */
-						sr.narrow = min(sr.narrow + 1, 2u);
-						dup = 1;
-					}
-				}
-				if(dup) { continue; }
-				/* upward */
-				{
-					gaba::Sec ca = rsec_r, cb = sr.rev ? qsec_f : qsec_r;
-					uint32_t ua = rlen - sr.tp_a, ub = qlen - sr.tp_b;
-					f = gaba::dp_fill_root(x, bw, ca, ua, cb, ub, 0); m = f; n_fill++;
-					mmax = (int64_t)rdfirst64((uint64_t)gaba::tail_at(x, f)->f.max);
-					uint32_t flag = gaba::STATUS_TERM;
-					while(true) {
-						uint32_t stt = (uint32_t)rdfirst((int)gaba::tail_at(x, f)->f.status);
-						if((flag & stt) != 0 || x.err) { break; }
-						if(stt & gaba::UPDATE_A) { ca = tailsec; }
-						if(stt & gaba::UPDATE_B) { cb = tailsec; }
-						flag |= stt & (gaba::UPDATE_A | gaba::UPDATE_B);
-						f = gaba::dp_fill(x, f, ca, cb, 0);
-						int64_t fm = (int64_t)rdfirst64((uint64_t)gaba::tail_at(x, f)->f.max);
-						if(fm > mmax) { m = f; mmax = fm; }
-					}
-				}
-				if(x.err) { err |= ERR_DP_SLAB; break; }
-				if(mmax < (int64_t)a.min_score) { continue; }
+				if(skip) { continue; }
 				/* trace into the output pools */
 				if(n_aln >= a.aln_cap_per_read) { err |= ERR_ALN_CAP; break; }
-				gaba::Leaf tlf;
-				uint64_t tplen = gaba::dp_trace_begin(x, m, tlf);
 				uint64_t need_words = (tplen + 31) / 32 + 2;
 				unsigned long long po = 0, so_ = 0;
 				if(lane == 0) { po = atomicAdd(a.path_top, (unsigned long long)need_words + 2); so_ = atomicAdd(a.seg_top, 8ull); }
 				po = rdfirst64(po); so_ = rdfirst64(so_);
 				if(po + need_words + 2 > a.path_pool_cap || so_ + 8 > a.seg_pool_cap) { err |= ERR_PATH_CAP; break; }
 				uint32_t *path = a.path_pool + po + 2;
-				gaba::AlnOut ao = gaba::dp_trace_finish(x, m, tlf, tplen, path, a.seg_pool + so_, 8);
+				DpIn din2; din2.c = x.c; din2.ar0 = ar[0]; din2.ar1 = ar[1]; din2.slab = x.slab; din2.top = x.top; din2.cap = x.cap;
+				TraceOut to = k3_trace(din2, m, tlf, tplen, path, a.seg_pool + so_);
+				gaba::AlnOut ao = to.ao; x.err = rdfirst(to.d.err); x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr);
+				ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
 				n_trace++;
 				if(x.err) { err |= (x.err == 1 ? ERR_DP_SLAB : (x.err == 2 ? ERR_PATH_CAP : ERR_SEG_CAP)); break; }
 				if(ao.status != 1) { continue; }           /* NULL alignment: path left the band */
