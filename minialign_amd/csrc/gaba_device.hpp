@@ -101,6 +101,9 @@ __device__ __forceinline__ uint64_t rdfirst64(uint64_t v)
 {
 	return ((uint64_t)(uint32_t)rdfirst((int)(v >> 32)) << 32) | (uint32_t)rdfirst((int)v);
 }
+/* zero-filling variants: bound_ctrl makes the lane without a source read 0, no `old` operand to set up */
+__device__ __forceinline__ int shift_up0(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); }
+__device__ __forceinline__ int shift_dn0(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true); }
 /* lane i <- lane i - 1, lane 0 <- fill  (_bsl_n, v64i8.h:152) */
 __device__ __forceinline__ int shift_up(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
 /* lane i <- lane i + 1, lane 63 <- fill (_bsr_n, v64i8.h:164) */
@@ -180,57 +183,119 @@ __device__ __forceinline__ int score_of(const Consts &c, int ab)
  * one anti-diagonal (gaba.c:1576-1699).  `down` is wave-uniform.  new_base: the base entering the window.
  * Returns t (the per-lane score increment fed to delta / drop / direction).
  */
+/*
+ * The recurrence of one anti-diagonal (gaba.c:1576-1640) after the lane shifts, as one hand-scheduled block: compares write
+ * SGPR pairs, the mask algebra of the COMBINED model runs on the scalar unit, and each of the four traceback bit columns
+ * takes its new bit with a single add-with-carry (m = m + m + bit).  dh/dv/de/df are int8 values kept sign-extended.
+ * Returns the new (dh, dv) in ndh / ndv.
+ */
+template<int MODEL>
+__device__ __forceinline__ void fill_core(const Consts &c, int s, int dh, int dv, int &de, int &df, int &ndh, int &ndv,
+	uint32_t &mh, uint32_t &mv, uint32_t &me, uint32_t &mf)
+{
+	int t, dfh, dfv;
+	uint64_t A, B, C, D;
+	if(MODEL == MODEL_COMBINED) {
+		asm volatile(
+			"v_add_u32 %[dfh], %[gfh], %[dv]\n\t"
+			"v_sub_u32 %[dfv], %[gfv], %[dh]\n\t"
+			"v_bfe_i32 %[dfh], %[dfh], 0, 8\n\t"
+			"v_bfe_i32 %[dfv], %[dfv], 0, 8\n\t"
+			"v_max3_i32 %[t], %[de], %[df], %[dfh]\n\t"
+			"v_max3_i32 %[t], %[t], %[s], %[dfv]\n\t"
+			"v_cmp_eq_u32 %[A], %[t], %[dfh]\n\t"
+			"v_cmp_eq_u32 %[B], %[t], %[de]\n\t"
+			"v_cmp_eq_u32 %[C], %[t], %[dfv]\n\t"
+			"v_cmp_eq_u32 %[D], %[t], %[df]\n\t"
+			"v_add_u32 %[de], %[adjh], %[de]\n\t"
+			"v_add_u32 %[df], %[adjv], %[df]\n\t"
+			"s_andn2_b64 vcc, %[B], %[A]\n\t"                /* gh & ~gfh */
+			"s_or_b64 %[A], %[A], %[B]\n\t"                  /* h */
+			"s_andn2_b64 %[B], %[D], %[C]\n\t"               /* gv & ~gfv */
+			"s_or_b64 %[C], %[C], %[D]\n\t"                  /* v */
+			"v_bfe_i32 %[de], %[de], 0, 8\n\t"
+			"v_bfe_i32 %[df], %[df], 0, 8\n\t"
+			"s_mov_b64 %[D], vcc\n\t"
+			"v_addc_co_u32 %[mh], vcc, %[mh], %[mh], %[A]\n\t"
+			"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t"
+			"v_cmp_ge_i32 %[A], %[t], %[de]\n\t"             /* max(de', t) == t */
+			"v_cmp_ge_i32 %[C], %[t], %[df]\n\t"
+			"v_max_i32 %[de], %[de], %[t]\n\t"
+			"v_max_i32 %[df], %[df], %[t]\n\t"
+			"s_or_b64 %[A], %[A], %[D]\n\t"                  /* e */
+			"s_or_b64 %[C], %[C], %[B]\n\t"                  /* f */
+			"v_add_u32 %[de], %[de], %[dh]\n\t"
+			"v_sub_u32 %[df], %[df], %[dv]\n\t"
+			"v_add_u32 %[ndv], %[dh], %[t]\n\t"
+			"v_sub_u32 %[ndh], %[dv], %[t]\n\t"
+			"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t"
+			"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t"
+			"v_bfe_i32 %[de], %[de], 0, 8\n\t"
+			"v_bfe_i32 %[df], %[df], 0, 8\n\t"
+			"v_bfe_i32 %[ndv], %[ndv], 0, 8\n\t"
+			"v_bfe_i32 %[ndh], %[ndh], 0, 8\n\t"
+			: [de] "+v"(de), [df] "+v"(df), [mh] "+v"(mh), [mv] "+v"(mv), [me] "+v"(me), [mf] "+v"(mf),
+			  [ndh] "=&v"(ndh), [ndv] "=&v"(ndv), [t] "=&v"(t), [dfh] "=&v"(dfh), [dfv] "=&v"(dfv),
+			  [A] "=&s"(A), [B] "=&s"(B), [C] "=&s"(C), [D] "=&s"(D)
+			: [s] "v"(s), [dh] "v"(dh), [dv] "v"(dv), [gfh] "s"(c.gfh), [gfv] "s"(c.gfv), [adjh] "s"(c.adjh), [adjv] "s"(c.adjv)
+			: "vcc");
+	} else {
+		asm volatile(
+			"v_max3_i32 %[t], %[de], %[df], %[s]\n\t"
+			"v_cmp_eq_u32 %[A], %[t], %[de]\n\t"
+			"v_cmp_eq_u32 %[C], %[t], %[df]\n\t"
+			"v_add_u32 %[de], %[adjh], %[de]\n\t"
+			"v_add_u32 %[df], %[adjv], %[df]\n\t"
+			"v_bfe_i32 %[de], %[de], 0, 8\n\t"
+			"v_bfe_i32 %[df], %[df], 0, 8\n\t"
+			"v_addc_co_u32 %[mh], vcc, %[mh], %[mh], %[A]\n\t"
+			"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t"
+			"v_cmp_ge_i32 %[A], %[t], %[de]\n\t"
+			"v_cmp_ge_i32 %[C], %[t], %[df]\n\t"
+			"v_max_i32 %[de], %[de], %[t]\n\t"
+			"v_max_i32 %[df], %[df], %[t]\n\t"
+			"v_add_u32 %[de], %[de], %[dh]\n\t"
+			"v_sub_u32 %[df], %[df], %[dv]\n\t"
+			"v_add_u32 %[ndv], %[dh], %[t]\n\t"
+			"v_sub_u32 %[ndh], %[dv], %[t]\n\t"
+			"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t"
+			"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t"
+			"v_bfe_i32 %[de], %[de], 0, 8\n\t"
+			"v_bfe_i32 %[df], %[df], 0, 8\n\t"
+			"v_bfe_i32 %[ndv], %[ndv], 0, 8\n\t"
+			"v_bfe_i32 %[ndh], %[ndh], 0, 8\n\t"
+			: [de] "+v"(de), [df] "+v"(df), [mh] "+v"(mh), [mv] "+v"(mv), [me] "+v"(me), [mf] "+v"(mf),
+			  [ndh] "=&v"(ndh), [ndv] "=&v"(ndv), [t] "=&v"(t), [A] "=&s"(A), [C] "=&s"(C)
+			: [s] "v"(s), [dh] "v"(dh), [dv] "v"(dv), [adjh] "s"(c.adjh), [adjv] "s"(c.adjv)
+			: "vcc");
+		(void)dfh; (void)dfv; (void)B; (void)D;
+	}
+}
+
+/*
+ * one anti-diagonal (gaba.c:1576-1699).  `down` is wave-uniform.  new_base: the base entering the window.
+ * Returns t (the per-lane score increment fed to delta / drop / direction).
+ */
 template<int MODEL>
 __device__ __forceinline__ int fill_vector(const Consts &c, Band &b, int W, bool down, int new_base, bool lane_top)
 {
 	if(!down) {
 		b.ach = shift_up(b.ach, new_base);
-		b.dh = shift_up(b.dh, 0);
-		b.df = shift_up(b.df, 0);
+		b.dh = shift_up0(b.dh);
+		b.df = shift_up0(b.df);
 	} else {
-		int nb = shift_dn(b.bch, new_base), nv = shift_dn(b.dv, 0), ne = shift_dn(b.de, 0);
+		int nb = shift_dn(b.bch, new_base), nv = shift_dn0(b.dv), ne = shift_dn0(b.de);
 		if(W != 64) {                              /* the top lane of a narrow band takes the fill values */
 			nb = lane_top ? new_base : nb; nv = lane_top ? 0 : nv; ne = lane_top ? 0 : ne;
 		}
 		b.bch = nb; b.dv = nv; b.de = ne;
 	}
 	int s = score_of(c, b.ach | b.bch);
-	int dh = b.dh, dv = b.dv, de = b.de, df = b.df, t;
-	uint32_t bh, bv, be, bf;
-	if(MODEL == MODEL_COMBINED) {                  /* gaba.c:1604-1640 */
-		int dfh = sext8(dv + c.gfh), dfv = sext8(c.gfv - dh);
-		int ss = max(max(de, df), dfh);
-		t = max(max(s, dfv), ss);
-		bool gfh = t == dfh, gh = t == de, gfv = t == dfv, gv = t == df;
-		bh = gfh | gh; gh = gh & !gfh;
-		bv = gfv | gv; gv = gv & !gfv;
-		de = sext8(de + c.adjh);
-		int te = max(de, t);
-		be = gh | (te == t);
-		de = sext8(te + dh);
-		dh = sext8(dh + t);
-		df = sext8(df + c.adjv);
-		int tf = max(df, t);
-		bf = gv | (tf == t);
-		df = sext8(tf - dv);
-	} else {                                       /* AFFINE, gaba.c:1576-1602 */
-		t = max(df, max(de, s));
-		bh = t == de; bv = t == df;
-		de = sext8(de + c.adjh);
-		int te = max(de, t);
-		be = te == t;
-		de = sext8(te + dh);
-		dh = sext8(dh + t);
-		df = sext8(df + c.adjv);
-		int tf = max(df, t);
-		bf = tf == t;
-		df = sext8(tf - dv);
-	}
-	int t2 = sext8(dv - t);
-	b.dv = dh; b.dh = t2; b.de = de; b.df = df;
-	b.mh = (b.mh << 1) | bh; b.mv = (b.mv << 1) | bv; b.me = (b.me << 1) | be; b.mf = (b.mf << 1) | bf;
+	int ndh, ndv;
+	fill_core<MODEL>(c, s, b.dh, b.dv, b.de, b.df, ndh, ndv, b.mh, b.mv, b.me, b.mf);
+	b.dv = ndv; b.dh = ndh;
 	/* _fill_update_delta (gaba.c:1647-1655): uses the new dh / dv */
-	int tt = !down ? sext8(c.ofsh - t2) : sext8(c.ofsv + dh);
+	int tt = !down ? sext8(c.ofsh - ndh) : sext8(c.ofsv + ndv);
 	b.delta = sext8(b.delta + tt);
 	b.drop = min(127, max(-128, b.drop - tt));     /* _subs_n */
 	return tt;
@@ -252,8 +317,8 @@ __device__ __forceinline__ void load_context(Ctx &x, Work &w, FillState &f, uint
 	f.b.dh = sext8((int)d); f.b.dv = sext8((int)(d >> 8)); f.b.de = sext8((int)(d >> 16)); f.b.df = sext8((int)(d >> 24));
 	f.b.delta = 0; f.b.drop = f.xd;
 	f.b.mh = f.b.mv = f.b.me = f.b.mf = 0;
-	w.dmask = 0; w.dacc = rdfirst((int)p->s.acc);
-	w.acnt = 0; w.bcnt = 0;
+	w.dmask = (uint32_t)rdfirst(0); w.dacc = rdfirst((int)p->s.acc);
+	w.acnt = (uint32_t)rdfirst(0); w.bcnt = (uint32_t)rdfirst(0);
 }
 
 /* fill_fetch_core (gaba.c:1125-1144): the windows are already in registers; load the look-ahead */
@@ -322,8 +387,8 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 	int64_t arem = w.rem[0], brem = w.rem[1], prem = w.pridx;
 	uint32_t k = 0;
 	for(; k < BLK; k++) {
-		w.dmask = (w.dmask << 1) | (uint32_t)(w.dacc < 0);         /* _dir_fetch, gaba.c:753 */
-		bool down = w.dmask & 1;
+		const bool down = w.dacc < 0;                                /* _dir_fetch, gaba.c:753 */
+		w.dmask = (w.dmask << 1) | (uint32_t)down;
 		if(bounded) {                                               /* _fill_cap_test_idx, gaba.c:1800-1809 */
 			int64_t ta = arem - (int64_t)(w.acnt + (down ? 0 : 1)), tb = brem - (int64_t)(w.bcnt + (down ? 1 : 0));
 			if((ta | tb | (ta + tb + prem)) < 0) { w.dmask >>= 1; break; }
