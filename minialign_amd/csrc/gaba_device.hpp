@@ -169,136 +169,177 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 	return off;
 }
 
-/* substitution score lookup: _shuf_n(sb, a | b) (gaba.c:1605, 1616): a 16-entry byte table held in four SGPRs, read with
- * two v_perm_b32 (byte select) + one select on bit 3 -- no memory access */
-__device__ __forceinline__ int score_of(const Consts &c, int ab)
+/*
+ * One anti-diagonal (gaba.c:1576-1699) as a single hand-scheduled block per direction: lane shift of the window and of the
+ * two diff vectors that move (DPP wave_shr / wave_shl), score lookup (_shuf_n(sb, a | b), gaba.c:1605: a 16-entry byte
+ * table in four VGPRs read with two v_perm_b32 + a select on bit 3), the recurrence (gaba.c:1576-1640), the delta / drop
+ * update (gaba.c:1647-1655) and the direction accumulator (_dir_update, gaba.c:761).
+ *
+ *  - every int8 quantity is kept sign-extended in a 32-bit lane; additions whose result is compared later use the SDWA
+ *    form `dst_sel:BYTE_0 dst_unused:UNUSED_SEXT` (add + wrap to int8 in one instruction).  The wrap is required: band
+ *    edge lanes do run into it (oracle/ora_gaba.c:og_wrap_events counts such events on the test corpus);
+ *  - compares write SGPR pairs, the mask algebra of the COMBINED model runs on the scalar unit, and each of the four
+ *    traceback bit columns takes its new bit with one add-with-carry (m = m + m + bit);
+ *  - everything is updated in place so that the right / down variants leave the same registers live (no copies at the
+ *    join), and the schedule keeps the gfx950 wait-state rules by construction: >= 2 instructions between a VALU write
+ *    of an SGPR / VCC and its VALU read, >= 1 between an SDWA write and its consumer, >= 2 between a VALU write and a DPP
+ *    read of the same VGPR (the shifted registers are last written >= 5 instructions before the block ends), >= 1 before
+ *    v_readlane of a fresh VGPR.
+ */
+#define GABA_SX         " dst_sel:BYTE_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t"
+#define GABA_SHR        " wave_shr:1 row_mask:0xf bank_mask:0xf"
+#define GABA_SHL        " wave_shl:1 row_mask:0xf bank_mask:0xf"
+#define GABA_PRE_RIGHT \
+	"v_readlane_b32 %[nb], %[look], %[ai]\n\t" \
+	"v_mov_b32_dpp %[ach], %[ach]" GABA_SHR "\n\t" \
+	"v_mov_b32_dpp %[dh], %[dh]" GABA_SHR " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[df], %[df]" GABA_SHR " bound_ctrl:0\n\t" \
+	"v_writelane_b32 %[ach], %[nb], 0\n\t"
+#define GABA_PRE_DOWN_WIDE \
+	"v_readlane_b32 %[nb], %[look], %[bi]\n\t" \
+	"v_mov_b32_dpp %[bch], %[bch]" GABA_SHL "\n\t" \
+	"v_mov_b32_dpp %[dv], %[dv]" GABA_SHL " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[de], %[de]" GABA_SHL " bound_ctrl:0\n\t" \
+	"v_writelane_b32 %[bch], %[nb], 63\n\t"
+#define GABA_PRE_DOWN_NARROW            /* the top lane (W - 1) of a narrow band takes the fill values */ \
+	"s_mov_b32 m0, %[wm1]\n\t" \
+	"v_readlane_b32 %[nb], %[look], %[bi]\n\t" \
+	"v_mov_b32_dpp %[bch], %[bch]" GABA_SHL "\n\t" \
+	"v_mov_b32_dpp %[dv], %[dv]" GABA_SHL " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[de], %[de]" GABA_SHL " bound_ctrl:0\n\t" \
+	"v_writelane_b32 %[bch], %[nb], m0\n\t" \
+	"v_writelane_b32 %[dv], 0, m0\n\t" \
+	"v_writelane_b32 %[de], 0, m0\n\t"
+#define GABA_BODY_COMBINED \
+	"v_or_b32 %[s], %[ach], %[bch]\n\t" \
+	"v_add_u32_sdwa %[dfh], %[gfh], %[dv]" GABA_SX \
+	"v_and_b32 %[t1], 7, %[s]\n\t" \
+	"v_and_b32 %[s], 8, %[s]\n\t" \
+	"v_sub_u32_sdwa %[dfv], %[gfv], %[dh]" GABA_SX \
+	"v_cmp_eq_u32 vcc, 0, %[s]\n\t" \
+	"v_perm_b32 %[t2], %[sb1], %[sb0], %[t1]\n\t" \
+	"v_perm_b32 %[t1], %[sb3], %[sb2], %[t1]\n\t" \
+	"v_max3_i32 %[t], %[de], %[df], %[dfh]\n\t" \
+	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_SX \
+	"v_add_u32_sdwa %[dea], %[adjh], %[de]" GABA_SX \
+	"v_add_u32_sdwa %[dfa], %[adjv], %[df]" GABA_SX \
+	"v_max3_i32 %[t], %[t], %[s], %[dfv]\n\t" \
+	"v_cmp_eq_u32 %[A], %[t], %[dfh]\n\t" \
+	"v_cmp_eq_u32 %[B], %[t], %[de]\n\t" \
+	"v_cmp_eq_u32 %[C], %[t], %[dfv]\n\t" \
+	"v_cmp_eq_u32 %[D], %[t], %[df]\n\t" \
+	"v_max_i32 %[de], %[dea], %[t]\n\t" \
+	"v_max_i32 %[df], %[dfa], %[t]\n\t" \
+	"s_andn2_b64 vcc, %[B], %[A]\n\t"                /* gh & ~gfh */ \
+	"s_or_b64 %[A], %[A], %[B]\n\t"                  /* h */ \
+	"s_andn2_b64 %[B], %[D], %[C]\n\t"               /* gv & ~gfv */ \
+	"s_or_b64 %[C], %[C], %[D]\n\t"                  /* v */ \
+	"s_mov_b64 %[D], vcc\n\t" \
+	"v_addc_co_u32 %[mh], vcc, %[mh], %[mh], %[A]\n\t" \
+	"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t" \
+	"v_cmp_ge_i32 %[A], %[t], %[dea]\n\t"            /* max(de', t) == t */ \
+	"v_cmp_ge_i32 %[C], %[t], %[dfa]\n\t" \
+	"v_sub_u32 %[nd], %[dv], %[t]\n\t"               /* new dh */ \
+	"v_add_u32_sdwa %[de], %[de], %[dh]" GABA_SX \
+	"v_sub_u32_sdwa %[df], %[df], %[dv]" GABA_SX \
+	"v_add_u32 %[dv], %[dh], %[t]\n\t"               /* new dv */ \
+	"s_or_b64 %[A], %[A], %[D]\n\t"                  /* e */ \
+	"s_or_b64 %[C], %[C], %[B]\n\t"                  /* f */ \
+	"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t" \
+	"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t"
+#define GABA_BODY_AFFINE \
+	"v_or_b32 %[s], %[ach], %[bch]\n\t" \
+	"v_and_b32 %[t1], 7, %[s]\n\t" \
+	"v_and_b32 %[s], 8, %[s]\n\t" \
+	"v_add_u32_sdwa %[dea], %[adjh], %[de]" GABA_SX \
+	"v_cmp_eq_u32 vcc, 0, %[s]\n\t" \
+	"v_perm_b32 %[t2], %[sb1], %[sb0], %[t1]\n\t" \
+	"v_perm_b32 %[t1], %[sb3], %[sb2], %[t1]\n\t" \
+	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_SX \
+	"v_add_u32_sdwa %[dfa], %[adjv], %[df]" GABA_SX \
+	"v_max3_i32 %[t], %[de], %[df], %[s]\n\t" \
+	"v_cmp_eq_u32 %[A], %[t], %[de]\n\t" \
+	"v_cmp_eq_u32 %[C], %[t], %[df]\n\t" \
+	"v_max_i32 %[de], %[dea], %[t]\n\t" \
+	"v_max_i32 %[df], %[dfa], %[t]\n\t" \
+	"v_addc_co_u32 %[mh], vcc, %[mh], %[mh], %[A]\n\t" \
+	"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t" \
+	"v_cmp_ge_i32 %[A], %[t], %[dea]\n\t" \
+	"v_cmp_ge_i32 %[C], %[t], %[dfa]\n\t" \
+	"v_sub_u32 %[nd], %[dv], %[t]\n\t" \
+	"v_add_u32_sdwa %[de], %[de], %[dh]" GABA_SX \
+	"v_sub_u32_sdwa %[df], %[df], %[dv]" GABA_SX \
+	"v_add_u32 %[dv], %[dh], %[t]\n\t" \
+	"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t" \
+	"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t"
+/* _fill_update_delta (gaba.c:1647-1655) uses the new dh / dv; then acc += t[0] - t[W - 1] */
+#define GABA_TAIL(first) \
+	first \
+	"v_mov_b32 %[dh], %[nd]\n\t" \
+	"v_add_u32_sdwa %[delta], %[delta], %[t]" GABA_SX \
+	"v_sub_u32 %[drop], %[drop], %[t]\n\t" \
+	"v_med3_i32 %[drop], %[drop], %[cm128], %[c127]\n\t"           /* _subs_n */
+#define GABA_TAIL_RIGHT GABA_TAIL("v_sub_u32_sdwa %[t], %[ofsh], %[nd]" GABA_SX)
+#define GABA_TAIL_DOWN  GABA_TAIL("v_add_u32_sdwa %[t], %[ofsv], %[dv]" GABA_SX)
+
+/* loop-invariant operands of the step, pinned in registers by the caller */
+struct StepK {
+	uint32_t sb0, sb1, sb2, sb3;     /* score table words (VGPR) */
+	int c127;                        /* VGPR constant */
+	int wm1;                         /* W - 1 (SGPR) */
+	int gfh, gfv, adjh, adjv, ofsh, ofsv;   /* SGPR */
+};
+__device__ __forceinline__ StepK step_consts(const Consts &c, int W)
 {
-	uint32_t sel = (uint32_t)ab & 7u;
-	uint32_t lo = __builtin_amdgcn_perm(c.sb[1], c.sb[0], sel);
-	uint32_t hi = __builtin_amdgcn_perm(c.sb[3], c.sb[2], sel);
-	return sext8((int)((ab & 8) ? hi : lo));
+	StepK k;
+	/* the asm below wants the table in VGPRs (v_perm_b32 takes one scalar operand at most) */
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.sb0) : "s"(rdfirst((int)c.sb[0])));
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.sb1) : "s"(rdfirst((int)c.sb[1])));
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.sb2) : "s"(rdfirst((int)c.sb[2])));
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.sb3) : "s"(rdfirst((int)c.sb[3])));
+	asm volatile("v_mov_b32 %0, 0x7f" : "=v"(k.c127));
+	k.wm1 = rdfirst(W - 1);
+	k.gfh = rdfirst(c.gfh); k.gfv = rdfirst(c.gfv); k.adjh = rdfirst(c.adjh); k.adjv = rdfirst(c.adjv);
+	k.ofsh = rdfirst(c.ofsh); k.ofsv = rdfirst(c.ofsv);
+	return k;
 }
 
-/*
- * one anti-diagonal (gaba.c:1576-1699).  `down` is wave-uniform.  new_base: the base entering the window.
- * Returns t (the per-lane score increment fed to delta / drop / direction).
- */
-/*
- * The recurrence of one anti-diagonal (gaba.c:1576-1640) after the lane shifts, as one hand-scheduled block: compares write
- * SGPR pairs, the mask algebra of the COMBINED model runs on the scalar unit, and each of the four traceback bit columns
- * takes its new bit with a single add-with-carry (m = m + m + bit).  dh/dv/de/df are int8 values kept sign-extended.
- * Returns the new (dh, dv) in ndh / ndv.
- */
-template<int MODEL>
-__device__ __forceinline__ void fill_core(const Consts &c, int s, int dh, int dv, int &de, int &df, int &ndh, int &ndv,
-	uint32_t &mh, uint32_t &mv, uint32_t &me, uint32_t &mf)
+#define GABA_STEP_OPERANDS \
+	: [ach] "+v"(b.ach), [bch] "+v"(b.bch), [dh] "+v"(b.dh), [dv] "+v"(b.dv), [de] "+v"(b.de), [df] "+v"(b.df), \
+	  [delta] "+v"(b.delta), [drop] "+v"(b.drop), [mh] "+v"(b.mh), [mv] "+v"(b.mv), [me] "+v"(b.me), [mf] "+v"(b.mf), \
+	  [s] "=&v"(s), [t] "=&v"(t), [t1] "=&v"(t1), [t2] "=&v"(t2), [dfh] "=&v"(dfh), [dfv] "=&v"(dfv), [dea] "=&v"(dea), \
+	  [dfa] "=&v"(dfa), [nd] "=&v"(nd), [A] "=&s"(A), [B] "=&s"(B), [C] "=&s"(C), [D] "=&s"(D), [nb] "=&s"(nb) \
+	: [look] "v"(look), [ai] "s"(ai), [bi] "s"(bi), [down] "s"(down), [sb0] "v"(k.sb0), [sb1] "v"(k.sb1), [sb2] "v"(k.sb2), [sb3] "v"(k.sb3), [c127] "v"(k.c127), [wm1] "s"(k.wm1), \
+	  [gfh] "s"(k.gfh), [gfv] "s"(k.gfv), [adjh] "s"(k.adjh), [adjv] "s"(k.adjv), [ofsh] "s"(k.ofsh), [ofsv] "s"(k.ofsv), \
+	  [cm128] "s"(-128) \
+	: "vcc", "scc"
+
+/* both directions live in one asm statement with a scalar branch inside, so that the compiler sees a single in-place
+ * update of the band registers (two statements on an if / else make it copy all twelve at the join) */
+#define GABA_STEP(pre_down, body) \
+	"s_cmp_lg_u32 %[down], 0\n\t" \
+	"s_cbranch_scc1 .Lgaba_down_%=\n\t" \
+	GABA_PRE_RIGHT body GABA_TAIL_RIGHT \
+	"s_branch .Lgaba_end_%=\n" \
+	".Lgaba_down_%=:\n\t" \
+	pre_down body GABA_TAIL_DOWN \
+	".Lgaba_end_%=:\n\t"
+
+/* WIDE: the band spans all 64 lanes (no top-lane patching).  down: wave-uniform direction.  look: the look-ahead bases (lanes
+ * 0..31 next a bases, 32..63 next b bases); ai / bi: the lane of the base entering the window for a right / down step (the
+ * v_readlane sits three instructions ahead of the v_writelane that consumes its SGPR).  Returns t (the per-lane score increment; final >= 4 instructions before the block ends, so a v_readlane may follow). */
+template<int MODEL, bool WIDE>
+__device__ __forceinline__ int step(const StepK &k, Band &b, int look, int down, int ai, int bi)
 {
-	int t, dfh, dfv;
-	uint64_t A, B, C, D;
+	int nb, s, t, t1, t2, dfh, dfv, dea, dfa, nd; uint64_t A, B, C, D;
 	if(MODEL == MODEL_COMBINED) {
-		asm volatile(
-			"v_add_u32 %[dfh], %[gfh], %[dv]\n\t"
-			"v_sub_u32 %[dfv], %[gfv], %[dh]\n\t"
-			"v_bfe_i32 %[dfh], %[dfh], 0, 8\n\t"
-			"v_bfe_i32 %[dfv], %[dfv], 0, 8\n\t"
-			"v_max3_i32 %[t], %[de], %[df], %[dfh]\n\t"
-			"v_max3_i32 %[t], %[t], %[s], %[dfv]\n\t"
-			"v_cmp_eq_u32 %[A], %[t], %[dfh]\n\t"
-			"v_cmp_eq_u32 %[B], %[t], %[de]\n\t"
-			"v_cmp_eq_u32 %[C], %[t], %[dfv]\n\t"
-			"v_cmp_eq_u32 %[D], %[t], %[df]\n\t"
-			"v_add_u32 %[de], %[adjh], %[de]\n\t"
-			"v_add_u32 %[df], %[adjv], %[df]\n\t"
-			"s_andn2_b64 vcc, %[B], %[A]\n\t"                /* gh & ~gfh */
-			"s_or_b64 %[A], %[A], %[B]\n\t"                  /* h */
-			"s_andn2_b64 %[B], %[D], %[C]\n\t"               /* gv & ~gfv */
-			"s_or_b64 %[C], %[C], %[D]\n\t"                  /* v */
-			"v_bfe_i32 %[de], %[de], 0, 8\n\t"
-			"v_bfe_i32 %[df], %[df], 0, 8\n\t"
-			"s_mov_b64 %[D], vcc\n\t"
-			"v_addc_co_u32 %[mh], vcc, %[mh], %[mh], %[A]\n\t"
-			"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t"
-			"v_cmp_ge_i32 %[A], %[t], %[de]\n\t"             /* max(de', t) == t */
-			"v_cmp_ge_i32 %[C], %[t], %[df]\n\t"
-			"v_max_i32 %[de], %[de], %[t]\n\t"
-			"v_max_i32 %[df], %[df], %[t]\n\t"
-			"s_or_b64 %[A], %[A], %[D]\n\t"                  /* e */
-			"s_or_b64 %[C], %[C], %[B]\n\t"                  /* f */
-			"v_add_u32 %[de], %[de], %[dh]\n\t"
-			"v_sub_u32 %[df], %[df], %[dv]\n\t"
-			"v_add_u32 %[ndv], %[dh], %[t]\n\t"
-			"v_sub_u32 %[ndh], %[dv], %[t]\n\t"
-			"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t"
-			"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t"
-			"v_bfe_i32 %[de], %[de], 0, 8\n\t"
-			"v_bfe_i32 %[df], %[df], 0, 8\n\t"
-			"v_bfe_i32 %[ndv], %[ndv], 0, 8\n\t"
-			"v_bfe_i32 %[ndh], %[ndh], 0, 8\n\t"
-			: [de] "+v"(de), [df] "+v"(df), [mh] "+v"(mh), [mv] "+v"(mv), [me] "+v"(me), [mf] "+v"(mf),
-			  [ndh] "=&v"(ndh), [ndv] "=&v"(ndv), [t] "=&v"(t), [dfh] "=&v"(dfh), [dfv] "=&v"(dfv),
-			  [A] "=&s"(A), [B] "=&s"(B), [C] "=&s"(C), [D] "=&s"(D)
-			: [s] "v"(s), [dh] "v"(dh), [dv] "v"(dv), [gfh] "s"(c.gfh), [gfv] "s"(c.gfv), [adjh] "s"(c.adjh), [adjv] "s"(c.adjv)
-			: "vcc");
+		if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_BODY_COMBINED) GABA_STEP_OPERANDS); }
+		else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_BODY_COMBINED) GABA_STEP_OPERANDS); }
 	} else {
-		asm volatile(
-			"v_max3_i32 %[t], %[de], %[df], %[s]\n\t"
-			"v_cmp_eq_u32 %[A], %[t], %[de]\n\t"
-			"v_cmp_eq_u32 %[C], %[t], %[df]\n\t"
-			"v_add_u32 %[de], %[adjh], %[de]\n\t"
-			"v_add_u32 %[df], %[adjv], %[df]\n\t"
-			"v_bfe_i32 %[de], %[de], 0, 8\n\t"
-			"v_bfe_i32 %[df], %[df], 0, 8\n\t"
-			"v_addc_co_u32 %[mh], vcc, %[mh], %[mh], %[A]\n\t"
-			"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t"
-			"v_cmp_ge_i32 %[A], %[t], %[de]\n\t"
-			"v_cmp_ge_i32 %[C], %[t], %[df]\n\t"
-			"v_max_i32 %[de], %[de], %[t]\n\t"
-			"v_max_i32 %[df], %[df], %[t]\n\t"
-			"v_add_u32 %[de], %[de], %[dh]\n\t"
-			"v_sub_u32 %[df], %[df], %[dv]\n\t"
-			"v_add_u32 %[ndv], %[dh], %[t]\n\t"
-			"v_sub_u32 %[ndh], %[dv], %[t]\n\t"
-			"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t"
-			"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t"
-			"v_bfe_i32 %[de], %[de], 0, 8\n\t"
-			"v_bfe_i32 %[df], %[df], 0, 8\n\t"
-			"v_bfe_i32 %[ndv], %[ndv], 0, 8\n\t"
-			"v_bfe_i32 %[ndh], %[ndh], 0, 8\n\t"
-			: [de] "+v"(de), [df] "+v"(df), [mh] "+v"(mh), [mv] "+v"(mv), [me] "+v"(me), [mf] "+v"(mf),
-			  [ndh] "=&v"(ndh), [ndv] "=&v"(ndv), [t] "=&v"(t), [A] "=&s"(A), [C] "=&s"(C)
-			: [s] "v"(s), [dh] "v"(dh), [dv] "v"(dv), [adjh] "s"(c.adjh), [adjv] "s"(c.adjv)
-			: "vcc");
-		(void)dfh; (void)dfv; (void)B; (void)D;
+		if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_BODY_AFFINE) GABA_STEP_OPERANDS); }
+		else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_BODY_AFFINE) GABA_STEP_OPERANDS); }
 	}
-}
-
-/*
- * one anti-diagonal (gaba.c:1576-1699).  `down` is wave-uniform.  new_base: the base entering the window.
- * Returns t (the per-lane score increment fed to delta / drop / direction).
- */
-template<int MODEL>
-__device__ __forceinline__ int fill_vector(const Consts &c, Band &b, int W, bool down, int new_base, bool lane_top)
-{
-	if(!down) {
-		b.ach = shift_up(b.ach, new_base);
-		b.dh = shift_up0(b.dh);
-		b.df = shift_up0(b.df);
-	} else {
-		int nb = shift_dn(b.bch, new_base), nv = shift_dn0(b.dv), ne = shift_dn0(b.de);
-		if(W != 64) {                              /* the top lane of a narrow band takes the fill values */
-			nb = lane_top ? new_base : nb; nv = lane_top ? 0 : nv; ne = lane_top ? 0 : ne;
-		}
-		b.bch = nb; b.dv = nv; b.de = ne;
-	}
-	int s = score_of(c, b.ach | b.bch);
-	int ndh, ndv;
-	fill_core<MODEL>(c, s, b.dh, b.dv, b.de, b.df, ndh, ndv, b.mh, b.mv, b.me, b.mf);
-	b.dv = ndv; b.dh = ndh;
-	/* _fill_update_delta (gaba.c:1647-1655): uses the new dh / dv */
-	int tt = !down ? sext8(c.ofsh - ndh) : sext8(c.ofsv + ndv);
-	b.delta = sext8(b.delta + tt);
-	b.drop = min(127, max(-128, b.drop - tt));     /* _subs_n */
-	return tt;
+	return t;
 }
 
 /* ---- fill state shared by the block routines ---- */
@@ -374,30 +415,32 @@ __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uin
 
 /* one block of up to BLK vectors.  bounded = per-vector sequence-end tests (fill_cap_seq_bounded, gaba.c:1925-1975).
  * Returns the number of vectors filled. */
-template<int MODEL, bool bounded>
+template<int MODEL, bool WIDE, bool bounded>
 __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off)
 {
 	const Consts &c = x.c;
-	int W = w.W;
-	bool lane_top = x.lane == W - 1;
+	const StepK sk = step_consts(c, w.W);
 	uint32_t alen = BLK, blen = BLK;
 	if(bounded) { alen = min(w.rem[0], (uint32_t)BLK); blen = min(w.rem[1], (uint32_t)BLK); }
 	fetch_look(x, w, f, alen, blen);
 	load_context(x, w, f, prev_off);
-	int64_t arem = w.rem[0], brem = w.rem[1], prem = w.pridx;
+	const int64_t arem = (uint32_t)rdfirst((int)w.rem[0]), brem = (uint32_t)rdfirst((int)w.rem[1]), prem = (uint32_t)rdfirst((int)w.pridx);
+	int dacc = rdfirst(w.dacc);
+	uint32_t bi = 32, dmask = 0;                                  /* bi = 32 + bcnt; acnt = k - bcnt */
 	uint32_t k = 0;
 	for(; k < BLK; k++) {
-		const bool down = w.dacc < 0;                                /* _dir_fetch, gaba.c:753 */
-		w.dmask = (w.dmask << 1) | (uint32_t)down;
+		const uint32_t down = (uint32_t)dacc >> 31;                  /* _dir_fetch, gaba.c:753 */
+		const uint32_t ai = k + 32 - bi;
 		if(bounded) {                                               /* _fill_cap_test_idx, gaba.c:1800-1809 */
-			int64_t ta = arem - (int64_t)(w.acnt + (down ? 0 : 1)), tb = brem - (int64_t)(w.bcnt + (down ? 1 : 0));
-			if((ta | tb | (ta + tb + prem)) < 0) { w.dmask >>= 1; break; }
+			int64_t ta = arem - (int64_t)(ai + 1 - down), tb = brem - (int64_t)(bi - 32 + down);
+			if((ta | tb | (ta + tb + prem)) < 0) { break; }
 		}
-		int t;
-		if(down) { int nb = rdlane(f.look, 32 + (int)w.bcnt); w.bcnt++; t = fill_vector<MODEL>(c, f.b, W, true, nb, lane_top); }
-		else { int nb = rdlane(f.look, (int)w.acnt); w.acnt++; t = fill_vector<MODEL>(c, f.b, W, false, nb, lane_top); }
-		w.dacc += rdlane(t, 0) - rdlane(t, W - 1);                  /* _dir_update, gaba.c:761 */
+		dmask = (dmask << 1) + down;
+		const int t = step<MODEL, WIDE>(sk, f.b, f.look, (int)down, (int)ai, (int)bi);
+		bi += down;
+		dacc += rdlane(t, 0) - rdlane(t, sk.wm1);                   /* _dir_update, gaba.c:761 */
 	}
+	w.dacc = dacc; w.bcnt = bi - 32; w.acnt = k - w.bcnt; w.dmask = dmask;
 	w.pridx -= k;
 	x.n_vec += k; x.n_blk += 1;
 	if(k != 0 && k != BLK) { w.dmask <<= (BLK - k); }              /* _dir_adjust_remainder, gaba.c:769 */
@@ -408,9 +451,13 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 template<bool bounded>
 __device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off)
 {
-	/* the gap model is fixed per context: pick the specialised 32-vector loop once per block */
-	if(x.c.model == MODEL_COMBINED) { return fill_block_t<MODEL_COMBINED, bounded>(x, w, f, prev_off, blk_off); }
-	return fill_block_t<MODEL_AFFINE, bounded>(x, w, f, prev_off, blk_off);
+	/* the gap model is fixed per context and the band width per fill: pick the specialised 32-vector loop once per block */
+	if(x.c.model == MODEL_COMBINED) {
+		if(w.W == 64) { return fill_block_t<MODEL_COMBINED, true, bounded>(x, w, f, prev_off, blk_off); }
+		return fill_block_t<MODEL_COMBINED, false, bounded>(x, w, f, prev_off, blk_off);
+	}
+	if(w.W == 64) { return fill_block_t<MODEL_AFFINE, true, bounded>(x, w, f, prev_off, blk_off); }
+	return fill_block_t<MODEL_AFFINE, false, bounded>(x, w, f, prev_off, blk_off);
 }
 
 /* ---- section / tail plumbing ---- */
@@ -692,14 +739,15 @@ __device__ __forceinline__ uint64_t leaf_search(Ctx &x, uint32_t tail_off, Leaf 
 	load_context(x, w, f, b - (uint32_t)sizeof(Blk));
 	int mx = f.b.delta;
 	uint32_t upd = 0;          /* per-lane: bit (k) = updated at vector k */
-	bool lane_top = l == W - 1;
+	const StepK sk = step_consts(c, W);
+	int dacc = rdfirst(w.dacc);
 	for(int k = 0; k < cnt; k++) {
-		w.dmask = (w.dmask << 1) | (uint32_t)(w.dacc < 0);
-		bool down = w.dmask & 1;
-		int tv;
-		if(down) { int nb = rdlane(f.look, 32 + (int)w.bcnt); w.bcnt++; tv = c.model == MODEL_COMBINED ? fill_vector<MODEL_COMBINED>(c, f.b, W, true, nb, lane_top) : fill_vector<MODEL_AFFINE>(c, f.b, W, true, nb, lane_top); }
-		else { int nb = rdlane(f.look, (int)w.acnt); w.acnt++; tv = c.model == MODEL_COMBINED ? fill_vector<MODEL_COMBINED>(c, f.b, W, false, nb, lane_top) : fill_vector<MODEL_AFFINE>(c, f.b, W, false, nb, lane_top); }
-		w.dacc += rdlane(tv, 0) - rdlane(tv, W - 1);
+		const bool down = dacc < 0;
+		const int sd = rdfirst((int)down), sa = rdfirst((int)w.acnt), sb_ = rdfirst(32 + (int)w.bcnt);
+		const int tv = c.model == MODEL_COMBINED ? step<MODEL_COMBINED, false>(sk, f.b, f.look, sd, sa, sb_)
+			: step<MODEL_AFFINE, false>(sk, f.b, f.look, sd, sa, sb_);
+		w.acnt += down ? 0 : 1; w.bcnt += down ? 1 : 0;
+		dacc += rdlane(tv, 0) - rdlane(tv, sk.wm1);
 		upd |= (uint32_t)(act && f.b.delta > mx) << k;
 		mx = max(mx, f.b.delta);
 	}

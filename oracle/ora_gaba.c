@@ -31,8 +31,12 @@ enum { MODEL_AFFINE = 1, MODEL_COMBINED = 2 };
 
 #define MAX2(x, y)  ( (x) > (y) ? (x) : (y) )
 #define MIN2(x, y)  ( (x) < (y) ? (x) : (y) )
-static inline int8_t add8(int a, int b) { return (int8_t)(a + b); }
-static inline int8_t sub8(int a, int b) { return (int8_t)(a - b); }
+/* test instrumentation: counts int8 wrap events of the diff-vector arithmetic (the device code may drop its sign
+ * re-extension only if this stays zero; see tests/test_oracle_gaba.py::test_no_int8_wrap_in_diff_vectors) */
+uint64_t og_wrap_events = 0;
+static inline int8_t add8(int a, int b) { int r = a + b; if(r > 127 || r < -128) { og_wrap_events++; } return (int8_t)r; }
+static inline int8_t sub8(int a, int b) { int r = a - b; if(r > 127 || r < -128) { og_wrap_events++; } return (int8_t)r; }
+static inline int8_t addw8(int a, int b) { return (int8_t)(a + b); }     /* delta: wraps by design (gaba.c:1649) */
 static inline int8_t subs8(int a, int b) { int r = a - b; return (int8_t)(r > 127 ? 127 : (r < -128 ? -128 : r)); }
 static inline int8_t max8(int8_t a, int8_t b) { return a > b ? a : b; }
 static inline uint64_t tz64(uint64_t x) { return x == 0 ? 64 : (uint64_t)__builtin_ctzll(x); }
@@ -388,7 +392,7 @@ static void fill_vector(og_dp_t *dp, regs_t *g, int down, uint64_t m[4])
 		t[l] = !down ? sub8(c->ofsh, t2) : add8(c->ofsv, dh);         /* uses the *new* dh / dv */
 	}
 	for(int l = 0; l < W; l++) {
-		g->delta[l] = add8(g->delta[l], t[l]);
+		g->delta[l] = addw8(g->delta[l], t[l]);
 		g->drop[l] = subs8(g->drop[l], t[l]);
 	}
 	g->dacc += (int32_t)t[0] - (int32_t)t[W - 1];                    /* _dir_update, gaba.c:761 */
@@ -410,7 +414,7 @@ static void store_context(og_dp_t *dp, og_block_t *blk, regs_t *g)
 	uint64_t mm = 0;
 	for(int l = 0; l < W; l++) {
 		int8_t prev_drop = dp->r.xd[l];
-		if(add8(g->drop[l], g->delta[l]) > prev_drop) { mm |= 1ULL << l; }
+		if(addw8(g->drop[l], g->delta[l]) > prev_drop) { mm |= 1ULL << l; }
 	}
 	blk->max_mask = mm;
 	cofs += 0x0100;
@@ -418,7 +422,7 @@ static void store_context(og_dp_t *dp, og_block_t *blk, regs_t *g)
 		int8_t drop = g->drop[l], delta = g->delta[l];
 		int16_t md = dp->r.md[l];
 		md = (int16_t)(md + (int16_t)delta);
-		int8_t ov = (int8_t)(~add8(drop, delta) & (drop & delta));          /* _andn_n(a, b) = ~a & b */
+		int8_t ov = (int8_t)(~addw8(drop, delta) & (drop & delta));          /* _andn_n(a, b) = ~a & b */
 		md = (int16_t)(md + (0x0100 & (int16_t)ov));
 		int8_t uv = (int8_t)(subs8(delta, 0x40) | drop);
 		md = (int16_t)(md + (0x0100 & (int16_t)uv));

@@ -106,6 +106,7 @@ typedef struct {
 	og_segment_t seg[16];
 	uint32_t n_path_words;
 } og_xresult_t;
+extern uint64_t og_wrap_events;      /* test instrumentation, see ora_gaba.c */
 int og_extend(og_dp_t *dp, int bw_idx,
 	uint8_t const *a, uint32_t alen, uint32_t apos, int arev,
 	uint8_t const *b, uint32_t blen, uint32_t bpos, int brev,
