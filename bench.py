@@ -23,7 +23,9 @@ class Stats(ctypes.Structure):
                 ('reads', ctypes.c_uint64), ('bases', ctypes.c_uint64), ('minimizers', ctypes.c_uint64), ('seeds', ctypes.c_uint64),
                 ('fills', ctypes.c_uint64), ('vectors', ctypes.c_uint64), ('blocks', ctypes.c_uint64), ('traces', ctypes.c_uint64),
                 ('trace_steps', ctypes.c_uint64), ('reruns', ctypes.c_uint64),
-                ('host_post_ms', ctypes.c_double), ('host_sam_ms', ctypes.c_double), ('wall_ms', ctypes.c_double)]
+                ('host_post_ms', ctypes.c_double), ('host_sam_ms', ctypes.c_double), ('wall_ms', ctypes.c_double),
+                ('k3_cycles_fill', ctypes.c_uint64), ('k3_cycles_leaf', ctypes.c_uint64), ('k3_cycles_trace', ctypes.c_uint64),
+                ('k3_cycles_total', ctypes.c_uint64)]
 
 def gensim(*args, out):
     exe = os.path.join(ROOT, 'tools', 'gensim')
@@ -144,7 +146,8 @@ def main():
             'config': {'workload': 'E.coli MG1655-size ref x PBSIM-like x%g (%.0f Mb, %d reads) -xpacbio on 1 MI355X per rank' % (args.depth, bases / 1e6, n_reads),
                        'reads_per_rank': n_reads, 'bases_per_rank': bases, 'parallelism': 'reads sharded, index replicated (no collective)',
                        'kernel_ms_per_step': {'sketch_seed': per_step(st.k1_ms), 'sort_chain': per_step(st.k2_ms), 'extend': per_step(st.k3_ms)},
-                       'dp_vectors_per_base': vec / bases, 'reruns_per_step': per_step(st.reruns), 'index_build_s': t_index,
+                       'extend_wave_time_split': {k: getattr(st2, 'k3_cycles_' + k) / max(1, st2.k3_cycles_total) for k in ('fill', 'leaf', 'trace')},
+                       'dp_vectors_per_base': vec / bases, 'trace_steps_per_base': trs / bases, 'reruns_per_step': per_step(st.reruns), 'index_build_s': t_index,
                        'finish_s (D2H + post-map + SAM, untimed)': t_finish, 'sam_bytes': slen.value},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,

@@ -77,6 +77,8 @@ typedef struct {
 	uint64_t k1_launches, k2_launches, k3_launches;
 	uint64_t reads, bases, minimizers, seeds, fills, vectors, blocks, traces, trace_steps, reruns;
 	double host_post_ms, host_sam_ms, wall_ms;
+	/* wave-cycles (s_memtime ticks summed over all waves of the extension kernel): DP fill, max search, traceback, whole wave */
+	uint64_t k3_cycles_fill, k3_cycles_leaf, k3_cycles_trace, k3_cycles_total;
 } mm_stats_t;
 void mm_stats(mm_align_t *a, mm_stats_t *out, int reset);
 

@@ -963,6 +963,49 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 				if(save >= head_cnt && can_bulk) { g0 -= ac; g1 -= bc; save = q; bulk = true; }
 			}
 		}
+		/*
+		 * diagonal run, batched.  The cells a run of diagonals visits are fixed by the direction bits alone: the k-th one
+		 * is (p - 2k, q + popcount(dir[0, 2k)) - k).  Lane k gathers the h / v mask words of its cell (ds_bpermute) and
+		 * two ballots give the first cell where the reference's loop (gaba.c:3133-3160) would leave the diagonal: a set
+		 * v bit (tested first, _trace_test_diag_v at the tail of the previous diagonal) or a set h bit.  The run is
+		 * capped to the vectors of this block and, in tail mode, to the section indices; whatever stops it is handled
+		 * by the step-wise code below.
+		 */
+		if(lbl == L_D_HEAD && p >= 1) {
+			uint32_t nmax = (uint32_t)(p + 1) >> 1;
+			if(!bulk) { nmax = min(nmax, (uint32_t)max(0, min(g0, g1))); }
+			if(nmax > 0) {
+				const uint32_t k = (uint32_t)x.lane;
+				const bool in_run = k < nmax;                                /* nmax <= 16 */
+				const uint32_t qk = q + (uint32_t)__popc(dir & ((1u << ((2 * k) & 31)) - 1u)) - k;
+				const uint32_t qlk = (W == 64) ? (qk & 63) : (qk & 31);
+				const uint32_t hw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qlk << 2), (int)t.lm[0]);
+				const uint32_t vw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qlk << 2), (int)t.lm[1]);
+				const uint32_t sh = (uint32_t)(31 - p) + 2 * k;               /* 31 - (p - 2k) */
+				const bool live = in_run && qlk < (uint32_t)W;
+				const uint64_t eh = __ballot(live && ((hw >> (sh & 31)) & 1u));
+				const uint64_t ev = __ballot(live && k >= 1 && ((vw >> (sh & 31)) & 1u));
+				const uint32_t e_h = eh ? (uint32_t)__builtin_ctzll(eh) : 64u, e_v = ev ? (uint32_t)__builtin_ctzll(ev) : 64u;
+				const uint32_t n = min(min(e_h, e_v), nmax);
+				lbl = (e_v < 64u && e_v <= e_h) ? L_V_HEAD : (e_h < 64u ? L_H_HEAD : L_D_TAIL);
+				if(n > 0) {
+					/* 2n pops: path bits 0,1,0,1,... (gaba.c:3114-3122), i.e. every position of ppos's parity below ppos */
+					uint32_t rem = 2 * n; const uint32_t par = (ppos & 1) ? 0xaaaaaaaau : 0x55555555u;
+					while(rem) {
+						if((ppos & 31) == 0) { if(x.lane == 0) { t.path[ppos >> 5] = pw; } pw = 0; }
+						const uint32_t inw = ((ppos - 1) & 31) + 1, take = min(rem, inw), lo = (ppos - take) & 31;
+						pw |= ((take == 32 ? 0xffffffffu : ((1u << take) - 1u)) << lo) & par;
+						ppos -= take; rem -= take;
+					}
+					q += (uint32_t)__popc(dir & (n == 16 ? 0xffffffffu : ((1u << (2 * n)) - 1u))) - n;
+					dir = n == 16 ? 0u : dir >> (2 * n);
+					p -= (int32_t)(2 * n); n_pop += 2 * n;
+					if(!bulk) { g0 -= (int32_t)n; g1 -= (int32_t)n; }
+					qsel = 0xffffffffu;
+				}
+				continue;
+			}
+		}
 		if(qsel != q) {
 			/* (mask >> q) & 1 with the x86 shift-count masking of the reference's word size (gaba.c:2931-2951) */
 			qsel = q; uint32_t ql = (W == 64) ? (q & 63) : (q & 31); bool dead = ql >= (uint32_t)W;

@@ -839,6 +839,8 @@ __global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
 	const DevIndex &ix = a.idx;
 	const gaba::Sec tailsec = { 0xfffffffeu, 96, 0, 2, 0 };
 	unsigned long long n_fill = 0, n_trace = 0;
+	unsigned long long cy_fill = 0, cy_leaf = 0, cy_trace = 0;        /* wave cycles spent in the three DP phases (s_memtime) */
+	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
 
 	while(true) {
 		uint32_t wi = 0;
@@ -980,7 +982,9 @@ __global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
 					gaba::Sec cb = ((sr.rev != 0) == (pass == 0)) ? qsec_r : qsec_f;
 					uint32_t sa = pass == 0 ? sr.cp_a : rlen - sr.tp_a, sb = pass == 0 ? sr.cp_b : qlen - sr.tp_b;
 					DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
+					const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
 					ExtOut eo = k3_extend_core(din, bw, ca, sa, cb, sb);
+					const unsigned long long cy1 = __builtin_amdgcn_s_memtime(); cy_fill += cy1 - cy0;
 					x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk);
 					m = (uint32_t)rdfirst((int)eo.m); mmax = (int64_t)rdfirst64((uint64_t)eo.mmax); n_fill += (uint32_t)rdfirst((int)eo.n_fill);
 					if(x.err) { skip = true; break; }
@@ -988,6 +992,7 @@ __global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
 					/* leaf_search: for pass 0 this is gaba_dp_search_max, for pass 1 the head of gaba_dp_trace */
 					din.top = x.top;
 					LeafOut lo = k3_leaf_search(din, m, pass == 0);
+					cy_leaf += __builtin_amdgcn_s_memtime() - cy1;
 					tlf = lo.lf; tplen = rdfirst64(lo.plen);
 					if(pass == 0) {
 						gaba::PosPair pp = lo.pp;
@@ -1021,7 +1026,9 @@ __global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
 				if(po + need_words + 2 > a.path_pool_cap || so_ + 8 > a.seg_pool_cap) { err |= ERR_PATH_CAP; break; }
 				uint32_t *path = a.path_pool + po + 2;
 				DpIn din2; din2.c = x.c; din2.ar0 = ar[0]; din2.ar1 = ar[1]; din2.slab = x.slab; din2.top = x.top; din2.cap = x.cap;
+				const unsigned long long cy2 = __builtin_amdgcn_s_memtime();
 				TraceOut to = k3_trace(din2, m, tlf, tplen, path, a.seg_pool + so_);
+				cy_trace += __builtin_amdgcn_s_memtime() - cy2;
 				gaba::AlnOut ao = to.ao; x.err = rdfirst(to.d.err); x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr);
 				ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
 				n_trace++;
@@ -1101,6 +1108,8 @@ __global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
 	if(lane == 0) {
 		atomicAdd(&a.stats[2], n_fill); atomicAdd(&a.stats[3], (unsigned long long)x.n_vec); atomicAdd(&a.stats[4], (unsigned long long)x.n_blk);
 		atomicAdd(&a.stats[5], n_trace); atomicAdd(&a.stats[6], (unsigned long long)x.n_tr);
+		atomicAdd(&a.stats[12], cy_fill); atomicAdd(&a.stats[13], cy_leaf); atomicAdd(&a.stats[14], cy_trace);
+		atomicAdd(&a.stats[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
 	}
 }
 

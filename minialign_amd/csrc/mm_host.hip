@@ -798,6 +798,7 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
 	unsigned long long tops[32]; CK(hipMemcpy(tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
+	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
 	std::vector<Root> root(std::max<uint64_t>(tops[2], 1)); std::vector<uint64_t> bin(std::max<uint64_t>(tops[3], 1)); std::vector<AlnRec> aln(std::max<uint64_t>(tops[4], 1));
