@@ -79,6 +79,8 @@ typedef struct {
 	double host_post_ms, host_sam_ms, wall_ms;
 	/* wave-cycles (s_memtime ticks summed over all waves of the extension kernel): DP fill, max search, traceback, whole wave */
 	uint64_t k3_cycles_fill, k3_cycles_leaf, k3_cycles_trace, k3_cycles_total;
+	/* the same for the first-round sort + chain kernel, and the number of reads whose seed array did not fit the LDS */
+	uint64_t k2_cycles_sort, k2_cycles_chain, k2_cycles_total, k2_reads_hbm;
 } mm_stats_t;
 void mm_stats(mm_align_t *a, mm_stats_t *out, int reset);
 

@@ -476,9 +476,16 @@ __global__ void __launch_bounds__(64) mm_sort_chain_kernel(K2Args a)
 struct K2aArgs {
 	ReadState *st; const uint32_t *work; uint32_t n_work;
 	Seed *seed_pool; Root *root_pool;
-	uint32_t lds_seeds;               /* capacity of the LDS seed array (elements) */
+	uint32_t lds_seeds;               /* capacity of the LDS seed array (elements); 0: sort in place in HBM */
+	uint32_t n_lo, n_hi;              /* this launch takes the reads with n_lo < k2a_need(seed_n) <= n_hi (size class) */
+	uint32_t retry;                   /* 1: take the reads whose leaf area overflowed in their class (flagged n_root = ~0), with room for 2 (n + 1) */
+	uint32_t *counter;                /* work-list cursor of this launch */
 	uint32_t twlen; double mcoef; uint32_t min_score;
+	unsigned long long *prof;         /* [0] sort [1] chain [2] whole wave (s_memtime ticks) [3] reads that did not fit the LDS */
 };
+/* elements a read is given in its first attempt: the seeds, the sentinel and a leaf area of a quarter of that (the worst case of
+ * one leaf per seed is left to the retry launch) */
+__host__ __device__ inline uint32_t k2a_need(uint32_t seed_n) { return (seed_n + 1) + (seed_n + 1) / 4 + 64; }
 typedef __attribute__((address_space(3))) Seed LSeed;
 typedef __attribute__((address_space(3))) uint32_t LU32;
 
@@ -504,9 +511,10 @@ __device__ __forceinline__ void lds_ins_sort(S *beg, S *end)
 /* sort + chain over a seed array that lives either in LDS (S = LSeed) or in HBM (S = Seed); returns false if the leaf area overflowed */
 template<typename S>
 __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t seed_n, LU32 *cnt, LU32 *bb, LU32 *be, LU32 *stack,
-	Root *c, const K2aArgs &a, int lane, uint32_t &nlid_out, uint32_t &ncid_out)
+	Root *c, const K2aArgs &a, int lane, uint32_t &nlid_out, uint32_t &ncid_out, unsigned long long &cy_sort, unsigned long long &cy_chain)
 {
 	const uint32_t n_all = seed_n + 1;
+	const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
 		/* ---- radix_sort_128x ---- */
 		if(n_all <= 64) { if(lane == 0) { lds_ins_sort(s, s + n_all); } }
 		else {
@@ -528,10 +536,19 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 					continue;
 				}
+				/* bucket bounds: each lane owns four consecutive buckets, one wave-wide exclusive scan */
+				{
+					const uint32_t c0 = cnt[4 * lane], c1 = cnt[4 * lane + 1], c2 = cnt[4 * lane + 2], c3 = cnt[4 * lane + 3];
+					uint32_t incl = c0 + c1 + c2 + c3;
+					for(int d = 1; d < 64; d <<= 1) { uint32_t o = (uint32_t)__shfl_up((int)incl, d); if(lane >= d) { incl += o; } }
+					uint32_t acc = beg + incl - (c0 + c1 + c2 + c3);
+					bb[4 * lane] = acc; acc += c0; be[4 * lane] = acc; bb[4 * lane + 1] = acc; acc += c1; be[4 * lane + 1] = acc;
+					bb[4 * lane + 2] = acc; acc += c2; be[4 * lane + 2] = acc; bb[4 * lane + 3] = acc; acc += c3; be[4 * lane + 3] = acc;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 				if(lane == 0) {
-					/* bucket bounds, then the in-place cycle-leader permutation (ksort.h:101-116) */
-					uint32_t acc = beg;
-					for(int k = 0; k < 256; k++) { bb[k] = acc; acc += cnt[k]; be[k] = acc; }
+					/* the in-place cycle-leader permutation (ksort.h:101-116): inherently sequential, and its exact element order is
+					 * what decides ties, so it is replayed as is */
 					for(int k = 0; k < 256;) {
 						uint32_t b = bb[k];
 						if(b != be[k]) {
@@ -544,23 +561,26 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 							} else { bb[k] = b + 1; }
 						} else { ++k; }
 					}
-					uint32_t acc2 = beg;
-					for(int k = 0; k < 256; k++) { bb[k] = acc2; acc2 = be[k]; }
 				}
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				for(int k = lane; k < 256; k += 64) { bb[k] = k == 0 ? beg : be[k - 1]; }
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 				if(sh) {
 					const int ns = sh > 8 ? sh - 8 : 0;
 					/* large buckets go back on the stack (order of siblings is irrelevant), small ones are sorted one per lane */
-					if(lane == 0) {
-						for(int k = 0; k < 256; k++) { uint32_t n = be[k] - bb[k]; if(n > 64) { stack[3 * sp] = bb[k]; stack[3 * sp + 1] = be[k]; stack[3 * sp + 2] = (uint32_t)ns; sp++; } }
+					for(int k0 = 0; k0 < 256; k0 += 64) {
+						const int k = k0 + lane; const uint32_t nb = be[k] - bb[k];
+						const uint64_t m = __ballot(nb > 64);
+						if(nb > 64) { const uint32_t slot = sp + (uint32_t)__popcll(m & ((1ull << lane) - 1)); stack[3 * slot] = bb[k]; stack[3 * slot + 1] = be[k]; stack[3 * slot + 2] = (uint32_t)ns; }
+						sp += (uint32_t)__popcll(m);
 					}
-					sp = (uint32_t)rdfirst((int)sp);
 					for(int k = lane; k < 256; k += 64) { uint32_t n = be[k] - bb[k]; if(n > 1 && n <= 64) { lds_ins_sort(s + bb[k], s + be[k]); } }
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		const unsigned long long cy1 = __builtin_amdgcn_s_memtime(); cy_sort += cy1 - cy0;
 
 		/* ---- mm_chain_seeds (minialign.c:3547-3625) ---- */
 		uint32_t ncid = 0, nlid = seed_n + 1, nlsid = 0; const uint32_t tsid = seed_n;
@@ -634,6 +654,7 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		}
 	nlid_out = nlid; ncid_out = ncid;
+	cy_chain += __builtin_amdgcn_s_memtime() - cy1;
 	return !overflow;
 }
 
@@ -645,29 +666,47 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 	LU32 *bb = cnt + 256, *be = bb + 256;             /* bucket begin / end */
 	LU32 *stack = be + 256;                           /* pending ranges: (beg, end, shift) x 256 */
 	const int lane = lane_id();
-	for(uint32_t wi = blockIdx.x; wi < a.n_work; wi += gridDim.x) {
+	unsigned long long cy_sort = 0, cy_chain = 0, n_big = 0; const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
+	while(true) {
+		uint32_t wi = 0;
+		if(lane == 0) { wi = atomicAdd(a.counter, 1u); }
+		wi = (uint32_t)rdfirst((int)wi);
+		if(wi >= a.n_work) { break; }
 		ReadState *st = &a.st[a.work[wi]];
 		const uint32_t seed_n = (uint32_t)rdfirst((int)st->seed_n);
+		if(seed_n == 0) { if(a.n_lo == 0 && !a.retry && lane == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; } continue; }
+		bool fits;
+		if(a.retry) {
+			if((uint32_t)rdfirst((int)st->n_root) != 0xffffffffu) { continue; }
+			fits = 2 * (seed_n + 1) <= a.lds_seeds;
+		} else {
+			const uint32_t need = k2a_need(seed_n);
+			if(need <= a.n_lo || need > a.n_hi) { continue; }              /* another size class */
+			fits = a.lds_seeds != 0;
+		}
 		Seed *gs = a.seed_pool + rdfirst64(st->seed_off);
 		Root *c = a.root_pool + rdfirst64(st->root_off);
 		const uint32_t gcap = (uint32_t)rdfirst((int)st->seed_cap);
 		if(lane == 0) { st->n_seed = seed_n; st->n_root = 0; st->pred_rid = gaba::NIL; }
-		if(seed_n == 0) { continue; }
-		const bool fits = 2 * (seed_n + 1) <= a.lds_seeds;
 		uint32_t nlid = 0, ncid = 0; bool ok;
 		if(fits) {
 			for(uint32_t i = (uint32_t)lane; i < seed_n; i += 64) { lds_st(&ls[i], gs[i]); }
 			if(lane == 0) { lds_st(&ls[seed_n], Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }); }      /* sentinel, minialign.c:3531 */
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-			ok = sort_chain_wave<LSeed>(ls, a.lds_seeds, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid);
+			ok = sort_chain_wave<LSeed>(ls, a.lds_seeds, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain);
 			if(ok) { for(uint32_t i = (uint32_t)lane; i < nlid; i += 64) { gs[i] = lds_ld(&ls[i]); } }
 		} else {
 			/* too large for LDS: same algorithm in place in HBM */
 			if(lane == 0) { gs[seed_n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }; }
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-			ok = sort_chain_wave<Seed>(gs, gcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid);
+			n_big++;
+			ok = sort_chain_wave<Seed>(gs, gcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain);
 		}
-		if(!ok) { if(lane == 0) { st->err |= ERR_SEED_CAP; } continue; }
+		if(!ok) {
+			/* leaf area exhausted: the seed array in HBM is untouched (LDS case), so the retry launch redoes the read with full room */
+			if(lane == 0) { if(!a.retry && fits) { st->n_root = 0xffffffffu; } else { st->err |= ERR_SEED_CAP; } }
+			continue;
+		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if(lane == 0) {
 			st->seed_n = nlid; st->n_root = ncid;
@@ -683,6 +722,10 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+	if(lane == 0) {
+		atomicAdd(&a.prof[0], cy_sort); atomicAdd(&a.prof[1], cy_chain); atomicAdd(&a.prof[2], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
+		atomicAdd(&a.prof[3], n_big);
 	}
 }
 

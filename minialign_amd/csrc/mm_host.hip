@@ -427,23 +427,28 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		};
 		CK(hipEventRecord(a->ev0, a->stream));
 		if(round == 0) {
-			/* wave-per-read kernel with the seed array in LDS; reads that do not fit are flagged and fall through to the serial one */
-			const uint32_t lds_bytes = 80 * 1024, lds_seeds = (lds_bytes - 1536 * 4) / sizeof(Seed);
+			/* wave-per-read kernel with the seed array in LDS.  Reads are split into size classes by the LDS they need, one launch
+			 * per class (largest first), so that small reads run at 5 blocks per CU while the few large ones still stay on chip;
+			 * whatever exceeds 160 KB is sorted in place in HBM by the same code. */
+			static const uint32_t cls_bytes[] = { 0, 160 * 1024, 80 * 1024, 53 * 1024, 32 * 1024 };
 			static bool attr_set = false;
-			if(!attr_set) { CK(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); attr_set = true; }
+			if(!attr_set) { CK(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
 			K2aArgs ka; ka.st = a->d_st.p; ka.work = a->d_work.p; ka.n_work = (uint32_t)work.size(); ka.seed_pool = a->seed_pool.p; ka.root_pool = a->root_pool.p;
-			ka.lds_seeds = lds_seeds; ka.twlen = a->twlen; ka.mcoef = a->mcoef; ka.min_score = a->o.min_score;
-			uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), a->n_waves);
-			hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(grid), dim3(64), lds_bytes, a->stream, ka);
-			CK(hipGetLastError());
-			CK(hipMemcpyAsync(hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost, a->stream));
-			CK(hipStreamSynchronize(a->stream));
-			std::vector<uint32_t> big; for(uint32_t wi : work) if(hst[wi].n_root == 0xffffffffu) big.push_back(wi);
-			if(!big.empty()) {
-				CK(hipMemcpyAsync(a->d_work.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, a->stream));
-				if(!launch_serial_k2((uint32_t)big.size())) return false;
-				CK(hipStreamSynchronize(a->stream));
-				CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
+			ka.prof = tops + 24; ka.twlen = a->twlen; ka.mcoef = a->mcoef; ka.min_score = a->o.min_score;
+			CK(hipMemsetAsync(tops + 28, 0, 32, a->stream));
+			auto cap_of = [](uint32_t bytes) -> uint32_t { return bytes ? (uint32_t)((bytes - 1536 * 4) / sizeof(Seed)) : 0u; };
+			for(int ci = 0; ci < 6; ci++) {
+				/* ci 0..4: size classes (HBM, 160, 80, 53, 32 KB); ci 5: retry of the reads whose leaf area overflowed, at 160 KB */
+				const uint32_t bytes = ci == 5 ? cls_bytes[1] : cls_bytes[ci];
+				ka.retry = ci == 5;
+				ka.lds_seeds = cap_of(bytes);
+				ka.n_hi = ci == 0 ? 0xffffffffu : cap_of(bytes);
+				ka.n_lo = ci == 0 ? cap_of(cls_bytes[1]) : (ci >= 4 ? 0u : cap_of(cls_bytes[ci + 1]));
+				ka.counter = (uint32_t *)(tops + 28) + ci;
+				const uint32_t per_cu = bytes ? (160 * 1024) / bytes : 8;
+				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / 16) * per_cu);
+				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(grid), dim3(64), bytes ? bytes : 1536 * 4, a->stream, ka);
+				CK(hipGetLastError());
 			}
 		} else {
 			if(!launch_serial_k2((uint32_t)work.size())) return false;
@@ -799,6 +804,7 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 	unsigned long long tops[32]; CK(hipMemcpy(tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
 	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23];
+	a->st.k2_cycles_sort += tops[24]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
 	std::vector<Root> root(std::max<uint64_t>(tops[2], 1)); std::vector<uint64_t> bin(std::max<uint64_t>(tops[3], 1)); std::vector<AlnRec> aln(std::max<uint64_t>(tops[4], 1));
