@@ -61,7 +61,8 @@ struct ReadState {
 	uint32_t pred_rid;                                /* after chaining: reference of the last chain passing the length test */
 	uint32_t done;                                    /* 1: finished (mapped or exhausted rounds) */
 	uint32_t err;                                     /* sticky error flags */
-	uint32_t kh_mask, kh_cnt, kh_ub, _pad0;            /* kh_t state of the per-read position hash (persists across rounds) */
+	uint32_t kh_mask, kh_cnt, kh_ub;                  /* kh_t state of the per-read position hash (persists across rounds) */
+	uint32_t seed_n0;                                 /* seed count as K1 left it: immutable, picks the size class of the first-round sort + chain */
 	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
 	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
 };
@@ -210,7 +211,7 @@ __global__ void __launch_bounds__(256) mm_sketch_seed_kernel(K1Args a)
 		if(lane == 0) { so = atomicAdd(a.seed_top, (unsigned long long)seed_cap); ro = atomicAdd(a.resc_top, (unsigned long long)n_resc + 1); to = atomicAdd(a.root_top, (unsigned long long)root_cap); }
 		so = rdfirst64(so); ro = rdfirst64(ro); to = rdfirst64(to);
 		bool ok = so + seed_cap <= a.seed_pool_cap && ro + n_resc + 1 <= a.resc_pool_cap && to + root_cap <= a.root_pool_cap;
-		if(!ok) { if(lane == 0) { st->err |= ERR_SEED_CAP; st->done = 1; st->seed_n = 0; st->n_seed = 0; st->n_resc = 0; } continue; }
+		if(!ok) { if(lane == 0) { st->err |= ERR_SEED_CAP; st->done = 1; st->seed_n = 0; st->seed_n0 = 0; st->n_seed = 0; st->n_resc = 0; } continue; }
 		Seed *seed = a.seed_pool + so; Resc *resc = a.resc_pool + ro;
 		/* pass 2: expand in order (mm_expand, minialign.c:3420-3447) */
 		uint32_t sp = 0, rp = 0;
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(256) mm_sketch_seed_kernel(K1Args a)
 		n_seedtot += n_seed;
 		if(lane == 0) {
 			st->n_min = n_rec;
-			st->seed_off = so; st->seed_cap = seed_cap; st->seed_n = n_seed; st->n_seed = 0;
+			st->seed_off = so; st->seed_cap = seed_cap; st->seed_n = n_seed; st->seed_n0 = n_seed; st->n_seed = 0;
 			st->resc_off = ro; st->n_resc = n_resc; st->presc = 0;
 			st->root_off = to; st->root_cap = root_cap; st->n_root = 0; st->n_res = 0;
 		}
@@ -589,15 +590,19 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 		while(nlsid < tsid) {
 			const uint32_t lid = nlid++;
 			if(lid >= cap) { overflow = true; break; }
-			const uint32_t l_rid = (uint32_t)rdfirst((int)s[nlsid].rid);
+			/* the seed the chain currently stands on is carried in (uniform) registers: each step takes it from the lanes of the
+			 * chunk it has just scanned instead of reading it back from the array */
+			Seed rs_ = lds_ld(&s[nlsid]);
+			int32_t rs_u = rdfirst((int)rs_.upos), rs_r = rdfirst((int)rs_.rid), rs_v = rdfirst((int)rs_.vpos);
+			const uint32_t l_rid = (uint32_t)rs_r;
 			if(lane == 0) { lds_st(&s[lid], Seed{ nlsid, l_rid, nlsid, 0xffffffffu }); }
-			uint32_t plen = (uint32_t)rdfirst((int)(s[nlsid].upos + s[nlsid].vpos)), scnt = 1;
+			uint32_t plen = (uint32_t)(rs_u + rs_v), scnt = 1;
 			const uint32_t lsid0 = nlsid;
 			uint64_t nrsid = nlsid; nlsid = 0xffffffffu;
 			while(true) {
 				const uint32_t rsid = (uint32_t)nrsid; nrsid = 0;
-				Seed rs_ = lds_ld(&s[rsid]);
-				V4 wv = add_win(V4{ rdfirst((int)rs_.upos), rdfirst((int)rs_.rid), rdfirst((int)rs_.vpos), rdfirst((int)rs_.vpos) }, tw);
+				V4 wv = add_win(V4{ rs_u, rs_r, rs_v, rs_v }, tw);
+				int32_t b_u = 0, b_r = 0, b_v = 0; uint32_t b_lid = 0;          /* record of the seed nrsid points at */
 				bool stop = false;
 				for(uint32_t base = rsid + 1; !stop; base += 64) {
 					const uint32_t sid = base + (uint32_t)lane;
@@ -621,19 +626,19 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 						V4 af = V4{ rdlane(fv.e0, (int)f_in), rdlane(fv.e1, (int)f_in), rdlane(fv.e2, (int)f_in), rdlane(fv.e3, (int)f_in) };
 						wv = update_wv(wv, af);
 						const int64_t di = (int64_t)(((uint64_t)(int64_t)pdiff(wv, af) << 32) | (uint64_t)(base + f_in));
-						nrsid = (uint64_t)((int64_t)nrsid > di ? (int64_t)nrsid : di);
+						if(di > (int64_t)nrsid) { nrsid = (uint64_t)di; b_u = af.e0; b_r = af.e1; b_v = af.e2; b_lid = (uint32_t)rdlane((int)cs.lid, (int)f_in); }
 						pending &= f_in >= 63 ? 0ull : ~((2ull << f_in) - 1);
 					}
 					if(!stop && base + 64 > tsid + 1) { stop = true; }       /* ran past the sentinel (cannot happen: the sentinel breaks) */
 				}
 				if(nrsid == 0) { nrsid = rsid; break; }
 				const uint32_t cand = (uint32_t)nrsid;
-				const uint32_t cl = (uint32_t)rdfirst((int)s[cand].lid);
-				if(cl != 0x7fffffffu) { nrsid = cand; break; }
+				if(b_lid != 0x7fffffffu) { nrsid = cand; break; }           /* s[cand].lid: nothing ahead of the chain has been marked by this leaf */
 				if(lane == 0) { s[cand].lid = lid; }
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 				scnt++;
 				if((uint64_t)nlsid <= nrsid) { nlsid = 0xffffffffu; }
+				rs_u = b_u; rs_r = b_r; rs_v = b_v;
 			}
 			if(nrsid == lsid0) { continue; }
 			uint32_t cid = 0xffffffffu;
@@ -673,7 +678,7 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 		wi = (uint32_t)rdfirst((int)wi);
 		if(wi >= a.n_work) { break; }
 		ReadState *st = &a.st[a.work[wi]];
-		const uint32_t seed_n = (uint32_t)rdfirst((int)st->seed_n);
+		const uint32_t seed_n = (uint32_t)rdfirst((int)st->seed_n0);     /* not seed_n: launches of other classes update that concurrently */
 		if(seed_n == 0) { if(a.n_lo == 0 && !a.retry && lane == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; } continue; }
 		bool fits;
 		if(a.retry) {

@@ -369,12 +369,14 @@ struct mm_align_s {
 	gaba_arena_t *ref_ar = nullptr;
 	uint32_t twlen, tglen; double mcoef, xcoef;
 	hipStream_t stream; hipEvent_t ev0, ev1;
+	hipStream_t k2s[12]; hipEvent_t k2e[12]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
 	/* pools */
 	DBuf<uint32_t> q_pk, q_nm; DBuf<ReadIn> d_in; DBuf<ReadState> d_st; DBuf<uint32_t> d_work;
 	DBuf<MinRec> min_pool; DBuf<Seed> seed_pool; DBuf<Resc> resc_pool; DBuf<Root> root_pool;
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
+	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
 	mm_stats_t st; double t_wall0;
@@ -430,25 +432,34 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			/* wave-per-read kernel with the seed array in LDS.  Reads are split into size classes by the LDS they need, one launch
 			 * per class (largest first), so that small reads run at 5 blocks per CU while the few large ones still stay on chip;
 			 * whatever exceeds 160 KB is sorted in place in HBM by the same code. */
-			static const uint32_t cls_bytes[] = { 0, 160 * 1024, 80 * 1024, 53 * 1024, 32 * 1024 };
+			static const uint32_t cls_div[] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12 };     /* blocks per CU of each class; 0 = HBM */
+			const int n_cls = (int)(sizeof(cls_div) / sizeof(cls_div[0]));
 			static bool attr_set = false;
 			if(!attr_set) { CK(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
 			K2aArgs ka; ka.st = a->d_st.p; ka.work = a->d_work.p; ka.n_work = (uint32_t)work.size(); ka.seed_pool = a->seed_pool.p; ka.root_pool = a->root_pool.p;
 			ka.prof = tops + 24; ka.twlen = a->twlen; ka.mcoef = a->mcoef; ka.min_score = a->o.min_score;
-			CK(hipMemsetAsync(tops + 28, 0, 32, a->stream));
+			CK(hipMemsetAsync(a->d_k2cnt.p, 0, 16 * 4, a->stream));
+			CK(hipEventRecord(a->ev0, a->stream));          /* re-recorded behind the memset: the side streams start from here */
+			auto bytes_of = [](uint32_t div) -> uint32_t { return div ? ((160u * 1024u / div) & ~255u) : 0u; };
 			auto cap_of = [](uint32_t bytes) -> uint32_t { return bytes ? (uint32_t)((bytes - 1536 * 4) / sizeof(Seed)) : 0u; };
-			for(int ci = 0; ci < 6; ci++) {
-				/* ci 0..4: size classes (HBM, 160, 80, 53, 32 KB); ci 5: retry of the reads whose leaf area overflowed, at 160 KB */
-				const uint32_t bytes = ci == 5 ? cls_bytes[1] : cls_bytes[ci];
-				ka.retry = ci == 5;
+			for(int ci = 0; ci <= n_cls; ci++) {
+				/* ci < n_cls: size classes, largest first; ci == n_cls: retry of the reads whose leaf area overflowed, at 160 KB */
+				const uint32_t div = ci == n_cls ? 1u : cls_div[ci];
+				const uint32_t bytes = bytes_of(div);
+				ka.retry = ci == n_cls;
 				ka.lds_seeds = cap_of(bytes);
 				ka.n_hi = ci == 0 ? 0xffffffffu : cap_of(bytes);
-				ka.n_lo = ci == 0 ? cap_of(cls_bytes[1]) : (ci >= 4 ? 0u : cap_of(cls_bytes[ci + 1]));
-				ka.counter = (uint32_t *)(tops + 28) + ci;
-				const uint32_t per_cu = bytes ? (160 * 1024) / bytes : 8;
+				ka.n_lo = ci == 0 ? cap_of(bytes_of(1)) : (ci >= n_cls - 1 ? 0u : cap_of(bytes_of(cls_div[ci + 1])));
+				ka.counter = a->d_k2cnt.p + ci;
+				const uint32_t per_cu = div ? div : 8;
 				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / 16) * per_cu);
-				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(grid), dim3(64), bytes ? bytes : 1536 * 4, a->stream, ka);
+				/* the classes are independent: each goes to its own stream behind ev0 so that their tails overlap; the retry waits for all */
+				hipStream_t sq = ci == n_cls ? a->stream : a->k2s[ci];
+				if(ci < n_cls) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
+				else { for(int j = 0; j < n_cls; j++) { CK(hipStreamWaitEvent(a->stream, a->k2e[j], 0)); } }
+				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(grid), dim3(64), bytes ? bytes : 1536 * 4, sq, ka);
 				CK(hipGetLastError());
+				if(ci < n_cls) { CK(hipEventRecord(a->k2e[ci], sq)); }
 			}
 		} else {
 			if(!launch_serial_k2((uint32_t)work.size())) return false;
@@ -470,6 +481,13 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
 			CK(hipMemcpy(a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState), hipMemcpyHostToDevice));
+		}
+		{
+			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
+			std::vector<uint32_t> by_len(work);
+			if(qlens.size() == n_reads) { std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return qlens[x] > qlens[y]; }); }
+			CK(hipMemcpyAsync(a->d_work.p, by_len.data(), by_len.size() * 4, hipMemcpyHostToDevice, a->stream));
+			CK(hipStreamSynchronize(a->stream));
 		}
 		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
 		K3Args k3; k3.idx = a->dix; k3.gc = a->gctx->hc; k3.roots = a->gctx->droots; k3.ar_ref = gaba::SeqArena{ a->ref_ar->pk, a->ref_ar->nm }; k3.ar_q = gaba::SeqArena{ a->q_pk.p, a->q_nm.p };
@@ -493,7 +511,6 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u)) nxt.push_back(wi);
 		work.swap(nxt);
 	}
-	(void)qlens;
 	return true;
 }
 
@@ -643,7 +660,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	uint64_t slab = (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull;
 	ok &= a->slabs.ensure(slab * a->n_waves);
 	if(ok && a->slabs.n != slab * a->n_waves) { /* keep the per-wave stride derived from the current allocation */ }
-	ok &= a->d_tops.ensure(32);
+	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(16);
 	return ok;
 }
 
@@ -662,6 +679,8 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	double mc = 0, xc = 0; for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 3)) mc += o->p.score_matrix[0]; else xc += o->p.score_matrix[0]; }
 	a->mcoef = mc / 4.0; a->xcoef = xc / 12.0;
 	if(hipStreamCreate(&a->stream) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) { delete a; return NULL; }
+	for(int i = 0; i < 12; i++) { if(hipStreamCreateWithFlags(&a->k2s[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) { delete a; return NULL; } }
+	a->k2s_ok = true;
 	/* reference: one arena, per-sequence offsets */
 	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
 	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
@@ -693,8 +712,9 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
-	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
+	if(a->k2s_ok) { for(int i = 0; i < 12; i++) { (void)hipStreamDestroy(a->k2s[i]); (void)hipEventDestroy(a->k2e[i]); } }
 	delete a;
 }
 extern "C" void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line)
