@@ -87,6 +87,11 @@ struct Consts {
 	int32_t tx;
 	int32_t gi, ge, gfa, gfb;
 	double imx, xmx;
+	/* single-v_perm score lookup (see step()): usable when every table entry has the same sign and sb[a | 2] is one value */
+	int32_t fast_score;  /* 0 / 1 */
+	int32_t score_n;     /* sb[a | 2], sign-extended (selector byte 4) */
+	uint32_t sel_hi;     /* selector bytes 1..3: 0x0c0c0c00 (zero) or 0x0d0d0d00 (0xff) */
+	uint32_t arow[5];    /* arow[a] = { sb[a | 0], sb[a | 4], sb[a | 8], sb[a | 12] } for a = 0..3, N */
 };
 constexpr uint32_t ROOT_STRIDE = sizeof(Blk) + sizeof(Tail);            /* [blk][tail] x {64, 32, 16} at the head of each slab */
 constexpr uint32_t SLAB_HEAD = 3 * ROOT_STRIDE;
@@ -171,63 +176,112 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 
 /*
  * One anti-diagonal (gaba.c:1576-1699) as a single hand-scheduled block per direction: lane shift of the window and of the
- * two diff vectors that move (DPP wave_shr / wave_shl), score lookup (_shuf_n(sb, a | b), gaba.c:1605: a 16-entry byte
- * table in four VGPRs read with two v_perm_b32 + a select on bit 3), the recurrence (gaba.c:1576-1640), the delta / drop
- * update (gaba.c:1647-1655) and the direction accumulator (_dir_update, gaba.c:761).
+ * two diff vectors that move (DPP wave_shr / wave_shl), score lookup (_shuf_n(sb, a | b), gaba.c:1605), the recurrence
+ * (gaba.c:1576-1640), the delta / drop update (gaba.c:1647-1655); the direction accumulator (_dir_update, gaba.c:761) is
+ * fed from the returned t.  The loop is bound by VALU issue (4 cycles per wave64 integer instruction), so the block is
+ * written to the instruction:
  *
  *  - every int8 quantity is kept sign-extended in a 32-bit lane; additions whose result is compared later use the SDWA
  *    form `dst_sel:BYTE_0 dst_unused:UNUSED_SEXT` (add + wrap to int8 in one instruction).  The wrap is required: band
  *    edge lanes do run into it (oracle/ora_gaba.c:og_wrap_events counts such events on the test corpus);
+ *  - delta and drop live in the top byte of their lane (value << 24) while a block is filled: a plain 32-bit add is then
+ *    the wrapping int8 add and v_sub_i32 + clamp is the saturating int8 subtract (_subs_n), and t is produced in the same
+ *    position by an SDWA `dst_sel:BYTE_3` subtract;
+ *  - score lookup, general form: the 16-entry byte table sits in four VGPRs, two v_perm_b32 + a select on bit 3.  Fast form
+ *    (Consts.fast_score: all entries of one sign and one common score against a `b` side N): the `a` window carries, per
+ *    lane, the four scores of its base against b = A, C, G, T as one dword, the `b` window carries a v_perm selector, and
+ *    the lookup is a single v_perm_b32;
  *  - compares write SGPR pairs, the mask algebra of the COMBINED model runs on the scalar unit, and each of the four
  *    traceback bit columns takes its new bit with one add-with-carry (m = m + m + bit);
- *  - everything is updated in place so that the right / down variants leave the same registers live (no copies at the
- *    join), and the schedule keeps the gfx950 wait-state rules by construction: >= 2 instructions between a VALU write
- *    of an SGPR / VCC and its VALU read, >= 1 between an SDWA write and its consumer, >= 2 between a VALU write and a DPP
- *    read of the same VGPR (the shifted registers are last written >= 5 instructions before the block ends), >= 1 before
+ *  - the shifted copies of the two moving vectors go to scratch registers and every result is written to its home register,
+ *    so both directions leave the same registers live (no copies at the join) and no register-to-register move is needed;
+ *  - the schedule keeps the gfx950 wait-state rules by construction: >= 2 instructions between a VALU write of an SGPR /
+ *    VCC and its VALU read, >= 1 between an SDWA write and its consumer, >= 2 between a VALU write and a DPP read of the
+ *    same VGPR (the shifted registers are last written >= 5 instructions before the block ends), >= 1 before a
  *    v_readlane of a fresh VGPR.
  */
 #define GABA_SX         " dst_sel:BYTE_0 dst_unused:UNUSED_SEXT src0_sel:DWORD src1_sel:DWORD\n\t"
+#define GABA_S24        " dst_sel:BYTE_3 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n\t"
 #define GABA_SHR        " wave_shr:1 row_mask:0xf bank_mask:0xf"
 #define GABA_SHL        " wave_shl:1 row_mask:0xf bank_mask:0xf"
+/* right: x0 = shifted dh, x1 = shifted df; down: x0 = shifted dv, x1 = shifted de */
 #define GABA_PRE_RIGHT \
 	"v_readlane_b32 %[nb], %[look], %[ai]\n\t" \
 	"v_mov_b32_dpp %[ach], %[ach]" GABA_SHR "\n\t" \
-	"v_mov_b32_dpp %[dh], %[dh]" GABA_SHR " bound_ctrl:0\n\t" \
-	"v_mov_b32_dpp %[df], %[df]" GABA_SHR " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[x0], %[dh]" GABA_SHR " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[x1], %[df]" GABA_SHR " bound_ctrl:0\n\t" \
 	"v_writelane_b32 %[ach], %[nb], 0\n\t"
 #define GABA_PRE_DOWN_WIDE \
 	"v_readlane_b32 %[nb], %[look], %[bi]\n\t" \
 	"v_mov_b32_dpp %[bch], %[bch]" GABA_SHL "\n\t" \
-	"v_mov_b32_dpp %[dv], %[dv]" GABA_SHL " bound_ctrl:0\n\t" \
-	"v_mov_b32_dpp %[de], %[de]" GABA_SHL " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[x0], %[dv]" GABA_SHL " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[x1], %[de]" GABA_SHL " bound_ctrl:0\n\t" \
 	"v_writelane_b32 %[bch], %[nb], 63\n\t"
 #define GABA_PRE_DOWN_NARROW            /* the top lane (W - 1) of a narrow band takes the fill values */ \
 	"s_mov_b32 m0, %[wm1]\n\t" \
 	"v_readlane_b32 %[nb], %[look], %[bi]\n\t" \
 	"v_mov_b32_dpp %[bch], %[bch]" GABA_SHL "\n\t" \
-	"v_mov_b32_dpp %[dv], %[dv]" GABA_SHL " bound_ctrl:0\n\t" \
-	"v_mov_b32_dpp %[de], %[de]" GABA_SHL " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[x0], %[dv]" GABA_SHL " bound_ctrl:0\n\t" \
+	"v_mov_b32_dpp %[x1], %[de]" GABA_SHL " bound_ctrl:0\n\t" \
 	"v_writelane_b32 %[bch], %[nb], m0\n\t" \
-	"v_writelane_b32 %[dv], 0, m0\n\t" \
-	"v_writelane_b32 %[de], 0, m0\n\t"
-#define GABA_BODY_COMBINED \
+	"v_writelane_b32 %[x0], 0, m0\n\t" \
+	"v_writelane_b32 %[x1], 0, m0\n\t"
+/* register names of the four inputs of the recurrence per direction */
+#define GABA_R_DH "%[x0]"
+#define GABA_R_DV "%[dv]"
+#define GABA_R_DE "%[de]"
+#define GABA_R_DF "%[x1]"
+#define GABA_D_DH "%[dh]"
+#define GABA_D_DV "%[x0]"
+#define GABA_D_DE "%[x1]"
+#define GABA_D_DF "%[df]"
+
+/* heads: everything up to t = max(...) (score s, biased gap candidates dea / dfa, and dfh / dfv for the COMBINED model) */
+#define GABA_HEAD_COMBINED(DH, DV, DE, DF) \
 	"v_or_b32 %[s], %[ach], %[bch]\n\t" \
-	"v_add_u32_sdwa %[dfh], %[gfh], %[dv]" GABA_SX \
+	"v_add_u32_sdwa %[dfh], %[gfh], " DV GABA_SX \
 	"v_and_b32 %[t1], 7, %[s]\n\t" \
 	"v_and_b32 %[s], 8, %[s]\n\t" \
-	"v_sub_u32_sdwa %[dfv], %[gfv], %[dh]" GABA_SX \
+	"v_sub_u32_sdwa %[dfv], %[gfv], " DH GABA_SX \
 	"v_cmp_eq_u32 vcc, 0, %[s]\n\t" \
 	"v_perm_b32 %[t2], %[sb1], %[sb0], %[t1]\n\t" \
 	"v_perm_b32 %[t1], %[sb3], %[sb2], %[t1]\n\t" \
-	"v_max3_i32 %[t], %[de], %[df], %[dfh]\n\t" \
+	"v_max3_i32 %[t], " DE ", " DF ", %[dfh]\n\t" \
 	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_SX \
-	"v_add_u32_sdwa %[dea], %[adjh], %[de]" GABA_SX \
-	"v_add_u32_sdwa %[dfa], %[adjv], %[df]" GABA_SX \
-	"v_max3_i32 %[t], %[t], %[s], %[dfv]\n\t" \
+	"v_add_u32_sdwa %[dea], %[adjh], " DE GABA_SX \
+	"v_add_u32_sdwa %[dfa], %[adjv], " DF GABA_SX \
+	"v_max3_i32 %[t], %[t], %[s], %[dfv]\n\t"
+#define GABA_HEAD_COMBINED_FAST(DH, DV, DE, DF) \
+	"v_add_u32_sdwa %[dfh], %[gfh], " DV GABA_SX \
+	"v_sub_u32_sdwa %[dfv], %[gfv], " DH GABA_SX \
+	"v_perm_b32 %[s], %[cN], %[ach], %[bch]\n\t" \
+	"v_add_u32_sdwa %[dea], %[adjh], " DE GABA_SX \
+	"v_max3_i32 %[t], " DE ", " DF ", %[dfh]\n\t" \
+	"v_add_u32_sdwa %[dfa], %[adjv], " DF GABA_SX \
+	"v_max3_i32 %[t], %[t], %[s], %[dfv]\n\t"
+#define GABA_HEAD_AFFINE(DH, DV, DE, DF) \
+	"v_or_b32 %[s], %[ach], %[bch]\n\t" \
+	"v_and_b32 %[t1], 7, %[s]\n\t" \
+	"v_and_b32 %[s], 8, %[s]\n\t" \
+	"v_add_u32_sdwa %[dea], %[adjh], " DE GABA_SX \
+	"v_cmp_eq_u32 vcc, 0, %[s]\n\t" \
+	"v_perm_b32 %[t2], %[sb1], %[sb0], %[t1]\n\t" \
+	"v_perm_b32 %[t1], %[sb3], %[sb2], %[t1]\n\t" \
+	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_SX \
+	"v_add_u32_sdwa %[dfa], %[adjv], " DF GABA_SX \
+	"v_max3_i32 %[t], " DE ", " DF ", %[s]\n\t"
+#define GABA_HEAD_AFFINE_FAST(DH, DV, DE, DF) \
+	"v_perm_b32 %[s], %[cN], %[ach], %[bch]\n\t" \
+	"v_add_u32_sdwa %[dea], %[adjh], " DE GABA_SX \
+	"v_add_u32_sdwa %[dfa], %[adjv], " DF GABA_SX \
+	"v_max3_i32 %[t], " DE ", " DF ", %[s]\n\t"
+/* cores: mask bits and the four new vectors.  UPD writes the new dh / dv (order per direction: the home register that is
+ * still an input goes last); TT produces t << 24 from the new dh (right) or dv (down), _fill_update_delta gaba.c:1647 */
+#define GABA_CORE_COMBINED(DH, DV, DE, DF, UPD, TT) \
 	"v_cmp_eq_u32 %[A], %[t], %[dfh]\n\t" \
-	"v_cmp_eq_u32 %[B], %[t], %[de]\n\t" \
+	"v_cmp_eq_u32 %[B], %[t], " DE "\n\t" \
 	"v_cmp_eq_u32 %[C], %[t], %[dfv]\n\t" \
-	"v_cmp_eq_u32 %[D], %[t], %[df]\n\t" \
+	"v_cmp_eq_u32 %[D], %[t], " DF "\n\t" \
 	"v_max_i32 %[de], %[dea], %[t]\n\t" \
 	"v_max_i32 %[df], %[dfa], %[t]\n\t" \
 	"s_andn2_b64 vcc, %[B], %[A]\n\t"                /* gh & ~gfh */ \
@@ -239,53 +293,42 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 	"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t" \
 	"v_cmp_ge_i32 %[A], %[t], %[dea]\n\t"            /* max(de', t) == t */ \
 	"v_cmp_ge_i32 %[C], %[t], %[dfa]\n\t" \
-	"v_sub_u32 %[nd], %[dv], %[t]\n\t"               /* new dh */ \
-	"v_add_u32_sdwa %[de], %[de], %[dh]" GABA_SX \
-	"v_sub_u32_sdwa %[df], %[df], %[dv]" GABA_SX \
-	"v_add_u32 %[dv], %[dh], %[t]\n\t"               /* new dv */ \
+	"v_add_u32_sdwa %[de], %[de], " DH GABA_SX \
+	"v_sub_u32_sdwa %[df], %[df], " DV GABA_SX \
+	UPD \
 	"s_or_b64 %[A], %[A], %[D]\n\t"                  /* e */ \
 	"s_or_b64 %[C], %[C], %[B]\n\t"                  /* f */ \
+	TT \
 	"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t" \
-	"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t"
-#define GABA_BODY_AFFINE \
-	"v_or_b32 %[s], %[ach], %[bch]\n\t" \
-	"v_and_b32 %[t1], 7, %[s]\n\t" \
-	"v_and_b32 %[s], 8, %[s]\n\t" \
-	"v_add_u32_sdwa %[dea], %[adjh], %[de]" GABA_SX \
-	"v_cmp_eq_u32 vcc, 0, %[s]\n\t" \
-	"v_perm_b32 %[t2], %[sb1], %[sb0], %[t1]\n\t" \
-	"v_perm_b32 %[t1], %[sb3], %[sb2], %[t1]\n\t" \
-	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_SX \
-	"v_add_u32_sdwa %[dfa], %[adjv], %[df]" GABA_SX \
-	"v_max3_i32 %[t], %[de], %[df], %[s]\n\t" \
-	"v_cmp_eq_u32 %[A], %[t], %[de]\n\t" \
-	"v_cmp_eq_u32 %[C], %[t], %[df]\n\t" \
+	"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t" \
+	"v_add_u32 %[delta], %[delta], %[t]\n\t" \
+	"v_sub_i32 %[drop], %[drop], %[t] clamp\n\t"
+#define GABA_CORE_AFFINE(DH, DV, DE, DF, UPD, TT) \
+	"v_cmp_eq_u32 %[A], %[t], " DE "\n\t" \
+	"v_cmp_eq_u32 %[C], %[t], " DF "\n\t" \
 	"v_max_i32 %[de], %[dea], %[t]\n\t" \
 	"v_max_i32 %[df], %[dfa], %[t]\n\t" \
 	"v_addc_co_u32 %[mh], vcc, %[mh], %[mh], %[A]\n\t" \
 	"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t" \
 	"v_cmp_ge_i32 %[A], %[t], %[dea]\n\t" \
 	"v_cmp_ge_i32 %[C], %[t], %[dfa]\n\t" \
-	"v_sub_u32 %[nd], %[dv], %[t]\n\t" \
-	"v_add_u32_sdwa %[de], %[de], %[dh]" GABA_SX \
-	"v_sub_u32_sdwa %[df], %[df], %[dv]" GABA_SX \
-	"v_add_u32 %[dv], %[dh], %[t]\n\t" \
+	"v_add_u32_sdwa %[de], %[de], " DH GABA_SX \
+	"v_sub_u32_sdwa %[df], %[df], " DV GABA_SX \
+	UPD \
+	TT \
 	"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t" \
-	"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t"
-/* _fill_update_delta (gaba.c:1647-1655) uses the new dh / dv; then acc += t[0] - t[W - 1] */
-#define GABA_TAIL(first) \
-	first \
-	"v_mov_b32 %[dh], %[nd]\n\t" \
-	"v_add_u32_sdwa %[delta], %[delta], %[t]" GABA_SX \
-	"v_sub_u32 %[drop], %[drop], %[t]\n\t" \
-	"v_med3_i32 %[drop], %[drop], %[cm128], %[c127]\n\t"           /* _subs_n */
-#define GABA_TAIL_RIGHT GABA_TAIL("v_sub_u32_sdwa %[t], %[ofsh], %[nd]" GABA_SX)
-#define GABA_TAIL_DOWN  GABA_TAIL("v_add_u32_sdwa %[t], %[ofsv], %[dv]" GABA_SX)
+	"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t" \
+	"v_add_u32 %[delta], %[delta], %[t]\n\t" \
+	"v_sub_i32 %[drop], %[drop], %[t] clamp\n\t"
+#define GABA_UPD_RIGHT  "v_sub_u32 %[dh], %[dv], %[t]\n\t" "v_add_u32 %[dv], %[x0], %[t]\n\t"
+#define GABA_UPD_DOWN   "v_add_u32 %[dv], %[dh], %[t]\n\t" "v_sub_u32 %[dh], %[x0], %[t]\n\t"
+#define GABA_TT_RIGHT   "v_sub_u32_sdwa %[t], %[ofsh], %[dh]" GABA_S24
+#define GABA_TT_DOWN    "v_add_u32_sdwa %[t], %[ofsv], %[dv]" GABA_S24
 
 /* loop-invariant operands of the step, pinned in registers by the caller */
 struct StepK {
-	uint32_t sb0, sb1, sb2, sb3;     /* score table words (VGPR) */
-	int c127;                        /* VGPR constant */
+	uint32_t sb0, sb1, sb2, sb3;     /* score table words (VGPR), general lookup */
+	int cN;                          /* fast lookup: the score against a b side N (SGPR) */
 	int wm1;                         /* W - 1 (SGPR) */
 	int gfh, gfv, adjh, adjv, ofsh, ofsv;   /* SGPR */
 };
@@ -297,7 +340,7 @@ __device__ __forceinline__ StepK step_consts(const Consts &c, int W)
 	asm volatile("v_mov_b32 %0, %1" : "=v"(k.sb1) : "s"(rdfirst((int)c.sb[1])));
 	asm volatile("v_mov_b32 %0, %1" : "=v"(k.sb2) : "s"(rdfirst((int)c.sb[2])));
 	asm volatile("v_mov_b32 %0, %1" : "=v"(k.sb3) : "s"(rdfirst((int)c.sb[3])));
-	asm volatile("v_mov_b32 %0, 0x7f" : "=v"(k.c127));
+	k.cN = rdfirst((int)c.score_n);
 	k.wm1 = rdfirst(W - 1);
 	k.gfh = rdfirst(c.gfh); k.gfv = rdfirst(c.gfv); k.adjh = rdfirst(c.adjh); k.adjv = rdfirst(c.adjv);
 	k.ofsh = rdfirst(c.ofsh); k.ofsv = rdfirst(c.ofsv);
@@ -308,39 +351,60 @@ __device__ __forceinline__ StepK step_consts(const Consts &c, int W)
 	: [ach] "+v"(b.ach), [bch] "+v"(b.bch), [dh] "+v"(b.dh), [dv] "+v"(b.dv), [de] "+v"(b.de), [df] "+v"(b.df), \
 	  [delta] "+v"(b.delta), [drop] "+v"(b.drop), [mh] "+v"(b.mh), [mv] "+v"(b.mv), [me] "+v"(b.me), [mf] "+v"(b.mf), \
 	  [s] "=&v"(s), [t] "=&v"(t), [t1] "=&v"(t1), [t2] "=&v"(t2), [dfh] "=&v"(dfh), [dfv] "=&v"(dfv), [dea] "=&v"(dea), \
-	  [dfa] "=&v"(dfa), [nd] "=&v"(nd), [A] "=&s"(A), [B] "=&s"(B), [C] "=&s"(C), [D] "=&s"(D), [nb] "=&s"(nb) \
-	: [look] "v"(look), [ai] "s"(ai), [bi] "s"(bi), [down] "s"(down), [sb0] "v"(k.sb0), [sb1] "v"(k.sb1), [sb2] "v"(k.sb2), [sb3] "v"(k.sb3), [c127] "v"(k.c127), [wm1] "s"(k.wm1), \
-	  [gfh] "s"(k.gfh), [gfv] "s"(k.gfv), [adjh] "s"(k.adjh), [adjv] "s"(k.adjv), [ofsh] "s"(k.ofsh), [ofsv] "s"(k.ofsv), \
-	  [cm128] "s"(-128) \
+	  [dfa] "=&v"(dfa), [x0] "=&v"(x0), [x1] "=&v"(x1), [A] "=&s"(A), [B] "=&s"(B), [C] "=&s"(C), [D] "=&s"(D), [nb] "=&s"(nb) \
+	: [look] "v"(look), [ai] "s"(ai), [bi] "s"(bi), [down] "s"(down), [sb0] "v"(k.sb0), [sb1] "v"(k.sb1), [sb2] "v"(k.sb2), [sb3] "v"(k.sb3), [wm1] "s"(k.wm1), \
+	  [gfh] "s"(k.gfh), [gfv] "s"(k.gfv), [adjh] "s"(k.adjh), [adjv] "s"(k.adjv), [ofsh] "s"(k.ofsh), [ofsv] "s"(k.ofsv), [cN] "s"(k.cN) \
 	: "vcc", "scc"
 
 /* both directions live in one asm statement with a scalar branch inside, so that the compiler sees a single in-place
  * update of the band registers (two statements on an if / else make it copy all twelve at the join) */
-#define GABA_STEP(pre_down, body) \
+#define GABA_STEP(pre_down, HEAD, CORE) \
 	"s_cmp_lg_u32 %[down], 0\n\t" \
 	"s_cbranch_scc1 .Lgaba_down_%=\n\t" \
-	GABA_PRE_RIGHT body GABA_TAIL_RIGHT \
+	GABA_PRE_RIGHT HEAD(GABA_R_DH, GABA_R_DV, GABA_R_DE, GABA_R_DF) CORE(GABA_R_DH, GABA_R_DV, GABA_R_DE, GABA_R_DF, GABA_UPD_RIGHT, GABA_TT_RIGHT) \
 	"s_branch .Lgaba_end_%=\n" \
 	".Lgaba_down_%=:\n\t" \
-	pre_down body GABA_TAIL_DOWN \
+	pre_down HEAD(GABA_D_DH, GABA_D_DV, GABA_D_DE, GABA_D_DF) CORE(GABA_D_DH, GABA_D_DV, GABA_D_DE, GABA_D_DF, GABA_UPD_DOWN, GABA_TT_DOWN) \
 	".Lgaba_end_%=:\n\t"
 
-/* WIDE: the band spans all 64 lanes (no top-lane patching).  down: wave-uniform direction.  look: the look-ahead bases (lanes
- * 0..31 next a bases, 32..63 next b bases); ai / bi: the lane of the base entering the window for a right / down step (the
- * v_readlane sits three instructions ahead of the v_writelane that consumes its SGPR).  Returns t (the per-lane score increment; final >= 4 instructions before the block ends, so a v_readlane may follow). */
-template<int MODEL, bool WIDE>
+/*
+ * WIDE: the band spans all 64 lanes (no top-lane patching).  FAST: single-v_perm score lookup (the windows then hold score
+ * rows / selectors, see fill_block_t).  down: wave-uniform direction.  look: the look-ahead (lanes 0..31 next a entries,
+ * 32..63 next b entries); ai / bi: the lane of the entry coming into the window for a right / down step (the v_readlane
+ * sits three instructions ahead of the v_writelane that consumes its SGPR).  b.delta / b.drop are in the << 24 domain.
+ * Returns t << 24 (the per-lane score increment), final >= 4 instructions before the block ends, so a v_readlane may follow.
+ */
+template<int MODEL, bool WIDE, bool FAST>
 __device__ __forceinline__ int step(const StepK &k, Band &b, int look, int down, int ai, int bi)
 {
-	int nb, s, t, t1, t2, dfh, dfv, dea, dfa, nd; uint64_t A, B, C, D;
+	int nb, s, t, t1, t2, dfh, dfv, dea, dfa, x0, x1; uint64_t A, B, C, D;
 	if(MODEL == MODEL_COMBINED) {
-		if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_BODY_COMBINED) GABA_STEP_OPERANDS); }
-		else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_BODY_COMBINED) GABA_STEP_OPERANDS); }
+		if(FAST) {
+			if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_HEAD_COMBINED_FAST, GABA_CORE_COMBINED) GABA_STEP_OPERANDS); }
+			else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_HEAD_COMBINED_FAST, GABA_CORE_COMBINED) GABA_STEP_OPERANDS); }
+		} else {
+			if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_HEAD_COMBINED, GABA_CORE_COMBINED) GABA_STEP_OPERANDS); }
+			else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_HEAD_COMBINED, GABA_CORE_COMBINED) GABA_STEP_OPERANDS); }
+		}
 	} else {
-		if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_BODY_AFFINE) GABA_STEP_OPERANDS); }
-		else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_BODY_AFFINE) GABA_STEP_OPERANDS); }
+		if(FAST) {
+			if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_HEAD_AFFINE_FAST, GABA_CORE_AFFINE) GABA_STEP_OPERANDS); }
+			else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_HEAD_AFFINE_FAST, GABA_CORE_AFFINE) GABA_STEP_OPERANDS); }
+		} else {
+			if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_HEAD_AFFINE, GABA_CORE_AFFINE) GABA_STEP_OPERANDS); }
+			else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_HEAD_AFFINE, GABA_CORE_AFFINE) GABA_STEP_OPERANDS); }
+		}
 	}
 	return t;
 }
+/* window encodings of the fast lookup.  a side: the score row of a base code (0..3, 4 = N); b side: the v_perm selector of an
+ * encoded b base (0, 4, 8, 12, 2 = N): byte 0 picks the row byte (or byte 4 = Consts.score_n), bytes 1..3 replicate the sign */
+__device__ __forceinline__ int fast_arow(const Consts &c, int code)
+{
+	return code == 0 ? (int)c.arow[0] : (code == 1 ? (int)c.arow[1] : (code == 2 ? (int)c.arow[2] : (code == 3 ? (int)c.arow[3] : (int)c.arow[4])));
+}
+__device__ __forceinline__ int fast_bsel(const Consts &c, int enc) { return (enc == 2 ? 4 : (enc >> 2)) | (int)c.sel_hi; }
+__device__ __forceinline__ int fast_bdec(int sel) { int v = sel & 7; return v == 4 ? 2 : (v << 2); }
 
 /* ---- fill state shared by the block routines ---- */
 struct FillState {
@@ -415,7 +479,7 @@ __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uin
 
 /* one block of up to BLK vectors.  bounded = per-vector sequence-end tests (fill_cap_seq_bounded, gaba.c:1925-1975).
  * Returns the number of vectors filled. */
-template<int MODEL, bool WIDE, bool bounded>
+template<int MODEL, bool WIDE, bool FAST, bool bounded>
 __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off)
 {
 	const Consts &c = x.c;
@@ -426,6 +490,15 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 	load_context(x, w, f, prev_off);
 	const int64_t arem = (uint32_t)rdfirst((int)w.rem[0]), brem = (uint32_t)rdfirst((int)w.rem[1]), prem = (uint32_t)rdfirst((int)w.pridx);
 	int dacc = rdfirst(w.dacc);
+	/* int8 delta / drop move to the top byte for the duration of the block (see step()) */
+	f.b.delta = 0; f.b.drop = (int)((uint32_t)f.b.drop << 24);
+	const int ach_in = f.b.ach, look_in = f.look;
+	int look = f.look;
+	if(FAST) {
+		/* windows and look-ahead switch to the encodings of the single-v_perm lookup */
+		f.b.ach = fast_arow(c, ach_in); f.b.bch = fast_bsel(c, f.b.bch);
+		look = x.lane < 32 ? fast_arow(c, look_in) : fast_bsel(c, look_in);
+	}
 	uint32_t bi = 32, dmask = 0;                                  /* bi = 32 + bcnt; acnt = k - bcnt */
 	uint32_t k = 0;
 	for(; k < BLK; k++) {
@@ -436,11 +509,20 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 			if((ta | tb | (ta + tb + prem)) < 0) { break; }
 		}
 		dmask = (dmask << 1) + down;
-		const int t = step<MODEL, WIDE>(sk, f.b, f.look, (int)down, (int)ai, (int)bi);
+		const int t = step<MODEL, WIDE, FAST>(sk, f.b, look, (int)down, (int)ai, (int)bi);
 		bi += down;
-		dacc += rdlane(t, 0) - rdlane(t, sk.wm1);                   /* _dir_update, gaba.c:761 */
+		dacc += (rdlane(t, 0) >> 24) - (rdlane(t, sk.wm1) >> 24);   /* _dir_update, gaba.c:761 (t sits in the top byte) */
 	}
 	w.dacc = dacc; w.bcnt = bi - 32; w.acnt = k - w.bcnt; w.dmask = dmask;
+	f.b.delta >>= 24; f.b.drop >>= 24;
+	if(FAST) {
+		/* back to base codes: the a window is the old one moved up by acnt lanes with the consumed look-ahead below it */
+		const int acnt = (int)w.acnt, l = x.lane;
+		const int from_old = __builtin_amdgcn_ds_bpermute(((l - acnt) & 63) << 2, ach_in);
+		const int from_look = __builtin_amdgcn_ds_bpermute(((acnt - 1 - l) & 63) << 2, look_in);
+		f.b.ach = l < acnt ? from_look : from_old;
+		f.b.bch = fast_bdec(f.b.bch);
+	}
 	w.pridx -= k;
 	x.n_vec += k; x.n_blk += 1;
 	if(k != 0 && k != BLK) { w.dmask <<= (BLK - k); }              /* _dir_adjust_remainder, gaba.c:769 */
@@ -451,13 +533,18 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 template<bool bounded>
 __device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off)
 {
-	/* the gap model is fixed per context and the band width per fill: pick the specialised 32-vector loop once per block */
-	if(x.c.model == MODEL_COMBINED) {
-		if(w.W == 64) { return fill_block_t<MODEL_COMBINED, true, bounded>(x, w, f, prev_off, blk_off); }
-		return fill_block_t<MODEL_COMBINED, false, bounded>(x, w, f, prev_off, blk_off);
-	}
-	if(w.W == 64) { return fill_block_t<MODEL_AFFINE, true, bounded>(x, w, f, prev_off, blk_off); }
-	return fill_block_t<MODEL_AFFINE, false, bounded>(x, w, f, prev_off, blk_off);
+	/* the gap model and the lookup form are fixed per context and the band width per fill: pick the specialised
+	 * 32-vector loop once per block */
+	/* the root windows hold two special codes (a = 0x0c, b = 0x03: gaba.c:3739 phantom block) that the row / selector
+	 * encoding cannot express: blocks that still see them take the general lookup (the first one or two after a root) */
+	const bool special = __ballot(x.lane < w.W && (f.b.ach > 4 || ((f.b.bch & 3) != 0 && f.b.bch != 2))) != 0;
+	const bool wide = w.W == 64, fast = x.c.fast_score != 0 && !special;
+	#define GABA_PICK(_m) \
+		( wide ? (fast ? fill_block_t<_m, true, true, bounded>(x, w, f, prev_off, blk_off) : fill_block_t<_m, true, false, bounded>(x, w, f, prev_off, blk_off)) \
+		       : (fast ? fill_block_t<_m, false, true, bounded>(x, w, f, prev_off, blk_off) : fill_block_t<_m, false, false, bounded>(x, w, f, prev_off, blk_off)) )
+	if(x.c.model == MODEL_COMBINED) { return GABA_PICK(MODEL_COMBINED); }
+	return GABA_PICK(MODEL_AFFINE);
+	#undef GABA_PICK
 }
 
 /* ---- section / tail plumbing ---- */
@@ -744,10 +831,10 @@ __device__ __forceinline__ uint64_t leaf_search(Ctx &x, uint32_t tail_off, Leaf 
 	for(int k = 0; k < cnt; k++) {
 		const bool down = dacc < 0;
 		const int sd = rdfirst((int)down), sa = rdfirst((int)w.acnt), sb_ = rdfirst(32 + (int)w.bcnt);
-		const int tv = c.model == MODEL_COMBINED ? step<MODEL_COMBINED, false>(sk, f.b, f.look, sd, sa, sb_)
-			: step<MODEL_AFFINE, false>(sk, f.b, f.look, sd, sa, sb_);
+		const int tv = c.model == MODEL_COMBINED ? step<MODEL_COMBINED, false, false>(sk, f.b, f.look, sd, sa, sb_)
+			: step<MODEL_AFFINE, false, false>(sk, f.b, f.look, sd, sa, sb_);
 		w.acnt += down ? 0 : 1; w.bcnt += down ? 1 : 0;
-		dacc += rdlane(tv, 0) - rdlane(tv, sk.wm1);
+		dacc += (rdlane(tv, 0) >> 24) - (rdlane(tv, sk.wm1) >> 24);
 		upd |= (uint32_t)(act && f.b.delta > mx) << k;
 		mx = max(mx, f.b.delta);
 	}

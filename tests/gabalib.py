@@ -121,7 +121,7 @@ class BatchStats(ctypes.Structure):
 
 def load_product():
     """load libminialign_amd.so; raises if it was not built (no silent fallback)"""
-    p = os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')
+    p = os.environ.get('MM_LIB_OVERRIDE') or os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')     # override: kernel experiments only
     if not os.path.exists(p):
         raise RuntimeError('minialign_amd/libminialign_amd.so is missing: run __graft_entry__.build()')
     L = ctypes.CDLL(p)
