@@ -196,12 +196,9 @@ gaba_t *gaba_init(gaba_params_t const *params)
 	/* single-v_perm lookup (gaba_device.hpp:step): rows of the table per a code, one score for a b side N */
 	{
 		const int8_t *sb = (const int8_t *)c.sb;
-		bool all_neg = true, all_pos = true;
-		for(int i = 0; i < 16; i++) { all_neg &= sb[i] < 0; all_pos &= sb[i] >= 0; }
-		c.fast_score = (all_neg || all_pos) && sb[2] == sb[3] && sb[2] == sb[6];
+		c.fast_score = sb[2] == sb[3] && sb[2] == sb[6];
 		if(getenv("MM_NO_FAST_SCORE")) { c.fast_score = 0; }           /* test hook: force the general lookup */
 		c.score_n = sb[2];
-		c.sel_hi = all_neg ? 0x0d0d0d00u : 0x0c0c0c00u;
 		for(int a = 0; a < 5; a++) {
 			uint32_t row = 0;
 			for(int j = 0; j < 4; j++) { row |= (uint32_t)(uint8_t)sb[(a | (4 * j)) & 15] << (8 * j); }

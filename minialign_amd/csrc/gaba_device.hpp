@@ -87,10 +87,9 @@ struct Consts {
 	int32_t tx;
 	int32_t gi, ge, gfa, gfb;
 	double imx, xmx;
-	/* single-v_perm score lookup (see step()): usable when every table entry has the same sign and sb[a | 2] is one value */
+	/* single-v_perm score lookup (see step()): usable when sb[a | 2] (the score against a b side N) is one value for all a */
 	int32_t fast_score;  /* 0 / 1 */
-	int32_t score_n;     /* sb[a | 2], sign-extended (selector byte 4) */
-	uint32_t sel_hi;     /* selector bytes 1..3: 0x0c0c0c00 (zero) or 0x0d0d0d00 (0xff) */
+	int32_t score_n;     /* sb[a | 2] (selector 4 reads its byte 0) */
 	uint32_t arow[5];    /* arow[a] = { sb[a | 0], sb[a | 4], sb[a | 8], sb[a | 12] } for a = 0..3, N */
 };
 constexpr uint32_t ROOT_STRIDE = sizeof(Blk) + sizeof(Tail);            /* [blk][tail] x {64, 32, 16} at the head of each slab */
@@ -239,44 +238,45 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 /* heads: everything up to t = max(...) (score s, biased gap candidates dea / dfa, and dfh / dfv for the COMBINED model) */
 #define GABA_HEAD_COMBINED(DH, DV, DE, DF) \
 	"v_or_b32 %[s], %[ach], %[bch]\n\t" \
-	"v_add_u32_sdwa %[dfh], %[gfh], " DV GABA_SX \
+	"v_add_u32 %[dfh], %[gfh], " DV "\n\t" \
 	"v_and_b32 %[t1], 7, %[s]\n\t" \
 	"v_and_b32 %[s], 8, %[s]\n\t" \
-	"v_sub_u32_sdwa %[dfv], %[gfv], " DH GABA_SX \
+	"v_sub_u32 %[dfv], %[gfv], " DH "\n\t" \
 	"v_cmp_eq_u32 vcc, 0, %[s]\n\t" \
 	"v_perm_b32 %[t2], %[sb1], %[sb0], %[t1]\n\t" \
 	"v_perm_b32 %[t1], %[sb3], %[sb2], %[t1]\n\t" \
 	"v_max3_i32 %[t], " DE ", " DF ", %[dfh]\n\t" \
-	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_SX \
-	"v_add_u32_sdwa %[dea], %[adjh], " DE GABA_SX \
-	"v_add_u32_sdwa %[dfa], %[adjv], " DF GABA_SX \
+	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_S24 \
+	"v_add_u32 %[dea], %[adjh], " DE "\n\t" \
+	"v_add_u32 %[dfa], %[adjv], " DF "\n\t" \
 	"v_max3_i32 %[t], %[t], %[s], %[dfv]\n\t"
 #define GABA_HEAD_COMBINED_FAST(DH, DV, DE, DF) \
-	"v_add_u32_sdwa %[dfh], %[gfh], " DV GABA_SX \
-	"v_sub_u32_sdwa %[dfv], %[gfv], " DH GABA_SX \
+	"v_add_u32 %[dfh], %[gfh], " DV "\n\t" \
+	"v_sub_u32 %[dfv], %[gfv], " DH "\n\t" \
 	"v_perm_b32 %[s], %[cN], %[ach], %[bch]\n\t" \
-	"v_add_u32_sdwa %[dea], %[adjh], " DE GABA_SX \
+	"v_add_u32 %[dea], %[adjh], " DE "\n\t" \
 	"v_max3_i32 %[t], " DE ", " DF ", %[dfh]\n\t" \
-	"v_add_u32_sdwa %[dfa], %[adjv], " DF GABA_SX \
+	"v_add_u32 %[dfa], %[adjv], " DF "\n\t" \
 	"v_max3_i32 %[t], %[t], %[s], %[dfv]\n\t"
 #define GABA_HEAD_AFFINE(DH, DV, DE, DF) \
 	"v_or_b32 %[s], %[ach], %[bch]\n\t" \
 	"v_and_b32 %[t1], 7, %[s]\n\t" \
 	"v_and_b32 %[s], 8, %[s]\n\t" \
-	"v_add_u32_sdwa %[dea], %[adjh], " DE GABA_SX \
+	"v_add_u32 %[dea], %[adjh], " DE "\n\t" \
 	"v_cmp_eq_u32 vcc, 0, %[s]\n\t" \
 	"v_perm_b32 %[t2], %[sb1], %[sb0], %[t1]\n\t" \
 	"v_perm_b32 %[t1], %[sb3], %[sb2], %[t1]\n\t" \
-	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_SX \
-	"v_add_u32_sdwa %[dfa], %[adjv], " DF GABA_SX \
+	"v_add_u32 %[dfa], %[adjv], " DF "\n\t" \
+	"v_cndmask_b32_sdwa %[s], %[t1], %[t2], vcc" GABA_S24 \
+	"s_nop 0\n\t" \
 	"v_max3_i32 %[t], " DE ", " DF ", %[s]\n\t"
 #define GABA_HEAD_AFFINE_FAST(DH, DV, DE, DF) \
 	"v_perm_b32 %[s], %[cN], %[ach], %[bch]\n\t" \
-	"v_add_u32_sdwa %[dea], %[adjh], " DE GABA_SX \
-	"v_add_u32_sdwa %[dfa], %[adjv], " DF GABA_SX \
+	"v_add_u32 %[dea], %[adjh], " DE "\n\t" \
+	"v_add_u32 %[dfa], %[adjv], " DF "\n\t" \
 	"v_max3_i32 %[t], " DE ", " DF ", %[s]\n\t"
 /* cores: mask bits and the four new vectors.  UPD writes the new dh / dv (order per direction: the home register that is
- * still an input goes last); TT produces t << 24 from the new dh (right) or dv (down), _fill_update_delta gaba.c:1647 */
+ * still an input goes last); TT produces t from the new dh (right) or dv (down), _fill_update_delta gaba.c:1647 */
 #define GABA_CORE_COMBINED(DH, DV, DE, DF, UPD, TT) \
 	"v_cmp_eq_u32 %[A], %[t], %[dfh]\n\t" \
 	"v_cmp_eq_u32 %[B], %[t], " DE "\n\t" \
@@ -293,8 +293,8 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 	"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t" \
 	"v_cmp_ge_i32 %[A], %[t], %[dea]\n\t"            /* max(de', t) == t */ \
 	"v_cmp_ge_i32 %[C], %[t], %[dfa]\n\t" \
-	"v_add_u32_sdwa %[de], %[de], " DH GABA_SX \
-	"v_sub_u32_sdwa %[df], %[df], " DV GABA_SX \
+	"v_add_u32 %[de], %[de], " DH "\n\t" \
+	"v_sub_u32 %[df], %[df], " DV "\n\t" \
 	UPD \
 	"s_or_b64 %[A], %[A], %[D]\n\t"                  /* e */ \
 	"s_or_b64 %[C], %[C], %[B]\n\t"                  /* f */ \
@@ -312,8 +312,8 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 	"v_addc_co_u32 %[mv], vcc, %[mv], %[mv], %[C]\n\t" \
 	"v_cmp_ge_i32 %[A], %[t], %[dea]\n\t" \
 	"v_cmp_ge_i32 %[C], %[t], %[dfa]\n\t" \
-	"v_add_u32_sdwa %[de], %[de], " DH GABA_SX \
-	"v_sub_u32_sdwa %[df], %[df], " DV GABA_SX \
+	"v_add_u32 %[de], %[de], " DH "\n\t" \
+	"v_sub_u32 %[df], %[df], " DV "\n\t" \
 	UPD \
 	TT \
 	"v_addc_co_u32 %[me], vcc, %[me], %[me], %[A]\n\t" \
@@ -322,15 +322,15 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 	"v_sub_i32 %[drop], %[drop], %[t] clamp\n\t"
 #define GABA_UPD_RIGHT  "v_sub_u32 %[dh], %[dv], %[t]\n\t" "v_add_u32 %[dv], %[x0], %[t]\n\t"
 #define GABA_UPD_DOWN   "v_add_u32 %[dv], %[dh], %[t]\n\t" "v_sub_u32 %[dh], %[x0], %[t]\n\t"
-#define GABA_TT_RIGHT   "v_sub_u32_sdwa %[t], %[ofsh], %[dh]" GABA_S24
-#define GABA_TT_DOWN    "v_add_u32_sdwa %[t], %[ofsv], %[dv]" GABA_S24
+#define GABA_TT_RIGHT   "v_sub_u32 %[t], %[ofsh], %[dh]\n\t"
+#define GABA_TT_DOWN    "v_add_u32 %[t], %[ofsv], %[dv]\n\t"
 
 /* loop-invariant operands of the step, pinned in registers by the caller */
 struct StepK {
 	uint32_t sb0, sb1, sb2, sb3;     /* score table words (VGPR), general lookup */
-	int cN;                          /* fast lookup: the score against a b side N (SGPR) */
+	int cN;                          /* fast lookup: the score against a b side N in byte 0 (SGPR) */
 	int wm1;                         /* W - 1 (SGPR) */
-	int gfh, gfv, adjh, adjv, ofsh, ofsv;   /* SGPR */
+	int gfh, gfv, adjh, adjv, ofsh, ofsv;   /* VGPR, value << 24: plain VGPR-only adds issue at full rate, a scalar operand halves it */
 };
 __device__ __forceinline__ StepK step_consts(const Consts &c, int W)
 {
@@ -342,8 +342,12 @@ __device__ __forceinline__ StepK step_consts(const Consts &c, int W)
 	asm volatile("v_mov_b32 %0, %1" : "=v"(k.sb3) : "s"(rdfirst((int)c.sb[3])));
 	k.cN = rdfirst((int)c.score_n);
 	k.wm1 = rdfirst(W - 1);
-	k.gfh = rdfirst(c.gfh); k.gfv = rdfirst(c.gfv); k.adjh = rdfirst(c.adjh); k.adjv = rdfirst(c.adjv);
-	k.ofsh = rdfirst(c.ofsh); k.ofsv = rdfirst(c.ofsv);
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.gfh) : "s"(rdfirst(c.gfh) << 24));
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.gfv) : "s"(rdfirst(c.gfv) << 24));
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.adjh) : "s"(rdfirst(c.adjh) << 24));
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.adjv) : "s"(rdfirst(c.adjv) << 24));
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.ofsh) : "s"(rdfirst(c.ofsh) << 24));
+	asm volatile("v_mov_b32 %0, %1" : "=v"(k.ofsv) : "s"(rdfirst(c.ofsv) << 24));
 	return k;
 }
 
@@ -353,7 +357,7 @@ __device__ __forceinline__ StepK step_consts(const Consts &c, int W)
 	  [s] "=&v"(s), [t] "=&v"(t), [t1] "=&v"(t1), [t2] "=&v"(t2), [dfh] "=&v"(dfh), [dfv] "=&v"(dfv), [dea] "=&v"(dea), \
 	  [dfa] "=&v"(dfa), [x0] "=&v"(x0), [x1] "=&v"(x1), [A] "=&s"(A), [B] "=&s"(B), [C] "=&s"(C), [D] "=&s"(D), [nb] "=&s"(nb) \
 	: [look] "v"(look), [ai] "s"(ai), [bi] "s"(bi), [down] "s"(down), [sb0] "v"(k.sb0), [sb1] "v"(k.sb1), [sb2] "v"(k.sb2), [sb3] "v"(k.sb3), [wm1] "s"(k.wm1), \
-	  [gfh] "s"(k.gfh), [gfv] "s"(k.gfv), [adjh] "s"(k.adjh), [adjv] "s"(k.adjv), [ofsh] "s"(k.ofsh), [ofsv] "s"(k.ofsv), [cN] "s"(k.cN) \
+	  [gfh] "v"(k.gfh), [gfv] "v"(k.gfv), [adjh] "v"(k.adjh), [adjv] "v"(k.adjv), [ofsh] "v"(k.ofsh), [ofsv] "v"(k.ofsv), [cN] "s"(k.cN) \
 	: "vcc", "scc"
 
 /* both directions live in one asm statement with a scalar branch inside, so that the compiler sees a single in-place
@@ -398,13 +402,13 @@ __device__ __forceinline__ int step(const StepK &k, Band &b, int look, int down,
 	return t;
 }
 /* window encodings of the fast lookup.  a side: the score row of a base code (0..3, 4 = N); b side: the v_perm selector of an
- * encoded b base (0, 4, 8, 12, 2 = N): byte 0 picks the row byte (or byte 4 = Consts.score_n), bytes 1..3 replicate the sign */
+ * encoded b base (0, 4, 8, 12, 2 = N): byte 3 picks the row byte (or Consts.score_n), bytes 0..2 select zero: the score comes out << 24 */
 __device__ __forceinline__ int fast_arow(const Consts &c, int code)
 {
 	return code == 0 ? (int)c.arow[0] : (code == 1 ? (int)c.arow[1] : (code == 2 ? (int)c.arow[2] : (code == 3 ? (int)c.arow[3] : (int)c.arow[4])));
 }
-__device__ __forceinline__ int fast_bsel(const Consts &c, int enc) { return (enc == 2 ? 4 : (enc >> 2)) | (int)c.sel_hi; }
-__device__ __forceinline__ int fast_bdec(int sel) { int v = sel & 7; return v == 4 ? 2 : (v << 2); }
+__device__ __forceinline__ int fast_bsel(int enc) { return ((enc == 2 ? 4 : (enc >> 2)) << 24) | 0x000c0c0c; }     /* the score lands in byte 3, zeros below */
+__device__ __forceinline__ int fast_bdec(int sel) { int v = (sel >> 24) & 7; return v == 4 ? 2 : (v << 2); }
 
 /* ---- fill state shared by the block routines ---- */
 struct FillState {
@@ -419,8 +423,9 @@ __device__ __forceinline__ void load_context(Ctx &x, Work &w, FillState &f, uint
 {
 	const Blk *p = blk_at(x, prev_off);
 	uint32_t d = p->diff[x.lane];
-	f.b.dh = sext8((int)d); f.b.dv = sext8((int)(d >> 8)); f.b.de = sext8((int)(d >> 16)); f.b.df = sext8((int)(d >> 24));
-	f.b.delta = 0; f.b.drop = f.xd;
+	/* every int8 of the band sits in the top byte of its lane while a block is worked on (see step()) */
+	f.b.dh = (int)(d << 24); f.b.dv = (int)((d << 16) & 0xff000000u); f.b.de = (int)((d << 8) & 0xff000000u); f.b.df = (int)(d & 0xff000000u);
+	f.b.delta = 0; f.b.drop = (int)((uint32_t)f.xd << 24);
 	f.b.mh = f.b.mv = f.b.me = f.b.mf = 0;
 	w.dmask = (uint32_t)rdfirst(0); w.dacc = rdfirst((int)p->s.acc);
 	w.acnt = (uint32_t)rdfirst(0); w.bcnt = (uint32_t)rdfirst(0);
@@ -452,7 +457,8 @@ __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uin
 	bool act = l < W;
 	p->m[0][l] = act ? b.mh << sh : 0; p->m[1][l] = act ? b.mv << sh : 0;
 	p->m[2][l] = act ? b.me << sh : 0; p->m[3][l] = act ? b.mf << sh : 0;
-	p->diff[l] = (uint32_t)(b.dh & 0xff) | ((uint32_t)(b.dv & 0xff) << 8) | ((uint32_t)(b.de & 0xff) << 16) | ((uint32_t)(b.df & 0xff) << 24);
+	p->diff[l] = ((uint32_t)b.dh >> 24) | (((uint32_t)b.dv >> 16) & 0xff00u) | (((uint32_t)b.de >> 8) & 0xff0000u) | ((uint32_t)b.df & 0xff000000u);
+	b.delta >>= 24; b.drop >>= 24;               /* back to plain sign-extended int8 */
 
 	int drop_c = rdlane(b.drop, W / 2), cofs = rdlane(b.delta, W / 2);
 	int xstat = (c.tx - drop_c) & TERM;
@@ -490,14 +496,12 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 	load_context(x, w, f, prev_off);
 	const int64_t arem = (uint32_t)rdfirst((int)w.rem[0]), brem = (uint32_t)rdfirst((int)w.rem[1]), prem = (uint32_t)rdfirst((int)w.pridx);
 	int dacc = rdfirst(w.dacc);
-	/* int8 delta / drop move to the top byte for the duration of the block (see step()) */
-	f.b.delta = 0; f.b.drop = (int)((uint32_t)f.b.drop << 24);
 	const int ach_in = f.b.ach, look_in = f.look;
 	int look = f.look;
 	if(FAST) {
 		/* windows and look-ahead switch to the encodings of the single-v_perm lookup */
-		f.b.ach = fast_arow(c, ach_in); f.b.bch = fast_bsel(c, f.b.bch);
-		look = x.lane < 32 ? fast_arow(c, look_in) : fast_bsel(c, look_in);
+		f.b.ach = fast_arow(c, ach_in); f.b.bch = fast_bsel(f.b.bch);
+		look = x.lane < 32 ? fast_arow(c, look_in) : fast_bsel(look_in);
 	}
 	uint32_t bi = 32, dmask = 0;                                  /* bi = 32 + bcnt; acnt = k - bcnt */
 	uint32_t k = 0;
@@ -514,7 +518,6 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 		dacc += (rdlane(t, 0) >> 24) - (rdlane(t, sk.wm1) >> 24);   /* _dir_update, gaba.c:761 (t sits in the top byte) */
 	}
 	w.dacc = dacc; w.bcnt = bi - 32; w.acnt = k - w.bcnt; w.dmask = dmask;
-	f.b.delta >>= 24; f.b.drop >>= 24;
 	if(FAST) {
 		/* back to base codes: the a window is the old one moved up by acnt lanes with the consumed look-ahead below it */
 		const int acnt = (int)w.acnt, l = x.lane;

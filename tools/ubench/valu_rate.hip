@@ -32,6 +32,21 @@ KERNEL(cmp_sgpr, "v_cmp_eq_u32 s[40:41], %8, %9\n\tv_cmp_eq_u32 s[42:43], %8, %9
 KERNEL(addc_sgpr, B8("v_addc_co_u32", "vcc, %8, %9, s[40:41]"))
 KERNEL(readlane, "v_readlane_b32 s40, %8, 0\n\tv_readlane_b32 s41, %8, 5\n\tv_readlane_b32 s42, %8, 9\n\tv_readlane_b32 s43, %8, 63\n\tv_readlane_b32 s44, %8, 0\n\tv_readlane_b32 s45, %8, 5\n\tv_readlane_b32 s46, %8, 9\n\tv_readlane_b32 s47, %8, 63")
 KERNEL(writelane, B8("v_writelane_b32", "s4, 3"))
+KERNEL(readfirst, "v_readfirstlane_b32 s40, %8\n\tv_readfirstlane_b32 s41, %9\n\tv_readfirstlane_b32 s42, %8\n\tv_readfirstlane_b32 s43, %9\n\tv_readfirstlane_b32 s44, %8\n\tv_readfirstlane_b32 s45, %9\n\tv_readfirstlane_b32 s46, %8\n\tv_readfirstlane_b32 s47, %9")
+KERNEL(addc_vcc, B8("v_addc_co_u32_e32", "vcc, %8, %9, vcc"))
+KERNEL(cndmask_vcc, B8("v_cndmask_b32_e32", "%8, %9, vcc"))
+KERNEL(bfe, B8("v_bfe_i32", "%8, 0, 8"))
+KERNEL(max_e32, B8("v_max_i32_e32", "%8, %9"))
+KERNEL(and_e32, B8("v_and_b32_e32", "%8, %9"))
+KERNEL(lshl_e32, B8("v_lshlrev_b32_e32", "3, %9"))
+KERNEL(add3, B8("v_add3_u32", "%8, %9, %8"))
+KERNEL(pk_add, B8("v_pk_add_i16", "%8, %9"))
+KERNEL(pk_max, B8("v_pk_max_i16", "%8, %9"))
+KERNEL(subco, B8("v_sub_co_u32_e32", "vcc, %8, %9"))
+KERNEL(mov, B8("v_mov_b32_e32", "%8"))
+KERNEL(add_sgpr, B8("v_add_u32_e32", "s4, %9"))
+KERNEL(max_sdwa, B8("v_max_i32_sdwa", "sext(%8), sext(%9) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1"))
+KERNEL(bperm, B8("ds_bpermute_b32", "%8, %9"))
 KERNEL(salu_or64, "s_or_b64 s[40:41], s[42:43], s[44:45]\n\ts_or_b64 s[42:43], s[40:41], s[44:45]\n\ts_or_b64 s[46:47], s[42:43], s[44:45]\n\ts_or_b64 s[40:41], s[42:43], s[44:45]\n\ts_or_b64 s[42:43], s[40:41], s[44:45]\n\ts_or_b64 s[46:47], s[42:43], s[44:45]\n\ts_or_b64 s[40:41], s[42:43], s[44:45]\n\ts_or_b64 s[42:43], s[40:41], s[44:45]")
 KERNEL(mix_valu_salu, "v_add_u32 %0, %8, %9\n\ts_or_b64 s[40:41], s[42:43], s[44:45]\n\tv_add_u32 %1, %8, %9\n\ts_or_b64 s[42:43], s[46:47], s[44:45]\n\tv_add_u32 %2, %8, %9\n\ts_or_b64 s[46:47], s[42:43], s[44:45]\n\tv_add_u32 %3, %8, %9\n\ts_or_b64 s[40:41], s[42:43], s[44:45]")
 KERNEL(dep_chain, "v_add_u32 %0, %0, %9\n\tv_add_u32 %0, %0, %9\n\tv_add_u32 %0, %0, %9\n\tv_add_u32 %0, %0, %9\n\tv_add_u32 %0, %0, %9\n\tv_add_u32 %0, %0, %9\n\tv_add_u32 %0, %0, %9\n\tv_add_u32 %0, %0, %9")
@@ -49,6 +64,6 @@ int main() {
 	unsigned long long *d; hipMalloc(&d, 16);
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 	RUN(add, 8) RUN(add, 8) RUN(add_sdwa, 8) RUN(max3, 8) RUN(perm, 8) RUN(subclamp, 8) RUN(dpp_wshr, 8) RUN(dpp_wshr_bc, 8) RUN(dpp_rshr, 8)
-	RUN(cmp_vcc, 8) RUN(cmp_sgpr, 8) RUN(addc_sgpr, 8) RUN(readlane, 8) RUN(writelane, 8) RUN(salu_or64, 8) RUN(mix_valu_salu, 8) RUN(dep_chain, 8) RUN(dep_chain_sdwa, 8)
+	RUN(cmp_vcc, 8) RUN(cmp_sgpr, 8) RUN(addc_sgpr, 8) RUN(readlane, 8) RUN(writelane, 8) RUN(readfirst, 8) RUN(addc_vcc, 8) RUN(cndmask_vcc, 8) RUN(bfe, 8) RUN(max_e32, 8) RUN(and_e32, 8) RUN(lshl_e32, 8) RUN(add3, 8) RUN(pk_add, 8) RUN(pk_max, 8) RUN(subco, 8) RUN(mov, 8) RUN(add_sgpr, 8) RUN(max_sdwa, 8) RUN(bperm, 8) RUN(salu_or64, 8) RUN(mix_valu_salu, 8) RUN(dep_chain, 8) RUN(dep_chain_sdwa, 8)
 	return 0;
 }
