@@ -73,6 +73,15 @@ def cpu_baseline(ref_fa, reads_fa, workdir, budget_reads):
     return {'value': (b2 / sec * 1e-9) if sec else None, 'unit': 'Gbases/s', 'cores': 1, 'kind': 'port',
             'sample': 'first %d reads (%.1f Mb), oracle/ora_minialign (plain-C restatement, single thread), mm_align_seq time only' % (min(k, 300), b2 / 1e6)}
 
+def pmc_traffic(args, world):
+    """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes (same workload only), else None"""
+    fn = os.path.join(ROOT, 'profiles', 'round1_c_pmc.json')
+    if world != 1 or args.depth != 100.0 or not os.path.exists(fn): return None
+    try:
+        with open(fn) as f: return json.load(f)['mm_extend_kernel_per_launch']['hbm_bytes']
+    except Exception:
+        return None
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=3); ap.add_argument('--warmup', type=int, default=1)
@@ -153,8 +162,9 @@ def main():
                        'dp_vectors_per_base': vec / bases, 'trace_steps_per_base': trs / bases, 'reruns_per_step': per_step(st.reruns), 'index_build_s': t_index,
                        'finish_s (D2H + post-map + SAM, untimed)': t_finish, 'sam_bytes': slen.value},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
-                         'alg_bytes_per_launch': alg_bytes, 'avg_launch_ms': k3_launch_ms},
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args, world),
+                         'alg_bytes_per_launch': alg_bytes, 'avg_launch_ms': k3_launch_ms,
+                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4): traffic = PMC bytes per launch from profiles/round1_c_pmc.json'},
         }
         if world == 1:
             out['cpu_baseline'] = cpu_baseline(ref_fa, reads_fa, work, 4000)
