@@ -95,7 +95,7 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group('nccl')
-    lib = os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')
+    lib = os.environ.get('MM_LIB_OVERRIDE') or os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')     # override: kernel experiments only
     if not os.path.exists(lib):
         sys.path.insert(0, ROOT); import __graft_entry__; __graft_entry__.build()
     L = ctypes.CDLL(lib)

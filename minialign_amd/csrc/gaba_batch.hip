@@ -21,7 +21,10 @@ using namespace gaba;
 struct DevJob { Sec a, b; uint32_t apos, bpos, bw_idx, do_trace; };
 
 /* ---- kernel ---- */
-__global__ void __launch_bounds__(256, 4)
+#ifndef GABA_WAVES_PER_SIMD
+#define GABA_WAVES_PER_SIMD 8
+#endif
+__global__ void __launch_bounds__(256, GABA_WAVES_PER_SIMD)
 gaba_extend_batch_kernel(const Consts c, const uint8_t *roots, SeqArena ar_a, SeqArena ar_b,
 	const DevJob *jobs, uint32_t njobs, gaba_xresult_t *res, uint32_t *paths, uint32_t path_stride,
 	uint8_t *slabs, uint64_t slab_bytes, uint32_t *counter, uint64_t *stats, int *errs)
@@ -272,7 +275,7 @@ int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const 
 	int dev = 0; hipDeviceProp_t prop;
 	HIP_OK(hipGetDevice(&dev), -1); HIP_OK(hipGetDeviceProperties(&prop, dev), -1);
 	const char *wenv = getenv("MM_WAVES_PER_CU");
-	uint32_t max_waves = (uint32_t)prop.multiProcessorCount * (wenv ? (uint32_t)atoi(wenv) : 16u);          /* default: 4 workgroups x 4 waves per CU */
+	uint32_t max_waves = (uint32_t)prop.multiProcessorCount * (wenv ? (uint32_t)atoi(wenv) : 4u * GABA_WAVES_PER_SIMD);          /* default: as many 4-wave workgroups per CU as the launch bound allows */
 	uint32_t waves = n < max_waves ? ((n + 3) & ~3u) : max_waves;
 	if(ctx->slab_bytes < need || ctx->n_waves < waves) {
 		if(ctx->slabs) hipFree(ctx->slabs);
@@ -300,6 +303,15 @@ int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const 
 	if(paths) HIP_OK(hipMemcpyAsync(paths, dpaths, (uint64_t)n * path_stride * 4, hipMemcpyDeviceToHost, ctx->stream), -1);
 	HIP_OK(hipMemcpyAsync(herr.data(), derr, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream), -1);
 	HIP_OK(hipMemcpyAsync(hstats, ctx->dstats, 32, hipMemcpyDeviceToHost, ctx->stream), -1);
+#ifdef GABA_TRACE_PROF
+	{
+		unsigned long long hp[16]; HIP_OK(hipStreamSynchronize(ctx->stream), -1);
+		HIP_OK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(gaba::g_trace_prof), sizeof(hp)), -1);
+		const char *nm[4] = { "reload", "diag-batch", "gap-batch", "stepwise" };
+		for(int i = 0; i < 4; i++) fprintf(stderr, "[trace prof] %-10s ticks %llu  events %llu  ticks/event %.1f\n", nm[i], hp[i], hp[8 + i], hp[8 + i] ? (double)hp[i] / hp[8 + i] : 0.0);
+		unsigned long long z[16] = { 0 }; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(gaba::g_trace_prof), z, sizeof(z)), -1);
+	}
+#endif
 	HIP_OK(hipStreamSynchronize(ctx->stream), -1);
 	float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
 	ctx->last.kernel_ms = ms; ctx->last.vectors = hstats[0]; ctx->last.blocks = hstats[1]; ctx->last.trace_steps = hstats[2];

@@ -149,6 +149,18 @@ struct Work {
 	uint32_t blk0;           /* slab offset of the head block of this fill */
 };
 
+#ifdef GABA_TRACE_PROF
+__device__ unsigned long long g_trace_prof[16];
+#define TPROF_T0() const unsigned long long tp0_ = __builtin_amdgcn_s_memtime()
+#define TPROF_ADD(_i) { tp_cy[(_i)] += __builtin_amdgcn_s_memtime() - tp0_; tp_n[(_i)]++; }
+#define TPROF_DECL() unsigned long long tp_cy[4] = { 0, 0, 0, 0 }; unsigned long long tp_n[4] = { 0, 0, 0, 0 }
+#define TPROF_FLUSH() { if(x.lane == 0) { for(int i_ = 0; i_ < 4; i_++) { atomicAdd(&g_trace_prof[i_], tp_cy[i_]); atomicAdd(&g_trace_prof[8 + i_], tp_n[i_]); } } }
+#else
+#define TPROF_T0()
+#define TPROF_ADD(_i)
+#define TPROF_DECL()
+#define TPROF_FLUSH()
+#endif
 struct Ctx {                 /* everything a device routine needs */
 	Consts c;                /* by value: lives in SGPRs, never re-loaded inside the DP loops */
 	const SeqArena *ar;
@@ -1024,6 +1036,12 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 	}
 	if(t.blk_loaded != blk) { t.blk = blk; trace_load_block(x, t); }
 	uint32_t qsel = 0xffffffffu, qh = 0, qv = 0, qe = 0, qf = 0;
+	TPROF_DECL();
+	/* one-block look-behind: mask columns and trailer of the block at pf_off (loads are issued here, waited for at first use) */
+	uint32_t pf_off = NIL, pf_m0 = 0, pf_m1 = 0, pf_m2 = 0, pf_m3 = 0; uint4 pf_s = make_uint4(0, 0, 0, 0);
+	#define TR_PREFETCH(_off) { const Blk *pb_ = blk_at(x, (_off)); pf_m0 = pb_->m[0][x.lane]; pf_m1 = pb_->m[1][x.lane]; pf_m2 = pb_->m[2][x.lane]; pf_m3 = pb_->m[3][x.lane]; \
+		pf_s = *(const uint4 *)&pb_->s; pf_off = (_off); }
+	if(blk >= 2 * (uint32_t)sizeof(Blk)) { TR_PREFETCH(blk - (uint32_t)sizeof(Blk)); }
 
 	#define TR_BIT(_w)      ( ((_w) >> (31 - p)) & 1u )
 	/* _pop_vector (gaba.c:3114-3122) without the reload */
@@ -1036,14 +1054,25 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 
 	while(true) {
 		if(p < 0) {
-			/* _trace_{bulk,tail}_load_n (gaba.c:3052-3089): step to the previous block, hopping over head blocks */
-			bool prev_head = (rdfirst((int)blk_at(x, blk - (uint32_t)sizeof(Blk))->s.xstat) & HEAD) != 0;
-			uint32_t nb = skip_heads(x, blk - (uint32_t)sizeof(Blk));
-			if(nb == NIL) { blk = NIL; break; }
-			const Blk *pb = blk_at(x, nb);
-			int ac = rdfirst((int)pb->s.acnt), bc = rdfirst((int)pb->s.bcnt);
-			p = ac + bc - 1; dir = (uint32_t)rdfirst((int)pb->s.dir_mask) >> (BLK - (ac + bc));
-			blk = nb; t.blk = nb; trace_load_block(x, t); qsel = 0xffffffffu;
+			TPROF_T0();
+			/* _trace_{bulk,tail}_load_n (gaba.c:3052-3089): step to the previous block, hopping over head blocks.  The block
+			 * below the current one was requested when the current one was entered (mask columns + the 16-B trailer in one
+			 * go), so the walk normally finds it in registers instead of paying four dependent HBM round trips here. */
+			const uint32_t cand = blk - (uint32_t)sizeof(Blk);
+			if(pf_off != cand) { TR_PREFETCH(cand); }
+			uint32_t w0 = (uint32_t)rdfirst((int)pf_s.x), dm = (uint32_t)rdfirst((int)pf_s.y);
+			const bool prev_head = (((int)(int8_t)(w0 >> 8)) & HEAD) != 0;
+			uint32_t nb = cand;
+			if(prev_head) {
+				nb = skip_heads(x, cand);
+				if(nb == NIL) { blk = NIL; break; }
+				TR_PREFETCH(nb);
+				w0 = (uint32_t)rdfirst((int)pf_s.x); dm = (uint32_t)rdfirst((int)pf_s.y);
+			}
+			const int ac = (int)(int8_t)(w0 >> 16), bc = (int)(int8_t)(w0 >> 24);
+			p = ac + bc - 1; dir = dm >> (BLK - (ac + bc));
+			blk = nb; t.blk = nb; t.lm[0] = pf_m0; t.lm[1] = pf_m1; t.lm[2] = pf_m2; t.lm[3] = pf_m3; t.blk_loaded = nb; qsel = 0xffffffffu;
+			if(nb >= 2 * (uint32_t)sizeof(Blk)) { TR_PREFETCH(nb - (uint32_t)sizeof(Blk)); }
 			bool can_bulk = !(W > g0 - ac) && !(W > g1 - bc);             /* _trace_test_bulk (gaba.c:3035-3046) */
 			if(bulk) {
 				if(can_bulk) { g0 -= ac; g1 -= bc; }
@@ -1052,6 +1081,7 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 				save--;
 				if(save >= head_cnt && can_bulk) { g0 -= ac; g1 -= bc; save = q; bulk = true; }
 			}
+			TPROF_ADD(0);
 		}
 		/*
 		 * diagonal run, batched.  The cells a run of diagonals visits are fixed by the direction bits alone: the k-th one
@@ -1061,41 +1091,102 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 		 * capped to the vectors of this block and, in tail mode, to the section indices; whatever stops it is handled
 		 * by the step-wise code below.
 		 */
-		if(lbl == L_D_HEAD && p >= 1) {
-			uint32_t nmax = (uint32_t)(p + 1) >> 1;
+		if((lbl == L_D_HEAD || lbl == L_D_TAIL) && p >= 0) {
+			/* entered either in front of the h test (head) or in front of the v test of the same cell (tail) */
+			const bool from_tail = lbl == L_D_TAIL;
+			uint32_t nmax = (uint32_t)(p + 1) >> 1;                        /* whole diagonals left in this block */
 			if(!bulk) { nmax = min(nmax, (uint32_t)max(0, min(g0, g1))); }
-			if(nmax > 0) {
-				const uint32_t k = (uint32_t)x.lane;
-				const bool in_run = k < nmax;                                /* nmax <= 16 */
-				const uint32_t qk = q + (uint32_t)__popc(dir & ((1u << ((2 * k) & 31)) - 1u)) - k;
-				const uint32_t qlk = (W == 64) ? (qk & 63) : (qk & 31);
-				const uint32_t hw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qlk << 2), (int)t.lm[0]);
-				const uint32_t vw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qlk << 2), (int)t.lm[1]);
-				const uint32_t sh = (uint32_t)(31 - p) + 2 * k;               /* 31 - (p - 2k) */
-				const bool live = in_run && qlk < (uint32_t)W;
-				const uint64_t eh = __ballot(live && ((hw >> (sh & 31)) & 1u));
-				const uint64_t ev = __ballot(live && k >= 1 && ((vw >> (sh & 31)) & 1u));
-				const uint32_t e_h = eh ? (uint32_t)__builtin_ctzll(eh) : 64u, e_v = ev ? (uint32_t)__builtin_ctzll(ev) : 64u;
-				const uint32_t n = min(min(e_h, e_v), nmax);
-				lbl = (e_v < 64u && e_v <= e_h) ? L_V_HEAD : (e_h < 64u ? L_H_HEAD : L_D_TAIL);
-				if(n > 0) {
-					/* 2n pops: path bits 0,1,0,1,... (gaba.c:3114-3122), i.e. every position of ppos's parity below ppos */
-					uint32_t rem = 2 * n; const uint32_t par = (ppos & 1) ? 0xaaaaaaaau : 0x55555555u;
-					while(rem) {
-						if((ppos & 31) == 0) { if(x.lane == 0) { t.path[ppos >> 5] = pw; } pw = 0; }
-						const uint32_t inw = ((ppos - 1) & 31) + 1, take = min(rem, inw), lo = (ppos - take) & 31;
-						pw |= ((take == 32 ? 0xffffffffu : ((1u << take) - 1u)) << lo) & par;
-						ppos -= take; rem -= take;
-					}
-					q += (uint32_t)__popc(dir & (n == 16 ? 0xffffffffu : ((1u << (2 * n)) - 1u))) - n;
-					dir = n == 16 ? 0u : dir >> (2 * n);
-					p -= (int32_t)(2 * n); n_pop += 2 * n;
-					if(!bulk) { g0 -= (int32_t)n; g1 -= (int32_t)n; }
-					qsel = 0xffffffffu;
+			TPROF_T0();
+			const uint32_t k = (uint32_t)x.lane;
+			const uint32_t ktest = min(nmax, (uint32_t)p >> 1);             /* cells 0..ktest lie in the block and are reached */
+			const uint32_t qk = q + (uint32_t)__popc(dir & ((1u << ((2 * k) & 31)) - 1u)) - k;
+			const uint32_t qlk = (W == 64) ? (qk & 63) : (qk & 31);
+			const uint32_t hw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qlk << 2), (int)t.lm[0]);
+			const uint32_t vw = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qlk << 2), (int)t.lm[1]);
+			const uint32_t sh = ((uint32_t)(31 - p) + 2 * k) & 31;         /* 31 - (p - 2k) */
+			const bool live = k <= ktest && qlk < (uint32_t)W;
+			const uint64_t eh = __ballot(live && ((hw >> sh) & 1u));
+			const uint64_t ev = __ballot(live && (from_tail || k >= 1) && ((vw >> sh) & 1u));
+			const uint32_t e_h = eh ? (uint32_t)__builtin_ctzll(eh) : 64u, e_v = ev ? (uint32_t)__builtin_ctzll(ev) : 64u;
+			const uint32_t n = min(min(e_h, e_v), nmax);
+			const bool event = (e_h & e_v) != 64u;
+			if(event) { lbl = (e_v < 64u && e_v <= e_h) ? L_V_HEAD : L_H_HEAD; }
+			else { lbl = (p - (int32_t)(2 * n) >= 0) ? L_D_HEAD : L_D_TAIL; }
+			if(n > 0) {
+				/* 2n pops: path bits 0,1,0,1,... (gaba.c:3114-3122), i.e. every position of ppos's parity below ppos */
+				uint32_t rem = 2 * n; const uint32_t par = (ppos & 1) ? 0xaaaaaaaau : 0x55555555u;
+				while(rem) {
+					if((ppos & 31) == 0) { if(x.lane == 0) { t.path[ppos >> 5] = pw; } pw = 0; }
+					const uint32_t inw = ((ppos - 1) & 31) + 1, take = min(rem, inw), lo = (ppos - take) & 31;
+					pw |= ((take == 32 ? 0xffffffffu : ((1u << take) - 1u)) << lo) & par;
+					ppos -= take; rem -= take;
 				}
+				q += (uint32_t)__popc(dir & (n == 16 ? 0xffffffffu : ((1u << (2 * n)) - 1u))) - n;
+				dir = n == 16 ? 0u : dir >> (2 * n);
+				p -= (int32_t)(2 * n); n_pop += 2 * n;
+				if(!bulk) { g0 -= (int32_t)n; g1 -= (int32_t)n; }
+				qsel = 0xffffffffu;
+			}
+			TPROF_ADD(1);
+			/* nothing moved and nothing found: the cell in front is clean (h and, from the tail, v are both clear) but no whole
+			 * diagonal fits; the step-wise code takes the half step (block boundary) or stops on the section test */
+			if(event || n > 0) { continue; }
+			lbl = L_D_HEAD;
+		}
+		/*
+		 * gap run, batched the same way.  Entered at the head of a gap (gaba.c:3163-3228 _trace_*_{h,v}_head): the cells a run
+		 * of horizontal (vertical) moves visits are again fixed by the direction bits, the j-th one is (p - j, q + popcount(dir[0, j))
+		 * [- j]).  Lane j gathers the two mask words its tests need; cell 0 decides between the one-step "fgap" form of the
+		 * COMBINED model and an ordinary gap, whose length is the first j >= 1 where the gap-continue test fails.  Capped to
+		 * the block and, in tail mode, to the section index; what is left over goes to the step-wise code.
+		 */
+		if((lbl == L_H_HEAD || lbl == L_V_HEAD) && p >= 0) {
+			const bool isv = lbl == L_V_HEAD;
+			uint32_t nmax = (uint32_t)(p + 1);
+			if(!bulk) { nmax = min(nmax, (uint32_t)max(0, isv ? g1 : g0)); }
+			if(nmax > 0) {
+				TPROF_T0();
+				const uint32_t j = (uint32_t)x.lane;
+				const uint32_t lowj = j >= 32 ? 0xffffffffu : ((1u << j) - 1u);
+				const uint32_t qj = q + (uint32_t)__popc(dir & lowj) - (isv ? j : 0u);
+				const uint32_t qlj = (W == 64) ? (qj & 63) : (qj & 31);
+				const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qlj << 2), (int)(isv ? t.lm[1] : t.lm[0]));   /* h / v */
+				const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(qlj << 2), (int)(isv ? t.lm[3] : t.lm[2]));   /* e / f */
+				const bool live = j <= (uint32_t)p && qlj < (uint32_t)W;
+				const uint32_t sh = ((uint32_t)(31 - p) + j) & 31;
+				const uint32_t b0 = live ? (w0 >> sh) & 1u : 0u, b1 = live ? (w1 >> sh) & 1u : 0u;
+				const uint64_t m_b1 = __ballot(b1 != 0);
+				const uint64_t m_stop = __ballot(j >= 1 && j <= (uint32_t)p && (comb ? (~b0 & b1 & 1u) : b1) != 0);
+				uint32_t m;
+				if(comb && (m_b1 & 1ull) == 0) {                            /* _trace_test_fgap_{h,v}: a single step, back to the diagonal */
+					if(isv) { fcnt1++; } else { fcnt0++; }
+					m = 1; lbl = isv ? L_D_TAIL : L_D_HEAD;
+				} else {
+					if(isv) { icnt1++; } else { icnt0++; }
+					const uint32_t first = m_stop ? (uint32_t)__builtin_ctzll(m_stop) : 64u;
+					m = min(first, nmax);
+					if(isv) { ecnt1 += m; } else { ecnt0 += m; }
+					if(first <= nmax) { lbl = isv ? L_D_TAIL : L_D_HEAD; }
+					else { lbl = (p - (int32_t)m >= 0) ? (isv ? L_V_LOOP : L_H_LOOP) : (isv ? L_V_TAIL : L_H_TAIL); }
+				}
+				/* m pops of one kind: path bits all 0 (h) or all 1 (v) */
+				uint32_t rem = m;
+				while(rem) {
+					if((ppos & 31) == 0) { if(x.lane == 0) { t.path[ppos >> 5] = pw; } pw = 0; }
+					const uint32_t inw = ((ppos - 1) & 31) + 1, take = min(rem, inw), lo = (ppos - take) & 31;
+					if(isv) { pw |= (take == 32 ? 0xffffffffu : ((1u << take) - 1u)) << lo; }
+					ppos -= take; rem -= take;
+				}
+				q += (uint32_t)__popc(dir & (m >= 32 ? 0xffffffffu : ((1u << m) - 1u))) - (isv ? m : 0u);
+				dir = m >= 32 ? 0u : dir >> m;
+				p -= (int32_t)m; n_pop += m;
+				if(!bulk) { if(isv) { g1 -= (int32_t)m; } else { g0 -= (int32_t)m; } }
+				qsel = 0xffffffffu;
+				TPROF_ADD(2);
 				continue;
 			}
 		}
+		TPROF_T0();
 		if(qsel != q) {
 			/* (mask >> q) & 1 with the x86 shift-count masking of the reference's word size (gaba.c:2931-2951) */
 			qsel = q; uint32_t ql = (W == 64) ? (q & 63) : (q & 31); bool dead = ql >= (uint32_t)W;
@@ -1145,9 +1236,12 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 		} else { /* L_V_TAIL */
 			lbl = ((comb ? TR_BIT(~qv & qf) : TR_BIT(qf)) == 0) ? L_V_LOOP : L_D_TAIL;
 		}
+		TPROF_ADD(3);
 	}
 	#undef TR_BIT
 	#undef TR_POP
+	#undef TR_PREFETCH
+	TPROF_FLUSH();
 	lf.state = state;
 	lf.blk = blk; lf.p = (uint32_t)p; lf.q = q;
 	lf.gidx[0] = g0; lf.gidx[1] = g1;

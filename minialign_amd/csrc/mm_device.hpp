@@ -872,7 +872,10 @@ __device__ __attribute__((noinline)) TraceOut k3_trace(DpIn in, uint32_t tail, g
 	return o;
 }
 
-__global__ void __launch_bounds__(256, 4) mm_extend_kernel(K3Args a)
+#ifndef MM_K3_WAVES_PER_SIMD
+#define MM_K3_WAVES_PER_SIMD 8
+#endif
+__global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3Args a)
 {
 	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
 	gaba::Ctx x;

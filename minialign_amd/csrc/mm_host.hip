@@ -452,7 +452,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				ka.n_lo = ci == 0 ? cap_of(bytes_of(1)) : (ci >= n_cls - 1 ? 0u : cap_of(bytes_of(cls_div[ci + 1])));
 				ka.counter = a->d_k2cnt.p + ci;
 				const uint32_t per_cu = div ? div : 8;
-				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / 16) * per_cu);
+				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / (4 * MM_K3_WAVES_PER_SIMD)) * per_cu);
 				/* the classes are independent: each goes to its own stream behind ev0 so that their tails overlap; the retry waits for all */
 				hipStream_t sq = ci == n_cls ? a->stream : a->k2s[ci];
 				if(ci < n_cls) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
@@ -701,7 +701,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	a->dix.n_seq = (uint32_t)mi->seq.size(); a->dix.k = mi->k; a->dix.w = mi->w; a->dix.n_occ = mi->n_occ;
 	for(int i = 0; i < 4; i++) a->dix.occ[i] = i < (int)mi->n_occ ? mi->occ[i] : 0;
 	hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
-	a->n_waves = (uint32_t)prop.multiProcessorCount * 16;
+	a->n_waves = (uint32_t)prop.multiProcessorCount * 4 * MM_K3_WAVES_PER_SIMD;       /* persistent waves of the extension kernel */
 	memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms();
 	return a;
 }
