@@ -477,8 +477,8 @@ __global__ void __launch_bounds__(64) mm_sort_chain_kernel(K2Args a)
 struct K2aArgs {
 	ReadState *st; const uint32_t *work; uint32_t n_work;
 	Seed *seed_pool; Root *root_pool;
-	uint32_t lds_seeds;               /* capacity of the LDS seed array (elements); 0: sort in place in HBM */
-	uint32_t n_lo, n_hi;              /* this launch takes the reads with n_lo < k2a_need(seed_n) <= n_hi (size class) */
+	uint32_t lds_bytes;               /* dynamic LDS of this launch (tables included); <= 1536 * 4: sort in place in HBM */
+	uint32_t n_lo, n_hi;              /* this launch takes the reads with n_lo < k2a_bytes(seed_n) <= n_hi (size class, bytes) */
 	uint32_t retry;                   /* 1: take the reads whose leaf area overflowed in their class (flagged n_root = ~0), with room for 2 (n + 1) */
 	uint32_t *counter;                /* work-list cursor of this launch */
 	uint32_t twlen; double mcoef; uint32_t min_score;
@@ -487,6 +487,8 @@ struct K2aArgs {
 /* elements a read is given in its first attempt: the seeds, the sentinel and a leaf area of a quarter of that (the worst case of
  * one leaf per seed is left to the retry launch) */
 __host__ __device__ inline uint32_t k2a_need(uint32_t seed_n) { return (seed_n + 1) + (seed_n + 1) / 4 + 64; }
+/* LDS bytes of a read: 16 B per element + the two u32 step tables of the chain sweep + the sort tables */
+__host__ __device__ inline uint32_t k2a_bytes(uint32_t seed_n, uint32_t elems) { return 16u * elems + 8u * (seed_n + 1) + 1536u * 4u; }
 typedef __attribute__((address_space(3))) Seed LSeed;
 typedef __attribute__((address_space(3))) uint32_t LU32;
 
@@ -512,7 +514,8 @@ __device__ __forceinline__ void lds_ins_sort(S *beg, S *end)
 /* sort + chain over a seed array that lives either in LDS (S = LSeed) or in HBM (S = Seed); returns false if the leaf area overflowed */
 template<typename S>
 __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t seed_n, LU32 *cnt, LU32 *bb, LU32 *be, LU32 *stack,
-	Root *c, const K2aArgs &a, int lane, uint32_t &nlid_out, uint32_t &ncid_out, unsigned long long &cy_sort, unsigned long long &cy_chain)
+	Root *c, const K2aArgs &a, int lane, uint32_t &nlid_out, uint32_t &ncid_out, unsigned long long &cy_sort, unsigned long long &cy_chain,
+	const bool pre, LU32 *succ, LU32 *seen)
 {
 	const uint32_t n_all = seed_n + 1;
 	const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
@@ -587,6 +590,30 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 		uint32_t ncid = 0, nlid = seed_n + 1, nlsid = 0; const uint32_t tsid = seed_n;
 		const int32_t tw = (int32_t)a.twlen;
 		bool overflow = false;
+		if(pre) {
+			/*
+			 * What one step of the chain sweep finds from a seed i -- the last seed inside the shrinking window (succ, 0 = none)
+			 * and the first seed it passes over (seen) -- depends on the sorted array alone, not on what earlier chains have
+			 * marked (the marks only decide where a chain stops).  So the window scans of all seeds run here, one seed per lane,
+			 * and the sequential sweep below is left with a pointer chase.  pdiff() of the reference is evaluated on the window
+			 * it has just updated and is therefore always 0: "the largest (pdiff, sid)" is simply the last accepted sid.
+			 */
+			for(uint32_t i0 = 0; i0 < tsid; i0 += 64) {
+				const uint32_t i = i0 + (uint32_t)lane;
+				if(i < tsid) {
+					V4 wv = add_win(load_pv(lds_ld(&s[i])), tw);
+					uint32_t last = 0, first_out = 0xffffffffu;
+					for(uint32_t jx = i + 1; jx <= tsid; jx++) {          /* the sentinel at tsid always ends the scan */
+						const V4 fv = load_pv(lds_ld(&s[jx]));
+						if(inside_wv(wv, fv)) { wv = update_wv(wv, fv); last = jx; continue; }
+						first_out = first_out < jx ? first_out : jx;
+						if(!inside_uub(wv, fv)) { break; }
+					}
+					succ[i] = last; seen[i] = first_out;
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		}
 		while(nlsid < tsid) {
 			const uint32_t lid = nlid++;
 			if(lid >= cap) { overflow = true; break; }
@@ -599,7 +626,21 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 			uint32_t plen = (uint32_t)(rs_u + rs_v), scnt = 1;
 			const uint32_t lsid0 = nlsid;
 			uint64_t nrsid = nlsid; nlsid = 0xffffffffu;
-			while(true) {
+			while(pre) {
+				/* pointer chase over the precomputed steps (same bookkeeping as the scanning form below) */
+				const uint32_t rsid = (uint32_t)nrsid;
+				const uint32_t nx = (uint32_t)rdfirst((int)succ[rsid]), sm = (uint32_t)rdfirst((int)seen[rsid]);
+				nlsid = nlsid < sm ? nlsid : sm;
+				if(nx == 0) { nrsid = rsid; break; }
+				const uint32_t cl = (uint32_t)rdfirst((int)s[nx].lid);
+				nrsid = nx;
+				if(cl != 0x7fffffffu) { break; }
+				if(lane == 0) { s[nx].lid = lid; }
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				scnt++;
+				if(nlsid <= nx) { nlsid = 0xffffffffu; }
+			}
+			while(!pre) {
 				const uint32_t rsid = (uint32_t)nrsid; nrsid = 0;
 				V4 wv = add_win(V4{ rs_u, rs_r, rs_v, rs_v }, tw);
 				int32_t b_u = 0, b_r = 0, b_v = 0; uint32_t b_lid = 0;          /* record of the seed nrsid points at */
@@ -666,8 +707,9 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 {
 	extern __shared__ uint8_t lds_raw[];
+	/* [seeds + leaves: cap x 16 B][succ, seen: (seed_n + 1) x 4 B each][tables: 1536 words at the end of the block] */
 	LSeed *ls = (LSeed *)lds_raw;
-	LU32 *cnt = (LU32 *)(ls + a.lds_seeds);         /* 256 counters */
+	LU32 *cnt = (LU32 *)(lds_raw + a.lds_bytes - 1536 * 4);      /* 256 counters */
 	LU32 *bb = cnt + 256, *be = bb + 256;             /* bucket begin / end */
 	LU32 *stack = be + 256;                           /* pending ranges: (beg, end, shift) x 256 */
 	const int lane = lane_id();
@@ -680,15 +722,17 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 		ReadState *st = &a.st[a.work[wi]];
 		const uint32_t seed_n = (uint32_t)rdfirst((int)st->seed_n0);     /* not seed_n: launches of other classes update that concurrently */
 		if(seed_n == 0) { if(a.n_lo == 0 && !a.retry && lane == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; } continue; }
-		bool fits;
+		bool fits; uint32_t lcap = 0;
 		if(a.retry) {
 			if((uint32_t)rdfirst((int)st->n_root) != 0xffffffffu) { continue; }
-			fits = 2 * (seed_n + 1) <= a.lds_seeds;
+			fits = k2a_bytes(seed_n, 2 * (seed_n + 1)) <= a.lds_bytes;
 		} else {
-			const uint32_t need = k2a_need(seed_n);
+			const uint32_t need = k2a_bytes(seed_n, k2a_need(seed_n));
 			if(need <= a.n_lo || need > a.n_hi) { continue; }              /* another size class */
-			fits = a.lds_seeds != 0;
+			fits = a.lds_bytes > 1536 * 4;
 		}
+		if(fits) { lcap = (a.lds_bytes - 1536u * 4u - 8u * (seed_n + 1)) / 16u; }      /* all the room of the class goes to the leaf area */
+		LU32 *succ = (LU32 *)(ls + lcap), *seen = succ + (seed_n + 1);
 		Seed *gs = a.seed_pool + rdfirst64(st->seed_off);
 		Root *c = a.root_pool + rdfirst64(st->root_off);
 		const uint32_t gcap = (uint32_t)rdfirst((int)st->seed_cap);
@@ -698,14 +742,14 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 			for(uint32_t i = (uint32_t)lane; i < seed_n; i += 64) { lds_st(&ls[i], gs[i]); }
 			if(lane == 0) { lds_st(&ls[seed_n], Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }); }      /* sentinel, minialign.c:3531 */
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-			ok = sort_chain_wave<LSeed>(ls, a.lds_seeds, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain);
+			ok = sort_chain_wave<LSeed>(ls, lcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain, true, succ, seen);
 			if(ok) { for(uint32_t i = (uint32_t)lane; i < nlid; i += 64) { gs[i] = lds_ld(&ls[i]); } }
 		} else {
 			/* too large for LDS: same algorithm in place in HBM */
 			if(lane == 0) { gs[seed_n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }; }
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			n_big++;
-			ok = sort_chain_wave<Seed>(gs, gcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain);
+			ok = sort_chain_wave<Seed>(gs, gcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain, false, succ, seen);
 		}
 		if(!ok) {
 			/* leaf area exhausted: the seed array in HBM is untouched (LDS case), so the retry launch redoes the read with full room */

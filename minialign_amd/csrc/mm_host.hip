@@ -441,15 +441,14 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			CK(hipMemsetAsync(a->d_k2cnt.p, 0, 16 * 4, a->stream));
 			CK(hipEventRecord(a->ev0, a->stream));          /* re-recorded behind the memset: the side streams start from here */
 			auto bytes_of = [](uint32_t div) -> uint32_t { return div ? ((160u * 1024u / div) & ~255u) : 0u; };
-			auto cap_of = [](uint32_t bytes) -> uint32_t { return bytes ? (uint32_t)((bytes - 1536 * 4) / sizeof(Seed)) : 0u; };
 			for(int ci = 0; ci <= n_cls; ci++) {
 				/* ci < n_cls: size classes, largest first; ci == n_cls: retry of the reads whose leaf area overflowed, at 160 KB */
 				const uint32_t div = ci == n_cls ? 1u : cls_div[ci];
 				const uint32_t bytes = bytes_of(div);
 				ka.retry = ci == n_cls;
-				ka.lds_seeds = cap_of(bytes);
-				ka.n_hi = ci == 0 ? 0xffffffffu : cap_of(bytes);
-				ka.n_lo = ci == 0 ? cap_of(bytes_of(1)) : (ci >= n_cls - 1 ? 0u : cap_of(bytes_of(cls_div[ci + 1])));
+				ka.lds_bytes = bytes ? bytes : 1536 * 4;
+				ka.n_hi = ci == 0 ? 0xffffffffu : bytes;                    /* classes are cut by k2a_bytes() of the read */
+				ka.n_lo = ci == 0 ? bytes_of(1) : (ci >= n_cls - 1 ? 0u : bytes_of(cls_div[ci + 1]));
 				ka.counter = a->d_k2cnt.p + ci;
 				const uint32_t per_cu = div ? div : 8;
 				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / (4 * MM_K3_WAVES_PER_SIMD)) * per_cu);
