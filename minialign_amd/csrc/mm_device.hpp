@@ -550,20 +550,30 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 					bb[4 * lane + 2] = acc; acc += c2; be[4 * lane + 2] = acc; bb[4 * lane + 3] = acc; acc += c3; be[4 * lane + 3] = acc;
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-				if(lane == 0) {
+				{
 					/* the in-place cycle-leader permutation (ksort.h:101-116): inherently sequential, and its exact element order is
-					 * what decides ties, so it is replayed as is */
-					for(int k = 0; k < 256;) {
-						uint32_t b = bb[k];
-						if(b != be[k]) {
-							int l_ = (int)((lkey(&s[b]) >> sh) & 255);
-							if(l_ != k) {
+					 * what decides ties, so it is replayed as is -- with one shortcut that changes nothing: a stretch of elements that
+					 * already sit in their bucket only advances that bucket's cursor, so the stretch is found 64 elements at a time
+					 * (one ballot) and the serial code (lane 0) runs for the displaced elements only.  Seeds arrive roughly in
+					 * diagonal order, i.e. nearly sorted for forward-strand hits. */
+					for(int k = 0; k < 256; k++) {
+						uint32_t b = (uint32_t)rdfirst((int)bb[k]); const uint32_t e = (uint32_t)rdfirst((int)be[k]);
+						while(b != e) {
+							const uint32_t idx = b + (uint32_t)lane;
+							const bool away = idx < e && (int)((lkey(&s[idx]) >> sh) & 255) != k;
+							const uint64_t m_away = __ballot(away);
+							if(m_away == 0) { b = b + 64 < e ? b + 64 : e; continue; }
+							b += (uint32_t)__builtin_ctzll(m_away);               /* everything in front of it is home */
+							if(lane == 0) {
 								Seed tmp = lds_ld(&s[b]), swp;
+								int l_ = (int)((((uint64_t)tmp.upos | ((uint64_t)tmp.rid << 32)) >> sh) & 255);
 								do { swp = tmp; uint32_t d = bb[l_]; tmp = lds_ld(&s[d]); lds_st(&s[d], swp); bb[l_] = d + 1;
 								     l_ = (int)((((uint64_t)tmp.upos | ((uint64_t)tmp.rid << 32)) >> sh) & 255); } while(l_ != k);
-								lds_st(&s[bb[k]], tmp); bb[k]++;
-							} else { bb[k] = b + 1; }
-						} else { ++k; }
+								lds_st(&s[b], tmp);
+							}
+							__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+							b++;
+						}
 					}
 				}
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
