@@ -25,7 +25,7 @@ class Stats(ctypes.Structure):
                 ('trace_steps', ctypes.c_uint64), ('reruns', ctypes.c_uint64),
                 ('host_post_ms', ctypes.c_double), ('host_sam_ms', ctypes.c_double), ('wall_ms', ctypes.c_double),
                 ('k3_cycles_fill', ctypes.c_uint64), ('k3_cycles_leaf', ctypes.c_uint64), ('k3_cycles_trace', ctypes.c_uint64),
-                ('k3_cycles_total', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
+                ('k3_cycles_total', ctypes.c_uint64), ('k3_cycles_max', ctypes.c_uint64), ('k3_waves', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
                 ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64)]
 
 def gensim(*args, out):
@@ -157,6 +157,7 @@ def main():
                        'reads_per_rank': n_reads, 'bases_per_rank': bases, 'parallelism': 'reads sharded, index replicated (no collective)',
                        'kernel_ms_per_step': {'sketch_seed': per_step(st.k1_ms), 'sort_chain': per_step(st.k2_ms), 'extend': per_step(st.k3_ms)},
                        'extend_wave_time_split': {k: getattr(st2, 'k3_cycles_' + k) / max(1, st2.k3_cycles_total) for k in ('fill', 'leaf', 'trace')},
+                       'extend_wave_balance (mean / max lifetime)': st2.k3_cycles_total / max(1, st2.k3_cycles_max * st2.k3_waves),
                        'sort_chain_wave_time_split': {'sort': st2.k2_cycles_sort / max(1, st2.k2_cycles_total), 'chain': st2.k2_cycles_chain / max(1, st2.k2_cycles_total),
                                                       'reads_not_in_lds': st2.k2_reads_hbm, 'sort_cycles_per_seed': st2.k2_cycles_sort / max(1, st2.seeds), 'chain_cycles_per_seed': st2.k2_cycles_chain / max(1, st2.seeds), 'seeds_per_read': st2.seeds / max(1, st2.reads)},
                        'dp_vectors_per_base': vec / bases, 'trace_steps_per_base': trs / bases, 'reruns_per_step': per_step(st.reruns), 'index_build_s': t_index,

@@ -498,14 +498,20 @@ __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uin
 /* one block of up to BLK vectors.  bounded = per-vector sequence-end tests (fill_cap_seq_bounded, gaba.c:1925-1975).
  * Returns the number of vectors filled. */
 template<int MODEL, bool WIDE, bool FAST, bool bounded>
-__device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off)
+__device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool cont)
 {
 	const Consts &c = x.c;
 	const StepK sk = step_consts(c, w.W);
 	uint32_t alen = BLK, blen = BLK;
 	if(bounded) { alen = min(w.rem[0], (uint32_t)BLK); blen = min(w.rem[1], (uint32_t)BLK); }
 	fetch_look(x, w, f, alen, blen);
-	load_context(x, w, f, prev_off);
+	if(cont) {
+		/* the previous block was filled by this wave a moment ago and its diff vectors are still in the registers: what
+		 * _fill_load_context (gaba.c:1527) would read back is what is here (acc went through its int8 slot) -- no HBM round trip */
+		f.b.delta = 0; f.b.drop = (int)((uint32_t)f.xd << 24);
+		f.b.mh = f.b.mv = f.b.me = f.b.mf = 0;
+		w.dmask = 0; w.dacc = (int)(int8_t)w.dacc; w.acnt = 0; w.bcnt = 0;
+	} else { load_context(x, w, f, prev_off); }
 	const int64_t arem = (uint32_t)rdfirst((int)w.rem[0]), brem = (uint32_t)rdfirst((int)w.rem[1]), prem = (uint32_t)rdfirst((int)w.pridx);
 	int dacc = rdfirst(w.dacc);
 	const int ach_in = f.b.ach, look_in = f.look;
@@ -546,7 +552,7 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 }
 
 template<bool bounded>
-__device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off)
+__device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool cont)
 {
 	/* the gap model and the lookup form are fixed per context and the band width per fill: pick the specialised
 	 * 32-vector loop once per block */
@@ -555,8 +561,8 @@ __device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, ui
 	const bool special = __ballot(x.lane < w.W && (f.b.ach > 4 || ((f.b.bch & 3) != 0 && f.b.bch != 2))) != 0;
 	const bool wide = w.W == 64, fast = x.c.fast_score != 0 && !special;
 	#define GABA_PICK(_m) \
-		( wide ? (fast ? fill_block_t<_m, true, true, bounded>(x, w, f, prev_off, blk_off) : fill_block_t<_m, true, false, bounded>(x, w, f, prev_off, blk_off)) \
-		       : (fast ? fill_block_t<_m, false, true, bounded>(x, w, f, prev_off, blk_off) : fill_block_t<_m, false, false, bounded>(x, w, f, prev_off, blk_off)) )
+		( wide ? (fast ? fill_block_t<_m, true, true, bounded>(x, w, f, prev_off, blk_off, cont) : fill_block_t<_m, true, false, bounded>(x, w, f, prev_off, blk_off, cont)) \
+		       : (fast ? fill_block_t<_m, false, true, bounded>(x, w, f, prev_off, blk_off, cont) : fill_block_t<_m, false, false, bounded>(x, w, f, prev_off, blk_off, cont)) )
 	if(x.c.model == MODEL_COMBINED) { return GABA_PICK(MODEL_COMBINED); }
 	return GABA_PICK(MODEL_AFFINE);
 	#undef GABA_PICK
@@ -660,6 +666,7 @@ __device__ __forceinline__ uint32_t create_tail(Ctx &x, Work &w, FillState &f, u
 __device__ __forceinline__ uint32_t fill_body(Ctx &x, Work &w, FillState &f, bool run_blocks)
 {
 	uint32_t last = w.blk0;                        /* last block written */
+	bool cont = false;                             /* the diff vectors of `last` are still in registers */
 	int xstat = (int)(int8_t)rdfirst((int)blk_at(x, w.blk0)->s.xstat);
 	uint32_t head_cnt_nz = 0;
 	if(!run_blocks) {
@@ -676,8 +683,8 @@ __device__ __forceinline__ uint32_t fill_body(Ctx &x, Work &w, FillState &f, boo
 		if(!can_bulk) { break; }
 		uint32_t off = slab_alloc(x, sizeof(Blk));
 		if(x.err) { break; }
-		fill_block<false>(x, w, f, last, off);
-		last = off; w.nblk++;
+		fill_block<false>(x, w, f, last, off, cont);
+		last = off; w.nblk++; cont = true;
 		xstat = (int)(int8_t)((x.c.tx - rdlane(f.xd, w.W / 2)) & TERM);
 	}
 	/* ... then the per-vector bounded cap (fill_cap_seq_bounded, gaba.c:1925-1975) */
@@ -685,7 +692,8 @@ __device__ __forceinline__ uint32_t fill_body(Ctx &x, Work &w, FillState &f, boo
 		while(xstat >= 0 && !x.err) {
 			uint32_t off = slab_alloc(x, sizeof(Blk));
 			if(x.err) { break; }
-			uint32_t k = fill_block<true>(x, w, f, last, off);
+			uint32_t k = fill_block<true>(x, w, f, last, off, cont);
+			cont = true;
 			xstat = (int)(int8_t)((x.c.tx - rdlane(f.xd, w.W / 2)) & TERM);
 			if(k != 0) { last = off; w.nblk++; } else { x.top = off; }   /* squash the empty block (gaba.c:1492) */
 			if(k != BLK) { break; }

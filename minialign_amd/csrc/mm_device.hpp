@@ -63,6 +63,7 @@ struct ReadState {
 	uint32_t err;                                     /* sticky error flags */
 	uint32_t kh_mask, kh_cnt, kh_ub;                  /* kh_t state of the per-read position hash (persists across rounds) */
 	uint32_t seed_n0;                                 /* seed count as K1 left it: immutable, picks the size class of the first-round sort + chain */
+	uint32_t k3_ticks, k3_vec;                        /* diagnostics: s_memtime ticks and DP vectors the extension kernel spent on this read */
 	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
 	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
 };
@@ -954,7 +955,12 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 		if(wi >= a.n_work) { break; }
 		const uint32_t r = (uint32_t)rdfirst((int)a.work[wi]);
 		ReadState *st = &a.st[r];
+		const unsigned long long cy_read0 = __builtin_amdgcn_s_memtime(); const uint32_t vec_read0 = x.n_vec;
 		const uint32_t n_root = (uint32_t)rdfirst((int)st->n_root);
+		/* reads with many chains run several extension trials and are the critical path of the launch (one of them can cost
+		 * three times a wave's fair share): their waves get issue priority so that they move at uncontended speed while the
+		 * ordinary reads fill the slots in between */
+		if(n_root >= 8) { __builtin_amdgcn_s_setprio(3); } else if(n_root >= 5) { __builtin_amdgcn_s_setprio(2); } else { __builtin_amdgcn_s_setprio(0); }
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
 		Seed *s = a.seed_pool + rdfirst64(st->seed_off);
@@ -1207,6 +1213,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 			st->n_bin = n_bin; st->bin_off = bin_off; st->n_aln = n_aln; st->aln_off = aln_off;
 			st->kh_mask = kh.mask; st->kh_cnt = kh.cnt; st->kh_ub = kh.ub;
 			st->err |= err;
+			st->k3_ticks += (uint32_t)(__builtin_amdgcn_s_memtime() - cy_read0); st->k3_vec += x.n_vec - vec_read0;
 			if(n_res > 0) { st->done = 1; }
 		}
 	}
@@ -1215,6 +1222,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 		atomicAdd(&a.stats[5], n_trace); atomicAdd(&a.stats[6], (unsigned long long)x.n_tr);
 		atomicAdd(&a.stats[12], cy_fill); atomicAdd(&a.stats[13], cy_leaf); atomicAdd(&a.stats[14], cy_trace);
 		atomicAdd(&a.stats[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
+		atomicMax(&a.stats[9], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));      /* longest-living wave: load balance */
 	}
 }
 

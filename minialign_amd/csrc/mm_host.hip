@@ -484,6 +484,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		{
 			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
 			std::vector<uint32_t> by_len(work);
+			/* (ordering by the chain count, the best predictor of a read's DP work, was tried and is worse: the heaviest reads then run
+			 * under full contention from the start and become the critical path) */
 			if(qlens.size() == n_reads) { std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return qlens[x] > qlens[y]; }); }
 			CK(hipMemcpyAsync(a->d_work.p, by_len.data(), by_len.size() * 4, hipMemcpyHostToDevice, a->stream));
 			CK(hipStreamSynchronize(a->stream));
@@ -820,9 +822,13 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 {
 	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
 	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
+	if(const char *fn = getenv("MM_DUMP_READ_COST")) {          /* diagnostics: per-read cost of the extension kernel */
+		std::vector<ReadState> d(n_reads); CK(hipMemcpy(d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost));
+		if(FILE *fp = fopen(fn, "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec); fclose(fp); }
+	}
 	unsigned long long tops[32]; CK(hipMemcpy(tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
-	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23];
+	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->n_waves;
 	a->st.k2_cycles_sort += tops[24]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
