@@ -62,7 +62,30 @@ struct gaba_segment_s {            /* gaba.h:193-200 */
 };
 typedef struct gaba_segment_s gaba_path_section_t;
 
+struct gaba_section_s {            /* gaba.h:131-135; base >= GABA_EOU selects the mirrored (reverse-complement) view */
+	uint32_t id, len;
+	uint8_t const *base;
+};
+typedef struct gaba_section_s gaba_section_t;
+#define GABA_EOU                    ( (uint8_t const *)0x800000000000 )
+#define gaba_mirror(base, len)      ( GABA_EOU + (uint64_t)GABA_EOU - (uint64_t)(base) - (uint64_t)(len) )
+#define gaba_build_section(_id, _base, _len)  ( (struct gaba_section_s){ .id = (_id), .len = (_len), .base = (uint8_t const *)(_base) } )
+
+struct gaba_alignment_s {          /* gaba.h:205-220 */
+	void *reserved[2];
+	int64_t score;
+	double identity;
+	uint32_t agcnt, bgcnt;
+	uint32_t dcnt;
+	uint32_t slen;
+	struct gaba_segment_s const *seg;
+	uint32_t plen, padding;
+	uint32_t path[];
+};
+typedef struct gaba_alignment_s gaba_alignment_t;
+
 typedef struct gaba_context_s gaba_t;          /* gaba.h:117 */
+typedef struct gaba_dp_context_s gaba_dp_t;    /* gaba.h:160 */
 typedef struct gaba_arena_s gaba_arena_t;      /* a set of sequences resident in HBM */
 
 /* gaba_init (gaba.h:245, gaba_wrap.h:245-295): validates the scores exactly as gaba_init_check_score
@@ -73,6 +96,24 @@ void gaba_clean(gaba_t *ctx);                  /* gaba.h:252 */
 /* upload `n` bases (one byte per base: A,C,G,T = 0..3, N = 4 -- minialign.c:214-220) as 2-bit + N-mask */
 gaba_arena_t *gaba_arena_upload(uint8_t const *bases, uint64_t n);
 void gaba_arena_free(gaba_arena_t *ar);
+
+/*
+ * The per-call API of gaba.h:266-357, same names and argument meaning.  Sections point into host arrays that were
+ * handed to gaba_arena_upload (the bases themselves are read from the HBM copy); all a-side sections of one context
+ * must lie in one arena and all b-side sections in one arena.  Every call is one single-wavefront launch on the
+ * context's persistent device workspace, so this form is for drop-in use and testing -- throughput comes from
+ * gaba_dp_extend_batch.  gaba_dp_init selects the 64-cell band, gaba_dp_init_bw the 32 / 16-cell variants the
+ * reference exposes through its wrapper (gaba_wrap.h:57).  NULL on error (reason on stderr).
+ */
+gaba_dp_t *gaba_dp_init(gaba_t const *ctx);                    /* gaba.h:266 */
+gaba_dp_t *gaba_dp_init_bw(gaba_t const *ctx, int bw_idx);     /* 0: 64 cells, 1: 32, 2: 16 */
+void gaba_dp_flush(gaba_dp_t *dp);                             /* gaba.h:273: drops every fill / position of the context */
+void gaba_dp_clean(gaba_dp_t *dp);                             /* gaba.h:295 */
+gaba_fill_t *gaba_dp_fill_root(gaba_dp_t *dp, gaba_section_t const *a, uint32_t apos, gaba_section_t const *b, uint32_t bpos, uint32_t pridx);   /* gaba.h:302 */
+gaba_fill_t *gaba_dp_fill(gaba_dp_t *dp, gaba_fill_t const *prev_sec, gaba_section_t const *a, gaba_section_t const *b, uint32_t pridx);          /* gaba.h:315 */
+gaba_pos_pair_t *gaba_dp_search_max(gaba_dp_t *dp, gaba_fill_t const *sec);                                                                       /* gaba.h:339 */
+gaba_alignment_t *gaba_dp_trace(gaba_dp_t *dp, gaba_fill_t const *tail, void const *alloc_params);                                                /* gaba.h:348 */
+void gaba_dp_res_free(gaba_dp_t *dp, gaba_alignment_t *aln);                                                                                      /* gaba.h:357 */
 
 /* one extension job: the arguments of gaba_dp_fill_root (gaba.c:2110) with host pointers replaced by
  * arena offsets; rev = 1 selects the mirrored (reverse-complement) view (gaba.h:151-155 gaba_mirror) */

@@ -234,6 +234,11 @@ void gaba_clean(gaba_t *ctx)
 	free(ctx);
 }
 
+/* arenas by the host range they were uploaded from: a gaba_section_t of the per-call API points into one of them */
+static std::vector<gaba_arena_t *> g_arenas;
+static void arena_registry_add(gaba_arena_t *ar) { g_arenas.push_back(ar); }
+static void arena_registry_del(gaba_arena_t *ar) { for(size_t i = 0; i < g_arenas.size(); i++) if(g_arenas[i] == ar) { g_arenas.erase(g_arenas.begin() + i); break; } }
+
 gaba_arena_t *gaba_arena_upload(uint8_t const *bases, uint64_t n)
 {
 	uint64_t nw = (n + 15) / 16 + 4, nn = (n + 31) / 32 + 4;
@@ -244,13 +249,15 @@ gaba_arena_t *gaba_arena_upload(uint8_t const *bases, uint64_t n)
 		pk[i >> 4] |= c << (2 * (i & 15));
 	}
 	gaba_arena_t *ar = (gaba_arena_t *)calloc(1, sizeof(gaba_arena_t));
-	ar->n = n;
+	ar->n = n; ar->host = bases;
 	HIP_OK(hipMalloc(&ar->pk, nw * 4), NULL); HIP_OK(hipMalloc(&ar->nm, nn * 4), NULL);
 	HIP_OK(hipMemcpy(ar->pk, pk.data(), nw * 4, hipMemcpyHostToDevice), NULL);
 	HIP_OK(hipMemcpy(ar->nm, nm.data(), nn * 4, hipMemcpyHostToDevice), NULL);
+	arena_registry_add(ar);
 	return ar;
 }
-void gaba_arena_free(gaba_arena_t *ar) { if(ar) { hipFree(ar->pk); hipFree(ar->nm); free(ar); } }
+void gaba_arena_unregister(gaba_arena_t *ar) { if(ar) { arena_registry_del(ar); ar->host = NULL; } }
+void gaba_arena_free(gaba_arena_t *ar) { if(ar) { arena_registry_del(ar); hipFree(ar->pk); hipFree(ar->nm); free(ar); } }
 
 int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const *b,
 	gaba_job_t const *jobs, uint32_t n, gaba_xresult_t *results, uint32_t *paths, uint32_t path_stride)
@@ -328,6 +335,162 @@ int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const 
 }
 
 void gaba_last_stats(gaba_t *ctx, gaba_batch_stats_t *out) { if(ctx && out) *out = ctx->last; }
+
+/* =====================================================================================================
+ * The per-call API of gaba.h:266-357 on a persistent device workspace: one single-wave launch per call.
+ * A gaba_dp_t owns one slab in HBM (root blocks at its head, bump pointer kept on the host); the gaba_fill_t
+ * returned to the caller carries the slab offset of its tail in reserved[0].
+ * ===================================================================================================== */
+struct ScalarOut { uint32_t tail, top; int32_t err; uint32_t _pad; Fill f; PosPair pp; AlnOut ao; };
+
+__global__ void __launch_bounds__(64) gaba_scalar_fill_kernel(const Consts c, SeqArena ar_a, SeqArena ar_b, uint8_t *slab, uint32_t top, uint32_t cap,
+	uint32_t prev_tail, int bw_idx, Sec sa, uint32_t apos, Sec sb, uint32_t bpos, uint32_t pridx, ScalarOut *out)
+{
+	SeqArena ar[2] = { ar_a, ar_b };
+	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	x.slab = slab; x.cap = cap; x.top = top;
+	const uint32_t f = dp_fill_any(x, prev_tail, bw_idx, sa, apos, sb, bpos, pridx);
+	if(x.lane == 0) { out->tail = f; out->top = x.top; out->err = x.err; out->f = tail_at(x, f)->f; }
+}
+__global__ void __launch_bounds__(64) gaba_scalar_search_kernel(const Consts c, SeqArena ar_a, SeqArena ar_b, uint8_t *slab, uint32_t top, uint32_t cap,
+	uint32_t tail, ScalarOut *out)
+{
+	SeqArena ar[2] = { ar_a, ar_b };
+	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	x.slab = slab; x.cap = cap; x.top = top;
+	Leaf lf;
+	const PosPair pp = dp_search_max(x, tail, lf);
+	if(x.lane == 0) { out->pp = pp; out->top = x.top; out->err = x.err; }
+}
+__global__ void __launch_bounds__(64) gaba_scalar_trace_kernel(const Consts c, SeqArena ar_a, SeqArena ar_b, uint8_t *slab, uint32_t top, uint32_t cap,
+	uint32_t tail, uint32_t *path, uint64_t path_words, Segment *seg, uint32_t max_seg, ScalarOut *out)
+{
+	SeqArena ar[2] = { ar_a, ar_b };
+	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	x.slab = slab; x.cap = cap; x.top = top;
+	const AlnOut ao = dp_trace(x, tail, path, path_words, seg, max_seg);
+	if(x.lane == 0) { out->ao = ao; out->top = x.top; out->err = x.err; }
+}
+
+struct gaba_dp_context_s {
+	gaba_t const *ctx; int bw_idx;
+	uint8_t *slab; uint32_t cap, top;
+	const gaba_arena_t *ar[2];               /* bound at the first fill: a sections come from ar[0], b sections from ar[1] */
+	ScalarOut *dout;
+	std::vector<gaba_fill_t *> fills; std::vector<gaba_pos_pair_t *> pps;
+	hipStream_t stream;
+};
+
+/* a host section -> device descriptor: the arena whose uploaded range holds it, mirrored pointers (gaba.h:151-155) included */
+static bool section_to_dev(gaba_dp_t *dp, int side, gaba_section_t const *s, Sec *out)
+{
+	const uint64_t eou = 0x800000000000ull;
+	uint64_t p = (uint64_t)(uintptr_t)s->base; bool rev = false;
+	if(p >= eou) { p = 2 * eou - p - s->len; rev = true; }          /* gaba_mirror */
+	const gaba_arena_t *hit = NULL;
+	for(gaba_arena_t *ar : g_arenas) { const uint64_t h = (uint64_t)(uintptr_t)ar->host; if(p >= h && p + s->len <= h + ar->n) { hit = ar; break; } }
+	if(!hit) { fprintf(stderr, "[minialign_amd] gaba_dp: section %u does not lie in an uploaded arena (gaba_arena_upload)\n", s->id); return false; }
+	if(dp->ar[side] == NULL) { dp->ar[side] = hit; }
+	if(dp->ar[side] != hit) { fprintf(stderr, "[minialign_amd] gaba_dp: all %c-side sections of a context must come from one arena\n", side ? 'b' : 'a'); return false; }
+	*out = Sec{ s->id, s->len, p - (uint64_t)(uintptr_t)hit->host, (uint32_t)side, rev ? 1u : 0u };
+	return true;
+}
+
+gaba_dp_t *gaba_dp_init_bw(gaba_t const *ctx, int bw_idx)
+{
+	if(!ctx || bw_idx < 0 || bw_idx > 2) return NULL;
+	gaba_dp_t *dp = new gaba_dp_t();
+	dp->ctx = ctx; dp->bw_idx = bw_idx; dp->cap = 64u << 20; dp->top = SLAB_HEAD; dp->ar[0] = dp->ar[1] = NULL;
+	if(hipMalloc(&dp->slab, dp->cap) != hipSuccess || hipMalloc(&dp->dout, sizeof(ScalarOut)) != hipSuccess || hipStreamCreate(&dp->stream) != hipSuccess) {
+		fprintf(stderr, "[minialign_amd] gaba_dp_init: no device workspace\n"); delete dp; return NULL;
+	}
+	HIP_OK(hipMemcpy(dp->slab, ctx->droots, SLAB_HEAD, hipMemcpyDeviceToDevice), NULL);
+	return dp;
+}
+gaba_dp_t *gaba_dp_init(gaba_t const *ctx) { return gaba_dp_init_bw(ctx, 0); }
+void gaba_dp_flush(gaba_dp_t *dp)
+{
+	if(!dp) return;
+	dp->top = SLAB_HEAD;
+	for(gaba_fill_t *f : dp->fills) free(f);
+	for(gaba_pos_pair_t *q : dp->pps) free(q);
+	dp->fills.clear(); dp->pps.clear();
+}
+void gaba_dp_clean(gaba_dp_t *dp)
+{
+	if(!dp) return;
+	gaba_dp_flush(dp);
+	(void)hipFree(dp->slab); (void)hipFree(dp->dout); (void)hipStreamDestroy(dp->stream);
+	delete dp;
+}
+static gaba_fill_t *scalar_fill(gaba_dp_t *dp, uint32_t prev_tail, gaba_section_t const *a, uint32_t apos, gaba_section_t const *b, uint32_t bpos, uint32_t pridx)
+{
+	Sec sa, sb;
+	if(!dp || !a || !b || !section_to_dev(dp, 0, a, &sa) || !section_to_dev(dp, 1, b, &sb)) return NULL;
+	SeqArena da = { dp->ar[0]->pk, dp->ar[0]->nm }, db = { dp->ar[1]->pk, dp->ar[1]->nm };
+	hipLaunchKernelGGL(gaba_scalar_fill_kernel, dim3(1), dim3(64), 0, dp->stream, dp->ctx->hc, da, db, dp->slab, dp->top, dp->cap,
+		prev_tail, dp->bw_idx, sa, apos, sb, bpos, pridx, dp->dout);
+	ScalarOut o;
+	HIP_OK(hipGetLastError(), NULL); HIP_OK(hipMemcpyAsync(&o, dp->dout, sizeof(o), hipMemcpyDeviceToHost, dp->stream), NULL); HIP_OK(hipStreamSynchronize(dp->stream), NULL);
+	if(o.err) { fprintf(stderr, "[minialign_amd] gaba_dp_fill: device workspace exhausted (%u B)\n", dp->cap); return NULL; }
+	dp->top = o.top;
+	gaba_fill_t *f = (gaba_fill_t *)calloc(1, sizeof(gaba_fill_t));
+	f->aid = o.f.aid; f->bid = o.f.bid; f->ascnt = o.f.ascnt; f->bscnt = o.f.bscnt; f->apos = o.f.apos; f->bpos = o.f.bpos; f->max = o.f.max; f->status = o.f.status;
+	f->reserved[0] = o.tail;
+	dp->fills.push_back(f);
+	return f;
+}
+gaba_fill_t *gaba_dp_fill_root(gaba_dp_t *dp, gaba_section_t const *a, uint32_t apos, gaba_section_t const *b, uint32_t bpos, uint32_t pridx)
+{
+	return scalar_fill(dp, NIL, a, apos, b, bpos, pridx);
+}
+gaba_fill_t *gaba_dp_fill(gaba_dp_t *dp, gaba_fill_t const *prev, gaba_section_t const *a, gaba_section_t const *b, uint32_t pridx)
+{
+	if(!prev) return NULL;
+	return scalar_fill(dp, prev->reserved[0], a, 0, b, 0, pridx);
+}
+gaba_pos_pair_t *gaba_dp_search_max(gaba_dp_t *dp, gaba_fill_t const *fill)
+{
+	if(!dp || !fill || !dp->ar[0] || !dp->ar[1]) return NULL;
+	SeqArena da = { dp->ar[0]->pk, dp->ar[0]->nm }, db = { dp->ar[1]->pk, dp->ar[1]->nm };
+	hipLaunchKernelGGL(gaba_scalar_search_kernel, dim3(1), dim3(64), 0, dp->stream, dp->ctx->hc, da, db, dp->slab, dp->top, dp->cap, fill->reserved[0], dp->dout);
+	ScalarOut o;
+	HIP_OK(hipGetLastError(), NULL); HIP_OK(hipMemcpyAsync(&o, dp->dout, sizeof(o), hipMemcpyDeviceToHost, dp->stream), NULL); HIP_OK(hipStreamSynchronize(dp->stream), NULL);
+	gaba_pos_pair_t *q = (gaba_pos_pair_t *)calloc(1, sizeof(gaba_pos_pair_t));
+	q->aid = o.pp.aid; q->bid = o.pp.bid; q->apos = o.pp.apos; q->bpos = o.pp.bpos; q->plen = o.pp.plen;
+	dp->pps.push_back(q);
+	return q;
+}
+gaba_alignment_t *gaba_dp_trace(gaba_dp_t *dp, gaba_fill_t const *fill, void const *alloc_params)
+{
+	(void)alloc_params;                              /* results are malloc'd; release with gaba_dp_res_free */
+	if(!dp || !fill || !dp->ar[0] || !dp->ar[1]) return NULL;
+	SeqArena da = { dp->ar[0]->pk, dp->ar[0]->nm }, db = { dp->ar[1]->pk, dp->ar[1]->nm };
+	/* the path cannot be longer than the two sequences walked: bounded by the fill's positions */
+	const uint64_t max_plen = (uint64_t)(fill->apos + fill->bpos) + 4 * 1024 * 1024;
+	const uint64_t words = (std::min<uint64_t>(max_plen, dp->cap / 8) + 31) / 32 + 8;
+	const uint32_t max_seg = 64;
+	uint32_t *dpath = NULL; Segment *dseg = NULL;
+	HIP_OK(hipMalloc(&dpath, words * 4), NULL); HIP_OK(hipMalloc(&dseg, max_seg * sizeof(Segment)), NULL);
+	hipLaunchKernelGGL(gaba_scalar_trace_kernel, dim3(1), dim3(64), 0, dp->stream, dp->ctx->hc, da, db, dp->slab, dp->top, dp->cap,
+		fill->reserved[0], dpath, words, dseg, max_seg, dp->dout);
+	ScalarOut o;
+	HIP_OK(hipGetLastError(), NULL); HIP_OK(hipMemcpyAsync(&o, dp->dout, sizeof(o), hipMemcpyDeviceToHost, dp->stream), NULL); HIP_OK(hipStreamSynchronize(dp->stream), NULL);
+	gaba_alignment_t *aln = NULL;
+	if(!o.err && o.ao.status == 1) {
+		const uint64_t pw = ((uint64_t)o.ao.plen + 31) / 32 + 2;
+		/* one allocation: header | path words (two header words {plen, 0x40000000} live in plen / padding, gaba.h:217) | segments */
+		aln = (gaba_alignment_t *)calloc(1, sizeof(gaba_alignment_t) + pw * 4 + o.ao.slen * sizeof(gaba_path_section_t));
+		aln->score = o.ao.score; aln->identity = o.ao.identity; aln->agcnt = o.ao.agcnt; aln->bgcnt = o.ao.bgcnt; aln->dcnt = o.ao.dcnt;
+		aln->slen = o.ao.slen; aln->plen = o.ao.plen; aln->padding = 0x40000000u;
+		gaba_path_section_t *seg = (gaba_path_section_t *)((uint8_t *)aln + sizeof(gaba_alignment_t) + pw * 4);
+		if(hipMemcpy(aln->path, dpath, pw * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(seg, dseg, o.ao.slen * sizeof(Segment), hipMemcpyDeviceToHost) != hipSuccess) { free(aln); aln = NULL; }
+		else { aln->seg = seg; }
+	}
+	(void)hipFree(dpath); (void)hipFree(dseg);
+	return aln;
+}
+void gaba_dp_res_free(gaba_dp_t *dp, gaba_alignment_t *aln) { (void)dp; free(aln); }
 
 /* ---- CIGAR printers over a path (gaba_parse.h:147-263): run-length decode of the path bits; host side ---- */
 static inline uint64_t cg_u64(const uint64_t *ptr, int64_t pos) { int64_t rem = pos & 63; return (ptr[pos >> 6] >> rem) | ((ptr[(pos >> 6) + 1] << (63 - rem)) << 1); }

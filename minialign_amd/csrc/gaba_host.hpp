@@ -8,7 +8,10 @@
 #define HIP_OK(_e, _ret) do { hipError_t _r = (_e); if(_r != hipSuccess) { \
 	fprintf(stderr, "[minialign_amd] HIP error %s at %s:%d\n", hipGetErrorString(_r), __FILE__, __LINE__); return _ret; } } while(0)
 
-struct gaba_arena_s { uint32_t *pk, *nm; uint64_t n; };
+struct gaba_arena_s { uint32_t *pk, *nm; uint64_t n; const uint8_t *host; };     /* host: the array it was uploaded from (section lookup of the per-call API) */
+
+/* drop an arena from the host-range registry of the per-call API (its host array is about to go away); not part of the C ABI */
+extern "C" void gaba_arena_unregister(gaba_arena_t *ar);
 
 struct gaba_context_s {
 	gaba::Consts hc;

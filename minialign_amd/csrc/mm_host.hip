@@ -689,6 +689,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	for(size_t i = 0; i < mi->seq.size(); i++) memcpy(all.data() + off[i], mi->seq[i].seq.data(), mi->seq[i].seq.size());
 	a->ref_ar = gaba_arena_upload(all.data(), total + 64);
 	if(!a->ref_ar) { delete a; return NULL; }
+	gaba_arena_unregister(a->ref_ar);                 /* `all` is a temporary: keep it out of the per-call API's section lookup */
 	bool ok = true;
 	ok &= hipMalloc(&a->d_slot, mi->slot.size() * sizeof(IdxSlot)) == hipSuccess;
 	ok &= hipMalloc(&a->d_val, mi->val.size() * 8) == hipSuccess;

@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     txt = open(os.path.join(ROOT, 'include', header)).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    txt = re.sub(r'^[ \t]*#[ \t]*define.*$', '', txt, flags=re.M)          # function-like macros are not symbols
     names = set()
     for m in re.finditer(r'\b((?:gaba|mm)_[a-z0-9_]+)\s*\(', txt):
         names.add(m.group(1))
