@@ -51,3 +51,15 @@ def test_sam_matches_oracle(s, workdir):
     refbin = os.path.join(M.ROOT, 'oracle', '_ref', 'minialign')
     if os.path.exists(refbin):
         assert got == _run(refbin, s['preset'], ref, rd)
+
+
+@pytest.mark.parametrize('fmt', ['fa', 'fq'])
+@pytest.mark.parametrize('preset', ['pacbio', 'ont.1dsq'])
+def test_edge_cases_match_reference_golden(preset, fmt, workdir):
+    """the hand-built edge-case set of tests/golden/make_edge_golden.py (reads shorter than k, all-N, N runs, unmappable,
+    chimera, contig ends, FASTQ, ...) through the HIP pipeline against the compiled reference's SAM"""
+    from golden.make_edge_golden import make_edge_inputs
+    ref, rd = make_edge_inputs(workdir, fmt)
+    got = _run(CLI, preset, ref, rd)
+    want = gzip.open(os.path.join(HERE, 'golden', 'edge_%s_%s.sam.gz' % (preset.replace('.', ''), fmt))).read()
+    assert got == want, _first_diff(got, want)

@@ -51,3 +51,17 @@ def test_oracle_vs_live_reference_multicontig(workdir):
     a = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', '_ref', 'minialign'), '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
     b = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign'), '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
     assert a == b
+
+
+@pytest.mark.parametrize('fmt', ['fa', 'fq'])
+@pytest.mark.parametrize('preset', ['pacbio', 'ont.1dsq'])
+def test_oracle_edge_cases_match_reference_golden(preset, fmt, workdir):
+    """hand-built edge cases (reads shorter than k, all-N, N runs, unmappable, both strands, chimera, contig ends, a read the
+    reference drops from its output altogether, FASTQ input): the golden SAM is the compiled reference's
+    (tests/golden/make_edge_golden.py)"""
+    import gzip
+    from golden.make_edge_golden import make_edge_inputs, strip_pg
+    ref, rd = make_edge_inputs(workdir, fmt)
+    got = strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign'), '-x' + preset, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+    want = gzip.open(os.path.join(HERE, 'golden', 'edge_%s_%s.sam.gz' % (preset.replace('.', ''), fmt))).read()
+    assert got == want
