@@ -109,6 +109,9 @@ gaba_dp_t *gaba_dp_init(gaba_t const *ctx);                    /* gaba.h:266 */
 gaba_dp_t *gaba_dp_init_bw(gaba_t const *ctx, int bw_idx);     /* 0: 64 cells, 1: 32, 2: 16 */
 void gaba_dp_flush(gaba_dp_t *dp);                             /* gaba.h:273: drops every fill / position of the context */
 void gaba_dp_clean(gaba_dp_t *dp);                             /* gaba.h:295 */
+typedef struct gaba_stack_s gaba_stack_t;                      /* gaba.h:124 */
+gaba_stack_t const *gaba_dp_save_stack(gaba_dp_t *dp);         /* gaba.h:280: remember the workspace level ... */
+void gaba_dp_flush_stack(gaba_dp_t *dp, gaba_stack_t const *stack);   /* gaba.h:287: ... and drop everything filled since (consumes `stack`) */
 gaba_fill_t *gaba_dp_fill_root(gaba_dp_t *dp, gaba_section_t const *a, uint32_t apos, gaba_section_t const *b, uint32_t bpos, uint32_t pridx);   /* gaba.h:302 */
 gaba_fill_t *gaba_dp_fill(gaba_dp_t *dp, gaba_fill_t const *prev_sec, gaba_section_t const *a, gaba_section_t const *b, uint32_t pridx);          /* gaba.h:315 */
 gaba_pos_pair_t *gaba_dp_search_max(gaba_dp_t *dp, gaba_fill_t const *sec);                                                                       /* gaba.h:339 */
@@ -152,6 +155,10 @@ int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const 
  * `path` must be preceded by the two header words {plen, 0x40000000} as in gaba_alignment_s (gaba.h:217). */
 uint64_t gaba_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
 uint64_t gaba_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
+/* gaba.h:385-406: the same through a printer callback, e.g. int pr(void *fp, uint64_t len, char c) { return fprintf(fp, "%c%lu", c, len); } */
+typedef int (*gaba_printer_t)(void *, uint64_t, char);
+uint64_t gaba_print_cigar_forward(gaba_printer_t printer, void *fp, uint32_t const *path, uint64_t offset, uint64_t len);
+uint64_t gaba_print_cigar_reverse(gaba_printer_t printer, void *fp, uint32_t const *path, uint64_t offset, uint64_t len);
 
 /* last kernel time of gaba_dp_extend_batch in milliseconds (HIP events on the launch stream) and work counters */
 typedef struct { double kernel_ms; uint64_t vectors, blocks, trace_steps; } gaba_batch_stats_t;

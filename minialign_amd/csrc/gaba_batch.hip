@@ -497,41 +497,78 @@ static inline uint64_t cg_u64(const uint64_t *ptr, int64_t pos) { int64_t rem = 
 static inline uint64_t cg_lz(uint64_t x) { return x ? (uint64_t)__builtin_clzll(x) : 64; }
 static inline uint64_t cg_tz(uint64_t x) { return x ? (uint64_t)__builtin_ctzll(x) : 64; }
 static inline char *cg_put(char *b, uint64_t n, char op) { char t[24]; int k = 0; if(!n) t[k++] = '0'; while(n) { t[k++] = (char)('0' + n % 10); n /= 10; } while(k) *b++ = t[--k]; *b++ = op; return b; }
-uint64_t gaba_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
+} /* extern "C" */
+/* the two run-length walks of gaba_parse.h:168-246 (_parser_loop_rv / _fw), emitting through a functor */
+template<typename F> static inline void cigar_walk_reverse(uint32_t const *path, uint64_t offset, uint64_t len, F emit)
 {
-	(void)buf_size;
-	char *b = buf;
 	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
 	uint64_t ofs = (uint64_t)((int64_t)offset + (((uintptr_t)path & 4) ? 32 : 0) - 64), idx = len;
 	while((int64_t)idx > 0) {
 		uint64_t m = cg_lz(cg_u64(p, (int64_t)(ofs + idx))), c = m - (m > 0); if(c > idx) c = idx;
-		idx -= c; if(c) b = cg_put(b, c, 'D');
+		idx -= c; if(c) emit(c, 'D');
 		m = cg_lz(~cg_u64(p, (int64_t)(ofs + idx))); c = m < idx ? m : idx;
-		idx -= c; if(c) b = cg_put(b, c, 'I');
+		idx -= c; if(c) emit(c, 'I');
 		uint64_t s0 = idx;
 		do { m = cg_lz(cg_u64(p, (int64_t)(ofs + idx)) ^ 0x5555555555555555ull); c = (m < idx ? m : idx) & ~1ull; idx -= c; } while(c == 64);
-		if((s0 - idx) >> 1) b = cg_put(b, (s0 - idx) >> 1, 'M');
+		if((s0 - idx) >> 1) emit((s0 - idx) >> 1, 'M');
 	}
-	*b = 0;
-	return (uint64_t)(b - buf);
 }
-uint64_t gaba_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
+template<typename F> static inline void cigar_walk_forward(uint32_t const *path, uint64_t offset, uint64_t len, F emit)
 {
-	(void)buf_size;
-	char *b = buf;
 	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
 	uint64_t lim = offset + (((uintptr_t)path & 4) ? 32 : 0) + len, ridx = len;
 	while((int64_t)ridx > 0) {
 		uint64_t m = cg_tz(~cg_u64(p, (int64_t)(lim - ridx))), c = m - (m > 0); if(c > ridx) c = ridx;
-		ridx -= c; if(c) b = cg_put(b, c, 'I');
+		ridx -= c; if(c) emit(c, 'I');
 		m = cg_tz(cg_u64(p, (int64_t)(lim - ridx))); c = m < ridx ? m : ridx;
-		ridx -= c; if(c) b = cg_put(b, c, 'D');
+		ridx -= c; if(c) emit(c, 'D');
 		uint64_t s0 = ridx;
 		do { m = cg_tz(cg_u64(p, (int64_t)(lim - ridx)) ^ 0x5555555555555555ull); c = (m < ridx ? m : ridx) & ~1ull; ridx -= c; } while(c == 64);
-		if((s0 - ridx) >> 1) b = cg_put(b, (s0 - ridx) >> 1, 'M');
+		if((s0 - ridx) >> 1) emit((s0 - ridx) >> 1, 'M');
 	}
-	*b = 0;
-	return (uint64_t)(b - buf);
+}
+extern "C" {
+uint64_t gaba_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
+{
+	(void)buf_size; char *b = buf;
+	cigar_walk_reverse(path, offset, len, [&](uint64_t n, char op) { b = cg_put(b, n, op); });
+	*b = 0; return (uint64_t)(b - buf);
+}
+uint64_t gaba_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
+{
+	(void)buf_size; char *b = buf;
+	cigar_walk_forward(path, offset, len, [&](uint64_t n, char op) { b = cg_put(b, n, op); });
+	*b = 0; return (uint64_t)(b - buf);
+}
+/* gaba.h:394-406: the same walks through a caller-supplied printer; returns the sum of what the printer returned */
+uint64_t gaba_print_cigar_reverse(gaba_printer_t printer, void *fp, uint32_t const *path, uint64_t offset, uint64_t len)
+{
+	uint64_t clen = 0;
+	cigar_walk_reverse(path, offset, len, [&](uint64_t n, char op) { clen += (uint64_t)printer(fp, n, op); });
+	return clen;
+}
+uint64_t gaba_print_cigar_forward(gaba_printer_t printer, void *fp, uint32_t const *path, uint64_t offset, uint64_t len)
+{
+	uint64_t clen = 0;
+	cigar_walk_forward(path, offset, len, [&](uint64_t n, char op) { clen += (uint64_t)printer(fp, n, op); });
+	return clen;
+}
+/* gaba_dp_save_stack / gaba_dp_flush_stack (gaba.h:280-289): the bump pointer of the context's device workspace */
+struct gaba_stack_s { uint32_t top; size_t n_fill, n_pp; };
+gaba_stack_t const *gaba_dp_save_stack(gaba_dp_t *dp)
+{
+	if(!dp) return NULL;
+	gaba_stack_t *s = (gaba_stack_t *)malloc(sizeof(gaba_stack_t));
+	s->top = dp->top; s->n_fill = dp->fills.size(); s->n_pp = dp->pps.size();
+	return s;
+}
+void gaba_dp_flush_stack(gaba_dp_t *dp, gaba_stack_t const *stack)
+{
+	if(!dp || !stack) return;
+	dp->top = stack->top;
+	while(dp->fills.size() > stack->n_fill) { free(dp->fills.back()); dp->fills.pop_back(); }
+	while(dp->pps.size() > stack->n_pp) { free(dp->pps.back()); dp->pps.pop_back(); }
+	free((void *)stack);
 }
 
 } /* extern "C" */

@@ -70,3 +70,20 @@ def test_product_cigar_known_answers():
         assert _cigar(L, 'gaba_dump_cigar_forward', words, ofs, ln)[0] == want
     for words, ofs, ln, want in CIGAR_KAT_RV:
         assert _cigar(L, 'gaba_dump_cigar_reverse', words, ofs, ln)[0] == want
+
+def test_product_cigar_printer_callbacks_match_dump():
+    """gaba_print_cigar_{forward,reverse} (gaba.h:394-406) drive a caller's printer with the same runs gaba_dump_cigar_* writes"""
+    import numpy as np
+    from test_oracle_gaba import CIGAR_KAT_FW, CIGAR_KAT_RV, _cigar
+    L = ctypes.CDLL(os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so'))
+    PR = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char)
+    for name, table in (('forward', CIGAR_KAT_FW), ('reverse', CIGAR_KAT_RV)):
+        fn = getattr(L, 'gaba_print_cigar_' + name); fn.restype = ctypes.c_uint64
+        for words, ofs, ln, want in table:
+            got = []
+            def pr(fp, n, c, got=got):
+                s = b'%d%s' % (n, c); got.append(s); return len(s)
+            buf = np.zeros(len(words) + 8, dtype=np.uint32); buf[2:2 + len(words)] = words      # two header words in front, as in gaba_alignment_s
+            base = buf.ctypes.data + 8
+            clen = fn(PR(pr), None, ctypes.c_void_p(base), ctypes.c_uint64(ofs), ctypes.c_uint64(ln))
+            assert b''.join(got).decode() == want and clen == len(want)
