@@ -19,6 +19,7 @@
 #include <time.h>
 #include <string>
 #include <vector>
+#include <thread>
 #include <algorithm>
 #include "gaba_host.hpp"
 #include "mm_device.hpp"
@@ -841,11 +842,29 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 	CK(hipMemcpy(seg.data(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost));
 	CK(hipMemcpy(path.data(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost));
 	double t1 = now_ms();
-	for(uint32_t i = 0; i < n_reads; i++) {
-		OutReg reg; const ReadState &rs = hst[i];
-		const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.data();
-		if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
-		sam_record(a, sam, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.data(), path.data());
+	/* post-map and SAM text are per read and independent: host threads take contiguous spans, the pieces are joined in input
+	 * order (mm_align_drain keeps the same order with its heap, minialign.c:4633-4645) */
+	{
+		const uint32_t want = a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 16);      /* -t sets it; default: up to 16 */
+		const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(1, n_reads / 64)));
+		std::vector<std::string> piece(nth);
+		auto span = [&](uint32_t t) {
+			const uint32_t lo = (uint32_t)((uint64_t)n_reads * t / nth), hi = (uint32_t)((uint64_t)n_reads * (t + 1) / nth);
+			std::string &out = piece[t];
+			for(uint32_t i = lo; i < hi; i++) {
+				OutReg reg; const ReadState &rs = hst[i];
+				const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.data();
+				if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
+				sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.data(), path.data());
+			}
+		};
+		std::vector<std::thread> th;
+		for(uint32_t t = 1; t < nth; t++) th.emplace_back(span, t);
+		span(0);
+		for(auto &x : th) x.join();
+		size_t tot = sam.size(); for(auto &x : piece) tot += x.size();
+		sam.reserve(tot);
+		for(auto &x : piece) sam += x;
 	}
 	a->st.host_post_ms += t1 - t0; a->st.host_sam_ms += now_ms() - t1;
 	return true;
