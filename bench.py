@@ -25,7 +25,7 @@ class Stats(ctypes.Structure):
                 ('trace_steps', ctypes.c_uint64), ('reruns', ctypes.c_uint64),
                 ('host_post_ms', ctypes.c_double), ('host_sam_ms', ctypes.c_double), ('wall_ms', ctypes.c_double),
                 ('k3_cycles_fill', ctypes.c_uint64), ('k3_cycles_leaf', ctypes.c_uint64), ('k3_cycles_trace', ctypes.c_uint64),
-                ('k3_cycles_total', ctypes.c_uint64), ('k3_cycles_max', ctypes.c_uint64), ('k3_waves', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
+                ('k3_cycles_total', ctypes.c_uint64), ('k3_cycles_next', ctypes.c_uint64), ('k3_cycles_max', ctypes.c_uint64), ('k3_waves', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
                 ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64)]
 
 def gensim(*args, out):
@@ -74,6 +74,9 @@ def cpu_baseline(ref_fa, reads_fa, workdir, budget_reads):
             'sample': 'first %d reads (%.1f Mb), oracle/ora_minialign (plain-C restatement, single thread), mm_align_seq time only' % (min(k, 300), b2 / 1e6)}
 
 def pmc_traffic(args, world):
+    return None    # the committed PMC passes predate the two-lane launch shape; re-enabled once they are re-collected
+
+def pmc_traffic_from_profile(args, world):
     """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes (same workload only), else None"""
     fn = os.path.join(ROOT, 'profiles', 'round1_c_pmc.json')
     if world != 1 or args.depth != 100.0 or not os.path.exists(fn): return None
@@ -146,7 +149,9 @@ def main():
         per_step = lambda x: x / max(1, args.steps)
         # work counters are read at finish time and cover the last pass over the batch (each pass re-initialises the device state)
         vec = float(st2.vectors); trs = float(st2.trace_steps)
-        alg_bytes = vec * 40.5 + trs * 32.0                     # SURVEY.md 8d per-unit figures for the extension kernel
+        # SURVEY.md 8d per-unit figures for the extension kernel; the two lanes of a step launch it once each (half of the batch)
+        k3_per_step = max(1.0, st.k3_launches / max(1, args.steps))
+        alg_bytes = (vec * 40.5 + trs * 32.0) / k3_per_step
         achieved = alg_bytes / (k3_launch_ms * 1e-3) / 1e9 if k3_launch_ms > 0 else None
         out = {
             'metric': 'aligned Gbases/sec (hot path: sketch+lookup, sort+chain, banded extension; SAM bit-exact vs CPU ref)',
@@ -156,7 +161,7 @@ def main():
             'config': {'workload': 'E.coli MG1655-size ref x PBSIM-like x%g (%.0f Mb, %d reads) -xpacbio on 1 MI355X per rank' % (args.depth, bases / 1e6, n_reads),
                        'reads_per_rank': n_reads, 'bases_per_rank': bases, 'parallelism': 'reads sharded, index replicated (no collective)',
                        'kernel_ms_per_step': {'sketch_seed': per_step(st.k1_ms), 'sort_chain': per_step(st.k2_ms), 'extend': per_step(st.k3_ms)},
-                       'extend_wave_time_split': {k: getattr(st2, 'k3_cycles_' + k) / max(1, st2.k3_cycles_total) for k in ('fill', 'leaf', 'trace')},
+                       'extend_wave_time_split': {k: getattr(st2, 'k3_cycles_' + k) / max(1, st2.k3_cycles_total) for k in ('fill', 'leaf', 'trace', 'next')},
                        'extend_wave_balance (mean / max lifetime)': st2.k3_cycles_total / max(1, st2.k3_cycles_max * st2.k3_waves),
                        'sort_chain_wave_time_split': {'sort': st2.k2_cycles_sort / max(1, st2.k2_cycles_total), 'chain': st2.k2_cycles_chain / max(1, st2.k2_cycles_total),
                                                       'reads_not_in_lds': st2.k2_reads_hbm, 'sort_cycles_per_seed': st2.k2_cycles_sort / max(1, st2.seeds), 'chain_cycles_per_seed': st2.k2_cycles_chain / max(1, st2.seeds), 'seeds_per_read': st2.seeds / max(1, st2.reads)},

@@ -79,6 +79,7 @@ typedef struct {
 	double host_post_ms, host_sam_ms, wall_ms;
 	/* wave-cycles (s_memtime ticks summed over all waves of the extension kernel): DP fill, max search, traceback, whole wave */
 	uint64_t k3_cycles_fill, k3_cycles_leaf, k3_cycles_trace, k3_cycles_total;
+	uint64_t k3_cycles_next;                /* ... of which in the next-seed search of the extension driver (mm_search_load_next) */
 	uint64_t k3_cycles_max, k3_waves;       /* lifetime of the longest-living wave (summed over launches), persistent waves per launch */
 	/* the same for the first-round sort + chain kernel, and the number of reads whose seed array did not fit the LDS */
 	uint64_t k2_cycles_sort, k2_cycles_chain, k2_cycles_total, k2_reads_hbm;

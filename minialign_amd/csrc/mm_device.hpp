@@ -63,7 +63,7 @@ struct ReadState {
 	uint32_t err;                                     /* sticky error flags */
 	uint32_t kh_mask, kh_cnt, kh_ub;                  /* kh_t state of the per-read position hash (persists across rounds) */
 	uint32_t seed_n0;                                 /* seed count as K1 left it: immutable, picks the size class of the first-round sort + chain */
-	uint32_t k3_ticks, k3_vec;                        /* diagnostics: s_memtime ticks and DP vectors the extension kernel spent on this read */
+	uint32_t k3_ticks, k3_vec, k3_fill_ticks, k3_trace_ticks;   /* diagnostics: s_memtime ticks (whole / DP fill / traceback) and DP vectors the extension kernel spent on this read */
 	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
 	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
 };
@@ -946,6 +946,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 	const gaba::Sec tailsec = { 0xfffffffeu, 96, 0, 2, 0 };
 	unsigned long long n_fill = 0, n_trace = 0;
 	unsigned long long cy_fill = 0, cy_leaf = 0, cy_trace = 0;        /* wave cycles spent in the three DP phases (s_memtime) */
+	unsigned long long cy_next = 0;                                  /* ... and in mm_search_load_next */
 	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
 
 	while(true) {
@@ -955,7 +956,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 		if(wi >= a.n_work) { break; }
 		const uint32_t r = (uint32_t)rdfirst((int)a.work[wi]);
 		ReadState *st = &a.st[r];
-		const unsigned long long cy_read0 = __builtin_amdgcn_s_memtime(); const uint32_t vec_read0 = x.n_vec;
+		const unsigned long long cy_read0 = __builtin_amdgcn_s_memtime(); const uint32_t vec_read0 = x.n_vec; const unsigned long long cyf_read0 = cy_fill, cyt_read0 = cy_trace;
 		const uint32_t n_root = (uint32_t)rdfirst((int)st->n_root);
 		/* reads with many chains run several extension trials and are the critical path of the launch (one of them can cost
 		 * three times a wave's fair share): their waves get issue priority so that they move at uncontended speed while the
@@ -1031,6 +1032,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 
 			bool first_iter = true;
 			while(true) {
+				const unsigned long long cy_n0 = __builtin_amdgcn_s_memtime();
 				if(!first_iter) {
 					/* mm_search_load_next (minialign.c:3888-3946) */
 					if(sr.srem == 0) { /* nothing */ }
@@ -1078,6 +1080,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 						}
 					}
 				}
+				cy_next += __builtin_amdgcn_s_memtime() - cy_n0;
 				first_iter = false;
 				if(!(sr.srem > 0 && sr.prem > 0)) { break; }
 
@@ -1214,13 +1217,14 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 			st->kh_mask = kh.mask; st->kh_cnt = kh.cnt; st->kh_ub = kh.ub;
 			st->err |= err;
 			st->k3_ticks += (uint32_t)(__builtin_amdgcn_s_memtime() - cy_read0); st->k3_vec += x.n_vec - vec_read0;
+			st->k3_fill_ticks += (uint32_t)(cy_fill - cyf_read0); st->k3_trace_ticks += (uint32_t)(cy_trace - cyt_read0);
 			if(n_res > 0) { st->done = 1; }
 		}
 	}
 	if(lane == 0) {
 		atomicAdd(&a.stats[2], n_fill); atomicAdd(&a.stats[3], (unsigned long long)x.n_vec); atomicAdd(&a.stats[4], (unsigned long long)x.n_blk);
 		atomicAdd(&a.stats[5], n_trace); atomicAdd(&a.stats[6], (unsigned long long)x.n_tr);
-		atomicAdd(&a.stats[12], cy_fill); atomicAdd(&a.stats[13], cy_leaf); atomicAdd(&a.stats[14], cy_trace);
+		atomicAdd(&a.stats[12], cy_fill); atomicAdd(&a.stats[13], cy_leaf); atomicAdd(&a.stats[14], cy_trace); atomicAdd(&a.stats[11], cy_next);
 		atomicAdd(&a.stats[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
 		atomicMax(&a.stats[9], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));      /* longest-living wave: load balance */
 	}

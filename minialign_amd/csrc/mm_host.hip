@@ -380,6 +380,8 @@ struct mm_align_s {
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
+	mm_align_s *sib = nullptr;             /* second lane: own streams and pools, shares index / reference / DP constants (see mm_batch_run) */
+	bool is_sib = false; int dev = 0;
 	mm_stats_t st; double t_wall0;
 	/* knobs (grown on overflow) */
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
@@ -482,18 +484,33 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
 			CK(hipMemcpy(a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState), hipMemcpyHostToDevice));
 		}
+		uint32_t k3_work_override = 0;
 		{
 			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
 			std::vector<uint32_t> by_len(work);
 			/* (ordering by the chain count, the best predictor of a read's DP work, was tried and is worse: the heaviest reads then run
 			 * under full contention from the start and become the critical path) */
 			if(qlens.size() == n_reads) { std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return qlens[x] > qlens[y]; }); }
+			/* ... except the few reads with by far the most chains (repeats: dozens of extension trials, several times a wave's
+			 * fair share of the DP work): one of them is the critical path of the launch, so they start first.  Moving *all* reads
+			 * into chain-count order is worse (measured): the bulk of moderately heavy reads then crowds the start. */
+			if(by_len.size() >= 256) {
+				std::vector<uint32_t> nr(by_len.size()); for(size_t i = 0; i < by_len.size(); i++) nr[i] = hst[by_len[i]].n_root;
+				std::nth_element(nr.begin(), nr.begin() + (nr.size() - 1 - nr.size() / 64), nr.end());
+				const uint32_t thr = std::max<uint32_t>(nr[nr.size() - 1 - nr.size() / 64], 4);          /* top ~1.5 % */
+				std::stable_partition(by_len.begin(), by_len.end(), [&](uint32_t x) { return hst[x].n_root >= thr; });
+			}
+			if(const char *e = getenv("MM_EXPERIMENT_K3_HEAVY")) {          /* timing experiment only (results incomplete): the N reads with the most chains */
+				std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return hst[x].n_root > hst[y].n_root; });
+				by_len.resize(std::min<size_t>(by_len.size(), (size_t)atoi(e)));
+				k3_work_override = (uint32_t)by_len.size();
+			}
 			CK(hipMemcpyAsync(a->d_work.p, by_len.data(), by_len.size() * 4, hipMemcpyHostToDevice, a->stream));
 			CK(hipStreamSynchronize(a->stream));
 		}
 		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
 		K3Args k3; k3.idx = a->dix; k3.gc = a->gctx->hc; k3.roots = a->gctx->droots; k3.ar_ref = gaba::SeqArena{ a->ref_ar->pk, a->ref_ar->nm }; k3.ar_q = gaba::SeqArena{ a->q_pk.p, a->q_nm.p };
-		k3.in = a->d_in.p; k3.st = a->d_st.p; k3.work = a->d_work.p; k3.n_work = (uint32_t)work.size();
+		k3.in = a->d_in.p; k3.st = a->d_st.p; k3.work = a->d_work.p; k3.n_work = k3_work_override ? k3_work_override : (uint32_t)work.size();
 		k3.seed_pool = a->seed_pool.p; k3.root_pool = a->root_pool.p; k3.slabs = a->slabs.p; k3.slab_bytes = a->slabs.n / a->n_waves;
 		k3.kh_pool = a->kh_pool.p; k3.kh_cap = a->kh_cap; k3.round = round; k3.next_pool = a->next_pool.p; k3.next_cap = a->next_cap;
 		k3.bin_pool = a->bin_pool.p; k3.bin_pool_cap = a->bin_pool.n; k3.bin_top = tops + 3; k3.bin_cap_per_read = a->bin_cap;
@@ -512,6 +529,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		std::vector<uint32_t> nxt;
 		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u)) nxt.push_back(wi);
 		work.swap(nxt);
+		if(getenv("MM_EXPERIMENT_K3_HEAVY")) { break; }
 	}
 	return true;
 }
@@ -703,7 +721,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	a->dix.slot = a->d_slot; a->dix.mask = mi->mask; a->dix.val = a->d_val; a->dix.seq_len = a->d_seq_len; a->dix.seq_off = a->d_seq_off;
 	a->dix.n_seq = (uint32_t)mi->seq.size(); a->dix.k = mi->k; a->dix.w = mi->w; a->dix.n_occ = mi->n_occ;
 	for(int i = 0; i < 4; i++) a->dix.occ[i] = i < (int)mi->n_occ ? mi->occ[i] : 0;
-	hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
+	hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev); a->dev = dev;
 	a->n_waves = (uint32_t)prop.multiProcessorCount * 4 * MM_K3_WAVES_PER_SIMD;       /* persistent waves of the extension kernel */
 	memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms();
 	return a;
@@ -711,8 +729,11 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 extern "C" void mm_align_destroy(mm_align_t *a)
 {
 	if(!a) return;
-	(void)hipFree(a->d_slot); (void)hipFree(a->d_val); (void)hipFree(a->d_seq_len); (void)hipFree(a->d_seq_off);
-	gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
+	if(a->sib) { mm_align_destroy(a->sib); a->sib = nullptr; }
+	if(!a->is_sib) {
+		(void)hipFree(a->d_slot); (void)hipFree(a->d_val); (void)hipFree(a->d_seq_len); (void)hipFree(a->d_seq_off);
+		gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
+	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
@@ -729,8 +750,19 @@ extern "C" void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *
 extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 {
 	a->st.wall_ms = now_ms() - a->t_wall0;
-	if(out) *out = a->st;
-	if(reset) { memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms(); }
+	if(out) {
+		*out = a->st;
+		if(a->sib) {            /* both lanes: counters add up; kernel times add up too (the lanes overlap in wall time) */
+			const mm_stats_t &q = a->sib->st;
+			out->k1_ms += q.k1_ms; out->k2_ms += q.k2_ms; out->k3_ms += q.k3_ms; out->k1_launches += q.k1_launches; out->k2_launches += q.k2_launches; out->k3_launches += q.k3_launches;
+			out->reads += q.reads; out->bases += q.bases; out->minimizers += q.minimizers; out->seeds += q.seeds; out->fills += q.fills; out->vectors += q.vectors; out->blocks += q.blocks;
+			out->traces += q.traces; out->trace_steps += q.trace_steps; out->reruns += q.reruns; out->host_post_ms += q.host_post_ms; out->host_sam_ms += q.host_sam_ms;
+			out->k3_cycles_fill += q.k3_cycles_fill; out->k3_cycles_leaf += q.k3_cycles_leaf; out->k3_cycles_trace += q.k3_cycles_trace; out->k3_cycles_total += q.k3_cycles_total;
+			out->k3_cycles_next += q.k3_cycles_next; out->k3_cycles_max += q.k3_cycles_max;             /* summed over launches; k3_waves stays the per-launch count */
+			out->k2_cycles_sort += q.k2_cycles_sort; out->k2_cycles_chain += q.k2_cycles_chain; out->k2_cycles_total += q.k2_cycles_total; out->k2_reads_hbm += q.k2_reads_hbm;
+		}
+	}
+	if(reset) { memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms(); if(a->sib) { memset(&a->sib->st, 0, sizeof(a->sib->st)); } }
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -743,6 +775,7 @@ struct Batch {
 	std::vector<uint32_t> lens; std::vector<uint64_t> qoff; std::vector<const uint8_t *> seq; std::vector<std::string> names;
 	std::vector<uint32_t> pk, nm; std::vector<ReadIn> in; std::vector<ReadState> hst; std::vector<uint32_t> work;
 	uint64_t scale = 1; bool uploaded = false, ran = false;
+	std::vector<uint32_t> used;            /* the carried reference length each read actually ran with */
 };
 namespace {
 bool batch_upload(mm_align_t *a, Batch &b)
@@ -774,14 +807,12 @@ bool batch_prepare(mm_align_t *a, Batch &b)
 	return batch_upload(a, b);
 }
 /* the hot path over the uploaded batch; returns 0 ok, 1 device pools overflowed (caller grows and retries), -1 error */
-int batch_run_once(mm_align_t *a, Batch &b)
+/* the carried reference length: check what each read ran with (b.used) against the chain of values the reads actually
+ * produce, starting from a->rlen_carry, and re-run the reads it changes until nothing moves.  0 ok, 1 overflow, -1 error */
+int batch_verify_carry(mm_align_t *a, Batch &b)
 {
 	const uint32_t n_reads = b.n;
-	std::vector<ReadState> &hst = b.hst;
-	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return -1;
-	/* the carried reference length: verify the prediction read by read, re-run the reads it changes */
-	std::vector<uint32_t> used(n_reads);
-	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size(); } }
+	std::vector<ReadState> &hst = b.hst; std::vector<uint32_t> &used = b.used;
 	bool overflow = false;
 	for(int iter = 0; iter < 64; iter++) {
 		std::vector<uint32_t> redo, redo_rlen;
@@ -803,7 +834,17 @@ int batch_run_once(mm_align_t *a, Batch &b)
 		if(hipMemcpy(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice) != hipSuccess) return -1;
 		if(!run_rounds(a, n_reads, redo, true, hst, &redo_rlen, b.lens)) return -1;
 	}
-	if(overflow) return 1;
+	return overflow ? 1 : 0;
+}
+int batch_run_once(mm_align_t *a, Batch &b)
+{
+	const uint32_t n_reads = b.n;
+	std::vector<ReadState> &hst = b.hst;
+	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return -1;
+	b.used.assign(n_reads, 0);
+	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size(); } }
+	const int rc = batch_verify_carry(a, b);
+	if(rc != 0) return rc;
 	b.ran = true;
 	return 0;
 }
@@ -826,11 +867,11 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
 	if(const char *fn = getenv("MM_DUMP_READ_COST")) {          /* diagnostics: per-read cost of the extension kernel */
 		std::vector<ReadState> d(n_reads); CK(hipMemcpy(d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost));
-		if(FILE *fp = fopen(fn, "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec); fclose(fp); }
+		if(FILE *fp = fopen(fn, "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks); fclose(fp); }
 	}
 	unsigned long long tops[32]; CK(hipMemcpy(tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
-	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->n_waves;
+	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->n_waves; a->st.k3_cycles_next += tops[19];
 	a->st.k2_cycles_sort += tops[24]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
@@ -898,23 +939,88 @@ extern "C" mm_reads_t *mm_reads_load(char const *fn)
 extern "C" void mm_reads_free(mm_reads_t *r) { delete r; }
 extern "C" uint32_t mm_reads_count(mm_reads_t const *r) { return (uint32_t)r->r.size(); }
 extern "C" uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t n) { uint64_t b = 0; for(uint32_t i = first; i < first + n && i < r->r.size(); i++) b += r->r[i].seq.size(); return b; }
-struct mm_batch_s { Batch b; };
+/*
+ * Two lanes.  A batch of ordinary size is cut in two halves by bases; each half runs the whole K1 -> K2 -> K3 sequence on
+ * its own context (own streams and pools, shared index / reference / DP constants) driven by its own host thread.  The
+ * stages have different limiters (K1 VALU, K2 LDS latency, K3 fill VALU / traceback + tail latency), and every launch
+ * ends in a tail where few wavefronts are left: with two lanes in flight one lane's tails and latency-bound stretches are
+ * filled by the other lane's work.  Results do not depend on the split: the only state reads share is the carried
+ * reference length, which the second lane guesses and batch_verify_carry() then corrects at the seam.
+ */
+struct mm_batch_s { Batch b; Batch h[2]; bool split = false; };
+static mm_align_t *align_lane(mm_align_t *a)
+{
+	if(a->sib) return a->sib;
+	mm_align_t *q = new mm_align_s();
+	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off;
+	q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
+	q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
+	if(hipStreamCreate(&q->stream) != hipSuccess || hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess) { delete q; return NULL; }
+	for(int i = 0; i < 12; i++) { if(hipStreamCreateWithFlags(&q->k2s[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&q->k2e[i], hipEventDisableTiming) != hipSuccess) { delete q; return NULL; } }
+	q->k2s_ok = true;
+	memset(&q->st, 0, sizeof(q->st)); q->t_wall0 = now_ms();
+	a->sib = q;
+	return q;
+}
 extern "C" mm_batch_t *mm_batch_upload(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n)
 {
 	mm_batch_t *h = new mm_batch_s();
-	for(uint32_t i = first; i < first + n && i < r->r.size(); i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); }
+	const uint32_t last = (uint32_t)std::min<uint64_t>((uint64_t)first + n, r->r.size());
+	/* opt-in (MM_TWO_LANES=<minimum reads per batch>): on the bench workload one lane is faster -- the extension launch is
+	 * bound by its single heaviest read (98 of 104 ms), which a second lane only delays */
+	const char *tl = getenv("MM_TWO_LANES");
+	const bool two = tl && last > first && last - first >= (uint32_t)std::max(2, atoi(tl));
+	mm_align_t *lane1 = two ? align_lane(a) : NULL;
+	if(lane1) {
+		uint64_t tot = 0, acc = 0; for(uint32_t i = first; i < last; i++) tot += r->r[i].seq.size();
+		uint32_t cut = first; while(cut < last && acc * 2 < tot) { acc += r->r[cut].seq.size(); cut++; }
+		for(uint32_t i = first; i < last; i++) { Batch &b = h->h[i < cut ? 0 : 1]; b.lens.push_back((uint32_t)r->r[i].seq.size()); b.seq.push_back(r->r[i].seq.data()); b.names.push_back(r->r[i].name); }
+		h->split = true;
+		if(!batch_prepare(a, h->h[0]) || !batch_prepare(lane1, h->h[1])) { delete h; return NULL; }
+		return h;
+	}
+	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); }
 	if(!batch_prepare(a, h->b)) { delete h; return NULL; }
 	return h;
 }
 extern "C" int mm_batch_run(mm_align_t *a, mm_batch_t *h)
 {
-	if(h->b.ran) { if(!batch_upload(a, h->b)) return -1; }        /* a second pass over the same batch starts from clean device state */
-	return batch_run(a, h->b) ? 0 : -1;
+	if(!h->split) {
+		if(h->b.ran) { if(!batch_upload(a, h->b)) return -1; }        /* a second pass over the same batch starts from clean device state */
+		return batch_run(a, h->b) ? 0 : -1;
+	}
+	mm_align_t *q = a->sib;
+	const uint32_t carry_in = a->rlen_carry;
+	bool ok[2] = { false, false };
+	auto lane = [&](int k) {
+		mm_align_t *c = k ? q : a; Batch &b = h->h[k];
+		if(hipSetDevice(a->dev) != hipSuccess) return;
+		if(b.ran && !batch_upload(c, b)) return;
+		if(k) { c->rlen_carry = carry_in; }                        /* the guess: what the first lane started from */
+		ok[k] = batch_run(c, b);
+	};
+	std::thread t1(lane, 1); lane(0); t1.join();
+	if(!ok[0] || !ok[1]) return -1;
+	/* the seam: the value the second half should have started from is the one the first half ends with */
+	uint32_t end0 = carry_in;
+	for(uint32_t i = 0; i < h->h[0].n; i++) { if(h->h[0].hst[i].rid_last != gaba::NIL) end0 = (uint32_t)a->mi->seq[h->h[0].hst[i].rid_last].seq.size(); }
+	if(end0 != carry_in) {
+		q->rlen_carry = end0;
+		if(batch_verify_carry(q, h->h[1]) != 0) { fprintf(stderr, "[minialign_amd] second lane: re-run at the seam failed\n"); return -1; }
+	}
+	return 0;
 }
 extern "C" int mm_batch_finish(mm_align_t *a, mm_batch_t *h, char **sam, uint64_t *sam_len)
 {
 	std::string s;
-	if(!batch_finish(a, h->b, s)) return -1;
+	if(!h->split) { if(!batch_finish(a, h->b, s)) return -1; }
+	else {
+		mm_align_t *q = a->sib;
+		if(!batch_finish(a, h->h[0], s)) return -1;               /* advances a->rlen_carry over the first half */
+		q->rlen_carry = a->rlen_carry;
+		if(!batch_finish(q, h->h[1], s)) return -1;
+		a->rlen_carry = q->rlen_carry;
+	}
 	if(sam) { uint64_t old = *sam ? *sam_len : 0; *sam = (char *)realloc(*sam, old + s.size() + 1); memcpy(*sam + old, s.data(), s.size()); (*sam)[old + s.size()] = 0; *sam_len = old + s.size(); }
 	return 0;
 }

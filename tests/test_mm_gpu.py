@@ -63,3 +63,17 @@ def test_edge_cases_match_reference_golden(preset, fmt, workdir):
     got = _run(CLI, preset, ref, rd)
     want = gzip.open(os.path.join(HERE, 'golden', 'edge_%s_%s.sam.gz' % (preset.replace('.', ''), fmt))).read()
     assert got == want, _first_diff(got, want)
+
+
+def test_two_lane_batches_give_the_same_sam(workdir):
+    """MM_TWO_LANES splits every batch over two device contexts driven by two host threads; the carried reference length is
+    guessed for the second half and corrected at the seam (multi-contig reference: the guess is wrong most of the time)"""
+    s = dict(name='g_lanes', preset='pacbio', genome=(331, 400000, 25, 0.10), reads=(332, 1.5, 'pacbio', 'fa', 3000, 1000))
+    ref, rd = make_inputs(s, workdir)
+    want = _run(CLI, s['preset'], ref, rd)
+    env = dict(os.environ, MM_TWO_LANES='16')
+    r = subprocess.run([CLI, '-x' + s['preset'], ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = _strip_pg(r.stdout)
+    assert got == want, _first_diff(got, want)
+    assert got == _run(os.path.join(M.ROOT, 'oracle', 'ora_minialign'), s['preset'], ref, rd)
