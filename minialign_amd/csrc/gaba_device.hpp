@@ -118,9 +118,11 @@ __device__ __forceinline__ uint32_t fetch_code(const SeqArena *ar, const Sec &s,
 {
 	if(s.arena == 2) { return 4; }
 	uint64_t p = s.off + (s.rev ? (uint64_t)(s.len - 1 - i) : (uint64_t)i);
-	const SeqArena &A = ar[s.arena];
-	uint32_t c = (A.pk[p >> 4] >> (2 * (p & 15))) & 3;
-	uint32_t n = (A.nm[p >> 5] >> (p & 31)) & 1;
+	/* constant indices only: `ar` is a two-element local array of the caller, a variable index would keep it in scratch memory and
+	 * put a dependent scratch load in front of every sequence fetch (two HBM-latency round trips per block instead of one) */
+	const uint32_t *pk = s.arena ? ar[1].pk : ar[0].pk, *nm = s.arena ? ar[1].nm : ar[0].nm;
+	uint32_t c = (pk[p >> 4] >> (2 * (p & 15))) & 3;
+	uint32_t n = (nm[p >> 5] >> (p & 31)) & 1;
 	c = s.rev ? 3 - c : c;                      /* comp_mask_a / compshift_mask_b, gaba.c:852-866 */
 	return n ? 4 : c;
 }
