@@ -74,9 +74,6 @@ def cpu_baseline(ref_fa, reads_fa, workdir, budget_reads):
             'sample': 'first %d reads (%.1f Mb), oracle/ora_minialign (plain-C restatement, single thread), mm_align_seq time only' % (min(k, 300), b2 / 1e6)}
 
 def pmc_traffic(args, world):
-    return None    # the committed PMC passes predate the two-lane launch shape; re-enabled once they are re-collected
-
-def pmc_traffic_from_profile(args, world):
     """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes (same workload only), else None"""
     fn = os.path.join(ROOT, 'profiles', 'round1_c_pmc.json')
     if world != 1 or args.depth != 100.0 or not os.path.exists(fn): return None
@@ -90,6 +87,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=3); ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=float, default=100.0, help='read depth over the 4.64 Mb reference (x100 = BASELINE configs[1])')
     ap.add_argument('--check', action='store_true', help='also verify the SAM of a sample against the CPU oracle')
+    ap.add_argument('--stagger-ms', type=float, default=0.0, help='delay of the second lane at the start of the timed region')
+    ap.add_argument('--inflight', type=int, default=3, choices=(1, 2, 3, 4), help='batches in flight per GPU: consecutive steps go to alternating lanes of the device context and overlap, as the batches of a read stream do (1: strictly one after the other)')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
     import torch
@@ -102,7 +101,7 @@ def main():
     if not os.path.exists(lib):
         sys.path.insert(0, ROOT); import __graft_entry__; __graft_entry__.build()
     L = ctypes.CDLL(lib)
-    for f in ('mm_opt_init', 'mm_idx_gen', 'mm_align_init', 'mm_reads_load', 'mm_batch_upload'): getattr(L, f).restype = ctypes.c_void_p
+    for f in ('mm_opt_init', 'mm_idx_gen', 'mm_align_init', 'mm_reads_load', 'mm_batch_upload', 'mm_batch_upload_lane'): getattr(L, f).restype = ctypes.c_void_p
     L.mm_reads_bases.restype = ctypes.c_uint64
     assert L.mm_set_device(local) == 0, 'no HIP device %d' % local
 
@@ -121,17 +120,32 @@ def main():
     t_index = time.time() - t0
     reads = ctypes.c_void_p(L.mm_reads_load(reads_fa.encode())); assert reads
     n_reads = L.mm_reads_count(reads); bases = L.mm_reads_bases(reads, 0, n_reads)
-    batch = ctypes.c_void_p(L.mm_batch_upload(al, reads, 0, n_reads)); assert batch, 'upload failed'
+    # one copy of the batch per lane; a step = one pass of the hot path over the batch.  With --inflight 2 consecutive steps go to
+    # alternating lanes and overlap (the way consecutive batches of a read stream do); every step still runs K1..K3 completely.
+    batches = [ctypes.c_void_p(L.mm_batch_upload_lane(al, reads, 0, n_reads, ln)) for ln in range(args.inflight)]
+    assert all(batches), 'upload failed'
+    batch = batches[0]
 
     def sync():
         torch.cuda.synchronize()
         if dist: dist.barrier()
-    for _ in range(args.warmup):
-        assert L.mm_batch_run(al, batch) == 0
+    def run_steps(k):
+        if args.inflight == 1:
+            for _ in range(k):
+                assert L.mm_batch_run(al, batch) == 0          # blocks until the last kernel of the step has finished
+            return
+        pending = [False] * args.inflight
+        for i in range(k):
+            ln = i % args.inflight
+            if pending[ln]: assert L.mm_batch_wait(al, batches[ln]) == 0
+            if i == 1 and args.stagger_ms > 0: time.sleep(args.stagger_ms * 1e-3)
+            assert L.mm_batch_run_async(al, batches[ln]) == 0; pending[ln] = True
+        for ln in range(args.inflight):
+            if pending[ln]: assert L.mm_batch_wait(al, batches[ln]) == 0
+    run_steps(args.warmup)
     L.mm_stats(al, None, 1)
     sync(); t0 = time.perf_counter()
-    for _ in range(args.steps):
-        assert L.mm_batch_run(al, batch) == 0          # blocks until the last kernel of the step has finished
+    run_steps(args.steps)
     sync(); dt = time.perf_counter() - t0
     st = Stats(); L.mm_stats(al, ctypes.byref(st), 0)
     if dist:
@@ -159,7 +173,7 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'i8',
             'data': 'synthetic (tools/gensim.c: 4.64 Mb reference with 5 % planted repeats, PBSIM-CLR-like reads 20k+-2k, acc 0.88+-0.07)',
             'config': {'workload': 'E.coli MG1655-size ref x PBSIM-like x%g (%.0f Mb, %d reads) -xpacbio on 1 MI355X per rank' % (args.depth, bases / 1e6, n_reads),
-                       'reads_per_rank': n_reads, 'bases_per_rank': bases, 'parallelism': 'reads sharded, index replicated (no collective)',
+                       'reads_per_rank': n_reads, 'bases_per_rank': bases, 'batches_in_flight': args.inflight, 'parallelism': 'reads sharded, index replicated (no collective)',
                        'kernel_ms_per_step': {'sketch_seed': per_step(st.k1_ms), 'sort_chain': per_step(st.k2_ms), 'extend': per_step(st.k3_ms)},
                        'extend_wave_time_split': {k: getattr(st2, 'k3_cycles_' + k) / max(1, st2.k3_cycles_total) for k in ('fill', 'leaf', 'trace', 'next')},
                        'extend_wave_balance (mean / max lifetime)': st2.k3_cycles_total / max(1, st2.k3_cycles_max * st2.k3_waves),

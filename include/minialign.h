@@ -67,6 +67,11 @@ uint32_t mm_reads_count(mm_reads_t const *r);
 uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t n);
 mm_batch_t *mm_batch_upload(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n);
 int mm_batch_run(mm_align_t *a, mm_batch_t *b);
+/* two batches in flight: upload to lane 0 / 1 (each lane owns streams and pools, the index is shared), start with _run_async, join with
+ * _wait (0 on success).  The launch tail and the latency-bound stages of one batch are then filled by the other batch's work. */
+mm_batch_t *mm_batch_upload_lane(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n, int lane);
+int mm_batch_run_async(mm_align_t *a, mm_batch_t *b);
+int mm_batch_wait(mm_align_t *a, mm_batch_t *b);
 int mm_batch_finish(mm_align_t *a, mm_batch_t *b, char **sam, uint64_t *sam_len);
 void mm_batch_free(mm_batch_t *b);
 int mm_set_device(int dev);

@@ -752,8 +752,8 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 	a->st.wall_ms = now_ms() - a->t_wall0;
 	if(out) {
 		*out = a->st;
-		if(a->sib) {            /* both lanes: counters add up; kernel times add up too (the lanes overlap in wall time) */
-			const mm_stats_t &q = a->sib->st;
+		for(mm_align_t *ln = a->sib; ln; ln = ln->sib) {            /* all lanes: counters add up; kernel times add up too (the lanes overlap in wall time) */
+			const mm_stats_t &q = ln->st;
 			out->k1_ms += q.k1_ms; out->k2_ms += q.k2_ms; out->k3_ms += q.k3_ms; out->k1_launches += q.k1_launches; out->k2_launches += q.k2_launches; out->k3_launches += q.k3_launches;
 			out->reads += q.reads; out->bases += q.bases; out->minimizers += q.minimizers; out->seeds += q.seeds; out->fills += q.fills; out->vectors += q.vectors; out->blocks += q.blocks;
 			out->traces += q.traces; out->trace_steps += q.trace_steps; out->reruns += q.reruns; out->host_post_ms += q.host_post_ms; out->host_sam_ms += q.host_sam_ms;
@@ -762,7 +762,7 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 			out->k2_cycles_sort += q.k2_cycles_sort; out->k2_cycles_chain += q.k2_cycles_chain; out->k2_cycles_total += q.k2_cycles_total; out->k2_reads_hbm += q.k2_reads_hbm;
 		}
 	}
-	if(reset) { memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms(); if(a->sib) { memset(&a->sib->st, 0, sizeof(a->sib->st)); } }
+	if(reset) { memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms(); for(mm_align_t *ln = a->sib; ln; ln = ln->sib) { memset(&ln->st, 0, sizeof(ln->st)); } }
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -947,10 +947,11 @@ extern "C" uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t
  * filled by the other lane's work.  Results do not depend on the split: the only state reads share is the carried
  * reference length, which the second lane guesses and batch_verify_carry() then corrects at the seam.
  */
-struct mm_batch_s { Batch b; Batch h[2]; bool split = false; };
+struct mm_batch_s { Batch b; Batch h[2]; bool split = false; mm_align_t *ctx = nullptr; std::thread th; int rc = 0; bool running = false; };
 static mm_align_t *align_lane(mm_align_t *a)
 {
 	if(a->sib) return a->sib;
+	while(a->is_sib && false) {}
 	mm_align_t *q = new mm_align_s();
 	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off;
 	q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
@@ -980,14 +981,32 @@ extern "C" mm_batch_t *mm_batch_upload(mm_align_t *a, mm_reads_t const *r, uint3
 		return h;
 	}
 	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); }
+	h->ctx = a;
 	if(!batch_prepare(a, h->b)) { delete h; return NULL; }
+	return h;
+}
+/* the same on the second lane of the context (own streams and pools): lets a caller keep two batches in flight, see
+ * mm_batch_run_async.  Batches on different lanes do not see each other's carried reference length. */
+extern "C" mm_batch_t *mm_batch_upload_lane(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n, int lane)
+{
+	if(lane == 0) return mm_batch_upload(a, r, first, n);
+	if(lane < 0 || lane > 7) return NULL;
+	mm_align_t *q = a;
+	for(int i = 0; i < lane && q; i++) { q = align_lane(q); }          /* lanes form a chain off the primary context */
+	if(!q) return NULL;
+	mm_batch_t *h = new mm_batch_s();
+	const uint32_t last = (uint32_t)std::min<uint64_t>((uint64_t)first + n, r->r.size());
+	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); }
+	h->ctx = q;
+	if(!batch_prepare(q, h->b)) { delete h; return NULL; }
 	return h;
 }
 extern "C" int mm_batch_run(mm_align_t *a, mm_batch_t *h)
 {
 	if(!h->split) {
-		if(h->b.ran) { if(!batch_upload(a, h->b)) return -1; }        /* a second pass over the same batch starts from clean device state */
-		return batch_run(a, h->b) ? 0 : -1;
+		mm_align_t *c = h->ctx ? h->ctx : a;
+		if(h->b.ran) { if(!batch_upload(c, h->b)) return -1; }        /* a second pass over the same batch starts from clean device state */
+		return batch_run(c, h->b) ? 0 : -1;
 	}
 	mm_align_t *q = a->sib;
 	const uint32_t carry_in = a->rlen_carry;
@@ -1013,7 +1032,7 @@ extern "C" int mm_batch_run(mm_align_t *a, mm_batch_t *h)
 extern "C" int mm_batch_finish(mm_align_t *a, mm_batch_t *h, char **sam, uint64_t *sam_len)
 {
 	std::string s;
-	if(!h->split) { if(!batch_finish(a, h->b, s)) return -1; }
+	if(!h->split) { if(!batch_finish(h->ctx ? h->ctx : a, h->b, s)) return -1; }
 	else {
 		mm_align_t *q = a->sib;
 		if(!batch_finish(a, h->h[0], s)) return -1;               /* advances a->rlen_carry over the first half */
@@ -1024,7 +1043,23 @@ extern "C" int mm_batch_finish(mm_align_t *a, mm_batch_t *h, char **sam, uint64_
 	if(sam) { uint64_t old = *sam ? *sam_len : 0; *sam = (char *)realloc(*sam, old + s.size() + 1); memcpy(*sam + old, s.data(), s.size()); (*sam)[old + s.size()] = 0; *sam_len = old + s.size(); }
 	return 0;
 }
-extern "C" void mm_batch_free(mm_batch_t *h) { delete h; }
+/* start the hot path of a batch on a host thread of its own and return; mm_batch_wait joins it (0 ok).  Two batches uploaded to
+ * different lanes can be in flight together: the launch tail and the latency-bound stages of one are filled by the other. */
+extern "C" int mm_batch_run_async(mm_align_t *a, mm_batch_t *h)
+{
+	if(h->running) return -1;
+	h->running = true; h->rc = -1;
+	h->th = std::thread([a, h]() { if(hipSetDevice(a->dev) != hipSuccess) { h->rc = -1; return; } h->rc = mm_batch_run(a, h); });
+	return 0;
+}
+extern "C" int mm_batch_wait(mm_align_t *a, mm_batch_t *h)
+{
+	(void)a;
+	if(!h->running) return 0;
+	h->th.join(); h->running = false;
+	return h->rc;
+}
+extern "C" void mm_batch_free(mm_batch_t *h) { if(h && h->running) { h->th.join(); } delete h; }
 extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
 
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
