@@ -395,6 +395,9 @@ struct BatchOut {                       /* host copies of what post-map / SAM ne
 	std::vector<gaba::Segment> seg; std::vector<uint32_t> path;
 };
 
+/* copies / memsets of the run path go to the lane's own (non-blocking) stream and wait on that stream only: the legacy default
+ * stream would serialise every lane against every other */
+#define CPY(_a, _dst, _src, _n, _kind) do { CK(hipMemcpyAsync((_dst), (_src), (_n), (_kind), (_a)->stream)); CK(hipStreamSynchronize((_a)->stream)); } while(0)
 #define CK(_e) do { hipError_t _r = (_e); if(_r != hipSuccess) { fprintf(stderr, "[minialign_amd] HIP error %s at %s:%d\n", hipGetErrorString(_r), __FILE__, __LINE__); return false; } } while(0)
 
 /* run K1..K3 over `work` (indices into the batch) with rlen_in already stored in d_st[].rlen */
@@ -472,7 +475,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		if(round == 0) {
 			/* seed the carried reference-length state (see ReadIn.rlen_in): either given exactly (re-runs), or predicted from
 			 * the chain lists: read i starts with the length of the last reference read i - 1 loads */
-			CK(hipMemcpy(hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost));
+			CPY(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
 			if(rlen_fixed) { for(size_t i = 0; i < work.size(); i++) hst[work[i]].rlen = (*rlen_fixed)[i]; }
 			else {
 				uint32_t cur = a->rlen_carry;
@@ -482,7 +485,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				}
 			}
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
-			CK(hipMemcpy(a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState), hipMemcpyHostToDevice));
+			CPY(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState), hipMemcpyHostToDevice);
 		}
 		uint32_t k3_work_override = 0;
 		{
@@ -525,7 +528,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
-		CK(hipMemcpy(hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost));
+		CPY(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
 		std::vector<uint32_t> nxt;
 		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u)) nxt.push_back(wi);
 		work.swap(nxt);
@@ -698,7 +701,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	/* mcoef / xcoef: both accumulate score_matrix[0] in the reference (minialign.c:4676-4681); kept */
 	double mc = 0, xc = 0; for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 3)) mc += o->p.score_matrix[0]; else xc += o->p.score_matrix[0]; }
 	a->mcoef = mc / 4.0; a->xcoef = xc / 12.0;
-	if(hipStreamCreate(&a->stream) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) { delete a; return NULL; }
+	if(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) { delete a; return NULL; }
 	for(int i = 0; i < 12; i++) { if(hipStreamCreateWithFlags(&a->k2s[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) { delete a; return NULL; } }
 	a->k2s_ok = true;
 	/* reference: one arena, per-sequence offsets */
@@ -790,10 +793,10 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		/* unmappable reads are skipped outright (minialign.c:4434) */
 		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
 	}
-	CK(hipMemcpy(a->q_pk.p, b.pk.data(), b.pk.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(a->q_nm.p, b.nm.data(), b.nm.size() * 4, hipMemcpyHostToDevice));
-	CK(hipMemcpy(a->d_in.p, b.in.data(), b.n * sizeof(ReadIn), hipMemcpyHostToDevice));
-	CK(hipMemcpy(a->d_st.p, b.hst.data(), b.n * sizeof(ReadState), hipMemcpyHostToDevice));
-	CK(hipMemset(a->d_tops.p, 0, 32 * 8));
+	CPY(a, a->q_pk.p, b.pk.data(), b.pk.size() * 4, hipMemcpyHostToDevice); CPY(a, a->q_nm.p, b.nm.data(), b.nm.size() * 4, hipMemcpyHostToDevice);
+	CPY(a, a->d_in.p, b.in.data(), b.n * sizeof(ReadIn), hipMemcpyHostToDevice);
+	CPY(a, a->d_st.p, b.hst.data(), b.n * sizeof(ReadState), hipMemcpyHostToDevice);
+	CK(hipMemsetAsync(a->d_tops.p, 0, 32 * 8, a->stream)); CK(hipStreamSynchronize(a->stream));
 	b.uploaded = true; b.ran = false;
 	return true;
 }
@@ -831,7 +834,7 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 			hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL;
 			used[i] = redo_rlen[j];
 		}
-		if(hipMemcpy(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice) != hipSuccess) return -1;
+		if(hipMemcpyAsync(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice, a->stream) != hipSuccess || hipStreamSynchronize(a->stream) != hipSuccess) return -1;
 		if(!run_rounds(a, n_reads, redo, true, hst, &redo_rlen, b.lens)) return -1;
 	}
 	return overflow ? 1 : 0;
@@ -866,10 +869,10 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
 	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
 	if(const char *fn = getenv("MM_DUMP_READ_COST")) {          /* diagnostics: per-read cost of the extension kernel */
-		std::vector<ReadState> d(n_reads); CK(hipMemcpy(d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost));
+		std::vector<ReadState> d(n_reads); CPY(a, d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
 		if(FILE *fp = fopen(fn, "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks); fclose(fp); }
 	}
-	unsigned long long tops[32]; CK(hipMemcpy(tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost));
+	unsigned long long tops[32]; CPY(a, tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
 	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->n_waves; a->st.k3_cycles_next += tops[19];
 	a->st.k2_cycles_sort += tops[24]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26]; a->st.k2_reads_hbm += tops[27];
@@ -877,11 +880,11 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 	double t0 = now_ms();
 	std::vector<Root> root(std::max<uint64_t>(tops[2], 1)); std::vector<uint64_t> bin(std::max<uint64_t>(tops[3], 1)); std::vector<AlnRec> aln(std::max<uint64_t>(tops[4], 1));
 	std::vector<gaba::Segment> seg(std::max<uint64_t>(tops[5], 1)); std::vector<uint32_t> path(std::max<uint64_t>(tops[6], 2) + 8);
-	CK(hipMemcpy(root.data(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost));
-	CK(hipMemcpy(bin.data(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost));
-	CK(hipMemcpy(aln.data(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost));
-	CK(hipMemcpy(seg.data(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost));
-	CK(hipMemcpy(path.data(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost));
+	CPY(a, root.data(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost);
+	CPY(a, bin.data(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost);
+	CPY(a, aln.data(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost);
+	CPY(a, seg.data(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost);
+	CPY(a, path.data(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost);
 	double t1 = now_ms();
 	/* post-map and SAM text are per read and independent: host threads take contiguous spans, the pieces are joined in input
 	 * order (mm_align_drain keeps the same order with its heap, minialign.c:4633-4645) */
@@ -956,7 +959,7 @@ static mm_align_t *align_lane(mm_align_t *a)
 	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off;
 	q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
 	q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
-	if(hipStreamCreate(&q->stream) != hipSuccess || hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess) { delete q; return NULL; }
+	if(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess) { delete q; return NULL; }
 	for(int i = 0; i < 12; i++) { if(hipStreamCreateWithFlags(&q->k2s[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&q->k2e[i], hipEventDisableTiming) != hipSuccess) { delete q; return NULL; } }
 	q->k2s_ok = true;
 	memset(&q->st, 0, sizeof(q->st)); q->t_wall0 = now_ms();
