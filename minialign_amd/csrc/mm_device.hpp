@@ -143,10 +143,28 @@ __global__ void __launch_bounds__(256) mm_sketch_seed_kernel(K1Args a)
 				 * influence the registers at p (one base before the window leaves one bit behind in k1) */
 				uint64_t k0 = 0, k1 = 0;
 				uint32_t start = p >= k ? p - k : 0;
-				for(uint32_t j = start; j <= p; j++) {
-					uint64_t c = q_code(a.qar, q_off + j);
-					k0 = (k0 << 2 | c) & kmask;
-					k1 = (k1 >> 2) | ((3ull ^ c) << (2 * (k - 1)));
+				/* without an N among those k + 1 bases the two registers are plain functions of the k packed bases ending at p:
+				 * k1 = their complement in array order, k0 = the same 2-bit groups in reverse order -- two word loads instead of
+				 * replaying the recurrence base by base (the replay stays for windows that contain an N, and for k > 16) */
+				bool plain = false;
+				if(k <= 16) {
+					const uint64_t nb = q_off + start, nn = (uint64_t)(p - start + 1);                    /* N bits of bases [start, p] */
+					const uint64_t nw = (uint64_t)a.qar.nm[nb >> 5] | ((uint64_t)a.qar.nm[(nb >> 5) + 1] << 32);
+					plain = ((nw >> (nb & 31)) & ((1ull << nn) - 1)) == 0;
+				}
+				if(plain) {
+					const uint64_t fb = q_off + p - (k - 1);
+					const uint64_t ww = (uint64_t)a.qar.pk[fb >> 4] | ((uint64_t)a.qar.pk[(fb >> 4) + 1] << 32);
+					const uint64_t W = (ww >> (2 * (fb & 15))) & kmask;
+					k1 = ~W & kmask;
+					uint64_t rv = __brevll(W) >> (64 - 2 * k);                                            /* bit i -> bit 2k - 1 - i */
+					k0 = ((rv >> 1) & 0x5555555555555555ull) | ((rv & 0x5555555555555555ull) << 1);      /* ... and the two bits of each base back in order */
+				} else {
+					for(uint32_t j = start; j <= p; j++) {
+						uint64_t c = q_code(a.qar, q_off + j);
+						k0 = (k0 << 2 | c) & kmask;
+						k1 = (k1 >> 2) | ((3ull ^ c) << (2 * (k - 1)));
+					}
 				}
 				uint64_t km = k0 < k1 ? k0 : k1, kx = k0 < k1 ? k1 : k0, m = k0 < k1 ? 0 : 0x80;
 				/* hash64 (minialign.c:2353): a CRC32C seeded with the low word of its own input is zero unless the high word is set */
