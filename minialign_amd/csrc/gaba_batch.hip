@@ -31,7 +31,7 @@ gaba_extend_batch_kernel(const Consts c, const uint8_t *roots, SeqArena ar_a, Se
 {
 	SeqArena ar[2] = { ar_a, ar_b };
 	Ctx x;
-	x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 	uint32_t wave = (uint32_t)rdfirst((int)(blockIdx.x * 4 + threadIdx.x / 64));
 	x.slab = slabs + (uint64_t)wave * slab_bytes;
 	x.cap = (uint32_t)slab_bytes; x.top = SLAB_HEAD;
@@ -52,7 +52,7 @@ gaba_extend_batch_kernel(const Consts c, const uint8_t *roots, SeqArena ar_a, Se
 		uint32_t apos = (uint32_t)rdfirst((int)job.apos), bpos = (uint32_t)rdfirst((int)job.bpos);
 		int bw = rdfirst((int)job.bw_idx); bool do_trace = rdfirst((int)job.do_trace) != 0;
 		gaba_xresult_t *r = &res[j];
-		x.err = 0;
+		x.err = 0; x.no_trace = !do_trace;          /* no traceback requested: the masks are never read */
 		dp_flush(x);
 
 		/* mm_extend_core call pattern (minialign.c:4075-4112), recording every fill */
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(64) gaba_scalar_fill_kernel(const Consts c, Se
 	uint32_t prev_tail, int bw_idx, Sec sa, uint32_t apos, Sec sb, uint32_t bpos, uint32_t pridx, ScalarOut *out)
 {
 	SeqArena ar[2] = { ar_a, ar_b };
-	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 	x.slab = slab; x.cap = cap; x.top = top;
 	const uint32_t f = dp_fill_any(x, prev_tail, bw_idx, sa, apos, sb, bpos, pridx);
 	if(x.lane == 0) { out->tail = f; out->top = x.top; out->err = x.err; out->f = tail_at(x, f)->f; }
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(64) gaba_scalar_search_kernel(const Consts c, 
 	uint32_t tail, ScalarOut *out)
 {
 	SeqArena ar[2] = { ar_a, ar_b };
-	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 	x.slab = slab; x.cap = cap; x.top = top;
 	Leaf lf;
 	const PosPair pp = dp_search_max(x, tail, lf);
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(64) gaba_scalar_trace_kernel(const Consts c, S
 	uint32_t tail, uint32_t *path, uint64_t path_words, Segment *seg, uint32_t max_seg, ScalarOut *out)
 {
 	SeqArena ar[2] = { ar_a, ar_b };
-	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	Ctx x; x.c = c; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 	x.slab = slab; x.cap = cap; x.top = top;
 	const AlnOut ao = dp_trace(x, tail, path, path_words, seg, max_seg);
 	if(x.lane == 0) { out->ao = ao; out->top = x.top; out->err = x.err; }

@@ -170,6 +170,7 @@ struct Ctx {                 /* everything a device routine needs */
 	uint32_t top, cap;       /* bump pointer / capacity (bytes) */
 	int lane;
 	int err;                 /* sticky: 1 = slab exhausted */
+	bool no_trace;           /* the fills of this call sequence will only be searched for their maximum, never walked back: skip the traceback masks */
 	uint32_t n_vec, n_blk, n_tr;   /* work counters (uniform): DP vectors, blocks stored, traceback steps */
 };
 
@@ -334,6 +335,16 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
 	"v_addc_co_u32 %[mf], vcc, %[mf], %[mf], %[C]\n\t" \
 	"v_add_u32 %[delta], %[delta], %[t]\n\t" \
 	"v_sub_i32 %[drop], %[drop], %[t] clamp\n\t"
+/* the same without the traceback bit columns (a fill that is only searched for its maximum: minialign's downward pass) */
+#define GABA_CORE_NOTRACE(DH, DV, DE, DF, UPD, TT) \
+	"v_max_i32 %[de], %[dea], %[t]\n\t" \
+	"v_max_i32 %[df], %[dfa], %[t]\n\t" \
+	"v_add_u32 %[de], %[de], " DH "\n\t" \
+	"v_sub_u32 %[df], %[df], " DV "\n\t" \
+	UPD \
+	TT \
+	"v_add_u32 %[delta], %[delta], %[t]\n\t" \
+	"v_sub_i32 %[drop], %[drop], %[t] clamp\n\t"
 #define GABA_UPD_RIGHT  "v_sub_u32 %[dh], %[dv], %[t]\n\t" "v_add_u32 %[dv], %[x0], %[t]\n\t"
 #define GABA_UPD_DOWN   "v_add_u32 %[dv], %[dh], %[t]\n\t" "v_sub_u32 %[dh], %[x0], %[t]\n\t"
 #define GABA_TT_RIGHT   "v_sub_u32 %[t], %[ofsh], %[dh]\n\t"
@@ -392,27 +403,29 @@ __device__ __forceinline__ StepK step_consts(const Consts &c, int W)
  * sits three instructions ahead of the v_writelane that consumes its SGPR).  b.delta / b.drop are in the << 24 domain.
  * Returns t << 24 (the per-lane score increment), final >= 4 instructions before the block ends, so a v_readlane may follow.
  */
-template<int MODEL, bool WIDE, bool FAST>
+template<int MODEL, bool WIDE, bool FAST, bool TRACE = true>
 __device__ __forceinline__ int step(const StepK &k, Band &b, int look, int down, int ai, int bi)
 {
 	int nb, s, t, t1, t2, dfh, dfv, dea, dfa, x0, x1; uint64_t A, B, C, D;
+	#define GABA_EMIT(_pre, _head, _core) asm volatile(GABA_STEP(_pre, _head, _core) GABA_STEP_OPERANDS)
 	if(MODEL == MODEL_COMBINED) {
-		if(FAST) {
-			if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_HEAD_COMBINED_FAST, GABA_CORE_COMBINED) GABA_STEP_OPERANDS); }
-			else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_HEAD_COMBINED_FAST, GABA_CORE_COMBINED) GABA_STEP_OPERANDS); }
+		if(TRACE) {
+			if(FAST) { if(WIDE) { GABA_EMIT(GABA_PRE_DOWN_WIDE, GABA_HEAD_COMBINED_FAST, GABA_CORE_COMBINED); } else { GABA_EMIT(GABA_PRE_DOWN_NARROW, GABA_HEAD_COMBINED_FAST, GABA_CORE_COMBINED); } }
+			else { if(WIDE) { GABA_EMIT(GABA_PRE_DOWN_WIDE, GABA_HEAD_COMBINED, GABA_CORE_COMBINED); } else { GABA_EMIT(GABA_PRE_DOWN_NARROW, GABA_HEAD_COMBINED, GABA_CORE_COMBINED); } }
 		} else {
-			if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_HEAD_COMBINED, GABA_CORE_COMBINED) GABA_STEP_OPERANDS); }
-			else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_HEAD_COMBINED, GABA_CORE_COMBINED) GABA_STEP_OPERANDS); }
+			if(FAST) { if(WIDE) { GABA_EMIT(GABA_PRE_DOWN_WIDE, GABA_HEAD_COMBINED_FAST, GABA_CORE_NOTRACE); } else { GABA_EMIT(GABA_PRE_DOWN_NARROW, GABA_HEAD_COMBINED_FAST, GABA_CORE_NOTRACE); } }
+			else { if(WIDE) { GABA_EMIT(GABA_PRE_DOWN_WIDE, GABA_HEAD_COMBINED, GABA_CORE_NOTRACE); } else { GABA_EMIT(GABA_PRE_DOWN_NARROW, GABA_HEAD_COMBINED, GABA_CORE_NOTRACE); } }
 		}
 	} else {
-		if(FAST) {
-			if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_HEAD_AFFINE_FAST, GABA_CORE_AFFINE) GABA_STEP_OPERANDS); }
-			else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_HEAD_AFFINE_FAST, GABA_CORE_AFFINE) GABA_STEP_OPERANDS); }
+		if(TRACE) {
+			if(FAST) { if(WIDE) { GABA_EMIT(GABA_PRE_DOWN_WIDE, GABA_HEAD_AFFINE_FAST, GABA_CORE_AFFINE); } else { GABA_EMIT(GABA_PRE_DOWN_NARROW, GABA_HEAD_AFFINE_FAST, GABA_CORE_AFFINE); } }
+			else { if(WIDE) { GABA_EMIT(GABA_PRE_DOWN_WIDE, GABA_HEAD_AFFINE, GABA_CORE_AFFINE); } else { GABA_EMIT(GABA_PRE_DOWN_NARROW, GABA_HEAD_AFFINE, GABA_CORE_AFFINE); } }
 		} else {
-			if(WIDE) { asm volatile(GABA_STEP(GABA_PRE_DOWN_WIDE, GABA_HEAD_AFFINE, GABA_CORE_AFFINE) GABA_STEP_OPERANDS); }
-			else { asm volatile(GABA_STEP(GABA_PRE_DOWN_NARROW, GABA_HEAD_AFFINE, GABA_CORE_AFFINE) GABA_STEP_OPERANDS); }
+			if(FAST) { if(WIDE) { GABA_EMIT(GABA_PRE_DOWN_WIDE, GABA_HEAD_AFFINE_FAST, GABA_CORE_NOTRACE); } else { GABA_EMIT(GABA_PRE_DOWN_NARROW, GABA_HEAD_AFFINE_FAST, GABA_CORE_NOTRACE); } }
+			else { if(WIDE) { GABA_EMIT(GABA_PRE_DOWN_WIDE, GABA_HEAD_AFFINE, GABA_CORE_NOTRACE); } else { GABA_EMIT(GABA_PRE_DOWN_NARROW, GABA_HEAD_AFFINE, GABA_CORE_NOTRACE); } }
 		}
 	}
+	#undef GABA_EMIT
 	return t;
 }
 /* window encodings of the fast lookup.  a side: the score row of a base code (0..3, 4 = N); b side: the v_perm selector of an
@@ -460,7 +473,7 @@ __device__ __forceinline__ void fetch_look(Ctx &x, Work &w, FillState &f, uint32
 }
 
 /* _fill_store_context (gaba.c:1734-1778) */
-__device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uint32_t blk_off, uint32_t cnt)
+__device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uint32_t blk_off, uint32_t cnt, bool trace = true)
 {
 	const Consts &c = x.c;
 	Blk *p = blk_at(x, blk_off);
@@ -469,8 +482,10 @@ __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uin
 	/* left-align the per-lane bit columns: vector k of the block -> bit (31 - k) */
 	uint32_t sh = cnt == 0 ? 0 : (uint32_t)(BLK - cnt);
 	bool act = l < W;
-	p->m[0][l] = act ? b.mh << sh : 0; p->m[1][l] = act ? b.mv << sh : 0;
-	p->m[2][l] = act ? b.me << sh : 0; p->m[3][l] = act ? b.mf << sh : 0;
+	if(trace) {              /* 1 KiB of the block; left unwritten when nobody will walk it */
+		p->m[0][l] = act ? b.mh << sh : 0; p->m[1][l] = act ? b.mv << sh : 0;
+		p->m[2][l] = act ? b.me << sh : 0; p->m[3][l] = act ? b.mf << sh : 0;
+	}
 	p->diff[l] = ((uint32_t)b.dh >> 24) | (((uint32_t)b.dv >> 16) & 0xff00u) | (((uint32_t)b.de >> 8) & 0xff0000u) | ((uint32_t)b.df & 0xff000000u);
 	b.delta >>= 24; b.drop >>= 24;               /* back to plain sign-extended int8 */
 
@@ -499,7 +514,7 @@ __device__ __forceinline__ void store_context(Ctx &x, Work &w, FillState &f, uin
 
 /* one block of up to BLK vectors.  bounded = per-vector sequence-end tests (fill_cap_seq_bounded, gaba.c:1925-1975).
  * Returns the number of vectors filled. */
-template<int MODEL, bool WIDE, bool FAST, bool bounded>
+template<int MODEL, bool WIDE, bool FAST, bool bounded, bool TRACE>
 __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool cont)
 {
 	const Consts &c = x.c;
@@ -533,7 +548,7 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 			if((ta | tb | (ta + tb + prem)) < 0) { break; }
 		}
 		dmask = (dmask << 1) + down;
-		const int t = step<MODEL, WIDE, FAST>(sk, f.b, look, (int)down, (int)ai, (int)bi);
+		const int t = step<MODEL, WIDE, FAST, TRACE>(sk, f.b, look, (int)down, (int)ai, (int)bi);
 		bi += down;
 		dacc += (rdlane(t, 0) >> 24) - (rdlane(t, sk.wm1) >> 24);   /* _dir_update, gaba.c:761 (t sits in the top byte) */
 	}
@@ -549,7 +564,7 @@ __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, 
 	w.pridx -= k;
 	x.n_vec += k; x.n_blk += 1;
 	if(k != 0 && k != BLK) { w.dmask <<= (BLK - k); }              /* _dir_adjust_remainder, gaba.c:769 */
-	store_context(x, w, f, blk_off, k);
+	store_context(x, w, f, blk_off, k, TRACE);
 	return k;
 }
 
@@ -562,11 +577,13 @@ __device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, ui
 	 * encoding cannot express: blocks that still see them take the general lookup (the first one or two after a root) */
 	const bool special = __ballot(x.lane < w.W && (f.b.ach > 4 || ((f.b.bch & 3) != 0 && f.b.bch != 2))) != 0;
 	const bool wide = w.W == 64, fast = x.c.fast_score != 0 && !special;
-	#define GABA_PICK(_m) \
-		( wide ? (fast ? fill_block_t<_m, true, true, bounded>(x, w, f, prev_off, blk_off, cont) : fill_block_t<_m, true, false, bounded>(x, w, f, prev_off, blk_off, cont)) \
-		       : (fast ? fill_block_t<_m, false, true, bounded>(x, w, f, prev_off, blk_off, cont) : fill_block_t<_m, false, false, bounded>(x, w, f, prev_off, blk_off, cont)) )
+	#define GABA_PICK2(_m, _tr) \
+		( wide ? (fast ? fill_block_t<_m, true, true, bounded, _tr>(x, w, f, prev_off, blk_off, cont) : fill_block_t<_m, true, false, bounded, _tr>(x, w, f, prev_off, blk_off, cont)) \
+		       : (fast ? fill_block_t<_m, false, true, bounded, _tr>(x, w, f, prev_off, blk_off, cont) : fill_block_t<_m, false, false, bounded, _tr>(x, w, f, prev_off, blk_off, cont)) )
+	#define GABA_PICK(_m) ( x.no_trace ? GABA_PICK2(_m, false) : GABA_PICK2(_m, true) )
 	if(x.c.model == MODEL_COMBINED) { return GABA_PICK(MODEL_COMBINED); }
 	return GABA_PICK(MODEL_AFFINE);
+	#undef GABA_PICK2
 	#undef GABA_PICK
 }
 

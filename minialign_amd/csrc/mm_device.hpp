@@ -905,7 +905,7 @@ __device__ __forceinline__ void dp_ctx_open(gaba::Ctx &x, gaba::SeqArena *ar, co
 	ar[0].pk = (const uint32_t *)rdfirst64((uint64_t)in.ar0.pk); ar[0].nm = (const uint32_t *)rdfirst64((uint64_t)in.ar0.nm);
 	ar[1].pk = (const uint32_t *)rdfirst64((uint64_t)in.ar1.pk); ar[1].nm = (const uint32_t *)rdfirst64((uint64_t)in.ar1.nm);
 	x.ar = ar; x.slab = (uint8_t *)rdfirst64((uint64_t)in.slab); x.top = (uint32_t)rdfirst((int)in.top); x.cap = (uint32_t)rdfirst((int)in.cap);
-	x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 }
 __device__ __forceinline__ gaba::Sec sec_uniform(const gaba::Sec &s)
 {
@@ -913,9 +913,10 @@ __device__ __forceinline__ gaba::Sec sec_uniform(const gaba::Sec &s)
 	r.arena = (uint32_t)rdfirst((int)s.arena); r.rev = (uint32_t)rdfirst((int)s.rev); return r;
 }
 struct ExtOut { DpOut d; uint32_t m; int64_t mmax; uint32_t n_fill; };
-__device__ __attribute__((noinline)) ExtOut k3_extend_core(DpIn in, int bw, gaba::Sec ca, uint32_t apos, gaba::Sec cb, uint32_t bpos)
+__device__ __attribute__((noinline)) ExtOut k3_extend_core(DpIn in, int bw, gaba::Sec ca, uint32_t apos, gaba::Sec cb, uint32_t bpos, int no_trace)
 {
 	gaba::Ctx x; gaba::SeqArena ar[2]; dp_ctx_open(x, ar, in);
+	x.no_trace = rdfirst(no_trace) != 0;
 	const gaba::Sec tailsec = { 0xfffffffeu, 96, 0, 2, 0 };
 	ExtOut o; o.n_fill = 0;
 	o.m = gaba::extend_core(x, rdfirst(bw), sec_uniform(ca), (uint32_t)rdfirst((int)apos), sec_uniform(cb), (uint32_t)rdfirst((int)bpos), tailsec, o.mmax, o.n_fill);
@@ -952,7 +953,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 {
 	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
 	gaba::Ctx x;
-	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.n_vec = x.n_blk = x.n_tr = 0;
+	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 	const int lane = x.lane;
 	uint32_t wave = (uint32_t)rdfirst((int)(blockIdx.x * 4 + threadIdx.x / 64));
 	x.slab = a.slabs + (uint64_t)wave * a.slab_bytes; x.cap = (uint32_t)a.slab_bytes; x.top = gaba::SLAB_HEAD;
@@ -1115,7 +1116,8 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 					uint32_t sa = pass == 0 ? sr.cp_a : rlen - sr.tp_a, sb = pass == 0 ? sr.cp_b : qlen - sr.tp_b;
 					DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
 					const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
-					ExtOut eo = k3_extend_core(din, bw, ca, sa, cb, sb);
+					/* the downward pass is only searched for its maximum (the walk-back runs on the upward pass): no traceback masks */
+					ExtOut eo = k3_extend_core(din, bw, ca, sa, cb, sb, pass == 0);
 					const unsigned long long cy1 = __builtin_amdgcn_s_memtime(); cy_fill += cy1 - cy0;
 					x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk);
 					m = (uint32_t)rdfirst((int)eo.m); mmax = (int64_t)rdfirst64((uint64_t)eo.mmax); n_fill += (uint32_t)rdfirst((int)eo.n_fill);
