@@ -42,6 +42,9 @@ def test_sam_matches_golden(s, workdir):
     dict(name='g_multi', preset='pacbio', genome=(301, 600000, 30, 0.10), reads=(302, 1.0, 'pacbio', 'fa', 4000, 1500)),
     dict(name='g_rep', preset='pacbio', genome=(311, 250000, 2, 0.50), reads=(312, 1.0, 'pacbio', 'fa', 5000, 2000)),
     dict(name='g_ont', preset='ont.1dsq', genome=(321, 500000, 6, 0.10), reads=(322, 1.0, 'ont', 'fa')),
+    # the shape of BASELINE configs[2] (dm6: many contigs) scaled down: 300 contigs, the carried reference length changes all the time
+    dict(name='g_dm6like', preset='pacbio', genome=(341, 12000000, 300, 0.08), reads=(342, 0.5, 'pacbio', 'fa', 6000, 2000)),
+    dict(name='g_dm6like_ont', preset='ont.1dsq', genome=(351, 6000000, 150, 0.08), reads=(352, 0.5, 'ont', 'fa')),
 ], ids=lambda s: s['name'])
 def test_sam_matches_oracle(s, workdir):
     ref, rd = make_inputs(s, workdir)
