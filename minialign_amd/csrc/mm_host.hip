@@ -523,6 +523,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.tglen = a->tglen; k3.mcoef = a->mcoef; k3.min_ratio = a->o.min_ratio; k3.min_score = a->o.min_score;
 		k3.counter = (uint32_t *)(tops + 16); k3.stats = tops + 8;
 		uint32_t waves = std::min<uint32_t>(a->n_waves, (uint32_t)((work.size() + 3) & ~3ull));
+		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* leave wave slots to the other lanes' kernels */
 		CK(hipEventRecord(a->ev0, a->stream));
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k3);
 		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
