@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <memory>
 #include <algorithm>
 #include "gaba_host.hpp"
 #include "mm_device.hpp"
@@ -87,14 +88,76 @@ inline void sort_res(ResEnt *p, size_t n) { auto key = [](const ResEnt &m) { ret
  * --------------------------------------------------------------------------------------------- */
 struct HSeq { std::string name; std::vector<uint8_t> seq; };
 
+/* run fn(t, nth) on up to 16 host threads (reads / records are independent in every host stage that uses this) */
+template<typename F> static void host_parallel(uint32_t want, F fn)
+{
+	const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 16)));
+	std::vector<std::thread> th;
+	for(uint32_t t = 1; t < nth; t++) th.emplace_back(fn, t, nth);
+	fn(0u, nth);
+	for(auto &x : th) x.join();
+}
+
 /* FASTA / FASTQ text; bases by the low-nibble table of minialign.c:223-229 (anything but ACGTUN -> A) */
+/* one FASTA stretch (starts at a '>' at the beginning of a line, holds whole records): lines by memchr, bases through the table */
+static void parse_fasta_span(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out)
+{
+	while(p < end) {
+		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
+		size_t n = (size_t)(le - p); while(n > 0 && p[n - 1] == '\r') n--;
+		if(n > 0) {
+			if(p[0] == '>') {
+				size_t q = 1; while(q < n && (p[q] == ' ' || p[q] == '\t')) q++;
+				size_t e = q; while(e < n && p[e] != ' ' && p[e] != '\t') e++;
+				out.emplace_back(); out.back().name.assign(p + q, e - q);
+			} else if(!out.empty()) {
+				auto &sq = out.back().seq; const size_t o = sq.size(); sq.resize(o + n);
+				uint8_t *d = sq.data() + o; for(size_t i = 0; i < n; i++) d[i] = enc[p[i] & 15];
+			}
+		}
+		p = nl ? nl + 1 : end;
+	}
+}
 bool read_seq_file(const char *fn, std::vector<HSeq> &out)
 {
 	FILE *fp = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
 	if(!fp) return false;
 	uint8_t enc[16] = { 0 };
 	enc['A' & 15] = 0; enc['C' & 15] = 1; enc['G' & 15] = 2; enc['T' & 15] = 3; enc['U' & 15] = 3; enc['N' & 15] = 4;
-	std::vector<char> buf(1 << 22);
+	/* the whole file in memory first (the reads are kept in memory anyway) */
+	std::vector<char> data;
+	{
+		size_t cap = 1 << 22, len = 0; 
+		if(fp != stdin && fseek(fp, 0, SEEK_END) == 0) { long sz = ftell(fp); if(sz > 0) cap = (size_t)sz + 1; rewind(fp); }
+		data.resize(cap);
+		size_t got;
+		while((got = fread(data.data() + len, 1, data.size() - len, fp)) > 0) { len += got; if(len == data.size()) data.resize(data.size() * 2); }
+		data.resize(len);
+	}
+	if(fp != stdin) fclose(fp);
+	size_t first = 0; while(first < data.size() && (data[first] == '\n' || data[first] == '\r')) first++;
+	if(first < data.size() && data[first] == '>') {
+		/* FASTA: '>' at the beginning of a line can only start a record, so the file splits at such points and the pieces are
+		 * parsed on host threads, each into its own list */
+		const char *base = data.data(), *end = base + data.size();
+		std::vector<std::vector<HSeq>> part;
+		std::vector<const char *> cut;
+		{
+			const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 16), (uint32_t)(data.size() >> 20) + 1));
+			cut.push_back(base + first);
+			for(uint32_t t = 1; t < nth; t++) {
+				const char *q = base + data.size() * t / nth;
+				while(q < end) { const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q)); if(!nl || nl + 1 >= end) { q = end; break; } if(nl[1] == '>') { q = nl + 1; break; } q = nl + 1; }
+				if(q > cut.back()) cut.push_back(q);
+			}
+			cut.push_back(end);
+			part.resize(cut.size() - 1);
+		}
+		host_parallel((uint32_t)part.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < part.size(); i += nth) parse_fasta_span(cut[i], cut[i + 1], enc, part[i]); });
+		size_t tot = 0; for(auto &v : part) tot += v.size();
+		out.reserve(out.size() + tot);
+		for(auto &v : part) for(auto &r : v) out.emplace_back(std::move(r));
+	} else {
 	std::string line; line.reserve(1 << 16);
 	int state = 0; char delim = 0; uint64_t qneed = 0, qgot = 0;
 	auto handle = [&](const char *l, size_t n) {
@@ -110,28 +173,30 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out)
 		if(state == 1 && delim == '@' && l[0] == '+') { state = 2; qneed = out.back().seq.size(); qgot = 0; if(qneed == 0) state = 0; return; }
 		if(state == 1) { auto &s = out.back().seq; size_t o = s.size(); s.resize(o + n); for(size_t i = 0; i < n; i++) s[o + i] = enc[l[i] & 15]; }
 	};
-	size_t got;
-	while((got = fread(buf.data(), 1, buf.size(), fp)) > 0) {
-		size_t st_ = 0;
-		for(size_t i = 0; i < got; i++) {
-			if(buf[i] == '\n') {
-				if(line.empty()) handle(buf.data() + st_, i - st_);
-				else { line.append(buf.data() + st_, i - st_); handle(line.data(), line.size()); line.clear(); }
-				st_ = i + 1;
-			}
-		}
-		if(st_ < got) line.append(buf.data() + st_, got - st_);
+	const char *p = data.data(), *end = p + data.size();
+	while(p < end) {
+		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
+		handle(p, (size_t)(le - p));
+		p = nl ? nl + 1 : end;
 	}
-	if(!line.empty()) handle(line.data(), line.size());
-	if(fp != stdin) fclose(fp);
+	}
 	/* -L 1 (minialign.c:2077): empty records are dropped */
 	out.erase(std::remove_if(out.begin(), out.end(), [](const HSeq &s) { return s.seq.empty(); }), out.end());
 	return true;
 }
 
+/* `at` is a multiple of 32 for every caller (reads start on 64-base boundaries): whole words are built and stored, no read-modify-write */
 void pack_bases(const uint8_t *b, uint64_t n, std::vector<uint32_t> &pk, std::vector<uint32_t> &nm, uint64_t at)
 {
-	for(uint64_t i = 0; i < n; i++) {
+	uint32_t *pw = pk.data() + (at >> 4), *nw = nm.data() + (at >> 5);
+	uint64_t i = 0;
+	for(; i + 32 <= n; i += 32) {
+		uint32_t w0 = 0, w1 = 0, m = 0;
+		for(int j = 0; j < 16; j++) { uint32_t c = b[i + j]; m |= (uint32_t)(c > 3) << j; w0 |= (c & 3 & (uint32_t)-(int32_t)(c <= 3)) << (2 * j); }
+		for(int j = 0; j < 16; j++) { uint32_t c = b[i + 16 + j]; m |= (uint32_t)(c > 3) << (16 + j); w1 |= (c & 3 & (uint32_t)-(int32_t)(c <= 3)) << (2 * j); }
+		pw[0] = w0; pw[1] = w1; nw[0] = m; pw += 2; nw += 1;
+	}
+	for(; i < n; i++) {
 		uint64_t p = at + i; uint32_t c = b[i];
 		if(c > 3) { nm[p >> 5] |= 1u << (p & 31); c = 0; }
 		pk[p >> 4] |= c << (2 * (p & 15));
@@ -145,22 +210,27 @@ void pack_bases(const uint8_t *b, uint64_t n, std::vector<uint32_t> &pk, std::ve
  * --------------------------------------------------------------------------------------------- */
 uint32_t h_crc32c(uint32_t crc, uint64_t v) { for(int i = 0; i < 64; i++) { uint32_t b = (crc ^ (uint32_t)(v >> i)) & 1u; crc = (crc >> 1) ^ (b ? 0x82f63b78u : 0u); } return crc; }
 struct HMin { uint64_t hash; uint32_t pos; uint32_t strand; };
-void sketch_host(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t w, std::vector<HMin> &out)
+/* minimizers of positions [begin, end) of a sequence.  A stretch that does not start at 0 warms the registers up over the k + 1 + w
+ * positions in front of it: an N stops influencing k1 after k + 1 bases, the window holds w positions, u is the previous minimum --
+ * so the stretches of a long sequence can be sketched independently and joined in order. */
+void sketch_host(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t w, std::vector<HMin> &out, uint32_t begin = 0, uint32_t end = 0xffffffffu)
 {
 	const uint64_t mask = (1ull << 2 * k) - 1; const int sh = 2 * (k - 1);
 	std::vector<uint64_t> ring(w, ~0ull);        /* h of the last w positions */
 	uint64_t k0 = 0, k1 = 0, u = 0;
-	for(uint32_t p = 0; p < len; p++) {
+	const uint32_t p0 = begin > k + 1 + w ? begin - (k + 1 + w) : 0;
+	if(end > len) end = len;
+	for(uint32_t p = p0; p < end; p++) {
 		uint64_t c = seq[p];
 		k0 = (k0 << 2 | c) & mask; k1 = (k1 >> 2) | ((3ull ^ c) << sh);
-		if(p + 1 < k) continue;
+		if(p + 1 < k || p < p0 + (p0 ? k : 0)) continue;
 		uint64_t km = k0 < k1 ? k0 : k1, kx = k0 < k1 ? k1 : k0, m = k0 < k1 ? 0 : 0x80;
 		uint64_t crc = (kx >> 32) ? (uint64_t)h_crc32c((uint32_t)kx, kx) : 0ull;
 		uint32_t i = (p - (k - 1)) % w;
 		uint64_t h = ((crc ^ km) & mask) << 8 | i | m;
 		ring[i] = h;
 		uint64_t v = ~0ull; for(uint32_t j = 0; j < w; j++) v = ring[j] < v ? ring[j] : v;
-		if(v == h || v != u) {
+		if(p >= begin && (v == h || v != u)) {
 			uint32_t iv = (uint32_t)(v & 0x7f);
 			out.push_back(HMin{ v >> 8, (p - (k - 1)) - ((i + w - iv) % w), (uint32_t)((v >> 7) & 1) });
 		}
@@ -284,20 +354,31 @@ extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 	const uint64_t nb = 1ull << b, bmask = nb - 1;
 	/* sketch every sequence and push (hrem, pos, rid) to its bucket in reference order (minialign.c:2790-2860) */
 	std::vector<std::vector<Mini>> bkt(nb);
-	std::vector<HMin> mins;
-	for(uint32_t i = 0; i < mi->seq.size(); i++) {
-		mins.clear();
-		sketch_host(mi->seq[i].seq.data(), (uint32_t)mi->seq[i].seq.size(), o->k, o->w, mins);
-		for(const HMin &m : mins) bkt[m.hash & bmask].push_back(Mini{ m.hash >> b, m.pos, (i << 1) + m.strand });
+	{
+		struct Task { uint32_t seq, begin, end; std::vector<HMin> mins; };
+		std::vector<Task> task; const uint32_t chunk = 1u << 18;
+		for(uint32_t i = 0; i < mi->seq.size(); i++) { const uint32_t L = (uint32_t)mi->seq[i].seq.size(); for(uint32_t bgn = 0; bgn < L || bgn == 0; bgn += chunk) { task.push_back(Task{ i, bgn, std::min(L, bgn + chunk), {} }); if(L == 0) break; } }
+		host_parallel((uint32_t)task.size(), [&](uint32_t t, uint32_t nth) {
+			for(size_t j = t; j < task.size(); j += nth) { Task &q = task[j]; sketch_host(mi->seq[q.seq].seq.data(), (uint32_t)mi->seq[q.seq].seq.size(), o->k, o->w, q.mins, q.begin, q.end); }
+		});
+		for(Task &q : task) { for(const HMin &m : q.mins) bkt[m.hash & bmask].push_back(Mini{ m.hash >> b, m.pos, (q.seq << 1) + m.strand }); std::vector<HMin>().swap(q.mins); }
 	}
-	/* per-bucket sort on hrem + occurrence histogram (minialign.c:2867-2900) */
+	/* per-bucket sort on hrem + occurrence histogram (minialign.c:2867-2900); buckets are independent */
 	std::vector<uint32_t> cnt;
-	for(auto &v : bkt) {
-		if(v.empty()) continue;
-		sort_minis(v.data(), v.size());
-		uint32_t n = 1;
-		for(size_t j = 1; j < v.size(); j++) { if(v[j - 1].hrem != v[j].hrem) { cnt.push_back(n); n = 0; } n++; }
-		cnt.push_back(n);
+	{
+		std::vector<std::vector<uint32_t>> pc(16);
+		host_parallel(16, [&](uint32_t t, uint32_t nth) {
+			std::vector<uint32_t> &c = pc[t];
+			for(uint64_t bi = t; bi < nb; bi += nth) {
+				auto &v = bkt[bi];
+				if(v.empty()) continue;
+				sort_minis(v.data(), v.size());
+				uint32_t n = 1;
+				for(size_t j = 1; j < v.size(); j++) { if(v[j - 1].hrem != v[j].hrem) { c.push_back(n); n = 0; } n++; }
+				c.push_back(n);
+			}
+		});
+		for(auto &c : pc) cnt.insert(cnt.end(), c.begin(), c.end());
 	}
 	/* thresholds: (1 - frq)-quantile of the per-key counts, + 1 (minialign.c:2981-2986) */
 	std::vector<uint32_t> sorted(cnt); std::sort(sorted.begin(), sorted.end());
@@ -784,7 +865,9 @@ struct Batch {
 namespace {
 bool batch_upload(mm_align_t *a, Batch &b)
 {
+	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
 	if(!ensure_pools(a, b.n, b.total + 64, b.max_qlen, b.scale)) return false;
+	if(verbose) { fprintf(stderr, "[minialign_amd]   pools %.1f ms\n", now_ms() - tv); tv = now_ms(); }
 	b.hst.assign(b.n, ReadState()); b.work.clear();
 	uint64_t moff = 0;
 	for(uint32_t i = 0; i < b.n; i++) {
@@ -798,6 +881,7 @@ bool batch_upload(mm_align_t *a, Batch &b)
 	CPY(a, a->d_in.p, b.in.data(), b.n * sizeof(ReadIn), hipMemcpyHostToDevice);
 	CPY(a, a->d_st.p, b.hst.data(), b.n * sizeof(ReadState), hipMemcpyHostToDevice);
 	CK(hipMemsetAsync(a->d_tops.p, 0, 32 * 8, a->stream)); CK(hipStreamSynchronize(a->stream));
+	if(verbose) { fprintf(stderr, "[minialign_amd]   host state + H2D %.1f ms\n", now_ms() - tv); }
 	b.uploaded = true; b.ran = false;
 	return true;
 }
@@ -806,8 +890,11 @@ bool batch_prepare(mm_align_t *a, Batch &b)
 	b.n = (uint32_t)b.lens.size(); b.total = 0; b.max_qlen = 0; b.qoff.resize(b.n); b.in.resize(b.n);
 	for(uint32_t i = 0; i < b.n; i++) { b.qoff[i] = b.total; b.total += ((uint64_t)b.lens[i] + 63) & ~63ull; b.max_qlen = std::max(b.max_qlen, b.lens[i]); }
 	b.pk.assign((b.total + 64) / 16 + 8, 0); b.nm.assign((b.total + 64) / 32 + 8, 0);
-	for(uint32_t i = 0; i < b.n; i++) { pack_bases(b.seq[i], b.lens[i], b.pk, b.nm, b.qoff[i]); b.in[i] = ReadIn{ b.qoff[i], b.lens[i], 0 }; }
+	host_parallel(b.n / 64 + 1, [&](uint32_t t, uint32_t nth) {          /* reads occupy disjoint, word-aligned stretches of the arena */
+		for(uint32_t i = (uint32_t)((uint64_t)b.n * t / nth); i < (uint32_t)((uint64_t)b.n * (t + 1) / nth); i++) { pack_bases(b.seq[i], b.lens[i], b.pk, b.nm, b.qoff[i]); b.in[i] = ReadIn{ b.qoff[i], b.lens[i], 0 }; }
+	});
 	b.scale = 1;
+	if(getenv("MM_VERBOSE")) { fprintf(stderr, "[minialign_amd]   pack done\n"); }
 	return batch_upload(a, b);
 }
 /* the hot path over the uploaded batch; returns 0 ok, 1 device pools overflowed (caller grows and retries), -1 error */
@@ -865,7 +952,7 @@ bool batch_run(mm_align_t *a, Batch &b)
 		if(!batch_upload(a, b)) return false;
 	}
 }
-bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
+bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piece_out)
 {
 	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
 	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
@@ -879,13 +966,16 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 	a->st.k2_cycles_sort += tops[24]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
-	std::vector<Root> root(std::max<uint64_t>(tops[2], 1)); std::vector<uint64_t> bin(std::max<uint64_t>(tops[3], 1)); std::vector<AlnRec> aln(std::max<uint64_t>(tops[4], 1));
-	std::vector<gaba::Segment> seg(std::max<uint64_t>(tops[5], 1)); std::vector<uint32_t> path(std::max<uint64_t>(tops[6], 2) + 8);
-	CPY(a, root.data(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost);
-	CPY(a, bin.data(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost);
-	CPY(a, aln.data(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost);
-	CPY(a, seg.data(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost);
-	CPY(a, path.data(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost);
+	/* host copies of the result pools (uninitialised storage: the copies fill them) */
+	std::unique_ptr<Root[]> root(new Root[std::max<uint64_t>(tops[2], 1)]); std::unique_ptr<uint64_t[]> bin(new uint64_t[std::max<uint64_t>(tops[3], 1)]);
+	std::unique_ptr<AlnRec[]> aln(new AlnRec[std::max<uint64_t>(tops[4], 1)]);
+	std::unique_ptr<gaba::Segment[]> seg(new gaba::Segment[std::max<uint64_t>(tops[5], 1)]); std::unique_ptr<uint32_t[]> path(new uint32_t[std::max<uint64_t>(tops[6], 2) + 8]);
+	CK(hipMemcpyAsync(root.get(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(bin.get(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(aln.get(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(seg.get(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(path.get(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost, a->stream));
+	CK(hipStreamSynchronize(a->stream));
 	double t1 = now_ms();
 	/* post-map and SAM text are per read and independent: host threads take contiguous spans, the pieces are joined in input
 	 * order (mm_align_drain keeps the same order with its heap, minialign.c:4633-4645) */
@@ -896,22 +986,31 @@ bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
 		auto span = [&](uint32_t t) {
 			const uint32_t lo = (uint32_t)((uint64_t)n_reads * t / nth), hi = (uint32_t)((uint64_t)n_reads * (t + 1) / nth);
 			std::string &out = piece[t];
+			uint64_t est = 0; for(uint32_t i = lo; i < hi; i++) est += b.lens[i];
+			out.reserve(est + est / 2 + 4096);
 			for(uint32_t i = lo; i < hi; i++) {
 				OutReg reg; const ReadState &rs = hst[i];
-				const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.data();
+				const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.get();
 				if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
-				sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.data(), path.data());
+				sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get());
 			}
 		};
 		std::vector<std::thread> th;
 		for(uint32_t t = 1; t < nth; t++) th.emplace_back(span, t);
 		span(0);
 		for(auto &x : th) x.join();
-		size_t tot = sam.size(); for(auto &x : piece) tot += x.size();
-		sam.reserve(tot);
-		for(auto &x : piece) sam += x;
+		for(auto &x : piece) piece_out.emplace_back(std::move(x));
 	}
 	a->st.host_post_ms += t1 - t0; a->st.host_sam_ms += now_ms() - t1;
+	return true;
+}
+bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
+{
+	std::vector<std::string> piece;
+	if(!batch_finish_pieces(a, b, piece)) return false;
+	size_t tot = sam.size(); for(auto &x : piece) tot += x.size();
+	sam.reserve(tot);
+	for(auto &x : piece) sam += x;
 	return true;
 }
 } /* anonymous */
@@ -1066,10 +1165,19 @@ extern "C" int mm_batch_wait(mm_align_t *a, mm_batch_t *h)
 extern "C" void mm_batch_free(mm_batch_t *h) { if(h && h->running) { h->th.join(); } delete h; }
 extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
 
+static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out);
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
+	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
 	mm_reads_t *reads = mm_reads_load(reads_fn);
 	if(!reads) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
+	if(verbose) { fprintf(stderr, "[minialign_amd] parse %.1f ms\n", now_ms() - tv); }
+	return align_reads(a, reads, out);
+}
+/* maps a parsed read set (consumed) and writes its SAM records */
+static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out)
+{
+	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
 	/* batches: bounded by bases so that the device pools stay modest; drained strictly in input order */
 	const uint64_t max_bases = 512ull << 20; const uint32_t max_reads = 1u << 17;
 	uint32_t i = 0, n = mm_reads_count(reads); int rc = 0;
@@ -1077,9 +1185,16 @@ extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 		uint32_t j = i; uint64_t nb = 0;
 		while(j < n && j - i < max_reads && (nb == 0 || nb + reads->r[j].seq.size() <= max_bases)) { nb += reads->r[j].seq.size(); j++; }
 		mm_batch_t *h = mm_batch_upload(a, reads, i, j - i);
+		if(verbose) { fprintf(stderr, "[minialign_amd] pack + upload %.1f ms\n", now_ms() - tv); tv = now_ms(); }
 		char *sam = NULL; uint64_t len = 0;
-		if(!h || mm_batch_run(a, h) || mm_batch_finish(a, h, &sam, &len)) rc = 1;
-		else fwrite(sam, 1, len, out);
+		if(!h || mm_batch_run(a, h)) rc = 1;
+		if(verbose) { fprintf(stderr, "[minialign_amd] run %.1f ms\n", now_ms() - tv); tv = now_ms(); }
+		std::vector<std::string> piece;
+		if(rc == 0 && h->split) { if(mm_batch_finish(a, h, &sam, &len)) rc = 1; }
+		else if(rc == 0 && !batch_finish_pieces(h->ctx ? h->ctx : a, h->b, piece)) rc = 1;      /* the text goes out piece by piece, no joined copy */
+		if(verbose) { fprintf(stderr, "[minialign_amd] finish %.1f ms\n", now_ms() - tv); tv = now_ms(); }
+		if(rc == 0) { if(sam) fwrite(sam, 1, len, out); for(auto &x : piece) fwrite(x.data(), 1, x.size(), out); }
+		if(verbose) { fprintf(stderr, "[minialign_amd] write %.1f ms\n", now_ms() - tv); tv = now_ms(); }
 		free(sam); if(h) mm_batch_free(h);
 		i = j;
 	}
@@ -1096,15 +1211,21 @@ extern "C" int mm_main(int argc, char **argv)
 		mm_opt_destroy(o); return 1;
 	}
 	double t0 = now_ms();
+	/* the first query file is parsed on a thread of its own while the index is built */
+	mm_reads_t *first_reads = NULL;
+	std::thread rt([&]() { if(strcmp(files[1], "-") != 0) first_reads = mm_reads_load(files[1]); });
+	std::thread hw([]() { int n = 0; if(hipGetDeviceCount(&n) == hipSuccess && n > 0) { (void)hipFree(0); } });      /* bring the HIP runtime up meanwhile */
 	mm_idx_t *mi = mm_idx_gen(o, files[0]);
-	if(!mi) { mm_opt_destroy(o); return 1; }
-	mm_align_t *a = mm_align_init(o, mi);
-	if(!a) { mm_idx_destroy(mi); mm_opt_destroy(o); return 1; }
+	hw.join();
+	mm_align_t *a = mi ? mm_align_init(o, mi) : NULL;
+	rt.join();
+	if(!mi || !a) { if(first_reads) mm_reads_free(first_reads); if(mi) mm_idx_destroy(mi); mm_opt_destroy(o); return 1; }
 	fprintf(stderr, "[M::main_align::%.3f] loaded/built index for %u target sequence(s).\n", (now_ms() - t0) * 1e-3, mm_idx_n_seq(mi));
 	mm_print_sam_header(a, stdout, o->arg_line.c_str());
 	int rc = 0;
 	for(int i = 1; i < nf && rc == 0; i++) {
-		rc = mm_align_file(a, files[i], stdout);
+		if(i == 1 && first_reads) { rc = align_reads(a, first_reads, stdout); }
+		else { rc = mm_align_file(a, files[i], stdout); }
 		fprintf(stderr, "[M::main_align::%.3f] finished mapping `%s' onto `%s'.\n", (now_ms() - t0) * 1e-3, files[i], files[0]);
 	}
 	mm_stats_t st; mm_stats(a, &st, 0);
