@@ -64,3 +64,20 @@ def test_full_size_properties_and_sample_parity():
             if not line.startswith(b'@'): want.setdefault(line.split(b'\t', 1)[0], []).append(line)
         for n in want_names:
             assert kept[n] == want[n], 'read %r differs from the oracle' % n
+        # and, where the compiled reference travelled with the snapshot, the whole 680 MB of SAM against it (-t1: with several
+        # threads the reference's own output depends on which thread buffer a read lands in)
+        refbin = os.path.join(M.ROOT, 'oracle', '_ref', 'minialign')
+        if os.path.exists(refbin):
+            import hashlib
+            def digest(cmd):
+                h = hashlib.md5(); p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                for line in p.stdout:
+                    if not line.startswith(b'@PG'): h.update(line)
+                assert p.wait() == 0
+                return h.hexdigest()
+            h_ref = digest([refbin, '-xpacbio', '-t1', ref, rd])
+            h_got = hashlib.md5()
+            with open(out, 'rb') as f:
+                for line in f:
+                    if not line.startswith(b'@PG'): h_got.update(line)
+            assert h_got.hexdigest() == h_ref, 'full-size SAM differs from the compiled reference'
