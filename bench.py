@@ -11,6 +11,8 @@ Prints ONE JSON line (see the contract in the task description) with `roofline` 
 algorithmic bytes = DP vectors x 40.5 B + traceback steps x 32 B per launch, SURVEY.md 8d, over the kernel's average
 launch time from HIP events) and `cpu_baseline` (the compiled reference when oracle/_ref travelled with the snapshot,
 else the repo's plain-C oracle, on a bounded sample of the same reads)."""
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # before the HIP runtime starts: the lanes' streams should not share hardware queues
 import argparse, ctypes, json, os, re, subprocess, sys, tempfile, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

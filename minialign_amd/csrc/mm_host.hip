@@ -540,8 +540,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				const uint32_t per_cu = div ? div : 8;
 				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / (4 * MM_K3_WAVES_PER_SIMD)) * per_cu);
 				/* the classes are independent: each goes to its own stream behind ev0 so that their tails overlap; the retry waits for all */
-				hipStream_t sq = ci == n_cls ? a->stream : a->k2s[ci];
-				if(ci < n_cls) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
+				hipStream_t sq = ci == n_cls ? a->stream : a->k2s[ci % 4];      /* four side streams: every stream wants a hardware queue, and those are few */
+				if(ci < n_cls && ci < 4) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
 				else { for(int j = 0; j < n_cls; j++) { CK(hipStreamWaitEvent(a->stream, a->k2e[j], 0)); } }
 				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(grid), dim3(64), bytes ? bytes : 1536 * 4, sq, ka);
 				CK(hipGetLastError());
@@ -1204,6 +1204,7 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out)
 
 extern "C" int mm_main(int argc, char **argv)
 {
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);          /* lanes and side streams should not share hardware queues (read when the HIP runtime starts) */
 	mm_opt_t *o = mm_opt_init();
 	const char *files[8]; int nf = 0;
 	if(mm_opt_parse(o, argc, (char const *const *)argv, files, 8, &nf) || nf < 2) {
