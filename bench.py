@@ -78,7 +78,7 @@ def cpu_baseline(ref_fa, reads_fa, workdir, budget_reads):
 def pmc_traffic(args, world):
     """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes (same workload only), else None"""
     fn = os.path.join(ROOT, 'profiles', 'round1_e_pmc.json')
-    if world != 1 or args.depth != 100.0 or not os.path.exists(fn): return None
+    if world != 1 or args.depth != 100.0 or args.repeat_frac != 0.05 or not os.path.exists(fn): return None
     try:
         with open(fn) as f: return json.load(f)['mm_extend_kernel_per_launch']['hbm_bytes']
     except Exception:
@@ -88,6 +88,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=3); ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=float, default=100.0, help='read depth over the 4.64 Mb reference (x100 = BASELINE configs[1])')
+    ap.add_argument('--repeat-frac', type=float, default=0.05, help='fraction of the synthetic reference made of planted repeats (default workload: 0.05)')
     ap.add_argument('--check', action='store_true', help='also verify the SAM of a sample against the CPU oracle')
     ap.add_argument('--stagger-ms', type=float, default=0.0, help='delay of the second lane at the start of the timed region')
     ap.add_argument('--inflight', type=int, default=3, choices=(1, 2, 3, 4), help='batches in flight per GPU: consecutive steps go to alternating lanes of the device context and overlap, as the batches of a read stream do (1: strictly one after the other)')
@@ -109,7 +110,7 @@ def main():
 
     work = tempfile.mkdtemp(prefix='mmbench_')
     ref_fa = os.path.join(work, 'ref.fa'); reads_fa = os.path.join(work, 'reads_%d.fa' % rank)
-    gensim('genome', 0x5eed0001, GENOME_LEN, 1, 0.05, out=ref_fa)
+    gensim('genome', 0x5eed0001, GENOME_LEN, 1, args.repeat_frac, out=ref_fa)
     gensim('reads', 0x5eed0002 + rank, ref_fa, args.depth, 'pacbio', 'fa', 20000, 2000, out=reads_fa)
 
     o = ctypes.c_void_p(L.mm_opt_init())

@@ -20,6 +20,8 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <condition_variable>
+#include <mutex>
 #include <memory>
 #include <algorithm>
 #include "gaba_host.hpp"
@@ -1042,15 +1044,11 @@ extern "C" mm_reads_t *mm_reads_load(char const *fn)
 extern "C" void mm_reads_free(mm_reads_t *r) { delete r; }
 extern "C" uint32_t mm_reads_count(mm_reads_t const *r) { return (uint32_t)r->r.size(); }
 extern "C" uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t n) { uint64_t b = 0; for(uint32_t i = first; i < first + n && i < r->r.size(); i++) b += r->r[i].seq.size(); return b; }
-/*
- * Two lanes.  A batch of ordinary size is cut in two halves by bases; each half runs the whole K1 -> K2 -> K3 sequence on
- * its own context (own streams and pools, shared index / reference / DP constants) driven by its own host thread.  The
- * stages have different limiters (K1 VALU, K2 LDS latency, K3 fill VALU / traceback + tail latency), and every launch
- * ends in a tail where few wavefronts are left: with two lanes in flight one lane's tails and latency-bound stretches are
- * filled by the other lane's work.  Results do not depend on the split: the only state reads share is the carried
- * reference length, which the second lane guesses and batch_verify_carry() then corrects at the seam.
- */
-struct mm_batch_s { Batch b; Batch h[2]; bool split = false; mm_align_t *ctx = nullptr; std::thread th; int rc = 0; bool running = false; };
+/* Lanes: a batch is bound to one lane of the device context (own streams, pools and -- when run asynchronously -- host thread; index,
+ * reference and DP constants shared).  Batches on different lanes overlap on the device: the launch tail and the latency-bound
+ * stages of one are filled by the other.  The one piece of state reads share, the carried reference length, is
+ * handed from batch to batch by whoever sequences them (align_reads below). */
+struct mm_batch_s { Batch b; mm_align_t *ctx = nullptr; std::thread th; int rc = 0; bool running = false; };
 static mm_align_t *align_lane(mm_align_t *a)
 {
 	if(a->sib) return a->sib;
@@ -1070,19 +1068,6 @@ extern "C" mm_batch_t *mm_batch_upload(mm_align_t *a, mm_reads_t const *r, uint3
 {
 	mm_batch_t *h = new mm_batch_s();
 	const uint32_t last = (uint32_t)std::min<uint64_t>((uint64_t)first + n, r->r.size());
-	/* opt-in (MM_TWO_LANES=<minimum reads per batch>): on the bench workload one lane is faster -- the extension launch is
-	 * bound by its single heaviest read (98 of 104 ms), which a second lane only delays */
-	const char *tl = getenv("MM_TWO_LANES");
-	const bool two = tl && last > first && last - first >= (uint32_t)std::max(2, atoi(tl));
-	mm_align_t *lane1 = two ? align_lane(a) : NULL;
-	if(lane1) {
-		uint64_t tot = 0, acc = 0; for(uint32_t i = first; i < last; i++) tot += r->r[i].seq.size();
-		uint32_t cut = first; while(cut < last && acc * 2 < tot) { acc += r->r[cut].seq.size(); cut++; }
-		for(uint32_t i = first; i < last; i++) { Batch &b = h->h[i < cut ? 0 : 1]; b.lens.push_back((uint32_t)r->r[i].seq.size()); b.seq.push_back(r->r[i].seq.data()); b.names.push_back(r->r[i].name); }
-		h->split = true;
-		if(!batch_prepare(a, h->h[0]) || !batch_prepare(lane1, h->h[1])) { delete h; return NULL; }
-		return h;
-	}
 	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); }
 	h->ctx = a;
 	if(!batch_prepare(a, h->b)) { delete h; return NULL; }
@@ -1106,43 +1091,14 @@ extern "C" mm_batch_t *mm_batch_upload_lane(mm_align_t *a, mm_reads_t const *r, 
 }
 extern "C" int mm_batch_run(mm_align_t *a, mm_batch_t *h)
 {
-	if(!h->split) {
-		mm_align_t *c = h->ctx ? h->ctx : a;
-		if(h->b.ran) { if(!batch_upload(c, h->b)) return -1; }        /* a second pass over the same batch starts from clean device state */
-		return batch_run(c, h->b) ? 0 : -1;
-	}
-	mm_align_t *q = a->sib;
-	const uint32_t carry_in = a->rlen_carry;
-	bool ok[2] = { false, false };
-	auto lane = [&](int k) {
-		mm_align_t *c = k ? q : a; Batch &b = h->h[k];
-		if(hipSetDevice(a->dev) != hipSuccess) return;
-		if(b.ran && !batch_upload(c, b)) return;
-		if(k) { c->rlen_carry = carry_in; }                        /* the guess: what the first lane started from */
-		ok[k] = batch_run(c, b);
-	};
-	std::thread t1(lane, 1); lane(0); t1.join();
-	if(!ok[0] || !ok[1]) return -1;
-	/* the seam: the value the second half should have started from is the one the first half ends with */
-	uint32_t end0 = carry_in;
-	for(uint32_t i = 0; i < h->h[0].n; i++) { if(h->h[0].hst[i].rid_last != gaba::NIL) end0 = (uint32_t)a->mi->seq[h->h[0].hst[i].rid_last].seq.size(); }
-	if(end0 != carry_in) {
-		q->rlen_carry = end0;
-		if(batch_verify_carry(q, h->h[1]) != 0) { fprintf(stderr, "[minialign_amd] second lane: re-run at the seam failed\n"); return -1; }
-	}
-	return 0;
+	mm_align_t *c = h->ctx ? h->ctx : a;
+	if(h->b.ran) { if(!batch_upload(c, h->b)) return -1; }        /* a second pass over the same batch starts from clean device state */
+	return batch_run(c, h->b) ? 0 : -1;
 }
 extern "C" int mm_batch_finish(mm_align_t *a, mm_batch_t *h, char **sam, uint64_t *sam_len)
 {
 	std::string s;
-	if(!h->split) { if(!batch_finish(h->ctx ? h->ctx : a, h->b, s)) return -1; }
-	else {
-		mm_align_t *q = a->sib;
-		if(!batch_finish(a, h->h[0], s)) return -1;               /* advances a->rlen_carry over the first half */
-		q->rlen_carry = a->rlen_carry;
-		if(!batch_finish(q, h->h[1], s)) return -1;
-		a->rlen_carry = q->rlen_carry;
-	}
+	if(!batch_finish(h->ctx ? h->ctx : a, h->b, s)) return -1;
 	if(sam) { uint64_t old = *sam ? *sam_len : 0; *sam = (char *)realloc(*sam, old + s.size() + 1); memcpy(*sam + old, s.data(), s.size()); (*sam)[old + s.size()] = 0; *sam_len = old + s.size(); }
 	return 0;
 }
@@ -1177,27 +1133,72 @@ extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 /* maps a parsed read set (consumed) and writes its SAM records */
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out)
 {
-	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
-	/* batches: bounded by bases so that the device pools stay modest; drained strictly in input order */
-	const uint64_t max_bases = 512ull << 20; const uint32_t max_reads = 1u << 17;
-	uint32_t i = 0, n = mm_reads_count(reads); int rc = 0;
-	while(i < n && rc == 0) {
+	const bool verbose = getenv("MM_VERBOSE") != NULL;
+	/*
+	 * batches (bounded by bases so that the device pools stay modest) on two lanes: this thread packs, uploads and runs batch
+	 * i on lane i & 1 while a second host thread does D2H + post-map + SAM text of batch i - 1 and writes it -- strictly in
+	 * input order, as mm_align_drain does (minialign.c:4633-4645).  The carried reference length is handed from
+	 * batch to batch by this thread: it is final as soon as a batch has run.
+	 */
+	const uint64_t max_bases = getenv("MM_BATCH_BASES") ? (uint64_t)atoll(getenv("MM_BATCH_BASES")) : (512ull << 20);      /* env: test hook (many small batches) */
+	const uint32_t max_reads = 1u << 17;
+	const uint32_t n = mm_reads_count(reads);
+	struct Slot { mm_batch_t *h = nullptr; bool ready = false, busy = false; };
+	Slot slot[2];
+	std::mutex mu; std::condition_variable cv;
+	int rc = 0; bool done = false; uint32_t produced = 0;
+	std::thread finisher([&]() {
+		if(hipSetDevice(a->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); rc = 1; cv.notify_all(); return; }
+		for(uint32_t k = 0;; k++) {
+			Slot &sl = slot[k & 1];
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&]() { return sl.ready || (done && k >= produced) || rc != 0; });
+				if(!sl.ready) { return; }
+			}
+			double tv = now_ms();
+			std::vector<std::string> piece; int r = 0;
+			mm_batch_t *h = sl.h;
+			if(!batch_finish_pieces(h->ctx, h->b, piece)) { r = 1; }
+			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: finish %.1f ms\n", k, now_ms() - tv); tv = now_ms(); }
+			if(r == 0) { for(auto &x : piece) fwrite(x.data(), 1, x.size(), out); }
+			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: write %.1f ms\n", k, now_ms() - tv); }
+			mm_batch_free(h);
+			{ std::lock_guard<std::mutex> lk(mu); sl.h = nullptr; sl.ready = false; sl.busy = false; if(r) rc = 1; }
+			cv.notify_all();
+		}
+	});
+	uint32_t carry = a->rlen_carry;
+	uint32_t i = 0;
+	for(uint32_t k = 0; i < n; k++) {
 		uint32_t j = i; uint64_t nb = 0;
 		while(j < n && j - i < max_reads && (nb == 0 || nb + reads->r[j].seq.size() <= max_bases)) { nb += reads->r[j].seq.size(); j++; }
-		mm_batch_t *h = mm_batch_upload(a, reads, i, j - i);
-		if(verbose) { fprintf(stderr, "[minialign_amd] pack + upload %.1f ms\n", now_ms() - tv); tv = now_ms(); }
-		char *sam = NULL; uint64_t len = 0;
-		if(!h || mm_batch_run(a, h)) rc = 1;
-		if(verbose) { fprintf(stderr, "[minialign_amd] run %.1f ms\n", now_ms() - tv); tv = now_ms(); }
-		std::vector<std::string> piece;
-		if(rc == 0 && h->split) { if(mm_batch_finish(a, h, &sam, &len)) rc = 1; }
-		else if(rc == 0 && !batch_finish_pieces(h->ctx ? h->ctx : a, h->b, piece)) rc = 1;      /* the text goes out piece by piece, no joined copy */
-		if(verbose) { fprintf(stderr, "[minialign_amd] finish %.1f ms\n", now_ms() - tv); tv = now_ms(); }
-		if(rc == 0) { if(sam) fwrite(sam, 1, len, out); for(auto &x : piece) fwrite(x.data(), 1, x.size(), out); }
-		if(verbose) { fprintf(stderr, "[minialign_amd] write %.1f ms\n", now_ms() - tv); tv = now_ms(); }
-		free(sam); if(h) mm_batch_free(h);
+		Slot &sl = slot[k & 1];
+		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return !sl.busy || rc != 0; }); if(rc != 0) break; sl.busy = true; }
+		double tv = now_ms();
+		mm_batch_t *h = mm_batch_upload_lane(a, reads, i, j - i, (int)(k & 1));
+		if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: pack + upload %.1f ms\n", k, now_ms() - tv); tv = now_ms(); }
+		int r = 0;
+		if(!h) { r = 1; }
+		else {
+			h->ctx->rlen_carry = carry;
+			if(mm_batch_run(a, h)) { r = 1; }
+			else { for(uint32_t x = 0; x < h->b.n; x++) { if(h->b.hst[x].rid_last != gaba::NIL) carry = (uint32_t)a->mi->seq[h->b.hst[x].rid_last].seq.size(); } }
+		}
+		if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: run %.1f ms\n", k, now_ms() - tv); }
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			if(r) { rc = 1; sl.busy = false; if(h) { mm_batch_free(h); } }
+			else { sl.h = h; sl.ready = true; produced = k + 1; }
+		}
+		cv.notify_all();
+		if(r) break;
 		i = j;
 	}
+	{ std::lock_guard<std::mutex> lk(mu); done = true; }
+	cv.notify_all();
+	finisher.join();
+	a->rlen_carry = carry;
 	mm_reads_free(reads);
 	return rc;
 }
