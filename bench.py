@@ -78,7 +78,7 @@ def cpu_baseline(ref_fa, reads_fa, workdir, budget_reads):
 def pmc_traffic(args, world):
     """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes (same workload only), else None"""
     fn = os.path.join(ROOT, 'profiles', 'round1_e_pmc.json')
-    if world != 1 or args.depth != 100.0 or args.repeat_frac != 0.05 or not os.path.exists(fn): return None
+    if world != 1 or args.depth != 100.0 or args.repeat_frac != 0.05 or args.genome_len != GENOME_LEN or args.contigs != 1 or not os.path.exists(fn): return None
     try:
         with open(fn) as f: return json.load(f)['mm_extend_kernel_per_launch']['hbm_bytes']
     except Exception:
@@ -88,6 +88,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=3); ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=float, default=100.0, help='read depth over the 4.64 Mb reference (x100 = BASELINE configs[1])')
+    ap.add_argument('--genome-len', type=int, default=GENOME_LEN, help='length of the synthetic reference (default workload: E.coli MG1655, 4 641 652)')
+    ap.add_argument('--contigs', type=int, default=1, help='number of contigs of the synthetic reference (default workload: 1)')
     ap.add_argument('--repeat-frac', type=float, default=0.05, help='fraction of the synthetic reference made of planted repeats (default workload: 0.05)')
     ap.add_argument('--check', action='store_true', help='also verify the SAM of a sample against the CPU oracle')
     ap.add_argument('--stagger-ms', type=float, default=0.0, help='delay of the second lane at the start of the timed region')
@@ -110,7 +112,7 @@ def main():
 
     work = tempfile.mkdtemp(prefix='mmbench_')
     ref_fa = os.path.join(work, 'ref.fa'); reads_fa = os.path.join(work, 'reads_%d.fa' % rank)
-    gensim('genome', 0x5eed0001, GENOME_LEN, 1, args.repeat_frac, out=ref_fa)
+    gensim('genome', 0x5eed0001, args.genome_len, args.contigs, args.repeat_frac, out=ref_fa)
     gensim('reads', 0x5eed0002 + rank, ref_fa, args.depth, 'pacbio', 'fa', 20000, 2000, out=reads_fa)
 
     o = ctypes.c_void_p(L.mm_opt_init())
@@ -174,8 +176,9 @@ def main():
             'metric': 'aligned Gbases/sec (hot path: sketch+lookup, sort+chain, banded extension; SAM bit-exact vs CPU ref)',
             'value': total_bases * args.steps / dt * 1e-9, 'unit': 'Gbases/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'i8',
-            'data': 'synthetic (tools/gensim.c: 4.64 Mb reference with 5 % planted repeats, PBSIM-CLR-like reads 20k+-2k, acc 0.88+-0.07)',
-            'config': {'workload': 'E.coli MG1655-size ref x PBSIM-like x%g (%.0f Mb, %d reads) -xpacbio on 1 MI355X per rank' % (args.depth, bases / 1e6, n_reads),
+            'data': 'synthetic (tools/gensim.c: %.2f Mb reference with %g %% planted repeats, PBSIM-CLR-like reads 20k+-2k, acc 0.88+-0.07)' % (args.genome_len / 1e6, args.repeat_frac * 100),
+            'config': {'workload': ('E.coli MG1655-size ref' if (args.genome_len == GENOME_LEN and args.contigs == 1 and args.repeat_frac == 0.05) else 'synthetic %.1f Mb / %d contig(s) / %g repeats ref' % (args.genome_len / 1e6, args.contigs, args.repeat_frac))
+                                   + ' x PBSIM-like x%g (%.0f Mb, %d reads) -xpacbio on 1 MI355X per rank' % (args.depth, bases / 1e6, n_reads),
                        'reads_per_rank': n_reads, 'bases_per_rank': bases, 'batches_in_flight': args.inflight, 'parallelism': 'reads sharded, index replicated (no collective)',
                        'kernel_ms_per_step': {'sketch_seed': per_step(st.k1_ms), 'sort_chain': per_step(st.k2_ms), 'extend': per_step(st.k3_ms)},
                        'extend_wave_time_split': {k: getattr(st2, 'k3_cycles_' + k) / max(1, st2.k3_cycles_total) for k in ('fill', 'leaf', 'trace', 'next')},
