@@ -962,7 +962,6 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 	Kh kh; kh.cap = a.kh_cap;
 	uint64_t *next = a.next_pool + (uint64_t)wave * a.next_cap;
 	const DevIndex &ix = a.idx;
-	const gaba::Sec tailsec = { 0xfffffffeu, 96, 0, 2, 0 };
 	unsigned long long n_fill = 0, n_trace = 0;
 	unsigned long long cy_fill = 0, cy_leaf = 0, cy_trace = 0;        /* wave cycles spent in the three DP phases (s_memtime) */
 	unsigned long long cy_next = 0;                                  /* ... and in mm_search_load_next */
