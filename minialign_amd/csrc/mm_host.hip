@@ -455,6 +455,7 @@ struct mm_align_s {
 	hipStream_t stream; hipEvent_t ev0, ev1;
 	hipStream_t k2s[12]; hipEvent_t k2e[12]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
+	uint32_t k3_waves = 0; uint64_t slab_stride = 0;      /* extension kernel: persistent waves actually launched and the DP workspace of each */
 	/* pools */
 	DBuf<uint32_t> q_pk, q_nm; DBuf<ReadIn> d_in; DBuf<ReadState> d_st; DBuf<uint32_t> d_work;
 	DBuf<MinRec> min_pool; DBuf<Seed> seed_pool; DBuf<Resc> resc_pool; DBuf<Root> root_pool;
@@ -597,7 +598,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
 		K3Args k3; k3.idx = a->dix; k3.gc = a->gctx->hc; k3.roots = a->gctx->droots; k3.ar_ref = gaba::SeqArena{ a->ref_ar->pk, a->ref_ar->nm }; k3.ar_q = gaba::SeqArena{ a->q_pk.p, a->q_nm.p };
 		k3.in = a->d_in.p; k3.st = a->d_st.p; k3.work = a->d_work.p; k3.n_work = k3_work_override ? k3_work_override : (uint32_t)work.size();
-		k3.seed_pool = a->seed_pool.p; k3.root_pool = a->root_pool.p; k3.slabs = a->slabs.p; k3.slab_bytes = a->slabs.n / a->n_waves;
+		k3.seed_pool = a->seed_pool.p; k3.root_pool = a->root_pool.p; k3.slabs = a->slabs.p; k3.slab_bytes = a->slab_stride;
 		k3.kh_pool = a->kh_pool.p; k3.kh_cap = a->kh_cap; k3.round = round; k3.next_pool = a->next_pool.p; k3.next_cap = a->next_cap;
 		k3.bin_pool = a->bin_pool.p; k3.bin_pool_cap = a->bin_pool.n; k3.bin_top = tops + 3; k3.bin_cap_per_read = a->bin_cap;
 		k3.aln_pool = a->aln_pool.p; k3.aln_pool_cap = a->aln_pool.n; k3.aln_top = tops + 4; k3.aln_cap_per_read = a->aln_cap;
@@ -605,7 +606,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.path_pool = a->path_pool.p; k3.path_pool_cap = a->path_pool.n; k3.path_top = tops + 6;
 		k3.tglen = a->tglen; k3.mcoef = a->mcoef; k3.min_ratio = a->o.min_ratio; k3.min_score = a->o.min_score;
 		k3.counter = (uint32_t *)(tops + 16); k3.stats = tops + 8;
-		uint32_t waves = std::min<uint32_t>(a->n_waves, (uint32_t)((work.size() + 3) & ~3ull));
+		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
 		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* leave wave slots to the other lanes' kernels */
 		CK(hipEventRecord(a->ev0, a->stream));
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k3);
@@ -765,8 +766,12 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	/* DP workspace: a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors */
 	uint64_t blocks = 2 * ((2ull * max_qlen + 8192) / 32 + 64);
 	uint64_t slab = (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull;
-	ok &= a->slabs.ensure(slab * a->n_waves);
-	if(ok && a->slabs.n != slab * a->n_waves) { /* keep the per-wave stride derived from the current allocation */ }
+	/* the workspace is per persistent wave and grows with the longest read of the batch (5 MB for 27 kb): with very long reads fewer waves
+	 * are launched rather than more than `budget` of HBM taken per lane (MM_SLAB_GB, default 48) */
+	const uint64_t budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 48ull) << 30;
+	uint32_t kw = (uint32_t)std::min<uint64_t>(a->n_waves, std::max<uint64_t>(256, budget / slab)) & ~3u;
+	if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
+	else { ok &= a->slabs.ensure(slab * kw); if(ok) { a->slab_stride = a->slabs.n / kw; a->k3_waves = kw; } }
 	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(16);
 	return ok;
 }
@@ -964,7 +969,7 @@ bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piec
 	}
 	unsigned long long tops[32]; CPY(a, tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
-	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->n_waves; a->st.k3_cycles_next += tops[19];
+	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->k3_waves; a->st.k3_cycles_next += tops[19];
 	a->st.k2_cycles_sort += tops[24]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
