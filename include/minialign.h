@@ -6,6 +6,7 @@
  *
  *   mm_opt_init / mm_opt_parse   <- mm_opt_init, mm_opt_parse_argv, presets   (minialign.c:6138, 5771, 5846)
  *   mm_idx_gen / mm_idx_destroy  <- mm_idx_gen, mm_idx_destroy                 (minialign.c:2951, 2703)
+ *   mm_idx_dump / mm_idx_load    <- mm_idx_dump, mm_idx_load                   (minialign.c:3070, 3136)
  *   mm_align_init / _destroy     <- mm_align_init, mm_align_destroy            (minialign.c:4671, 4650)
  *   mm_align_file                <- mm_align_file + mm_print_sam_*             (minialign.c:4725, 5096-5426)
  *   mm_main                      <- main                                       (minialign.c:6451)
@@ -38,6 +39,11 @@ void mm_opt_destroy(mm_opt_t *o);
 /* index over a FASTA file (host build; value-list order and occurrence thresholds as the reference) */
 mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta);
 void mm_idx_destroy(mm_idx_t *mi);
+/* index files (mm_idx_dump / mm_idx_load, minialign.c:3070, 3136; `-d idx.mai` and a reference argument ending in .mai).  The layout is this
+ * library's own (the reference's is a memory image of its tables and changes between its releases); a file may hold several blocks.
+ * mm_idx_dump returns 0 on success; mm_idx_load returns the next block or NULL, with *at_eof telling a clean end of file from a damaged block. */
+int mm_idx_dump(mm_idx_t const *mi, FILE *fp);
+mm_idx_t *mm_idx_load(FILE *fp, int *at_eof);
 uint32_t mm_idx_n_seq(mm_idx_t const *mi);
 uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i);
 /* mm_idx_get (minialign.c:2728) on the host copy: writes up to max values (pos | rid << 32), returns the count */

@@ -250,7 +250,7 @@ struct mm_opt_s {
 	uint32_t wlen = 7000, glen = 7000, min_score = 50; float min_ratio = 0.3f;
 	gaba_params_t p;
 	uint32_t nth = 1;
-	std::string arg_line;
+	std::string arg_line, fnw;       /* fnw: -d, file the index is dumped to (minialign.c:5979 mm_opt_fnw) */
 	mm_opt_s() { memset(&p, 0, sizeof(p)); for(int i = 0; i < 16; i++) p.score_matrix[i] = (i & 3) == (i >> 2) ? 1 : -1; p.gi = 1; p.ge = 1; p.xdrop = 50; }
 };
 namespace {
@@ -310,6 +310,7 @@ int opt_one(mm_opt_t *o, char c, const char *arg)
 		case 't': o->nth = atoi(arg); return 0;
 		case 'W': o->wlen = atoi(arg); return 0;
 		case 'G': o->glen = atoi(arg); return 0;
+		case 'd': o->fnw = arg; return o->fnw.empty();
 		default: fprintf(stderr, "[minialign_amd] unsupported option -%c\n", c); return 1;
 	}
 }
@@ -326,7 +327,7 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
 		const char *a = argv[i];
 		if(a[0] == '-' && a[1]) {
 			const char *arg = a + 2;
-			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWG", a[1])) arg = argv[++i];
+			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGd", a[1])) arg = argv[++i];
 			if(opt_one(o, a[1], arg)) return 1;
 		} else if(nf < max_files) files[nf++] = a;
 	}
@@ -418,6 +419,54 @@ extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 	return mi;
 }
 extern "C" void mm_idx_destroy(mm_idx_t *mi) { delete mi; }
+
+/* index files (-d idx.mai, then `minialign idx.mai reads.fa`; mm_idx_dump / mm_idx_load, minialign.c:3070-3167).  The reference's file is a
+ * memory image of its own tables with pointers turned into offsets, declared unstable across its releases (README.md:198); this one holds the
+ * flattened table the device uses: magic, the parameters, the sequences (name + one byte per base), the slots and the value array.  A file
+ * may hold several such blocks back to back (one per reference file given to -d), as the reference's does. */
+namespace {
+const uint32_t MAI_MAGIC = 0x0141414du;        /* "MAA\x01" */
+struct MaiHead { uint32_t b, w, k, n_occ, occ[4]; uint64_t n_seq, n_slot, n_val, n_keys; };
+}
+extern "C" int mm_idx_dump(mm_idx_t const *mi, FILE *fp)
+{
+	bool ok = true;
+	auto put = [&](const void *p, size_t n) { ok = ok && (n == 0 || fwrite(p, 1, n, fp) == n); };
+	MaiHead h = { mi->b, mi->w, mi->k, mi->n_occ, { mi->occ[0], mi->occ[1], mi->occ[2], mi->occ[3] }, mi->seq.size(), mi->slot.size(), mi->val.size(), mi->n_keys };
+	put(&MAI_MAGIC, 4); put(&h, sizeof(h));
+	for(const HSeq &q : mi->seq) {
+		uint64_t l[2] = { q.name.size(), q.seq.size() };
+		put(l, sizeof(l)); put(q.name.data(), l[0]); put(q.seq.data(), l[1]);
+	}
+	put(mi->slot.data(), mi->slot.size() * sizeof(IdxSlot)); put(mi->val.data(), mi->val.size() * sizeof(uint64_t));
+	return ok && fflush(fp) == 0 ? 0 : 1;
+}
+/* next block of an index file; NULL at the end of the file (*at_eof = 1) or when the block is damaged / of another version (*at_eof = 0) */
+extern "C" mm_idx_t *mm_idx_load(FILE *fp, int *at_eof)
+{
+	if(at_eof) *at_eof = 0;
+	uint32_t magic = 0; size_t got = fread(&magic, 1, 4, fp);
+	if(got == 0) { if(at_eof) *at_eof = 1; return NULL; }
+	MaiHead h;
+	if(got != 4 || magic != MAI_MAGIC || fread(&h, 1, sizeof(h), fp) != sizeof(h)) return NULL;
+	if(h.n_occ == 0 || h.n_occ > 4 || h.k < 2 || h.k > 31 || h.w < 1 || h.w > 31 || h.n_slot == 0 || (h.n_slot & (h.n_slot - 1)) || h.n_val == 0) return NULL;
+	mm_idx_t *mi = new mm_idx_s();
+	mi->b = h.b; mi->w = h.w; mi->k = h.k; mi->n_occ = h.n_occ; memcpy(mi->occ, h.occ, sizeof(h.occ)); mi->n_keys = h.n_keys; mi->mask = h.n_slot - 1;
+	bool ok = true;
+	auto get = [&](void *p, size_t n) { ok = ok && (n == 0 || fread(p, 1, n, fp) == n); };
+	try {
+		for(uint64_t i = 0; ok && i < h.n_seq; i++) {
+			uint64_t l[2] = { 0, 0 }; get(l, sizeof(l));
+			if(!ok || l[0] > (1u << 20) || l[1] > 0xffffffffull) { ok = false; break; }
+			mi->seq.emplace_back(); HSeq &q = mi->seq.back();
+			q.name.resize(l[0]); q.seq.resize(l[1]); get(&q.name[0], l[0]); get(q.seq.data(), l[1]);
+		}
+		if(ok) { mi->slot.resize(h.n_slot); get(mi->slot.data(), h.n_slot * sizeof(IdxSlot)); }
+		if(ok) { mi->val.resize(h.n_val); get(mi->val.data(), h.n_val * sizeof(uint64_t)); }
+	} catch(std::bad_alloc &) { ok = false; }
+	if(!ok || mi->seq.empty()) { delete mi; return NULL; }
+	return mi;
+}
 extern "C" uint32_t mm_idx_n_seq(mm_idx_t const *mi) { return (uint32_t)mi->seq.size(); }
 extern "C" uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i) { return mi->occ[i]; }
 extern "C" uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t max)
@@ -1126,7 +1175,7 @@ extern "C" int mm_batch_wait(mm_align_t *a, mm_batch_t *h)
 extern "C" void mm_batch_free(mm_batch_t *h) { if(h && h->running) { h->th.join(); } delete h; }
 extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
 
-static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out);
+static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = false);
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
 	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
@@ -1135,8 +1184,8 @@ extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 	if(verbose) { fprintf(stderr, "[minialign_amd] parse %.1f ms\n", now_ms() - tv); }
 	return align_reads(a, reads, out);
 }
-/* maps a parsed read set (consumed) and writes its SAM records */
-static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out)
+/* maps a parsed read set (consumed unless keep) and writes its SAM records */
+static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 {
 	const bool verbose = getenv("MM_VERBOSE") != NULL;
 	/*
@@ -1204,40 +1253,83 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out)
 	cv.notify_all();
 	finisher.join();
 	a->rlen_carry = carry;
-	mm_reads_free(reads);
+	if(!keep) mm_reads_free(reads);
 	return rc;
 }
 
+namespace {
+bool ends_with(const char *s, const char *suf) { size_t n = strlen(s), m = strlen(suf); return n >= m && strcmp(s + n - m, suf) == 0; }
+/* minialign -d idx.mai ref.fa [ref2.fa ...]: one index block per reference file, no mapping (main_index, minialign.c:6293-6345) */
+int main_index(mm_opt_t *o, const char *const *files, int nf, double t0)
+{
+	FILE *fp = fopen(o->fnw.c_str(), "wb");
+	if(!fp) { fprintf(stderr, "[E::main_index] failed to open index file `%s' in write mode. Please check file path and its permission.\n", o->fnw.c_str()); return 1; }
+	int rc = 0;
+	for(int i = 0; i < nf && rc == 0; i++) {
+		mm_idx_t *mi = mm_idx_gen(o, files[i]);
+		if(!mi) { fprintf(stderr, "[E::main_index] failed to build index for `%s'. Please check file path and format.\n", files[i]); rc = 1; break; }
+		rc = mm_idx_dump(mi, fp);
+		if(rc) fprintf(stderr, "[E::main_index] failed to write the index to `%s'.\n", o->fnw.c_str());
+		else fprintf(stderr, "[M::main_index::%.3f] built and dumped index for %u target sequence(s).\n", (now_ms() - t0) * 1e-3, mm_idx_n_seq(mi));
+		mm_idx_destroy(mi);
+	}
+	fclose(fp);
+	return rc;
+}
+}
 extern "C" int mm_main(int argc, char **argv)
 {
 	setenv("GPU_MAX_HW_QUEUES", "16", 0);          /* lanes and side streams should not share hardware queues (read when the HIP runtime starts) */
 	mm_opt_t *o = mm_opt_init();
-	const char *files[8]; int nf = 0;
-	if(mm_opt_parse(o, argc, (char const *const *)argv, files, 8, &nf) || nf < 2) {
-		fprintf(stderr, "usage: minialign [-x preset] [-k -w -a -b -p -q -r -Y -s -m -t] ref.fa reads.{fa,fq} > out.sam\n");
+	const char *files[64]; int nf = 0;
+	if(mm_opt_parse(o, argc, (char const *const *)argv, files, 63, &nf) || nf < 1) {
+		fprintf(stderr, "usage: minialign [-x preset] [-k -w -a -b -p -q -r -Y -s -m -t] [-d idx.mai] ref.{fa,mai} reads.{fa,fq} > out.sam\n");
 		mm_opt_destroy(o); return 1;
 	}
 	double t0 = now_ms();
-	/* the first query file is parsed on a thread of its own while the index is built */
+	if(!o->fnw.empty()) { int rc = main_index(o, files, nf, t0); mm_opt_destroy(o); return rc; }
+	if(nf == 1) { fprintf(stderr, "[M::main_align] query-side input redirected to stdin.\n"); files[nf++] = "-"; }     /* minialign.c:6380-6384 */
+	/* the first query file is parsed on a thread of its own while the index is built or loaded */
 	mm_reads_t *first_reads = NULL;
 	std::thread rt([&]() { if(strcmp(files[1], "-") != 0) first_reads = mm_reads_load(files[1]); });
 	std::thread hw([]() { int n = 0; if(hipGetDeviceCount(&n) == hipSuccess && n > 0) { (void)hipFree(0); } });      /* bring the HIP runtime up meanwhile */
-	mm_idx_t *mi = mm_idx_gen(o, files[0]);
-	hw.join();
-	mm_align_t *a = mi ? mm_align_init(o, mi) : NULL;
-	rt.join();
-	if(!mi || !a) { if(first_reads) mm_reads_free(first_reads); if(mi) mm_idx_destroy(mi); mm_opt_destroy(o); return 1; }
-	fprintf(stderr, "[M::main_align::%.3f] loaded/built index for %u target sequence(s).\n", (now_ms() - t0) * 1e-3, mm_idx_n_seq(mi));
-	mm_print_sam_header(a, stdout, o->arg_line.c_str());
-	int rc = 0;
-	for(int i = 1; i < nf && rc == 0; i++) {
-		if(i == 1 && first_reads) { rc = align_reads(a, first_reads, stdout); }
-		else { rc = mm_align_file(a, files[i], stdout); }
-		fprintf(stderr, "[M::main_align::%.3f] finished mapping `%s' onto `%s'.\n", (now_ms() - t0) * 1e-3, files[i], files[0]);
+	/* a prebuilt index (file name ending in .mai) may hold several blocks: every query file is mapped onto each in turn, with a header per block
+	 * (minialign.c:6373, 6413-6436) */
+	const bool prebuilt = ends_with(files[0], ".mai");
+	FILE *pg = prebuilt ? fopen(files[0], "rb") : NULL;
+	int rc = 0, at_eof = 0; uint32_t micnt = 0;
+	bool joined = false;
+	auto join = [&]() { if(!joined) { hw.join(); rt.join(); joined = true; } };
+	if(prebuilt && !pg) { fprintf(stderr, "[E::main_align] failed to build index for `%s'. Please check file path and format.\n", files[0]); rc = 1; }
+	mm_stats_t tot; memset(&tot, 0, sizeof(tot));
+	while(rc == 0) {
+		mm_idx_t *mi = prebuilt ? mm_idx_load(pg, &at_eof) : (micnt == 0 ? mm_idx_gen(o, files[0]) : NULL);
+		if(!mi) {
+			if(prebuilt && (micnt == 0 || !at_eof)) { fprintf(stderr, "[E::main_align] failed to load index block from `%s'. Please check file path and version, or rebuild the index.\n", files[0]); rc = 1; }
+			else if(!prebuilt && micnt == 0) { fprintf(stderr, "[E::main_align] failed to build index for `%s'. Please check file path and format.\n", files[0]); rc = 1; }
+			break;
+		}
+		if(!joined) hw.join();
+		mm_align_t *a = mm_align_init(o, mi);
+		if(!joined) { rt.join(); joined = true; }
+		if(!a) { fprintf(stderr, "[E::main_align] failed to instanciate alignment context.\n"); mm_idx_destroy(mi); rc = 1; break; }
+		fprintf(stderr, "[M::main_align::%.3f] loaded/built index for %u target sequence(s).\n", (now_ms() - t0) * 1e-3, mm_idx_n_seq(mi));
+		mm_print_sam_header(a, stdout, o->arg_line.c_str());
+		for(int i = 1; i < nf && rc == 0; i++) {
+			if(i == 1 && first_reads) { rc = align_reads(a, first_reads, stdout, prebuilt); if(!prebuilt) first_reads = NULL; }      /* kept for the next block of a prebuilt index */
+			else { rc = mm_align_file(a, files[i], stdout); }
+			if(rc) fprintf(stderr, "[E::main_align] failed to map sequence file `%s'. Please check file path and format.\n", files[i]);
+			else fprintf(stderr, "[M::main_align::%.3f] finished mapping `%s' onto `%s'.\n", (now_ms() - t0) * 1e-3, files[i], files[0]);
+		}
+		mm_stats_t st; mm_stats(a, &st, 0);
+		tot.reads += st.reads; tot.bases += st.bases; tot.k1_ms += st.k1_ms; tot.k2_ms += st.k2_ms; tot.k3_ms += st.k3_ms; tot.host_post_ms += st.host_post_ms; tot.host_sam_ms += st.host_sam_ms; tot.reruns += st.reruns;
+		mm_align_destroy(a); mm_idx_destroy(mi); micnt++;
 	}
-	mm_stats_t st; mm_stats(a, &st, 0);
-	fprintf(stderr, "[M::main] %lu reads, %lu bases; kernels: sketch %.1f ms, sort+chain %.1f ms, extend %.1f ms; host post-map %.1f ms, SAM %.1f ms; %lu re-run(s)\n",
-		(unsigned long)st.reads, (unsigned long)st.bases, st.k1_ms, st.k2_ms, st.k3_ms, st.host_post_ms, st.host_sam_ms, (unsigned long)st.reruns);
-	mm_align_destroy(a); mm_idx_destroy(mi); mm_opt_destroy(o);
+	join();
+	if(first_reads) mm_reads_free(first_reads);
+	if(pg) fclose(pg);
+	if(rc == 0) fprintf(stderr, "[M::main] %lu reads, %lu bases; kernels: sketch %.1f ms, sort+chain %.1f ms, extend %.1f ms; host post-map %.1f ms, SAM %.1f ms; %lu re-run(s)\n",
+		(unsigned long)tot.reads, (unsigned long)tot.bases, tot.k1_ms, tot.k2_ms, tot.k3_ms, tot.host_post_ms, tot.host_sam_ms, (unsigned long)tot.reruns);
+	mm_opt_destroy(o);
 	return rc;
 }

@@ -87,3 +87,46 @@ def test_product_cigar_printer_callbacks_match_dump():
             base = buf.ctypes.data + 8
             clen = fn(PR(pr), None, ctypes.c_void_p(base), ctypes.c_uint64(ofs), ctypes.c_uint64(ln))
             assert b''.join(got).decode() == want and clen == len(want)
+
+
+def test_host_index_matches_oracle_and_survives_dump_and_load(tmp_path):
+    """mm_idx_gen of the product is host code (no GPU): occurrence thresholds and value lists against the oracle's index, then the same
+    answers from a block written by `minialign -d` (mm_idx_dump) and read back (mm_idx_load); a cut-off file is refused, not half-loaded."""
+    import subprocess, numpy as np, mmlib as M
+    ref = str(tmp_path / 'ref.fa'); ref2 = str(tmp_path / 'ref2.fa'); mai = str(tmp_path / 'idx.mai')
+    M.gensim('genome', 901, 200000, 3, 0.15, out=ref); M.gensim('genome', 902, 50000, 1, 0.0, out=ref2)
+    L = ctypes.CDLL(os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so'))
+    for f in ('mm_opt_init', 'mm_idx_gen', 'mm_idx_load'): getattr(L, f).restype = ctypes.c_void_p
+    libc = ctypes.CDLL(None); libc.fopen.restype = ctypes.c_void_p; libc.fclose.argtypes = [ctypes.c_void_p]
+    o = ctypes.c_void_p(L.mm_opt_init())
+    argv = (ctypes.c_char_p * 3)(b'minialign', b'-xpacbio', ref.encode()); files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
+    assert L.mm_opt_parse(o, 3, argv, files, 8, ctypes.byref(nf)) == 0
+    mi = ctypes.c_void_p(L.mm_idx_gen(o, ref.encode())); assert mi
+    refseq = M.read_fasta(ref); ora = M.OracleMM('pacbio', refseq)
+    keys = [int(m) >> 8 for _, q in refseq for m in ora.sketch(q)[::37]] + [12345, 1 << 29]
+    buf = (ctypes.c_uint64 * 65536)()
+    def answers(h):
+        return [L.mm_idx_n_seq(h)] + [L.mm_idx_occ(h, i) for i in range(3)] + [[int(buf[i]) for i in range(L.mm_idx_get(h, ctypes.c_uint64(k), buf, 65536))] for k in keys]
+    want = answers(mi)
+    assert want[1:4] == ora.occ()[:3]
+    assert want[4:] == [[int(v) for v in ora.idx_get(k)] for k in keys]
+    assert sum(len(v) for v in want[4:]) > len(keys) // 2
+    # -d: two reference files -> two blocks in one file; no GPU is touched on this path
+    cli = os.path.join(ROOT, 'minialign_amd', 'minialign')
+    r = subprocess.run([cli, '-xpacbio', '-d', mai, ref, ref2], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == b'', r.stderr.decode()
+    fp = ctypes.c_void_p(libc.fopen(mai.encode(), b'rb')); eof = ctypes.c_int(0)
+    m1 = ctypes.c_void_p(L.mm_idx_load(fp, ctypes.byref(eof))); assert m1 and eof.value == 0
+    assert answers(m1) == want
+    m2 = ctypes.c_void_p(L.mm_idx_load(fp, ctypes.byref(eof))); assert m2 and L.mm_idx_n_seq(m2) == 1
+    assert not L.mm_idx_load(fp, ctypes.byref(eof)) and eof.value == 1
+    libc.fclose(fp)
+    # a truncated block and a foreign file
+    data = open(mai, 'rb').read()
+    for name, blob in (('cut.mai', data[:len(data) // 3]), ('other.mai', b'MAI\x08' + data[4:])):
+        p = str(tmp_path / name); open(p, 'wb').write(blob)
+        fp = ctypes.c_void_p(libc.fopen(p.encode(), b'rb'))
+        assert not L.mm_idx_load(fp, ctypes.byref(eof)) and eof.value == 0
+        libc.fclose(fp)
+    for h in (mi, m1, m2): L.mm_idx_destroy(h)
+    L.mm_opt_destroy(o)

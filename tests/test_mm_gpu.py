@@ -81,3 +81,31 @@ def test_many_batches_on_two_lanes_give_the_same_sam(workdir):
         got = _strip_pg(r.stdout)
         assert got == want, _first_diff(got, want)
     assert want == _run(os.path.join(M.ROOT, 'oracle', 'ora_minialign'), s['preset'], ref, rd)
+
+
+def test_very_long_reads_with_a_small_workspace_budget(workdir):
+    """the DP workspace of a persistent wave grows with the longest read of the batch; MM_SLAB_GB caps what a lane may take, in which
+    case fewer waves are launched.  Reads of tens of kilobases under a 1 GB cap against the oracle."""
+    s = dict(name='g_long', preset='pacbio', genome=(341, 900000, 2, 0.10), reads=(342, 1.2, 'pacbio', 'fa', 40000, 8000))
+    ref, rd = make_inputs(s, workdir)
+    r = subprocess.run([CLI, '-x' + s['preset'], ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='1'))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = _strip_pg(r.stdout)
+    assert got == _run(CLI, s['preset'], ref, rd)
+    want = _run(os.path.join(M.ROOT, 'oracle', 'ora_minialign'), s['preset'], ref, rd)
+    assert got == want, _first_diff(got, want)
+
+
+def test_prebuilt_index_file_gives_the_same_sam(workdir):
+    """`minialign -d idx.mai ref.fa` then `minialign idx.mai reads.fa` (main_index / the .mai branch of main_align, minialign.c:6293-6436):
+    same records as the on-the-fly index; reads from stdin when no query file is named; two blocks give two headers and both sets of records"""
+    s = dict(name='g_mai', preset='pacbio', genome=(371, 250000, 3, 0.10), reads=(372, 0.8, 'pacbio', 'fa', 3000, 1000))
+    ref, rd = make_inputs(s, workdir)
+    mai = os.path.join(workdir, 'g_mai.mai')
+    want = _run(CLI, s['preset'], ref, rd)
+    assert subprocess.run([CLI, '-x' + s['preset'], '-d', mai, ref]).returncode == 0
+    assert _run(CLI, s['preset'], mai, rd) == want
+    r = subprocess.run([CLI, '-x' + s['preset'], mai], stdin=open(rd, 'rb'), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and _strip_pg(r.stdout) == want
+    assert subprocess.run([CLI, '-x' + s['preset'], '-d', mai, ref, ref]).returncode == 0
+    assert _run(CLI, s['preset'], mai, rd) == want + want
