@@ -32,7 +32,7 @@ struct DevIndex {
 	const uint32_t *seq_len;                           /* per reference sequence */
 	const uint64_t *seq_off;                           /* first base of each reference sequence in the a-side arena */
 	uint32_t n_seq, k, w, n_occ;
-	uint32_t occ[4];
+	uint32_t occ[8];
 };
 __device__ __forceinline__ uint64_t idx_hash(uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; }
 

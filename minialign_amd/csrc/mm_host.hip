@@ -120,7 +120,7 @@ static void parse_fasta_span(const char *p, const char *end, const uint8_t *enc,
 		p = nl ? nl + 1 : end;
 	}
 }
-bool read_seq_file(const char *fn, std::vector<HSeq> &out)
+bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1)
 {
 	FILE *fp = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
 	if(!fp) return false;
@@ -182,8 +182,8 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out)
 		p = nl ? nl + 1 : end;
 	}
 	}
-	/* -L 1 (minialign.c:2077): empty records are dropped */
-	out.erase(std::remove_if(out.begin(), out.end(), [](const HSeq &s) { return s.seq.empty(); }), out.end());
+	/* -L (default 1, minialign.c:2077, 6145): records shorter than the limit are dropped, reference and query side alike */
+	out.erase(std::remove_if(out.begin(), out.end(), [min_len](const HSeq &s) { return s.seq.size() < min_len; }), out.end());
 	return true;
 }
 
@@ -246,7 +246,8 @@ void sketch_host(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t w, std::
  * options
  * ============================================================================================= */
 struct mm_opt_s {
-	uint32_t k = 15, w = 32, b = 14, n_frq = 3; float frq[4] = { 0.05f, 0.01f, 0.001f, 0 };
+	uint32_t k = 15, w = 32, b = 14, n_frq = 3; float frq[8] = { 0.05f, 0.01f, 0.001f, 0 };     /* up to MAX_FRQ_CNT = 7 thresholds, minialign.c:29 */
+	uint32_t min_len = 1, help = 0;
 	uint32_t wlen = 7000, glen = 7000, min_score = 50; float min_ratio = 0.3f;
 	gaba_params_t p;
 	uint32_t nth = 1;
@@ -293,26 +294,71 @@ int opt_preset(mm_opt_t *o, const char *name)     /* preset tree, minialign.c:58
 	if(parts[0] == "ava") { opt_line(o, "-k15 -w5 -a2 -b3 -p0 -q2 -Y50 -s30 -m0.05"); return 0; }
 	return 1;
 }
+/* the option handlers of minialign.c:5990-6099 with their range checks; a failed check is an error (the reference counts it and exits 1) */
+bool opt_fail(const char *msg) { fprintf(stderr, "[E::mm_opt_parse] %s\n", msg); return true; }
+template<typename F> void split_each(const char *arg, const char *delims, F fn)          /* mm_split_foreach */
+{
+	int i = 0;
+	for(const char *p = arg; ; ) { const char *e = p; while(*e && !strchr(delims, *e)) e++; if(e > p) fn(i++, std::string(p, e)); if(!*e) break; p = e + 1; }
+}
 int opt_one(mm_opt_t *o, char c, const char *arg)
 {
+	auto base_of = [](char ch) -> int { switch(ch) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': case 'U': return 4; default: return 0; } };     /* idxaf, minialign.c:232 */
 	switch(c) {
 		case 'x': return opt_preset(o, arg);
-		case 'k': o->k = atoi(arg); return !(o->k > 1 && o->k < 32);
-		case 'w': o->w = atoi(arg); return !(o->w > 1 && o->w < 32);
-		case 'a': { int m = atoi(arg); for(int i = 0; i < 16; i++) if((i & 3) == (i >> 2)) o->p.score_matrix[i] = (int8_t)m; return !(m > 0 && m < 7); }
-		case 'b': { int x = atoi(arg); for(int i = 0; i < 16; i++) if((i & 3) != (i >> 2)) o->p.score_matrix[i] = (int8_t)-x; return !(x > 0 && x < 7); }
-		case 'p': o->p.gi = (int8_t)atoi(arg); return 0;
-		case 'q': o->p.ge = (int8_t)atoi(arg); return 0;
-		case 'r': { o->p.gfa = o->p.gfb = (int8_t)atoi(arg); const char *cm = strchr(arg, ','); if(cm) o->p.gfb = (int8_t)atoi(cm + 1); return 0; }
-		case 'Y': o->p.xdrop = (int8_t)atoi(arg); return 0;
-		case 's': o->min_score = atoi(arg); return 0;
-		case 'm': o->min_ratio = (float)atof(arg); return 0;
-		case 't': o->nth = atoi(arg); return 0;
+		case 'k': o->k = atoi(arg); return !(o->k > 1 && o->k < 32) && opt_fail("k must be inside [1,32).");
+		case 'w': o->w = atoi(arg); return !(o->w > 1 && o->w < 32) && opt_fail("w must be inside [1,32).");
+		case 'B': o->b = atoi(arg); return !(o->b > 1 && o->b < 32) && opt_fail("b must be inside [1,32).");
+		case 'f': {
+			bool bad = false; o->n_frq = 0;
+			split_each(arg, ",;:/", [&](int i, const std::string &t) {
+				if(i >= 7) { bad = true; return; }
+				float f = o->frq[o->n_frq++] = (float)atof(t.c_str());
+				if(!(f >= 0.0 && f < 1.0) || (i > 0 && !(o->frq[i - 1] > o->frq[i]))) bad = true;
+			});
+			return (bad || o->n_frq == 0) && opt_fail("frequency thresholds (-f) must be inside [0,1), descending, at most 7.");
+		}
+		case 'L': o->min_len = atoi(arg); return !(o->min_len > 0) && opt_fail("minimum sequence length must be > 0.");
+		case 'a': { int m = atoi(arg); for(int i = 0; i < 16; i++) if((i & 3) == (i >> 2)) o->p.score_matrix[i] = (int8_t)m; return !(m > 0 && m < 7) && opt_fail("match award (-a) must be inside [1,7]."); }
+		case 'b': { int x = atoi(arg); for(int i = 0; i < 16; i++) if((i & 3) != (i >> 2)) o->p.score_matrix[i] = (int8_t)-x; return !(x > 0 && x < 7) && opt_fail("mismatch penalty (-b) must be inside [1,7]."); }
+		case 'e': {
+			bool bad = false;
+			split_each(arg, ",;:/", [&](int, const std::string &t) {
+				if(t.size() < 3 || !base_of(t[0]) || !base_of(t[1])) { bad = true; return; }
+				o->p.score_matrix[(base_of(t[1]) - 1) * 4 + (base_of(t[0]) - 1)] += (int8_t)atoi(t.c_str() + 2);
+			});
+			return bad && opt_fail("unknown base in score modifier (-e).");
+		}
+		case 'p': { int gi = atoi(arg); o->p.gi = (int8_t)gi; return !(gi < 32) && opt_fail("gap open penalty (-p) must be inside [0,32]."); }
+		case 'q': { int ge = atoi(arg); o->p.ge = (int8_t)ge; return !(ge > 0 && ge < 32) && opt_fail("gap extension penalty (-q) must be inside [1,32]."); }
+		case 'r': {
+			int g[2] = { 0, 0 };
+			split_each(arg, ",;:/", [&](int i, const std::string &t) { if(i == 0) g[0] = g[1] = atoi(t.c_str()); else if(i == 1) g[1] = atoi(t.c_str()); });
+			o->p.gfa = (int8_t)g[0]; o->p.gfb = (int8_t)g[1];
+			return !(g[0] >= 0 && g[0] < 32 && g[1] >= 0 && g[1] < 32) && opt_fail("short-gap extension penalty (-r) must be inside [0,32].");
+		}
+		case 'Y': { int x = atoi(arg); o->p.xdrop = (int8_t)x; return !(x > 10 && x < 128) && opt_fail("X-drop cutoff must be inside [10,128]."); }
+		case 's': o->min_score = atoi(arg); return !(o->min_score > 0) && opt_fail("minimum alignment score must be > 0.");
+		case 'm': o->min_ratio = (float)atof(arg); return !(o->min_ratio > 0.0 && o->min_ratio < 1.0) && opt_fail("minimum alignment score ratio must be inside [0.0,1.0].");
+		case 't': o->nth = atoi(arg); return 0;             /* host threads of the reference; the device path sizes its own */
 		case 'W': o->wlen = atoi(arg); return 0;
 		case 'G': o->glen = atoi(arg); return 0;
 		case 'd': o->fnw = arg; return o->fnw.empty();
-		default: fprintf(stderr, "[minialign_amd] unsupported option -%c\n", c); return 1;
+		case '1': case '2': return 0;                      /* input batch / output buffer sizes of the reference's host pipeline: accepted, no meaning here */
+		case 'v': return 0;
+		case 'h': o->help = 1; return 0;
+		default: fprintf(stderr, "[E::mm_opt_parse] unsupported option -%c\n", c); return 1;
 	}
+}
+/* mm_opt_check_sanity, minialign.c:6097-6112 */
+int opt_check(mm_opt_t *o)
+{
+	int x = 0; for(int i = 0; i < 16; i++) x = std::max(x, -(int)o->p.score_matrix[i]);
+	const int gfa = o->p.gfa, gfb = o->p.gfb, ge = o->p.ge;
+	if(!(gfa == 0 || gfa > ge) || !(gfb == 0 || gfb > ge)) return opt_fail("short-gap extension penalty (-r) must be larger than gap extension penalty.");
+	if((gfa == 0) != (gfb == 0)) return opt_fail("short-gap extension penalty (-r) must be set for both sides.");
+	if(!(gfa == 0 || gfb == 0 || gfa + gfb > x)) return opt_fail("short-gap extension penalty (-r) must not be greater than mismatch penalty.");
+	return 0;
 }
 } /* anonymous */
 
@@ -327,11 +373,12 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
 		const char *a = argv[i];
 		if(a[0] == '-' && a[1]) {
 			const char *arg = a + 2;
-			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGd", a[1])) arg = argv[++i];
+			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGdfBLe12", a[1])) arg = argv[++i];
 			if(opt_one(o, a[1], arg)) return 1;
 		} else if(nf < max_files) files[nf++] = a;
 	}
 	if(n_files) *n_files = nf;
+	if(opt_check(o)) return 1;
 	if(o->w >= 32) o->w = (uint32_t)(int)(2.0 / 3.0 * o->k + .499);       /* minialign.c:6111 */
 	return 0;
 }
@@ -340,7 +387,7 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
  * index (host): mm_idx_gen, minialign.c:2951-3040
  * ============================================================================================= */
 struct mm_idx_s {
-	uint32_t b, w, k, n_occ; uint32_t occ[4];
+	uint32_t b, w, k, n_occ; uint32_t occ[8];
 	std::vector<HSeq> seq;
 	/* flattened table, also what the device gets */
 	std::vector<IdxSlot> slot; uint64_t mask;
@@ -351,7 +398,7 @@ struct mm_idx_s {
 extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 {
 	mm_idx_t *mi = new mm_idx_s();
-	if(!read_seq_file(ref_fasta, mi->seq) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); delete mi; return NULL; }
+	if(!read_seq_file(ref_fasta, mi->seq, o->min_len) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); delete mi; return NULL; }
 	uint32_t b = std::min(o->k * 2, o->b);
 	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq;
 	const uint64_t nb = 1ull << b, bmask = nb - 1;
@@ -425,14 +472,15 @@ extern "C" void mm_idx_destroy(mm_idx_t *mi) { delete mi; }
  * flattened table the device uses: magic, the parameters, the sequences (name + one byte per base), the slots and the value array.  A file
  * may hold several such blocks back to back (one per reference file given to -d), as the reference's does. */
 namespace {
-const uint32_t MAI_MAGIC = 0x0141414du;        /* "MAA\x01" */
-struct MaiHead { uint32_t b, w, k, n_occ, occ[4]; uint64_t n_seq, n_slot, n_val, n_keys; };
+const uint32_t MAI_MAGIC = 0x0241414du;        /* "MAA\x02" */
+struct MaiHead { uint32_t b, w, k, n_occ, occ[8]; uint64_t n_seq, n_slot, n_val, n_keys; };
 }
 extern "C" int mm_idx_dump(mm_idx_t const *mi, FILE *fp)
 {
 	bool ok = true;
 	auto put = [&](const void *p, size_t n) { ok = ok && (n == 0 || fwrite(p, 1, n, fp) == n); };
-	MaiHead h = { mi->b, mi->w, mi->k, mi->n_occ, { mi->occ[0], mi->occ[1], mi->occ[2], mi->occ[3] }, mi->seq.size(), mi->slot.size(), mi->val.size(), mi->n_keys };
+	MaiHead h; memset(&h, 0, sizeof(h));
+	h.b = mi->b; h.w = mi->w; h.k = mi->k; h.n_occ = mi->n_occ; memcpy(h.occ, mi->occ, sizeof(h.occ)); h.n_seq = mi->seq.size(); h.n_slot = mi->slot.size(); h.n_val = mi->val.size(); h.n_keys = mi->n_keys;
 	put(&MAI_MAGIC, 4); put(&h, sizeof(h));
 	for(const HSeq &q : mi->seq) {
 		uint64_t l[2] = { q.name.size(), q.seq.size() };
@@ -449,7 +497,7 @@ extern "C" mm_idx_t *mm_idx_load(FILE *fp, int *at_eof)
 	if(got == 0) { if(at_eof) *at_eof = 1; return NULL; }
 	MaiHead h;
 	if(got != 4 || magic != MAI_MAGIC || fread(&h, 1, sizeof(h), fp) != sizeof(h)) return NULL;
-	if(h.n_occ == 0 || h.n_occ > 4 || h.k < 2 || h.k > 31 || h.w < 1 || h.w > 31 || h.n_slot == 0 || (h.n_slot & (h.n_slot - 1)) || h.n_val == 0) return NULL;
+	if(h.n_occ == 0 || h.n_occ > 7 || h.k < 2 || h.k > 31 || h.w < 1 || h.w > 31 || h.n_slot == 0 || (h.n_slot & (h.n_slot - 1)) || h.n_val == 0) return NULL;
 	mm_idx_t *mi = new mm_idx_s();
 	mi->b = h.b; mi->w = h.w; mi->k = h.k; mi->n_occ = h.n_occ; memcpy(mi->occ, h.occ, sizeof(h.occ)); mi->n_keys = h.n_keys; mi->mask = h.n_slot - 1;
 	bool ok = true;
@@ -861,7 +909,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	(void)hipMemcpy(a->d_seq_off, off.data(), off.size() * 8, hipMemcpyHostToDevice);
 	a->dix.slot = a->d_slot; a->dix.mask = mi->mask; a->dix.val = a->d_val; a->dix.seq_len = a->d_seq_len; a->dix.seq_off = a->d_seq_off;
 	a->dix.n_seq = (uint32_t)mi->seq.size(); a->dix.k = mi->k; a->dix.w = mi->w; a->dix.n_occ = mi->n_occ;
-	for(int i = 0; i < 4; i++) a->dix.occ[i] = i < (int)mi->n_occ ? mi->occ[i] : 0;
+	for(int i = 0; i < 8; i++) a->dix.occ[i] = i < (int)mi->n_occ ? mi->occ[i] : 0;
 	hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev); a->dev = dev;
 	a->n_waves = (uint32_t)prop.multiProcessorCount * 4 * MM_K3_WAVES_PER_SIMD;       /* persistent waves of the extension kernel */
 	memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms();
@@ -1088,10 +1136,12 @@ extern "C" int mm_align_batch(mm_align_t *a, uint8_t const *bases, uint32_t cons
 }
 
 /* phase-split entry points over a parsed read set (bench.py times mm_batch_run alone: inputs resident in HBM) */
-extern "C" mm_reads_t *mm_reads_load(char const *fn)
+static mm_reads_t *reads_load(char const *fn, uint32_t min_len);
+extern "C" mm_reads_t *mm_reads_load(char const *fn) { return reads_load(fn, 1); }
+static mm_reads_t *reads_load(char const *fn, uint32_t min_len)
 {
 	mm_reads_t *r = new mm_reads_s();
-	if(!read_seq_file(fn, r->r)) { delete r; return NULL; }
+	if(!read_seq_file(fn, r->r, min_len)) { delete r; return NULL; }
 	for(const HSeq &s : r->r) r->bases += s.seq.size();
 	return r;
 }
@@ -1179,7 +1229,7 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = 
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
 	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
-	mm_reads_t *reads = mm_reads_load(reads_fn);
+	mm_reads_t *reads = reads_load(reads_fn, a->o.min_len);
 	if(!reads) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
 	if(verbose) { fprintf(stderr, "[minialign_amd] parse %.1f ms\n", now_ms() - tv); }
 	return align_reads(a, reads, out);
@@ -1291,7 +1341,7 @@ extern "C" int mm_main(int argc, char **argv)
 	if(nf == 1) { fprintf(stderr, "[M::main_align] query-side input redirected to stdin.\n"); files[nf++] = "-"; }     /* minialign.c:6380-6384 */
 	/* the first query file is parsed on a thread of its own while the index is built or loaded */
 	mm_reads_t *first_reads = NULL;
-	std::thread rt([&]() { if(strcmp(files[1], "-") != 0) first_reads = mm_reads_load(files[1]); });
+	std::thread rt([&]() { if(strcmp(files[1], "-") != 0) first_reads = reads_load(files[1], o->min_len); });
 	std::thread hw([]() { int n = 0; if(hipGetDeviceCount(&n) == hipSuccess && n > 0) { (void)hipFree(0); } });      /* bring the HIP runtime up meanwhile */
 	/* a prebuilt index (file name ending in .mai) may hold several blocks: every query file is mapped onto each in turn, with a header per block
 	 * (minialign.c:6373, 6413-6436) */

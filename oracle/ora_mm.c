@@ -76,50 +76,130 @@ RADIX_SORT(128x, v4u32_t, KEY128, 8)        /* minialign.c:203-204 */
 RADIX_SORT(64x, v2u32_t, KEY64, 4)          /* minialign.c:205-206 */
 
 /* ---- options ---- */
-static void opt_apply(om_opt_t *o, char const *s)
+/* one option letter with its argument (the handlers of minialign.c:5990-6099); returns nonzero where the reference's range check fails */
+static int opt_preset(om_opt_t *o, char const *preset);
+static int opt_one(om_opt_t *o, char c, char const *arg, size_t l)
 {
+	char buf[256]; if(l > 255) { l = 255; } memcpy(buf, arg, l); buf[l] = 0; arg = buf;
+	static uint8_t const base_idx[128] = { ['A'] = 1, ['C'] = 2, ['G'] = 3, ['T'] = 4, ['U'] = 4 };
+	switch(c) {
+		case 'x': return opt_preset(o, arg);
+		case 'k': o->k = (uint32_t)atoi(arg); return !(o->k > 1 && o->k < 32);
+		case 'w': o->w = (uint32_t)atoi(arg); return !(o->w > 1 && o->w < 32);
+		case 'B': o->b = (uint32_t)atoi(arg); return !(o->b > 1 && o->b < 32);
+		case 'f': {
+			int bad = 0; o->n_frq = 0;
+			for(char *p = buf; *p; ) {
+				char *e = p; while(*e && !strchr(",;:/", *e)) { e++; }
+				if(e > p) {
+					if(o->n_frq >= 7) { return 1; }
+					float f = o->frq[o->n_frq] = (float)atof(p);
+					if(!(f >= 0.0 && f < 1.0) || (o->n_frq > 0 && !(o->frq[o->n_frq - 1] > f))) { bad = 1; }
+					o->n_frq++;
+				}
+				if(!*e) { break; } p = e + 1;
+			}
+			return bad || o->n_frq == 0;
+		}
+		case 'L': o->min_len = (uint32_t)atoi(arg); return !(o->min_len > 0);
+		case 'a': { int m = atoi(arg); for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 2)) { o->p.score_matrix[i] = (int8_t)m; } } return !(m > 0 && m < 7); }
+		case 'b': { int x = atoi(arg); for(int i = 0; i < 16; i++) { if((i & 3) != (i >> 2)) { o->p.score_matrix[i] = (int8_t)-x; } } return !(x > 0 && x < 7); }
+		case 'e': {                      /* mm_opt_mod, minialign.c:6045: "<query base><ref base><delta>", ... */
+			for(char *p = buf; *p; ) {
+				char *e = p; while(*e && !strchr(",;:/", *e)) { e++; }
+				if(e > p) {
+					if(e - p < 3 || (p[0] & 0x80) || (p[1] & 0x80) || !base_idx[(int)p[0]] || !base_idx[(int)p[1]]) { return 1; }
+					char sv = *e; *e = 0;
+					o->p.score_matrix[(base_idx[(int)p[1]] - 1) * 4 + (base_idx[(int)p[0]] - 1)] += (int8_t)atoi(p + 2);
+					*e = sv;
+				}
+				if(!*e) { break; } p = e + 1;
+			}
+			return 0;
+		}
+		case 'p': { int gi = atoi(arg); o->p.gi = (int8_t)gi; return !(gi < 32); }
+		case 'q': { int ge = atoi(arg); o->p.ge = (int8_t)ge; return !(ge > 0 && ge < 32); }
+		case 'r': {
+			int g0 = atoi(arg), g1 = g0; char const *cm = arg; while(*cm && !strchr(",;:/", *cm)) { cm++; } if(*cm) { g1 = atoi(cm + 1); }
+			o->p.gfa = (int8_t)g0; o->p.gfb = (int8_t)g1;
+			return !(g0 >= 0 && g0 < 32 && g1 >= 0 && g1 < 32);
+		}
+		case 'Y': { int x = atoi(arg); o->p.xdrop = (int8_t)x; return !(x > 10 && x < 128); }
+		case 's': o->min_score = (uint32_t)atoi(arg); return !(o->min_score > 0);
+		case 'm': o->min_ratio = (float)atof(arg); return !(o->min_ratio > 0.0 && o->min_ratio < 1.0);
+		case 'W': o->wlen = (uint32_t)atoi(arg); return 0;
+		case 'G': o->glen = (uint32_t)atoi(arg); return 0;
+		case 't': case '1': case '2': case 'v': return 0;
+		default: return 1;
+	}
+}
+static int opt_apply(om_opt_t *o, char const *s)
+{
+	int rc = 0;
 	while(*s) {
 		while(*s == ' ') { s++; }
 		if(*s != '-') { break; }
 		char c = s[1]; s += 2;
 		char const *arg = s;
 		while(*s && *s != ' ') { s++; }
-		switch(c) {
-			case 'k': o->k = (uint32_t)atoi(arg); break;
-			case 'w': o->w = (uint32_t)atoi(arg); break;
-			case 'a': { int m = atoi(arg); for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 2)) { o->p.score_matrix[i] = (int8_t)m; } } break; }
-			case 'b': { int x = atoi(arg); for(int i = 0; i < 16; i++) { if((i & 3) != (i >> 2)) { o->p.score_matrix[i] = (int8_t)-x; } } break; }
-			case 'p': o->p.gi = (int8_t)atoi(arg); break;
-			case 'q': o->p.ge = (int8_t)atoi(arg); break;
-			case 'r': { o->p.gfa = o->p.gfb = (int8_t)atoi(arg); char const *cm = arg; while(cm < s && *cm != ',') { cm++; } if(cm < s) { o->p.gfb = (int8_t)atoi(cm + 1); } break; }
-			case 'Y': o->p.xdrop = (int8_t)atoi(arg); break;
-			case 's': o->min_score = (uint32_t)atoi(arg); break;
-			case 'm': o->min_ratio = (float)atof(arg); break;
-			default: break;
-		}
+		rc |= opt_one(o, c, arg, (size_t)(s - arg));
 	}
+	return rc;
 }
-int om_opt_init(om_opt_t *o, char const *preset)
+static void opt_defaults(om_opt_t *o)
 {
 	memset(o, 0, sizeof(*o));
 	o->k = 15; o->w = 32; o->b = 14; o->n_frq = 3; o->frq[0] = 0.05f; o->frq[1] = 0.01f; o->frq[2] = 0.001f;
-	o->wlen = 7000; o->glen = 7000; o->min_score = 50; o->min_ratio = 0.3f;
+	o->wlen = 7000; o->glen = 7000; o->min_score = 50; o->min_ratio = 0.3f; o->min_len = 1;
 	for(int i = 0; i < 16; i++) { o->p.score_matrix[i] = (i & 3) == (i >> 2) ? 1 : -1; }
 	o->p.gi = 1; o->p.ge = 1; o->p.gfa = 0; o->p.gfb = 0; o->p.xdrop = 50;
+}
+static int opt_preset(om_opt_t *o, char const *preset)
+{
+	/* preset tree, minialign.c:5853-5878 (the paths used by BASELINE's configs) */
 	int rc = 0;
-	if(preset && *preset) {
-		/* preset tree, minialign.c:5853-5878 (the paths used by BASELINE's configs) */
-		if(strcmp(preset, "pacbio") == 0 || strcmp(preset, "pacbio.clr") == 0) { opt_apply(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3"); }
-		else if(strcmp(preset, "pacbio.ccs") == 0) { opt_apply(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3"); opt_apply(o, "-b5 -p6 -p2"); }
-		else if(strncmp(preset, "ont", 3) == 0) {
-			opt_apply(o, "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3");
-			if(strcmp(preset, "ont.1d") == 0) { opt_apply(o, "-a2"); }
-			else if(strcmp(preset, "ont.1dsq") == 0 || strcmp(preset, "ont.2d") == 0) { opt_apply(o, "-a2 -b6 -r4,4"); }
-			else if(strcmp(preset, "ont") != 0) { rc = 1; }
-		} else { rc = 1; }
-	}
+	if(strcmp(preset, "pacbio") == 0 || strcmp(preset, "pacbio.clr") == 0) { opt_apply(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3"); }
+	else if(strcmp(preset, "pacbio.ccs") == 0) { opt_apply(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3"); opt_apply(o, "-b5 -p6 -p2"); }
+	else if(strncmp(preset, "ont", 3) == 0) {
+		opt_apply(o, "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3");
+		if(strcmp(preset, "ont.1d") == 0) { opt_apply(o, "-a2"); }
+		else if(strcmp(preset, "ont.1dsq") == 0 || strcmp(preset, "ont.2d") == 0) { opt_apply(o, "-a2 -b6 -r4,4"); }
+		else if(strcmp(preset, "ont") != 0) { rc = 1; }
+	} else { rc = 1; }
+	return rc;
+}
+static int opt_check(om_opt_t *o)           /* mm_opt_check_sanity, minialign.c:6097-6112 */
+{
+	int x = 0; for(int i = 0; i < 16; i++) { if(-(int)o->p.score_matrix[i] > x) { x = -(int)o->p.score_matrix[i]; } }
+	int const gfa = o->p.gfa, gfb = o->p.gfb, ge = o->p.ge;
+	int rc = 0;
+	if(!(gfa == 0 || gfa > ge) || !(gfb == 0 || gfb > ge)) { rc = 1; }
+	if((gfa == 0) != (gfb == 0)) { rc = 1; }
+	if(!(gfa == 0 || gfb == 0 || gfa + gfb > x)) { rc = 1; }
 	if(o->w >= 32) { o->w = (uint32_t)(int)(2.0 / 3.0 * o->k + .499); }   /* minialign.c:6111 */
 	return rc;
+}
+int om_opt_init(om_opt_t *o, char const *preset)
+{
+	opt_defaults(o);
+	int rc = 0;
+	if(preset && *preset) { rc = opt_preset(o, preset); }
+	return rc | opt_check(o);
+}
+int om_opt_parse(om_opt_t *o, int argc, char const *const *argv, char const **files, int max_files, int *n_files)
+{
+	opt_defaults(o);
+	int rc = 0, nf = 0;
+	for(int i = 1; i < argc; i++) {
+		char const *a = argv[i];
+		if(a[0] == '-' && a[1]) {
+			char const *arg = a + 2;
+			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGfBLe12", a[1])) { arg = argv[++i]; }
+			rc |= opt_one(o, a[1], arg, strlen(arg));
+		} else if(nf < max_files) { files[nf++] = a; }
+	}
+	if(n_files) { *n_files = nf; }
+	return rc | opt_check(o);
 }
 
 /* ---- FASTA / FASTQ (bseq_read_fasta, minialign.c:1996-2090; encoding minialign.c:223-229) ---- */
@@ -154,11 +234,15 @@ om_seqs_t om_read_fasta(char const *fn)
 		}
 	}
 	free(line); fclose(fp);
-	/* -L 1: sequences shorter than min_len = 1 are dropped (minialign.c:2077) */
-	uint64_t j = 0;
-	for(uint64_t i = 0; i < v.n; i++) { if(v.a[i].l_seq >= 1) { v.a[j++] = v.a[i]; } else { free(v.a[i].name); free(v.a[i].seq); } }
-	r.a = v.a; r.n = j;
+	r.a = v.a; r.n = v.n;
+	om_seqs_drop_short(&r, 1);       /* -L 1, the default (minialign.c:6145) */
 	return r;
+}
+void om_seqs_drop_short(om_seqs_t *s, uint32_t min_len)       /* sequences shorter than min_len are squashed by the reader (minialign.c:2077) */
+{
+	uint64_t j = 0;
+	for(uint64_t i = 0; i < s->n; i++) { if(s->a[i].l_seq >= min_len) { s->a[j++] = s->a[i]; } else { free(s->a[i].name); free(s->a[i].seq); free(s->a[i].qual); } }
+	s->n = j;
 }
 void om_seqs_free(om_seqs_t *s)
 {
@@ -1024,14 +1108,19 @@ int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *
 	om_opt_t o;
 	if(om_opt_init(&o, preset)) { return 1; }
 	o.arg_line = arg_line;
-	om_seqs_t ref = om_read_fasta(ref_fn);
+	return om_main_opt(&o, ref_fn, query_fn, out, map_seconds, bases);
+}
+int om_main_opt(om_opt_t const *op, char const *ref_fn, char const *query_fn, FILE *out, double *map_seconds, uint64_t *bases)
+{
+	om_opt_t o = *op;
+	om_seqs_t ref = om_read_fasta(ref_fn); om_seqs_drop_short(&ref, o.min_len);
 	if(ref.n == 0) { return 2; }
 	om_idx_t *mi = om_idx_build(&o, ref.a, (uint32_t)ref.n);
 	om_align_t *al = om_align_init(&o, mi);
 	if(al == NULL) { return 3; }
-	om_seqs_t qs = om_read_fasta(query_fn);
+	om_seqs_t qs = om_read_fasta(query_fn); om_seqs_drop_short(&qs, o.min_len);
 	om_sam_header(out, &o, ref.a, (uint32_t)ref.n);
-	double t0 = now_s(), tmap = 0; uint64_t nb = 0;
+	double tmap = 0; uint64_t nb = 0;
 	for(uint64_t i = 0; i < qs.n; i++) {
 		double t1 = now_s();
 		om_reg_t *reg = om_align_seq(al, qs.a[i].l_seq, qs.a[i].seq);
@@ -1039,7 +1128,6 @@ int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *
 		om_sam_record(out, ref.a, &qs.a[i], reg);
 		om_reg_free(reg);
 	}
-	(void)t0;
 	if(map_seconds) { *map_seconds = tmap; }
 	if(bases) { *bases = nb; }
 	om_align_free(al); om_idx_free(mi); om_seqs_free(&qs); om_seqs_free(&ref);

@@ -24,11 +24,15 @@ typedef struct {
 	uint32_t wlen, glen, min_score; float min_ratio;
 	og_params_t p;
 	char const *arg_line;       /* @PG CL: text */
+	uint32_t min_len;           /* -L, minialign.c:6077, 6145 */
 } om_opt_t;
 
 /* defaults (minialign.c:6141-6162) followed by a preset string such as "pacbio" or "ont.1dsq" (minialign.c:5846-5900);
  * returns nonzero on unknown preset */
 int om_opt_init(om_opt_t *o, char const *preset);
+/* defaults, then the options of an argv in order (-x presets and the single-letter options of minialign.c:5990-6099, `-k15` or `-k 15`), then
+ * mm_opt_check_sanity (minialign.c:6097); positional arguments go to files[]; returns nonzero on an option the reference would reject */
+int om_opt_parse(om_opt_t *o, int argc, char const *const *argv, char const **files, int max_files, int *n_files);
 
 typedef struct {
 	char *name; uint32_t l_name;
@@ -37,6 +41,7 @@ typedef struct {
 } om_seq_t;
 typedef struct { om_seq_t *a; uint64_t n; } om_seqs_t;
 om_seqs_t om_read_fasta(char const *fn);        /* FASTA / FASTQ, plain text (bseq_read_fasta, minialign.c:1996) */
+void om_seqs_drop_short(om_seqs_t *s, uint32_t min_len);    /* the -L filter of the reader (minialign.c:2077) */
 void om_seqs_free(om_seqs_t *s);
 
 typedef struct om_idx_s om_idx_t;
@@ -76,6 +81,7 @@ void om_sam_record(FILE *fp, om_seq_t const *ref, om_seq_t const *q, om_reg_t co
 
 /* whole program: `minialign -x<preset> ref.fa reads.fa > out` (minialign.c:6365-6447) */
 int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *out, char const *arg_line, double *map_seconds, uint64_t *bases);
+int om_main_opt(om_opt_t const *o, char const *ref_fn, char const *query_fn, FILE *out, double *map_seconds, uint64_t *bases);
 
 #ifdef __cplusplus
 }

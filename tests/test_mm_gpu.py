@@ -109,3 +109,27 @@ def test_prebuilt_index_file_gives_the_same_sam(workdir):
     assert r.returncode == 0 and _strip_pg(r.stdout) == want
     assert subprocess.run([CLI, '-x' + s['preset'], '-d', mai, ref, ref]).returncode == 0
     assert _run(CLI, s['preset'], mai, rd) == want + want
+
+
+def _opt_lines():
+    from golden.make_opt_golden import OPTION_LINES
+    return OPTION_LINES
+
+@pytest.mark.parametrize('name,opts', _opt_lines(), ids=[n for n, _ in _opt_lines()])
+def test_option_lines_match_reference_golden(name, opts, workdir):
+    """the command-line options beyond the presets through the HIP pipeline against the compiled reference's SAM (tests/golden/make_opt_golden.py):
+    other k / w, bucket bits, 3 and 5 occurrence thresholds (= rescue rounds), the length filter on both sides, plain affine gaps (-r0), an
+    asymmetric score matrix (-e), chaining windows and X-drop"""
+    from golden.make_opt_golden import make_opt_inputs
+    ref, rd = make_opt_inputs(workdir)
+    r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = _strip_pg(r.stdout)
+    want = gzip.open(os.path.join(HERE, 'golden', 'opt_%s.sam.gz' % name)).read()
+    assert got == want, _first_diff(got, want)
+
+
+def test_options_the_reference_rejects_are_rejected(workdir):
+    for bad in (['-k40'], ['-w1'], ['-a9'], ['-r1,1'], ['-xpacbio', '-r3,0'], ['-Y5'], ['-f0.1,0.2'], ['-m1.5'], ['-xnosuch'], ['-eAZ1']):
+        r = subprocess.run([CLI] + bad + ['/dev/null', '/dev/null'], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1 and r.stdout == b'', bad

@@ -65,3 +65,19 @@ def test_oracle_edge_cases_match_reference_golden(preset, fmt, workdir):
     got = strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign'), '-x' + preset, ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
     want = gzip.open(os.path.join(HERE, 'golden', 'edge_%s_%s.sam.gz' % (preset.replace('.', ''), fmt))).read()
     assert got == want
+
+
+def _opt_lines():
+    from golden.make_opt_golden import OPTION_LINES
+    return OPTION_LINES
+
+@pytest.mark.parametrize('name,opts', _opt_lines(), ids=[n for n, _ in _opt_lines()])
+def test_oracle_option_lines_match_reference_golden(name, opts, workdir):
+    """options beyond the presets (sketch, index thresholds / bucket bits / length filter, score matrix incl. modifiers, plain affine gaps,
+    chaining windows, X-drop): golden SAM from the compiled reference (tests/golden/make_opt_golden.py)"""
+    import gzip
+    from golden.make_opt_golden import make_opt_inputs, strip_pg
+    ref, rd = make_opt_inputs(workdir)
+    got = strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+    want = gzip.open(os.path.join(HERE, 'golden', 'opt_%s.sam.gz' % name)).read()
+    assert got == want
