@@ -88,7 +88,7 @@ inline void sort_res(ResEnt *p, size_t n) { auto key = [](const ResEnt &m) { ret
 /* ---------------------------------------------------------------------------------------------
  * sequences
  * --------------------------------------------------------------------------------------------- */
-struct HSeq { std::string name; std::vector<uint8_t> seq; };
+struct HSeq { std::string name; std::vector<uint8_t> seq; std::string qual, comment; bool has_comment = false; };     /* qual / comment: kept on request only (-Q, -T CO) */
 
 /* run fn(t, nth) on up to 16 host threads (reads / records are independent in every host stage that uses this) */
 template<typename F> static void host_parallel(uint32_t want, F fn)
@@ -100,18 +100,29 @@ template<typename F> static void host_parallel(uint32_t want, F fn)
 	for(auto &x : th) x.join();
 }
 
-/* FASTA / FASTQ text; bases by the low-nibble table of minialign.c:223-229 (anything but ACGTUN -> A) */
+/* FASTA / FASTQ text; bases by the low-nibble table of minialign.c:223-229 (anything but ACGTUN -> A).  A record name runs to the first space;
+ * a tab does not end it but is rewritten to a space (bseq_read_fasta copies through an escape while testing the raw bytes, minialign.c:1957-1968) */
 /* one FASTA stretch (starts at a '>' at the beginning of a line, holds whole records): lines by memchr, bases through the table */
-static void parse_fasta_span(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out)
+/* text after the name on a header line: tabs become spaces, spaces at the end go (bseq_read_fasta states 4-5, minialign.c:2030-2036) */
+static void keep_header_comment(HSeq &r, const char *l, size_t e, size_t n)
+{
+	if(e >= n) return;
+	size_t c = e + 1; while(c < n && l[c] == ' ') c++;
+	r.comment.assign(l + c, n - c); r.has_comment = true;
+	for(char &ch : r.comment) if(ch == '\t') ch = ' ';
+	while(!r.comment.empty() && r.comment.back() == ' ') r.comment.pop_back();
+}
+static void parse_fasta_span(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out, bool keep_comment)
 {
 	while(p < end) {
 		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
 		size_t n = (size_t)(le - p); while(n > 0 && p[n - 1] == '\r') n--;
 		if(n > 0) {
 			if(p[0] == '>') {
-				size_t q = 1; while(q < n && (p[q] == ' ' || p[q] == '\t')) q++;
-				size_t e = q; while(e < n && p[e] != ' ' && p[e] != '\t') e++;
-				out.emplace_back(); out.back().name.assign(p + q, e - q);
+				size_t q = 1; while(q < n && p[q] == ' ') q++;
+				size_t e = q; while(e < n && p[e] != ' ') e++;
+				out.emplace_back(); out.back().name.assign(p + q, e - q); for(char &ch : out.back().name) if(ch == '\t') ch = ' ';
+				if(keep_comment) keep_header_comment(out.back(), p, e, n);
 			} else if(!out.empty()) {
 				auto &sq = out.back().seq; const size_t o = sq.size(); sq.resize(o + n);
 				uint8_t *d = sq.data() + o; for(size_t i = 0; i < n; i++) d[i] = enc[p[i] & 15];
@@ -120,7 +131,7 @@ static void parse_fasta_span(const char *p, const char *end, const uint8_t *enc,
 		p = nl ? nl + 1 : end;
 	}
 }
-bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1)
+bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1, bool keep_qual = false, bool keep_comment = false)
 {
 	FILE *fp = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
 	if(!fp) return false;
@@ -155,7 +166,7 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1)
 			cut.push_back(end);
 			part.resize(cut.size() - 1);
 		}
-		host_parallel((uint32_t)part.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < part.size(); i += nth) parse_fasta_span(cut[i], cut[i + 1], enc, part[i]); });
+		host_parallel((uint32_t)part.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < part.size(); i += nth) parse_fasta_span(cut[i], cut[i + 1], enc, part[i], keep_comment); });
 		size_t tot = 0; for(auto &v : part) tot += v.size();
 		out.reserve(out.size() + tot);
 		for(auto &v : part) for(auto &r : v) out.emplace_back(std::move(r));
@@ -164,13 +175,13 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1)
 	int state = 0; char delim = 0; uint64_t qneed = 0, qgot = 0;
 	auto handle = [&](const char *l, size_t n) {
 		while(n > 0 && (l[n - 1] == '\r')) n--;
-		if(state == 2) { qgot += n; if(qgot >= qneed) state = 0; return; }
+		if(state == 2) { if(keep_qual) out.back().qual.append(l, n); qgot += n; if(qgot >= qneed) state = 0; return; }
 		if(n == 0) return;
 		if(delim == 0 && (l[0] == '>' || l[0] == '@')) delim = l[0];
 		if(l[0] == delim && (state == 0 || delim == '>')) {
-			size_t p = 1; while(p < n && (l[p] == ' ' || l[p] == '\t')) p++;
-			size_t e = p; while(e < n && l[e] != ' ' && l[e] != '\t') e++;
-			out.emplace_back(); out.back().name.assign(l + p, e - p); state = 1; return;
+			size_t p = 1; while(p < n && l[p] == ' ') p++;
+			size_t e = p; while(e < n && l[e] != ' ') e++;
+			out.emplace_back(); out.back().name.assign(l + p, e - p); for(char &ch : out.back().name) if(ch == '\t') ch = ' '; if(keep_comment) keep_header_comment(out.back(), l, e, n); state = 1; return;
 		}
 		if(state == 1 && delim == '@' && l[0] == '+') { state = 2; qneed = out.back().seq.size(); qgot = 0; if(qneed == 0) state = 0; return; }
 		if(state == 1) { auto &s = out.back().seq; size_t o = s.size(); s.resize(o + n); for(size_t i = 0; i < n; i++) s[o + i] = enc[l[i] & 15]; }
@@ -248,6 +259,10 @@ void sketch_host(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t w, std::
 struct mm_opt_s {
 	uint32_t k = 15, w = 32, b = 14, n_frq = 3; float frq[8] = { 0.05f, 0.01f, 0.001f, 0 };     /* up to MAX_FRQ_CNT = 7 thresholds, minialign.c:29 */
 	uint32_t min_len = 1, help = 0;
+	/* output (minialign.c:5880-5967): flag = -P 0x08 and bit 0 when -R is given; tags = bits 1 << MM_xx of -T.  The reference's printer ORs the two
+	 * into one word (minialign.c:5677), so -P also switches IH on and -T IH also omits the secondary records: kept */
+	uint64_t flag = 0, tags = 0; std::string rg_line, rg_id; bool keep_qual = false;
+	uint64_t ptags() const { return flag | tags; }
 	uint32_t wlen = 7000, glen = 7000, min_score = 50; float min_ratio = 0.3f;
 	gaba_params_t p;
 	uint32_t nth = 1;
@@ -347,6 +362,22 @@ int opt_one(mm_opt_t *o, char c, const char *arg)
 		case '1': case '2': return 0;                      /* input batch / output buffer sizes of the reference's host pipeline: accepted, no meaning here */
 		case 'v': return 0;
 		case 'h': o->help = 1; return 0;
+		case 'P': o->flag |= 0x08; return 0;
+		case 'Q': o->keep_qual = true; return 0;
+		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
+			static const char *const names[] = { "RG", "CO", "NH", "IH", "AS", "XS", "NM", "SA", "MD", "CG", "ID", "SQ" };
+			bool bad = false;
+			split_each(arg, ",;:/", [&](int, const std::string &t) { if(t.size() != 2) { bad = true; return; } for(int i = 0; i < 12; i++) if(t == names[i]) o->tags |= 1ull << i; });
+			return bad && opt_fail("unknown tag (-T).");
+		}
+		case 'R': {                      /* mm_opt_rg, minialign.c:5890-5921: a backslash turns the next character into a tab */
+			o->rg_line.clear(); o->rg_id.clear(); o->flag &= ~1ull;
+			std::string line; for(const char *q = arg; *q; q++) { if(*q == '\\') { q++; line.push_back('\t'); if(!*q) break; } else line.push_back(*q); }
+			bool found = false;
+			split_each(line.c_str(), "\t\r\n", [&](int, const std::string &t) { if(!found && t.compare(0, 3, "ID:") == 0) { o->rg_id = t; found = true; } });
+			if(!found) return opt_fail("RG line must start with @RG and contains ID, like `@RG\\tID:1'.");
+			o->rg_line = line; o->flag |= 1ull; return 0;
+		}
 		default: fprintf(stderr, "[E::mm_opt_parse] unsupported option -%c\n", c); return 1;
 	}
 }
@@ -373,7 +404,7 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
 		const char *a = argv[i];
 		if(a[0] == '-' && a[1]) {
 			const char *arg = a + 2;
-			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGdfBLe12", a[1])) arg = argv[++i];
+			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGdfBLe12TR", a[1])) arg = argv[++i];
 			if(opt_one(o, a[1], arg)) return 1;
 		} else if(nf < max_files) files[nf++] = a;
 	}
@@ -812,15 +843,64 @@ void sam_seq(std::string &s, const uint8_t *q, uint32_t n, bool rev)
 	if(!rev) for(uint32_t i = 0; i < n; i++) s[o + i] = fw[q[i] & 15];
 	else for(uint32_t i = 0; i < n; i++) s[o + i] = rv[q[n - 1 - i] & 15];
 }
-void sam_record(const mm_align_t *a, std::string &s, const char *qname, const uint8_t *qseq, uint32_t qlen, const OutReg &reg,
-	const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths)
+/* walks the path bits in the order of _parser_loop_rv (gaba_parse.h:168-188); fn(op, count) sees every nonzero run ('D', 'I', 'M') */
+template<typename F> void path_walk_reverse(const uint32_t *path, uint64_t offset, uint64_t len, F fn)
 {
+	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
+	uint64_t ofs = (uint64_t)((int64_t)offset + (((uintptr_t)path & 4) ? 32 : 0) - 64), idx = len;
+	while((int64_t)idx > 0) {
+		uint64_t m = lzc(path_u64(p, (int64_t)(ofs + idx))), c = std::min(idx, m - (m > 0));
+		idx -= c; if(c) fn('D', c);
+		m = lzc(~path_u64(p, (int64_t)(ofs + idx))); c = std::min(idx, m);
+		idx -= c; if(c) fn('I', c);
+		uint64_t sidx = idx;
+		do { m = lzc(path_u64(p, (int64_t)(ofs + idx)) ^ 0x5555555555555555ull); c = std::min(idx, m) & ~1ull; idx -= c; } while(c == 64);
+		if((sidx - idx) >> 1) fn('M', (sidx - idx) >> 1);
+	}
+}
+/* MD:Z (mm_print_sam_md, minialign.c:5243-5301): match counts, the reference base at a mismatch, ^ + reference bases at a deletion.  On the
+ * reverse strand the query base is complemented by xor 3, so an N there never equals the reference's N. */
+void sam_md(std::string &s, const HSeq &r, const uint8_t *qseq, uint32_t qlen, const gaba::Segment &sg, const uint32_t *path)
+{
+	static const char dec[] = "ACGTN\0\0\0\0\0\0\0\0\0\0\0";
+	s += "\tMD:Z:";
+	const bool rev = (~sg.bid & 1) != 0;
+	const uint8_t *rp = r.seq.data() + (r.seq.size() - sg.apos - sg.alen), *rb = rp;
+	const uint8_t *qp = rev ? qseq + (qlen - sg.bpos) : qseq + (qlen - sg.bpos - sg.blen);
+	path_walk_reverse(path, sg.ppos, (uint64_t)sg.alen + sg.blen, [&](char op, uint64_t c) {
+		if(op == 'D') { put_num(s, (uint64_t)(rp - rb)); s.push_back('^'); rb = rp + c; for(uint64_t i = 0; i < c; i++) s.push_back(dec[*rp++ & 15]); }
+		else if(op == 'I') { if(rev) qp -= c; else qp += c; }
+		else {
+			for(uint64_t t = 0; t < c; t++) {
+				const uint8_t rc = rp[t], qc = rev ? (uint8_t)(3 ^ qp[-1 - (int64_t)t]) : qp[t];
+				if(rc != qc) { put_num(s, (uint64_t)(rp + t - rb)); s.push_back(dec[rc & 15]); rb = rp + t + 1; }
+			}
+			rp += c; if(rev) qp -= c; else qp += c;
+		}
+	});
+	put_num(s, (uint64_t)(rp - rb));
+}
+inline void put_int(std::string &s, int64_t v) { if(v < 0) { s.push_back('-'); put_num(s, (uint64_t)-v); } else put_num(s, (uint64_t)v); }
+/* mm_print_sam_mapped with its tag printers (minialign.c:5127-5426).  QUIRKS kept: flags and tag bits share one word (-P switches IH on, -T IH omits
+ * secondaries); the SA entries name the first reference sequence whatever they hit and carry the raw 16x fixed-point mapping quality; RG:Z prints
+ * the whole "ID:..." token. */
+void sam_record(const mm_align_t *a, std::string &s, const char *qname, const uint8_t *qseq, uint32_t qlen, const OutReg &reg,
+	const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths, const HSeq *rec)
+{
+	const uint64_t f = a->o.ptags();
+	auto tag = [f](int x) { return ((f >> x) & 1) != 0; };
+	const bool has_qual = rec && !rec->qual.empty(), has_co = rec && rec->has_comment;
 	if(!reg.mapped || reg.n_all == 0) {
-		s += qname; s += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; sam_seq(s, qseq, qlen, false); s += "\t*\n";
+		s += qname; s += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; sam_seq(s, qseq, qlen, false); s.push_back('\t');
+		if(has_qual) s.append(rec->qual, 0, qlen); else s.push_back('*');
+		if(has_co) { s += "\tCO:Z:"; s += rec->comment; }
+		s.push_back('\n');
 		return;
 	}
+	auto edit = [&](const AlnRec &al) { return (uint32_t)((double)al.dcnt * (1.0 - al.identity)) + al.agcnt + al.bgcnt; };
 	uint32_t flag = 0;
-	for(uint32_t i = 0; i < reg.n_all; i++) {
+	const uint32_t n = (f & 0x08) ? reg.n_uniq : reg.n_all;           /* MM_OMIT_REP */
+	for(uint32_t i = 0; i < n; i++) {
 		if(i >= reg.n_uniq) flag = 0x100;
 		const AlnRec &al = alns[reg.aln[i].aln];
 		for(uint32_t j = al.slen; j > 0; j--) {
@@ -837,8 +917,45 @@ void sam_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 			if(tl) { put_num(s, tl); s.push_back(clip); }
 			s += "\t*\t0\t0\t";
 			if(sg.bid & 1) sam_seq(s, qseq + qs, qe - qs, false); else sam_seq(s, qseq + (qlen - qe), qe - qs, true);
-			s += "\t*";
-			if(i == 0 && j == al.slen) flag = 0x800;
+			s.push_back('\t');
+			if(has_qual) {
+				if(sg.bid & 1) s.append(rec->qual, qs, qe - qs);
+				else { const char *qq = rec->qual.data() + (qlen - qe); for(uint32_t x = qe - qs; x > 0; x--) s.push_back(qq[x - 1]); }
+			} else s.push_back('*');
+			if(f) {
+				if(tag(0)) { s += "\tRG:Z:"; s += a->o.rg_id; }
+				if(tag(2)) { s += "\tNH:i:"; put_num(s, reg.n_all); }
+				if(tag(3)) { s += "\tIH:i:"; put_num(s, i); }
+				if(tag(4)) { s += "\tAS:i:"; put_int(s, al.score); }
+				if(tag(6)) { s += "\tNM:i:"; put_num(s, edit(al)); }
+				if(tag(8)) sam_md(s, r, qseq, qlen, sg, paths + al.path_off);
+			}
+			if(i == 0 && j == al.slen) {
+				flag = 0x800;
+				bool stop = false;
+				if(tag(5)) { s += "\tXS:i:"; put_int(s, reg.n_all > 1 ? alns[reg.aln[1].aln].score : 0); }
+				if(tag(7) && (reg.n_uniq > 1 || alns[reg.aln[0].aln].slen > 1)) {
+					s += "\tSA:Z:";
+					for(uint32_t x = 0; x < reg.n_uniq; x++) {
+						const AlnRec &bl = alns[reg.aln[x].aln];
+						for(uint32_t y = bl.slen; y > 0; y--) {
+							if(x == 0 && y == bl.slen) continue;
+							const gaba::Segment &sh = segs[bl.seg_off + y - 1];
+							const HSeq &rr = a->mi->seq[sh.aid >> 1];
+							s += a->mi->seq[0].name; s.push_back(','); put_num(s, (uint32_t)rr.seq.size() - sh.apos - sh.alen + 1); s.push_back(',');
+							s.push_back((sh.bid & 1) ? '+' : '-'); s.push_back(',');
+							uint32_t h2 = qlen - sh.bpos - sh.blen, t2 = sh.bpos;
+							if(h2) { put_num(s, h2); s.push_back('H'); }
+							cigar_reverse(s, paths + bl.path_off, sh.ppos, (uint64_t)sh.alen + sh.blen);
+							if(t2) { put_num(s, t2); s.push_back('H'); }
+							s.push_back(','); put_num(s, reg.aln[x].mapq); s.push_back(','); put_num(s, edit(bl)); s.push_back(';');
+						}
+					}
+					stop = true;
+				}
+				if(has_co) { s += "\tCO:Z:"; s += rec->comment; }
+				if(stop) { s.push_back('\n'); return; }                 /* the other records are in the SA tag (minialign.c:5418-5420) */
+			}
 			s.push_back('\n');
 		}
 		flag = 0x800;
@@ -934,6 +1051,7 @@ extern "C" void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *
 {
 	fputs("@HD\tVN:1.0\tSO:unsorted\n", out);
 	for(const HSeq &s : a->mi->seq) fprintf(out, "@SQ\tSN:%s\tLN:%u\n", s.name.c_str(), (uint32_t)s.seq.size());
+	if((a->o.ptags() & 1) && !a->o.rg_line.empty()) fprintf(out, "%s\n", a->o.rg_line.c_str());       /* minialign.c:5111 */
 	fprintf(out, "@PG\tID:minialign\tPN:minialign\tVN:%s\tCL:%s\n", "0.6.0-devel", arg_line ? arg_line : "");
 }
 extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
@@ -962,6 +1080,7 @@ struct mm_reads_s { std::vector<HSeq> r; uint64_t bases = 0; };
 struct Batch {
 	uint32_t n = 0; uint64_t total = 0; uint32_t max_qlen = 0;
 	std::vector<uint32_t> lens; std::vector<uint64_t> qoff; std::vector<const uint8_t *> seq; std::vector<std::string> names;
+	std::vector<const HSeq *> rec;         /* the parsed records (qualities, comments) when the batch comes from a file; empty for in-memory batches */
 	std::vector<uint32_t> pk, nm; std::vector<ReadIn> in; std::vector<ReadState> hst; std::vector<uint32_t> work;
 	uint64_t scale = 1; bool uploaded = false, ran = false;
 	std::vector<uint32_t> used;            /* the carried reference length each read actually ran with */
@@ -1096,7 +1215,7 @@ bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piec
 				OutReg reg; const ReadState &rs = hst[i];
 				const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.get();
 				if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
-				sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get());
+				sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get(), i < b.rec.size() ? b.rec[i] : nullptr);
 			}
 		};
 		std::vector<std::thread> th;
@@ -1136,12 +1255,12 @@ extern "C" int mm_align_batch(mm_align_t *a, uint8_t const *bases, uint32_t cons
 }
 
 /* phase-split entry points over a parsed read set (bench.py times mm_batch_run alone: inputs resident in HBM) */
-static mm_reads_t *reads_load(char const *fn, uint32_t min_len);
+static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual = false, bool keep_comment = false);
 extern "C" mm_reads_t *mm_reads_load(char const *fn) { return reads_load(fn, 1); }
-static mm_reads_t *reads_load(char const *fn, uint32_t min_len)
+static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual, bool keep_comment)
 {
 	mm_reads_t *r = new mm_reads_s();
-	if(!read_seq_file(fn, r->r, min_len)) { delete r; return NULL; }
+	if(!read_seq_file(fn, r->r, min_len, keep_qual, keep_comment)) { delete r; return NULL; }
 	for(const HSeq &s : r->r) r->bases += s.seq.size();
 	return r;
 }
@@ -1172,7 +1291,7 @@ extern "C" mm_batch_t *mm_batch_upload(mm_align_t *a, mm_reads_t const *r, uint3
 {
 	mm_batch_t *h = new mm_batch_s();
 	const uint32_t last = (uint32_t)std::min<uint64_t>((uint64_t)first + n, r->r.size());
-	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); }
+	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); h->b.rec.push_back(&r->r[i]); }
 	h->ctx = a;
 	if(!batch_prepare(a, h->b)) { delete h; return NULL; }
 	return h;
@@ -1188,7 +1307,7 @@ extern "C" mm_batch_t *mm_batch_upload_lane(mm_align_t *a, mm_reads_t const *r, 
 	if(!q) return NULL;
 	mm_batch_t *h = new mm_batch_s();
 	const uint32_t last = (uint32_t)std::min<uint64_t>((uint64_t)first + n, r->r.size());
-	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); }
+	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); h->b.rec.push_back(&r->r[i]); }
 	h->ctx = q;
 	if(!batch_prepare(q, h->b)) { delete h; return NULL; }
 	return h;
@@ -1229,7 +1348,7 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = 
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
 	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
-	mm_reads_t *reads = reads_load(reads_fn, a->o.min_len);
+	mm_reads_t *reads = reads_load(reads_fn, a->o.min_len, a->o.keep_qual, (a->o.ptags() >> 1) & 1);
 	if(!reads) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
 	if(verbose) { fprintf(stderr, "[minialign_amd] parse %.1f ms\n", now_ms() - tv); }
 	return align_reads(a, reads, out);
@@ -1341,7 +1460,7 @@ extern "C" int mm_main(int argc, char **argv)
 	if(nf == 1) { fprintf(stderr, "[M::main_align] query-side input redirected to stdin.\n"); files[nf++] = "-"; }     /* minialign.c:6380-6384 */
 	/* the first query file is parsed on a thread of its own while the index is built or loaded */
 	mm_reads_t *first_reads = NULL;
-	std::thread rt([&]() { if(strcmp(files[1], "-") != 0) first_reads = reads_load(files[1], o->min_len); });
+	std::thread rt([&]() { if(strcmp(files[1], "-") != 0) first_reads = reads_load(files[1], o->min_len, o->keep_qual, (o->ptags() >> 1) & 1); });
 	std::thread hw([]() { int n = 0; if(hipGetDeviceCount(&n) == hipSuccess && n > 0) { (void)hipFree(0); } });      /* bring the HIP runtime up meanwhile */
 	/* a prebuilt index (file name ending in .mai) may hold several blocks: every query file is mapped onto each in turn, with a header per block
 	 * (minialign.c:6373, 6413-6436) */

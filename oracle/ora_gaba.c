@@ -1009,6 +1009,27 @@ uint64_t og_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *pat
 	*b = '\0';
 	return (uint64_t)(b - buf);
 }
+void og_parse_path_reverse(uint32_t const *path, uint64_t offset, uint64_t len, void (*fn)(void *ctx, char op, uint64_t cnt), void *ctx)
+{
+	uint64_t const *p = PARSE_PTR(path);
+	uint64_t ofs = (uint64_t)((int64_t)offset + PARSE_OFS(path) - 64), idx = len;
+	while((int64_t)idx > 0) {
+		uint64_t m, c;
+		m = lz64(parse_u64(p, (int64_t)(ofs + idx)));
+		c = MIN2(idx, m - (m > 0));
+		idx -= c; if(c) { fn(ctx, 'D', c); }
+		m = lz64(~parse_u64(p, (int64_t)(ofs + idx)));
+		c = MIN2(idx, m);
+		idx -= c; if(c) { fn(ctx, 'I', c); }
+		uint64_t sidx = idx;
+		do {
+			m = lz64(parse_u64(p, (int64_t)(ofs + idx)) ^ 0x5555555555555555ULL);
+			c = MIN2(idx, m) & ~0x01ULL;
+			idx -= c;
+		} while(c == 64);
+		if((sidx - idx) >> 1) { fn(ctx, 'M', (sidx - idx) >> 1); }
+	}
+}
 uint64_t og_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
 {
 	(void)buf_size;

@@ -91,6 +91,8 @@ void og_aln_free(og_alignment_t *aln);
 /* gaba_parse.h:259 gaba_dump_cigar_reverse / :258 forward */
 uint64_t og_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
 uint64_t og_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
+/* _parser_loop_rv (gaba_parse.h:168-188) with a callback per nonzero run, in the order the reverse dumpers see them: op is 'D', 'I' or 'M' */
+void og_parse_path_reverse(uint32_t const *path, uint64_t offset, uint64_t len, void (*fn)(void *ctx, char op, uint64_t cnt), void *ctx);
 
 /* convenience used by the tests: same record as oracle/ref_harness/gaba_ref_shim.c:shim_result_t */
 typedef struct {

@@ -130,6 +130,30 @@ static int opt_one(om_opt_t *o, char c, char const *arg, size_t l)
 		case 'W': o->wlen = (uint32_t)atoi(arg); return 0;
 		case 'G': o->glen = (uint32_t)atoi(arg); return 0;
 		case 't': case '1': case '2': case 'v': return 0;
+		case 'P': o->flag |= 0x08; return 0;
+		case 'Q': o->keep_qual = 1; return 0;
+		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
+			static char const *const names[] = { "RG", "CO", "NH", "IH", "AS", "XS", "NM", "SA", "MD", "CG", "ID", "SQ" };
+			for(char *p = buf; *p; ) {
+				char *e = p; while(*e && !strchr(",;:/", *e)) { e++; }
+				if(e > p) { if(e - p != 2) { return 1; } for(int i = 0; i < 12; i++) { if(p[0] == names[i][0] && p[1] == names[i][1]) { o->tags |= 1ULL << i; } } }
+				if(!*e) { break; } p = e + 1;
+			}
+			return 0;
+		}
+		case 'R': {                      /* mm_opt_rg, minialign.c:5890-5921: a backslash turns the next character into a tab */
+			free(o->rg_line); free(o->rg_id); o->rg_line = o->rg_id = NULL; o->flag &= ~1ULL;
+			char *line = (char *)malloc(l + 1); size_t n = 0;
+			for(char const *p = arg; *p; p++) { if(*p == '\\') { p++; line[n++] = '\t'; if(!*p) { break; } } else { line[n++] = *p; } }
+			line[n] = 0;
+			for(char *p = line; *p; ) {
+				char *e = p; while(*e && !strchr("\t\r\n", *e)) { e++; }
+				if(e > p && strncmp(p, "ID:", 3) == 0) { o->rg_line = line; o->rg_id = strndup(p, (size_t)(e - p)); o->flag |= 1ULL; break; }
+				if(!*e) { break; } p = e + 1;
+			}
+			if(o->rg_id == NULL) { free(line); return 1; }
+			return 0;
+		}
 		default: return 1;
 	}
 }
@@ -194,7 +218,7 @@ int om_opt_parse(om_opt_t *o, int argc, char const *const *argv, char const **fi
 		char const *a = argv[i];
 		if(a[0] == '-' && a[1]) {
 			char const *arg = a + 2;
-			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGfBLe12", a[1])) { arg = argv[++i]; }
+			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGfBLe12TR", a[1])) { arg = argv[++i]; }
 			rc |= opt_one(o, a[1], arg, strlen(arg));
 		} else if(nf < max_files) { files[nf++] = a; }
 	}
@@ -204,7 +228,8 @@ int om_opt_parse(om_opt_t *o, int argc, char const *const *argv, char const **fi
 
 /* ---- FASTA / FASTQ (bseq_read_fasta, minialign.c:1996-2090; encoding minialign.c:223-229) ---- */
 static uint8_t const encaf[16] = { [('A' & 0xf)] = 0, [('C' & 0xf)] = 1, [('G' & 0xf)] = 2, [('T' & 0xf)] = 3, [('U' & 0xf)] = 3, [('N' & 0xf)] = 4 };
-om_seqs_t om_read_fasta(char const *fn)
+om_seqs_t om_read_fasta(char const *fn) { return om_read_fasta_ex(fn, 0, 0); }
+om_seqs_t om_read_fasta_ex(char const *fn, int keep_qual, int keep_comment)
 {
 	om_seqs_t r = { 0, 0 };
 	FILE *fp = fopen(fn, "r");
@@ -216,13 +241,25 @@ om_seqs_t om_read_fasta(char const *fn)
 	uint64_t scap = 0, qneed = 0, qgot = 0;
 	while((l = getline(&line, &cap, fp)) > 0) {
 		while(l > 0 && (line[l - 1] == '\n' || line[l - 1] == '\r')) { line[--l] = 0; }
-		if(state == 2) { qgot += (uint64_t)l; if(qgot >= qneed) { state = 0; } continue; }
+		if(state == 2) {
+			if(keep_qual) { om_seq_t *s = &v.a[v.n - 1]; s->qual = (char *)realloc(s->qual, qgot + (uint64_t)l + 1); memcpy(s->qual + qgot, line, (size_t)l); s->qual[qgot + (uint64_t)l] = 0; }
+			qgot += (uint64_t)l; if(qgot >= qneed) { state = 0; } continue;
+		}
 		if(delim == 0 && (line[0] == '>' || line[0] == '@')) { delim = line[0]; }
 		if(state != 2 && line[0] == delim && (state == 0 || delim == '>' || 1) && (state == 0 || delim == '>')) {
 			om_seq_t s; memset(&s, 0, sizeof(s));
-			char *p = line + 1; while(*p == ' ' || *p == '\t') { p++; }
-			char *e = p; while(*e && *e != ' ' && *e != '\t') { e++; }
+			/* the name runs to the first space (a tab does not end it: tabs are rewritten to spaces as the text is copied, the delimiter test
+			 * sees the raw bytes; bseq_read_fasta states 2-3 and _readline, minialign.c:1957-1968, 2024-2029) */
+			char *p = line + 1; while(*p == ' ') { p++; }
+			char *e = p; while(*e && *e != ' ') { e++; }
 			s.l_name = (uint32_t)(e - p); s.name = strndup(p, s.l_name);
+			for(uint32_t i = 0; i < s.l_name; i++) { if(s.name[i] == '\t') { s.name[i] = ' '; } }
+			if(keep_comment && *e) {
+				char *c = e + 1; while(*c == ' ') { c++; }
+				size_t cl = strlen(c); s.comment = strndup(c, cl);
+				for(size_t i = 0; i < cl; i++) { if(s.comment[i] == '\t') { s.comment[i] = ' '; } }
+				while(cl > 0 && s.comment[cl - 1] == ' ') { s.comment[--cl] = 0; }
+			}
 			vec_push(om_seq_t, v, s); scap = 0; state = 1;
 			continue;
 		}
@@ -241,12 +278,12 @@ om_seqs_t om_read_fasta(char const *fn)
 void om_seqs_drop_short(om_seqs_t *s, uint32_t min_len)       /* sequences shorter than min_len are squashed by the reader (minialign.c:2077) */
 {
 	uint64_t j = 0;
-	for(uint64_t i = 0; i < s->n; i++) { if(s->a[i].l_seq >= min_len) { s->a[j++] = s->a[i]; } else { free(s->a[i].name); free(s->a[i].seq); free(s->a[i].qual); } }
+	for(uint64_t i = 0; i < s->n; i++) { if(s->a[i].l_seq >= min_len) { s->a[j++] = s->a[i]; } else { free(s->a[i].name); free(s->a[i].seq); free(s->a[i].qual); free(s->a[i].comment); } }
 	s->n = j;
 }
 void om_seqs_free(om_seqs_t *s)
 {
-	for(uint64_t i = 0; i < s->n; i++) { free(s->a[i].name); free(s->a[i].seq); free(s->a[i].qual); }
+	for(uint64_t i = 0; i < s->n; i++) { free(s->a[i].name); free(s->a[i].seq); free(s->a[i].qual); free(s->a[i].comment); }
 	free(s->a); s->a = NULL; s->n = 0;
 }
 
@@ -1048,6 +1085,7 @@ void om_sam_header(FILE *fp, om_opt_t const *o, om_seq_t const *ref, uint32_t n_
 {
 	fputs("@HD\tVN:1.0\tSO:unsorted\n", fp);
 	for(uint32_t i = 0; i < n_ref; i++) { fprintf(fp, "@SQ\tSN:%.*s\tLN:%u\n", (int)ref[i].l_name, ref[i].name, ref[i].l_seq); }
+	if(((o->flag | o->tags) & (1ULL << OM_RG)) && o->rg_line) { fprintf(fp, "%s\n", o->rg_line); }        /* minialign.c:5111 */
 	fprintf(fp, "@PG\tID:minialign\tPN:minialign\tVN:%s\tCL:%s\n", "0.6.0-devel", o->arg_line ? o->arg_line : "");
 }
 static void put_seq(FILE *fp, uint8_t const *s, uint32_t n, int rev)
@@ -1076,30 +1114,108 @@ static void sam_core(FILE *fp, om_seq_t const *r, om_seq_t const *q, og_segment_
 	if(s->bid & 0x01) { put_seq(fp, &q->seq[qs], qe - qs, 0); }
 	else { put_seq(fp, &q->seq[q->l_seq - qe], qe - qs, 1); }
 	fputc('\t', fp);
-	fputc('*', fp);          /* qualities are dropped unless -Q (minialign.c:5186, 5964) */
+	if(q->qual && q->qual[0] != '\0') {      /* kept with -Q only (minialign.c:5186-5195, 5964) */
+		if(s->bid & 0x01) { fwrite(&q->qual[qs], 1, qe - qs, fp); }
+		else { for(uint32_t i = 0; i < qe - qs; i++) { fputc(q->qual[q->l_seq - qe + (qe - qs - 1 - i)], fp); } }
+	} else { fputc('*', fp); }
 }
-/* mm_print_sam_mapped, minialign.c:5390-5426 (+ mm_print_sam_unmapped :5127) */
-void om_sam_record(FILE *fp, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg)
+/* mm_print_sam_supp, minialign.c:5204-5236: one "rname,pos,strand,CIGAR,mapQ,NM;" entry.  QUIRKS kept: the name is always the first reference
+ * sequence's (r->name, not r[rid].name), and the mapping quality is the raw 16x fixed-point value */
+static void sam_supp(FILE *fp, om_seq_t const *r, om_seq_t const *q, uint32_t const *path, og_segment_t const *s, uint32_t ed, uint32_t mapq)
 {
+	uint32_t rid = s->aid >> 1;
+	uint32_t rs = r[rid].l_seq - s->apos - s->alen;
+	uint32_t hl = q->l_seq - s->bpos - s->blen, tl = s->bpos;
+	fprintf(fp, "%.*s,%u,%c,", (int)r[0].l_name, r[0].name, rs + 1, (s->bid & 0x01) ? '+' : '-');
+	if(hl != 0) { fprintf(fp, "%uH", hl); }
+	uint64_t plen = (uint64_t)s->alen + s->blen;
+	char *buf = (char *)malloc(plen * 3 + 64);
+	og_dump_cigar_reverse(buf, plen * 3 + 64, path, s->ppos, plen);
+	fputs(buf, fp); free(buf);
+	if(tl != 0) { fprintf(fp, "%uH", tl); }
+	fprintf(fp, ",%u,%u;", mapq, ed);
+}
+/* mm_print_sam_md, minialign.c:5243-5301: reference bases at mismatches, ^ + bases at deletions, match counts between them */
+typedef struct { FILE *fp; uint8_t const *rp, *rb, *qp; int rev; } md_ctx_t;
+static void md_step(void *ctx, char op, uint64_t c)
+{
+	md_ctx_t *m = (md_ctx_t *)ctx;
+	if(op == 'D') {
+		fprintf(m->fp, "%lu^", (unsigned long)(m->rp - m->rb)); m->rb = m->rp + c;
+		for(uint64_t i = 0; i < c; i++) { fputc("ACGTN\0\0\0\0\0\0\0\0\0\0\0"[*m->rp++ & 15], m->fp); }
+	} else if(op == 'I') {
+		if(m->rev) { m->qp -= c; } else { m->qp += c; }
+	} else {
+		for(uint64_t t = 0; t < c; t++) {
+			uint8_t rc = m->rp[t], qc = m->rev ? (uint8_t)(0x03 ^ m->qp[-1 - (int64_t)t]) : m->qp[t];     /* reverse strand: complement by xor 3, so N (4) never equals N */
+			if(rc != qc) { fprintf(m->fp, "%lu%c", (unsigned long)(&m->rp[t] - m->rb), "ACGTN\0\0\0\0\0\0\0\0\0\0\0"[rc & 15]); m->rb = &m->rp[t] + 1; }
+		}
+		m->rp += c; if(m->rev) { m->qp -= c; } else { m->qp += c; }
+	}
+}
+static void sam_md(FILE *fp, om_seq_t const *r, om_seq_t const *q, uint32_t const *path, og_segment_t const *s)
+{
+	fputs("\tMD:Z:", fp);
+	uint32_t rev = ~s->bid & 0x01, rid = s->aid >> 1;
+	md_ctx_t m; m.fp = fp; m.rev = (int)rev;
+	m.rp = m.rb = &r[rid].seq[r[rid].l_seq - s->apos - s->alen];
+	m.qp = rev ? &q->seq[q->l_seq - s->bpos] : &q->seq[q->l_seq - s->bpos - s->blen];
+	og_parse_path_reverse(path, s->ppos, (uint64_t)s->alen + s->blen, md_step, &m);
+	fprintf(fp, "%lu", (unsigned long)(m.rp - m.rb));
+}
+/* mm_print_sam_mapped, minialign.c:5390-5426 (+ _unmapped :5127, _general_tags :5304, _primary_tags :5347) */
+void om_sam_record_opt(FILE *fp, om_opt_t const *o, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg)
+{
+	uint64_t const f = o ? (o->flag | o->tags) : 0;         /* one word for flags and tag bits (minialign.c:5677) */
+	#define TAG(_x)     ( (f >> (_x)) & 1 )
 	if(reg == NULL) {
 		fprintf(fp, "%.*s\t4\t*\t0\t0\t*\t*\t0\t0\t", (int)q->l_name, q->name);
 		put_seq(fp, q->seq, q->l_seq, 0);
-		fputs("\t*\n", fp);
+		fputc('\t', fp);
+		if(q->qual && q->qual[0] != '\0') { fwrite(q->qual, 1, q->l_seq, fp); } else { fputc('*', fp); }
+		if(q->comment) { fprintf(fp, "\tCO:Z:%s", q->comment); }
+		fputc('\n', fp);
 		return;
 	}
-	uint64_t n = reg->n_all;
+	uint64_t n = (f & 0x08) ? reg->n_uniq : reg->n_all;      /* MM_OMIT_REP */
 	uint32_t flag = 0;
 	for(uint64_t i = 0; i < n; i++) {
 		if(i >= reg->n_uniq) { flag = 0x100; }
 		om_aln_t const *a = &reg->aln[i];
 		for(uint64_t j = a->a->slen; j > 0; j--) {
 			sam_core(fp, ref, q, &a->a->seg[j - 1], a->a->path, flag, a->mapq);
-			if(i == 0 && j == a->a->slen) { flag = 0x800; }
+			if(TAG(OM_RG)) { fprintf(fp, "\tRG:Z:%s", o->rg_id); }
+			if(TAG(OM_NH)) { fprintf(fp, "\tNH:i:%u", reg->n_all); }
+			if(TAG(OM_IH)) { fprintf(fp, "\tIH:i:%lu", (unsigned long)i); }
+			if(TAG(OM_AS)) { fprintf(fp, "\tAS:i:%ld", (long)a->a->score); }
+			if(TAG(OM_NM)) { uint32_t xcnt = (uint32_t)((double)a->a->dcnt * (1.0 - a->a->identity)); fprintf(fp, "\tNM:i:%u", xcnt + a->a->agcnt + a->a->bgcnt); }
+			if(TAG(OM_MD)) { sam_md(fp, ref, q, a->a->path, &a->a->seg[j - 1]); }
+			if(i == 0 && j == a->a->slen) {
+				flag = 0x800;
+				uint64_t stop = 0;
+				if(TAG(OM_XS)) { fprintf(fp, "\tXS:i:%ld", reg->n_all > 1 ? (long)reg->aln[1].a->score : 0L); }
+				if(TAG(OM_SA) && (reg->n_uniq > 1 || reg->aln[0].a->slen > 1)) {
+					fputs("\tSA:Z:", fp);
+					for(uint64_t x = 0; x < reg->n_uniq; x++) {
+						om_aln_t const *b = &reg->aln[x];
+						uint32_t ed = (uint32_t)((double)b->a->dcnt * (1.0 - b->a->identity)) + b->a->agcnt + b->a->bgcnt;
+						for(uint64_t y = b->a->slen; y > 0; y--) {
+							if(x == 0 && y == b->a->slen) { continue; }
+							sam_supp(fp, ref, q, b->a->path, &b->a->seg[y - 1], ed, b->mapq);
+						}
+					}
+					stop = 1;
+				}
+				if(q->comment) { fprintf(fp, "\tCO:Z:%s", q->comment); }
+				if(stop) { i = n; j = 1; }                        /* the other records are in the SA tag (minialign.c:5418-5420) */
+			}
 			fputc('\n', fp);
 		}
 		flag = 0x800;
 	}
+	#undef TAG
 }
+void om_sam_record(FILE *fp, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg) { om_sam_record_opt(fp, NULL, ref, q, reg); }
 
 /* ---- whole program ---- */
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -1118,14 +1234,14 @@ int om_main_opt(om_opt_t const *op, char const *ref_fn, char const *query_fn, FI
 	om_idx_t *mi = om_idx_build(&o, ref.a, (uint32_t)ref.n);
 	om_align_t *al = om_align_init(&o, mi);
 	if(al == NULL) { return 3; }
-	om_seqs_t qs = om_read_fasta(query_fn); om_seqs_drop_short(&qs, o.min_len);
+	om_seqs_t qs = om_read_fasta_ex(query_fn, (int)o.keep_qual, (int)(((o.flag | o.tags) >> OM_CO) & 1)); om_seqs_drop_short(&qs, o.min_len);
 	om_sam_header(out, &o, ref.a, (uint32_t)ref.n);
 	double tmap = 0; uint64_t nb = 0;
 	for(uint64_t i = 0; i < qs.n; i++) {
 		double t1 = now_s();
 		om_reg_t *reg = om_align_seq(al, qs.a[i].l_seq, qs.a[i].seq);
 		tmap += now_s() - t1; nb += qs.a[i].l_seq;
-		om_sam_record(out, ref.a, &qs.a[i], reg);
+		om_sam_record_opt(out, &o, ref.a, &qs.a[i], reg);
 		om_reg_free(reg);
 	}
 	if(map_seconds) { *map_seconds = tmap; }

@@ -25,7 +25,13 @@ typedef struct {
 	og_params_t p;
 	char const *arg_line;       /* @PG CL: text */
 	uint32_t min_len;           /* -L, minialign.c:6077, 6145 */
+	/* output (minialign.c:5880-5967): flag = -X 0x01 | -P 0x08 | -A 0x10 and bit 0 when -R is given; tags = bits 1 << MM_xx of -T.  The printer
+	 * ORs the two into one word (minialign.c:5677) -- so -P also switches IH on and -T IH also omits secondaries: kept */
+	uint64_t flag, tags;
+	char *rg_line, *rg_id;      /* -R, unescaped line and the "ID:..." token */
+	uint32_t keep_qual;         /* -Q */
 } om_opt_t;
+enum { OM_RG = 0, OM_CO = 1, OM_NH = 2, OM_IH = 3, OM_AS = 4, OM_XS = 5, OM_NM = 6, OM_SA = 7, OM_MD = 8 };     /* minialign.c:2530-2538 */
 
 /* defaults (minialign.c:6141-6162) followed by a preset string such as "pacbio" or "ont.1dsq" (minialign.c:5846-5900);
  * returns nonzero on unknown preset */
@@ -38,9 +44,11 @@ typedef struct {
 	char *name; uint32_t l_name;
 	uint8_t *seq; uint32_t l_seq;       /* 0..4 per base, minialign.c:214-229 */
 	char *qual;                         /* NULL unless kept */
+	char *comment;                      /* NULL unless kept (-T CO): text after the name, tabs turned into spaces, trailing spaces cut (minialign.c:2030-2036) */
 } om_seq_t;
 typedef struct { om_seq_t *a; uint64_t n; } om_seqs_t;
 om_seqs_t om_read_fasta(char const *fn);        /* FASTA / FASTQ, plain text (bseq_read_fasta, minialign.c:1996) */
+om_seqs_t om_read_fasta_ex(char const *fn, int keep_qual, int keep_comment);
 void om_seqs_drop_short(om_seqs_t *s, uint32_t min_len);    /* the -L filter of the reader (minialign.c:2077) */
 void om_seqs_free(om_seqs_t *s);
 
@@ -78,6 +86,8 @@ void om_counters(om_align_t const *a, uint64_t out[8]);               /* work co
 /* SAM (minialign.c:5096-5426); default tag set (none) */
 void om_sam_header(FILE *fp, om_opt_t const *o, om_seq_t const *ref, uint32_t n_ref);
 void om_sam_record(FILE *fp, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg);
+/* with the optional tags, read group, qualities and -P of o (minialign.c:5204-5426) */
+void om_sam_record_opt(FILE *fp, om_opt_t const *o, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg);
 
 /* whole program: `minialign -x<preset> ref.fa reads.fa > out` (minialign.c:6365-6447) */
 int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *out, char const *arg_line, double *map_seconds, uint64_t *bases);

@@ -133,3 +133,20 @@ def test_options_the_reference_rejects_are_rejected(workdir):
     for bad in (['-k40'], ['-w1'], ['-a9'], ['-r1,1'], ['-xpacbio', '-r3,0'], ['-Y5'], ['-f0.1,0.2'], ['-m1.5'], ['-xnosuch'], ['-eAZ1']):
         r = subprocess.run([CLI] + bad + ['/dev/null', '/dev/null'], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 1 and r.stdout == b'', bad
+
+
+def _tag_lines():
+    from golden.make_tag_golden import TAG_LINES
+    return TAG_LINES
+
+@pytest.mark.parametrize('name,opts', _tag_lines(), ids=[n for n, _ in _tag_lines()])
+def test_optional_sam_fields_match_reference_golden(name, opts, workdir):
+    """-T tags (RG CO NH IH AS XS NM SA MD), -R read group, -Q qualities, -P through the HIP pipeline against the compiled reference's SAM
+    (tests/golden/make_tag_golden.py)"""
+    from golden.make_tag_golden import inputs_for
+    ref, rd = inputs_for(name, workdir)
+    r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = _strip_pg(r.stdout)
+    want = gzip.open(os.path.join(HERE, 'golden', 'tag_%s.sam.gz' % name)).read()
+    assert got == want, _first_diff(got, want)

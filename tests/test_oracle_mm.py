@@ -81,3 +81,19 @@ def test_oracle_option_lines_match_reference_golden(name, opts, workdir):
     got = strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
     want = gzip.open(os.path.join(HERE, 'golden', 'opt_%s.sam.gz' % name)).read()
     assert got == want
+
+
+def _tag_lines():
+    from golden.make_tag_golden import TAG_LINES
+    return TAG_LINES
+
+@pytest.mark.parametrize('name,opts', _tag_lines(), ids=[n for n, _ in _tag_lines()])
+def test_oracle_optional_sam_fields_match_reference_golden(name, opts, workdir):
+    """-T tags (RG CO NH IH AS XS NM SA MD), -R, -Q, -P on FASTQ reads with header comments: golden SAM from the compiled reference
+    (tests/golden/make_tag_golden.py), including its quirks (shared flag / tag word, SA names and mapping qualities, tabs in read names)"""
+    import gzip
+    from golden.make_tag_golden import inputs_for, strip_pg
+    ref, rd = inputs_for(name, workdir)
+    got = strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+    want = gzip.open(os.path.join(HERE, 'golden', 'tag_%s.sam.gz' % name)).read()
+    assert got == want
