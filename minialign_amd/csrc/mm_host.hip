@@ -12,6 +12,7 @@
  * drained strictly in input order.
  */
 #include <hip/hip_runtime.h>
+#include <zlib.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -148,6 +149,27 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1,
 		data.resize(len);
 	}
 	if(fp != stdin) fclose(fp);
+	/* gzip input is inflated in memory (the reference reads through gzread, minialign.c:1184-1363: plain and gzip text alike, members back to back) */
+	if(data.size() >= 2 && (uint8_t)data[0] == 0x1f && (uint8_t)data[1] == 0x8b) {
+		std::vector<char> raw; raw.resize(std::max<size_t>(data.size() * 4, 1 << 16));
+		z_stream zs; memset(&zs, 0, sizeof(zs));
+		if(inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return false;
+		zs.next_in = (Bytef *)data.data(); size_t in_left = data.size(), out_len = 0;
+		bool ok = true;
+		while(ok) {
+			zs.avail_in = (uInt)std::min<size_t>(in_left, 1u << 30); const size_t in_before = zs.avail_in;
+			if(raw.size() - out_len < (1u << 16)) raw.resize(raw.size() * 2);
+			zs.next_out = (Bytef *)raw.data() + out_len; zs.avail_out = (uInt)std::min<size_t>(raw.size() - out_len, 1u << 30); const size_t out_before = zs.avail_out;
+			int rc = inflate(&zs, Z_NO_FLUSH);
+			in_left -= in_before - zs.avail_in; out_len += out_before - zs.avail_out;
+			if(rc == Z_STREAM_END) { if(in_left < 2 || (uint8_t)zs.next_in[0] != 0x1f || (uint8_t)zs.next_in[1] != 0x8b) break; if(inflateReset(&zs) != Z_OK) ok = false; }
+			else if(rc != Z_OK && !(rc == Z_BUF_ERROR && zs.avail_out == 0)) ok = false;
+			else if(in_left == 0 && zs.avail_out != 0) ok = false;          /* truncated stream */
+		}
+		inflateEnd(&zs);
+		if(!ok) { fprintf(stderr, "[minialign_amd] broken gzip stream in `%s'\n", fn); return false; }
+		raw.resize(out_len); data.swap(raw);
+	}
 	size_t first = 0; while(first < data.size() && (data[first] == '\n' || data[first] == '\r')) first++;
 	if(first < data.size() && data[first] == '>') {
 		/* FASTA: '>' at the beginning of a line can only start a record, so the file splits at such points and the pieces are

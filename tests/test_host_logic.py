@@ -128,5 +128,15 @@ def test_host_index_matches_oracle_and_survives_dump_and_load(tmp_path):
         fp = ctypes.c_void_p(libc.fopen(p.encode(), b'rb'))
         assert not L.mm_idx_load(fp, ctypes.byref(eof)) and eof.value == 0
         libc.fclose(fp)
+    # gzip-compressed input (one member, and two members back to back) builds the same index; a cut-off stream is an error
+    import gzip
+    text = open(ref, 'rb').read()
+    open(ref + '.gz', 'wb').write(gzip.compress(text)); open(ref + '.2.gz', 'wb').write(gzip.compress(text[:70001]) + gzip.compress(text[70001:]))
+    open(str(tmp_path / 'cut.fa.gz'), 'wb').write(gzip.compress(text)[:5000])
+    plain = str(tmp_path / 'plain.mai'); subprocess.run([cli, '-xpacbio', '-d', plain, ref], check=True, stderr=subprocess.DEVNULL)
+    for z in (ref + '.gz', ref + '.2.gz'):
+        subprocess.run([cli, '-xpacbio', '-d', mai, z], check=True, stderr=subprocess.DEVNULL)
+        assert open(mai, 'rb').read() == open(plain, 'rb').read()
+    assert subprocess.run([cli, '-xpacbio', '-d', mai, str(tmp_path / 'cut.fa.gz')], stderr=subprocess.DEVNULL).returncode == 1
     for h in (mi, m1, m2): L.mm_idx_destroy(h)
     L.mm_opt_destroy(o)

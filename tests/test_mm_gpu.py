@@ -109,6 +109,9 @@ def test_prebuilt_index_file_gives_the_same_sam(workdir):
     assert r.returncode == 0 and _strip_pg(r.stdout) == want
     assert subprocess.run([CLI, '-x' + s['preset'], '-d', mai, ref, ref]).returncode == 0
     assert _run(CLI, s['preset'], mai, rd) == want + want
+    # gzip-compressed reference and reads
+    open(ref + '.gz', 'wb').write(gzip.compress(open(ref, 'rb').read())); open(rd + '.gz', 'wb').write(gzip.compress(open(rd, 'rb').read()))
+    assert _run(CLI, s['preset'], ref + '.gz', rd + '.gz') == want
 
 
 def _opt_lines():
