@@ -151,6 +151,18 @@ typedef struct {
 int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const *b,
 	gaba_job_t const *jobs, uint32_t n, gaba_xresult_t *results, uint32_t *paths, uint32_t path_stride);
 
+/* gaba_dp_calc_score (gaba.h:223-243, 357-371): score, identity and counts of one segment, recomputed on the host from the path and the two sections
+ * (host memory; mirrored sections allowed).  The object belongs to dp and dies at gaba_dp_flush.  agcnt / aicnt count gap bases / gap regions where a
+ * advances alone, bgcnt / bicnt where b does.  As through the reference's public wrapper (gaba_wrap.h:446-454, which always calls its linear-model
+ * build), gaps cost gi per region + ge per base whatever the model, and the short-gap fields and adj stay zero. */
+struct gaba_score_s {
+	int64_t score; double identity;
+	uint32_t agcnt, bgcnt, mcnt, xcnt, aicnt, bicnt, afgcnt, bfgcnt, aficnt, bficnt;
+	int32_t adj; uint32_t reserved;
+};
+typedef struct gaba_score_s gaba_score_t;
+gaba_score_t *gaba_dp_calc_score(gaba_dp_t *dp, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b);
+
 /* CIGAR printers over a path (gaba.h:393-420, gaba_parse.h:247-263); host side, operate on host memory.
  * `path` must be preceded by the two header words {plen, 0x40000000} as in gaba_alignment_s (gaba.h:217). */
 uint64_t gaba_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
@@ -159,6 +171,21 @@ uint64_t gaba_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *p
 typedef int (*gaba_printer_t)(void *, uint64_t, char);
 uint64_t gaba_print_cigar_forward(gaba_printer_t printer, void *fp, uint32_t const *path, uint64_t offset, uint64_t len);
 uint64_t gaba_print_cigar_reverse(gaba_printer_t printer, void *fp, uint32_t const *path, uint64_t offset, uint64_t len);
+/* extended CIGAR with '=' and 'X' for one segment over its two sections (gaba.h:427-461, gaba_parse.h:274-372); bases compare raw, so N equals N */
+uint64_t gaba_print_xcigar_forward(gaba_printer_t printer, void *fp, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b);
+uint64_t gaba_print_xcigar_reverse(gaba_printer_t printer, void *fp, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b);
+uint64_t gaba_dump_xcigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b);
+uint64_t gaba_dump_xcigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b);
+/* one row of the gapped alignment as text (gaba.h:463-505, gaba_parse.h:380-529): conf = GABA_SEQ_A | GABA_SEQ_B with GABA_SEQ_FW | GABA_SEQ_RV; seq is one
+ * byte per base (0..3, 4 = N), read forward from seq or, with GABA_SEQ_RV, backward from seq[-1] and complemented.  buf needs len + 1 bytes. */
+#define GABA_SEQ_FW                 ( 0x00 )
+#define GABA_SEQ_RV                 ( 0x01 )
+#define GABA_SEQ_A                  ( 0x00 )
+#define GABA_SEQ_B                  ( 0x02 )
+uint64_t gaba_dump_seq_forward(char *buf, uint64_t buf_size, uint32_t conf, uint32_t const *path, uint64_t offset, uint64_t len, uint8_t const *seq, char gap);
+uint64_t gaba_dump_seq_reverse(char *buf, uint64_t buf_size, uint32_t conf, uint32_t const *path, uint64_t offset, uint64_t len, uint8_t const *seq, char gap);
+uint64_t gaba_dump_seq_ref(char *buf, uint64_t buf_size, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a);
+uint64_t gaba_dump_seq_query(char *buf, uint64_t buf_size, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *b);
 
 /* last kernel time of gaba_dp_extend_batch in milliseconds (HIP events on the launch stream) and work counters */
 typedef struct { double kernel_ms; uint64_t vectors, blocks, trace_steps; } gaba_batch_stats_t;

@@ -377,7 +377,7 @@ struct gaba_dp_context_s {
 	uint8_t *slab; uint32_t cap, top;
 	const gaba_arena_t *ar[2];               /* bound at the first fill: a sections come from ar[0], b sections from ar[1] */
 	ScalarOut *dout;
-	std::vector<gaba_fill_t *> fills; std::vector<gaba_pos_pair_t *> pps;
+	std::vector<gaba_fill_t *> fills; std::vector<gaba_pos_pair_t *> pps; std::vector<gaba_score_t *> scores;
 	hipStream_t stream;
 };
 
@@ -414,7 +414,8 @@ void gaba_dp_flush(gaba_dp_t *dp)
 	dp->top = SLAB_HEAD;
 	for(gaba_fill_t *f : dp->fills) free(f);
 	for(gaba_pos_pair_t *q : dp->pps) free(q);
-	dp->fills.clear(); dp->pps.clear();
+	for(gaba_score_t *q : dp->scores) free(q);
+	dp->fills.clear(); dp->pps.clear(); dp->scores.clear();
 }
 void gaba_dp_clean(gaba_dp_t *dp)
 {
@@ -552,6 +553,142 @@ uint64_t gaba_print_cigar_forward(gaba_printer_t printer, void *fp, uint32_t con
 	uint64_t clen = 0;
 	cigar_walk_forward(path, offset, len, [&](uint64_t n, char op) { clen += (uint64_t)printer(fp, n, op); });
 	return clen;
+}
+} /* extern "C" */
+/* one row of a gapped alignment (gaba_dump_seq_forward / _reverse, gaba_parse.h:380-493): the walk gives runs of 'D' (a advances), 'I' (b advances) and
+ * 'M'; row A prints gaps for I, row B for D.  GABA_SEQ_RV reads backward from seq[-1] and complements. */
+template<typename W> static inline uint64_t dump_seq_walk(W walk, char *buf, uint32_t conf, const uint8_t *seq, char gap)
+{
+	static const char fw[] = "ACGTNNNNNNNNNNNN", rv[] = "TGCANNNNNNNNNNNN";
+	char *r = buf; const uint8_t *q = seq; const bool is_b = (conf & GABA_SEQ_B) != 0, rev = (conf & GABA_SEQ_RV) != 0;
+	walk([&](uint64_t c, char op) {
+		if((op == 'D' && is_b) || (op == 'I' && !is_b)) { memset(r, gap, c); r += c; return; }
+		if(rev) { for(uint64_t t = 0; t < c; t++) *r++ = rv[*--q & 15]; } else { for(uint64_t t = 0; t < c; t++) *r++ = fw[*q++ & 15]; }
+	});
+	*r = 0; return (uint64_t)(r - buf);
+}
+/* extended CIGAR with = and X (gaba_parse.h:274-372): base getters hide the direction of the two sections; the bases compare raw (N equals N) */
+struct xc_side { const uint8_t *p; bool rev; uint8_t get(uint64_t i) const { static const uint8_t comp[16] = { 3, 2, 1, 0, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4 }; return rev ? comp[p[-1 - (int64_t)i] & 15] : p[i]; } void adv(uint64_t c) { if(rev) p -= c; else p += c; } };
+static inline xc_side xc_open(gaba_section_t const *sec, uint64_t pos)
+{
+	const uint8_t *q = sec->base + pos;
+	if(sec->base < GABA_EOU) return xc_side{ q, false };
+	return xc_side{ gaba_mirror(q, 0), true };
+}
+template<typename W, typename E> static inline void xcigar_walk(W walk, xc_side a, xc_side b, E emit)
+{
+	walk([&](uint64_t c, char op) {
+		if(op == 'D') { a.adv(c); emit(c, 'D'); return; }
+		if(op == 'I') { b.adv(c); emit(c, 'I'); return; }
+		uint64_t i = 0;
+		while(i < c) {
+			uint64_t s0 = i; while(i < c && a.get(i) == b.get(i)) i++;
+			if(i > s0) emit(i - s0, '=');
+			s0 = i; while(i < c && a.get(i) != b.get(i)) i++;
+			if(i > s0) emit(i - s0, 'X');
+		}
+		a.adv(c); b.adv(c);
+	});
+}
+extern "C" {
+uint64_t gaba_dump_seq_forward(char *buf, uint64_t buf_size, uint32_t conf, uint32_t const *path, uint64_t offset, uint64_t len, uint8_t const *seq, char gap)
+{
+	(void)buf_size;
+	return dump_seq_walk([&](auto fn) { cigar_walk_forward(path, offset, len, fn); }, buf, conf, seq, gap);
+}
+uint64_t gaba_dump_seq_reverse(char *buf, uint64_t buf_size, uint32_t conf, uint32_t const *path, uint64_t offset, uint64_t len, uint8_t const *seq, char gap)
+{
+	(void)buf_size;
+	return dump_seq_walk([&](auto fn) { cigar_walk_reverse(path, offset, len, fn); }, buf, conf, seq, gap);
+}
+uint64_t gaba_dump_seq_ref(char *buf, uint64_t buf_size, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a)
+{
+	const bool fwd = a->base < GABA_EOU;
+	return gaba_dump_seq_forward(buf, buf_size, GABA_SEQ_A | (fwd ? GABA_SEQ_FW : GABA_SEQ_RV), path, s->ppos, (uint64_t)s->alen + s->blen,
+		fwd ? &a->base[s->apos] : gaba_mirror(&a->base[s->apos], 0), '-');
+}
+uint64_t gaba_dump_seq_query(char *buf, uint64_t buf_size, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *b)
+{
+	const bool fwd = b->base < GABA_EOU;
+	return gaba_dump_seq_forward(buf, buf_size, GABA_SEQ_B | (fwd ? GABA_SEQ_FW : GABA_SEQ_RV), path, s->ppos, (uint64_t)s->alen + s->blen,
+		fwd ? &b->base[s->bpos] : gaba_mirror(&b->base[s->bpos], 0), '-');
+}
+/* forward: from (apos, bpos) upward; reverse: from the segment's end downward, so each side is read in the opposite sense (gaba_parse.h:325-352) */
+uint64_t gaba_print_xcigar_forward(gaba_printer_t printer, void *fp, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b)
+{
+	uint64_t clen = 0;
+	xcigar_walk([&](auto fn) { cigar_walk_forward(path, s->ppos, (uint64_t)s->alen + s->blen, fn); }, xc_open(a, s->apos), xc_open(b, s->bpos),
+		[&](uint64_t n, char op) { clen += (uint64_t)printer(fp, n, op); });
+	return clen;
+}
+uint64_t gaba_print_xcigar_reverse(gaba_printer_t printer, void *fp, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b)
+{
+	uint64_t clen = 0;
+	xc_side sa = xc_open(a, (uint64_t)s->apos + s->alen), sb = xc_open(b, (uint64_t)s->bpos + s->blen); sa.rev = !sa.rev; sb.rev = !sb.rev;
+	xcigar_walk([&](auto fn) { cigar_walk_reverse(path, s->ppos, (uint64_t)s->alen + s->blen, fn); }, sa, sb, [&](uint64_t n, char op) { clen += (uint64_t)printer(fp, n, op); });
+	return clen;
+}
+uint64_t gaba_dump_xcigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b)
+{
+	(void)buf_size; char *q = buf;
+	xcigar_walk([&](auto fn) { cigar_walk_forward(path, s->ppos, (uint64_t)s->alen + s->blen, fn); }, xc_open(a, s->apos), xc_open(b, s->bpos),
+		[&](uint64_t n, char op) { q = cg_put(q, n, op); });
+	*q = 0; return (uint64_t)(q - buf);
+}
+uint64_t gaba_dump_xcigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b)
+{
+	(void)buf_size; char *q = buf;
+	xc_side sa = xc_open(a, (uint64_t)s->apos + s->alen), sb = xc_open(b, (uint64_t)s->bpos + s->blen); sa.rev = !sa.rev; sb.rev = !sb.rev;
+	xcigar_walk([&](auto fn) { cigar_walk_reverse(path, s->ppos, (uint64_t)s->alen + s->blen, fn); }, sa, sb, [&](uint64_t n, char op) { q = cg_put(q, n, op); });
+	*q = 0; return (uint64_t)(q - buf);
+}
+/* gaba_dp_calc_score (gaba.h:357-371, gaba.c:3409-3560): score, identity, match / mismatch / gap counts of one segment, recomputed on the host from the
+ * path and the two sections.  What callers of the reference get is its public wrapper, which always dispatches to the linear-model build of this
+ * function (gaba_wrap.h:446-454): gaps are charged gi per region + ge per base whatever the model, the short-gap counts stay zero and adj is never set
+ * -- reproduced as such.  The forward walk hands over gaps in pieces of at most 64 (63 for the first kind), so a longer gap counts as several
+ * regions; the lookup index is a | shift(b) with N -> 4 | 2 of the p-fetch tables (gaba.c:866-905).  The object lives until gaba_dp_flush. */
+gaba_score_t *gaba_dp_calc_score(gaba_dp_t *dp, uint32_t const *path, gaba_path_section_t const *s, gaba_section_t const *a, gaba_section_t const *b)
+{
+	if(!dp || !path || !s || !a || !b) return NULL;
+	const Consts &c = dp->ctx->hc;
+	const int ofs = 2 * (c.gi + c.ge);
+	int8_t sbt[16]; for(int i = 0; i < 16; i++) sbt[i] = (int8_t)(((const int8_t *)c.sb)[i] - ofs);
+	static const uint8_t shift_b[16] = { 0, 4, 8, 12, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2 }, comp_a[16] = { 3, 2, 1, 0, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4 }, compshift_b[16] = { 12, 8, 4, 0, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2 };
+	const bool arev = a->base >= GABA_EOU, brev = b->base >= GABA_EOU;
+	const uint8_t *ap = !arev ? &a->base[s->apos] : gaba_mirror(&a->base[s->apos], 0), *bp = !brev ? &b->base[s->bpos] : gaba_mirror(&b->base[s->bpos], 0);
+	int64_t gac[2] = { 0, 0 }, gbc[2] = { 0, 0 };       /* { bases, regions } */
+	uint64_t xc = 0, dc = 0; int64_t score = 0;
+	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
+	const uint64_t len = (uint64_t)s->alen + s->blen;
+	uint64_t lim = s->ppos + (((uintptr_t)path & 4) ? 32 : 0) + len, ridx = len;
+	while((int64_t)ridx > 0) {                                                                 /* _parser_loop_fw, gaba_parse.h:147-167 */
+		uint64_t m = cg_tz(~cg_u64(p, (int64_t)(lim - ridx))), n = m - (m > 0); if(n > ridx) n = ridx;
+		ridx -= n;                                                                              /* insertion: b advances */
+		if(brev) bp -= n; else bp += n;
+		gac[0] += (int64_t)n; gac[1] += n > 0;
+		m = cg_tz(cg_u64(p, (int64_t)(lim - ridx))); n = m < ridx ? m : ridx;
+		ridx -= n;                                                                              /* deletion: a advances */
+		if(arev) ap -= n; else ap += n;
+		gbc[0] += (int64_t)n; gbc[1] += n > 0;
+		do {
+			m = cg_tz(cg_u64(p, (int64_t)(lim - ridx)) ^ 0x5555555555555555ull); n = (m < ridx ? m : ridx) & ~1ull; ridx -= n;
+			const uint64_t d = n >> 1;
+			for(uint64_t t = 0; t < d; t++) {
+				const uint8_t av = arev ? comp_a[ap[-1 - (int64_t)t] & 15] : ap[t], bv = brev ? compshift_b[bp[-1 - (int64_t)t] & 15] : shift_b[bp[t] & 15];
+				const int8_t sc = sbt[(av | bv) & 15];
+				score += sc; xc += sc < 0;
+			}
+			dc += d; if(arev) ap -= d; else ap += d; if(brev) bp -= d; else bp += d;
+		} while(n == 64);
+	}
+	gaba_score_t *sc = (gaba_score_t *)calloc(1, sizeof(gaba_score_t));
+	if(!sc) return NULL;
+	dp->scores.push_back(sc);
+	sc->score = score - (int64_t)c.gi * (gac[1] + gbc[1]) - (int64_t)c.ge * (gac[0] + gbc[0]);
+	sc->identity = dc > 0 ? (double)(dc - xc) / (double)dc : 0.0;
+	sc->agcnt = (uint32_t)gbc[0]; sc->bgcnt = (uint32_t)gac[0]; sc->mcnt = (uint32_t)(dc - xc); sc->xcnt = (uint32_t)xc;
+	sc->aicnt = (uint32_t)gbc[1]; sc->bicnt = (uint32_t)gac[1];
+	return sc;
 }
 /* gaba_dp_save_stack / gaba_dp_flush_stack (gaba.h:280-289): the bump pointer of the context's device workspace */
 struct gaba_stack_s { uint32_t top; size_t n_fill, n_pp; };

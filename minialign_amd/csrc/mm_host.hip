@@ -284,6 +284,7 @@ struct mm_opt_s {
 	/* output (minialign.c:5880-5967): flag = -P 0x08 and bit 0 when -R is given; tags = bits 1 << MM_xx of -T.  The reference's printer ORs the two
 	 * into one word (minialign.c:5677), so -P also switches IH on and -T IH also omits the secondary records: kept */
 	uint64_t flag = 0, tags = 0; std::string rg_line, rg_id; bool keep_qual = false;
+	uint32_t format = 0;             /* -O: 0 sam, 1 maf, 2 blast6, 5 paf (minialign.c:2543-2549, 5940) */
 	uint64_t ptags() const { return flag | tags; }
 	uint32_t wlen = 7000, glen = 7000, min_score = 50; float min_ratio = 0.3f;
 	gaba_params_t p;
@@ -384,6 +385,11 @@ int opt_one(mm_opt_t *o, char c, const char *arg)
 		case '1': case '2': return 0;                      /* input batch / output buffer sizes of the reference's host pipeline: accepted, no meaning here */
 		case 'v': return 0;
 		case 'h': o->help = 1; return 0;
+		case 'O': {
+			static const struct { const char *k; uint32_t v; } t[] = { { "sam", 0 }, { "maf", 1 }, { "blast6", 2 }, { "paf", 5 } };
+			for(auto &e : t) if(strcmp(arg, e.k) == 0) { o->format = e.v; return 0; }
+			return opt_fail("unknown output format (-O).");
+		}
 		case 'P': o->flag |= 0x08; return 0;
 		case 'Q': o->keep_qual = true; return 0;
 		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
@@ -426,7 +432,7 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
 		const char *a = argv[i];
 		if(a[0] == '-' && a[1]) {
 			const char *arg = a + 2;
-			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGdfBLe12TR", a[1])) arg = argv[++i];
+			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGdfBLe12TRO", a[1])) arg = argv[++i];
 			if(opt_one(o, a[1], arg)) return 1;
 		} else if(nf < max_files) files[nf++] = a;
 	}
@@ -984,6 +990,86 @@ void sam_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 	}
 }
 
+/* ---- the other output formats: MAF, BLAST6 (tabular), PAF (minialign.c:5427-5625); nothing is printed for unmapped reads ---- */
+void put_fixed(std::string &s, uint32_t n, int c)           /* _putfi, minialign.c:4812: n with a decimal point in front of its last c digits */
+{
+	char d[24]; int i = 0;
+	while(n || i <= c) { d[i++] = (char)('0' + n % 10); n /= 10; }
+	for(int j = i; j > c; j--) s.push_back(d[j - 1]);
+	s.push_back('.');
+	for(int j = c; j > 0; j--) s.push_back(d[j - 1]);
+}
+void put_pair(std::string &s1, std::string &s2, uint32_t n1, uint32_t n2)       /* _putpi, minialign.c:4847: two numbers right-aligned to one width */
+{
+	char d1[16], d2[16]; int i = 0;
+	while(n1 | n2) { d1[i] = (char)(n1 % 10); d2[i] = (char)(n2 % 10); n1 /= 10; n2 /= 10; i++; }
+	if(i == 0) { d1[0] = d2[0] = 0; i = 1; }
+	int z1 = 0, z2 = 0;
+	for(int j = i; j > 0; j--) {
+		z1 |= d1[j - 1] | (j == 1); z2 |= d2[j - 1] | (j == 1);
+		s1.push_back((char)(d1[j - 1] + '0' - (z1 ? 0 : 0x10))); s2.push_back((char)(d2[j - 1] + '0' - (z2 ? 0 : 0x10)));
+	}
+}
+void alt_record(const mm_align_t *a, std::string &s, const char *qname, const uint8_t *qseq, uint32_t qlen, const OutReg &reg,
+	const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths)
+{
+	if(!reg.mapped || reg.n_all == 0) return;
+	const uint64_t f = a->o.ptags();
+	const uint32_t n = (f & 0x08) ? reg.n_uniq : reg.n_all;
+	const size_t l_qname = strlen(qname);
+	std::vector<char> buf;
+	for(uint32_t i = 0; i < n; i++) {
+		const AlnRec &al = alns[reg.aln[i].aln];
+		const gaba::Segment &sg = segs[al.seg_off + al.slen - 1], &eg = segs[al.seg_off];
+		const HSeq &r = a->mi->seq[sg.aid >> 1]; const uint32_t rl = (uint32_t)r.seq.size();
+		const uint32_t dcnt = al.dcnt, mcnt = h_d2u32((double)dcnt * al.identity), gcnt = al.agcnt + al.bgcnt;
+		if(a->o.format == 1) {                 /* mm_print_maf_mapped, :5476 */
+			for(uint32_t j = al.slen; j > 0; j--) {
+				const gaba::Segment &g = segs[al.seg_off + j - 1];
+				const HSeq &rr = a->mi->seq[g.aid >> 1]; const uint32_t rrl = (uint32_t)rr.seq.size();
+				const uint32_t rs = rrl - g.apos - g.alen, qs = qlen - g.bpos - g.blen;
+				const uint64_t plen = (uint64_t)g.alen + g.blen;
+				s += "a score="; put_num(s, (uint32_t)al.score); s.push_back('\n');
+				const size_t w = std::max(rr.name.size(), l_qname) + 1;
+				std::string q2 = "s "; q2 += qname; q2.append(w - l_qname, ' ');
+				s += "s "; s += rr.name; s.append(w - rr.name.size(), ' ');
+				put_pair(s, q2, rs, qs); s.push_back(' '); q2.push_back(' ');
+				put_pair(s, q2, g.alen, g.blen); s.push_back(' '); q2.push_back(' ');
+				s += "+ "; q2.push_back((g.bid & 1) ? '+' : '-'); q2.push_back(' ');
+				put_pair(s, q2, rrl, qlen); s.push_back(' '); q2.push_back(' ');
+				buf.resize(plen + 64);
+				uint64_t m = gaba_dump_seq_reverse(buf.data(), buf.size(), GABA_SEQ_A, paths + al.path_off, g.ppos, plen, rr.seq.data() + rs, '-');
+				s.append(buf.data(), m); s.push_back('\n');
+				s += q2;
+				m = gaba_dump_seq_reverse(buf.data(), buf.size(), GABA_SEQ_B | ((g.bid & 1) ? GABA_SEQ_FW : GABA_SEQ_RV), paths + al.path_off, g.ppos, plen,
+					(g.bid & 1) ? qseq + qs : qseq + (qlen - qs), '-');
+				s.append(buf.data(), m); s += "\n\n";
+			}
+		} else if(a->o.format == 2) {          /* mm_print_blast6_mapped, :5497: qname rname idt len #x #gap qs qe rs re e-value bitscore */
+			const uint32_t rs = (sg.bid & 1) ? rl - sg.apos - sg.alen + 1 : rl - eg.apos, re = (sg.bid & 1) ? rl - eg.apos : rl - sg.apos - sg.alen + 1;
+			const uint32_t qs = qlen - sg.bpos - sg.blen + 1, qe = qlen - eg.bpos;
+			s += qname; s.push_back('\t'); s += r.name; s.push_back('\t');
+			put_fixed(s, h_d2u32(1000.0 * al.identity), 3);
+			for(uint32_t v : { dcnt + gcnt, dcnt - mcnt, gcnt, qs, qe, rs, re }) { s.push_back('\t'); put_num(s, v); }
+			s.push_back('\t');
+			const double bit = 1.85 * (double)al.score - 0.02;
+			put_fixed(s, h_d2u32(1000.0 * (double)rl * (double)qlen * pow(2.0, -bit)), 3);
+			s.push_back('\t'); put_num(s, h_d2u32(bit)); s.push_back('\n');
+		} else {                                /* mm_print_paf_mapped, :5549: qname ql qs qe strand rname rl rs re #match block_len mapq [tags] */
+			const uint32_t rs = rl - sg.apos - sg.alen, re = rl - eg.apos, qs = qlen - sg.bpos - sg.blen, qe = qlen - eg.bpos;
+			s += qname; for(uint32_t v : { qlen, qs, qe }) { s.push_back('\t'); put_num(s, v); }
+			s.push_back('\t'); s.push_back((sg.bid & 1) ? '+' : '-'); s.push_back('\t'); s += r.name;
+			for(uint32_t v : { rl, rs, re, mcnt, dcnt + gcnt, reg.aln[i].mapq >> 4 }) { s.push_back('\t'); put_num(s, v); }
+			if((f >> 4) & 1) { s += "\tAS:i:"; put_num(s, (uint32_t)al.score); }
+			if((f >> 10) & 1) { s += "\tID:f:"; put_fixed(s, h_d2u32(al.identity * 10000.0), 4); }
+			if((f >> 6) & 1) { s += "\tNM:i:"; put_num(s, (dcnt - mcnt) + gcnt); }
+			if((f >> 11) & 1) { s += "\tSQ:i:"; sam_seq(s, qseq, qlen, false); }
+			if((f >> 9) & 1) { s += "\tCG:Z:"; cigar_reverse(s, paths + al.path_off, 0, al.plen); }
+			s.push_back('\n');
+		}
+	}
+}
+
 bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_qlen, uint64_t scale)
 {
 	bool ok = true;
@@ -1237,7 +1323,8 @@ bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piec
 				OutReg reg; const ReadState &rs = hst[i];
 				const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.get();
 				if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
-				sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get(), i < b.rec.size() ? b.rec[i] : nullptr);
+				if(a->o.format == 0) sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get(), i < b.rec.size() ? b.rec[i] : nullptr);
+				else alt_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get());
 			}
 		};
 		std::vector<std::thread> th;
@@ -1505,7 +1592,7 @@ extern "C" int mm_main(int argc, char **argv)
 		if(!joined) { rt.join(); joined = true; }
 		if(!a) { fprintf(stderr, "[E::main_align] failed to instanciate alignment context.\n"); mm_idx_destroy(mi); rc = 1; break; }
 		fprintf(stderr, "[M::main_align::%.3f] loaded/built index for %u target sequence(s).\n", (now_ms() - t0) * 1e-3, mm_idx_n_seq(mi));
-		mm_print_sam_header(a, stdout, o->arg_line.c_str());
+		if(o->format == 0) mm_print_sam_header(a, stdout, o->arg_line.c_str());        /* only SAM has a header (minialign.c:5666-5671) */
 		for(int i = 1; i < nf && rc == 0; i++) {
 			if(i == 1 && first_reads) { rc = align_reads(a, first_reads, stdout, prebuilt); if(!prebuilt) first_reads = NULL; }      /* kept for the next block of a prebuilt index */
 			else { rc = mm_align_file(a, files[i], stdout); }

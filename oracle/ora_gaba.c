@@ -1030,6 +1030,23 @@ void og_parse_path_reverse(uint32_t const *path, uint64_t offset, uint64_t len, 
 		if((sidx - idx) >> 1) { fn(ctx, 'M', (sidx - idx) >> 1); }
 	}
 }
+typedef struct { char *r; uint8_t const *q; uint32_t conf; char gap; } dump_seq_t;
+static void dump_seq_step(void *ctx, char op, uint64_t c)
+{
+	dump_seq_t *d = (dump_seq_t *)ctx;
+	int const is_b = (d->conf & OG_SEQ_B) != 0;
+	if((op == 'D' && is_b) || (op == 'I' && !is_b)) { memset(d->r, d->gap, c); d->r += c; return; }
+	if(d->conf & OG_SEQ_RV) { for(uint64_t t = 0; t < c; t++) { *d->r++ = "TGCANNNNNNNNNNNN"[*--d->q & 15]; } }
+	else { for(uint64_t t = 0; t < c; t++) { *d->r++ = "ACGTNNNNNNNNNNNN"[*d->q++ & 15]; } }
+}
+uint64_t og_dump_seq_reverse(char *buf, uint64_t buf_size, uint32_t conf, uint32_t const *path, uint64_t offset, uint64_t len, uint8_t const *seq, char gap)
+{
+	(void)buf_size;
+	dump_seq_t d = { buf, seq, conf, gap };
+	og_parse_path_reverse(path, offset, len, dump_seq_step, &d);
+	*d.r = 0;
+	return (uint64_t)(d.r - buf);
+}
 uint64_t og_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
 {
 	(void)buf_size;

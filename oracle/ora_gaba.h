@@ -92,6 +92,10 @@ void og_aln_free(og_alignment_t *aln);
 uint64_t og_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
 uint64_t og_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len);
 /* _parser_loop_rv (gaba_parse.h:168-188) with a callback per nonzero run, in the order the reverse dumpers see them: op is 'D', 'I' or 'M' */
+/* gaba_dump_seq_reverse (gaba_parse.h:445-493): one row of a gapped alignment; conf = OG_SEQ_A / OG_SEQ_B | OG_SEQ_FW / OG_SEQ_RV, seq one byte per
+ * base (0..4), read forward from seq or, with OG_SEQ_RV, backward from seq[-1] and complemented; returns the length written (plus a NUL) */
+enum { OG_SEQ_FW = 0, OG_SEQ_RV = 1, OG_SEQ_A = 0, OG_SEQ_B = 2 };
+uint64_t og_dump_seq_reverse(char *buf, uint64_t buf_size, uint32_t conf, uint32_t const *path, uint64_t offset, uint64_t len, uint8_t const *seq, char gap);
 void og_parse_path_reverse(uint32_t const *path, uint64_t offset, uint64_t len, void (*fn)(void *ctx, char op, uint64_t cnt), void *ctx);
 
 /* convenience used by the tests: same record as oracle/ref_harness/gaba_ref_shim.c:shim_result_t */

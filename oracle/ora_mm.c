@@ -130,6 +130,11 @@ static int opt_one(om_opt_t *o, char c, char const *arg, size_t l)
 		case 'W': o->wlen = (uint32_t)atoi(arg); return 0;
 		case 'G': o->glen = (uint32_t)atoi(arg); return 0;
 		case 't': case '1': case '2': case 'v': return 0;
+		case 'O': {
+			static struct { char const *k; uint32_t v; } const t[] = { { "sam", 0 }, { "maf", 1 }, { "blast6", 2 }, { "paf", 5 } };
+			for(int i = 0; i < 4; i++) { if(strcmp(arg, t[i].k) == 0) { o->format = t[i].v; return 0; } }
+			return 1;
+		}
 		case 'P': o->flag |= 0x08; return 0;
 		case 'Q': o->keep_qual = 1; return 0;
 		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
@@ -218,7 +223,7 @@ int om_opt_parse(om_opt_t *o, int argc, char const *const *argv, char const **fi
 		char const *a = argv[i];
 		if(a[0] == '-' && a[1]) {
 			char const *arg = a + 2;
-			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGfBLe12TR", a[1])) { arg = argv[++i]; }
+			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGfBLe12TRO", a[1])) { arg = argv[++i]; }
 			rc |= opt_one(o, a[1], arg, strlen(arg));
 		} else if(nf < max_files) { files[nf++] = a; }
 	}
@@ -1217,6 +1222,89 @@ void om_sam_record_opt(FILE *fp, om_opt_t const *o, om_seq_t const *ref, om_seq_
 }
 void om_sam_record(FILE *fp, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg) { om_sam_record_opt(fp, NULL, ref, q, reg); }
 
+/* ---- the other output formats (minialign.c:5427-5625) ---- */
+static void put_fixed(FILE *fp, uint32_t n, int c)          /* _putfi, minialign.c:4812: n with a decimal point in front of its last c digits */
+{
+	char d[24]; int i = 0;
+	while(n || i <= c) { d[i++] = (char)('0' + n % 10); n /= 10; }
+	for(int j = i; j > c; j--) { fputc(d[j - 1], fp); }
+	fputc('.', fp);
+	for(int j = c; j > 0; j--) { fputc(d[j - 1], fp); }
+}
+static void put_pair(char *b1, char *b2, uint32_t n1, uint32_t n2, int *l)      /* _putpi, minialign.c:4847: two numbers right-aligned to one width */
+{
+	char d1[16], d2[16]; int i = 0;
+	uint32_t m1 = n1, m2 = n2;
+	while(m1 | m2) { d1[i] = (char)(m1 % 10); d2[i] = (char)(m2 % 10); m1 /= 10; m2 /= 10; i++; }
+	if(i == 0) { d1[0] = d2[0] = 0; i = 1; }
+	int z1 = 0, z2 = 0;
+	for(int j = i; j > 0; j--) {
+		z1 |= d1[j - 1] | (j == 1); z2 |= d2[j - 1] | (j == 1);
+		*b1++ = (char)(d1[j - 1] + '0' - (z1 ? 0 : 0x10)); *b2++ = (char)(d2[j - 1] + '0' - (z2 ? 0 : 0x10));
+	}
+	*l = i;
+}
+static void maf_core(FILE *fp, om_seq_t const *r, om_seq_t const *q, uint32_t const *path, og_segment_t const *s, int64_t score)     /* mm_print_maf_mapped_core, :5427 */
+{
+	fprintf(fp, "a score=%u\n", (uint32_t)score);
+	uint32_t rid = s->aid >> 1;
+	uint32_t const rs = r[rid].l_seq - s->apos - s->alen, qs = q->l_seq - s->bpos - s->blen;
+	uint32_t l = (r[rid].l_name > q->l_name ? r[rid].l_name : q->l_name) + 1;
+	char n1[3][16], n2[3][16]; int w[3];
+	put_pair(n1[0], n2[0], rs, qs, &w[0]); put_pair(n1[1], n2[1], s->alen, s->blen, &w[1]); put_pair(n1[2], n2[2], r[rid].l_seq, q->l_seq, &w[2]);
+	uint64_t plen = (uint64_t)s->alen + s->blen;
+	char *buf = (char *)malloc(plen + 64);
+	fprintf(fp, "s %.*s%*s%.*s %.*s + %.*s ", (int)r[rid].l_name, r[rid].name, (int)(l - r[rid].l_name), "", w[0], n1[0], w[1], n1[1], w[2], n1[2]);
+	og_dump_seq_reverse(buf, plen + 64, OG_SEQ_A, path, s->ppos, plen, &r[rid].seq[rs], '-');
+	fprintf(fp, "%s\n", buf);
+	fprintf(fp, "s %.*s%*s%.*s %.*s %c %.*s ", (int)q->l_name, q->name, (int)(l - q->l_name), "", w[0], n2[0], w[1], n2[1], (s->bid & 0x01) ? '+' : '-', w[2], n2[2]);
+	og_dump_seq_reverse(buf, plen + 64, OG_SEQ_B | ((s->bid & 0x01) ? OG_SEQ_FW : OG_SEQ_RV), path, s->ppos, plen, (s->bid & 0x01) ? &q->seq[qs] : &q->seq[q->l_seq - qs], '-');
+	fprintf(fp, "%s\n\n", buf);
+	free(buf);
+}
+void om_print_record(FILE *fp, om_opt_t const *o, om_seq_t const *r, om_seq_t const *q, om_reg_t const *reg)
+{
+	if(o->format == 0) { om_sam_record_opt(fp, o, r, q, reg); return; }
+	if(reg == NULL) { return; }
+	uint64_t const f = o->flag | o->tags;
+	uint64_t const n = (f & 0x08) ? reg->n_uniq : reg->n_all;
+	for(uint64_t i = 0; i < n; i++) {
+		om_aln_t const *a = &reg->aln[i];
+		og_segment_t const *s = &a->a->seg[a->a->slen - 1], *e = &a->a->seg[0];
+		uint32_t rid = s->aid >> 1;
+		uint32_t dcnt = a->a->dcnt, mcnt = d2u32((double)dcnt * a->a->identity), gcnt = a->a->agcnt + a->a->bgcnt;
+		if(o->format == 1) {
+			for(uint64_t j = a->a->slen; j > 0; j--) { maf_core(fp, r, q, a->a->path, &a->a->seg[j - 1], a->a->score); }
+		} else if(o->format == 2) {          /* mm_print_blast6_mapped, :5497: qname rname idt len #x #gap qs qe rs re e-value bitscore */
+			uint32_t rs = (s->bid & 0x01) ? r[rid].l_seq - s->apos - s->alen + 1 : r[rid].l_seq - e->apos;
+			uint32_t re = (s->bid & 0x01) ? r[rid].l_seq - e->apos : r[rid].l_seq - s->apos - s->alen + 1;
+			uint32_t qs = q->l_seq - s->bpos - s->blen + 1, qe = q->l_seq - e->bpos;
+			fprintf(fp, "%.*s\t%.*s\t", (int)q->l_name, q->name, (int)r[rid].l_name, r[rid].name);
+			put_fixed(fp, d2u32(1000.0 * a->a->identity), 3);
+			fprintf(fp, "\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t", dcnt + gcnt, dcnt - mcnt, gcnt, qs, qe, rs, re);
+			double bit = 1.85 * (double)a->a->score - 0.02;
+			put_fixed(fp, d2u32(1000.0 * (double)r[rid].l_seq * (double)q->l_seq * pow(2.0, -bit)), 3);
+			fprintf(fp, "\t%u\n", d2u32(bit));
+		} else {                              /* mm_print_paf_mapped, :5549: qname ql qs qe strand rname rl rs re #match block_len mapq [tags] */
+			uint32_t const rs = r[rid].l_seq - s->apos - s->alen, re = r[rid].l_seq - e->apos;
+			uint32_t const qs = q->l_seq - s->bpos - s->blen, qe = q->l_seq - e->bpos;
+			fprintf(fp, "%.*s\t%u\t%u\t%u\t%c\t%.*s\t%u\t%u\t%u\t%u\t%u\t%u", (int)q->l_name, q->name, q->l_seq, qs, qe, (s->bid & 0x01) ? '+' : '-',
+				(int)r[rid].l_name, r[rid].name, r[rid].l_seq, rs, re, mcnt, dcnt + gcnt, a->mapq >> MAPQ_DEC);
+			if((f >> OM_AS) & 1) { fprintf(fp, "\tAS:i:%u", (uint32_t)a->a->score); }
+			if((f >> OM_ID) & 1) { fputs("\tID:f:", fp); put_fixed(fp, d2u32(a->a->identity * 10000.0), 4); }
+			if((f >> OM_NM) & 1) { fprintf(fp, "\tNM:i:%u", (dcnt - mcnt) + gcnt); }
+			if((f >> OM_SQ) & 1) { fputs("\tSQ:i:", fp); put_seq(fp, q->seq, q->l_seq, 0); }
+			if((f >> OM_CG) & 1) {
+				fputs("\tCG:Z:", fp);
+				char *buf = (char *)malloc((uint64_t)a->a->plen * 3 + 64);
+				og_dump_cigar_reverse(buf, (uint64_t)a->a->plen * 3 + 64, a->a->path, 0, a->a->plen);
+				fputs(buf, fp); free(buf);
+			}
+			fputc('\n', fp);
+		}
+	}
+}
+
 /* ---- whole program ---- */
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *out, char const *arg_line, double *map_seconds, uint64_t *bases)
@@ -1235,13 +1323,13 @@ int om_main_opt(om_opt_t const *op, char const *ref_fn, char const *query_fn, FI
 	om_align_t *al = om_align_init(&o, mi);
 	if(al == NULL) { return 3; }
 	om_seqs_t qs = om_read_fasta_ex(query_fn, (int)o.keep_qual, (int)(((o.flag | o.tags) >> OM_CO) & 1)); om_seqs_drop_short(&qs, o.min_len);
-	om_sam_header(out, &o, ref.a, (uint32_t)ref.n);
+	if(o.format == 0) { om_sam_header(out, &o, ref.a, (uint32_t)ref.n); }          /* only SAM has a header (minialign.c:5666-5671) */
 	double tmap = 0; uint64_t nb = 0;
 	for(uint64_t i = 0; i < qs.n; i++) {
 		double t1 = now_s();
 		om_reg_t *reg = om_align_seq(al, qs.a[i].l_seq, qs.a[i].seq);
 		tmap += now_s() - t1; nb += qs.a[i].l_seq;
-		om_sam_record_opt(out, &o, ref.a, &qs.a[i], reg);
+		om_print_record(out, &o, ref.a, &qs.a[i], reg);
 		om_reg_free(reg);
 	}
 	if(map_seconds) { *map_seconds = tmap; }

@@ -30,8 +30,9 @@ typedef struct {
 	uint64_t flag, tags;
 	char *rg_line, *rg_id;      /* -R, unescaped line and the "ID:..." token */
 	uint32_t keep_qual;         /* -Q */
+	uint32_t format;            /* -O: 0 sam, 1 maf, 2 blast6, 5 paf (minialign.c:2543-2549, 5940) */
 } om_opt_t;
-enum { OM_RG = 0, OM_CO = 1, OM_NH = 2, OM_IH = 3, OM_AS = 4, OM_XS = 5, OM_NM = 6, OM_SA = 7, OM_MD = 8 };     /* minialign.c:2530-2538 */
+enum { OM_RG = 0, OM_CO = 1, OM_NH = 2, OM_IH = 3, OM_AS = 4, OM_XS = 5, OM_NM = 6, OM_SA = 7, OM_MD = 8, OM_CG = 9, OM_ID = 10, OM_SQ = 11 };     /* minialign.c:2530-2538 */
 
 /* defaults (minialign.c:6141-6162) followed by a preset string such as "pacbio" or "ont.1dsq" (minialign.c:5846-5900);
  * returns nonzero on unknown preset */
@@ -88,6 +89,8 @@ void om_sam_header(FILE *fp, om_opt_t const *o, om_seq_t const *ref, uint32_t n_
 void om_sam_record(FILE *fp, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg);
 /* with the optional tags, read group, qualities and -P of o (minialign.c:5204-5426) */
 void om_sam_record_opt(FILE *fp, om_opt_t const *o, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg);
+/* the record of a read in the format o->format selects (SAM, or MAF / BLAST6 / PAF: minialign.c:5427-5625; those print nothing for unmapped reads) */
+void om_print_record(FILE *fp, om_opt_t const *o, om_seq_t const *ref, om_seq_t const *q, om_reg_t const *reg);
 
 /* whole program: `minialign -x<preset> ref.fa reads.fa > out` (minialign.c:6365-6447) */
 int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *out, char const *arg_line, double *map_seconds, uint64_t *bases);

@@ -13,6 +13,7 @@
 #define _GABA_PARSE_EXPORT_LEVEL static inline
 #define _GABA_WRAP_EXPORT_LEVEL  static inline
 #define UNITTEST 0
+#define BIT 2                          /* as minialign.c:155 sets it before it includes the same headers */
 #include <stdlib.h>
 #include <string.h>
 #include "/root/reference/gaba_wrap.h"
@@ -119,4 +120,27 @@ uint64_t shim_dump_cigar_reverse(char *buf, uint64_t buf_size, uint32_t const *p
 uint64_t shim_dump_cigar_forward(char *buf, uint64_t buf_size, uint32_t const *path, uint64_t offset, uint64_t len)
 {
 	return gaba_dump_cigar_forward(buf, buf_size, path, offset, len);
+}
+
+/* the other text dumpers of gaba_parse.h (extended CIGAR :274-372, gapped sequence rows :380-529) and gaba_dp_calc_score (gaba.c:3493), for the golden
+ * vectors of tests/golden/make_dumper_golden.py.  Sections are built as in shim_extend; `path` points behind the two header words of gaba_alignment_s.
+ * out[0..4] receive the five strings (xcigar forward / reverse, row A, row B through gaba_dump_seq_ref / _query, row A reverse as the MAF printer calls it),
+ * each of capacity cap; sc receives score, mcnt, xcnt, agcnt, bgcnt, aicnt, bicnt, afgcnt, bfgcnt, aficnt, bficnt, adj and *identity the identity. */
+int shim_dumpers(gaba_dp_t *dp0, uint8_t const *a, uint32_t alen, int arev, uint8_t const *b, uint32_t blen, int brev,
+	uint32_t const *path, struct gaba_segment_s const *seg, char *out, uint64_t cap, int64_t *sc, double *identity)
+{
+	gaba_section_t as = gaba_build_section(arev ? 1 : 0, arev ? gaba_mirror(a, alen) : a, alen);
+	gaba_section_t bs = gaba_build_section(brev ? 3 : 2, brev ? gaba_mirror(b, blen) : b, blen);
+	gaba_dump_xcigar_forward(out + 0 * cap, cap, path, seg, &as, &bs);
+	gaba_dump_xcigar_reverse(out + 1 * cap, cap, path, seg, &as, &bs);
+	gaba_dump_seq_ref(out + 2 * cap, cap, path, seg, &as);
+	gaba_dump_seq_query(out + 3 * cap, cap, path, seg, &bs);
+	if(!arev) { gaba_dump_seq_reverse(out + 4 * cap, cap, GABA_SEQ_A | GABA_SEQ_FW, path, seg->ppos, gaba_plen(seg), &a[seg->apos], '-'); } else { out[4 * cap] = 0; }
+	gaba_dp_flush(dp0);
+	gaba_score_t const *s = gaba_dp_calc_score(dp0, path, seg, &as, &bs);
+	if(s == NULL) { return -1; }
+	sc[0] = s->score; sc[1] = s->mcnt; sc[2] = s->xcnt; sc[3] = s->agcnt; sc[4] = s->bgcnt; sc[5] = s->aicnt; sc[6] = s->bicnt;
+	sc[7] = s->afgcnt; sc[8] = s->bfgcnt; sc[9] = s->aficnt; sc[10] = s->bficnt; sc[11] = s->adj;
+	*identity = s->identity;
+	return 0;
 }

@@ -13,6 +13,11 @@ TAG_LINES = [
     ('p',     ['-xpacbio', '-P']),                                # QUIRK: also prints IH (flag and tag bits share a word)
     ('ih',    ['-xont.1dsq', '-TIH,AS', '-Q']),                   # QUIRK: also omits the secondary records
     ('rg',    ['-xpacbio', '-TSA', '-R' + RG]),                   # -R alone switches RG:Z on
+    ('paf',   ['-xpacbio', '-Opaf']),                             # the other output formats (-O): no header, nothing for unmapped reads
+    ('paftag', ['-xpacbio', '-O', 'paf', '-TAS,ID,NM,CG,SQ', '-P']),
+    ('blast6', ['-xpacbio', '-Oblast6']),
+    ('maf',   ['-xont.1dsq', '-Omaf']),
+    ('edge_maf', ['-xpacbio', '-Omaf']),
     ('edge_sa', ['-xpacbio', '-TSA,NM,MD,XS', '-Q']),             # on the edge-case reads of make_edge_golden.py (FASTQ): chimeras, N runs, both strands
 ]
 
@@ -64,7 +69,7 @@ def main():
             with gzip.GzipFile(os.path.join(HERE, 'tag_%s.sam.gz' % name), 'wb', mtime=0) as f: f.write(sam)
             flags = {}
             for l in sam.splitlines():
-                if not l.startswith(b'@'): flags[l.split(b'\t')[1]] = flags.get(l.split(b'\t')[1], 0) + 1
+                if '-O' not in ' '.join(opts) and not l.startswith(b'@'): flags[l.split(b'\t')[1]] = flags.get(l.split(b'\t')[1], 0) + 1
             print(name, sam.count(b'\n'), 'lines', flags, 'SA' if b'SA:Z' in sam else '')
 
 if __name__ == '__main__':
