@@ -31,10 +31,10 @@ typedef struct mm_idx_s mm_idx_t;
 typedef struct mm_align_s mm_align_t;
 
 /* options: defaults of minialign.c:6141-6162; mm_opt_parse applies "-x preset" strings and the single-letter options of
- * minialign.c:5990-6099 in argv order, `-k15` or `-k 15`: sketch and index (-k -w -B -f -L), scores (-a -b -e -p -q -r -Y), mapping
+ * minialign.c:5990-6099 in argv order, `-k15` or `-k 15`: sketch and index (-k -w -B -f -L, -c [names] for circular references), scores (-a -b -e -p -q -r -Y), mapping
  * (-s -m -W -G), output (-T tags, -R read group, -Q qualities, -P), -d (index file to write), -t -v -1 -2 (accepted; they size the
  * reference's host pipeline), with the reference's range checks and mm_opt_check_sanity (minialign.c:6097).  Returns 0 on success, nonzero
- * on anything the reference rejects or this build does not provide (-c -O -X -A -C: DESIGN.md 1). */
+ * on anything the reference rejects or this build does not provide (-X -A -C: DESIGN.md 1). */
 mm_opt_t *mm_opt_init(void);
 int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char const **files, int max_files, int *n_files);
 void mm_opt_destroy(mm_opt_t *o);

@@ -765,8 +765,9 @@ __device__ __forceinline__ uint32_t dp_fill(Ctx &x, uint32_t prev_tail, const Se
 }
 
 /* mm_extend_core (minialign.c:4075-4112): fill_root, then continue into the tail sections until X-drop or until a side that
- * was already updated asks again; returns the tail with the largest max */
-__device__ __forceinline__ uint32_t extend_core(Ctx &x, int bw_idx, Sec ca, uint32_t apos, Sec cb, uint32_t bpos, const Sec &tailsec, int64_t &mmax_out, uint32_t &n_fill)
+ * was already updated asks again; returns the tail with the largest max.  The a-side tail of a circular reference is the
+ * reference section itself (minialign.c:3753), else both are the run of N. */
+__device__ __forceinline__ uint32_t extend_core(Ctx &x, int bw_idx, Sec ca, uint32_t apos, Sec cb, uint32_t bpos, const Sec &atail, const Sec &btail, int64_t &mmax_out, uint32_t &n_fill)
 {
 	uint32_t f = NIL, m = NIL, flag = STATUS_TERM; int64_t mmax = 0;
 	while(true) {
@@ -776,8 +777,8 @@ __device__ __forceinline__ uint32_t extend_core(Ctx &x, int bw_idx, Sec ca, uint
 		int64_t fm = (int64_t)rdfirst64((uint64_t)t->f.max);
 		if(m == NIL || fm > mmax) { m = f; mmax = fm; }
 		if((flag & st) != 0 || x.err) { break; }
-		if(st & UPDATE_A) { ca = tailsec; }
-		if(st & UPDATE_B) { cb = tailsec; }
+		if(st & UPDATE_A) { ca = atail; }
+		if(st & UPDATE_B) { cb = btail; }
 		flag |= st & (UPDATE_A | UPDATE_B);
 	}
 	mmax_out = mmax;

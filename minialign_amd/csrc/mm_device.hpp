@@ -30,6 +30,7 @@ struct DevIndex {
 	const IdxSlot *slot; uint64_t mask;                /* table size - 1 */
 	const uint64_t *val;                               /* multi-hit lists: pos | rid << 32, in the reference's list order */
 	const uint32_t *seq_len;                           /* per reference sequence */
+	const uint8_t *seq_circ;                           /* per reference sequence: circular (-c); NULL when none is */
 	const uint64_t *seq_off;                           /* first base of each reference sequence in the a-side arena */
 	uint32_t n_seq, k, w, n_occ;
 	uint32_t occ[8];
@@ -267,6 +268,41 @@ __global__ void __launch_bounds__(256) mm_sketch_seed_kernel(K1Args a)
 /* =====================================================================================================
  * K2: seed sort + chaining, one lane per read (serial by nature; 64 reads per wavefront)
  * ===================================================================================================== */
+/* mm_circularize (minialign.c:3632-3696), after the chains of a read are known and before they are sorted: a chain whose root seed lies within the
+ * window of the end of a circular reference is linked to a leaf seed just behind the origin -- the far chain is switched off (top bit of plen), its
+ * length and root seed pass to the near one.  Serial, one lane; only reads that hit a circular reference get here.  Leaf view of a Seed:
+ * upos = rsid, rid, vpos = lsid, lid = cid. */
+__device__ inline void circularize(Seed *s, Root *c, uint32_t n_seed, uint32_t tlid, uint32_t n_root, const uint32_t *seq_len, const uint8_t *seq_circ, uint32_t twlen)
+{
+	uint32_t blid = n_seed + 1;
+	for(uint32_t rcid = 0; rcid < n_root; rcid++) {
+		const uint32_t rlid = c[rcid].lid, rsid = s[rlid].upos, rid = s[rlid].rid;
+		if(seq_circ[rid] == 0 || (uint32_t)(seq_len[rid] - (uint32_t)AS(s[rsid])) > twlen) { continue; }
+		const uint32_t rlen = seq_len[rid];
+		const int32_t uofs = (int32_t)(rlen << 1), vofs = -(int32_t)rlen;              /* _ud(rlen, 0), _vd(rlen, 0) */
+		while(blid < tlid && s[s[blid].vpos].rid < rid) { blid++; }
+		const uint32_t vub = s[rsid].vpos - (uint32_t)vofs + twlen;
+		while(blid < tlid && s[s[blid].vpos].vpos > vub) { blid++; }
+		/* window of the root seed moved by one turn: (u <= uub, rid <= rid, v <= vub, v > vlb), signed */
+		const int32_t w_u = (int32_t)(s[rsid].upos + twlen - (uint32_t)uofs), w_r = (int32_t)s[rsid].rid;
+		const int32_t w_vub = (int32_t)(s[rsid].vpos + twlen - (uint32_t)vofs), w_vlb = (int32_t)(s[rsid].vpos - (uint32_t)vofs);
+		uint64_t best = ~0ull;
+		for(uint32_t lid = blid; lid < tlid; lid++) {
+			const Seed &f = s[s[lid].vpos];
+			if(!((int32_t)f.upos <= w_u && (int32_t)f.rid <= w_r && (int32_t)f.vpos <= w_vub && (int32_t)f.vpos > w_vlb)) { continue; }
+			const uint32_t cid = s[lid].lid;
+			if(cid == 0xffffffffu || (c[cid].plen & 0x80000000u)) { continue; }
+			const uint64_t cand = ((uint64_t)c[cid].plen << 32) | lid;
+			best = cand < best ? cand : best;
+		}
+		if(best == ~0ull) { continue; }
+		const uint32_t pd = (uint32_t)(best >> 32), llid = (uint32_t)best, lcid = s[llid].lid;
+		c[lcid].lid = rlid; c[lcid].plen |= 0x80000000u;
+		s[s[llid].vpos].lid = ~s[rlid].upos;
+		c[rcid].plen -= (uint32_t)OFS((int32_t)pd);
+		s[rlid].upos = s[llid].upos;
+	}
+}
 struct K2Args {
 	DevIndex idx;
 	ReadState *st; const uint32_t *work; uint32_t n_work;     /* indices of the reads taking part in this round */
@@ -472,6 +508,7 @@ __global__ void __launch_bounds__(64) mm_sort_chain_kernel(K2Args a)
 	}
 	st->seed_n = nlid; st->n_root = ncid;
 	if(ncid == 0) { return; }
+	if(a.idx.seq_circ) { circularize(s, c, seed_n, nlid, ncid, a.idx.seq_len, a.idx.seq_circ, a.twlen); }
 	if(!radix_sort_64((U64R *)c, ncid, scratch, a.rs_stride)) { st->err |= ERR_STACK; }      /* longest first (minialign.c:3719) */
 	/* prediction for the carried reference-length state: the last chain that passes the length test of
 	 * mm_search_load_root (minialign.c:3849) is the last one mm_init_ref sees, unless the extension loop stops early */
@@ -501,6 +538,7 @@ struct K2aArgs {
 	uint32_t retry;                   /* 1: take the reads whose leaf area overflowed in their class (flagged n_root = ~0), with room for 2 (n + 1) */
 	uint32_t *counter;                /* work-list cursor of this launch */
 	uint32_t twlen; double mcoef; uint32_t min_score;
+	const uint32_t *seq_len; const uint8_t *seq_circ;   /* reference lengths and circular flags (NULL: no circular reference) for mm_circularize */
 	unsigned long long *prof;         /* [0] sort [1] chain [2] whole wave (s_memtime ticks) [3] reads that did not fit the LDS */
 };
 /* elements a read is given in its first attempt: the seeds, the sentinel and a leaf area of a quarter of that (the worst case of
@@ -789,6 +827,7 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 		if(lane == 0) {
 			st->seed_n = nlid; st->n_root = ncid;
 			if(ncid) {
+				if(a.seq_circ) { circularize(gs, c, seed_n, nlid, ncid, a.seq_len, a.seq_circ, a.twlen); }
 				if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)cnt, 1536)) { st->err |= ERR_STACK; }              /* longest first (minialign.c:3719); LDS tables reused as scratch */
 				uint32_t pred = gaba::NIL;
 				for(uint32_t kq = 0; kq < ncid; kq++) {
@@ -913,13 +952,14 @@ __device__ __forceinline__ gaba::Sec sec_uniform(const gaba::Sec &s)
 	r.arena = (uint32_t)rdfirst((int)s.arena); r.rev = (uint32_t)rdfirst((int)s.rev); return r;
 }
 struct ExtOut { DpOut d; uint32_t m; int64_t mmax; uint32_t n_fill; };
-__device__ __attribute__((noinline)) ExtOut k3_extend_core(DpIn in, int bw, gaba::Sec ca, uint32_t apos, gaba::Sec cb, uint32_t bpos, int no_trace)
+__device__ __attribute__((noinline)) ExtOut k3_extend_core(DpIn in, int bw, gaba::Sec ca, uint32_t apos, gaba::Sec cb, uint32_t bpos, int no_trace, int circ)
 {
 	gaba::Ctx x; gaba::SeqArena ar[2]; dp_ctx_open(x, ar, in);
 	x.no_trace = rdfirst(no_trace) != 0;
 	const gaba::Sec tailsec = { 0xfffffffeu, 96, 0, 2, 0 };
 	ExtOut o; o.n_fill = 0;
-	o.m = gaba::extend_core(x, rdfirst(bw), sec_uniform(ca), (uint32_t)rdfirst((int)apos), sec_uniform(cb), (uint32_t)rdfirst((int)bpos), tailsec, o.mmax, o.n_fill);
+	const gaba::Sec cau = sec_uniform(ca);
+	o.m = gaba::extend_core(x, rdfirst(bw), cau, (uint32_t)rdfirst((int)apos), sec_uniform(cb), (uint32_t)rdfirst((int)bpos), rdfirst(circ) ? cau : tailsec, tailsec, o.mmax, o.n_fill);
 	o.d = DpOut{ x.top, x.err, x.n_vec, x.n_blk, x.n_tr };
 	return o;
 }
@@ -1012,7 +1052,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 		sr.crem = MM_CREM; sr.min_score = a.min_score; sr.narrow = 0; sr.srem = 0; sr.prem = 0; sr.pacc = 0;
 		sr.cp_a = sr.cp_b = sr.tp_a = sr.tp_b = 0; sr.aid = sr.bid = sr.iid = sr.eid = sr.sid = sr.rev = 0;
 		uint32_t next_n = 0;
-		gaba::Sec rsec_f, rsec_r, qsec_f, qsec_r;
+		gaba::Sec rsec_f, rsec_r, qsec_f, qsec_r; int rcirc = 0;
 		qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }; qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
 
 		#define LOAD_POS(_p, _cpa, _cpb, _rev) { \
@@ -1047,6 +1087,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 			rlen = (uint32_t)rdfirst((int)ix.seq_len[sr.aid]); rid_last = sr.aid;
 			uint64_t roff = rdfirst64(ix.seq_off[sr.aid]);
 			rsec_f = gaba::Sec{ sr.aid << 1, rlen, roff, 0, 0 }; rsec_r = gaba::Sec{ (sr.aid << 1) + 1, rlen, roff, 0, 1 };
+			rcirc = ix.seq_circ ? rdfirst((int)ix.seq_circ[sr.aid]) : 0;          /* rtp = circular ? r : t (minialign.c:3753) */
 
 			bool first_iter = true;
 			while(true) {
@@ -1116,7 +1157,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 					DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
 					const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
 					/* the downward pass is only searched for its maximum (the walk-back runs on the upward pass): no traceback masks */
-					ExtOut eo = k3_extend_core(din, bw, ca, sa, cb, sb, pass == 0);
+					ExtOut eo = k3_extend_core(din, bw, ca, sa, cb, sb, pass == 0, rcirc);
 					const unsigned long long cy1 = __builtin_amdgcn_s_memtime(); cy_fill += cy1 - cy0;
 					x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk);
 					m = (uint32_t)rdfirst((int)eo.m); mmax = (int64_t)rdfirst64((uint64_t)eo.mmax); n_fill += (uint32_t)rdfirst((int)eo.n_fill);

@@ -89,7 +89,7 @@ inline void sort_res(ResEnt *p, size_t n) { auto key = [](const ResEnt &m) { ret
 /* ---------------------------------------------------------------------------------------------
  * sequences
  * --------------------------------------------------------------------------------------------- */
-struct HSeq { std::string name; std::vector<uint8_t> seq; std::string qual, comment; bool has_comment = false; };     /* qual / comment: kept on request only (-Q, -T CO) */
+struct HSeq { std::string name; std::vector<uint8_t> seq; std::string qual, comment; bool has_comment = false; bool circular = false; };     /* qual / comment: kept on request only (-Q, -T CO) */
 
 /* run fn(t, nth) on up to 16 host threads (reads / records are independent in every host stage that uses this) */
 template<typename F> static void host_parallel(uint32_t want, F fn)
@@ -273,6 +273,43 @@ void sketch_host(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t w, std::
 	}
 }
 
+/* a circular reference sequence (-c): the reference runs its window on over the first min(len, w) bases (mm_sketch_cap, minialign.c:2438-2444) from the
+ * state its block-wise loop was left in, and decodes positions from the local indices of the stream (minialign.c:2831-2835) -- so the wrap-around
+ * minimizers carry the positions that decoder gives them.  Reproduced by walking the sequence the way mm_sketch does (blocks of w with a backward-min
+ * array, minialign.c:2410-2435); circular sequences are chromosomes / plasmids, one host thread each. */
+void sketch_host_circular(const uint8_t *seq, uint32_t len, uint32_t k_, uint32_t w_, std::vector<HMin> &out)
+{
+	const uint64_t kk = k_ - 1, shift1 = 2 * kk, mask = (1ull << 2 * k_) - 1, w = w_;
+	uint64_t r[64]; for(int i = 0; i < 64; i++) r[i] = ~0ull;
+	const uint8_t *p = seq, *t = seq + len;
+	uint64_t u = 0, k0 = 0, k1 = 0;
+	uint64_t base = (uint64_t)-(int64_t)w, dv = w;                  /* position decoder state */
+	auto push = [&](uint64_t v) { uint64_t lu = v & 0x7f; base += lu <= dv ? w : 0; dv = lu; out.push_back(HMin{ v >> 8, (uint32_t)(base + lu), (uint32_t)((v >> 7) & 1) }); };
+	auto kmer = [&]() { uint64_t c = *p++; k0 = (k0 << 2 | c) & mask; k1 = (k1 >> 2) | ((3ull ^ c) << shift1); };
+	auto core = [&](uint64_t i, uint64_t &f) -> uint64_t {
+		kmer();
+		uint64_t km = k0 < k1 ? k0 : k1, kx = k0 < k1 ? k1 : k0, m = k0 < k1 ? 0 : 0x80;
+		uint64_t crc = (kx >> 32) ? (uint64_t)h_crc32c((uint32_t)kx, kx) : 0ull;
+		uint64_t hh = ((crc ^ km) & mask) << 8 | i | m; f = std::min(f, hh); uint64_t v = std::min(f, r[i + 1]);
+		if((v == hh) | (v - u)) push(v);
+		u = v; return hh;
+	};
+	for(uint64_t i = 0; i < kk && p < t; i++) kmer();
+	while((int64_t)(t - p) >= (int64_t)w) {
+		uint64_t f = ~0ull; for(uint64_t i = 0; i < w; i++) r[i] = core(i, f);
+		uint64_t rr = ~0ull; for(uint64_t i = 0; i < w; i++) { rr = std::min(rr, r[w - i - 1]); r[w - i - 1] = rr; }
+	}
+	const uint64_t l = (uint64_t)(t - p);
+	if(l > 0) {
+		uint64_t f = ~0ull; for(uint64_t i = 0; i < l; i++) r[w + i] = core(i, f) + w;
+		uint64_t rr = ~0ull; for(uint64_t i = 0; i < w; i++) { rr = std::min(rr, r[w + l - i - 1]); r[w + l - i - 1] = rr; }
+		for(uint64_t i = 0; i < w; i++) r[i] = r[l + i] - l;
+		u += w - l;
+	}
+	p = seq; t = seq + std::min<uint64_t>(len, w);
+	{ uint64_t f = ~0ull; for(uint64_t i = 0; i < w && p < t; i++) core(i, f); }
+}
+
 } /* anonymous */
 
 /* =============================================================================================
@@ -285,6 +322,7 @@ struct mm_opt_s {
 	 * into one word (minialign.c:5677), so -P also switches IH on and -T IH also omits the secondary records: kept */
 	uint64_t flag = 0, tags = 0; std::string rg_line, rg_id; bool keep_qual = false;
 	uint32_t format = 0;             /* -O: 0 sam, 1 maf, 2 blast6, 5 paf (minialign.c:2543-2549, 5940) */
+	bool circ_set = false; std::vector<std::string> circ_names;     /* -c: given at all / names of the circular reference sequences (none: all), minialign.c:2457, 5986 */
 	uint64_t ptags() const { return flag | tags; }
 	uint32_t wlen = 7000, glen = 7000, min_score = 50; float min_ratio = 0.3f;
 	gaba_params_t p;
@@ -390,6 +428,11 @@ int opt_one(mm_opt_t *o, char c, const char *arg)
 			for(auto &e : t) if(strcmp(arg, e.k) == 0) { o->format = e.v; return 0; }
 			return opt_fail("unknown output format (-O).");
 		}
+		case 'c': {                      /* mm_opt_circular, minialign.c:5986-5997: no name, `*' or `-' marks every sequence */
+			o->circ_set = true;
+			split_each(arg, ",;:/", [&](int, const std::string &t) { if(t == "*" || t == "-") o->circ_names.clear(); else o->circ_names.push_back(t); });
+			return 0;
+		}
 		case 'P': o->flag |= 0x08; return 0;
 		case 'Q': o->keep_qual = true; return 0;
 		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
@@ -433,6 +476,8 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
 		if(a[0] == '-' && a[1]) {
 			const char *arg = a + 2;
 			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGdfBLe12TRO", a[1])) arg = argv[++i];
+			/* options with an optional argument take the next word unless it looks like an option (mm_opt_parse_argv, minialign.c:5786) */
+			else if(*arg == 0 && i + 1 < argc && strchr("cv", a[1]) && (argv[i + 1][0] != '-' || argv[i + 1][1] == 0)) arg = argv[++i];
 			if(opt_one(o, a[1], arg)) return 1;
 		} else if(nf < max_files) files[nf++] = a;
 	}
@@ -460,15 +505,20 @@ extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 	if(!read_seq_file(ref_fasta, mi->seq, o->min_len) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); delete mi; return NULL; }
 	uint32_t b = std::min(o->k * 2, o->b);
 	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq;
+	if(o->circ_set) for(HSeq &q : mi->seq) q.circular = o->circ_names.empty() || std::find(o->circ_names.begin(), o->circ_names.end(), q.name) != o->circ_names.end();
 	const uint64_t nb = 1ull << b, bmask = nb - 1;
 	/* sketch every sequence and push (hrem, pos, rid) to its bucket in reference order (minialign.c:2790-2860) */
 	std::vector<std::vector<Mini>> bkt(nb);
 	{
 		struct Task { uint32_t seq, begin, end; std::vector<HMin> mins; };
 		std::vector<Task> task; const uint32_t chunk = 1u << 18;
-		for(uint32_t i = 0; i < mi->seq.size(); i++) { const uint32_t L = (uint32_t)mi->seq[i].seq.size(); for(uint32_t bgn = 0; bgn < L || bgn == 0; bgn += chunk) { task.push_back(Task{ i, bgn, std::min(L, bgn + chunk), {} }); if(L == 0) break; } }
+		for(uint32_t i = 0; i < mi->seq.size(); i++) { const uint32_t L = (uint32_t)mi->seq[i].seq.size(); if(mi->seq[i].circular) { task.push_back(Task{ i, 0, L, {} }); continue; } for(uint32_t bgn = 0; bgn < L || bgn == 0; bgn += chunk) { task.push_back(Task{ i, bgn, std::min(L, bgn + chunk), {} }); if(L == 0) break; } }
 		host_parallel((uint32_t)task.size(), [&](uint32_t t, uint32_t nth) {
-			for(size_t j = t; j < task.size(); j += nth) { Task &q = task[j]; sketch_host(mi->seq[q.seq].seq.data(), (uint32_t)mi->seq[q.seq].seq.size(), o->k, o->w, q.mins, q.begin, q.end); }
+			for(size_t j = t; j < task.size(); j += nth) {
+				Task &q = task[j]; const HSeq &sq = mi->seq[q.seq];
+				if(sq.circular) sketch_host_circular(sq.seq.data(), (uint32_t)sq.seq.size(), o->k, o->w, q.mins);
+				else sketch_host(sq.seq.data(), (uint32_t)sq.seq.size(), o->k, o->w, q.mins, q.begin, q.end);
+			}
 		});
 		for(Task &q : task) { for(const HMin &m : q.mins) bkt[m.hash & bmask].push_back(Mini{ m.hash >> b, m.pos, (q.seq << 1) + m.strand }); std::vector<HMin>().swap(q.mins); }
 	}
@@ -531,7 +581,7 @@ extern "C" void mm_idx_destroy(mm_idx_t *mi) { delete mi; }
  * flattened table the device uses: magic, the parameters, the sequences (name + one byte per base), the slots and the value array.  A file
  * may hold several such blocks back to back (one per reference file given to -d), as the reference's does. */
 namespace {
-const uint32_t MAI_MAGIC = 0x0241414du;        /* "MAA\x02" */
+const uint32_t MAI_MAGIC = 0x0341414du;        /* "MAA\x03" */
 struct MaiHead { uint32_t b, w, k, n_occ, occ[8]; uint64_t n_seq, n_slot, n_val, n_keys; };
 }
 extern "C" int mm_idx_dump(mm_idx_t const *mi, FILE *fp)
@@ -542,7 +592,7 @@ extern "C" int mm_idx_dump(mm_idx_t const *mi, FILE *fp)
 	h.b = mi->b; h.w = mi->w; h.k = mi->k; h.n_occ = mi->n_occ; memcpy(h.occ, mi->occ, sizeof(h.occ)); h.n_seq = mi->seq.size(); h.n_slot = mi->slot.size(); h.n_val = mi->val.size(); h.n_keys = mi->n_keys;
 	put(&MAI_MAGIC, 4); put(&h, sizeof(h));
 	for(const HSeq &q : mi->seq) {
-		uint64_t l[2] = { q.name.size(), q.seq.size() };
+		uint64_t l[3] = { q.name.size(), q.seq.size(), q.circular ? 1u : 0u };
 		put(l, sizeof(l)); put(q.name.data(), l[0]); put(q.seq.data(), l[1]);
 	}
 	put(mi->slot.data(), mi->slot.size() * sizeof(IdxSlot)); put(mi->val.data(), mi->val.size() * sizeof(uint64_t));
@@ -563,10 +613,10 @@ extern "C" mm_idx_t *mm_idx_load(FILE *fp, int *at_eof)
 	auto get = [&](void *p, size_t n) { ok = ok && (n == 0 || fread(p, 1, n, fp) == n); };
 	try {
 		for(uint64_t i = 0; ok && i < h.n_seq; i++) {
-			uint64_t l[2] = { 0, 0 }; get(l, sizeof(l));
+			uint64_t l[3] = { 0, 0, 0 }; get(l, sizeof(l));
 			if(!ok || l[0] > (1u << 20) || l[1] > 0xffffffffull) { ok = false; break; }
 			mi->seq.emplace_back(); HSeq &q = mi->seq.back();
-			q.name.resize(l[0]); q.seq.resize(l[1]); get(&q.name[0], l[0]); get(q.seq.data(), l[1]);
+			q.name.resize(l[0]); q.seq.resize(l[1]); q.circular = l[2] != 0; get(&q.name[0], l[0]); get(q.seq.data(), l[1]);
 		}
 		if(ok) { mi->slot.resize(h.n_slot); get(mi->slot.data(), h.n_slot * sizeof(IdxSlot)); }
 		if(ok) { mi->val.resize(h.n_val); get(mi->val.data(), h.n_val * sizeof(uint64_t)); }
@@ -605,7 +655,7 @@ template<typename T> struct DBuf {
 struct mm_align_s {
 	mm_opt_s o; const mm_idx_s *mi;
 	gaba_t *gctx;
-	DevIndex dix; IdxSlot *d_slot = nullptr; uint64_t *d_val = nullptr; uint32_t *d_seq_len = nullptr; uint64_t *d_seq_off = nullptr;
+	DevIndex dix; IdxSlot *d_slot = nullptr; uint64_t *d_val = nullptr; uint32_t *d_seq_len = nullptr; uint64_t *d_seq_off = nullptr; uint8_t *d_seq_circ = nullptr;
 	gaba_arena_t *ref_ar = nullptr;
 	uint32_t twlen, tglen; double mcoef, xcoef;
 	hipStream_t stream; hipEvent_t ev0, ev1;
@@ -683,7 +733,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			static bool attr_set = false;
 			if(!attr_set) { CK(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
 			K2aArgs ka; ka.st = a->d_st.p; ka.work = a->d_work.p; ka.n_work = (uint32_t)work.size(); ka.seed_pool = a->seed_pool.p; ka.root_pool = a->root_pool.p;
-			ka.prof = tops + 24; ka.twlen = a->twlen; ka.mcoef = a->mcoef; ka.min_score = a->o.min_score;
+			ka.prof = tops + 24; ka.twlen = a->twlen; ka.mcoef = a->mcoef; ka.min_score = a->o.min_score; ka.seq_len = a->dix.seq_len; ka.seq_circ = a->dix.seq_circ;
 			CK(hipMemsetAsync(a->d_k2cnt.p, 0, 16 * 4, a->stream));
 			CK(hipEventRecord(a->ev0, a->stream));          /* re-recorded behind the memset: the side streams start from here */
 			auto bytes_of = [](uint32_t div) -> uint32_t { return div ? ((160u * 1024u / div) & ~255u) : 0u; };
@@ -1133,6 +1183,16 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	(void)hipMemcpy(a->d_seq_len, len.data(), len.size() * 4, hipMemcpyHostToDevice);
 	(void)hipMemcpy(a->d_seq_off, off.data(), off.size() * 8, hipMemcpyHostToDevice);
 	a->dix.slot = a->d_slot; a->dix.mask = mi->mask; a->dix.val = a->d_val; a->dix.seq_len = a->d_seq_len; a->dix.seq_off = a->d_seq_off;
+	a->dix.seq_circ = nullptr;
+	{
+		std::vector<uint8_t> circ; bool any = false;
+		for(const HSeq &s : mi->seq) { circ.push_back(s.circular ? 1 : 0); any |= s.circular; }
+		if(any) {          /* circular references (-c): the chain stage links across the origin, the extension continues into the reference itself */
+			if(hipMalloc(&a->d_seq_circ, circ.size()) != hipSuccess) { fprintf(stderr, "[minialign_amd] mm_align_init: index upload failed\n"); delete a; return NULL; }
+			(void)hipMemcpy(a->d_seq_circ, circ.data(), circ.size(), hipMemcpyHostToDevice);
+			a->dix.seq_circ = a->d_seq_circ;
+		}
+	}
 	a->dix.n_seq = (uint32_t)mi->seq.size(); a->dix.k = mi->k; a->dix.w = mi->w; a->dix.n_occ = mi->n_occ;
 	for(int i = 0; i < 8; i++) a->dix.occ[i] = i < (int)mi->n_occ ? mi->occ[i] : 0;
 	hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev); a->dev = dev;
@@ -1145,7 +1205,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	if(!a) return;
 	if(a->sib) { mm_align_destroy(a->sib); a->sib = nullptr; }
 	if(!a->is_sib) {
-		(void)hipFree(a->d_slot); (void)hipFree(a->d_val); (void)hipFree(a->d_seq_len); (void)hipFree(a->d_seq_off);
+		(void)hipFree(a->d_slot); (void)hipFree(a->d_val); (void)hipFree(a->d_seq_len); (void)hipFree(a->d_seq_off); if(a->d_seq_circ) (void)hipFree(a->d_seq_circ);
 		gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
@@ -1386,7 +1446,7 @@ static mm_align_t *align_lane(mm_align_t *a)
 	if(a->sib) return a->sib;
 	while(a->is_sib && false) {}
 	mm_align_t *q = new mm_align_s();
-	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off;
+	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off; q->d_seq_circ = a->d_seq_circ;
 	q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
 	q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
 	if(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess) { delete q; return NULL; }

@@ -5,7 +5,8 @@
  *   chain (:3547-3725)                   extension driver (:3785-4173)      post-map (:4185-4398)
  *   SAM (:5096-5426)                     ksort radix sorts (ksort.h:84-131) kh_t (:341-683)
  * Quirks of the reference that are part of its observable output are reproduced and marked "QUIRK".
- * Not restated: circular references (-c), all-versus-all, BAM / gz input, non-SAM printers, optional tags.
+ *   circular references (:2438-2444, 3632-3696, 3753)   optional SAM fields and the MAF / BLAST6 / PAF printers (:5204-5625)
+ * Not restated: all-versus-all, BAM / gz input, the pthread pipeline.
  */
 #define _GNU_SOURCE
 #include <stdlib.h>
@@ -135,6 +136,16 @@ static int opt_one(om_opt_t *o, char c, char const *arg, size_t l)
 			for(int i = 0; i < 4; i++) { if(strcmp(arg, t[i].k) == 0) { o->format = t[i].v; return 0; } }
 			return 1;
 		}
+		case 'c': {                      /* mm_opt_circular, minialign.c:5986-5997: no name, `*' or `-' marks every sequence */
+			o->circ_set = 1;
+			if(l == 0) { return 0; }
+			if(l == 1 && (arg[0] == '*' || arg[0] == '-')) { free(o->circ_names); o->circ_names = NULL; return 0; }
+			size_t have = o->circ_names ? strlen(o->circ_names) : 0;
+			o->circ_names = (char *)realloc(o->circ_names, have + l + 2);
+			if(have) { o->circ_names[have++] = ','; }
+			memcpy(o->circ_names + have, arg, l); o->circ_names[have + l] = 0;
+			return 0;
+		}
 		case 'P': o->flag |= 0x08; return 0;
 		case 'Q': o->keep_qual = 1; return 0;
 		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
@@ -224,6 +235,8 @@ int om_opt_parse(om_opt_t *o, int argc, char const *const *argv, char const **fi
 		if(a[0] == '-' && a[1]) {
 			char const *arg = a + 2;
 			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGfBLe12TRO", a[1])) { arg = argv[++i]; }
+			/* options with an optional argument take the next word unless it looks like an option (mm_opt_parse_argv, minialign.c:5786) */
+			else if(*arg == 0 && i + 1 < argc && strchr("cv", a[1]) && (argv[i + 1][0] != '-' || argv[i + 1][1] == 0)) { arg = argv[++i]; }
 			rc |= opt_one(o, a[1], arg, strlen(arg));
 		} else if(nf < max_files) { files[nf++] = a; }
 	}
@@ -307,7 +320,10 @@ static inline uint64_t crc32c_u64(uint64_t crc, uint64_t v)     /* _mm_crc32_u64
 }
 #define HASH64(k0, k1, mask)    ( (crc32c_u64((k1), (k1)) ^ (k0)) & (mask) )       /* minialign.c:2353 */
 
-uint64_t om_sketch(uint32_t w_, uint32_t k_, uint8_t const *seq, uint32_t len, uint64_t *out)
+static uint64_t sketch_intl(uint32_t w_, uint32_t k_, uint8_t const *seq, uint32_t len, uint64_t *out, int circular);
+uint64_t om_sketch(uint32_t w_, uint32_t k_, uint8_t const *seq, uint32_t len, uint64_t *out) { return sketch_intl(w_, k_, seq, len, out, 0); }
+/* with circular != 0 the window runs on over the first min(len, w) bases (mm_sketch_cap, minialign.c:2438-2444, "tail margin for circular sequences") */
+static uint64_t sketch_intl(uint32_t w_, uint32_t k_, uint8_t const *seq, uint32_t len, uint64_t *out, int circular)
 {
 	if(!crc_init_done) { crc_init(); }
 	uint64_t r[64]; for(int i = 0; i < 64; i++) { r[i] = UINT64_MAX; }     /* QUIRK: the reference initialises r[0..32) only (minialign.c:2373); w < 16 keeps all reads inside */
@@ -331,7 +347,16 @@ uint64_t om_sketch(uint32_t w_, uint32_t k_, uint8_t const *seq, uint32_t len, u
 	uint64_t l = (uint64_t)(t - p);
 	if(l > 0) {
 		for(uint64_t i = 0, f = UINT64_MAX; i < l; i++) { uint64_t h; LOOP_CORE(h); r[w + i] = h + w; }
-		/* (the folded r[] is only needed by a following circular cap, minialign.c:2424-2433) */
+		/* fold the backward-min array, move it to the head, adjust u (minialign.c:2427-2432); read only by the cap that may follow */
+		for(uint64_t i = 0, rr = UINT64_MAX; i < w; i++) { rr = MIN2(rr, r[w + l - i - 1]); r[w + l - i - 1] = rr; }
+		for(uint64_t i = 0; i < w; i++) { r[i] = r[l + i] - l; }
+		u += w - l;
+	}
+	if(circular) {
+		/* mm_sketch_cap: the cap holds i = 0, so up to w more positions, bases taken from the head of the sequence */
+		uint64_t lc = MIN2((uint64_t)len, w);
+		p = seq; t = seq + lc;
+		for(uint64_t i = 0, f = UINT64_MAX; i < w && p < t; i++) { uint64_t h; LOOP_CORE(h); (void)h; }
 	}
 	#undef PUSH_KMER
 	#undef LOOP_CORE
@@ -421,24 +446,37 @@ struct om_idx_s {
 	uint32_t occ[16];
 	bkt_t *bkt;
 	om_seq_t const *s; uint32_t n_seq;
+	uint8_t *circular;          /* per sequence, minialign.c:2468 */
 };
 uint32_t om_idx_occ(om_idx_t const *mi, uint32_t i) { return mi->occ[i]; }
 
 static int cmp_u32(void const *a, void const *b) { uint32_t x = *(uint32_t const *)a, y = *(uint32_t const *)b; return x < y ? -1 : x > y; }
 
+static int name_listed(char const *list, char const *name, uint32_t l_name)
+{
+	for(char const *p = list; *p; ) {
+		char const *e = p; while(*e && !strchr(",;:/", *e)) { e++; }
+		if((uint32_t)(e - p) == l_name && memcmp(p, name, l_name) == 0) { return 1; }
+		if(!*e) { break; } p = e + 1;
+	}
+	return 0;
+}
 om_idx_t *om_idx_build(om_opt_t const *o, om_seq_t const *ref, uint32_t n_ref)
 {
 	om_idx_t *mi = (om_idx_t *)calloc(1, sizeof(om_idx_t));
 	uint32_t b = MIN2(o->k * 2, o->b);
 	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq; mi->mask = (1ULL << b) - 1;
-	mi->s = ref; mi->n_seq = n_ref;
+	mi->s = ref; mi->n_seq = n_ref; mi->circular = (uint8_t *)calloc(n_ref + 1, 1);
 	uint64_t nb = 1ULL << b;
 	typedef vec_t(mini_t) mini_v;
 	mini_v *arr = (mini_v *)calloc(nb, sizeof(mini_v));
 	/* mm_idx_worker + mm_idx_drain_intl (minialign.c:2790-2860): sketch every sequence, push in reference order */
 	for(uint32_t i = 0; i < n_ref; i++) {
 		uint64_t *m = (uint64_t *)malloc(sizeof(uint64_t) * (4 * (uint64_t)ref[i].l_seq / o->w + 512));
-		uint64_t n = om_sketch(o->w, o->k, ref[i].seq, ref[i].l_seq, m);
+		/* circular: every sequence when -c came without names, else the named ones (minialign.c:2796, 2963-2964) */
+		int circ = o->circ_set && (o->circ_names == NULL || o->circ_names[0] == 0 ? 1 : name_listed(o->circ_names, ref[i].name, ref[i].l_name));
+		mi->circular[i] = (uint8_t)circ;
+		uint64_t n = sketch_intl(o->w, o->k, ref[i].seq, ref[i].l_seq, m, circ);
 		uint64_t w = o->w, base = (uint64_t)-(int64_t)w, v = w;
 		for(uint64_t j = 0; j < n; j++) {
 			uint64_t u = m[j] & 0x7f, fr = (m[j] >> 7) & 0x01, h = m[j] >> 8;
@@ -498,7 +536,7 @@ void om_idx_free(om_idx_t *mi)
 {
 	if(!mi) { return; }
 	for(uint64_t i = 0; i < (1ULL << mi->b); i++) { free(mi->bkt[i].key); free(mi->bkt[i].start); free(mi->bkt[i].val); }
-	free(mi->bkt); free(mi);
+	free(mi->bkt); free(mi->circular); free(mi);
 }
 uint64_t const *om_idx_get(om_idx_t const *mi, uint64_t minier, uint32_t *n)
 {
@@ -536,6 +574,7 @@ struct om_align_s {
 	uint32_t rid, qid, rlen, qlen;
 	uint8_t const *rseq, *qseq;
 	og_section_t r[2], q[3], t[2];
+	og_section_t *rtp;          /* reference-side tail sections: r for a circular reference, else t (minialign.c:3319, 3753) */
 	uint8_t tail[128];
 	vec_t(resc_t) resc; uint64_t presc;
 	vec_t(om_seed_t) seed; uint64_t n_seed;
@@ -713,7 +752,46 @@ static uint64_t mm_chain_seeds(om_align_t *self)
 	self->root.n = ncid; self->seed.n = nlid;
 	return ncid;
 }
-/* mm_chain, minialign.c:3702-3721 (mm_circularize is a no-op without circular references) */
+/* mm_circularize, minialign.c:3632-3696: a chain whose root seed lies within the window of the end of a circular reference is linked to a leaf
+ * seed just behind the origin: the far chain is switched off (top bit of plen), its length and root seed pass to the near one */
+static void mm_circularize(om_align_t *self)
+{
+	root_t *c = self->root.a;
+	om_seed_t *s = self->seed.a;
+	leaf_t *ls = (leaf_t *)self->seed.a;
+	uint32_t blid = (uint32_t)self->n_seed + 1, tlid = (uint32_t)self->seed.n;
+	v4 tv = window((int32_t)self->twlen);
+	for(uint32_t rcid = 0; rcid < self->root.n; rcid++) {
+		uint32_t rlid = c[rcid].lid;
+		uint32_t rsid = ls[rlid].rsid, rid = ls[rlid].rid;
+		int32_t as = AS(&s[rsid]);
+		if(self->mi->circular[rid] == 0 || (uint32_t)(self->mi->s[rid].l_seq - (uint32_t)as) > self->twlen) { continue; }
+		uint32_t rlen = self->mi->s[rid].l_seq;
+		int32_t uofs = (int32_t)((rlen << 1) - 0), vofs = (int32_t)((0 << 1) - rlen);             /* _ud(rlen, 0), _vd(rlen, 0) */
+		v4 ov = { { uofs, 0, vofs, vofs } };
+		while(blid < tlid && s[ls[blid].lsid].rid < rid) { blid++; }
+		uint32_t vub = s[rsid].vpos - (uint32_t)vofs + self->twlen;
+		while(blid < tlid && s[ls[blid].lsid].vpos > vub) { blid++; }
+		uint64_t llid = UINT64_MAX;
+		v4 rv = sub4(add4(load_pv(&s[rsid]), tv), ov);
+		for(uint32_t lid = blid; lid < tlid; lid++) {
+			v4 lv = load_pv(&s[ls[lid].lsid]);
+			if(!INSIDE_WV(rv, lv)) { continue; }
+			uint32_t cid = ls[lid].cid;
+			if(cid == UINT32_MAX || (c[cid].plen & 0x80000000u)) { continue; }
+			llid = MIN2(llid, ((uint64_t)c[cid].plen << 32) | lid);
+		}
+		if(llid == UINT64_MAX) { continue; }
+		uint32_t pd = (uint32_t)(llid >> 32); llid = (uint32_t)llid;
+		uint32_t lcid = ls[llid].cid;
+		c[lcid].lid = rlid;
+		c[lcid].plen |= 0x80000000u;
+		s[ls[llid].lsid].lid = ~ls[rlid].rsid;
+		c[rcid].plen -= (uint32_t)OFS(pd);
+		ls[rlid].rsid = ls[llid].rsid;
+	}
+}
+/* mm_chain, minialign.c:3702-3721 */
 static uint64_t mm_chain(om_align_t *self)
 {
 	vec_reserve(om_seed_t, self->seed, self->seed.n + self->seed.n);
@@ -721,6 +799,7 @@ static uint64_t mm_chain(om_align_t *self)
 	vec_reserve(v2u32_t, self->next, self->seed.n);
 	self->root.n = 0; self->next.n = 0;
 	if(mm_chain_seeds(self) == 0) { return 0; }
+	mm_circularize(self);
 	radix_sort_64x((v2u32_t *)self->root.a, self->root.n);
 	self->cnt[2] += self->root.n;
 	return self->root.n;
@@ -733,6 +812,7 @@ static void init_ref(om_align_t *self, uint32_t rid)
 	self->rid = rid; self->rlen = ref->l_seq; self->rseq = ref->seq;
 	self->r[0] = (og_section_t){ rid << 1, ref->l_seq, ref->seq };
 	self->r[1] = (og_section_t){ (rid << 1) + 1, ref->l_seq, og_mirror(ref->seq, ref->l_seq) };
+	self->rtp = self->mi->circular[rid] ? self->r : self->t;        /* a circular reference continues into itself (minialign.c:3753) */
 }
 static void init_query(om_align_t *self, uint32_t l_seq, uint8_t const *seq)
 {
@@ -924,13 +1004,13 @@ static uint64_t mm_extend(om_align_t *self)
 		for(; st.srem > 0 && st.prem > 0; mm_search_load_next(self, &st)) {
 			og_dp_flush(self->dp);
 			/* QUIRK (minialign.c:4123): _dp(x) ignores its argument, every call uses dp[st.narrow] */
-			og_fill_t const *f = mm_extend_core(self, (int)st.narrow, &self->r[0], &self->t[0], &self->q[st.rev], &self->t[0], st.cp);
+			og_fill_t const *f = mm_extend_core(self, (int)st.narrow, &self->r[0], self->rtp, &self->q[st.rev], &self->t[0], st.cp);
 			if(getenv("OM_DEBUG")) fprintf(stderr, "  down max %ld\n", f->max);
 			if(f->max == 0) { continue; }
 			og_pos_pair_t const *pp = og_dp_search_max(self->dp, f);
 			if(mm_search_test_dup(self, &st, pp) != 0) { if(getenv("OM_DEBUG")) fprintf(stderr, "  dup\n"); continue; }
 			pos_pair_t up = { .apos = self->r[0].len - st.tp.apos, .bpos = self->q[0].len - st.tp.bpos };
-			f = mm_extend_core(self, (int)st.narrow, &self->r[1], &self->t[0], &self->q[1 - st.rev], &self->t[0], up);
+			f = mm_extend_core(self, (int)st.narrow, &self->r[1], self->rtp + 1, &self->q[1 - st.rev], &self->t[0], up);
 			og_alignment_t *a = NULL;
 			if(getenv("OM_DEBUG")) fprintf(stderr, "  up max %ld (from %u,%u)\n", f->max, up.apos, up.bpos);
 			if(f->max < (int64_t)self->min_score || (a = og_dp_trace(self->dp, f)) == NULL) { continue; }

@@ -40,16 +40,18 @@ class OmOpt(ctypes.Structure):
                 ('p_sm', ctypes.c_int8 * 16), ('p_gi', ctypes.c_int8), ('p_ge', ctypes.c_int8), ('p_gfa', ctypes.c_int8), ('p_gfb', ctypes.c_int8),
                 ('p_xdrop', ctypes.c_int8), ('p_ft', ctypes.c_uint8), ('p_reserved', ctypes.c_void_p), ('p_pad', ctypes.c_uint64),
                 ('arg_line', ctypes.c_char_p), ('min_len', ctypes.c_uint32),
-                ('flag', ctypes.c_uint64), ('tags', ctypes.c_uint64), ('rg_line', ctypes.c_char_p), ('rg_id', ctypes.c_char_p), ('keep_qual', ctypes.c_uint32), ('format', ctypes.c_uint32)]
+                ('flag', ctypes.c_uint64), ('tags', ctypes.c_uint64), ('rg_line', ctypes.c_char_p), ('rg_id', ctypes.c_char_p), ('keep_qual', ctypes.c_uint32), ('format', ctypes.c_uint32),
+                ('circ_set', ctypes.c_uint32), ('circ_names', ctypes.c_char_p)]
 
 class OmSeq(ctypes.Structure):
     _fields_ = [('name', ctypes.c_char_p), ('l_name', ctypes.c_uint32), ('seq', ctypes.c_void_p), ('l_seq', ctypes.c_uint32), ('qual', ctypes.c_char_p), ('comment', ctypes.c_char_p)]
 
 class OracleMM:
-    def __init__(self, preset, ref):
-        """ref: list of (name, uint8 array)"""
+    def __init__(self, preset, ref, circ=None):
+        """ref: list of (name, uint8 array); circ: None, or a comma list of circular sequence names (b'' = all)"""
         L = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'liboracle.so')); self.L = L
         self.opt = OmOpt(); assert L.om_opt_init(ctypes.byref(self.opt), preset.encode()) == 0
+        if circ is not None: self.opt.circ_set = 1; self.opt.circ_names = circ
         self.ref = ref
         self._keep = [np.ascontiguousarray(s) for _, s in ref]
         self.seqs = (OmSeq * len(ref))()

@@ -140,3 +140,35 @@ def test_host_index_matches_oracle_and_survives_dump_and_load(tmp_path):
     assert subprocess.run([cli, '-xpacbio', '-d', mai, str(tmp_path / 'cut.fa.gz')], stderr=subprocess.DEVNULL).returncode == 1
     for h in (mi, m1, m2): L.mm_idx_destroy(h)
     L.mm_opt_destroy(o)
+
+
+def test_host_index_of_circular_references_matches_oracle(tmp_path):
+    """-c: minimizers of the windows that span the origin of a circular sequence, with the positions the reference's stream decoder gives them
+    (minialign.c:2438-2444, 2831-2835) -- product host index against the oracle's, all sequences circular and by name"""
+    import numpy as np, mmlib as M
+    sys_path = os.path.join(ROOT, 'tests', 'golden')
+    import sys; sys.path.insert(0, sys_path)
+    from make_circ_golden import make_circ_inputs
+    ref, _ = make_circ_inputs(str(tmp_path))
+    L = ctypes.CDLL(os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so'))
+    for f in ('mm_opt_init', 'mm_idx_gen'): getattr(L, f).restype = ctypes.c_void_p
+    refseq = M.read_fasta(ref)
+    for copt, names in ((b'-c*', None), (b'-cplasmid', b'plasmid')):
+        o = ctypes.c_void_p(L.mm_opt_init())
+        argv = (ctypes.c_char_p * 4)(b'minialign', b'-xpacbio', copt, ref.encode()); files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
+        assert L.mm_opt_parse(o, 4, argv, files, 8, ctypes.byref(nf)) == 0 and nf.value == 1
+        mi = ctypes.c_void_p(L.mm_idx_gen(o, ref.encode())); assert mi
+        ora = M.OracleMM('pacbio', refseq, circ=(names if names else b''))
+        assert [L.mm_idx_occ(mi, i) for i in range(3)] == ora.occ()[:3]
+        buf = (ctypes.c_uint64 * 65536)()
+        n_wrap = 0
+        for name, q in refseq:
+            dbl = np.concatenate([q, q[:40]])                  # k-mers across the origin are looked up too
+            for m in ora.sketch(dbl)[::3]:
+                k = int(m) >> 8
+                got = [int(buf[i]) for i in range(L.mm_idx_get(mi, ctypes.c_uint64(k), buf, 65536))]
+                want = [int(v) for v in ora.idx_get(k)]
+                assert got == want
+                n_wrap += sum(1 for v in want if (v & 0xffffffff) + 15 > len(q) and (v >> 33) == [n for n, _ in refseq].index(name))
+        assert n_wrap > 0
+        L.mm_idx_destroy(mi); L.mm_opt_destroy(o)

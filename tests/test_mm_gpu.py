@@ -153,3 +153,24 @@ def test_optional_sam_fields_match_reference_golden(name, opts, workdir):
     got = _strip_pg(r.stdout)
     want = gzip.open(os.path.join(HERE, 'golden', 'tag_%s.sam.gz' % name)).read()
     assert got == want, _first_diff(got, want)
+
+
+def _circ_lines():
+    from golden.make_circ_golden import CIRC_LINES
+    return CIRC_LINES
+
+@pytest.mark.parametrize('name,opts', _circ_lines(), ids=[n for n, _ in _circ_lines()])
+def test_circular_references_match_reference_golden(name, opts, workdir):
+    """-c through the HIP pipeline: reads across the origin of circular references on both strands, a read longer than the circle, by-name selection;
+    also through an index file, which keeps the circular flags"""
+    from golden.make_circ_golden import make_circ_inputs
+    ref, rd = make_circ_inputs(workdir)
+    want = gzip.open(os.path.join(HERE, 'golden', 'circ_%s.sam.gz' % name)).read()
+    r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = _strip_pg(r.stdout)
+    assert got == want, _first_diff(got, want)
+    mai = os.path.join(workdir, 'circ_%s.mai' % name)
+    assert subprocess.run([CLI] + opts + ['-d', mai, ref], stderr=subprocess.DEVNULL).returncode == 0
+    r = subprocess.run([CLI] + [o for o in opts if not o.startswith('-c') and o != 'plasmid'] + [mai, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and _strip_pg(r.stdout) == want

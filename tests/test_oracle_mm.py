@@ -97,3 +97,19 @@ def test_oracle_optional_sam_fields_match_reference_golden(name, opts, workdir):
     got = strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
     want = gzip.open(os.path.join(HERE, 'golden', 'tag_%s.sam.gz' % name)).read()
     assert got == want
+
+
+def _circ_lines():
+    from golden.make_circ_golden import CIRC_LINES
+    return CIRC_LINES
+
+@pytest.mark.parametrize('name,opts', _circ_lines(), ids=[n for n, _ in _circ_lines()])
+def test_oracle_circular_references_match_reference_golden(name, opts, workdir):
+    """-c: wrap-around minimizers in the index, chains linked across the origin (mm_circularize), extension continuing into the reference itself, the two
+    segments printed as primary + supplementary: golden SAM from the compiled reference (tests/golden/make_circ_golden.py)"""
+    import gzip
+    from golden.make_circ_golden import make_circ_inputs, strip_pg
+    ref, rd = make_circ_inputs(workdir)
+    got = strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+    want = gzip.open(os.path.join(HERE, 'golden', 'circ_%s.sam.gz' % name)).read()
+    assert got == want
