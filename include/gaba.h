@@ -115,7 +115,13 @@ void gaba_dp_flush_stack(gaba_dp_t *dp, gaba_stack_t const *stack);   /* gaba.h:
 gaba_fill_t *gaba_dp_fill_root(gaba_dp_t *dp, gaba_section_t const *a, uint32_t apos, gaba_section_t const *b, uint32_t bpos, uint32_t pridx);   /* gaba.h:302 */
 gaba_fill_t *gaba_dp_fill(gaba_dp_t *dp, gaba_fill_t const *prev_sec, gaba_section_t const *a, gaba_section_t const *b, uint32_t pridx);          /* gaba.h:315 */
 gaba_pos_pair_t *gaba_dp_search_max(gaba_dp_t *dp, gaba_fill_t const *sec);                                                                       /* gaba.h:339 */
-gaba_alignment_t *gaba_dp_trace(gaba_dp_t *dp, gaba_fill_t const *tail, void const *alloc_params);                                                /* gaba.h:348 */
+/* gaba.h:61-75: the caller may supply where alignment objects live; NULL = this library's own heap.  lmalloc gets one request per alignment
+ * (header + path + segments), lfree gets that pointer back from gaba_dp_res_free. */
+typedef void *(*gaba_lmalloc_t)(void *opaque, size_t size);
+typedef void (*gaba_lfree_t)(void *opaque, void *ptr);
+struct gaba_alloc_s { void *opaque; gaba_lmalloc_t lmalloc; gaba_lfree_t lfree; };
+typedef struct gaba_alloc_s gaba_alloc_t;
+gaba_alignment_t *gaba_dp_trace(gaba_dp_t *dp, gaba_fill_t const *tail, gaba_alloc_t const *alloc);                                               /* gaba.h:348 */
 void gaba_dp_res_free(gaba_dp_t *dp, gaba_alignment_t *aln);                                                                                      /* gaba.h:357 */
 
 /* one extension job: the arguments of gaba_dp_fill_root (gaba.c:2110) with host pointers replaced by

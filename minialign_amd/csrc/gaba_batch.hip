@@ -462,9 +462,8 @@ gaba_pos_pair_t *gaba_dp_search_max(gaba_dp_t *dp, gaba_fill_t const *fill)
 	dp->pps.push_back(q);
 	return q;
 }
-gaba_alignment_t *gaba_dp_trace(gaba_dp_t *dp, gaba_fill_t const *fill, void const *alloc_params)
+gaba_alignment_t *gaba_dp_trace(gaba_dp_t *dp, gaba_fill_t const *fill, gaba_alloc_t const *alloc)
 {
-	(void)alloc_params;                              /* results are malloc'd; release with gaba_dp_res_free */
 	if(!dp || !fill || !dp->ar[0] || !dp->ar[1]) return NULL;
 	SeqArena da = { dp->ar[0]->pk, dp->ar[0]->nm }, db = { dp->ar[1]->pk, dp->ar[1]->nm };
 	/* the path cannot be longer than the two sequences walked: bounded by the fill's positions */
@@ -481,17 +480,27 @@ gaba_alignment_t *gaba_dp_trace(gaba_dp_t *dp, gaba_fill_t const *fill, void con
 	if(!o.err && o.ao.status == 1) {
 		const uint64_t pw = ((uint64_t)o.ao.plen + 31) / 32 + 2;
 		/* one allocation: header | path words (two header words {plen, 0x40000000} live in plen / padding, gaba.h:217) | segments */
-		aln = (gaba_alignment_t *)calloc(1, sizeof(gaba_alignment_t) + pw * 4 + o.ao.slen * sizeof(gaba_path_section_t));
+		const size_t bytes = sizeof(gaba_alignment_t) + pw * 4 + o.ao.slen * sizeof(gaba_path_section_t);
+		/* the caller's allocator when one is given (gaba.c:3263-3265); it and its handle ride in the two reserved words for gaba_dp_res_free */
+		aln = (gaba_alignment_t *)(alloc && alloc->lmalloc ? alloc->lmalloc(alloc->opaque, bytes) : malloc(bytes));
+		if(!aln) { (void)hipFree(dpath); (void)hipFree(dseg); return NULL; }
+		memset(aln, 0, bytes);
+		if(alloc && alloc->lmalloc) { aln->reserved[0] = alloc->opaque; aln->reserved[1] = (void *)alloc->lfree; }
 		aln->score = o.ao.score; aln->identity = o.ao.identity; aln->agcnt = o.ao.agcnt; aln->bgcnt = o.ao.bgcnt; aln->dcnt = o.ao.dcnt;
 		aln->slen = o.ao.slen; aln->plen = o.ao.plen; aln->padding = 0x40000000u;
 		gaba_path_section_t *seg = (gaba_path_section_t *)((uint8_t *)aln + sizeof(gaba_alignment_t) + pw * 4);
-		if(hipMemcpy(aln->path, dpath, pw * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(seg, dseg, o.ao.slen * sizeof(Segment), hipMemcpyDeviceToHost) != hipSuccess) { free(aln); aln = NULL; }
+		if(hipMemcpy(aln->path, dpath, pw * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(seg, dseg, o.ao.slen * sizeof(Segment), hipMemcpyDeviceToHost) != hipSuccess) { gaba_dp_res_free(dp, aln); aln = NULL; }
 		else { aln->seg = seg; }
 	}
 	(void)hipFree(dpath); (void)hipFree(dseg);
 	return aln;
 }
-void gaba_dp_res_free(gaba_dp_t *dp, gaba_alignment_t *aln) { (void)dp; free(aln); }
+void gaba_dp_res_free(gaba_dp_t *dp, gaba_alignment_t *aln)
+{
+	(void)dp;
+	if(!aln) return;
+	if(aln->reserved[1]) { ((gaba_lfree_t)aln->reserved[1])(aln->reserved[0], (void *)aln); } else { free(aln); }       /* gaba.c:3398-3407 */
+}
 
 /* ---- CIGAR printers over a path (gaba_parse.h:147-263): run-length decode of the path bits; host side ---- */
 static inline uint64_t cg_u64(const uint64_t *ptr, int64_t pos) { int64_t rem = pos & 63; return (ptr[pos >> 6] >> rem) | ((ptr[(pos >> 6) + 1] << (63 - rem)) << 1); }

@@ -110,6 +110,14 @@ def test_per_call_api_matches_oracle(bw):
     HL.gaba_dp_search_max.restype = ctypes.POINTER(_Pos); HL.gaba_dp_trace.restype = ctypes.POINTER(_DevAln)
     HL.gaba_dp_init_bw.restype = ctypes.c_void_p; HL.gaba_arena_upload.restype = ctypes.c_void_p
     rng = np.random.default_rng(1234 + bw)
+    # every other trial traces through a caller-supplied allocator (gaba_alloc_t, gaba.h:61-75): one lmalloc per alignment, handed back to lfree
+    libc = ctypes.CDLL(None); libc.malloc.restype = ctypes.c_void_p; libc.malloc.argtypes = [ctypes.c_size_t]; libc.free.argtypes = [ctypes.c_void_p]
+    LM = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t); LF = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)
+    class _Alloc(ctypes.Structure): _fields_ = [('opaque', ctypes.c_void_p), ('lmalloc', LM), ('lfree', LF)]
+    live = {}
+    def _lm(opaque, size): p = libc.malloc(size); live[p] = opaque; return p
+    def _lf(opaque, ptr): assert live.pop(ptr) == opaque; libc.free(ptr)
+    alloc = _Alloc(0x1234, LM(_lm), LF(_lf)); n_custom = 0
     for trial in range(12):
         L = int(rng.integers(40, 1500))
         a = rng.integers(0, 4, L, dtype=np.uint8)
@@ -139,7 +147,7 @@ def test_per_call_api_matches_oracle(bw):
         d_f, d_best, d_pp, d_aln = _drive(
             lambda x, ap, y, bp: HL.gaba_dp_fill_root(dp, ctypes.byref(x), ap, ctypes.byref(y), bp, 0),
             lambda f, x, y: HL.gaba_dp_fill(dp, f, ctypes.byref(x), ctypes.byref(y), 0),
-            lambda f: HL.gaba_dp_search_max(dp, f), lambda f: HL.gaba_dp_trace(dp, f, None), asecs, bsecs, tail_a, tail_b, apos, bpos)
+            lambda f: HL.gaba_dp_search_max(dp, f), lambda f: HL.gaba_dp_trace(dp, f, ctypes.byref(alloc) if trial & 1 else None), asecs, bsecs, tail_a, tail_b, apos, bpos)
         assert [_fill_tuple(f.contents) for f in d_f] == [_fill_tuple(f.contents) for f in o_f], 'fills differ (trial %d)' % trial
         op, dpp = o_pp.contents, d_pp.contents
         assert (op.aid, op.bid, op.apos, op.bpos, op.plen) == (dpp.aid, dpp.bid, dpp.apos, dpp.bpos, dpp.plen)
@@ -153,5 +161,8 @@ def test_per_call_api_matches_oracle(bw):
             assert [oa.path[i] for i in range(nw)] == [dpath[i] for i in range(nw)]
             seg = lambda s: (s.aid, s.bid, s.apos, s.bpos, s.alen, s.blen, s.ppos)
             assert [seg(oa.seg[i]) for i in range(oa.slen)] == [seg(da.seg[i]) for i in range(da.slen)]
+            if trial & 1: assert len(live) == 1; n_custom += 1
             OL.og_aln_free(o_aln); HL.gaba_dp_res_free(dp, d_aln)
+            assert len(live) == 0
         HL.gaba_dp_clean(dp); HL.gaba_arena_free(ara); HL.gaba_arena_free(arb)
+    assert n_custom > 0
