@@ -34,7 +34,7 @@ typedef struct mm_align_s mm_align_t;
  * minialign.c:5990-6099 in argv order, `-k15` or `-k 15`: sketch and index (-k -w -B -f -L, -c [names] for circular references), scores (-a -b -e -p -q -r -Y), mapping
  * (-s -m -W -G), output (-T tags, -R read group, -Q qualities, -P), -d (index file to write), -t -v -1 -2 (accepted; they size the
  * reference's host pipeline), with the reference's range checks and mm_opt_check_sanity (minialign.c:6097).  Returns 0 on success, nonzero
- * on anything the reference rejects or this build does not provide (-X -A -C: DESIGN.md 1). */
+ * on anything the reference rejects.  -X (all versus all), -A and -C follow the reference, where only -X changes what is mapped. */
 mm_opt_t *mm_opt_init(void);
 int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char const **files, int max_files, int *n_files);
 void mm_opt_destroy(mm_opt_t *o);

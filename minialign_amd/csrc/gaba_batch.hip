@@ -180,8 +180,11 @@ gaba_t *gaba_init(gaba_params_t const *params)
 	HP p; memcpy(p.sm, params->score_matrix, 16);
 	p.gi = params->gi; p.ge = params->ge; p.gfa = params->gfa; p.gfb = params->gfb;
 	p.xdrop = params->xdrop == 0 ? 50 : params->xdrop;                  /* gaba_init_restore_default, gaba.c:3605 */
-	p.model = p.gi != 0 ? ((p.gfa != 0 && p.gfb != 0) ? MODEL_COMBINED : MODEL_AFFINE) : 0;   /* gaba_wrap.h:213-221 */
-	if(p.model == 0) { fprintf(stderr, "[minialign_amd] gaba_init: linear-gap model (gi == 0) is not supported\n"); return NULL; }
+	/* gaba_wrap.h:213-221.  gi == 0 selects the reference's linear-gap build (the `ava' preset); its fills, max positions, paths, segments and counts
+	 * are those of the affine recurrences run with gi = 0 and gf ignored (checked against the compiled reference on random jobs over five score sets,
+	 * tests/golden/gaba_extend.json group `linear'), so the AFFINE kernels run */
+	p.model = p.gi != 0 ? ((p.gfa != 0 && p.gfb != 0) ? MODEL_COMBINED : MODEL_AFFINE) : MODEL_AFFINE;
+	if(p.gi == 0) { p.gfa = p.gfb = 0; }
 	if(!scores_ok(p)) return NULL;
 
 	gaba_t *ctx = (gaba_t *)calloc(1, sizeof(gaba_t));

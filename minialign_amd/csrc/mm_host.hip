@@ -322,6 +322,7 @@ struct mm_opt_s {
 	 * into one word (minialign.c:5677), so -P also switches IH on and -T IH also omits the secondary records: kept */
 	uint64_t flag = 0, tags = 0; std::string rg_line, rg_id; bool keep_qual = false;
 	uint32_t format = 0;             /* -O: 0 sam, 1 maf, 2 blast6, 5 paf (minialign.c:2543-2549, 5940) */
+	bool ava = false;                /* -X (MM_AVA in the mapper's flag word, minialign.c:5965, 6377) */
 	bool circ_set = false; std::vector<std::string> circ_names;     /* -c: given at all / names of the circular reference sequences (none: all), minialign.c:2457, 5986 */
 	uint64_t ptags() const { return flag | tags; }
 	uint32_t wlen = 7000, glen = 7000, min_score = 50; float min_ratio = 0.3f;
@@ -433,6 +434,9 @@ int opt_one(mm_opt_t *o, char c, const char *arg)
 			split_each(arg, ",;:/", [&](int, const std::string &t) { if(t == "*" || t == "-") o->circ_names.clear(); else o->circ_names.push_back(t); });
 			return 0;
 		}
+		case 'X': o->flag |= 0x01; o->ava = true; return 0;      /* MM_AVA: every file is mapped onto every file (minialign.c:6377); QUIRK kept: the bit is also the RG tag's */
+		case 'A': o->flag |= 0x10; return 0;      /* MM_COMP: no effect on the mapping; QUIRK kept: the bit is also the AS tag's */
+		case 'C': return 0;                       /* base ids: parsed, unused (minialign.c:3768 pins qid to 0) */
 		case 'P': o->flag |= 0x08; return 0;
 		case 'Q': o->keep_qual = true; return 0;
 		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
@@ -477,7 +481,7 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
 			const char *arg = a + 2;
 			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGdfBLe12TRO", a[1])) arg = argv[++i];
 			/* options with an optional argument take the next word unless it looks like an option (mm_opt_parse_argv, minialign.c:5786) */
-			else if(*arg == 0 && i + 1 < argc && strchr("cv", a[1]) && (argv[i + 1][0] != '-' || argv[i + 1][1] == 0)) arg = argv[++i];
+			else if(*arg == 0 && i + 1 < argc && strchr("cvC", a[1]) && (argv[i + 1][0] != '-' || argv[i + 1][1] == 0)) arg = argv[++i];
 			if(opt_one(o, a[1], arg)) return 1;
 		} else if(nf < max_files) files[nf++] = a;
 	}
@@ -1626,14 +1630,17 @@ extern "C" int mm_main(int argc, char **argv)
 	}
 	double t0 = now_ms();
 	if(!o->fnw.empty()) { int rc = main_index(o, files, nf, t0); mm_opt_destroy(o); return rc; }
-	if(nf == 1) { fprintf(stderr, "[M::main_align] query-side input redirected to stdin.\n"); files[nf++] = "-"; }     /* minialign.c:6380-6384 */
+	/* a prebuilt index (file name ending in .mai) may hold several blocks: every query file is mapped onto each in turn, with a header per block;
+	 * -X without a prebuilt index maps every file onto every file, one index per file (minialign.c:6373-6379, 6413-6436) */
+	const bool prebuilt = ends_with(files[0], ".mai");
+	const bool ava = o->ava && !prebuilt;           /* the mapper's own flag word (a.flag); -R sets the same bit in the printer's only */
+	const int n_ref = ava ? nf : 1, qh = ava ? 0 : 1;
+	if(qh == nf) { fprintf(stderr, "[M::main_align] query-side input redirected to stdin.\n"); files[nf++] = "-"; }     /* minialign.c:6380-6384 */
 	/* the first query file is parsed on a thread of its own while the index is built or loaded */
 	mm_reads_t *first_reads = NULL;
-	std::thread rt([&]() { if(strcmp(files[1], "-") != 0) first_reads = reads_load(files[1], o->min_len, o->keep_qual, (o->ptags() >> 1) & 1); });
+	std::thread rt([&]() { if(strcmp(files[qh], "-") != 0) first_reads = reads_load(files[qh], o->min_len, o->keep_qual, (o->ptags() >> 1) & 1); });
 	std::thread hw([]() { int n = 0; if(hipGetDeviceCount(&n) == hipSuccess && n > 0) { (void)hipFree(0); } });      /* bring the HIP runtime up meanwhile */
-	/* a prebuilt index (file name ending in .mai) may hold several blocks: every query file is mapped onto each in turn, with a header per block
-	 * (minialign.c:6373, 6413-6436) */
-	const bool prebuilt = ends_with(files[0], ".mai");
+	const bool keep_first = prebuilt || n_ref > 1;      /* the parsed first query file serves every index */
 	FILE *pg = prebuilt ? fopen(files[0], "rb") : NULL;
 	int rc = 0, at_eof = 0; uint32_t micnt = 0;
 	bool joined = false;
@@ -1641,10 +1648,10 @@ extern "C" int mm_main(int argc, char **argv)
 	if(prebuilt && !pg) { fprintf(stderr, "[E::main_align] failed to build index for `%s'. Please check file path and format.\n", files[0]); rc = 1; }
 	mm_stats_t tot; memset(&tot, 0, sizeof(tot));
 	while(rc == 0) {
-		mm_idx_t *mi = prebuilt ? mm_idx_load(pg, &at_eof) : (micnt == 0 ? mm_idx_gen(o, files[0]) : NULL);
+		mm_idx_t *mi = prebuilt ? mm_idx_load(pg, &at_eof) : ((int)micnt < n_ref ? mm_idx_gen(o, files[micnt]) : NULL);
 		if(!mi) {
 			if(prebuilt && (micnt == 0 || !at_eof)) { fprintf(stderr, "[E::main_align] failed to load index block from `%s'. Please check file path and version, or rebuild the index.\n", files[0]); rc = 1; }
-			else if(!prebuilt && micnt == 0) { fprintf(stderr, "[E::main_align] failed to build index for `%s'. Please check file path and format.\n", files[0]); rc = 1; }
+			else if(!prebuilt && (int)micnt < n_ref) { fprintf(stderr, "[E::main_align] failed to build index for `%s'. Please check file path and format.\n", files[micnt]); rc = 1; }
 			break;
 		}
 		if(!joined) hw.join();
@@ -1653,11 +1660,11 @@ extern "C" int mm_main(int argc, char **argv)
 		if(!a) { fprintf(stderr, "[E::main_align] failed to instanciate alignment context.\n"); mm_idx_destroy(mi); rc = 1; break; }
 		fprintf(stderr, "[M::main_align::%.3f] loaded/built index for %u target sequence(s).\n", (now_ms() - t0) * 1e-3, mm_idx_n_seq(mi));
 		if(o->format == 0) mm_print_sam_header(a, stdout, o->arg_line.c_str());        /* only SAM has a header (minialign.c:5666-5671) */
-		for(int i = 1; i < nf && rc == 0; i++) {
-			if(i == 1 && first_reads) { rc = align_reads(a, first_reads, stdout, prebuilt); if(!prebuilt) first_reads = NULL; }      /* kept for the next block of a prebuilt index */
+		for(int i = qh; i < nf && rc == 0; i++) {
+			if(i == qh && first_reads) { rc = align_reads(a, first_reads, stdout, keep_first); if(!keep_first) first_reads = NULL; }
 			else { rc = mm_align_file(a, files[i], stdout); }
 			if(rc) fprintf(stderr, "[E::main_align] failed to map sequence file `%s'. Please check file path and format.\n", files[i]);
-			else fprintf(stderr, "[M::main_align::%.3f] finished mapping `%s' onto `%s'.\n", (now_ms() - t0) * 1e-3, files[i], files[0]);
+			else fprintf(stderr, "[M::main_align::%.3f] finished mapping `%s' onto `%s'.\n", (now_ms() - t0) * 1e-3, files[i], files[prebuilt ? 0 : micnt]);
 		}
 		mm_stats_t st; mm_stats(a, &st, 0);
 		tot.reads += st.reads; tot.bases += st.bases; tot.k1_ms += st.k1_ms; tot.k2_ms += st.k2_ms; tot.k3_ms += st.k3_ms; tot.host_post_ms += st.host_post_ms; tot.host_sam_ms += st.host_sam_ms; tot.reruns += st.reruns;

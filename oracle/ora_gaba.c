@@ -11,8 +11,8 @@
  * link to the block that precedes the fill; results do not depend on the stack mechanics
  * (gaba.c:2057-2099 only decide *where* blocks live).
  *
- * Not implemented (not reachable from minialign's presets): LINEAR model, gaba_dp_merge,
- * breakpoint masks (abrk/bbrk are always 0 in minialign's call pattern).
+ * The linear-gap model (gi == 0, the `ava' preset) runs the affine recurrences with gi = 0: same observable results (see og_init).
+ * Not implemented: gaba_dp_merge, breakpoint masks (abrk/bbrk are always 0 in minialign's call pattern).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -213,8 +213,11 @@ og_ctx_t *og_init(og_params_t const *params)
 {
 	if(params == NULL) { return NULL; }
 	og_params_t p = *params;
-	int model = (p.gi != 0) ? ((p.gfa != 0 && p.gfb != 0) ? MODEL_COMBINED : MODEL_AFFINE) : 0;    /* gaba_wrap.h:213-221 */
-	if(model == 0) { return NULL; }                                  /* LINEAR: not restated */
+	/* gaba_wrap.h:213-221.  gi == 0 selects the reference's linear-gap build; its fills, max positions, paths, segments and counts are those of the affine
+	 * recurrences run with gi = 0 (gf ignored) -- pinned against the compiled reference on random jobs over five score sets (tests/test_oracle_gaba.py,
+	 * tests/golden/gaba_extend.json group `linear') -- so that is what runs */
+	int model = (p.gi != 0) ? ((p.gfa != 0 && p.gfb != 0) ? MODEL_COMBINED : MODEL_AFFINE) : MODEL_AFFINE;
+	if(p.gi == 0) { p.gfa = p.gfb = 0; }
 	/* gaba_init_restore_default, gaba.c:3582-3608 (only xdrop matters for non-zero matrices) */
 	int allzero = 1; for(int i = 0; i < 16; i++) { allzero &= p.score_matrix[i] == 0; }
 	if(allzero) { return NULL; }

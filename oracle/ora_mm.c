@@ -146,6 +146,9 @@ static int opt_one(om_opt_t *o, char c, char const *arg, size_t l)
 			memcpy(o->circ_names + have, arg, l); o->circ_names[have + l] = 0;
 			return 0;
 		}
+		case 'X': o->flag |= 0x01; o->ava = 1; return 0;      /* MM_AVA: every file is mapped onto every file (minialign.c:6377); QUIRK: the bit is also the RG tag's */
+		case 'A': o->flag |= 0x10; return 0;      /* MM_COMP: no effect on the mapping; QUIRK: the bit is also the AS tag's */
+		case 'C': return 0;                       /* base ids: parsed, unused (minialign.c:3768 pins qid to 0) */
 		case 'P': o->flag |= 0x08; return 0;
 		case 'Q': o->keep_qual = 1; return 0;
 		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
@@ -205,7 +208,8 @@ static int opt_preset(om_opt_t *o, char const *preset)
 		if(strcmp(preset, "ont.1d") == 0) { opt_apply(o, "-a2"); }
 		else if(strcmp(preset, "ont.1dsq") == 0 || strcmp(preset, "ont.2d") == 0) { opt_apply(o, "-a2 -b6 -r4,4"); }
 		else if(strcmp(preset, "ont") != 0) { rc = 1; }
-	} else { rc = 1; }
+	} else if(strcmp(preset, "ava") == 0) { opt_apply(o, "-k15 -w5 -a2 -b3 -p0 -q2 -Y50 -s30 -m0.05"); }      /* linear gaps (gi = 0), minialign.c:5879 */
+	else { rc = 1; }
 	return rc;
 }
 static int opt_check(om_opt_t *o)           /* mm_opt_check_sanity, minialign.c:6097-6112 */
@@ -236,7 +240,7 @@ int om_opt_parse(om_opt_t *o, int argc, char const *const *argv, char const **fi
 			char const *arg = a + 2;
 			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGfBLe12TRO", a[1])) { arg = argv[++i]; }
 			/* options with an optional argument take the next word unless it looks like an option (mm_opt_parse_argv, minialign.c:5786) */
-			else if(*arg == 0 && i + 1 < argc && strchr("cv", a[1]) && (argv[i + 1][0] != '-' || argv[i + 1][1] == 0)) { arg = argv[++i]; }
+			else if(*arg == 0 && i + 1 < argc && strchr("cvC", a[1]) && (argv[i + 1][0] != '-' || argv[i + 1][1] == 0)) { arg = argv[++i]; }
 			rc |= opt_one(o, a[1], arg, strlen(arg));
 		} else if(nf < max_files) { files[nf++] = a; }
 	}
@@ -1396,25 +1400,39 @@ int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *
 }
 int om_main_opt(om_opt_t const *op, char const *ref_fn, char const *query_fn, FILE *out, double *map_seconds, uint64_t *bases)
 {
+	char const *files[2] = { ref_fn, query_fn };
+	return om_main_files(op, files, 2, out, map_seconds, bases);
+}
+/* main_align, minialign.c:6365-6447: the first file is the reference, the others are queries -- or, with -X, every file is indexed in turn and every file
+ * mapped onto it (a header per index in SAM) */
+int om_main_files(om_opt_t const *op, char const *const *files, int nf, FILE *out, double *map_seconds, uint64_t *bases)
+{
 	om_opt_t o = *op;
-	om_seqs_t ref = om_read_fasta(ref_fn); om_seqs_drop_short(&ref, o.min_len);
-	if(ref.n == 0) { return 2; }
-	om_idx_t *mi = om_idx_build(&o, ref.a, (uint32_t)ref.n);
-	om_align_t *al = om_align_init(&o, mi);
-	if(al == NULL) { return 3; }
-	om_seqs_t qs = om_read_fasta_ex(query_fn, (int)o.keep_qual, (int)(((o.flag | o.tags) >> OM_CO) & 1)); om_seqs_drop_short(&qs, o.min_len);
-	if(o.format == 0) { om_sam_header(out, &o, ref.a, (uint32_t)ref.n); }          /* only SAM has a header (minialign.c:5666-5671) */
+	int const ava = o.ava != 0 && nf > 0;          /* the mapper's own flag word (a.flag); -R sets the same bit in the printer's only */
+	int const rt = ava ? nf : 1, qh = ava ? 0 : 1;
 	double tmap = 0; uint64_t nb = 0;
-	for(uint64_t i = 0; i < qs.n; i++) {
-		double t1 = now_s();
-		om_reg_t *reg = om_align_seq(al, qs.a[i].l_seq, qs.a[i].seq);
-		tmap += now_s() - t1; nb += qs.a[i].l_seq;
-		om_print_record(out, &o, ref.a, &qs.a[i], reg);
-		om_reg_free(reg);
+	for(int r = 0; r < rt; r++) {
+		om_seqs_t ref = om_read_fasta(files[r]); om_seqs_drop_short(&ref, o.min_len);
+		if(ref.n == 0) { return 2; }
+		om_idx_t *mi = om_idx_build(&o, ref.a, (uint32_t)ref.n);
+		om_align_t *al = om_align_init(&o, mi);
+		if(al == NULL) { return 3; }
+		if(o.format == 0) { om_sam_header(out, &o, ref.a, (uint32_t)ref.n); }          /* only SAM has a header (minialign.c:5666-5671) */
+		for(int q = qh; q < nf; q++) {
+			om_seqs_t qs = om_read_fasta_ex(files[q], (int)o.keep_qual, (int)(((o.flag | o.tags) >> OM_CO) & 1)); om_seqs_drop_short(&qs, o.min_len);
+			for(uint64_t i = 0; i < qs.n; i++) {
+				double t1 = now_s();
+				om_reg_t *reg = om_align_seq(al, qs.a[i].l_seq, qs.a[i].seq);
+				tmap += now_s() - t1; nb += qs.a[i].l_seq;
+				om_print_record(out, &o, ref.a, &qs.a[i], reg);
+				om_reg_free(reg);
+			}
+			om_seqs_free(&qs);
+		}
+		om_align_free(al); om_idx_free(mi); om_seqs_free(&ref);
 	}
 	if(map_seconds) { *map_seconds = tmap; }
 	if(bases) { *bases = nb; }
-	om_align_free(al); om_idx_free(mi); om_seqs_free(&qs); om_seqs_free(&ref);
 	return 0;
 }
 

@@ -31,6 +31,7 @@ typedef struct {
 	char *rg_line, *rg_id;      /* -R, unescaped line and the "ID:..." token */
 	uint32_t keep_qual;         /* -Q */
 	uint32_t format;            /* -O: 0 sam, 1 maf, 2 blast6, 5 paf (minialign.c:2543-2549, 5940) */
+	uint32_t ava;               /* -X (MM_AVA in the mapper's flag word, minialign.c:5965, 6377) */
 	uint32_t circ_set; char *circ_names;   /* -c: given at all / comma list of circular reference names (NULL or empty: all), minialign.c:2457, 5986 */
 } om_opt_t;
 enum { OM_RG = 0, OM_CO = 1, OM_NH = 2, OM_IH = 3, OM_AS = 4, OM_XS = 5, OM_NM = 6, OM_SA = 7, OM_MD = 8, OM_CG = 9, OM_ID = 10, OM_SQ = 11 };     /* minialign.c:2530-2538 */
@@ -96,6 +97,7 @@ void om_print_record(FILE *fp, om_opt_t const *o, om_seq_t const *ref, om_seq_t 
 /* whole program: `minialign -x<preset> ref.fa reads.fa > out` (minialign.c:6365-6447) */
 int om_main(char const *preset, char const *ref_fn, char const *query_fn, FILE *out, char const *arg_line, double *map_seconds, uint64_t *bases);
 int om_main_opt(om_opt_t const *o, char const *ref_fn, char const *query_fn, FILE *out, double *map_seconds, uint64_t *bases);
+int om_main_files(om_opt_t const *o, char const *const *files, int nf, FILE *out, double *map_seconds, uint64_t *bases);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,7 @@ class XResult(ctypes.Structure):
 PACBIO = dict(m=2, x=4, gi=4, ge=2, gfa=3, gfb=3, xdrop=50)      # minialign.c:5854
 ONT1DSQ = dict(m=2, x=6, gi=6, ge=2, gfa=4, gfb=4, xdrop=50)     # minialign.c:5857-5877 (-a2 -b6 -p6 -q2 -r4,4)
 AFFINE_DEFAULT = dict(m=1, x=1, gi=1, ge=1, gfa=0, gfb=0, xdrop=50)  # minialign.c:6158-6161
+LINEAR_AVA = dict(m=2, x=3, gi=0, ge=2, gfa=0, gfb=0, xdrop=50)      # minialign.c:5879 (-xava: -a2 -b3 -p0 -q2); gi == 0 selects the linear-gap build
 
 def score_matrix(m, x):
     return (ctypes.c_int8 * 16)(*[m if (i & 3) == (i >> 2) else -x for i in range(16)])

@@ -8,7 +8,8 @@ import gabalib as G
 
 def main():
     out = {'generator': 'tests/golden/make_gaba_golden.py', 'reference': 'ocxtal/minialign 0.6.0-devel libgaba (AVX2 build)', 'groups': []}
-    for name, P, seed in (('pacbio', G.PACBIO, 9001), ('ont1dsq', G.ONT1DSQ, 9002), ('affine', G.AFFINE_DEFAULT, 9003)):
+    for name, P, seed in (('pacbio', G.PACBIO, 9001), ('ont1dsq', G.ONT1DSQ, 9002), ('affine', G.AFFINE_DEFAULT, 9003),
+                          ('linear', G.LINEAR_AVA, 9004)):         # gi == 0: the reference's linear-gap build (the `ava' preset)
         ref = G.Reference(**P)
         jobs = G.random_jobs(seed, 24, max_len=700)
         grp = {'name': name, 'params': dict(P), 'jobs': []}

@@ -18,6 +18,9 @@ TAG_LINES = [
     ('blast6', ['-xpacbio', '-Oblast6']),
     ('maf',   ['-xont.1dsq', '-Omaf']),
     ('edge_maf', ['-xpacbio', '-Omaf']),
+    ('ava',   ['-xava', '-Opaf']),                                # the `ava' preset: linear gaps (gi = 0)
+    ('avasam', ['-xava', '-A']),                                  # QUIRK: -A shares its bit with the AS tag
+    ('avax',  ['-xava', '-X', '-C', '3,4', '-Opaf', '-TAS,NM']),  # -X: every file onto every file (here: reference and reads alike), one index per file
     ('edge_sa', ['-xpacbio', '-TSA,NM,MD,XS', '-Q']),             # on the edge-case reads of make_edge_golden.py (FASTQ): chimeras, N runs, both strands
 ]
 

@@ -41,7 +41,7 @@ class OmOpt(ctypes.Structure):
                 ('p_xdrop', ctypes.c_int8), ('p_ft', ctypes.c_uint8), ('p_reserved', ctypes.c_void_p), ('p_pad', ctypes.c_uint64),
                 ('arg_line', ctypes.c_char_p), ('min_len', ctypes.c_uint32),
                 ('flag', ctypes.c_uint64), ('tags', ctypes.c_uint64), ('rg_line', ctypes.c_char_p), ('rg_id', ctypes.c_char_p), ('keep_qual', ctypes.c_uint32), ('format', ctypes.c_uint32),
-                ('circ_set', ctypes.c_uint32), ('circ_names', ctypes.c_char_p)]
+                ('ava', ctypes.c_uint32), ('circ_set', ctypes.c_uint32), ('circ_names', ctypes.c_char_p)]
 
 class OmSeq(ctypes.Structure):
     _fields_ = [('name', ctypes.c_char_p), ('l_name', ctypes.c_uint32), ('seq', ctypes.c_void_p), ('l_seq', ctypes.c_uint32), ('qual', ctypes.c_char_p), ('comment', ctypes.c_char_p)]

@@ -23,9 +23,12 @@ def test_oracle_matches_golden():
             n += 1
     assert n >= 60
 
+LINEAR_SETS = [dict(m=1, x=1, gi=0, ge=1, gfa=0, gfb=0, xdrop=50), dict(m=1, x=2, gi=0, ge=1, gfa=0, gfb=0, xdrop=50), dict(m=2, x=4, gi=0, ge=3, gfa=0, gfb=0, xdrop=50),
+               dict(m=1, x=3, gi=0, ge=2, gfa=0, gfb=0, xdrop=50)]
 @pytest.mark.skipif(not G.Reference.available(), reason="oracle/_ref not built (needs /root/reference)")
-@pytest.mark.parametrize("P,seed", [(G.PACBIO, 21), (G.ONT1DSQ, 22), (G.AFFINE_DEFAULT, 23)])
+@pytest.mark.parametrize("P,seed", [(G.PACBIO, 21), (G.ONT1DSQ, 22), (G.AFFINE_DEFAULT, 23), (G.LINEAR_AVA, 24)] + [(p, 25 + i) for i, p in enumerate(LINEAR_SETS)])
 def test_oracle_matches_compiled_reference(P, seed):
+    """gi == 0 runs the reference's linear-gap build on its side and the affine recurrences with gi = 0 on the oracle's: same fills, positions, paths, counts"""
     ora = G.Oracle(**P); ref = G.Reference(**P)
     for j in G.random_jobs(seed, 120, max_len=3000):
         assert ora.extend(*j) == ref.extend(*j)
