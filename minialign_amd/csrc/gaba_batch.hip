@@ -7,6 +7,9 @@
  * gaba_init (gaba.c:3614-3830); sequences are packed 2-bit + N-mask before upload.
  */
 #include <hip/hip_runtime.h>
+#include <thread>
+#include <vector>
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -246,10 +249,20 @@ gaba_arena_t *gaba_arena_upload(uint8_t const *bases, uint64_t n)
 {
 	uint64_t nw = (n + 15) / 16 + 4, nn = (n + 31) / 32 + 4;
 	std::vector<uint32_t> pk(nw, 0), nm(nn, 0);
-	for(uint64_t i = 0; i < n; i++) {
-		uint32_t c = bases[i];
-		if(c > 3) { nm[i >> 5] |= 1u << (i & 31); c = 0; }
-		pk[i >> 4] |= c << (2 * (i & 15));
+	/* stretches that start on a multiple of 32 bases own whole words of both arrays: packed on host threads for long inputs (a genome) */
+	auto pack = [&](uint64_t lo, uint64_t hi) {
+		for(uint64_t i = lo; i < hi; i++) {
+			uint32_t c = bases[i];
+			if(c > 3) { nm[i >> 5] |= 1u << (i & 31); c = 0; }
+			pk[i >> 4] |= c << (2 * (i & 15));
+		}
+	};
+	const uint32_t nth = n < (64u << 20) ? 1u : std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 32);
+	if(nth == 1) pack(0, n);
+	else {
+		std::vector<std::thread> th; const uint64_t step = ((n / nth) + 31) & ~31ull;
+		for(uint32_t t = 0; t < nth; t++) { const uint64_t lo = std::min<uint64_t>(n, t * step), hi = t + 1 == nth ? n : std::min<uint64_t>(n, (t + 1) * step); if(lo < hi) th.emplace_back(pack, lo, hi); }
+		for(auto &x : th) x.join();
 	}
 	gaba_arena_t *ar = (gaba_arena_t *)calloc(1, sizeof(gaba_arena_t));
 	ar->n = n; ar->host = bases;

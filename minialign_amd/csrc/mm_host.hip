@@ -91,10 +91,10 @@ inline void sort_res(ResEnt *p, size_t n) { auto key = [](const ResEnt &m) { ret
  * --------------------------------------------------------------------------------------------- */
 struct HSeq { std::string name; std::vector<uint8_t> seq; std::string qual, comment; bool has_comment = false; bool circular = false; };     /* qual / comment: kept on request only (-Q, -T CO) */
 
-/* run fn(t, nth) on up to 16 host threads (reads / records are independent in every host stage that uses this) */
-template<typename F> static void host_parallel(uint32_t want, F fn)
+/* run fn(t, nth) on up to `cap` (default 16) host threads (reads / records are independent in every host stage that uses this) */
+template<typename F> static void host_parallel(uint32_t want, F fn, uint32_t cap = 16)
 {
-	const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 16)));
+	const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), cap)));
 	std::vector<std::thread> th;
 	for(uint32_t t = 1; t < nth; t++) th.emplace_back(fn, t, nth);
 	fn(0u, nth);
@@ -506,76 +506,130 @@ struct mm_idx_s {
 extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 {
 	mm_idx_t *mi = new mm_idx_s();
+	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
+	auto lap = [&](const char *what) { if(verbose) { double t = now_ms(); fprintf(stderr, "[minialign_amd] index: %s %.1f ms\n", what, t - tv); tv = t; } };
 	if(!read_seq_file(ref_fasta, mi->seq, o->min_len) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); delete mi; return NULL; }
+	lap("read + parse");
 	uint32_t b = std::min(o->k * 2, o->b);
 	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq;
 	if(o->circ_set) for(HSeq &q : mi->seq) q.circular = o->circ_names.empty() || std::find(o->circ_names.begin(), o->circ_names.end(), q.name) != o->circ_names.end();
 	const uint64_t nb = 1ull << b, bmask = nb - 1;
-	/* sketch every sequence and push (hrem, pos, rid) to its bucket in reference order (minialign.c:2790-2860) */
-	std::vector<std::vector<Mini>> bkt(nb);
+	/* sketch every sequence and put (hrem, pos, rid) into its bucket in reference order (minialign.c:2790-2860): stretches of the sequences are
+	 * sketched on host threads, a histogram per stretch turns into write positions (stretch order inside a bucket = reference order), and the
+	 * stretches scatter their minimizers in parallel into one flat array */
+	std::vector<Mini> flat; std::vector<uint64_t> bofs(nb + 1, 0);
 	{
 		struct Task { uint32_t seq, begin, end; std::vector<HMin> mins; };
-		std::vector<Task> task; const uint32_t chunk = 1u << 18;
+		uint64_t total_bases = 0; for(const HSeq &q : mi->seq) total_bases += q.seq.size();
+		std::vector<Task> task; const uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 18, total_bases / 2048), 1u << 24);
 		for(uint32_t i = 0; i < mi->seq.size(); i++) { const uint32_t L = (uint32_t)mi->seq[i].seq.size(); if(mi->seq[i].circular) { task.push_back(Task{ i, 0, L, {} }); continue; } for(uint32_t bgn = 0; bgn < L || bgn == 0; bgn += chunk) { task.push_back(Task{ i, bgn, std::min(L, bgn + chunk), {} }); if(L == 0) break; } }
+		std::vector<uint32_t> hist((size_t)task.size() * nb, 0);
 		host_parallel((uint32_t)task.size(), [&](uint32_t t, uint32_t nth) {
 			for(size_t j = t; j < task.size(); j += nth) {
 				Task &q = task[j]; const HSeq &sq = mi->seq[q.seq];
 				if(sq.circular) sketch_host_circular(sq.seq.data(), (uint32_t)sq.seq.size(), o->k, o->w, q.mins);
 				else sketch_host(sq.seq.data(), (uint32_t)sq.seq.size(), o->k, o->w, q.mins, q.begin, q.end);
+				uint32_t *h = &hist[j * nb]; for(const HMin &m : q.mins) h[m.hash & bmask]++;
 			}
-		});
-		for(Task &q : task) { for(const HMin &m : q.mins) bkt[m.hash & bmask].push_back(Mini{ m.hash >> b, m.pos, (q.seq << 1) + m.strand }); std::vector<HMin>().swap(q.mins); }
+		}, 64);
+		lap("sketch");
+		/* hist[j][bi] -> first write position of stretch j in bucket bi (row by row: the rows are contiguous) */
+		for(size_t j = 0; j < task.size(); j++) { const uint32_t *h = &hist[j * nb]; for(uint64_t bi = 0; bi < nb; bi++) bofs[bi + 1] += h[bi]; }
+		for(uint64_t bi = 0; bi < nb; bi++) bofs[bi + 1] += bofs[bi];
+		flat.resize(bofs[nb]);
+		std::vector<uint64_t> wpos((size_t)task.size() * nb);
+		{ std::vector<uint64_t> run(bofs.begin(), bofs.end() - 1); for(size_t j = 0; j < task.size(); j++) { const uint32_t *h = &hist[j * nb]; uint64_t *w = &wpos[j * nb]; for(uint64_t bi = 0; bi < nb; bi++) { w[bi] = run[bi]; run[bi] += h[bi]; } } }
+		lap("bucket offsets");
+		host_parallel((uint32_t)task.size(), [&](uint32_t t, uint32_t nth) {
+			for(size_t j = t; j < task.size(); j += nth) {
+				Task &q = task[j]; uint64_t *w = &wpos[j * nb];
+				for(const HMin &m : q.mins) flat[w[m.hash & bmask]++] = Mini{ m.hash >> b, m.pos, (q.seq << 1) + m.strand };
+				std::vector<HMin>().swap(q.mins);
+			}
+		}, 64);
 	}
+	lap("bucket scatter");
 	/* per-bucket sort on hrem + occurrence histogram (minialign.c:2867-2900); buckets are independent */
 	std::vector<uint32_t> cnt;
 	{
-		std::vector<std::vector<uint32_t>> pc(16);
-		host_parallel(16, [&](uint32_t t, uint32_t nth) {
+		std::vector<std::vector<uint32_t>> pc(64);
+		host_parallel(64, [&](uint32_t t, uint32_t nth) {
 			std::vector<uint32_t> &c = pc[t];
 			for(uint64_t bi = t; bi < nb; bi += nth) {
-				auto &v = bkt[bi];
-				if(v.empty()) continue;
-				sort_minis(v.data(), v.size());
+				Mini *v = flat.data() + bofs[bi]; const size_t vn = bofs[bi + 1] - bofs[bi];
+				if(vn == 0) continue;
+				sort_minis(v, vn);
 				uint32_t n = 1;
-				for(size_t j = 1; j < v.size(); j++) { if(v[j - 1].hrem != v[j].hrem) { c.push_back(n); n = 0; } n++; }
+				for(size_t j = 1; j < vn; j++) { if(v[j - 1].hrem != v[j].hrem) { c.push_back(n); n = 0; } n++; }
 				c.push_back(n);
 			}
-		});
+		}, 64);
 		for(auto &c : pc) cnt.insert(cnt.end(), c.begin(), c.end());
 	}
+	lap("bucket sort");
 	/* thresholds: (1 - frq)-quantile of the per-key counts, + 1 (minialign.c:2981-2986) */
-	std::vector<uint32_t> sorted(cnt); std::sort(sorted.begin(), sorted.end());
 	for(uint32_t i = 0; i < o->n_frq; i++) {
 		if(o->frq[i] <= 0.0) { mi->occ[i] = UINT32_MAX; continue; }
 		uint32_t kk = (uint32_t)((1.0 - o->frq[i]) * cnt.size());
-		mi->occ[i] = (cnt.empty() ? 0 : sorted[std::min<size_t>(kk, cnt.size() - 1)]) + 1;
+		if(cnt.empty()) { mi->occ[i] = 1; continue; }
+		auto nth_it = cnt.begin() + std::min<size_t>(kk, cnt.size() - 1);
+		std::nth_element(cnt.begin(), nth_it, cnt.end());            /* the k-th smallest count; the order of cnt itself carries no meaning */
+		mi->occ[i] = *nth_it + 1;
 	}
 	/* key -> value-list map (minialign.c:2905-2944).  The reference stops advancing its fill cursor at the first key of a
-	 * bucket that exceeds the last threshold, which silently drops every later key of that bucket: kept. */
+	 * bucket that exceeds the last threshold, which silently drops every later key of that bucket: kept.  Buckets are independent: keys and list
+	 * lengths are counted per bucket, a prefix sum gives every bucket its stretch of the value array, and the table is filled by threads that each
+	 * own a range of home slots (a key whose probe sequence would leave its owner's range waits for a serial pass), so the layout does not depend
+	 * on the number of threads or their timing. */
 	const uint64_t max_cnt = mi->occ[mi->n_occ - 1];
-	uint64_t n_keys = 0, n_multi_vals = 0;
-	for(auto &v : bkt) {
-		for(size_t j = 0; j < v.size();) { size_t e = j + 1; while(e < v.size() && v[e].hrem == v[j].hrem) e++; if(e - j > max_cnt) break; n_keys++; if(e - j > 1) n_multi_vals += e - j; j = e; }
-	}
-	uint64_t tsize = 1024; while(tsize < n_keys * 2) tsize <<= 1;
-	mi->slot.assign(tsize, IdxSlot{ 0, 0 }); mi->mask = tsize - 1; mi->val.reserve(n_multi_vals + 1); mi->n_keys = n_keys;
-	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
-	for(uint64_t bi = 0; bi < nb; bi++) {
-		auto &v = bkt[bi];
-		for(size_t j = 0; j < v.size();) {
-			size_t e = j + 1; while(e < v.size() && v[e].hrem == v[j].hrem) e++;
-			if(e - j > max_cnt) break;
-			uint64_t minier = (v[j].hrem << b) | bi, value;
-			if(e - j == 1) value = (uint64_t)v[j].pos | ((uint64_t)v[j].rid << 32);
-			else { value = (1ull << 63) | ((uint64_t)mi->val.size() << 24) | (uint64_t)(e - j); for(size_t x = j; x < e; x++) mi->val.push_back((uint64_t)v[x].pos | ((uint64_t)v[x].rid << 32)); }
-			uint64_t s = hash(minier) & mi->mask;
-			while(mi->slot[s].key != 0) s = (s + 1) & mi->mask;
-			mi->slot[s] = IdxSlot{ minier + 1, value };
-			j = e;
+	std::vector<uint64_t> bkeys(nb + 1, 0), bvals(nb + 1, 0);
+	host_parallel(64, [&](uint32_t t, uint32_t nth) {
+		for(uint64_t bi = t; bi < nb; bi += nth) {
+			const Mini *v = flat.data() + bofs[bi]; const size_t vn = bofs[bi + 1] - bofs[bi]; uint64_t nk = 0, nv = 0;
+			for(size_t j = 0; j < vn;) { size_t e = j + 1; while(e < vn && v[e].hrem == v[j].hrem) e++; if(e - j > max_cnt) break; nk++; if(e - j > 1) nv += e - j; j = e; }
+			bkeys[bi + 1] = nk; bvals[bi + 1] = nv;
 		}
-		std::vector<Mini>().swap(v);
+	}, 64);
+	for(uint64_t bi = 0; bi < nb; bi++) { bkeys[bi + 1] += bkeys[bi]; bvals[bi + 1] += bvals[bi]; }
+	const uint64_t n_keys = bkeys[nb], n_multi_vals = bvals[nb];
+	uint64_t tsize = 1024; while(tsize < n_keys * 2) tsize <<= 1;
+	mi->slot.assign(tsize, IdxSlot{ 0, 0 }); mi->mask = tsize - 1; mi->val.assign(std::max<uint64_t>(n_multi_vals, 1), 0); mi->n_keys = n_keys;
+	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
+	/* (key, value) records in bucket order, value lists written in place */
+	std::vector<IdxSlot> kv(n_keys);
+	host_parallel(64, [&](uint32_t t, uint32_t nth) {
+		for(uint64_t bi = t; bi < nb; bi += nth) {
+			const Mini *v = flat.data() + bofs[bi]; const size_t vn = bofs[bi + 1] - bofs[bi]; uint64_t ko = bkeys[bi], vo = bvals[bi];
+			for(size_t j = 0; j < vn;) {
+				size_t e = j + 1; while(e < vn && v[e].hrem == v[j].hrem) e++;
+				if(e - j > max_cnt) break;
+				uint64_t minier = (v[j].hrem << b) | bi, value;
+				if(e - j == 1) value = (uint64_t)v[j].pos | ((uint64_t)v[j].rid << 32);
+				else { value = (1ull << 63) | (vo << 24) | (uint64_t)(e - j); for(size_t x = j; x < e; x++) mi->val[vo++] = (uint64_t)v[x].pos | ((uint64_t)v[x].rid << 32); }
+				kv[ko++] = IdxSlot{ minier + 1, value };
+				j = e;
+			}
+		}
+	}, 64);
+	std::vector<Mini>().swap(flat);
+	{
+		const uint32_t parts = 64; const uint64_t span = tsize / parts;            /* tsize >= 1024: a power of two, divisible */
+		std::vector<std::vector<uint64_t>> late(parts);
+		host_parallel(parts, [&](uint32_t t, uint32_t nth) {
+			for(uint32_t pt = t; pt < parts; pt += nth) {
+				const uint64_t lo = pt * span, hi = lo + span;
+				for(uint64_t i = 0; i < n_keys; i++) {
+					uint64_t s0 = hash(kv[i].key - 1) & mi->mask;
+					if(s0 < lo || s0 >= hi) continue;
+					uint64_t sl = s0; while(sl < hi && mi->slot[sl].key != 0) sl++;
+					if(sl < hi) mi->slot[sl] = kv[i]; else late[pt].push_back(i);
+				}
+			}
+		}, 64);
+		for(auto &l : late) for(uint64_t i : l) { uint64_t sl = hash(kv[i].key - 1) & mi->mask; while(mi->slot[sl].key != 0) sl = (sl + 1) & mi->mask; mi->slot[sl] = kv[i]; }
 	}
 	if(mi->val.empty()) mi->val.push_back(0);
+	lap("thresholds + table");
 	return mi;
 }
 extern "C" void mm_idx_destroy(mm_idx_t *mi) { delete mi; }

@@ -10,7 +10,7 @@ t() { date +%s.%N; }
 t0=$(t); tools/gensim genome 4001 "$GL" "$NC" 0.05 > "$W/ref.fa"; tools/gensim reads 4002 "$W/ref.fa" "$DEPTH" pacbio fa 20000 2000 > "$W/rd.fa"; t1=$(t)
 echo "generate: $(awk "BEGIN{print $t1-$t0}") s; reads: $(grep -c '>' "$W/rd.fa")" | tee "$OUT/log.txt"
 t0=$(t); MM_VERBOSE=1 minialign_amd/minialign -xpacbio "$W/ref.fa" "$W/rd.fa" > "$W/ours.sam" 2> "$OUT/ours.err"; echo "ours rc=$? $(awk "BEGIN{print $(t)-$t0}") s" | tee -a "$OUT/log.txt"
-grep -E "main_align|M::main\]" "$OUT/ours.err" | tee -a "$OUT/log.txt"
+grep -E "main_align|M::main\]|index:" "$OUT/ours.err" | tee -a "$OUT/log.txt"
 t0=$(t); minialign_amd/minialign -xpacbio -d "$W/ours.mai" "$W/ref.fa" 2>> "$OUT/ours.err"; minialign_amd/minialign -xpacbio "$W/ours.mai" "$W/rd.fa" 2>> "$OUT/ours.err" | grep -v '^@PG' | md5sum | tee -a "$OUT/log.txt"; echo "ours via .mai $(awk "BEGIN{print $(t)-$t0}") s" | tee -a "$OUT/log.txt"; rm -f "$W/ours.mai"
 t0=$(t); oracle/_ref/minialign -xpacbio -t16 -d "$W/ref.mai" "$W/ref.fa" 2> "$OUT/ref.err"; echo "ref index rc=$? $(awk "BEGIN{print $(t)-$t0}") s" | tee -a "$OUT/log.txt"
 t0=$(t); oracle/_ref/minialign -xpacbio -t1 "$W/ref.mai" "$W/rd.fa" > "$W/ref.sam" 2>> "$OUT/ref.err"; echo "ref map -t1 rc=$? $(awk "BEGIN{print $(t)-$t0}") s" | tee -a "$OUT/log.txt"
