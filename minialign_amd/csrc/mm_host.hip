@@ -103,34 +103,80 @@ template<typename F> static void host_parallel(uint32_t want, F fn, uint32_t cap
 
 /* FASTA / FASTQ text; bases by the low-nibble table of minialign.c:223-229 (anything but ACGTUN -> A).  A record name runs to the first space;
  * a tab does not end it but is rewritten to a space (bseq_read_fasta copies through an escape while testing the raw bytes, minialign.c:1957-1968) */
-/* one FASTA stretch (starts at a '>' at the beginning of a line, holds whole records): lines by memchr, bases through the table */
-/* text after the name on a header line: tabs become spaces, spaces at the end go (bseq_read_fasta states 4-5, minialign.c:2030-2036) */
-static void keep_header_comment(HSeq &r, const char *l, size_t e, size_t n)
+/* The reader follows bseq_read_fasta (minialign.c:1996-2090) byte for byte, oddities included:
+ *   - the file type is the first '>' or '@' among the first four bytes (minialign.c:1784-1792); what stands in front of it is dropped
+ *   - name: spaces skipped, then up to the first space or end of line, tabs rewritten to spaces, one trailing CR dropped; a comment exists when the
+ *     name ended at a space: spaces skipped, to the end of the line, tabs to spaces, one CR and then the spaces at the end dropped
+ *   - bases: every byte of the following lines goes through the low-nibble table -- a CR too (it reads as A) -- until the record delimiter ('>' for
+ *     FASTA, '+' for FASTQ) shows up ANYWHERE in a line, or the text ends
+ *   - FASTQ: the rest of the '+' line is skipped, then quality lines are taken until their length reaches the number of bases (counted without a
+ *     trailing CR when the qualities are kept, with it when they are only skipped), newlines after that are skipped and the next byte must be '@' */
+/* header line at p (just behind the delimiter): fills name / comment, returns the first byte of the next line */
+static const char *parse_header(const char *p, const char *end, HSeq &r, bool keep_comment)
 {
-	if(e >= n) return;
-	size_t c = e + 1; while(c < n && l[c] == ' ') c++;
-	r.comment.assign(l + c, n - c); r.has_comment = true;
-	for(char &ch : r.comment) if(ch == '\t') ch = ' ';
-	while(!r.comment.empty() && r.comment.back() == ' ') r.comment.pop_back();
+	while(p < end && *p == ' ') p++;
+	const char *b0 = p; while(p < end && *p != ' ' && *p != '\n') p++;
+	size_t ln = (size_t)(p - b0); const bool has_comment = p < end && *p == ' ';
+	if(ln > 0 && b0[ln - 1] == '\r') ln--;
+	r.name.assign(b0, ln); for(char &ch : r.name) if(ch == '\t') ch = ' ';
+	if(p < end) p++;
+	if(has_comment) {
+		while(p < end && *p == ' ') p++;
+		const char *c0 = (const char *)p, *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
+		size_t cl = (size_t)(le - c0);
+		p = nl ? nl + 1 : end;
+		if(cl > 0 && c0[cl - 1] == '\r') cl--;
+		while(cl > 0 && c0[cl - 1] == ' ') cl--;
+		if(keep_comment) { r.comment.assign(c0, cl); r.has_comment = true; for(char &ch : r.comment) if(ch == '\t') ch = ' '; }
+	}
+	return p;
 }
+/* sequence lines at p up to the delimiter dv anywhere in a line (returns its position) or the end of the text */
+static const char *parse_bases(const char *p, const char *end, char dv, const uint8_t *enc, std::vector<uint8_t> &sq, bool &at_delim)
+{
+	at_delim = false;
+	while(p < end) {
+		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
+		const char *dl = (const char *)memchr(p, dv, (size_t)(le - p)); const char *stop = dl ? dl : le;
+		const size_t n = (size_t)(stop - p), o = sq.size();
+		if(n) { sq.resize(o + n); uint8_t *d = sq.data() + o; for(size_t i = 0; i < n; i++) d[i] = enc[p[i] & 15]; }
+		if(dl) { at_delim = true; return dl; }
+		p = nl ? nl + 1 : end;
+	}
+	return p;
+}
+/* one FASTA stretch (starts at a '>', holds whole records) */
 static void parse_fasta_span(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out, bool keep_comment)
 {
 	while(p < end) {
-		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
-		size_t n = (size_t)(le - p); while(n > 0 && p[n - 1] == '\r') n--;
-		if(n > 0) {
-			if(p[0] == '>') {
-				size_t q = 1; while(q < n && p[q] == ' ') q++;
-				size_t e = q; while(e < n && p[e] != ' ') e++;
-				out.emplace_back(); out.back().name.assign(p + q, e - q); for(char &ch : out.back().name) if(ch == '\t') ch = ' ';
-				if(keep_comment) keep_header_comment(out.back(), p, e, n);
-			} else if(!out.empty()) {
-				auto &sq = out.back().seq; const size_t o = sq.size(); sq.resize(o + n);
-				uint8_t *d = sq.data() + o; for(size_t i = 0; i < n; i++) d[i] = enc[p[i] & 15];
-			}
-		}
-		p = nl ? nl + 1 : end;
+		p++;                                         /* the '>' */
+		out.emplace_back(); HSeq &r = out.back();
+		p = parse_header(p, end, r, keep_comment);
+		bool at; p = parse_bases(p, end, '>', enc, r.seq, at);
 	}
+}
+/* FASTQ, in sequence; false when a record does not start with '@' where one must */
+static bool parse_fastq(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out, bool keep_qual, bool keep_comment)
+{
+	while(p < end) {
+		if(*p++ != '@') return false;
+		out.emplace_back(); HSeq &r = out.back();
+		p = parse_header(p, end, r, keep_comment);
+		bool at; p = parse_bases(p, end, '+', enc, r.seq, at);
+		if(!at) break;
+		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); p = nl ? nl + 1 : end;      /* the '+' line */
+		uint64_t acc = 0; const uint64_t lim = r.seq.size();
+		while(p < end) {
+			nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
+			size_t ll = (size_t)(le - p);
+			if(keep_qual) { size_t kl = ll; if(kl > 0 && p[kl - 1] == '\r') kl--; r.qual.append(p, kl); acc += kl; } else acc += ll;
+			p = le;
+			if(p >= end || acc >= lim) break;
+			p++;
+		}
+		while(p < end && *p == '\n') p++;
+	}
+	return true;
 }
 bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1, bool keep_qual = false, bool keep_comment = false)
 {
@@ -170,9 +216,11 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1,
 		if(!ok) { fprintf(stderr, "[minialign_amd] broken gzip stream in `%s'\n", fn); return false; }
 		raw.resize(out_len); data.swap(raw);
 	}
-	size_t first = 0; while(first < data.size() && (data[first] == '\n' || data[first] == '\r')) first++;
-	if(first < data.size() && data[first] == '>') {
-		/* FASTA: '>' at the beginning of a line can only start a record, so the file splits at such points and the pieces are
+	size_t first = 0; char delim = 0;
+	for(int i = 0; i < 4 && first < data.size(); i++) { if(data[first] == '>' || data[first] == '@') { delim = data[first]; break; } first++; }
+	if(!delim) { fprintf(stderr, "[minialign_amd] `%s' is neither FASTA nor FASTQ\n", fn); return false; }
+	if(delim == '>') {
+		/* FASTA: a '>' at the beginning of a line always starts a record, so the file splits at such points and the pieces are
 		 * parsed on host threads, each into its own list */
 		const char *base = data.data(), *end = base + data.size();
 		std::vector<std::vector<HSeq>> part;
@@ -192,28 +240,8 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1,
 		size_t tot = 0; for(auto &v : part) tot += v.size();
 		out.reserve(out.size() + tot);
 		for(auto &v : part) for(auto &r : v) out.emplace_back(std::move(r));
-	} else {
-	std::string line; line.reserve(1 << 16);
-	int state = 0; char delim = 0; uint64_t qneed = 0, qgot = 0;
-	auto handle = [&](const char *l, size_t n) {
-		while(n > 0 && (l[n - 1] == '\r')) n--;
-		if(state == 2) { if(keep_qual) out.back().qual.append(l, n); qgot += n; if(qgot >= qneed) state = 0; return; }
-		if(n == 0) return;
-		if(delim == 0 && (l[0] == '>' || l[0] == '@')) delim = l[0];
-		if(l[0] == delim && (state == 0 || delim == '>')) {
-			size_t p = 1; while(p < n && l[p] == ' ') p++;
-			size_t e = p; while(e < n && l[e] != ' ') e++;
-			out.emplace_back(); out.back().name.assign(l + p, e - p); for(char &ch : out.back().name) if(ch == '\t') ch = ' '; if(keep_comment) keep_header_comment(out.back(), l, e, n); state = 1; return;
-		}
-		if(state == 1 && delim == '@' && l[0] == '+') { state = 2; qneed = out.back().seq.size(); qgot = 0; if(qneed == 0) state = 0; return; }
-		if(state == 1) { auto &s = out.back().seq; size_t o = s.size(); s.resize(o + n); for(size_t i = 0; i < n; i++) s[o + i] = enc[l[i] & 15]; }
-	};
-	const char *p = data.data(), *end = p + data.size();
-	while(p < end) {
-		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
-		handle(p, (size_t)(le - p));
-		p = nl ? nl + 1 : end;
-	}
+	} else if(!parse_fastq(data.data() + first, data.data() + data.size(), enc, out, keep_qual, keep_comment)) {
+		fprintf(stderr, "[minialign_amd] `%s': broken FASTQ record\n", fn); return false;       /* the reference gives up on the run (exit 1) */
 	}
 	/* -L (default 1, minialign.c:2077, 6145): records shorter than the limit are dropped, reference and query side alike */
 	out.erase(std::remove_if(out.begin(), out.end(), [min_len](const HSeq &s) { return s.seq.size() < min_len; }), out.end());

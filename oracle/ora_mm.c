@@ -251,48 +251,83 @@ int om_opt_parse(om_opt_t *o, int argc, char const *const *argv, char const **fi
 /* ---- FASTA / FASTQ (bseq_read_fasta, minialign.c:1996-2090; encoding minialign.c:223-229) ---- */
 static uint8_t const encaf[16] = { [('A' & 0xf)] = 0, [('C' & 0xf)] = 1, [('G' & 0xf)] = 2, [('T' & 0xf)] = 3, [('U' & 0xf)] = 3, [('N' & 0xf)] = 4 };
 om_seqs_t om_read_fasta(char const *fn) { return om_read_fasta_ex(fn, 0, 0); }
+/* bseq_read_fasta as a walk over the whole text (minialign.c:1996-2090; the reference refills a buffer, which does not change what is read):
+ *   - the file type is the first '>' or '@' among the first four bytes (minialign.c:1784-1792); what stands in front of it is dropped
+ *   - name: spaces skipped, then up to the first space or end of line, tabs rewritten to spaces, one trailing CR dropped; a comment exists when
+ *     the name ended at a space: spaces skipped, to the end of the line, tabs to spaces, one CR and then the spaces at the end dropped
+ *   - bases: every byte of the following lines goes through the low-nibble table -- a CR too (it reads as A) -- until the record delimiter
+ *     ('>' for FASTA, '+' for FASTQ) shows up ANYWHERE in a line, or the text ends
+ *   - FASTQ: the rest of the '+' line is skipped, then quality lines are taken until their length reaches the number of bases (counted without
+ *     a trailing CR when the qualities are kept, with it when they are only skipped), newlines after that are skipped and the next byte must be '@'
+ * om_read_error is set when the text is not in this shape (the reference gives up on the whole run: exit 1, no output). */
+int om_read_error = 0;
 om_seqs_t om_read_fasta_ex(char const *fn, int keep_qual, int keep_comment)
 {
 	om_seqs_t r = { 0, 0 };
+	om_read_error = 0;
 	FILE *fp = fopen(fn, "r");
-	if(!fp) { return r; }
-	vec_t(om_seq_t) v = { 0, 0, 0 };
-	char *line = NULL; size_t cap = 0; ssize_t l;
-	int state = 0;          /* 0: expect header, 1: seq lines, 2: qual lines */
+	if(!fp) { om_read_error = 1; return r; }
+	size_t cap = 1 << 20, n = 0; char *d = (char *)malloc(cap + 1); size_t got;
+	while((got = fread(d + n, 1, cap - n, fp)) > 0) { n += got; if(n == cap) { cap *= 2; d = (char *)realloc(d, cap + 1); } }
+	fclose(fp);
+	char const *p = d, *t = d + n;
 	char delim = 0;
-	uint64_t scap = 0, qneed = 0, qgot = 0;
-	while((l = getline(&line, &cap, fp)) > 0) {
-		while(l > 0 && (line[l - 1] == '\n' || line[l - 1] == '\r')) { line[--l] = 0; }
-		if(state == 2) {
-			if(keep_qual) { om_seq_t *s = &v.a[v.n - 1]; s->qual = (char *)realloc(s->qual, qgot + (uint64_t)l + 1); memcpy(s->qual + qgot, line, (size_t)l); s->qual[qgot + (uint64_t)l] = 0; }
-			qgot += (uint64_t)l; if(qgot >= qneed) { state = 0; } continue;
+	for(int i = 0; i < 4 && p < t; i++) { char c = *p; if(c == '>' || c == '@') { delim = c; break; } p++; }
+	if(!delim) { free(d); om_read_error = 1; return r; }
+	char const dv = delim == '@' ? '+' : delim;
+	vec_t(om_seq_t) v = { 0, 0, 0 };
+	while(p < t) {
+		if(*p++ != delim) { om_read_error = 1; break; }
+		om_seq_t s; memset(&s, 0, sizeof(s));
+		while(p < t && *p == ' ') { p++; }
+		char const *b0 = p; while(p < t && *p != ' ' && *p != '\n') { p++; }
+		size_t ln = (size_t)(p - b0); int const has_comment = p < t && *p == ' ';
+		if(ln > 0 && b0[ln - 1] == '\r') { ln--; }
+		s.l_name = (uint32_t)ln; s.name = strndup(b0, ln);
+		for(size_t i = 0; i < ln; i++) { if(s.name[i] == '\t') { s.name[i] = ' '; } }
+		if(p < t) { p++; }
+		if(has_comment) {
+			while(p < t && *p == ' ') { p++; }
+			char const *c0 = p; while(p < t && *p != '\n') { p++; }
+			size_t cl = (size_t)(p - c0);
+			if(p < t) { p++; }
+			if(cl > 0 && c0[cl - 1] == '\r') { cl--; }
+			while(cl > 0 && c0[cl - 1] == ' ') { cl--; }
+			if(keep_comment) { s.comment = strndup(c0, cl); for(size_t i = 0; i < cl; i++) { if(s.comment[i] == '\t') { s.comment[i] = ' '; } } }
 		}
-		if(delim == 0 && (line[0] == '>' || line[0] == '@')) { delim = line[0]; }
-		if(state != 2 && line[0] == delim && (state == 0 || delim == '>' || 1) && (state == 0 || delim == '>')) {
-			om_seq_t s; memset(&s, 0, sizeof(s));
-			/* the name runs to the first space (a tab does not end it: tabs are rewritten to spaces as the text is copied, the delimiter test
-			 * sees the raw bytes; bseq_read_fasta states 2-3 and _readline, minialign.c:1957-1968, 2024-2029) */
-			char *p = line + 1; while(*p == ' ') { p++; }
-			char *e = p; while(*e && *e != ' ') { e++; }
-			s.l_name = (uint32_t)(e - p); s.name = strndup(p, s.l_name);
-			for(uint32_t i = 0; i < s.l_name; i++) { if(s.name[i] == '\t') { s.name[i] = ' '; } }
-			if(keep_comment && *e) {
-				char *c = e + 1; while(*c == ' ') { c++; }
-				size_t cl = strlen(c); s.comment = strndup(c, cl);
-				for(size_t i = 0; i < cl; i++) { if(s.comment[i] == '\t') { s.comment[i] = ' '; } }
-				while(cl > 0 && s.comment[cl - 1] == ' ') { s.comment[--cl] = 0; }
+		/* bases */
+		uint64_t scap = 256; s.seq = (uint8_t *)malloc(scap);
+		int at_delim = 0;
+		while(p < t) {
+			char const *l0 = p; while(p < t && *p != '\n' && *p != dv) { p++; }
+			uint64_t ll = (uint64_t)(p - l0);
+			if(s.l_seq + ll + 1 > scap) { scap = (s.l_seq + ll + 1) * 2; s.seq = (uint8_t *)realloc(s.seq, scap); }
+			for(uint64_t i = 0; i < ll; i++) { s.seq[s.l_seq++] = encaf[l0[i] & 0x0f]; }
+			if(p < t && *p == dv) { at_delim = 1; break; }
+			if(p < t) { p++; }
+		}
+		if(delim == '@' && at_delim) {
+			while(p < t && *p != '\n') { p++; }          /* the '+' line */
+			if(p < t) { p++; }
+			uint64_t acc = 0, lim = s.l_seq, ql = 0;
+			if(keep_qual) { s.qual = (char *)malloc(lim + 2); }
+			while(p < t) {
+				char const *l0 = p; while(p < t && *p != '\n') { p++; }
+				uint64_t ll = (uint64_t)(p - l0);
+				if(keep_qual) {
+					uint64_t kl = ll; if(kl > 0 && l0[kl - 1] == '\r') { kl--; }
+					s.qual = (char *)realloc(s.qual, ql + kl + 2); memcpy(s.qual + ql, l0, kl); ql += kl; acc += kl;
+				} else { acc += ll; }
+				if(p >= t) { break; }
+				if(acc >= lim) { break; }
+				p++;
 			}
-			vec_push(om_seq_t, v, s); scap = 0; state = 1;
-			continue;
+			if(keep_qual) { s.qual[ql] = 0; }
+			while(p < t && *p == '\n') { p++; }
 		}
-		if(state == 1 && delim == '@' && line[0] == '+') { state = 2; qneed = v.a[v.n - 1].l_seq; qgot = 0; if(qneed == 0) { state = 0; } continue; }
-		if(state == 1) {
-			om_seq_t *s = &v.a[v.n - 1];
-			if(s->l_seq + (uint64_t)l + 1 > scap) { scap = (s->l_seq + (uint64_t)l + 1) * 2; s->seq = (uint8_t *)realloc(s->seq, scap); }
-			for(ssize_t i = 0; i < l; i++) { s->seq[s->l_seq++] = encaf[line[i] & 0x0f]; }
-		}
+		vec_push(om_seq_t, v, s);
 	}
-	free(line); fclose(fp);
+	free(d);
 	r.a = v.a; r.n = v.n;
 	om_seqs_drop_short(&r, 1);       /* -L 1, the default (minialign.c:6145) */
 	return r;
@@ -1420,6 +1455,8 @@ int om_main_files(om_opt_t const *op, char const *const *files, int nf, FILE *ou
 		if(o.format == 0) { om_sam_header(out, &o, ref.a, (uint32_t)ref.n); }          /* only SAM has a header (minialign.c:5666-5671) */
 		for(int q = qh; q < nf; q++) {
 			om_seqs_t qs = om_read_fasta_ex(files[q], (int)o.keep_qual, (int)(((o.flag | o.tags) >> OM_CO) & 1)); om_seqs_drop_short(&qs, o.min_len);
+			/* a query file that is not in shape ends the run with exit 1 (the reference drops the block it was reading: nothing of this file is printed here) */
+			if(om_read_error) { om_seqs_free(&qs); om_align_free(al); om_idx_free(mi); om_seqs_free(&ref); return 4; }
 			for(uint64_t i = 0; i < qs.n; i++) {
 				double t1 = now_s();
 				om_reg_t *reg = om_align_seq(al, qs.a[i].l_seq, qs.a[i].seq);

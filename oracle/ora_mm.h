@@ -52,6 +52,7 @@ typedef struct {
 typedef struct { om_seq_t *a; uint64_t n; } om_seqs_t;
 om_seqs_t om_read_fasta(char const *fn);        /* FASTA / FASTQ, plain text (bseq_read_fasta, minialign.c:1996) */
 om_seqs_t om_read_fasta_ex(char const *fn, int keep_qual, int keep_comment);
+extern int om_read_error;      /* set by the readers when the text is not FASTA / FASTQ as bseq_read_fasta accepts it */
 void om_seqs_drop_short(om_seqs_t *s, uint32_t min_len);    /* the -L filter of the reader (minialign.c:2077) */
 void om_seqs_free(om_seqs_t *s);
 

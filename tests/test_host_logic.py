@@ -172,3 +172,35 @@ def test_host_index_of_circular_references_matches_oracle(tmp_path):
                 n_wrap += sum(1 for v in want if (v & 0xffffffff) + 15 > len(q) and (v >> 33) == [n for n, _ in refseq].index(name))
         assert n_wrap > 0
         L.mm_idx_destroy(mi); L.mm_opt_destroy(o)
+
+
+def test_reader_matches_oracle_on_oddly_formatted_files(tmp_path):
+    """FASTA / FASTQ reader (bseq_read_fasta): wrapped lines, CRLF (a CR in a sequence line reads as a base), lower case, IUPAC letters, blank lines, no final
+    newline, tabs and spaces in headers, empty records, a delimiter in the middle of a sequence line, FASTQ with '@' qualities / wrapped / short qualities.
+    The product reads each file through `minialign -d` (host only); names and bases must equal the oracle reader's, which is pinned on the compiled
+    reference's output for the same files (tests/golden/parse_cases.json.gz, tests/test_oracle_mm.py)."""
+    import struct, subprocess, sys, numpy as np, mmlib as M
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from make_parse_golden import make_parse_inputs
+    _, files = make_parse_inputs(str(tmp_path))
+    OL = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'liboracle.so'))
+    class Seqs(ctypes.Structure): _fields_ = [('a', ctypes.POINTER(M.OmSeq)), ('n', ctypes.c_uint64)]
+    OL.om_read_fasta_ex.restype = Seqs
+    cli = os.path.join(ROOT, 'minialign_amd', 'minialign')
+    n_err = 0
+    for name, path in files.items():
+        want = OL.om_read_fasta_ex(path.encode(), 0, 0)
+        err = ctypes.c_int.in_dll(OL, 'om_read_error').value
+        recs = [(want.a[i].name[:want.a[i].l_name], bytes(ctypes.string_at(want.a[i].seq, want.a[i].l_seq))) for i in range(want.n)]
+        mai = str(tmp_path / (name + '.mai'))
+        r = subprocess.run([cli, '-xpacbio', '-d', mai, path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        if err or not recs:
+            assert r.returncode == 1, name; n_err += bool(err); continue
+        assert r.returncode == 0, (name, r.stderr.decode())
+        blob = open(mai, 'rb').read(); off = 4 + 4 * 12 + 8 * 4; got = []
+        n_seq = struct.unpack_from('<Q', blob, 4 + 4 * 12)[0]
+        for _ in range(n_seq):
+            ln, ls, _c = struct.unpack_from('<QQQ', blob, off); off += 24
+            got.append((blob[off:off + ln], blob[off + ln:off + ln + ls])); off += ln + ls
+        assert got == recs, name
+    assert n_err >= 1

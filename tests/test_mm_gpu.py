@@ -174,3 +174,16 @@ def test_circular_references_match_reference_golden(name, opts, workdir):
     assert subprocess.run([CLI] + opts + ['-d', mai, ref], stderr=subprocess.DEVNULL).returncode == 0
     r = subprocess.run([CLI] + [o for o in opts if not o.startswith('-c') and o != 'plasmid'] + [mai, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and _strip_pg(r.stdout) == want
+
+
+def test_oddly_formatted_read_files_match_reference_golden(workdir):
+    """wrapped / CRLF / lower-case / IUPAC / blank lines / missing final newline / tabs in headers / empty records / a delimiter inside a sequence line /
+    FASTQ variants, read with -Q -T CO: records as the compiled reference prints them; where the reference gives up (exit 1 after the header), so does this"""
+    import json
+    from golden.make_parse_golden import make_parse_inputs, OPTS
+    gold = json.loads(gzip.open(os.path.join(HERE, 'golden', 'parse_cases.json.gz')).read())
+    ref, files = make_parse_inputs(workdir)
+    for name, p in files.items():
+        r = subprocess.run([CLI] + OPTS + [ref, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert (r.returncode != 0) == (gold[name][0] != 0), (name, r.stderr.decode()[-500:])
+        assert _strip_pg(r.stdout).decode('latin1') == gold[name][1], name

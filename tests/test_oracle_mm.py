@@ -113,3 +113,16 @@ def test_oracle_circular_references_match_reference_golden(name, opts, workdir):
     got = strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
     want = gzip.open(os.path.join(HERE, 'golden', 'circ_%s.sam.gz' % name)).read()
     assert got == want
+
+
+def test_oracle_reader_matches_reference_on_oddly_formatted_files(workdir):
+    """the reader's view of oddly formatted FASTA / FASTQ read files (names, bases, qualities, comments of the -- mostly unmapped -- records, and the runs
+    the reference gives up on): golden output of the compiled reference (tests/golden/make_parse_golden.py)"""
+    import gzip, json
+    from golden.make_parse_golden import make_parse_inputs, strip_pg, OPTS
+    gold = json.loads(gzip.open(os.path.join(HERE, 'golden', 'parse_cases.json.gz')).read())
+    ref, files = make_parse_inputs(workdir)
+    for name, p in files.items():
+        r = subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + OPTS + [ref, p], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=60)
+        assert (r.returncode != 0) == (gold[name][0] != 0), name
+        assert strip_pg(r.stdout).decode('latin1') == gold[name][1], name
