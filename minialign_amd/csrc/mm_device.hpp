@@ -850,6 +850,7 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
  * K3: extension driver, one wavefront per read
  * ===================================================================================================== */
 struct KhSlot { uint64_t k, v; };
+#define MM_NEXT_SCRATCH 1024u          /* u64 words behind each wave's next[] array: 512 bucket words + 512 pending ranges for radix_sort_64 */
 struct AlnRec {                /* what the host needs of a gaba_alignment_t (gaba.h:205-220) */
 	int64_t score; double identity;
 	uint32_t agcnt, bgcnt, dcnt, slen, plen;
@@ -1000,7 +1001,8 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 	for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	Kh kh; kh.cap = a.kh_cap;
-	uint64_t *next = a.next_pool + (uint64_t)wave * a.next_cap;
+	uint64_t *next = a.next_pool + (uint64_t)wave * (a.next_cap + MM_NEXT_SCRATCH);      /* [next_cap entries][radix-sort scratch] */
+	uint32_t *next_scratch = (uint32_t *)(next + a.next_cap);
 	const DevIndex &ix = a.idx;
 	unsigned long long n_fill = 0, n_trace = 0;
 	unsigned long long cy_fill = 0, cy_leaf = 0, cy_trace = 0;        /* wave cycles spent in the three DP phases (s_memtime) */
@@ -1121,8 +1123,8 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 								rcnt--;
 							}
 							sid_out = (uint32_t)sid;
-							/* radix_sort_64x: arrays here are far below the 64-element insertion-sort threshold in practice */
-							if(ncnt <= 64) { ins_sort_64((U64R *)next, (U64R *)next + ncnt); } else { err |= ERR_NEXT_CAP; ins_sort_64((U64R *)next, (U64R *)next + ncnt); }
+							/* radix_sort_64x (minialign.c:3932): mostly below the 64-element insertion-sort threshold, the radix passes for the rest */
+							if(!radix_sort_64((U64R *)next, ncnt, next_scratch, 2 * MM_NEXT_SCRATCH)) { err |= ERR_STACK; }
 						}
 						__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 						ncnt = (uint32_t)rdfirst((int)ncnt); sr.sid = (uint32_t)rdfirst((int)sid_out); err = (uint32_t)rdfirst((int)err);

@@ -1216,7 +1216,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
 	ok &= a->resc_pool.ensure(bases / 2 + 64ull * n_reads + 1024);
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
-	ok &= a->next_pool.ensure((uint64_t)a->n_waves * a->next_cap);
+	ok &= a->next_pool.ensure((uint64_t)a->n_waves * (a->next_cap + MM_NEXT_SCRATCH));
 	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap);
 	ok &= a->aln_pool.ensure(((uint64_t)n_reads + 2048) * a->aln_cap);
 	ok &= a->seg_pool.ensure((uint64_t)n_reads * a->aln_cap * 2 + 4096);
@@ -1386,7 +1386,7 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 		std::vector<uint32_t> redo, redo_rlen;
 		uint32_t cur = a->rlen_carry;
 		for(uint32_t i = 0; i < n_reads; i++) {
-			if(hst[i].err) overflow = true;
+			if(hst[i].err) { if(!overflow && getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   read %u (%u bases) reports err 0x%x: seed_n %u n_seed %u seed_cap %u n_root %u\n", i, b.lens[i], hst[i].err, hst[i].seed_n, hst[i].n_seed, hst[i].seed_cap, hst[i].n_root); overflow = true; }
 			uint32_t truth = cur;
 			if(truth != used[i] && hst[i].apos0 != gaba::NIL && !hst[i].cond0 && ((hst[i].apos0 >= used[i]) != (hst[i].apos0 >= truth))) { redo.push_back(i); redo_rlen.push_back(truth); }
 			cur = hst[i].rid_last != gaba::NIL ? (uint32_t)a->mi->seq[hst[i].rid_last].seq.size() : truth;

@@ -81,3 +81,28 @@ def test_full_size_properties_and_sample_parity():
                 for line in f:
                     if not line.startswith(b'@PG'): h_got.update(line)
             assert h_got.hexdigest() == h_ref, 'full-size SAM differs from the compiled reference'
+
+
+@pytest.mark.parametrize('gseed,rseed,glen,contigs,rep,depth,preset,prof', [
+    (1, 2, 4641652, 1, 0.05, 100.0, 'pacbio', 'pacbio'),        # a read of this set keeps more than 64 candidate seeds in mm_search_load_next (radix passes of its sort)
+    (11, 12, 12000000, 16, 0.20, 20.0, 'pacbio', 'pacbio'),     # repeat-rich, several contigs
+    (21, 22, 4641652, 1, 0.05, 40.0, 'ont.1dsq', 'ont'),
+])
+def test_more_full_size_sets_against_the_compiled_reference(gseed, rseed, glen, contigs, rep, depth, preset, prof):
+    """whole SAM (md5) of further full-size read sets against oracle/_ref/minialign -t1; skipped where the compiled reference did not travel"""
+    import hashlib
+    refbin = os.path.join(M.ROOT, 'oracle', '_ref', 'minialign')
+    if not os.path.exists(refbin): pytest.skip('oracle/_ref not built')
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
+        M.gensim('genome', gseed, glen, contigs, rep, out=ref)
+        M.gensim('reads', rseed, ref, depth, prof, 'fa', 20000, 2000, out=rd)
+        def digest(cmd):
+            h = hashlib.md5(); n = 0; p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            for line in p.stdout:
+                if not line.startswith(b'@PG'): h.update(line); n += 1
+            assert p.wait() == 0, cmd
+            return h.hexdigest(), n
+        got = digest([os.path.join(M.ROOT, 'minialign_amd', 'minialign'), '-x' + preset, ref, rd])
+        want = digest([refbin, '-x' + preset, '-t1', ref, rd])
+        assert got == want
