@@ -91,8 +91,8 @@ inline void sort_res(ResEnt *p, size_t n) { auto key = [](const ResEnt &m) { ret
  * --------------------------------------------------------------------------------------------- */
 struct HSeq { std::string name; std::vector<uint8_t> seq; std::string qual, comment; bool has_comment = false; bool circular = false; };     /* qual / comment: kept on request only (-Q, -T CO) */
 
-/* run fn(t, nth) on up to `cap` (default 16) host threads (reads / records are independent in every host stage that uses this) */
-template<typename F> static void host_parallel(uint32_t want, F fn, uint32_t cap = 16)
+/* run fn(t, nth) on up to `cap` (default 32) host threads (reads / records are independent in every host stage that uses this) */
+template<typename F> static void host_parallel(uint32_t want, F fn, uint32_t cap = 32)
 {
 	const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), cap)));
 	std::vector<std::thread> th;
@@ -226,7 +226,7 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1,
 		std::vector<std::vector<HSeq>> part;
 		std::vector<const char *> cut;
 		{
-			const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 16), (uint32_t)(data.size() >> 20) + 1));
+			const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 32), (uint32_t)(data.size() >> 20) + 1));
 			cut.push_back(base + first);
 			for(uint32_t t = 1; t < nth; t++) {
 				const char *q = base + data.size() * t / nth;
@@ -747,6 +747,7 @@ struct mm_align_s {
 	hipStream_t stream; hipEvent_t ev0, ev1;
 	hipStream_t k2s[12]; hipEvent_t k2e[12]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
+	uint32_t qlen_hint = 0;                                    /* longest read of the input being mapped, when known (mm_align_file) */
 	uint32_t k3_waves = 0; uint64_t slab_stride = 0;      /* extension kernel: persistent waves actually launched and the DP workspace of each */
 	/* pools */
 	DBuf<uint32_t> q_pk, q_nm; DBuf<ReadIn> d_in; DBuf<ReadState> d_st; DBuf<uint32_t> d_work;
@@ -1222,6 +1223,8 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	ok &= a->seg_pool.ensure((uint64_t)n_reads * a->aln_cap * 2 + 4096);
 	ok &= a->path_pool.ensure((bases / 4 + 1024ull * n_reads) * scale + (1ull << 20));
 	/* DP workspace: a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors */
+	/* re-allocating tens of GB costs seconds: size for the longest read of the whole input when the caller knows it (qlen_hint), in steps of 8 k bases */
+	max_qlen = (std::max(max_qlen, a->qlen_hint) + 8191u) & ~8191u;
 	uint64_t blocks = 2 * ((2ull * max_qlen + 8192) / 32 + 64);
 	uint64_t slab = (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull;
 	/* the workspace is per persistent wave and grows with the longest read of the batch (5 MB for 27 kb): with very long reads fewer waves
@@ -1457,7 +1460,7 @@ bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piec
 	/* post-map and SAM text are per read and independent: host threads take contiguous spans, the pieces are joined in input
 	 * order (mm_align_drain keeps the same order with its heap, minialign.c:4633-4645) */
 	{
-		const uint32_t want = a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 16);      /* -t sets it; default: up to 16 */
+		const uint32_t want = a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 32);      /* -t sets it; default: up to 32 */
 		const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(1, n_reads / 64)));
 		std::vector<std::string> piece(nth);
 		auto span = [&](uint32_t t) {
@@ -1534,7 +1537,7 @@ static mm_align_t *align_lane(mm_align_t *a)
 	mm_align_t *q = new mm_align_s();
 	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off; q->d_seq_circ = a->d_seq_circ;
 	q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
-	q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
+	q->qlen_hint = a->qlen_hint; q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
 	if(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess) { delete q; return NULL; }
 	for(int i = 0; i < 12; i++) { if(hipStreamCreateWithFlags(&q->k2s[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&q->k2e[i], hipEventDisableTiming) != hipSuccess) { delete q; return NULL; } }
 	q->k2s_ok = true;
@@ -1621,6 +1624,7 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 	const uint64_t max_bases = getenv("MM_BATCH_BASES") ? (uint64_t)atoll(getenv("MM_BATCH_BASES")) : (512ull << 20);      /* env: test hook (many small batches) */
 	const uint32_t max_reads = 1u << 17;
 	const uint32_t n = mm_reads_count(reads);
+	{ uint32_t mx = 0; for(const HSeq &q : reads->r) mx = std::max<uint32_t>(mx, (uint32_t)q.seq.size()); for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, mx); a->qlen_hint = std::max(a->qlen_hint, mx); }
 	struct Slot { mm_batch_t *h = nullptr; bool ready = false, busy = false; };
 	Slot slot[2];
 	std::mutex mu; std::condition_variable cv;
@@ -1736,9 +1740,15 @@ extern "C" int mm_main(int argc, char **argv)
 			else if(!prebuilt && (int)micnt < n_ref) { fprintf(stderr, "[E::main_align] failed to build index for `%s'. Please check file path and format.\n", files[micnt]); rc = 1; }
 			break;
 		}
+		const bool vb = getenv("MM_VERBOSE") != NULL; double tq = now_ms();
+		auto lapm = [&](const char *w) { if(vb) { double t = now_ms(); fprintf(stderr, "[minialign_amd] main: %s %.1f ms (at %.3f s)\n", w, t - tq, (t - t0) * 1e-3); tq = t; } };
+		lapm("index");
 		if(!joined) hw.join();
+		lapm("wait for the HIP runtime");
 		mm_align_t *a = mm_align_init(o, mi);
+		lapm("device context");
 		if(!joined) { rt.join(); joined = true; }
+		lapm("wait for the read parser");
 		if(!a) { fprintf(stderr, "[E::main_align] failed to instanciate alignment context.\n"); mm_idx_destroy(mi); rc = 1; break; }
 		fprintf(stderr, "[M::main_align::%.3f] loaded/built index for %u target sequence(s).\n", (now_ms() - t0) * 1e-3, mm_idx_n_seq(mi));
 		if(o->format == 0) mm_print_sam_header(a, stdout, o->arg_line.c_str());        /* only SAM has a header (minialign.c:5666-5671) */
