@@ -951,7 +951,7 @@ struct Trace {
 	bool oob;
 	/* this lane's mask words of the current block, and the 4 words of lane q (uniform) */
 	uint32_t lm[4];
-	uint32_t qh, qv, qe, qf; uint32_t qcur; uint32_t blk_loaded;
+	uint32_t qh, qv, qe, qf; uint64_t qcur; uint32_t blk_loaded;      /* qcur: the q the four words were read for; ~0ull = none (q itself can be 0xffffffff: a walk that left the band at its lower edge) */
 	uint32_t pw; uint64_t pw_idx;   /* path word being assembled (uniform) */
 };
 
@@ -960,13 +960,13 @@ __device__ __forceinline__ void trace_load_block(Ctx &x, Trace &t)
 	const Blk *b = blk_at(x, t.blk);
 	int l = x.lane;
 	t.lm[0] = b->m[0][l]; t.lm[1] = b->m[1][l]; t.lm[2] = b->m[2][l]; t.lm[3] = b->m[3][l];
-	t.blk_loaded = t.blk; t.qcur = 0xffffffffu;
+	t.blk_loaded = t.blk; t.qcur = ~0ull;
 }
 /* (mask->x.all >> q) & 1 with the x86 shift-count masking of the reference's word size (gaba.c:2931-2951) */
 __device__ __forceinline__ void trace_sel_q(Trace &t)
 {
-	if(t.qcur == t.q) { return; }
-	t.qcur = t.q;
+	if(t.qcur == (uint64_t)t.q) { return; }
+	t.qcur = (uint64_t)t.q;
 	uint32_t ql = (t.W == 64) ? (t.q & 63) : (t.q & 31);
 	bool dead = ql >= (uint32_t)t.W;
 	t.qh = dead ? 0 : (uint32_t)rdlane((int)t.lm[0], (int)ql); t.qv = dead ? 0 : (uint32_t)rdlane((int)t.lm[1], (int)ql);
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 		default: return;
 	}
 	if(t.blk_loaded != blk) { t.blk = blk; trace_load_block(x, t); }
-	uint32_t qsel = 0xffffffffu, qh = 0, qv = 0, qe = 0, qf = 0;
+	uint64_t qsel = ~0ull; uint32_t qh = 0, qv = 0, qe = 0, qf = 0;    /* qsel: the q the cached mask words belong to; ~0ull = none (q can be 0xffffffff when the walk has left the band) */
 	TPROF_DECL();
 	/* one-block look-behind: mask columns and trailer of the block at pf_off (loads are issued here, waited for at first use) */
 	uint32_t pf_off = NIL, pf_m0 = 0, pf_m1 = 0, pf_m2 = 0, pf_m3 = 0; uint4 pf_s = make_uint4(0, 0, 0, 0);
@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 			}
 			const int ac = (int)(int8_t)(w0 >> 16), bc = (int)(int8_t)(w0 >> 24);
 			p = ac + bc - 1; dir = dm >> (BLK - (ac + bc));
-			blk = nb; t.blk = nb; t.lm[0] = pf_m0; t.lm[1] = pf_m1; t.lm[2] = pf_m2; t.lm[3] = pf_m3; t.blk_loaded = nb; qsel = 0xffffffffu;
+			blk = nb; t.blk = nb; t.lm[0] = pf_m0; t.lm[1] = pf_m1; t.lm[2] = pf_m2; t.lm[3] = pf_m3; t.blk_loaded = nb; qsel = ~0ull;
 			if(nb >= 2 * (uint32_t)sizeof(Blk)) { TR_PREFETCH(nb - (uint32_t)sizeof(Blk)); }
 			bool can_bulk = !(W > g0 - ac) && !(W > g1 - bc);             /* _trace_test_bulk (gaba.c:3035-3046) */
 			if(bulk) {
@@ -1153,7 +1153,7 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 				dir = n == 16 ? 0u : dir >> (2 * n);
 				p -= (int32_t)(2 * n); n_pop += 2 * n;
 				if(!bulk) { g0 -= (int32_t)n; g1 -= (int32_t)n; }
-				qsel = 0xffffffffu;
+				qsel = ~0ull;
 			}
 			TPROF_ADD(1);
 			/* nothing moved and nothing found: the cell in front is clean (h and, from the tail, v are both clear) but no whole
@@ -1209,15 +1209,15 @@ __device__ __forceinline__ void trace_core(Ctx &x, Trace &t, Leaf &lf)
 				dir = m >= 32 ? 0u : dir >> m;
 				p -= (int32_t)m; n_pop += m;
 				if(!bulk) { if(isv) { g1 -= (int32_t)m; } else { g0 -= (int32_t)m; } }
-				qsel = 0xffffffffu;
+				qsel = ~0ull;
 				TPROF_ADD(2);
 				continue;
 			}
 		}
 		TPROF_T0();
-		if(qsel != q) {
+		if(qsel != (uint64_t)q) {
 			/* (mask >> q) & 1 with the x86 shift-count masking of the reference's word size (gaba.c:2931-2951) */
-			qsel = q; uint32_t ql = (W == 64) ? (q & 63) : (q & 31); bool dead = ql >= (uint32_t)W;
+			qsel = (uint64_t)q; uint32_t ql = (W == 64) ? (q & 63) : (q & 31); bool dead = ql >= (uint32_t)W;
 			qh = dead ? 0u : (uint32_t)rdlane((int)t.lm[0], (int)ql); qv = dead ? 0u : (uint32_t)rdlane((int)t.lm[1], (int)ql);
 			qe = dead ? 0u : (uint32_t)rdlane((int)t.lm[2], (int)ql); qf = dead ? 0u : (uint32_t)rdlane((int)t.lm[3], (int)ql);
 		}
@@ -1328,7 +1328,7 @@ __device__ __forceinline__ AlnOut dp_trace_finish(Ctx &x, uint32_t tail_off, Lea
 	Trace t;
 	t.W = rdfirst(tail->W); t.model = c.model; t.path = path; t.ppos = plen;
 	t.blk_loaded = NIL; t.pw_idx = plen >> 5; t.pw = 1u << (plen & 31);            /* sentinel bit (gaba.c:3288) */
-	t.blk = NIL; t.p = 0; t.q = 0; t.save = 0; t.dir_mask = 0; t.bulk = false; t.oob = false; t.qcur = 0xffffffffu;
+	t.blk = NIL; t.p = 0; t.q = 0; t.save = 0; t.dir_mask = 0; t.bulk = false; t.oob = false; t.qcur = ~0ull;
 	uint32_t slen = 0;
 	while(t.ppos > 0) {
 		if(lf.gidx[0] < (int32_t)((lf.state & TS_H) != 0)) { trace_reload_section(x, lf, 0); }

@@ -809,6 +809,7 @@ static int trace_pop(tr_t *t, int is_v)
 	t->dir_mask >>= 1;
 	t->p--;
 	if(t->p >= 0) { return 0; }
+	if(getenv("OG_DEBUG_TRACE")) { fprintf(stderr, "blk ppos %lu q %d bulk %d g %d %d save %u\n", (unsigned long)t->ppos, (int)t->q, t->bulk, t->gidx[0], t->gidx[1], t->save); }
 	if(t->bulk) {
 		trace_reload(t);
 		if(!trace_test_bulk(t)) {
@@ -927,6 +928,7 @@ og_alignment_t *og_dp_trace(og_dp_t *dp, og_fill_t const *fill)
 		if(dp->l.gidx[0] < (int32_t)((dp->l.state & TS_H) != 0)) { trace_reload_section(dp, 0); }
 		if(dp->l.gidx[1] < (int32_t)((dp->l.state & TS_V) != 0)) { trace_reload_section(dp, 1); }
 		trace_core(dp, &t);
+		if(getenv("OG_DEBUG_TRACE")) { fprintf(stderr, "tc ppos %lu q %u state %u gidx %d %d\n", (unsigned long)t.ppos, dp->l.q, dp->l.state, dp->l.gidx[0], dp->l.gidx[1]); }
 		if(dp->l.q >= (uint32_t)t.W) {                                /* out of band: abort, gaba.c:3324 */
 			free(aln->path - 2); free(segbuf); free(aln);
 			return NULL;

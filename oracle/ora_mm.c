@@ -1009,6 +1009,7 @@ static uint64_t mm_search_record(om_align_t *self, search_t *st, og_alignment_t 
 		if(b0 != a) { self->bin.a[nid] = handle; }
 		*h = *t = (uint64_t)st->eid | ((uint64_t)nid << 32);
 	}
+	if(getenv("OM_DEBUG_REC")) { fprintf(stderr, "rec eid %u iid %u aid %u p %u %u %u %u score %ld plen %u new %u n_bin %u kh %u/%u\n", st->eid, st->iid, st->aid, p[0], p[1], p[2], p[3], (long)a->score, (uint32_t)a->plen, (uint32_t)new, (uint32_t)self->bin.n - (uint32_t)new, self->pos.cnt, self->pos.mask); }
 	st->srem = MM_SREM; st->narrow = 0;
 	{
 		float cand = (float)a->score * self->min_ratio, cur = (float)st->min_score;
@@ -1052,7 +1053,8 @@ static uint64_t mm_extend(om_align_t *self)
 			f = mm_extend_core(self, (int)st.narrow, &self->r[1], self->rtp + 1, &self->q[1 - st.rev], &self->t[0], up);
 			og_alignment_t *a = NULL;
 			if(getenv("OM_DEBUG")) fprintf(stderr, "  up max %ld (from %u,%u)\n", f->max, up.apos, up.bpos);
-			if(f->max < (int64_t)self->min_score || (a = og_dp_trace(self->dp, f)) == NULL) { continue; }
+			if(getenv("OM_DEBUG_REC")) { fprintf(stderr, "up eid %u max %ld tp %u %u\n", st.eid, (long)f->max, st.tp.apos, st.tp.bpos); }
+			if(f->max < (int64_t)self->min_score || (a = og_dp_trace(self->dp, f)) == NULL) { if(getenv("OM_DEBUG_REC")) { fprintf(stderr, "  rejected (%s)\n", f->max < (int64_t)self->min_score ? "score" : "trace"); } continue; }
 			self->cnt[4]++;
 			if(mm_search_record(self, &st, a)) { break; }
 		}

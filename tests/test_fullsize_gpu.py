@@ -87,6 +87,7 @@ def test_full_size_properties_and_sample_parity():
     (1, 2, 4641652, 1, 0.05, 100.0, 'pacbio', 'pacbio'),        # a read of this set keeps more than 64 candidate seeds in mm_search_load_next (radix passes of its sort)
     (11, 12, 12000000, 16, 0.20, 20.0, 'pacbio', 'pacbio'),     # repeat-rich, several contigs
     (21, 22, 4641652, 1, 0.05, 40.0, 'ont.1dsq', 'ont'),
+    (114, 115, 2000000, 6, 0.25, 25.0, 'ava', 'pacbio'),        # linear gaps, many weak hits per read; one traceback leaves the band
 ])
 def test_more_full_size_sets_against_the_compiled_reference(gseed, rseed, glen, contigs, rep, depth, preset, prof):
     """whole SAM (md5) of further full-size read sets against oracle/_ref/minialign -t1; skipped where the compiled reference did not travel"""
@@ -96,7 +97,7 @@ def test_more_full_size_sets_against_the_compiled_reference(gseed, rseed, glen, 
     with tempfile.TemporaryDirectory() as d:
         ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
         M.gensim('genome', gseed, glen, contigs, rep, out=ref)
-        M.gensim('reads', rseed, ref, depth, prof, 'fa', 20000, 2000, out=rd)
+        M.gensim('reads', rseed, ref, depth, prof, 'fa', *((15000, 4000) if preset == 'ava' else (20000, 2000)), out=rd)
         def digest(cmd):
             h = hashlib.md5(); n = 0; p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
             for line in p.stdout:

@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 def _diff(x, y):
     return [k for k in y if x.get(k) != y[k]]
 
-@pytest.mark.parametrize("name,P", [("pacbio", G.PACBIO), ("ont1dsq", G.ONT1DSQ), ("affine", G.AFFINE_DEFAULT)])
+@pytest.mark.parametrize("name,P", [("pacbio", G.PACBIO), ("ont1dsq", G.ONT1DSQ), ("affine", G.AFFINE_DEFAULT), ("linear", G.LINEAR_AVA)])
 def test_extend_batch_matches_oracle(name, P):
     hip = G.Hip(**P); ora = G.Oracle(**P)
-    jobs = G.random_jobs(1234, 300)
+    jobs = G.random_jobs(1234, 300) + (G.random_jobs(4321, 300, max_len=12000) if name == "linear" else [])       # gi = 0: ties everywhere, the traceback's tie-breaks matter
     got = hip.extend_batch(jobs)
     bad = []
     for i, j in enumerate(jobs):

@@ -187,3 +187,19 @@ def test_oddly_formatted_read_files_match_reference_golden(workdir):
         r = subprocess.run([CLI] + OPTS + [ref, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         assert (r.returncode != 0) == (gold[name][0] != 0), (name, r.stderr.decode()[-500:])
         assert _strip_pg(r.stdout).decode('latin1') == gold[name][1], name
+
+
+def test_traceback_that_leaves_the_band_is_dropped_like_the_reference(workdir):
+    """-xava on a read whose weak secondary hits drift out of the band: one of the up-extensions walks back across the lower band edge (q = -1, masks read
+    with the wrapped lane as the reference's shifts do) and never returns -- the reference drops it (gaba_dp_trace NULL, gaba.c:3324).  Regression: the
+    cached mask words used 0xffffffff as their "none" mark, which is also q = -1."""
+    ref = os.path.join(workdir, 'oob.ref.fa'); rd = os.path.join(workdir, 'oob.reads.fa'); one = os.path.join(workdir, 'oob.one.fa')
+    M.gensim('genome', 114, 2000000, 6, 0.25, out=ref); M.gensim('reads', 115, ref, 25, 'pacbio', 'fa', 15000, 4000, out=rd)
+    keep = False
+    with open(rd, 'rb') as f, open(one, 'wb') as g:
+        for line in f:
+            if line.startswith(b'>'): keep = line.startswith(b'>r519_') or line.startswith(b'>r52')
+            if keep: g.write(line)
+    got = _run(CLI, 'ava', ref, one)
+    want = _run(os.path.join(M.ROOT, 'oracle', 'ora_minialign'), 'ava', ref, one)
+    assert got == want, _first_diff(got, want)
