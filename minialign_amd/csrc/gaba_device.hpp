@@ -117,6 +117,10 @@ __device__ __forceinline__ int shift_dn(int v, int fill) { return __builtin_amdg
 __device__ __forceinline__ uint32_t fetch_code(const SeqArena *ar, const Sec &s, uint32_t i)
 {
 	if(s.arena == 2) { return 4; }
+	/* past the end of the section: an extension may start a few bases beyond a sequence (a seed at the wrap of a circular reference; minialign.c:3823-3827
+	 * only pulls the position back by k).  The reference then reads the zero bytes that terminate / pad its copy of the sequence: A, or T through the
+	 * complement of a mirrored section. */
+	if(i >= s.len) { return s.rev ? 3u : 0u; }
 	uint64_t p = s.off + (s.rev ? (uint64_t)(s.len - 1 - i) : (uint64_t)i);
 	/* constant indices only: `ar` is a two-element local array of the caller, a variable index would keep it in scratch memory and
 	 * put a dependent scratch load in front of every sequence fetch (two HBM-latency round trips per block instead of one) */

@@ -915,6 +915,9 @@ __device__ inline bool kh_extend(Kh &h)
 __device__ inline uint64_t kh_put(Kh &h, uint64_t key, bool extend, uint32_t *err)
 {
 	if(extend && h.cnt >= h.ub) { if(!kh_extend(h)) { *err |= ERR_KH_CAP; } }
+	/* the table cannot grow any further in its slot of the pool: the read is given up here (the host enlarges the slots and runs the batch again);
+	 * inserting on would fill the table and the probe loop would never find a free slot */
+	if((*err & ERR_KH_CAP) || h.cnt + 2 >= h.mask) { *err |= ERR_KH_CAP; return 0; }
 	uint32_t nw; uint64_t idx = kh_allocate(h.a, key, ~0ull, h.mask, &nw);
 	h.cnt += nw;
 	return idx;
@@ -1182,6 +1185,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 							kh.a[ti].v = (uint64_t)sr.eid | (0xffffffffull << 32);
 						}
 						prev = rdfirst64(prev); err = (uint32_t)rdfirst((int)err);
+						if(err & ERR_KH_CAP) { skip = true; break; }
 						int32_t pa = max(1, min((int32_t)pp.apos, (int32_t)rlen)), pb = max(1, min((int32_t)pp.bpos, (int32_t)qlen));
 						sr.tp_a = (uint32_t)pa; sr.tp_b = (uint32_t)pb;
 						if(prev != ~0ull) {
@@ -1192,6 +1196,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 					}
 				}
 				if(x.err) { err |= ERR_DP_SLAB; break; }
+				if(err & ERR_KH_CAP) { break; }
 				if(skip) { continue; }
 				/* trace into the output pools */
 				if(n_aln >= a.aln_cap_per_read) { err |= ERR_ALN_CAP; break; }
@@ -1262,7 +1267,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 				if(!(isnew && sr.prem > 0)) { break; }
 			}
-			if(err & (ERR_DP_SLAB | ERR_PATH_CAP | ERR_ALN_CAP | ERR_SEG_CAP)) { break; }
+			if(err & (ERR_DP_SLAB | ERR_PATH_CAP | ERR_ALN_CAP | ERR_SEG_CAP | ERR_KH_CAP)) { break; }
 			/* mm_finish_root (minialign.c:3795-3813) */
 			{
 				uint32_t *hdr = (uint32_t *)&bin[sr.iid];

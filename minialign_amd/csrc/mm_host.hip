@@ -832,6 +832,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				ka.lds_bytes = bytes ? bytes : 1536 * 4;
 				ka.n_hi = ci == 0 ? 0xffffffffu : bytes;                    /* classes are cut by k2a_bytes() of the read */
 				ka.n_lo = ci == 0 ? bytes_of(1) : (ci >= n_cls - 1 ? 0u : bytes_of(cls_div[ci + 1]));
+				if(getenv("MM_K2_FORCE_HBM")) { if(ci == 0) { ka.n_lo = 0; } else if(ci < n_cls) { ka.n_hi = 0; ka.n_lo = 0; } }       /* test hook: every read through the in-HBM path */
 				ka.counter = a->d_k2cnt.p + ci;
 				const uint32_t per_cu = div ? div : 8;
 				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / (4 * MM_K3_WAVES_PER_SIMD)) * per_cu);

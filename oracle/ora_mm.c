@@ -260,6 +260,7 @@ om_seqs_t om_read_fasta(char const *fn) { return om_read_fasta_ex(fn, 0, 0); }
  *   - FASTQ: the rest of the '+' line is skipped, then quality lines are taken until their length reaches the number of bases (counted without
  *     a trailing CR when the qualities are kept, with it when they are only skipped), newlines after that are skipped and the next byte must be '@'
  * om_read_error is set when the text is not in this shape (the reference gives up on the whole run: exit 1, no output). */
+#define OM_SEQ_MARGIN 4096
 int om_read_error = 0;
 om_seqs_t om_read_fasta_ex(char const *fn, int keep_qual, int keep_comment)
 {
@@ -306,6 +307,10 @@ om_seqs_t om_read_fasta_ex(char const *fn, int keep_qual, int keep_comment)
 			if(p < t && *p == dv) { at_delim = 1; break; }
 			if(p < t) { p++; }
 		}
+		{	/* zero margins on both sides: an extension may start a few bases past the end of a sequence (a seed at the wrap of a circular reference,
+			 * minialign.c:3823-3827 only pulls it back by k) and the reference then reads the terminators / margins around its copy of the sequence */
+			uint8_t *m = (uint8_t *)calloc(1, (size_t)s.l_seq + 2 * OM_SEQ_MARGIN); memcpy(m + OM_SEQ_MARGIN, s.seq, s.l_seq); free(s.seq); s.seq = m + OM_SEQ_MARGIN;
+		}
 		if(delim == '@' && at_delim) {
 			while(p < t && *p != '\n') { p++; }          /* the '+' line */
 			if(p < t) { p++; }
@@ -335,12 +340,12 @@ om_seqs_t om_read_fasta_ex(char const *fn, int keep_qual, int keep_comment)
 void om_seqs_drop_short(om_seqs_t *s, uint32_t min_len)       /* sequences shorter than min_len are squashed by the reader (minialign.c:2077) */
 {
 	uint64_t j = 0;
-	for(uint64_t i = 0; i < s->n; i++) { if(s->a[i].l_seq >= min_len) { s->a[j++] = s->a[i]; } else { free(s->a[i].name); free(s->a[i].seq); free(s->a[i].qual); free(s->a[i].comment); } }
+	for(uint64_t i = 0; i < s->n; i++) { if(s->a[i].l_seq >= min_len) { s->a[j++] = s->a[i]; } else { free(s->a[i].name); free(s->a[i].seq - OM_SEQ_MARGIN); free(s->a[i].qual); free(s->a[i].comment); } }
 	s->n = j;
 }
 void om_seqs_free(om_seqs_t *s)
 {
-	for(uint64_t i = 0; i < s->n; i++) { free(s->a[i].name); free(s->a[i].seq); free(s->a[i].qual); free(s->a[i].comment); }
+	for(uint64_t i = 0; i < s->n; i++) { free(s->a[i].name); free(s->a[i].seq - OM_SEQ_MARGIN); free(s->a[i].qual); free(s->a[i].comment); }
 	free(s->a); s->a = NULL; s->n = 0;
 }
 
