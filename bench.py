@@ -86,7 +86,7 @@ def pmc_traffic(args, world):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=3); ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=6); ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--depth', type=float, default=100.0, help='read depth over the 4.64 Mb reference (x100 = BASELINE configs[1])')
     ap.add_argument('--genome-len', type=int, default=GENOME_LEN, help='length of the synthetic reference (default workload: E.coli MG1655, 4 641 652)')
     ap.add_argument('--contigs', type=int, default=1, help='number of contigs of the synthetic reference (default workload: 1)')
