@@ -15,8 +15,9 @@ for ((i=0; i<N; i++)); do
 	set -- ${shapes[$((i % ${#shapes[@]}))]}; glen=$1; nc=$2; rep=$3; prof=$4; lm=$5; ls=$6; depth=$7; shift 7; opts="$*"
 	seed=$((S0 + 2 * i))
 	tools/gensim genome $seed $glen $nc $rep > "$W/ref.fa"
-	if [ "$prof" = ont ]; then tools/gensim reads $((seed + 1)) "$W/ref.fa" $depth ont fa > "$W/rd.fa"; else tools/gensim reads $((seed + 1)) "$W/ref.fa" $depth $prof fa $lm $ls > "$W/rd.fa"; fi
-	timeout 300 minialign_amd/minialign $opts "$W/ref.fa" "$W/rd.fa" > "$W/o.sam" 2> "$W/o.err"; arc=$?
+	fmt=fa; [ -n "$SOAK_FQ" ] && { fmt=fq; case "$opts" in *-O*) ;; *) opts="$opts -Q -TAS,NM,MD,XS,NH";; esac; }       # SOAK_FQ=1: FASTQ input, qualities kept, tags printed
+	if [ "$prof" = ont ]; then tools/gensim reads $((seed + 1)) "$W/ref.fa" $depth ont $fmt > "$W/rd.fa"; else tools/gensim reads $((seed + 1)) "$W/ref.fa" $depth $prof $fmt $lm $ls > "$W/rd.fa"; fi
+	timeout 300 env $SOAK_ENV minialign_amd/minialign $opts "$W/ref.fa" "$W/rd.fa" > "$W/o.sam" 2> "$W/o.err"; arc=$?     # SOAK_ENV: e.g. MM_BATCH_BASES=20000000 for many small batches on two lanes
 	timeout 600 oracle/_ref/minialign $opts -t1 "$W/ref.fa" "$W/rd.fa" > "$W/r.sam" 2> /dev/null; brc=$?
 	a=$(grep -v '^@PG' "$W/o.sam" | md5sum | cut -c1-16); b=$(grep -v '^@PG' "$W/r.sam" | md5sum | cut -c1-16)
 	st=ok
@@ -26,7 +27,7 @@ for ((i=0; i<N; i++)); do
 		a2=$(grep -v '^@PG' "$W/o.sam" | head -n "$n" | md5sum | cut -c1-16); b=$(grep -v '^@PG' "$W/r.sam" | head -n "$n" | md5sum | cut -c1-16)
 		if [ "$a2" = "$b" ] && [ "$arc" = 0 ]; then st="ok(reference died with rc=$brc after $n lines, identical up to there)"; else st=DIFF; bad=$((bad + 1)); fi
 	elif [ "$a" != "$b" ] || [ "$arc" != 0 ]; then st=DIFF; bad=$((bad + 1)); tail -3 "$W/o.err" >> "$OUT/soak.txt"; fi
-	echo "$st seed=$seed genome=$glen/$nc/$rep reads=$prof/$lm/$ls x$depth ($(grep -c '>' "$W/rd.fa") reads) opts='$opts' ours=$a(rc=$arc) ref=$b $(grep 're-run' "$W/o.err" | sed 's/.*kernels/kernels/' | cut -c1-90)" | tee -a "$OUT/soak.txt"
+	echo "$st seed=$seed genome=$glen/$nc/$rep reads=$prof/$lm/$ls x$depth ($(grep -c '^[>@]r' "$W/rd.fa") reads) opts='$opts' ours=$a(rc=$arc) ref=$b $(grep 're-run' "$W/o.err" | sed 's/.*kernels/kernels/' | cut -c1-90)" | tee -a "$OUT/soak.txt"
 done
 echo "mismatches: $bad of $N" | tee -a "$OUT/soak.txt"
 rm -rf "$W"
