@@ -77,7 +77,7 @@ def cpu_baseline(ref_fa, reads_fa, workdir, budget_reads):
 
 def pmc_traffic(args, world):
     """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes (same workload only), else None"""
-    fn = os.path.join(ROOT, 'profiles', 'round1_e_pmc.json')
+    fn = os.path.join(ROOT, 'profiles', 'round1_j_pmc.json')          # tools/pmc_traffic.sh on the code as it stands
     if world != 1 or args.depth != 100.0 or args.repeat_frac != 0.05 or args.genome_len != GENOME_LEN or args.contigs != 1 or not os.path.exists(fn): return None
     try:
         with open(fn) as f: return json.load(f)['mm_extend_kernel_per_launch']['hbm_bytes']
@@ -190,7 +190,7 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args, world),
                          'alg_bytes_per_launch': alg_bytes, 'avg_launch_ms': k3_launch_ms,
-                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4): traffic = PMC bytes per launch from profiles/round1_e_pmc.json'},
+                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4): traffic = PMC bytes per launch from profiles/round1_j_pmc.json'},
         }
         if world == 1:
             out['cpu_baseline'] = cpu_baseline(ref_fa, reads_fa, work, 4000)
