@@ -901,7 +901,11 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.tglen = a->tglen; k3.mcoef = a->mcoef; k3.min_ratio = a->o.min_ratio; k3.min_score = a->o.min_score;
 		k3.counter = (uint32_t *)(tops + 16); k3.stats = tops + 8;
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
-		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* leave wave slots to the other lanes' kernels */
+		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
+		/* several batches in flight (lanes): 5 persistent waves per SIMD keep the integer VALU as busy as 8 do (a wave issues at most every 4th cycle, about two
+		 * thirds of its instructions are VALU) and leave wave slots for the sketch and sort + chain kernels of the other lanes, which otherwise wait for the
+		 * tail of this launch: +4 % on the bench workload with 3 in flight (4.33 against 4.15 G bases/s), -10 % for a launch running alone */
+		else if(a->is_sib || a->sib) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u); }
 		CK(hipEventRecord(a->ev0, a->stream));
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k3);
 		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
@@ -1231,7 +1235,8 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	/* the workspace is per persistent wave and grows with the longest read of the batch (5 MB for 27 kb): with very long reads fewer waves
 	 * are launched rather than more than `budget` of HBM taken per lane (MM_SLAB_GB, default 48) */
 	const uint64_t budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 48ull) << 30;
-	uint32_t kw = (uint32_t)std::min<uint64_t>(a->n_waves, std::max<uint64_t>(256, budget / slab)) & ~3u;
+	const uint32_t lane_waves = a->is_sib ? (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u : a->n_waves;      /* lanes other than the first never launch more (run_rounds) */
+	uint32_t kw = (uint32_t)std::min<uint64_t>(lane_waves, std::max<uint64_t>(256, budget / slab)) & ~3u;
 	if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
 	else { ok &= a->slabs.ensure(slab * kw); if(ok) { a->slab_stride = a->slabs.n / kw; a->k3_waves = kw; } }
 	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(16);
