@@ -371,41 +371,37 @@ int opt_line(mm_opt_t *o, const char *s)
 	}
 	return 0;
 }
-int opt_preset(mm_opt_t *o, const char *name)     /* preset tree, minialign.c:5853-5878 */
-{
-	std::string n(name); std::vector<std::string> parts; size_t st_ = 0;
-	for(size_t i = 0; i <= n.size(); i++) if(i == n.size() || n[i] == '.' || n[i] == ':') { parts.push_back(n.substr(st_, i - st_)); st_ = i + 1; }
-	if(parts.empty()) return 1;
-	if(parts[0] == "pacbio") {
-		opt_line(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3");
-		if(parts.size() > 1) { if(parts[1] == "ccs") opt_line(o, "-b5 -p6 -p2"); else if(parts[1] != "clr") return 1; }
-		return 0;
-	}
-	if(parts[0] == "ont") {
-		opt_line(o, "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3");
-		for(size_t i = 1; i < parts.size(); i++) {
-			const std::string &q = parts[i];
-			if(q == "r7") opt_line(o, "-b4");
-			else if(q == "r9" || q == "1") {}
-			else if(q == "4" || q == "5") opt_line(o, "-a2");
-			else if(q == "1d" || q == "2d" || q == "1dsq") {
-				bool under_r = i > 1;              /* leaves directly under "ont" also set -a2 */
-				if(q == "1d") { if(!under_r) opt_line(o, "-a2"); }
-				else { opt_line(o, under_r ? "-b6 -r4,4" : "-a2 -b6 -r4,4"); }
-			} else return 1;
-		}
-		return 0;
-	}
-	if(parts[0] == "ava") { opt_line(o, "-k15 -w5 -a2 -b3 -p0 -q2 -Y50 -s30 -m0.05"); return 0; }
-	return 1;
-}
-/* the option handlers of minialign.c:5990-6099 with their range checks; a failed check is an error (the reference counts it and exits 1) */
-bool opt_fail(const char *msg) { fprintf(stderr, "[E::mm_opt_parse] %s\n", msg); return true; }
 template<typename F> void split_each(const char *arg, const char *delims, F fn)          /* mm_split_foreach */
 {
 	int i = 0;
 	for(const char *p = arg; ; ) { const char *e = p; while(*e && !strchr(delims, *e)) e++; if(e > p) fn(i++, std::string(p, e)); if(!*e) break; p = e + 1; }
 }
+/* the preset tree of minialign.c:5853-5878 as data: each name applies its option line, then the next name is looked up among its children
+ * (mm_opt_preset, minialign.c:5880-5889); a name that is not there is an error (the reference then tries to read it as a configuration file) */
+struct PresetNode { const char *key, *val; const PresetNode *kids; };
+#define PN_END { nullptr, nullptr, nullptr }
+const PresetNode pn_leaf_r7[] = { { "1d", "", nullptr }, { "2d", "", nullptr }, PN_END };
+const PresetNode pn_leaf_1[] = { { "1d", "", nullptr }, { "1dsq", "-b6 -r4,4", nullptr }, { "2d", "-b6 -r4,4", nullptr }, PN_END };
+const PresetNode pn_r9_45[] = { { "1", "", pn_leaf_1 }, { "1d", "", nullptr }, { "1dsq", "-b6 -r4,4", nullptr }, { "2d", "-b6 -r4,4", nullptr }, PN_END };
+const PresetNode pn_r9[] = { { "4", "-a2", pn_r9_45 }, { "5", "-a2", pn_r9_45 }, { "1d", "", nullptr }, { "1dsq", "-b6 -r4,4", nullptr }, { "2d", "-b6 -r4,4", nullptr }, PN_END };
+const PresetNode pn_ont[] = { { "r7", "-b4", pn_leaf_r7 }, { "r9", "", pn_r9 }, { "1d", "-a2", nullptr }, { "1dsq", "-a2 -b6 -r4,4", nullptr }, { "2d", "-a2 -b6 -r4,4", nullptr }, PN_END };
+const PresetNode pn_pacbio[] = { { "clr", "", nullptr }, { "ccs", "-b5 -p6 -p2", nullptr }, PN_END };
+const PresetNode pn_root[] = { { "pacbio", "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3", pn_pacbio }, { "ont", "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3", pn_ont },
+	{ "ava", "-k15 -w5 -a2 -b3 -p0 -q2 -Y50 -s30 -m0.05", nullptr }, PN_END };
+int opt_preset(mm_opt_t *o, const char *name)
+{
+	const PresetNode *c = pn_root; int rc = 0; bool any = false;
+	split_each(name, ".:", [&](int, const std::string &t) {
+		if(rc) return;
+		const PresetNode *q = c; while(q && q->key && t != q->key) q++;
+		if(!q || !q->key) { rc = 1; return; }
+		if(opt_line(o, q->val)) { rc = 1; return; }
+		c = q->kids; any = true;
+	});
+	return rc || !any;
+}
+/* the option handlers of minialign.c:5990-6099 with their range checks; a failed check is an error (the reference counts it and exits 1) */
+bool opt_fail(const char *msg) { fprintf(stderr, "[E::mm_opt_parse] %s\n", msg); return true; }
 int opt_one(mm_opt_t *o, char c, const char *arg)
 {
 	auto base_of = [](char ch) -> int { switch(ch) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': case 'U': return 4; default: return 0; } };     /* idxaf, minialign.c:232 */

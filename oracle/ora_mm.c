@@ -197,20 +197,30 @@ static void opt_defaults(om_opt_t *o)
 	for(int i = 0; i < 16; i++) { o->p.score_matrix[i] = (i & 3) == (i >> 2) ? 1 : -1; }
 	o->p.gi = 1; o->p.ge = 1; o->p.gfa = 0; o->p.gfb = 0; o->p.xdrop = 50;
 }
+/* preset tree, minialign.c:5853-5878: each name applies its line, the next name is looked up among its children (mm_opt_preset, :5880-5889) */
+typedef struct preset_s { char const *key, *val; struct preset_s const *kids; } preset_t;
+static preset_t const pt_r7[] = { { "1d", "", 0 }, { "2d", "", 0 }, { 0, 0, 0 } };
+static preset_t const pt_1[] = { { "1d", "", 0 }, { "1dsq", "-b6 -r4,4", 0 }, { "2d", "-b6 -r4,4", 0 }, { 0, 0, 0 } };
+static preset_t const pt_45[] = { { "1", "", pt_1 }, { "1d", "", 0 }, { "1dsq", "-b6 -r4,4", 0 }, { "2d", "-b6 -r4,4", 0 }, { 0, 0, 0 } };
+static preset_t const pt_r9[] = { { "4", "-a2", pt_45 }, { "5", "-a2", pt_45 }, { "1d", "", 0 }, { "1dsq", "-b6 -r4,4", 0 }, { "2d", "-b6 -r4,4", 0 }, { 0, 0, 0 } };
+static preset_t const pt_ont[] = { { "r7", "-b4", pt_r7 }, { "r9", "", pt_r9 }, { "1d", "-a2", 0 }, { "1dsq", "-a2 -b6 -r4,4", 0 }, { "2d", "-a2 -b6 -r4,4", 0 }, { 0, 0, 0 } };
+static preset_t const pt_pacbio[] = { { "clr", "", 0 }, { "ccs", "-b5 -p6 -p2", 0 }, { 0, 0, 0 } };
+static preset_t const pt_root[] = { { "pacbio", "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3", pt_pacbio }, { "ont", "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3", pt_ont },
+	{ "ava", "-k15 -w5 -a2 -b3 -p0 -q2 -Y50 -s30 -m0.05", 0 }, { 0, 0, 0 } };
 static int opt_preset(om_opt_t *o, char const *preset)
 {
-	/* preset tree, minialign.c:5853-5878 (the paths used by BASELINE's configs) */
-	int rc = 0;
-	if(strcmp(preset, "pacbio") == 0 || strcmp(preset, "pacbio.clr") == 0) { opt_apply(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3"); }
-	else if(strcmp(preset, "pacbio.ccs") == 0) { opt_apply(o, "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3"); opt_apply(o, "-b5 -p6 -p2"); }
-	else if(strncmp(preset, "ont", 3) == 0) {
-		opt_apply(o, "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3");
-		if(strcmp(preset, "ont.1d") == 0) { opt_apply(o, "-a2"); }
-		else if(strcmp(preset, "ont.1dsq") == 0 || strcmp(preset, "ont.2d") == 0) { opt_apply(o, "-a2 -b6 -r4,4"); }
-		else if(strcmp(preset, "ont") != 0) { rc = 1; }
-	} else if(strcmp(preset, "ava") == 0) { opt_apply(o, "-k15 -w5 -a2 -b3 -p0 -q2 -Y50 -s30 -m0.05"); }      /* linear gaps (gi = 0), minialign.c:5879 */
-	else { rc = 1; }
-	return rc;
+	preset_t const *c = pt_root; int any = 0;
+	for(char const *p = preset; *p; ) {
+		char const *e = p; while(*e && *e != '.' && *e != ':') { e++; }
+		if(e > p) {
+			preset_t const *q = c; while(q && q->key && !(strlen(q->key) == (size_t)(e - p) && strncmp(q->key, p, (size_t)(e - p)) == 0)) { q++; }
+			if(!q || !q->key) { return 1; }
+			if(opt_apply(o, q->val)) { return 1; }
+			c = q->kids; any = 1;
+		}
+		if(!*e) { break; } p = e + 1;
+	}
+	return !any;
 }
 static int opt_check(om_opt_t *o)           /* mm_opt_check_sanity, minialign.c:6097-6112 */
 {
