@@ -1213,10 +1213,11 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	bool ok = true;
 	ok &= a->d_in.ensure(n_reads); ok &= a->d_st.ensure(n_reads); ok &= a->d_work.ensure(n_reads);
 	ok &= a->q_pk.ensure(bases / 16 + 8); ok &= a->q_nm.ensure(bases / 32 + 8);
-	ok &= a->min_pool.ensure(bases / 2 + 64ull * n_reads + 1024);
+	const uint64_t min_total = (a->mi->w < 4 ? bases : bases / 2) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
+	ok &= a->min_pool.ensure(min_total);
 	ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
 	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
-	ok &= a->resc_pool.ensure(bases / 2 + 64ull * n_reads + 1024);
+	ok &= a->resc_pool.ensure(min_total);
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
 	ok &= a->next_pool.ensure((uint64_t)a->n_waves * (a->next_cap + MM_NEXT_SCRATCH));
 	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap);
@@ -1354,7 +1355,8 @@ bool batch_upload(mm_align_t *a, Batch &b)
 	uint64_t moff = 0;
 	for(uint32_t i = 0; i < b.n; i++) {
 		memset(&b.hst[i], 0, sizeof(ReadState));
-		b.hst[i].min_off = moff; b.hst[i].min_cap = b.lens[i] / 2 + 64; moff += b.hst[i].min_cap;
+		/* minimizers of a read: at most one per position; 2 / (w + 1) per base on average, so half the length is ample from w = 4 up */
+		b.hst[i].min_off = moff; b.hst[i].min_cap = (a->mi->w < 4 ? b.lens[i] : b.lens[i] / 2) + 64; moff += b.hst[i].min_cap;
 		b.hst[i].bin_off = ~0ull; b.hst[i].apos0 = gaba::NIL; b.hst[i].rid_last = gaba::NIL; b.hst[i].pred_rid = gaba::NIL;
 		/* unmappable reads are skipped outright (minialign.c:4434) */
 		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
