@@ -65,6 +65,14 @@ void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line);
 int mm_align_batch(mm_align_t *a, uint8_t const *bases, uint32_t const *lens, char const *const *names, uint32_t n_reads,
 	char **sam, uint64_t *sam_len);
 
+/* structured results, as mm_align_seq hands them to its caller (minialign.c:4427; mm_aln_t :3260, mm_reg_t :3264): aln[0 .. n_uniq) are the primary and
+ * supplementary alignments, aln[n_uniq .. n_all) the secondary ones; mapq is the 16x fixed-point value (>> 4 for SAM); each mm_aln_t is directly followed by
+ * its gaba_alignment_t (gaba.h).  regs[i] = NULL for an unmapped read; every non-NULL entry is one block to be released with mm_reg_free. */
+typedef struct { uint32_t aid, mapq; gaba_alignment_t a[]; } mm_aln_t;
+typedef struct mm_reg_s { uint32_t n_all, n_uniq; mm_aln_t const *aln[]; } mm_reg_t;
+int mm_align_batch_regs(mm_align_t *a, uint8_t const *bases, uint32_t const *lens, uint32_t n_reads, mm_reg_t **regs);
+void mm_reg_free(mm_reg_t *r);
+
 /* the same batch in three phases, so that callers can keep inputs resident in HBM and time the hot path alone:
  * upload (parse-free H2D of 2-bit packed reads) -> run (K1 sketch/lookup/expand, K2 sort/chain, K3 extend, in rounds;
  * results stay in HBM) -> finish (D2H, post-map, SAM text appended to *sam).  mm_batch_run may be repeated. */

@@ -1341,6 +1341,7 @@ struct Batch {
 	uint32_t n = 0; uint64_t total = 0; uint32_t max_qlen = 0;
 	std::vector<uint32_t> lens; std::vector<uint64_t> qoff; std::vector<const uint8_t *> seq; std::vector<std::string> names;
 	std::vector<const HSeq *> rec;         /* the parsed records (qualities, comments) when the batch comes from a file; empty for in-memory batches */
+	mm_reg_t **regs = nullptr;             /* when set: one mm_reg_t per read (NULL = unmapped) instead of text (mm_align_batch_regs) */
 	std::vector<uint32_t> pk, nm; std::vector<ReadIn> in; std::vector<ReadState> hst; std::vector<uint32_t> work;
 	uint64_t scale = 1; bool uploaded = false, ran = false;
 	std::vector<uint32_t> used;            /* the carried reference length each read actually ran with */
@@ -1436,6 +1437,32 @@ bool batch_run(mm_align_t *a, Batch &b)
 		if(!batch_upload(a, b)) return false;
 	}
 }
+/* mm_pack_reg (minialign.c:4364-4398) into one malloc block per read: the mm_reg_t header with its pointer array, then for every alignment an mm_aln_t
+ * { aid, mapq } directly followed by its gaba_alignment_t (header, path words with the two header words in plen / padding, segments) */
+mm_reg_t *build_reg(const OutReg &reg, const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths)
+{
+	if(!reg.mapped || reg.n_all == 0) return nullptr;
+	auto aln_bytes = [&](const AlnRec &al) { return (size_t)((sizeof(mm_aln_t) + sizeof(gaba_alignment_t) + (((uint64_t)al.plen + 31) / 32 + 2 + 7) / 8 * 8 * 4 + al.slen * sizeof(gaba_path_section_t) + 15) & ~15ull); };
+	size_t head = (sizeof(mm_reg_t) + reg.n_all * sizeof(mm_aln_t *) + 15) & ~15ull, total = head;
+	for(uint32_t i = 0; i < reg.n_all; i++) total += aln_bytes(alns[reg.aln[i].aln]);
+	uint8_t *blk = (uint8_t *)calloc(1, total);
+	if(!blk) return nullptr;
+	mm_reg_t *r = (mm_reg_t *)blk; r->n_all = reg.n_all; r->n_uniq = reg.n_uniq;
+	mm_aln_t const **tab = (mm_aln_t const **)(blk + sizeof(mm_reg_t));
+	uint8_t *p = blk + head;
+	for(uint32_t i = 0; i < reg.n_all; i++) {
+		const AlnRec &al = alns[reg.aln[i].aln];
+		mm_aln_t *m = (mm_aln_t *)p; m->aid = i; m->mapq = reg.aln[i].mapq;
+		gaba_alignment_t *g = (gaba_alignment_t *)(p + sizeof(mm_aln_t));
+		g->score = al.score; g->identity = al.identity; g->agcnt = al.agcnt; g->bgcnt = al.bgcnt; g->dcnt = al.dcnt; g->slen = al.slen; g->plen = al.plen; g->padding = 0x40000000u;
+		const uint64_t pw = (((uint64_t)al.plen + 31) / 32 + 2 + 7) / 8 * 8;
+		memcpy(g->path, paths + al.path_off, (((uint64_t)al.plen + 31) / 32) * 4);
+		gaba_path_section_t *sg = (gaba_path_section_t *)((uint8_t *)g->path + pw * 4);
+		memcpy(sg, segs + al.seg_off, al.slen * sizeof(gaba_path_section_t)); g->seg = sg;
+		tab[i] = m; p += aln_bytes(al);
+	}
+	return r;
+}
 bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piece_out)
 {
 	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
@@ -1476,6 +1503,7 @@ bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piec
 				OutReg reg; const ReadState &rs = hst[i];
 				const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.get();
 				if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
+				if(b.regs) { b.regs[i] = build_reg(reg, alns, seg.get(), path.get()); continue; }
 				if(a->o.format == 0) sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get(), i < b.rec.size() ? b.rec[i] : nullptr);
 				else alt_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get());
 			}
@@ -1515,6 +1543,18 @@ extern "C" int mm_align_batch(mm_align_t *a, uint8_t const *bases, uint32_t cons
 	memcpy(*sam + old, s.data(), s.size()); (*sam)[old + s.size()] = 0; *sam_len = old + s.size();
 	return 0;
 }
+
+/* the same batch with structured results, what mm_align_seq returns per read (minialign.c:4427, mm_reg_t :3264): regs[i] = NULL for an unmapped read */
+extern "C" int mm_align_batch_regs(mm_align_t *a, uint8_t const *bases, uint32_t const *lens, uint32_t n_reads, mm_reg_t **regs)
+{
+	Batch b; uint64_t off = 0;
+	for(uint32_t i = 0; i < n_reads; i++) { b.lens.push_back(lens[i]); b.seq.push_back(bases + off); off += lens[i]; b.names.emplace_back(); regs[i] = nullptr; }
+	b.regs = regs;
+	std::string s;
+	if(n_reads && !(batch_prepare(a, b) && batch_run(a, b) && batch_finish(a, b, s))) { for(uint32_t i = 0; i < n_reads; i++) { free(regs[i]); regs[i] = nullptr; } return -1; }
+	return 0;
+}
+extern "C" void mm_reg_free(mm_reg_t *r) { free(r); }
 
 /* phase-split entry points over a parsed read set (bench.py times mm_batch_run alone: inputs resident in HBM) */
 static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual = false, bool keep_comment = false);

@@ -74,3 +74,49 @@ def test_index_queries_and_batch_entries_match_cli_and_oracle():
         for b in (b0, b1, c0, c1): L.mm_batch_free(b)
         L.mm_reads_free(rs); L.mm_reads_free(rs1)
         L.mm_align_destroy(al); L.mm_align_destroy(al1); L.mm_idx_destroy(mi); L.mm_idx_destroy(mi1)
+
+
+def test_structured_results_match_the_sam_records():
+    """mm_align_batch_regs: what mm_align_seq returns per read (mm_reg_t / mm_aln_t / gaba_alignment_t).  Flag, position, mapping quality and CIGAR rebuilt from
+    the structures must equal fields 2-6 of the SAM records of the command-line program"""
+    import gabalib as G
+    s = dict(name='g_regs', preset='pacbio', genome=(381, 300000, 4, 0.25), reads=(382, 1.0, 'pacbio', 'fa', 4000, 1500))
+    with tempfile.TemporaryDirectory() as d:
+        ref, rd = make_inputs(s, d)
+        sam = subprocess.run([CLI, '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        want = {}
+        for l in sam.splitlines():
+            if not l.startswith(b'@'): f = l.split(b'\t'); want.setdefault(f[0].decode(), []).append((int(f[1]), f[2].decode(), int(f[3]), int(f[4]), f[5].decode()))
+        L = _lib(); o, mi, al = _open(L, 'pacbio', ref, rd)
+        L.gaba_dump_cigar_reverse.restype = ctypes.c_uint64
+        refseq = M.read_fasta(ref); reads = M.read_fasta(rd)
+        lens = (ctypes.c_uint32 * len(reads))(*[len(q) for _, q in reads]); cat = np.concatenate([q for _, q in reads]).astype(np.uint8)
+        regs = (ctypes.c_void_p * len(reads))()
+        assert L.mm_align_batch_regs(al, cat.ctypes.data_as(ctypes.c_void_p), lens, len(reads), regs) == 0
+        class Aln(ctypes.Structure):          # mm_aln_t { aid, mapq } + gaba_alignment_t header
+            _fields_ = [('aid', ctypes.c_uint32), ('mapq', ctypes.c_uint32), ('res', ctypes.c_void_p * 2), ('score', ctypes.c_int64), ('identity', ctypes.c_double),
+                        ('agcnt', ctypes.c_uint32), ('bgcnt', ctypes.c_uint32), ('dcnt', ctypes.c_uint32), ('slen', ctypes.c_uint32), ('seg', ctypes.POINTER(G.Seg)),
+                        ('plen', ctypes.c_uint32), ('padding', ctypes.c_uint32)]
+        buf = ctypes.create_string_buffer(1 << 18); n_checked = 0
+        for i, (name, q) in enumerate(reads):
+            if not regs[i]:
+                assert want[name][0][0] == 4; continue
+            n_all, n_uniq = (ctypes.c_uint32 * 2).from_address(regs[i])
+            tab = (ctypes.c_void_p * n_all).from_address(regs[i] + 8)
+            got = []; flag = 0
+            for k in range(n_all):
+                if k >= n_uniq: flag = 0x100
+                a = Aln.from_address(tab[k]); path = tab[k] + ctypes.sizeof(Aln)
+                assert a.aid == k and a.padding == 0x40000000
+                for j in range(a.slen, 0, -1):
+                    sg = a.seg[j - 1]; rlen = len(refseq[sg.aid >> 1][1])
+                    hl = len(q) - sg.bpos - sg.blen; tl = sg.bpos; clip = 'H' if flag & 0x900 else 'S'
+                    L.gaba_dump_cigar_reverse(buf, ctypes.c_uint64(len(buf)), ctypes.c_void_p(path), ctypes.c_uint64(sg.ppos), ctypes.c_uint64(sg.alen + sg.blen))
+                    cig = ('%d%s' % (hl, clip) if hl else '') + buf.value.decode() + ('%d%s' % (tl, clip) if tl else '')
+                    got.append((flag | ((~sg.bid & 1) << 4), refseq[sg.aid >> 1][0], rlen - sg.apos - sg.alen + 1, a.mapq >> 4, cig))
+                    if k == 0 and j == a.slen: flag = 0x800
+                flag = 0x800
+            assert got == want[name], name
+            n_checked += len(got); L.mm_reg_free(ctypes.c_void_p(regs[i]))
+        assert n_checked > len(reads)
+        L.mm_align_destroy(al); L.mm_idx_destroy(mi)
