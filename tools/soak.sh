@@ -13,7 +13,7 @@ shapes=( "3000000 1 0.05 pacbio 20000 2000 30 -xpacbio" "2000000 8 0.30 pacbio 8
 bad=0
 for ((i=0; i<N; i++)); do
 	set -- ${shapes[$((i % ${#shapes[@]}))]}; glen=$1; nc=$2; rep=$3; prof=$4; lm=$5; ls=$6; depth=$7; shift 7; opts="$*"
-	seed=$((S0 + 2 * i))
+	seed=$((S0 + 2 * i)); glen=$(( glen * ${SOAK_SCALE:-1} ))        # SOAK_SCALE: longer references (and, at equal depth, more reads)
 	tools/gensim genome $seed $glen $nc $rep > "$W/ref.fa"
 	fmt=fa; [ -n "$SOAK_FQ" ] && { fmt=fq; case "$opts" in *-O*) ;; *) opts="$opts -Q -TAS,NM,MD,XS,NH";; esac; }       # SOAK_FQ=1: FASTQ input, qualities kept, tags printed
 	if [ "$prof" = ont ]; then tools/gensim reads $((seed + 1)) "$W/ref.fa" $depth ont $fmt > "$W/rd.fa"; else tools/gensim reads $((seed + 1)) "$W/ref.fa" $depth $prof $fmt $lm $ls > "$W/rd.fa"; fi
