@@ -639,13 +639,15 @@ extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 	{
 		const uint32_t parts = 64; const uint64_t span = tsize / parts;            /* tsize >= 1024: a power of two, divisible */
 		std::vector<std::vector<uint64_t>> late(parts);
+		/* home slot of every key once (parallel over the keys); the owner of a slot range then walks the one-byte owner column */
+		std::vector<uint64_t> home(n_keys); std::vector<uint8_t> owner(n_keys);
+		host_parallel(64, [&](uint32_t t, uint32_t nth) { for(uint64_t i = (uint64_t)n_keys * t / nth, e = (uint64_t)n_keys * (t + 1) / nth; i < e; i++) { home[i] = hash(kv[i].key - 1) & mi->mask; owner[i] = (uint8_t)(home[i] / span); } }, 64);
 		host_parallel(parts, [&](uint32_t t, uint32_t nth) {
 			for(uint32_t pt = t; pt < parts; pt += nth) {
-				const uint64_t lo = pt * span, hi = lo + span;
+				const uint64_t hi = ((uint64_t)pt + 1) * span;
 				for(uint64_t i = 0; i < n_keys; i++) {
-					uint64_t s0 = hash(kv[i].key - 1) & mi->mask;
-					if(s0 < lo || s0 >= hi) continue;
-					uint64_t sl = s0; while(sl < hi && mi->slot[sl].key != 0) sl++;
+					if(owner[i] != pt) continue;
+					uint64_t sl = home[i]; while(sl < hi && mi->slot[sl].key != 0) sl++;
 					if(sl < hi) mi->slot[sl] = kv[i]; else late[pt].push_back(i);
 				}
 			}
