@@ -1675,6 +1675,18 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 	Slot slot[2];
 	std::mutex mu; std::condition_variable cv;
 	int rc = 0; bool done = false; uint32_t produced = 0;
+	/* the text of a finished batch goes to a writer thread, so that formatting the next batch does not wait for the output file (at most two batches queued) */
+	std::mutex wmu; std::condition_variable wcv; std::vector<std::vector<std::string>> wq; bool wdone = false;
+	std::thread writer([&]() {
+		while(true) {
+			std::vector<std::string> piece;
+			{ std::unique_lock<std::mutex> lk(wmu); wcv.wait(lk, [&]() { return !wq.empty() || wdone; }); if(wq.empty()) return; piece = std::move(wq.front()); wq.erase(wq.begin()); }
+			wcv.notify_all();
+			double tv = now_ms(); size_t nb = 0;
+			for(auto &x : piece) { fwrite(x.data(), 1, x.size(), out); nb += x.size(); }
+			if(verbose) { fprintf(stderr, "[minialign_amd] write %.1f MB %.1f ms\n", nb * 1e-6, now_ms() - tv); }
+		}
+	});
 	std::thread finisher([&]() {
 		if(hipSetDevice(a->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); rc = 1; cv.notify_all(); return; }
 		for(uint32_t k = 0;; k++) {
@@ -1689,8 +1701,8 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 			mm_batch_t *h = sl.h;
 			if(!batch_finish_pieces(h->ctx, h->b, piece)) { r = 1; }
 			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: finish %.1f ms\n", k, now_ms() - tv); tv = now_ms(); }
-			if(r == 0) { for(auto &x : piece) fwrite(x.data(), 1, x.size(), out); }
-			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: write %.1f ms\n", k, now_ms() - tv); }
+			if(r == 0) { std::unique_lock<std::mutex> lk(wmu); wcv.wait(lk, [&]() { return wq.size() < 2; }); wq.emplace_back(std::move(piece)); }
+			wcv.notify_all();
 			mm_batch_free(h);
 			{ std::lock_guard<std::mutex> lk(mu); sl.h = nullptr; sl.ready = false; sl.busy = false; if(r) rc = 1; }
 			cv.notify_all();
@@ -1726,6 +1738,9 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 	{ std::lock_guard<std::mutex> lk(mu); done = true; }
 	cv.notify_all();
 	finisher.join();
+	{ std::lock_guard<std::mutex> lk(wmu); wdone = true; }
+	wcv.notify_all();
+	writer.join();
 	a->rlen_carry = carry;
 	if(!keep) mm_reads_free(reads);
 	return rc;
