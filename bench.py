@@ -190,6 +190,9 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args, world),
                          'alg_bytes_per_launch': alg_bytes, 'avg_launch_ms': k3_launch_ms,
+                         # with several batches in flight the launches of the lanes share the chip: one launch lasts longer than it would alone, so besides the
+                         # per-launch figure above, the same bytes over the wall time of the timed region (all lanes of this rank together)
+                         'achieved_all_lanes': (alg_bytes / (dt / args.steps) * 1e-9) if alg_bytes else None,
                          'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4): traffic = PMC bytes per launch from profiles/round1_j_pmc.json'},
         }
         if world == 1:
