@@ -279,7 +279,9 @@ struct HMin { uint64_t hash; uint32_t pos; uint32_t strand; };
 void sketch_host(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t w, std::vector<HMin> &out, uint32_t begin = 0, uint32_t end = 0xffffffffu)
 {
 	const uint64_t mask = (1ull << 2 * k) - 1; const int sh = 2 * (k - 1);
-	std::vector<uint64_t> ring(w, ~0ull);        /* h of the last w positions */
+	/* minimum of h over the last w positions: a monotone queue (ascending h from head to tail; h carries its position mod w in the low bits, so no two
+	 * entries of a window are equal) -- O(1) per base instead of a scan of the window */
+	uint64_t qh[64]; uint32_t qp[64]; uint32_t qb = 0, qe = 0;          /* ring of at most w <= 31 live entries */
 	uint64_t k0 = 0, k1 = 0, u = 0;
 	const uint32_t p0 = begin > k + 1 + w ? begin - (k + 1 + w) : 0;
 	if(end > len) end = len;
@@ -291,8 +293,10 @@ void sketch_host(const uint8_t *seq, uint32_t len, uint32_t k, uint32_t w, std::
 		uint64_t crc = (kx >> 32) ? (uint64_t)h_crc32c((uint32_t)kx, kx) : 0ull;
 		uint32_t i = (p - (k - 1)) % w;
 		uint64_t h = ((crc ^ km) & mask) << 8 | i | m;
-		ring[i] = h;
-		uint64_t v = ~0ull; for(uint32_t j = 0; j < w; j++) v = ring[j] < v ? ring[j] : v;
+		while(qe != qb && qh[(qe - 1) & 63] > h) qe--;                 /* entries that can never be the minimum again */
+		qh[qe & 63] = h; qp[qe & 63] = p; qe++;
+		while(qp[qb & 63] + w <= p) qb++;                             /* entries that left the window */
+		const uint64_t v = qh[qb & 63];
 		if(p >= begin && (v == h || v != u)) {
 			uint32_t iv = (uint32_t)(v & 0x7f);
 			out.push_back(HMin{ v >> 8, (p - (k - 1)) - ((i + w - iv) % w), (uint32_t)((v >> 7) & 1) });
