@@ -1,7 +1,7 @@
 #!/bin/bash
 # Soak run on the GPU box: seeded synthetic sets of varied shape through the command-line program and the compiled reference (oracle/_ref, -t1);
-# whole-SAM md5 compared.  Usage: tools/soak.sh <outdir> [first_seed] [count]
-OUT=${1:-gpurun_out/soak}; S0=${2:-100}; N=${3:-12}
+# whole-SAM md5 compared.  Usage: tools/soak.sh <outdir> [first_seed] [count] [first_shape]
+OUT=${1:-gpurun_out/soak}; S0=${2:-100}; N=${3:-12}; FIRST=${4:-0}          # FIRST: index of the first shape
 mkdir -p "$OUT"; W=$(mktemp -d /tmp/soak.XXXX); : > "$OUT/soak.txt"
 [ -x tools/gensim ] || gcc -O2 -o tools/gensim tools/gensim.c -lm
 shapes=( "3000000 1 0.05 pacbio 20000 2000 30 -xpacbio" "2000000 8 0.30 pacbio 8000 3000 30 -xpacbio" "5000000 40 0.10 ont 0 0 20 -xont.1dsq" "1500000 3 0.50 pacbio 40000 10000 30 -xpacbio"
@@ -12,7 +12,7 @@ shapes=( "3000000 1 0.05 pacbio 20000 2000 30 -xpacbio" "2000000 8 0.30 pacbio 8
          "2000000 4 0.30 ont 0 0 30 -xava -Opaf" "3000000 3 0.15 pacbio 15000 5000 20 -xpacbio -TSA,MD,NM,AS,XS" "2000000 2 0.40 pacbio 5000 2500 30 -xpacbio -Omaf" "1500000 1 0.10 pacbio 20000 8000 30 -xont.1dsq -W2000 -G1500" )
 bad=0
 for ((i=0; i<N; i++)); do
-	set -- ${shapes[$((i % ${#shapes[@]}))]}; glen=$1; nc=$2; rep=$3; prof=$4; lm=$5; ls=$6; depth=$7; shift 7; opts="$*"
+	set -- ${shapes[$(( (i + FIRST) % ${#shapes[@]} ))]}; glen=$1; nc=$2; rep=$3; prof=$4; lm=$5; ls=$6; depth=$7; shift 7; opts="$*"
 	seed=$((S0 + 2 * i)); glen=$(( glen * ${SOAK_SCALE:-1} ))        # SOAK_SCALE: longer references (and, at equal depth, more reads)
 	tools/gensim genome $seed $glen $nc $rep > "$W/ref.fa"
 	fmt=fa; [ -n "$SOAK_FQ" ] && { fmt=fq; case "$opts" in *-O*) ;; *) opts="$opts -Q -TAS,NM,MD,XS,NH";; esac; }       # SOAK_FQ=1: FASTQ input, qualities kept, tags printed
