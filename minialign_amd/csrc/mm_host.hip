@@ -1775,9 +1775,19 @@ extern "C" int mm_main(int argc, char **argv)
 	setenv("GPU_MAX_HW_QUEUES", "16", 0);          /* lanes and side streams should not share hardware queues (read when the HIP runtime starts) */
 	mm_opt_t *o = mm_opt_init();
 	const char *files[64]; int nf = 0;
-	if(mm_opt_parse(o, argc, (char const *const *)argv, files, 63, &nf) || nf < 1) {
-		fprintf(stderr, "usage: minialign [-x preset] [-k -w -a -b -p -q -r -Y -s -m -t] [-d idx.mai] ref.{fa,mai} reads.{fa,fq} > out.sam\n");
-		mm_opt_destroy(o); return 1;
+	const int prc = mm_opt_parse(o, argc, (char const *const *)argv, files, 63, &nf);
+	if(prc || nf < 1 || o->help) {
+		/* -h: the text goes to stdout and the exit status is 0 (minialign.c:6466-6470); no input file or a bad option: stderr, 1 */
+		FILE *hf = (!prc && o->help) ? stdout : stderr;
+		fprintf(hf, "usage: minialign [-x preset] [options] [-d idx.mai] ref.{fa,fa.gz,mai} reads.{fa,fq}[.gz] ... > out.sam\n"
+			"  presets    -x pacbio[.clr|.ccs] | ont[.r7|.r9[.4|.5[.1]]][.1d|.1dsq|.2d] | ava\n"
+			"  index      -k INT  -w INT  -B INT  -f FLOAT,...  -c [NAME,...]  -L INT  -d FILE\n"
+			"  scores     -a INT  -b INT  -e XYn,...  -p INT  -q INT  -r INT[,INT]  -Y INT\n"
+			"  mapping    -s INT  -m FLOAT  -W INT  -G INT  -X  -A  -C [INT,INT]\n"
+			"  output     -O sam|maf|blast6|paf  -T TAG,...  -R '@RG\\tID:...'  -Q  -P\n"
+			"  accepted   -t INT  -v [INT]  -1 INT  -2 INT  -h\n");
+		const int ret = (!prc && o->help) ? 0 : 1;
+		mm_opt_destroy(o); return ret;
 	}
 	double t0 = now_ms();
 	if(!o->fnw.empty()) { int rc = main_index(o, files, nf, t0); mm_opt_destroy(o); return rc; }
