@@ -196,7 +196,7 @@ def main():
                          'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4): traffic = PMC bytes per launch from profiles/round1_j_pmc.json'},
         }
         if world == 1:
-            out['cpu_baseline'] = cpu_baseline(ref_fa, reads_fa, work, 4000)
+            out['cpu_baseline'] = cpu_baseline(ref_fa, reads_fa, work, 20000)      # about 15 s of CPU work at 16 threads
         print(json.dumps(out), flush=True)
     if dist: dist.destroy_process_group()
 
