@@ -1,6 +1,6 @@
 """CPU tests (no GPU): the C-ABI library loads and exports every symbol the headers declare; the multi-GPU host logic
 (sharding, ordered merge, carried-state chain, timing reduction) under a 2-process gloo group."""
-import ctypes, os, re, sys
+import ctypes, os, re, subprocess, sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -204,3 +204,46 @@ def test_reader_matches_oracle_on_oddly_formatted_files(tmp_path):
             got.append((blob[off:off + ln], blob[off + ln:off + ln + ls])); off += ln + ls
         assert got == recs, name
     assert n_err >= 1
+
+
+C_CALLER = r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "gaba.h"
+#include "minialign.h"
+/* what a libgaba user writes (INTEGRATION.md, per-call form) -- compiled and linked only, never run here */
+static int printer(void *fp, int64_t len, char c) { return fprintf((FILE *)fp, "%ld%c", (long)len, c); }
+int main(int argc, char **argv)
+{
+	struct gaba_params_s p; char cig[64]; uint8_t a[64] = { 0 }, b[64] = { 0 };
+	if(argc < 100) { return 0; }
+	p = (struct gaba_params_s){ .xdrop = 50 };
+	gaba_t *ctx = gaba_init(&p);
+	gaba_arena_t *ra = gaba_arena_upload(a, 64), *qa = gaba_arena_upload(b, 64);
+	gaba_dp_t *dp = gaba_dp_init(ctx);
+	struct gaba_section_s sa = gaba_build_section(0, a, 64), sb = gaba_build_section(1, b, 64);
+	gaba_fill_t *f = gaba_dp_fill_root(dp, &sa, 0, &sb, 0, 0);
+	gaba_pos_pair_t *m = gaba_dp_search_max(dp, f);
+	gaba_alignment_t *r = gaba_dp_trace(dp, f, NULL);
+	gaba_dump_cigar_forward(cig, sizeof(cig), r->path, 0, r->plen);
+	gaba_print_cigar_reverse(printer, stdout, r->path, 0, r->plen);
+	gaba_dp_res_free(dp, r); gaba_dp_flush(dp); gaba_dp_clean(dp); gaba_clean(ctx);
+	(void)m; (void)ra; (void)qa; (void)argv;
+	return mm_main(argc, argv);
+}
+'''
+
+
+def test_headers_stand_alone_and_a_c_caller_links(tmp_path):
+    """include/*.h are what a maintainer binds: each must compile on its own as C99 and as C++, and a C caller written against the reference's
+    names must link against the library (INTEGRATION.md)."""
+    inc = os.path.join(ROOT, 'include')
+    for h in sorted(os.listdir(inc)):
+        for lang, std in (('c', '-std=c99'), ('c++', '-std=c++11')):
+            r = subprocess.run(['gcc', std, '-Wall', '-Werror', '-fsyntax-only', '-x', lang, os.path.join(inc, h)], capture_output=True, text=True)
+            assert r.returncode == 0, (h, lang, r.stderr[:2000])
+    src = tmp_path / 'caller.c'; src.write_text(C_CALLER)
+    lib = os.path.join(ROOT, 'minialign_amd')
+    r = subprocess.run(['gcc', '-std=gnu99', '-Wall', '-I', inc, str(src), '-o', str(tmp_path / 'caller'), '-L', lib, '-lminialign_amd',
+                        '-Wl,-rpath,' + lib, '-Wl,--allow-shlib-undefined'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:3000]
