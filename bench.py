@@ -1,23 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- aligned Gbases/s of the MI355X hot path (sketch + index lookup -> seed sort + chaining -> banded extension)
-on BASELINE.json's configs[1]: an E.coli-MG1655-sized reference x PBSIM-CLR-like reads at x100 (about 460 Mb), -xpacbio.
+"""bench.py -- aligned Gbases/s of the MI355X mapper on BASELINE.json's headline shape, timed end to end over the map phase.
 
-A "step" is one pass of the hot path over the whole read set (one batch), with the 2-bit packed reads, the reference
-and the index already resident in HBM.  Synthetic data comes from the repo's own seeded generator (tools/gensim.c).
-For N > 1 GPUs (torch.distributed.run, one process per GPU) every rank maps its own read set against its own replica
-of the index: weak scaling, no collective on the data path (the only collectives are the barrier / max of the timing).
+Default workload (`--workload hg38`): a human-genome-size synthetic reference (3.1 Gb in 25 contigs, 5 % planted repeats, N runs) x PBSIM-CLR-like reads at
+x3 (9.2 Gb, about 447 000 reads of 20 kb +- 2 kb, accuracy 0.88 +- 0.07, sub:ins:del 10:60:30), `-xpacbio` -- the configuration BASELINE.json's metric is quoted
+on.  `--workload dm6 | ecoli | ont` give the other BASELINE shapes (D.melanogaster size x20; E.coli MG1655 size x100; human size x ONT-like reads with
+`-xont.1dsq`), `--genome-len / --contigs / --depth / --repeat-frac` any other.  Data comes from the repo's own seeded generator (tools/gensim.c, 16 parts
+generated side by side; the set is their concatenation).
 
-Prints ONE JSON line (see the contract in the task description) with `roofline` (dominant kernel mm_extend_kernel:
-algorithmic bytes = DP vectors x 40.5 B + traceback steps x 32 B per launch, SURVEY.md 8d, over the kernel's average
-launch time from HIP events) and `cpu_baseline` (the compiled reference when oracle/_ref travelled with the snapshot,
-else the repo's plain-C oracle, on a bounded sample of the same reads)."""
+A step = the whole read set once through the map phase of the reference (minialign.c:6417-6431): the timed region starts from 2-bit packed reads in host
+memory and ends with the SAM text of every read in host memory -- H2D, K1 sketch + lookup, K2 sort + chain, K3 banded extension (in rounds, several batches
+in flight on the lanes of the device context), D2H, post-map, SAM formatting.  Index construction and FASTA parsing are outside (as in the README's figure).
+With N > 1 GPUs (torch.distributed.run, one process per GPU) the SAME read set is split over the ranks (strong scaling): rank r maps parts r*16/N .. of
+the set against its own replica of the index, the ranks settle the one value reads share (the carried reference length, minialign_amd/multi.py) with one
+tiny all_gather, and value = total bases / max over ranks of the time.  No collective on the data path.
+
+Prints ONE JSON line: metric / value / ... as the contract asks, `roofline` for the dominant kernel (mm_extend_kernel: DP vectors x 40.5 B + traceback
+steps x 32 B, SURVEY.md 8d, counted by the kernel, over the summed launch time from HIP events on the launch streams), `cpu_baseline` (the compiled
+reference oracle/_ref/minialign when it travelled with the snapshot, else the plain-C oracle, on a bounded sample of the same reads; N = 1 only) and
+`sam_identical` (the records of the first reads against the compiled reference at -t1 -- the reference's output depends on its thread count through the
+carried value, DESIGN.md 5 -- or against the oracle; N = 1 or --check)."""
 import os as _os
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # before the HIP runtime starts: the lanes' streams should not share hardware queues
-import argparse, ctypes, json, os, re, subprocess, sys, tempfile, time
+import argparse, ctypes, json, os, re, shutil, subprocess, sys, tempfile, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-GENOME_LEN = 4641652          # E.coli K-12 MG1655
+sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+PARTS = 16
+WORKLOADS = {
+    'hg38':  dict(genome_len=3100000000, contigs=25,   repeat_frac=0.05, depth=3.0,   kind='pacbio', preset='pacbio',   name='human hg38-size ref (3.1 Gb, 25 contigs)'),
+    'dm6':   dict(genome_len=143700000,  contigs=1870, repeat_frac=0.05, depth=20.0,  kind='pacbio', preset='pacbio',   name='D.melanogaster dm6-size ref (143.7 Mb, 1870 contigs)'),
+    'ecoli': dict(genome_len=4641652,    contigs=1,    repeat_frac=0.05, depth=100.0, kind='pacbio', preset='pacbio',   name='E.coli MG1655-size ref (4.64 Mb)'),
+    'ont':   dict(genome_len=3100000000, contigs=25,   repeat_frac=0.05, depth=1.0,   kind='ont',    preset='ont.1dsq', name='human hg38-size ref (3.1 Gb, 25 contigs), ONT-like reads'),
+}
 
 class Stats(ctypes.Structure):
     _fields_ = [('k1_ms', ctypes.c_double), ('k2_ms', ctypes.c_double), ('k3_ms', ctypes.c_double),
@@ -30,174 +45,222 @@ class Stats(ctypes.Structure):
                 ('k3_cycles_total', ctypes.c_uint64), ('k3_cycles_next', ctypes.c_uint64), ('k3_cycles_max', ctypes.c_uint64), ('k3_waves', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
                 ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64)]
 
-def gensim(*args, out):
+def gensim_exe():
     exe = os.path.join(ROOT, 'tools', 'gensim')
     if not os.path.exists(exe):
         subprocess.check_call(['gcc', '-O2', '-o', exe, os.path.join(ROOT, 'tools', 'gensim.c'), '-lm'])
-    with open(out, 'wb') as f:
-        subprocess.check_call([exe] + [str(a) for a in args], stdout=f)
+    return exe
 
-def cpu_baseline(ref_fa, reads_fa, workdir, budget_reads):
-    """time the CPU path on a bounded sample of the same reads (rank 0, N = 1 only)"""
-    sample = os.path.join(workdir, 'sample.fa')
-    n = 0; bases = 0
-    with open(reads_fa, 'rb') as f, open(sample, 'wb') as g:
-        for line in f:
-            if line.startswith(b'>'):
-                n += 1
-                if n > budget_reads: break
-            else:
-                bases += len(line) - 1
-            g.write(line)
-    refbin = os.path.join(ROOT, 'oracle', '_ref', 'minialign')
-    cores = os.cpu_count() or 1
+def generate(work, w, seed=0x5eed0001):
+    """reference + the PARTS read files of the set (generated side by side)"""
+    exe = gensim_exe(); ref_fa = os.path.join(work, 'ref.fa')
+    with open(ref_fa, 'wb') as f: subprocess.check_call([exe, 'genome', str(seed), str(w['genome_len']), str(w['contigs']), str(w['repeat_frac'])], stdout=f)
+    parts = [os.path.join(work, 'reads_%02d.fa' % p) for p in range(PARTS)]; procs = []
+    for p, fn in enumerate(parts):
+        f = open(fn, 'wb')
+        procs.append((subprocess.Popen([exe, 'reads', str(seed + 1), ref_fa, str(w['depth']), w['kind'], 'fa', '20000', '2000', str(p), str(PARTS)], stdout=f), f))
+    for pr, f in procs:
+        if pr.wait() != 0: raise RuntimeError('gensim failed')
+        f.close()
+    return ref_fa, parts
+
+def head_reads(parts, n, out):
+    """the first n reads of the set as one FASTA file; returns (reads written, bases)"""
+    k = 0; bases = 0
+    with open(out, 'wb') as g:
+        for fn in parts:
+            with open(fn, 'rb') as f:
+                for line in f:
+                    if line.startswith(b'>'):
+                        k += 1
+                        if k > n: return n, bases
+                    else: bases += len(line) - 1
+                    g.write(line)
+    return k, bases
+
+def strip_header(sam): return b''.join(l for l in sam.splitlines(True) if not l.startswith(b'@'))
+
+def reference_runs(w, ref_fa, parts, work, n_check, n_time, want_check):
+    """the CPU side, rank 0 only: the compiled reference when it travelled with the snapshot (oracle/_ref; index file built once, then the first n_check reads
+    at -t1 for the identity check and the first n_time reads on many threads for the baseline), else the repo's plain-C oracle on a small sample"""
+    refbin = os.path.join(ROOT, 'oracle', '_ref', 'minialign'); cores = os.cpu_count() or 1
+    out = {'cpu_baseline': None, 'check_sam': None, 'check_reads': 0, 'check_kind': None}
     if os.path.exists(refbin):
-        nth = min(cores, 16)
-        r = subprocess.run([refbin, '-xpacbio', '-t%d' % nth, ref_fa, sample], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        # map phase = "finished mapping" - "loaded/built index" stamps (minialign.c:6417,6431), as the README measures it
-        ts = [float(m.group(1)) for m in re.finditer(rb'\[M::main_align::([0-9.]+)\*', r.stderr)]
-        sec = (ts[-1] - ts[0]) if len(ts) >= 2 else None
-        if r.returncode == 0 and sec and sec > 0:
-            return {'value': bases / sec * 1e-9, 'unit': 'Gbases/s', 'cores': nth, 'kind': 'reference',
-                    'sample': 'first %d reads (%.1f Mb) of the same set, oracle/_ref/minialign -xpacbio -t%d, map phase only' % (min(n, budget_reads), bases / 1e6, nth)}
+        nth = max(1, min(cores, 64))          # the reference refuses 128 threads and more (minialign.c:5973)
+        mai = os.path.join(work, 'ref.mai')
+        r = subprocess.run([refbin, '-x' + w['preset'], '-t%d' % nth, '-d', mai, ref_fa], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        if r.returncode == 0:
+            tf = os.path.join(work, 'time.fa'); nt, bt = head_reads(parts, n_time, tf)
+            # its pipeline does not scale with the thread count on every host (one source / drain thread): the best of a few counts is the baseline
+            for t in sorted(set(max(1, min(cores, x)) for x in (16, 32, 64))):
+                r = subprocess.run([refbin, '-x' + w['preset'], '-t%d' % t, mai, tf], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                # map phase = "finished mapping" - "loaded/built index" stamps (minialign.c:6417,6431), as the README measures it
+                ts = [float(m.group(1)) for m in re.finditer(rb'\[M::main_align::([0-9.]+)\*', r.stderr)]
+                sec = (ts[-1] - ts[0]) if len(ts) >= 2 else None
+                if r.returncode == 0 and sec and sec > 0 and (out['cpu_baseline'] is None or bt / sec * 1e-9 > out['cpu_baseline']['value']):
+                    out['cpu_baseline'] = {'value': bt / sec * 1e-9, 'unit': 'Gbases/s', 'cores': t, 'kind': 'reference',
+                                           'sample': 'first %d reads (%.1f Mb) of the same set, oracle/_ref/minialign -x%s -t%d (best of -t16/32/64) from its own index file, map phase only (%.2f s)' % (nt, bt / 1e6, w['preset'], t, sec)}
+            if want_check:
+                cf = os.path.join(work, 'check.fa'); nc, _ = head_reads(parts, n_check, cf)
+                r = subprocess.run([refbin, '-x' + w['preset'], '-t1', mai, cf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                if r.returncode == 0: out.update(check_sam=strip_header(r.stdout), check_reads=nc, check_kind='oracle/_ref/minialign -t1 (the compiled reference)')
+            return out
     ora = os.path.join(ROOT, 'oracle', 'ora_minialign')
-    small = os.path.join(workdir, 'sample_small.fa'); k = 0; b2 = 0
-    with open(sample, 'rb') as f, open(small, 'wb') as g:
-        for line in f:
-            if line.startswith(b'>'):
-                k += 1
-                if k > 300: break
-            else: b2 += len(line) - 1
-            g.write(line)
-    r = subprocess.run([ora, '-xpacbio', ref_fa, small], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-    m = re.search(rb'in ([0-9.]+) s', r.stderr)
-    sec = float(m.group(1)) if m else None
-    return {'value': (b2 / sec * 1e-9) if sec else None, 'unit': 'Gbases/s', 'cores': 1, 'kind': 'port',
-            'sample': 'first %d reads (%.1f Mb), oracle/ora_minialign (plain-C restatement, single thread), mm_align_seq time only' % (min(k, 300), b2 / 1e6)}
+    sf = os.path.join(work, 'small.fa'); ns, bs = head_reads(parts, min(n_check, 300), sf)
+    r = subprocess.run([ora, '-x' + w['preset'], ref_fa, sf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    m = re.search(rb'in ([0-9.]+) s', r.stderr); sec = float(m.group(1)) if m else None
+    out['cpu_baseline'] = {'value': (bs / sec * 1e-9) if sec else None, 'unit': 'Gbases/s', 'cores': 1, 'kind': 'port',
+                           'sample': 'first %d reads (%.1f Mb), oracle/ora_minialign (plain-C restatement, single thread), mm_align_seq time only' % (ns, bs / 1e6)}
+    if want_check and r.returncode == 0: out.update(check_sam=strip_header(r.stdout), check_reads=ns, check_kind='oracle/ora_minialign (plain-C restatement)')
+    return out
 
-def pmc_traffic(args, world):
-    """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes (same workload only), else None"""
-    fn = os.path.join(ROOT, 'profiles', 'round1_j_pmc.json')          # tools/pmc_traffic.sh on the code as it stands
-    if world != 1 or args.depth != 100.0 or args.repeat_frac != 0.05 or args.genome_len != GENOME_LEN or args.contigs != 1 or not os.path.exists(fn): return None
+def pmc_traffic(wname, world):
+    """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes of the same workload (tools/pmc_traffic.sh), else None"""
+    fn = os.path.join(ROOT, 'profiles', 'round2_pmc.json')
+    if world != 1 or not os.path.exists(fn): return None
     try:
-        with open(fn) as f: return json.load(f)['mm_extend_kernel_per_launch']['hbm_bytes']
+        with open(fn) as f: d = json.load(f)
+        return d['mm_extend_kernel_per_launch']['hbm_bytes'] if d.get('workload') == wname else None
     except Exception:
         return None
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=6); ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--depth', type=float, default=100.0, help='read depth over the 4.64 Mb reference (x100 = BASELINE configs[1])')
-    ap.add_argument('--genome-len', type=int, default=GENOME_LEN, help='length of the synthetic reference (default workload: E.coli MG1655, 4 641 652)')
-    ap.add_argument('--contigs', type=int, default=1, help='number of contigs of the synthetic reference (default workload: 1)')
-    ap.add_argument('--repeat-frac', type=float, default=0.05, help='fraction of the synthetic reference made of planted repeats (default workload: 0.05)')
-    ap.add_argument('--check', action='store_true', help='also verify the SAM of a sample against the CPU oracle')
-    ap.add_argument('--stagger-ms', type=float, default=0.0, help='delay of the second lane at the start of the timed region')
-    ap.add_argument('--inflight', type=int, default=3, choices=(1, 2, 3, 4), help='batches in flight per GPU: consecutive steps go to alternating lanes of the device context and overlap, as the batches of a read stream do (1: strictly one after the other)')
+    ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=2); ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='hg38', choices=sorted(WORKLOADS))
+    ap.add_argument('--depth', type=float); ap.add_argument('--genome-len', type=int); ap.add_argument('--contigs', type=int); ap.add_argument('--repeat-frac', type=float)
+    ap.add_argument('--lanes', type=int, default=3, help='batches in flight per GPU (lanes of the device context)')
+    ap.add_argument('--check', action='store_true', help='verify the records of the first reads against the CPU reference also when N > 1')
+    ap.add_argument('--check-reads', type=int, default=2000); ap.add_argument('--baseline-reads', type=int, default=60000)
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU legs (baseline and identity check)')
+    ap.add_argument('--keep', action='store_true', help='keep the generated data (prints the directory)')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
+    w = dict(WORKLOADS[args.workload]); custom = False
+    for k in ('depth', 'genome_len', 'contigs', 'repeat_frac'):
+        if getattr(args, k) is not None: w[k] = getattr(args, k); custom = True
     import torch
-    dist = None
+    dist = None; device = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local); device = torch.device('cuda', local)
         dist.init_process_group('nccl')
+    from minialign_amd import multi
     lib = os.environ.get('MM_LIB_OVERRIDE') or os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')     # override: kernel experiments only
     if not os.path.exists(lib):
-        sys.path.insert(0, ROOT); import __graft_entry__; __graft_entry__.build()
-    L = ctypes.CDLL(lib)
-    for f in ('mm_opt_init', 'mm_idx_gen', 'mm_align_init', 'mm_reads_load', 'mm_batch_upload', 'mm_batch_upload_lane'): getattr(L, f).restype = ctypes.c_void_p
-    L.mm_reads_bases.restype = ctypes.c_uint64
+        import __graft_entry__; __graft_entry__.build()
+    L = multi.load_library(lib)
     assert L.mm_set_device(local) == 0, 'no HIP device %d' % local
+    if world > 1 and not os.environ.get('MM_HOST_THREADS'):
+        os.environ['MM_HOST_THREADS'] = str(max(8, (os.cpu_count() or 8) // world - 4))        # the ranks share the host cores
 
-    work = tempfile.mkdtemp(prefix='mmbench_')
-    ref_fa = os.path.join(work, 'ref.fa'); reads_fa = os.path.join(work, 'reads_%d.fa' % rank)
-    gensim('genome', 0x5eed0001, args.genome_len, args.contigs, args.repeat_frac, out=ref_fa)
-    gensim('reads', 0x5eed0002 + rank, ref_fa, args.depth, 'pacbio', 'fa', 20000, 2000, out=reads_fa)
+    # data: rank 0 generates into a directory every rank can name
+    work = os.path.join(tempfile.gettempdir(), 'mmbench_%s_%s' % (os.environ.get('MASTER_PORT', 'solo'), os.environ.get('TORCHELASTIC_RUN_ID', str(os.getppid() if world > 1 else os.getpid()))))
+    t_gen0 = time.time()
+    if rank == 0:
+        shutil.rmtree(work, ignore_errors=True); os.makedirs(work)
+        ref_fa, parts = generate(work, w)
+        open(os.path.join(work, 'ready'), 'w').close()
+    if dist: dist.barrier()
+    ref_fa = os.path.join(work, 'ref.fa'); parts = [os.path.join(work, 'reads_%02d.fa' % p) for p in range(PARTS)]
+    t_gen = time.time() - t_gen0
 
     o = ctypes.c_void_p(L.mm_opt_init())
-    argv = (ctypes.c_char_p * 4)(b'minialign', b'-xpacbio', ref_fa.encode(), reads_fa.encode())
+    argv = (ctypes.c_char_p * 4)(b'minialign', ('-x' + w['preset']).encode(), ref_fa.encode(), b'reads.fa')
     files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
     assert L.mm_opt_parse(o, 4, argv, files, 8, ctypes.byref(nf)) == 0
     t0 = time.time()
     mi = ctypes.c_void_p(L.mm_idx_gen(o, ref_fa.encode())); assert mi
     al = ctypes.c_void_p(L.mm_align_init(o, mi)); assert al, 'mm_align_init failed (no GPU?)'
     t_index = time.time() - t0
-    reads = ctypes.c_void_p(L.mm_reads_load(reads_fa.encode())); assert reads
-    n_reads = L.mm_reads_count(reads); bases = L.mm_reads_bases(reads, 0, n_reads)
-    # one copy of the batch per lane; a step = one pass of the hot path over the batch.  With --inflight 2 consecutive steps go to
-    # alternating lanes and overlap (the way consecutive batches of a read stream do); every step still runs K1..K3 completely.
-    batches = [ctypes.c_void_p(L.mm_batch_upload_lane(al, reads, 0, n_reads, ln)) for ln in range(args.inflight)]
-    assert all(batches), 'upload failed'
-    batch = batches[0]
+    # this rank's shard: parts [p0, p1) of the set (PARTS is a multiple of every N the driver uses; otherwise the split is by parts, as even as it gets)
+    p0, p1 = multi.shard_bounds(PARTS, rank, world)
+    t0 = time.time()
+    reads = ctypes.c_void_p(L.mm_reads_load(parts[p0].encode())) if p1 > p0 else None
+    for p in range(p0 + 1, p1): assert L.mm_reads_append(reads, parts[p].encode()) == 0
+    n_reads = L.mm_reads_count(reads) if reads else 0; bases = L.mm_reads_bases(reads, 0, n_reads) if reads else 0
+    cap = 4096; arr = (ctypes.c_void_p * cap)()
+    nb = L.mm_batch_pack_all(reads, 0, n_reads, arr, cap) if reads else 0
+    packed = [arr[i] for i in range(nb)]
+    t_load = time.time() - t0
+    guess = L.mm_idx_max_len(mi)
+    keep_bytes = 96 << 20          # text kept per step: enough for the identity check and for a spliced head window
 
     def sync():
         torch.cuda.synchronize()
         if dist: dist.barrier()
-    def run_steps(k):
-        if args.inflight == 1:
-            for _ in range(k):
-                assert L.mm_batch_run(al, batch) == 0          # blocks until the last kernel of the step has finished
-            return
-        pending = [False] * args.inflight
-        for i in range(k):
-            ln = i % args.inflight
-            if pending[ln]: assert L.mm_batch_wait(al, batches[ln]) == 0
-            if i == 1 and args.stagger_ms > 0: time.sleep(args.stagger_ms * 1e-3)
-            assert L.mm_batch_run_async(al, batches[ln]) == 0; pending[ln] = True
-        for ln in range(args.inflight):
-            if pending[ln]: assert L.mm_batch_wait(al, batches[ln]) == 0
-    run_steps(args.warmup)
+    def one_step():
+        sm = multi.ShardMapper(L, al, reads, 0, n_reads, lanes=args.lanes, packed=packed, keep=keep_bytes, guess=0 if rank == 0 else guess)
+        sm.map()
+        sm.settle(dist, rank, world, 0, device)
+        return sm
+    sm = None
+    for _ in range(args.warmup): sm = one_step()
     L.mm_stats(al, None, 1)
     sync(); t0 = time.perf_counter()
-    run_steps(args.steps)
+    for _ in range(args.steps): sm = one_step()
     sync(); dt = time.perf_counter() - t0
     st = Stats(); L.mm_stats(al, ctypes.byref(st), 0)
+    sam_bytes = sm.col.total if sm else 0
     if dist:
-        t = torch.tensor([dt], device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        tb = torch.tensor([float(bases)], device='cuda', dtype=torch.float64); dist.all_reduce(tb); total_bases = float(tb.item())
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        v = torch.tensor([float(bases), float(n_reads), float(sam_bytes), st.k1_ms, st.k2_ms, st.k3_ms, float(st.vectors), float(st.trace_steps), float(st.k3_launches), float(sm.stats['checks']), float(sm.stats['remapped_reads']), float(sm.stats['full_remaps'])], device='cuda', dtype=torch.float64)
+        dist.all_reduce(v); tot = [float(x) for x in v.tolist()]
     else:
-        total_bases = float(bases)
-    # one untimed finish (D2H + post-map + SAM) to report the end-to-end rate and, optionally, check a sample
-    sam = ctypes.c_char_p(); slen = ctypes.c_uint64(0)
-    t1 = time.perf_counter(); assert L.mm_batch_finish(al, batch, ctypes.byref(sam), ctypes.byref(slen)) == 0; t_finish = time.perf_counter() - t1
-    st2 = Stats(); L.mm_stats(al, ctypes.byref(st2), 0)
+        tot = [float(bases), float(n_reads), float(sam_bytes), st.k1_ms, st.k2_ms, st.k3_ms, float(st.vectors), float(st.trace_steps), float(st.k3_launches), float(sm.stats['checks']), float(sm.stats['remapped_reads']), float(sm.stats['full_remaps'])]
+    total_bases, total_reads, total_sam, k1_ms, k2_ms, k3_ms, vec, trs, k3_launches, n_checks, n_remap, n_full = tot
 
     if rank == 0:
-        k3_launch_ms = st.k3_ms / max(1, st.k3_launches)
-        per_step = lambda x: x / max(1, args.steps)
-        # work counters are read at finish time and cover the last pass over the batch (each pass re-initialises the device state)
-        vec = float(st2.vectors); trs = float(st2.trace_steps)
-        # SURVEY.md 8d per-unit figures for the extension kernel; the two lanes of a step launch it once each (half of the batch)
-        k3_per_step = max(1.0, st.k3_launches / max(1, args.steps))
-        alg_bytes = (vec * 40.5 + trs * 32.0) / k3_per_step
-        achieved = alg_bytes / (k3_launch_ms * 1e-3) / 1e9 if k3_launch_ms > 0 else None
+        K = max(1, args.steps)
+        # the dominant kernel: algorithmic bytes (units counted by the kernel itself, SURVEY.md 8d per-unit figures) over its launch time (HIP events on the launch streams)
+        alg_bytes = vec * 40.5 + trs * 32.0                      # all launches of the timed region, all ranks
+        k3_launch_ms = k3_ms / max(1.0, k3_launches)
+        achieved = (alg_bytes / max(1.0, k3_launches)) / (k3_launch_ms * 1e-3) / 1e9 if k3_ms > 0 else None
         out = {
-            'metric': 'aligned Gbases/sec (hot path: sketch+lookup, sort+chain, banded extension; SAM bit-exact vs CPU ref)',
+            'metric': 'aligned Gbases/sec (whole node), map phase end to end: packed reads in host memory -> SAM text in host memory',
             'value': total_bases * args.steps / dt * 1e-9, 'unit': 'Gbases/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'i8',
-            'data': 'synthetic (tools/gensim.c: %.2f Mb reference with %g %% planted repeats, PBSIM-CLR-like reads 20k+-2k, acc 0.88+-0.07)' % (args.genome_len / 1e6, args.repeat_frac * 100),
-            'config': {'workload': ('E.coli MG1655-size ref' if (args.genome_len == GENOME_LEN and args.contigs == 1 and args.repeat_frac == 0.05) else 'synthetic %.1f Mb / %d contig(s) / %g repeats ref' % (args.genome_len / 1e6, args.contigs, args.repeat_frac))
-                                   + ' x PBSIM-like x%g (%.0f Mb, %d reads) -xpacbio on 1 MI355X per rank' % (args.depth, bases / 1e6, n_reads),
-                       'reads_per_rank': n_reads, 'bases_per_rank': bases, 'batches_in_flight': args.inflight, 'parallelism': 'reads sharded, index replicated (no collective)',
-                       'kernel_ms_per_step': {'sketch_seed': per_step(st.k1_ms), 'sort_chain': per_step(st.k2_ms), 'extend': per_step(st.k3_ms)},
-                       'extend_wave_time_split': {k: getattr(st2, 'k3_cycles_' + k) / max(1, st2.k3_cycles_total) for k in ('fill', 'leaf', 'trace', 'next')},
-                       'extend_wave_balance (mean / max lifetime)': st2.k3_cycles_total / max(1, st2.k3_cycles_max * st2.k3_waves),
-                       'sort_chain_wave_time_split': {'sort': st2.k2_cycles_sort / max(1, st2.k2_cycles_total), 'chain': st2.k2_cycles_chain / max(1, st2.k2_cycles_total),
-                                                      'reads_not_in_lds': st2.k2_reads_hbm, 'sort_cycles_per_seed': st2.k2_cycles_sort / max(1, st2.seeds), 'chain_cycles_per_seed': st2.k2_cycles_chain / max(1, st2.seeds), 'seeds_per_read': st2.seeds / max(1, st2.reads)},
-                       'dp_vectors_per_base': vec / bases, 'trace_steps_per_base': trs / bases, 'reruns_per_step': per_step(st.reruns), 'index_build_s': t_index,
-                       'finish_s (D2H + post-map + SAM, untimed)': t_finish, 'sam_bytes': slen.value},
+            'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'i8',
+            'data': 'synthetic (tools/gensim.c, seed 0x5eed0001: %.2f Mb reference in %d contig(s) with %g %% planted repeats; %s-like reads in %d parts)' % (w['genome_len'] / 1e6, w['contigs'], w['repeat_frac'] * 100, 'ONT' if w['kind'] == 'ont' else 'PBSIM-CLR', PARTS),
+            'config': {'workload': '%s%s x %s x%g (%.2f Gb, %d reads) -x%s, one read set split over %d MI355X' % (w['name'], ' [custom shape]' if custom else '', 'ONT-like' if w['kind'] == 'ont' else 'PBSIM-like', w['depth'], total_bases / 1e9, int(total_reads), w['preset'], world),
+                       'workload_key': args.workload if not custom else 'custom', 'reads_total': int(total_reads), 'bases_total': int(total_bases), 'batches_per_rank0': nb, 'lanes': args.lanes,
+                       'parallelism': 'reads sharded contiguously, index replicated (no data-path collective; one all_gather of 2 integers per step for the carried value)',
+                       'timed_region': 'H2D + K1 sketch/lookup + K2 sort/chain + K3 extension (rounds, carried-value verification) + D2H + post-map + SAM text; index build, FASTA parse and 2-bit packing outside',
+                       'device_only_gbases_per_s (sum of kernel time, lanes overlap)': total_bases * K / max(1e-9, (k1_ms + k2_ms + k3_ms) * 1e-3) * 1e-9 / 1.0,
+                       'kernel_ms_per_step (summed over lanes and ranks)': {'sketch_seed': k1_ms / K, 'sort_chain': k2_ms / K, 'extend': k3_ms / K},
+                       'host_ms_per_step (rank 0, summed over its threads\' critical paths)': {'d2h': st.host_post_ms / K, 'post_map_and_sam_text': st.host_sam_ms / K},
+                       'extend_wave_time_split': {k: getattr(st, 'k3_cycles_' + k) / max(1, st.k3_cycles_total) for k in ('fill', 'leaf', 'trace', 'next')},
+                       'extend_wave_balance (mean / max lifetime)': st.k3_cycles_total / max(1, st.k3_cycles_max * st.k3_waves),
+                       'sort_chain_wave_time_split': {'sort_cycles_per_seed': st.k2_cycles_sort / max(1, st.seeds), 'chain_cycles_per_seed': st.k2_cycles_chain / max(1, st.seeds), 'seeds_per_read': st.seeds / max(1, st.reads), 'reads_not_in_lds': st.k2_reads_hbm},
+                       'dp_vectors_per_base': vec / max(1.0, total_bases * K), 'trace_steps_per_base': trs / max(1.0, total_bases * K), 'reruns_per_step (rank 0)': st.reruns / K,
+                       'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
+                       'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'parse_and_pack_s': t_load},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args, world),
-                         'alg_bytes_per_launch': alg_bytes, 'avg_launch_ms': k3_launch_ms,
-                         # with several batches in flight the launches of the lanes share the chip: one launch lasts longer than it would alone, so besides the
-                         # per-launch figure above, the same bytes over the wall time of the timed region (all lanes of this rank together)
-                         'achieved_all_lanes': (alg_bytes / (dt / args.steps) * 1e-9) if alg_bytes else None,
-                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4): traffic = PMC bytes per launch from profiles/round1_j_pmc.json'},
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args.workload if not custom else 'custom', world),
+                         'alg_bytes_per_launch': alg_bytes / max(1.0, k3_launches), 'avg_launch_ms': k3_launch_ms, 'launches': k3_launches,
+                         # launches of different lanes share the chip, so one launch lasts longer than it would alone: the same bytes over the wall time of the timed region
+                         'achieved_all_lanes': alg_bytes / dt * 1e-9 / world,
+                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4); achieved = algorithmic bytes per launch / mean launch time, achieved_all_lanes = per GPU over the wall time'},
         }
-        if world == 1:
-            out['cpu_baseline'] = cpu_baseline(ref_fa, reads_fa, work, 20000)      # about 15 s of CPU work at 16 threads
+        if (world == 1 or args.check) and not args.no_cpu:
+            cpu = reference_runs(w, ref_fa, parts, work, args.check_reads, args.baseline_reads, True)
+            if world == 1: out['cpu_baseline'] = cpu['cpu_baseline']
+            if cpu['check_sam'] is not None:
+                names = set()
+                with open(os.path.join(work, 'check.fa' if cpu['check_kind'].startswith('oracle/_ref') else 'small.fa'), 'rb') as f:
+                    for line in f:
+                        if line.startswith(b'>'): names.add(line[1:].split()[0].rstrip(b'\n'))
+                text = sm.col.text(); cut = multi._head_cut(text, names)
+                ours = text[:cut] if cut is not None else None
+                out['sam_identical'] = bool(ours is not None and ours == cpu['check_sam'])
+                out['sam_check'] = 'records of the first %d reads (%d bytes) against %s' % (cpu['check_reads'], len(cpu['check_sam']), cpu['check_kind'])
+            else:
+                out['sam_identical'] = None; out['sam_check'] = 'not run'
         print(json.dumps(out), flush=True)
+    for h in packed: L.mm_batch_free(h)
+    if dist: dist.barrier()
+    if rank == 0:
+        if args.keep: sys.stderr.write('[bench] data kept in %s\n' % work)
+        else: shutil.rmtree(work, ignore_errors=True)
     if dist: dist.destroy_process_group()
 
 if __name__ == '__main__':

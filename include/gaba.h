@@ -115,6 +115,9 @@ void gaba_dp_flush_stack(gaba_dp_t *dp, gaba_stack_t const *stack);   /* gaba.h:
 gaba_fill_t *gaba_dp_fill_root(gaba_dp_t *dp, gaba_section_t const *a, uint32_t apos, gaba_section_t const *b, uint32_t bpos, uint32_t pridx);   /* gaba.h:302 */
 gaba_fill_t *gaba_dp_fill(gaba_dp_t *dp, gaba_fill_t const *prev_sec, gaba_section_t const *a, gaba_section_t const *b, uint32_t pridx);          /* gaba.h:315 */
 gaba_pos_pair_t *gaba_dp_search_max(gaba_dp_t *dp, gaba_fill_t const *sec);                                                                       /* gaba.h:339 */
+/* gaba.h:329 (gaba.c:2581): merging of up to 14 bands on one anti-diagonal.  minialign never calls it and the reference has no COMBINED-model branch in
+ * merge_slice_vectors (gaba.c:2452-2472); exported so that libgaba callers link, always answers NULL ("unmergeable", the reference's own error return). */
+gaba_fill_t *gaba_dp_merge(gaba_dp_t *dp, gaba_fill_t const *const *sec, uint8_t const *qofs, uint32_t cnt);
 /* gaba.h:61-75: the caller may supply where alignment objects live; NULL = this library's own heap.  lmalloc gets one request per alignment
  * (header + path + segments), lfree gets that pointer back from gaba_dp_res_free. */
 typedef void *(*gaba_lmalloc_t)(void *opaque, size_t size);

@@ -49,8 +49,12 @@ int mm_idx_dump(mm_idx_t const *mi, FILE *fp);
 mm_idx_t *mm_idx_load(FILE *fp, int *at_eof);
 uint32_t mm_idx_n_seq(mm_idx_t const *mi);
 uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i);
+uint32_t mm_idx_max_len(mm_idx_t const *mi);          /* length of the longest reference sequence */
 /* mm_idx_get (minialign.c:2728) on the host copy: writes up to max values (pos | rid << 32), returns the count */
 uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t max);
+/* mm_sketch (minialign.c:2410) on the host: minimizer stream words (hash << 8 | strand << 7 | index inside the block of w, minialign.c:2402) of a sequence given
+ * one byte per base (0..3, 4 = N), and -- when pos != NULL -- the decoded k-mer start positions (minialign.c:2831-2835); returns the count, writes at most max */
+uint32_t mm_sketch(uint8_t const *seq, uint32_t len, uint32_t w, uint32_t k, uint64_t *words, uint32_t *pos, uint32_t max);
 
 /* device context: uploads the reference (2-bit + N mask) and the flattened index, builds the DP constants */
 mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi);
@@ -72,6 +76,12 @@ typedef struct { uint32_t aid, mapq; gaba_alignment_t a[]; } mm_aln_t;
 typedef struct mm_reg_s { uint32_t n_all, n_uniq; mm_aln_t const *aln[]; } mm_reg_t;
 int mm_align_batch_regs(mm_align_t *a, uint8_t const *bases, uint32_t const *lens, uint32_t n_reads, mm_reg_t **regs);
 void mm_reg_free(mm_reg_t *r);
+/* mm_align_seq (minialign.c:4427) for one read (a one-read batch; qid / lmm as in the reference's argument list, unused); NULL = unmapped; mm_reg_free releases it */
+mm_reg_t const *mm_align_seq(mm_align_t *a, uint32_t l_seq, uint8_t const *seq, uint32_t qid, void *lmm);
+/* the state reads share through the reference's thread buffer (self->rlen, minialign.c:3864: the length of the reference the previous read loaded last): callers
+ * that split one read set over several contexts pass it from the end of one part to the start of the next (minialign_amd/multi.py) */
+uint32_t mm_align_get_carry(mm_align_t const *a);
+void mm_align_set_carry(mm_align_t *a, uint32_t rlen);
 
 /* the same batch in three phases, so that callers can keep inputs resident in HBM and time the hot path alone:
  * upload (parse-free H2D of 2-bit packed reads) -> run (K1 sketch/lookup/expand, K2 sort/chain, K3 extend, in rounds;
@@ -80,6 +90,8 @@ typedef struct mm_reads_s mm_reads_t;
 typedef struct mm_batch_s mm_batch_t;
 mm_reads_t *mm_reads_load(char const *fn);
 void mm_reads_free(mm_reads_t *r);
+int mm_reads_append(mm_reads_t *r, char const *fn);          /* another file behind the reads already loaded; 0 on success */
+char const *mm_reads_name(mm_reads_t const *r, uint32_t i);
 uint32_t mm_reads_count(mm_reads_t const *r);
 uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t n);
 mm_batch_t *mm_batch_upload(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n);
@@ -92,6 +104,22 @@ int mm_batch_wait(mm_align_t *a, mm_batch_t *b);
 int mm_batch_finish(mm_align_t *a, mm_batch_t *b, char **sam, uint64_t *sam_len);
 void mm_batch_free(mm_batch_t *b);
 int mm_set_device(int dev);
+
+/* the streaming form main_align uses (minialign.c:6413-6436 with the pipeline of mm_align_file, :4725): the batches of a read set go through `lanes` lanes of
+ * the device context, several in flight, with pack / H2D in front and D2H / post-map / text behind overlapped on host threads, and the text is handed to `sink`
+ * in input order (a nonzero return from the sink stops the run).  mm_batch_pack prepares a batch ahead of time (2-bit packing on the host, no device work), so a
+ * caller can time the map phase from packed reads in host memory to text in host memory; mm_map_reads packs on the fly.  lanes <= 0: the default (3).
+ * Returns 0 on success.  The carried reference length (mm_align_get_carry) enters at the first batch and is left at its value after the last read. */
+typedef int (*mm_sam_sink_t)(void *opaque, uint32_t batch, char const *text, uint64_t len);
+mm_batch_t *mm_batch_pack(mm_reads_t const *r, uint32_t first, uint32_t n);
+uint32_t mm_batch_reads(mm_batch_t const *b);
+uint32_t mm_batch_pack_all(mm_reads_t const *r, uint32_t first, uint32_t n, mm_batch_t **out, uint32_t max);   /* all batches of a span; returns how many there are */
+/* a read set split over several contexts: what another carried reference length at the start of the stream mapped last would change -- 0 nothing, 1 read
+ * *first_affected decides differently (re-map from there), 2 undecided within the recorded head (re-map the part); mm_carry_after(i): the value behind read i */
+int mm_carry_check(mm_align_t const *a, uint32_t truth, uint32_t *first_affected);
+uint32_t mm_carry_after(mm_align_t const *a, uint32_t i);
+int mm_map_packed(mm_align_t *a, mm_batch_t *const *batches, uint32_t n_batches, int lanes, mm_sam_sink_t sink, void *opaque);
+int mm_map_reads(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n, int lanes, mm_sam_sink_t sink, void *opaque);
 
 /* timing / work counters of everything run since the last reset */
 typedef struct {

@@ -466,6 +466,8 @@ gaba_fill_t *gaba_dp_fill(gaba_dp_t *dp, gaba_fill_t const *prev, gaba_section_t
 	if(!prev) return NULL;
 	return scalar_fill(dp, prev->reserved[0], a, 0, b, 0, pridx);
 }
+/* gaba.h:329: never called on the mapper's path, no COMBINED branch in the reference (gaba.c:2452-2472); NULL is the reference's "unmergeable" answer */
+gaba_fill_t *gaba_dp_merge(gaba_dp_t *dp, gaba_fill_t const *const *sec, uint8_t const *qofs, uint32_t cnt) { (void)dp; (void)sec; (void)qofs; (void)cnt; return NULL; }
 gaba_pos_pair_t *gaba_dp_search_max(gaba_dp_t *dp, gaba_fill_t const *fill)
 {
 	if(!dp || !fill || !dp->ar[0] || !dp->ar[1]) return NULL;

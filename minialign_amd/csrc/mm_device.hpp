@@ -1041,7 +1041,8 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 			unsigned long long bo = 0, ao = 0;
 			if(lane == 0) { bo = atomicAdd(a.bin_top, (unsigned long long)a.bin_cap_per_read); ao = atomicAdd(a.aln_top, (unsigned long long)a.aln_cap_per_read); }
 			bin_off = rdfirst64(bo); aln_off = rdfirst64(ao); n_bin = 0; n_aln = 0;
-			if(bin_off + a.bin_cap_per_read > a.bin_pool_cap || aln_off + a.aln_cap_per_read > a.aln_pool_cap) { err |= ERR_BIN_CAP; bin_off = 0; aln_off = 0; }
+			/* no room in the pools: the read is given up for this pass (the host grows the pools and redoes the batch); it must not touch another read's region */
+			if(bin_off + a.bin_cap_per_read > a.bin_pool_cap || aln_off + a.aln_cap_per_read > a.aln_pool_cap) { if(lane == 0) { st->err |= ERR_BIN_CAP; } continue; }
 			/* first round of this read: mm_tbuf_clear (minialign.c:4402) */
 		}
 		uint64_t *bin = a.bin_pool + bin_off;

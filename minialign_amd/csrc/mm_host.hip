@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <map>
+#include <functional>
 #include <condition_variable>
 #include <mutex>
 #include <memory>
@@ -409,6 +411,11 @@ bool opt_fail(const char *msg) { fprintf(stderr, "[E::mm_opt_parse] %s\n", msg);
 int opt_one(mm_opt_t *o, char c, const char *arg)
 {
 	auto base_of = [](char ch) -> int { switch(ch) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': case 'U': return 4; default: return 0; } };     /* idxaf, minialign.c:232 */
+	/* mm_opt_atoi / mm_opt_atof (minialign.c:5745-5768): digits only for the integer options, [0-9-.,eE] for the real ones; anything else is "unparsable number" */
+	auto digits = [](const char *t, size_t n) { for(size_t i = 0; i < n && t[i]; i++) if(!isdigit((unsigned char)t[i])) return false; return true; };
+	if(strchr("kwBLabpqYstWG12", c) && !digits(arg, strlen(arg))) return opt_fail("unparsable number.");
+	if(strchr("rC", c)) { bool bad = false; split_each(arg, ",;:/", [&](int, const std::string &t) { if(!digits(t.c_str(), t.size())) bad = true; }); if(bad) return opt_fail("unparsable number."); }
+	if(strchr("fm", c)) { for(const char *t = arg; *t; t++) if(!strchr("0123456789-.,eE", *t) && !(c == 'f' && strchr(";:/", *t))) return opt_fail("unparsable number."); }
 	switch(c) {
 		case 'x': return opt_preset(o, arg);
 		case 'k': o->k = atoi(arg); return !(o->k > 1 && o->k < 32) && opt_fail("k must be inside [1,32).");
@@ -503,15 +510,20 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
 	int nf = 0;
 	o->arg_line.clear();
 	for(int i = 0; i < argc; i++) { if(i) o->arg_line += ' '; o->arg_line += argv[i]; }    /* mm_join(argv, ' '), minialign.c:6163 */
+	/* the walk of mm_opt_parse_argv (minialign.c:5786-5812): a word that does not start with '-' (or is "-" alone) is positional; behind the dash the boolean
+	 * letters (X A P Q h) are eaten one by one, the first other letter is the option, its argument is the rest of the word or -- when the word ends there -- the
+	 * next word unless that one looks like an option; a required argument that is missing and an unknown letter are errors */
+	auto isarg = [](const char *w) { return w[0] != '-' || w[1] == 0; };
 	for(int i = 1; i < argc; i++) {
-		const char *a = argv[i];
-		if(a[0] == '-' && a[1]) {
-			const char *arg = a + 2;
-			if(*arg == 0 && i + 1 < argc && strchr("xkwabpqrYsmtWGdfBLe12TRO", a[1])) arg = argv[++i];
-			/* options with an optional argument take the next word unless it looks like an option (mm_opt_parse_argv, minialign.c:5786) */
-			else if(*arg == 0 && i + 1 < argc && strchr("cvC", a[1]) && (argv[i + 1][0] != '-' || argv[i + 1][1] == 0)) arg = argv[++i];
-			if(opt_one(o, a[1], arg)) return 1;
-		} else if(nf < max_files) files[nf++] = a;
+		const char *q = argv[i];
+		if(isarg(q)) { if(nf < max_files) files[nf++] = q; continue; }
+		while(*++q && strchr("XAPQh", *q)) { if(opt_one(o, *q, "")) return 1; }
+		if(*q == 0) continue;
+		const bool req = strchr("xRTOdtkwfBLWGabepqrYsm12", *q) != NULL, optl = strchr("cvC", *q) != NULL;
+		if(!req && !optl) { fprintf(stderr, "[E::mm_opt_parse] unknown option `-%c'.\n", *q); return 1; }
+		const char *r = q[1] ? q + 1 : ((i + 1 < argc && isarg(argv[i + 1])) ? argv[++i] : NULL);
+		if(req && !r) { fprintf(stderr, "[E::mm_opt_parse] missing argument for option `-%c'.\n", *q); return 1; }
+		if(opt_one(o, *q, r ? r : "")) return 1;
 	}
 	if(n_files) *n_files = nf;
 	if(opt_check(o)) return 1;
@@ -714,6 +726,7 @@ extern "C" mm_idx_t *mm_idx_load(FILE *fp, int *at_eof)
 }
 extern "C" uint32_t mm_idx_n_seq(mm_idx_t const *mi) { return (uint32_t)mi->seq.size(); }
 extern "C" uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i) { return mi->occ[i]; }
+extern "C" uint32_t mm_idx_max_len(mm_idx_t const *mi) { uint32_t m = 0; for(const HSeq &q : mi->seq) m = std::max<uint32_t>(m, (uint32_t)q.seq.size()); return m; }
 extern "C" uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t max)
 {
 	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
@@ -729,6 +742,18 @@ extern "C" uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *ou
 		s = (s + 1) & mi->mask;
 	}
 	return 0;
+}
+
+/* mm_sketch (minialign.c:2410-2435) on the host: the (w,k)-minimizer stream of a sequence given one byte per base (0..3, 4 = N), as the words the
+ * reference's stream holds -- hash << 8 | strand << 7 | index inside its block of w (minialign.c:2402) -- plus, when pos != NULL, the k-mer start position
+ * the stream decoder (minialign.c:2831-2835) gives each word.  Returns the count (at most max are written).  Reads are sketched on the device by K1;
+ * this is the entry the index construction uses. */
+extern "C" uint32_t mm_sketch(uint8_t const *seq, uint32_t len, uint32_t w, uint32_t k, uint64_t *words, uint32_t *pos, uint32_t max)
+{
+	if(!seq || k < 2 || k > 31 || w < 1 || w > 31) return 0;
+	std::vector<HMin> m; sketch_host(seq, len, k, w, m);
+	for(size_t i = 0; i < m.size() && i < max; i++) { if(words) words[i] = m[i].hash << 8 | (uint64_t)m[i].strand << 7 | (m[i].pos % w); if(pos) pos[i] = m[i].pos; }
+	return (uint32_t)m.size();
 }
 
 /* =============================================================================================
@@ -759,6 +784,9 @@ struct mm_align_s {
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
+	/* the head of the last stream mapped through this context (mm_map_*): what decides whether another carried value at its start changes anything */
+	struct HeadRec { uint32_t apos0, cond0, used, rid_last; };
+	std::vector<HeadRec> head; uint32_t head_carry_in = 0;
 	mm_align_s *sib = nullptr;             /* second lane: own streams and pools, shares index / reference / DP constants (see mm_batch_run) */
 	bool is_sib = false; int dev = 0;
 	mm_stats_t st; double t_wall0;
@@ -1219,11 +1247,11 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	bool ok = true;
 	ok &= a->d_in.ensure(n_reads); ok &= a->d_st.ensure(n_reads); ok &= a->d_work.ensure(n_reads);
 	ok &= a->q_pk.ensure(bases / 16 + 8); ok &= a->q_nm.ensure(bases / 32 + 8);
-	const uint64_t min_total = (a->mi->w < 4 ? bases : bases / 2) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
+	const uint64_t min_total = ((a->mi->w < 4 || scale > 1) ? bases : bases / 2) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
 	ok &= a->min_pool.ensure(min_total);
 	ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
 	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
-	ok &= a->resc_pool.ensure(min_total);
+	ok &= a->resc_pool.ensure(min_total * std::min<uint64_t>(scale, 4));
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
 	ok &= a->next_pool.ensure((uint64_t)a->n_waves * (a->next_cap + MM_NEXT_SCRATCH));
 	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap);
@@ -1349,7 +1377,7 @@ struct Batch {
 	std::vector<const HSeq *> rec;         /* the parsed records (qualities, comments) when the batch comes from a file; empty for in-memory batches */
 	mm_reg_t **regs = nullptr;             /* when set: one mm_reg_t per read (NULL = unmapped) instead of text (mm_align_batch_regs) */
 	std::vector<uint32_t> pk, nm; std::vector<ReadIn> in; std::vector<ReadState> hst; std::vector<uint32_t> work;
-	uint64_t scale = 1; bool uploaded = false, ran = false;
+	uint64_t scale = 1; bool packed = false, uploaded = false, ran = false;
 	std::vector<uint32_t> used;            /* the carried reference length each read actually ran with */
 };
 namespace {
@@ -1363,7 +1391,8 @@ bool batch_upload(mm_align_t *a, Batch &b)
 	for(uint32_t i = 0; i < b.n; i++) {
 		memset(&b.hst[i], 0, sizeof(ReadState));
 		/* minimizers of a read: at most one per position; 2 / (w + 1) per base on average, so half the length is ample from w = 4 up */
-		b.hst[i].min_off = moff; b.hst[i].min_cap = (a->mi->w < 4 ? b.lens[i] : b.lens[i] / 2) + 64; moff += b.hst[i].min_cap;
+		/* (a read whose hashes keep falling emits one per position: after a pool overflow the batch is redone with room for that) */
+		b.hst[i].min_off = moff; b.hst[i].min_cap = ((a->mi->w < 4 || b.scale > 1) ? b.lens[i] : b.lens[i] / 2) + 64; moff += b.hst[i].min_cap;
 		b.hst[i].bin_off = ~0ull; b.hst[i].apos0 = gaba::NIL; b.hst[i].rid_last = gaba::NIL; b.hst[i].pred_rid = gaba::NIL;
 		/* unmappable reads are skipped outright (minialign.c:4434) */
 		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
@@ -1376,7 +1405,8 @@ bool batch_upload(mm_align_t *a, Batch &b)
 	b.uploaded = true; b.ran = false;
 	return true;
 }
-bool batch_prepare(mm_align_t *a, Batch &b)
+/* host side of a batch: arena offsets and the 2-bit / N-mask words of its reads (no device work) */
+void batch_pack(Batch &b)
 {
 	b.n = (uint32_t)b.lens.size(); b.total = 0; b.max_qlen = 0; b.qoff.resize(b.n); b.in.resize(b.n);
 	for(uint32_t i = 0; i < b.n; i++) { b.qoff[i] = b.total; b.total += ((uint64_t)b.lens[i] + 63) & ~63ull; b.max_qlen = std::max(b.max_qlen, b.lens[i]); }
@@ -1384,8 +1414,12 @@ bool batch_prepare(mm_align_t *a, Batch &b)
 	host_parallel(b.n / 64 + 1, [&](uint32_t t, uint32_t nth) {          /* reads occupy disjoint, word-aligned stretches of the arena */
 		for(uint32_t i = (uint32_t)((uint64_t)b.n * t / nth); i < (uint32_t)((uint64_t)b.n * (t + 1) / nth); i++) { pack_bases(b.seq[i], b.lens[i], b.pk, b.nm, b.qoff[i]); b.in[i] = ReadIn{ b.qoff[i], b.lens[i], 0 }; }
 	});
-	b.scale = 1;
+	b.scale = 1; b.packed = true;
 	if(getenv("MM_VERBOSE")) { fprintf(stderr, "[minialign_amd]   pack done\n"); }
+}
+bool batch_prepare(mm_align_t *a, Batch &b)
+{
+	if(!b.packed) batch_pack(b);
 	return batch_upload(a, b);
 }
 /* the hot path over the uploaded batch; returns 0 ok, 1 device pools overflowed (caller grows and retries), -1 error */
@@ -1418,17 +1452,39 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 	}
 	return overflow ? 1 : 0;
 }
-int batch_run_once(mm_align_t *a, Batch &b)
+/* K1..K3 over the batch with the carried reference length predicted from a->rlen_carry on (b.used = what each read ran with); the device pools are
+ * checked right away.  0 ok, 1 a pool or a per-read cap overflowed, -1 error */
+int batch_run_spec(mm_align_t *a, Batch &b)
 {
 	const uint32_t n_reads = b.n;
 	std::vector<ReadState> &hst = b.hst;
 	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return -1;
 	b.used.assign(n_reads, 0);
 	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size(); } }
-	const int rc = batch_verify_carry(a, b);
+	for(uint32_t i = 0; i < n_reads; i++) if(hst[i].err) return 1;
+	return 0;
+}
+int batch_run_once(mm_align_t *a, Batch &b)
+{
+	int rc = batch_run_spec(a, b);
+	if(rc < 0) return rc;
+	rc = batch_verify_carry(a, b);          /* (also reports which read overflowed, with MM_VERBOSE) */
 	if(rc != 0) return rc;
 	b.ran = true;
 	return 0;
+}
+/* after an overflow: larger pools and per-read caps for the next attempt; false when there is no point in growing further */
+bool batch_grow(mm_align_t *a, Batch &b)
+{
+	if(b.scale >= 256) { fprintf(stderr, "[minialign_amd] batch does not fit the device pools\n"); return false; }
+	b.scale *= 4; a->bin_cap *= 2; a->aln_cap *= 2; a->kh_cap *= 4; a->next_cap *= 2; a->rs_stride = 512 + (a->rs_stride - 512) * 4;
+	fprintf(stderr, "[minialign_amd] device pools overflowed, retrying the batch with scale %lu\n", (unsigned long)b.scale);
+	return true;
+}
+uint32_t batch_carry_out(const mm_align_t *a, const Batch &b, uint32_t cur)
+{
+	for(uint32_t i = 0; i < b.n; i++) { if(b.hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[b.hst[i].rid_last].seq.size(); }
+	return cur;
 }
 bool batch_run(mm_align_t *a, Batch &b)
 {
@@ -1437,10 +1493,7 @@ bool batch_run(mm_align_t *a, Batch &b)
 		if(rc < 0) return false;
 		if(rc == 0) return true;
 		/* a pool or a per-read cap overflowed: grow and redo the batch */
-		if(b.scale >= 256) { fprintf(stderr, "[minialign_amd] batch does not fit the device pools\n"); return false; }
-		b.scale *= 4; a->bin_cap *= 2; a->aln_cap *= 2; a->kh_cap *= 4; a->next_cap *= 2; a->rs_stride = 512 + (a->rs_stride - 512) * 4;
-		fprintf(stderr, "[minialign_amd] device pools overflowed, retrying the batch with scale %lu\n", (unsigned long)b.scale);
-		if(!batch_upload(a, b)) return false;
+		if(!batch_grow(a, b) || !batch_upload(a, b)) return false;
 	}
 }
 /* mm_pack_reg (minialign.c:4364-4398) into one malloc block per read: the mm_reg_t header with its pointer array, then for every alignment an mm_aln_t
@@ -1469,58 +1522,77 @@ mm_reg_t *build_reg(const OutReg &reg, const AlnRec *alns, const gaba::Segment *
 	}
 	return r;
 }
-bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piece_out)
+/* finish, first half (needs the lane's device pools): counters, then the result pools of the batch copied to the host */
+struct Fetched {
+	unsigned long long tops[32];
+	std::unique_ptr<Root[]> root; std::unique_ptr<uint64_t[]> bin; std::unique_ptr<AlnRec[]> aln; std::unique_ptr<gaba::Segment[]> seg; std::unique_ptr<uint32_t[]> path;
+};
+bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 {
 	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
-	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].rid_last].seq.size(); } a->rlen_carry = cur; }
+	a->rlen_carry = batch_carry_out(a, b, a->rlen_carry);
 	if(const char *fn = getenv("MM_DUMP_READ_COST")) {          /* diagnostics: per-read cost of the extension kernel */
 		std::vector<ReadState> d(n_reads); CPY(a, d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
 		if(FILE *fp = fopen(fn, "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks); fclose(fp); }
 	}
-	unsigned long long tops[32]; CPY(a, tops, a->d_tops.p, sizeof(tops), hipMemcpyDeviceToHost);
+	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
 	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->k3_waves; a->st.k3_cycles_next += tops[19];
 	a->st.k2_cycles_sort += tops[24]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
 	/* host copies of the result pools (uninitialised storage: the copies fill them) */
-	std::unique_ptr<Root[]> root(new Root[std::max<uint64_t>(tops[2], 1)]); std::unique_ptr<uint64_t[]> bin(new uint64_t[std::max<uint64_t>(tops[3], 1)]);
-	std::unique_ptr<AlnRec[]> aln(new AlnRec[std::max<uint64_t>(tops[4], 1)]);
-	std::unique_ptr<gaba::Segment[]> seg(new gaba::Segment[std::max<uint64_t>(tops[5], 1)]); std::unique_ptr<uint32_t[]> path(new uint32_t[std::max<uint64_t>(tops[6], 2) + 8]);
-	CK(hipMemcpyAsync(root.get(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(bin.get(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(aln.get(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(seg.get(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(path.get(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost, a->stream));
+	f.root.reset(new Root[std::max<uint64_t>(tops[2], 1)]); f.bin.reset(new uint64_t[std::max<uint64_t>(tops[3], 1)]);
+	f.aln.reset(new AlnRec[std::max<uint64_t>(tops[4], 1)]);
+	f.seg.reset(new gaba::Segment[std::max<uint64_t>(tops[5], 1)]); f.path.reset(new uint32_t[std::max<uint64_t>(tops[6], 2) + 8]);
+	CK(hipMemcpyAsync(f.root.get(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.bin.get(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.aln.get(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.seg.get(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.path.get(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost, a->stream));
 	CK(hipStreamSynchronize(a->stream));
+	a->st.host_post_ms += now_ms() - t0;
+	return true;
+}
+/* finish, second half (host only): post-map and the output text of every read.  Reads are independent: host threads take contiguous spans, the pieces are
+ * joined in input order (mm_align_drain keeps the same order with its heap, minialign.c:4633-4645).  max_threads = 0: -t, or up to 32. */
+void batch_format(const mm_align_t *a, Batch &b, const Fetched &f, std::vector<std::string> &piece_out, uint32_t max_threads)
+{
+	const uint32_t n_reads = b.n; const std::vector<ReadState> &hst = b.hst;
+	const uint32_t want = max_threads ? max_threads : (a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 32));
+	const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(1, n_reads / 64)));
+	std::vector<std::string> piece(nth);
+	Root *root = f.root.get(); uint64_t *bin = f.bin.get(); const AlnRec *aln = f.aln.get(); const gaba::Segment *seg = f.seg.get(); const uint32_t *path = f.path.get();
+	/* spans of equal bases (not equal read counts): the text of a read grows with its length */
+	std::vector<uint32_t> cut(nth + 1, n_reads);
+	{ uint64_t tot = 0; for(uint32_t i = 0; i < n_reads; i++) tot += b.lens[i] + 256; uint64_t acc = 0; uint32_t t = 0; cut[0] = 0; for(uint32_t i = 0; i < n_reads && t + 1 < nth; i++) { acc += b.lens[i] + 256; if(acc * nth >= tot * (t + 1)) { cut[++t] = i + 1; } } }
+	auto span = [&](uint32_t t) {
+		const uint32_t lo = cut[t], hi = cut[t + 1];
+		std::string &out = piece[t];
+		uint64_t est = 0; for(uint32_t i = lo; i < hi; i++) est += b.lens[i];
+		out.reserve(est + est / 2 + 4096);
+		for(uint32_t i = lo; i < hi; i++) {
+			OutReg reg; const ReadState &rs = hst[i];
+			const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln;
+			if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
+			if(b.regs) { b.regs[i] = build_reg(reg, alns, seg, path); continue; }
+			if(a->o.format == 0) sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg, path, i < b.rec.size() ? b.rec[i] : nullptr);
+			else alt_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg, path);
+		}
+	};
+	std::vector<std::thread> th;
+	for(uint32_t t = 1; t < nth; t++) th.emplace_back(span, t);
+	span(0);
+	for(auto &x : th) x.join();
+	for(auto &x : piece) piece_out.emplace_back(std::move(x));
+}
+bool batch_finish_pieces(mm_align_t *a, Batch &b, std::vector<std::string> &piece_out)
+{
+	Fetched f;
+	if(!batch_fetch(a, b, f)) return false;
 	double t1 = now_ms();
-	/* post-map and SAM text are per read and independent: host threads take contiguous spans, the pieces are joined in input
-	 * order (mm_align_drain keeps the same order with its heap, minialign.c:4633-4645) */
-	{
-		const uint32_t want = a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 32);      /* -t sets it; default: up to 32 */
-		const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(1, n_reads / 64)));
-		std::vector<std::string> piece(nth);
-		auto span = [&](uint32_t t) {
-			const uint32_t lo = (uint32_t)((uint64_t)n_reads * t / nth), hi = (uint32_t)((uint64_t)n_reads * (t + 1) / nth);
-			std::string &out = piece[t];
-			uint64_t est = 0; for(uint32_t i = lo; i < hi; i++) est += b.lens[i];
-			out.reserve(est + est / 2 + 4096);
-			for(uint32_t i = lo; i < hi; i++) {
-				OutReg reg; const ReadState &rs = hst[i];
-				const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln.get();
-				if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
-				if(b.regs) { b.regs[i] = build_reg(reg, alns, seg.get(), path.get()); continue; }
-				if(a->o.format == 0) sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get(), i < b.rec.size() ? b.rec[i] : nullptr);
-				else alt_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg.get(), path.get());
-			}
-		};
-		std::vector<std::thread> th;
-		for(uint32_t t = 1; t < nth; t++) th.emplace_back(span, t);
-		span(0);
-		for(auto &x : th) x.join();
-		for(auto &x : piece) piece_out.emplace_back(std::move(x));
-	}
-	a->st.host_post_ms += t1 - t0; a->st.host_sam_ms += now_ms() - t1;
+	batch_format(a, b, f, piece_out, 0);
+	a->st.host_sam_ms += now_ms() - t1;
 	return true;
 }
 bool batch_finish(mm_align_t *a, Batch &b, std::string &sam)
@@ -1561,6 +1633,20 @@ extern "C" int mm_align_batch_regs(mm_align_t *a, uint8_t const *bases, uint32_t
 	return 0;
 }
 extern "C" void mm_reg_free(mm_reg_t *r) { free(r); }
+/* mm_align_seq (minialign.c:4427): one read; a one-read batch on the device.  qid and lmm are accepted for the reference's argument list (it pins qid to 0,
+ * minialign.c:3768; the result is one malloc block, released with mm_reg_free).  NULL = unmapped (or error, reported on stderr). */
+extern "C" mm_reg_t const *mm_align_seq(mm_align_t *a, uint32_t l_seq, uint8_t const *seq, uint32_t qid, void *lmm)
+{
+	(void)qid; (void)lmm;
+	mm_reg_t *r = nullptr;
+	if(!a || !seq || l_seq == 0 || mm_align_batch_regs(a, seq, &l_seq, 1, &r)) return nullptr;
+	return r;
+}
+/* the one value reads share (minialign.c:3864): the length of the reference sequence the previous read loaded last.  A caller that splits one
+ * read set over several contexts (processes, devices) hands it from the end of one part to the start of the next. */
+extern "C" uint32_t mm_align_get_carry(mm_align_t const *a) { return a->rlen_carry; }
+extern "C" void mm_align_set_carry(mm_align_t *a, uint32_t rlen) { for(mm_align_t *q = a; q; q = q->sib) q->rlen_carry = rlen; }
+
 
 /* phase-split entry points over a parsed read set (bench.py times mm_batch_run alone: inputs resident in HBM) */
 static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual = false, bool keep_comment = false);
@@ -1573,6 +1659,15 @@ static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual, 
 	return r;
 }
 extern "C" void mm_reads_free(mm_reads_t *r) { delete r; }
+/* another file behind the reads already loaded (bench.py: the parts of one read set) */
+extern "C" int mm_reads_append(mm_reads_t *r, char const *fn)
+{
+	std::vector<HSeq> more;
+	if(!read_seq_file(fn, more, 1, false, false)) return -1;
+	for(HSeq &q : more) { r->bases += q.seq.size(); r->r.emplace_back(std::move(q)); }
+	return 0;
+}
+extern "C" char const *mm_reads_name(mm_reads_t const *r, uint32_t i) { return i < r->r.size() ? r->r[i].name.c_str() : NULL; }
 extern "C" uint32_t mm_reads_count(mm_reads_t const *r) { return (uint32_t)r->r.size(); }
 extern "C" uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t n) { uint64_t b = 0; for(uint32_t i = first; i < first + n && i < r->r.size(); i++) b += r->r[i].seq.size(); return b; }
 /* Lanes: a batch is bound to one lane of the device context (own streams, pools and -- when run asynchronously -- host thread; index,
@@ -1661,93 +1756,238 @@ extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 	if(verbose) { fprintf(stderr, "[minialign_amd] parse %.1f ms\n", now_ms() - tv); }
 	return align_reads(a, reads, out);
 }
-/* maps a parsed read set (consumed unless keep) and writes its SAM records */
-static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
+/*
+ * The streaming engine.  Batches 0 .. n - 1 of a read set go through `lanes` lanes of the device context (each lane: own streams, pools and host thread; index,
+ * reference and DP constants shared), several at a time, so that the launch tails and the latency-bound rescue rounds of one batch are filled by the kernels of
+ * the others, and the host halves (pack before, post-map + text behind) overlap the device work:
+ *
+ *   lane thread (one per lane), batch k:   make(k) [pack]  ->  H2D  ->  K1..K3 with the carried reference length *predicted*  ->  wait until batch k - 1 is
+ *                                           verified  ->  verify / re-run against the true value (minialign.c:3864)  ->  D2H of the result pools
+ *   finisher threads:                       post-map + SAM text of a fetched batch on their share of the host threads
+ *   writer thread:                          hands the pieces to the sink strictly in batch order (mm_align_drain, minialign.c:4633-4645)
+ *
+ * The only value that couples batches, the carried reference length, is final for batch k as soon as batch k - 1 has been verified; a batch that ran ahead
+ * with a guess re-runs the reads whose `apos >= rlen` decision the true value changes (batch_verify_carry), which is what a single stream would have computed.
+ */
+typedef std::function<bool(uint32_t, std::vector<std::string> &)> PieceSink;          /* (batch, pieces) in batch order; false = stop */
+static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_batch_t *(uint32_t)> &make, const std::function<void(mm_batch_t *)> &release,
+	const PieceSink &sink, int lanes_want)
 {
+	if(n_batches == 0) return 0;
 	const bool verbose = getenv("MM_VERBOSE") != NULL;
-	/*
-	 * batches (bounded by bases so that the device pools stay modest) on two lanes: this thread packs, uploads and runs batch
-	 * i on lane i & 1 while a second host thread does D2H + post-map + SAM text of batch i - 1 and writes it -- strictly in
-	 * input order, as mm_align_drain does (minialign.c:4633-4645).  The carried reference length is handed from
-	 * batch to batch by this thread: it is final as soon as a batch has run.
-	 */
-	const uint64_t max_bases = getenv("MM_BATCH_BASES") ? (uint64_t)atoll(getenv("MM_BATCH_BASES")) : (512ull << 20);      /* env: test hook (many small batches) */
-	const uint32_t max_reads = 1u << 17;
-	const uint32_t n = mm_reads_count(reads);
-	{ uint32_t mx = 0; for(const HSeq &q : reads->r) mx = std::max<uint32_t>(mx, (uint32_t)q.seq.size()); for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, mx); a->qlen_hint = std::max(a->qlen_hint, mx); }
-	struct Slot { mm_batch_t *h = nullptr; bool ready = false, busy = false; };
-	Slot slot[2];
+	const int lanes = (int)std::max<uint32_t>(1, std::min<uint32_t>({ (uint32_t)lanes_want, n_batches, 8u }));
+	std::vector<mm_align_t *> ctx; { mm_align_t *q = a; for(int i = 0; i < lanes && q; i++) { ctx.push_back(q); if(i + 1 < lanes) q = align_lane(q); } }
+	if((int)ctx.size() < lanes || !ctx.back()) return 1;
+	/* host threads for post-map + text: -t when given, MM_HOST_THREADS, else up to 96; two finishers share them */
+	const uint32_t hw = std::max<uint32_t>(1, std::thread::hardware_concurrency());
+	const uint32_t fmt_total = getenv("MM_HOST_THREADS") ? (uint32_t)std::max(1, atoi(getenv("MM_HOST_THREADS"))) : (a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(hw, 96));
+	const int n_fin = fmt_total >= 8 ? 2 : 1;
+	struct Item { mm_batch_t *h = nullptr; Fetched f; std::vector<std::string> piece; uint32_t k = 0; };
 	std::mutex mu; std::condition_variable cv;
-	int rc = 0; bool done = false; uint32_t produced = 0;
-	/* the text of a finished batch goes to a writer thread, so that formatting the next batch does not wait for the output file (at most two batches queued) */
-	std::mutex wmu; std::condition_variable wcv; std::vector<std::vector<std::string>> wq; bool wdone = false;
-	std::thread writer([&]() {
+	uint32_t next_k = 0, verified = 0, next_write = 0, pending = 0; uint32_t carry = a->rlen_carry; int rc = 0;
+	std::vector<Item *> fetched;                       /* waiting for a finisher */
+	std::map<uint32_t, Item *> formatted;              /* waiting for the writer */
+	uint32_t lanes_done = 0, fin_done = 0; bool head_open = true;
+	const uint32_t max_pending = (uint32_t)lanes + 2;
+
+	auto lane_main = [&](int li) {
+		mm_align_t *c = ctx[li];
+		if(hipSetDevice(a->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); rc = 1; lanes_done++; cv.notify_all(); return; }
 		while(true) {
-			std::vector<std::string> piece;
-			{ std::unique_lock<std::mutex> lk(wmu); wcv.wait(lk, [&]() { return !wq.empty() || wdone; }); if(wq.empty()) return; piece = std::move(wq.front()); wq.erase(wq.begin()); }
-			wcv.notify_all();
-			double tv = now_ms(); size_t nb = 0;
-			for(auto &x : piece) { fwrite(x.data(), 1, x.size(), out); nb += x.size(); }
-			if(verbose) { fprintf(stderr, "[minialign_amd] write %.1f MB %.1f ms\n", nb * 1e-6, now_ms() - tv); }
+			uint32_t k, guess;
+			{ std::lock_guard<std::mutex> lk(mu); if(rc || next_k >= n_batches) break; k = next_k++; guess = carry; }
+			double tv = now_ms();
+			mm_batch_t *h = make(k);
+			bool ok = h != nullptr;
+			if(ok) {
+				h->ctx = c; Batch &b = h->b;
+				if(!b.packed) batch_pack(b);
+				c->rlen_carry = guess;
+				ok = batch_upload(c, b);
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): pack + upload %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
+				/* run ahead with the predicted carry; pools that overflow are grown here, before anybody waits for this batch */
+				while(ok) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0 || !batch_grow(c, b) || !batch_upload(c, b)) ok = false; }
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): run %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
+				uint32_t truth = 0;
+				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return verified == k || rc != 0; }); if(rc) ok = false; truth = carry; }
+				while(ok) {
+					c->rlen_carry = truth;
+					int r = batch_verify_carry(c, b);
+					if(r == 0) break;
+					/* an overflow among the re-runs: the whole batch again with larger pools, now with the true value from the start */
+					if(r < 0 || !batch_grow(c, b) || !batch_upload(c, b)) { ok = false; break; }
+					r = batch_run_spec(c, b); if(r < 0) { ok = false; }
+				}
+				if(ok) {
+					b.ran = true;
+					const uint32_t out = batch_carry_out(c, b, truth);
+					{
+						std::lock_guard<std::mutex> lk(mu); carry = out; verified = k + 1;
+						if(k == 0) { a->head.clear(); a->head_carry_in = truth; }
+						for(uint32_t i = 0; i < b.n && a->head.size() < 4096 && head_open; i++) { a->head.push_back(mm_align_s::HeadRec{ b.hst[i].apos0, b.hst[i].cond0, b.used[i], b.hst[i].rid_last }); }
+						if(a->head.size() >= 4096) head_open = false;
+					}
+					cv.notify_all();
+					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): carry wait + verify %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
+					/* the batch that is written next never waits here: everything queued in front of the writer is behind it */
+					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return pending < max_pending || k == next_write || rc != 0; }); if(rc) ok = false; else pending++; }
+				}
+				if(ok) {
+					Item *it = new Item(); it->h = h; it->k = k;
+					ok = batch_fetch(c, b, it->f);
+					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): D2H %.1f ms\n", k, li, now_ms() - tv); }
+					if(ok) { std::lock_guard<std::mutex> lk(mu); fetched.push_back(it); } else { delete it; std::lock_guard<std::mutex> lk(mu); pending--; }
+					cv.notify_all();
+				}
+			}
+			if(!ok) { std::lock_guard<std::mutex> lk(mu); rc = 1; if(h) release(h); cv.notify_all(); break; }
 		}
-	});
-	std::thread finisher([&]() {
-		if(hipSetDevice(a->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); rc = 1; cv.notify_all(); return; }
-		for(uint32_t k = 0;; k++) {
-			Slot &sl = slot[k & 1];
+		{ std::lock_guard<std::mutex> lk(mu); lanes_done++; }
+		cv.notify_all();
+	};
+	auto fin_main = [&]() {
+		while(true) {
+			Item *it = nullptr;
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv.wait(lk, [&]() { return sl.ready || (done && k >= produced) || rc != 0; });
-				if(!sl.ready) { return; }
+				cv.wait(lk, [&]() { return !fetched.empty() || lanes_done == (uint32_t)lanes; });
+				if(fetched.empty()) break;
+				/* the oldest batch first */
+				size_t best = 0; for(size_t i = 1; i < fetched.size(); i++) if(fetched[i]->k < fetched[best]->k) best = i;
+				it = fetched[best]; fetched.erase(fetched.begin() + best);
 			}
 			double tv = now_ms();
-			std::vector<std::string> piece; int r = 0;
-			mm_batch_t *h = sl.h;
-			if(!batch_finish_pieces(h->ctx, h->b, piece)) { r = 1; }
-			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: finish %.1f ms\n", k, now_ms() - tv); tv = now_ms(); }
-			if(r == 0) { std::unique_lock<std::mutex> lk(wmu); wcv.wait(lk, [&]() { return wq.size() < 2; }); wq.emplace_back(std::move(piece)); }
-			wcv.notify_all();
-			mm_batch_free(h);
-			{ std::lock_guard<std::mutex> lk(mu); sl.h = nullptr; sl.ready = false; sl.busy = false; if(r) rc = 1; }
+			batch_format(it->h->ctx, it->h->b, it->f, it->piece, std::max<uint32_t>(1, fmt_total / n_fin));
+			it->f = Fetched();
+			{ std::lock_guard<std::mutex> lk(mu); it->h->ctx->st.host_sam_ms += now_ms() - tv; formatted[it->k] = it; }
+			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: post-map + text %.1f ms\n", it->k, now_ms() - tv); }
 			cv.notify_all();
 		}
-	});
-	uint32_t carry = a->rlen_carry;
-	uint32_t i = 0;
-	for(uint32_t k = 0; i < n; k++) {
-		uint32_t j = i; uint64_t nb = 0;
-		while(j < n && j - i < max_reads && (nb == 0 || nb + reads->r[j].seq.size() <= max_bases)) { nb += reads->r[j].seq.size(); j++; }
-		Slot &sl = slot[k & 1];
-		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return !sl.busy || rc != 0; }); if(rc != 0) break; sl.busy = true; }
-		double tv = now_ms();
-		mm_batch_t *h = mm_batch_upload_lane(a, reads, i, j - i, (int)(k & 1));
-		if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: pack + upload %.1f ms\n", k, now_ms() - tv); tv = now_ms(); }
-		int r = 0;
-		if(!h) { r = 1; }
-		else {
-			h->ctx->rlen_carry = carry;
-			if(mm_batch_run(a, h)) { r = 1; }
-			else { for(uint32_t x = 0; x < h->b.n; x++) { if(h->b.hst[x].rid_last != gaba::NIL) carry = (uint32_t)a->mi->seq[h->b.hst[x].rid_last].seq.size(); } }
-		}
-		if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: run %.1f ms\n", k, now_ms() - tv); }
-		{
-			std::lock_guard<std::mutex> lk(mu);
-			if(r) { rc = 1; sl.busy = false; if(h) { mm_batch_free(h); } }
-			else { sl.h = h; sl.ready = true; produced = k + 1; }
-		}
+		{ std::lock_guard<std::mutex> lk(mu); fin_done++; }
 		cv.notify_all();
-		if(r) break;
-		i = j;
+	};
+	auto writer_main = [&]() {
+		while(true) {
+			Item *it = nullptr;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&]() { return formatted.count(next_write) || fin_done == (uint32_t)n_fin; });
+				auto f = formatted.find(next_write);
+				if(f == formatted.end()) break;
+				it = f->second; formatted.erase(f);
+			}
+			double tv = now_ms(); size_t nb = 0; for(auto &x : it->piece) nb += x.size();
+			const bool ok = rc == 0 ? sink(it->k, it->piece) : true;
+			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: written %.1f MB in %.1f ms\n", it->k, nb * 1e-6, now_ms() - tv); }
+			release(it->h); delete it;
+			{ std::lock_guard<std::mutex> lk(mu); next_write++; pending--; if(!ok) rc = 1; }
+			cv.notify_all();
+		}
+		/* whatever is left after an error */
+		std::lock_guard<std::mutex> lk(mu);
+		for(auto &kv : formatted) { release(kv.second->h); delete kv.second; } formatted.clear();
+	};
+	std::vector<std::thread> th;
+	for(int i = 0; i < lanes; i++) th.emplace_back(lane_main, i);
+	for(int i = 0; i < n_fin; i++) th.emplace_back(fin_main);
+	th.emplace_back(writer_main);
+	for(auto &t : th) t.join();
+	for(Item *it : fetched) { release(it->h); delete it; }
+	if(rc == 0) { for(mm_align_t *q = a; q; q = q->sib) q->rlen_carry = carry; }
+	return rc;
+}
+static void batch_fill(mm_batch_t *h, mm_reads_t const *r, uint32_t first, uint32_t last)
+{
+	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); h->b.rec.push_back(&r->r[i]); }
+}
+/* batch boundaries of a read set: bounded by bases (so that the device pools stay modest) and by reads */
+static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *reads, uint32_t first, uint32_t n)
+{
+	const uint64_t max_bases = getenv("MM_BATCH_BASES") ? (uint64_t)atoll(getenv("MM_BATCH_BASES")) : (512ull << 20);      /* env: test hook (many small batches) */
+	const uint32_t max_reads = 1u << 17;
+	const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)first + n, reads->r.size());
+	std::vector<std::pair<uint32_t, uint32_t>> sp;
+	for(uint32_t i = first; i < end;) {
+		uint32_t j = i; uint64_t nb = 0;
+		while(j < end && j - i < max_reads && (nb == 0 || nb + reads->r[j].seq.size() <= max_bases)) { nb += reads->r[j].seq.size(); j++; }
+		sp.emplace_back(i, j); i = j;
 	}
-	{ std::lock_guard<std::mutex> lk(mu); done = true; }
-	cv.notify_all();
-	finisher.join();
-	{ std::lock_guard<std::mutex> lk(wmu); wdone = true; }
-	wcv.notify_all();
-	writer.join();
-	a->rlen_carry = carry;
+	return sp;
+}
+static int default_lanes() { return getenv("MM_LANES") ? std::max(1, atoi(getenv("MM_LANES"))) : 3; }
+/* maps a parsed read set (consumed unless keep) and writes its records */
+static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
+{
+	const uint32_t n = mm_reads_count(reads);
+	{ uint32_t mx = 0; for(const HSeq &q : reads->r) mx = std::max<uint32_t>(mx, (uint32_t)q.seq.size()); for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, mx); }
+	const auto sp = batch_spans(reads, 0, n);
+	const int rc = stream_map(a, (uint32_t)sp.size(),
+		[&](uint32_t k) { mm_batch_t *h = new mm_batch_s(); batch_fill(h, reads, sp[k].first, sp[k].second); return h; },
+		[](mm_batch_t *h) { mm_batch_free(h); },
+		[&](uint32_t, std::vector<std::string> &piece) { for(auto &x : piece) { if(fwrite(x.data(), 1, x.size(), out) != x.size()) return false; } return true; },
+		default_lanes());
 	if(!keep) mm_reads_free(reads);
 	return rc;
+}
+/* the same engine behind the C-ABI: packed batches prepared ahead of time (bench.py: the timed region then starts from packed reads in host memory) or packed on
+ * the fly, text handed to a callback in input order */
+extern "C" mm_batch_t *mm_batch_pack(mm_reads_t const *r, uint32_t first, uint32_t n)
+{
+	mm_batch_t *h = new mm_batch_s();
+	batch_fill(h, r, first, (uint32_t)std::min<uint64_t>((uint64_t)first + n, r->r.size()));
+	batch_pack(h->b);
+	return h;
+}
+extern "C" uint32_t mm_batch_reads(mm_batch_t const *h) { return h->b.n; }
+/* every batch of reads [first, first + n) packed ahead of time, with the boundaries the streaming entries use; returns the count (at most max are made) */
+extern "C" uint32_t mm_batch_pack_all(mm_reads_t const *r, uint32_t first, uint32_t n, mm_batch_t **out, uint32_t max)
+{
+	const auto sp = batch_spans(r, first, n);
+	for(size_t k = 0; k < sp.size() && k < max; k++) { out[k] = mm_batch_pack(r, sp[k].first, sp[k].second - sp[k].first); }
+	return (uint32_t)sp.size();
+}
+/*
+ * A read set split over several contexts (one process per GPU, minialign_amd/multi.py): each part runs ahead with a guess for the carried reference length
+ * (minialign.c:3864) at its start; once the part in front has finished, mm_carry_check tells what the true value changes, from the head of the stream the
+ * context mapped last: 0 = nothing (every read made the same `apos >= rlen` decision and the chain of values has met the old one again), 1 = read
+ * *first_affected decides differently (re-map from there), 2 = the recorded head (4 096 reads) ran out before the chains met (re-map the part).
+ * mm_carry_after(i) is the value the chain had behind read i of that stream (what a re-mapped window must reproduce at its end to be spliced in).
+ */
+extern "C" int mm_carry_check(mm_align_t const *a, uint32_t truth, uint32_t *first_affected)
+{
+	uint32_t cur = truth, old = a->head_carry_in;
+	if(first_affected) *first_affected = 0;
+	if(cur == old) return 0;
+	for(size_t i = 0; i < a->head.size(); i++) {
+		const mm_align_s::HeadRec &h = a->head[i];
+		/* the read ran with h.used (the old chain value, predicted and verified); with `cur` in its place the one test that reads it is apos0 >= rlen */
+		if(h.apos0 != gaba::NIL && !h.cond0 && ((h.apos0 >= h.used) != (h.apos0 >= cur))) { if(first_affected) *first_affected = (uint32_t)i; return 1; }
+		if(h.rid_last != gaba::NIL) return 0;          /* both chains continue from the length of this reference */
+	}
+	return 2;
+}
+extern "C" uint32_t mm_carry_after(mm_align_t const *a, uint32_t i)
+{
+	uint32_t cur = a->head_carry_in;
+	for(size_t j = 0; j <= i && j < a->head.size(); j++) { if(a->head[j].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[a->head[j].rid_last].seq.size(); }
+	return cur;
+}
+extern "C" int mm_map_packed(mm_align_t *a, mm_batch_t *const *batches, uint32_t n_batches, int lanes, mm_sam_sink_t sink, void *opaque)
+{
+	uint32_t mx = 0; for(uint32_t k = 0; k < n_batches; k++) mx = std::max(mx, batches[k]->b.max_qlen);
+	for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, mx);
+	return stream_map(a, n_batches, [&](uint32_t k) { return batches[k]; }, [](mm_batch_t *) {},
+		[&](uint32_t k, std::vector<std::string> &piece) { for(auto &x : piece) { if(sink && sink(opaque, k, x.data(), x.size())) return false; } return true; }, lanes > 0 ? lanes : default_lanes());
+}
+extern "C" int mm_map_reads(mm_align_t *a, mm_reads_t const *reads, uint32_t first, uint32_t n, int lanes, mm_sam_sink_t sink, void *opaque)
+{
+	const auto sp = batch_spans(reads, first, n);
+	uint32_t mx = 0; for(auto &q : sp) for(uint32_t i = q.first; i < q.second; i++) mx = std::max<uint32_t>(mx, (uint32_t)reads->r[i].seq.size());
+	for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, mx);
+	return stream_map(a, (uint32_t)sp.size(),
+		[&](uint32_t k) { mm_batch_t *h = new mm_batch_s(); batch_fill(h, reads, sp[k].first, sp[k].second); return h; },
+		[](mm_batch_t *h) { mm_batch_free(h); },
+		[&](uint32_t k, std::vector<std::string> &piece) { for(auto &x : piece) { if(sink && sink(opaque, k, x.data(), x.size())) return false; } return true; }, lanes > 0 ? lanes : default_lanes());
 }
 
 namespace {
@@ -1777,7 +2017,8 @@ extern "C" int mm_main(int argc, char **argv)
 	const char *files[64]; int nf = 0;
 	const int prc = mm_opt_parse(o, argc, (char const *const *)argv, files, 63, &nf);
 	if(prc || nf < 1 || o->help) {
-		/* -h: the text goes to stdout and the exit status is 0 (minialign.c:6466-6470); no input file or a bad option: stderr, 1 */
+		/* -h: the text goes to stdout (minialign.c:6466-6470); the exit status is 1 either way -- the reference sets 0 for -h and then overwrites it with the
+		 * return value of mm_print_help, which is 1 once the text is printed (minialign.c:6469, 6301) */
 		FILE *hf = (!prc && o->help) ? stdout : stderr;
 		fprintf(hf, "usage: minialign [-x preset] [options] [-d idx.mai] ref.{fa,fa.gz,mai} reads.{fa,fq}[.gz] ... > out.sam\n"
 			"  presets    -x pacbio[.clr|.ccs] | ont[.r7|.r9[.4|.5[.1]]][.1d|.1dsq|.2d] | ava\n"
@@ -1786,7 +2027,7 @@ extern "C" int mm_main(int argc, char **argv)
 			"  mapping    -s INT  -m FLOAT  -W INT  -G INT  -X  -A  -C [INT,INT]\n"
 			"  output     -O sam|maf|blast6|paf  -T TAG,...  -R '@RG\\tID:...'  -Q  -P\n"
 			"  accepted   -t INT  -v [INT]  -1 INT  -2 INT  -h\n");
-		const int ret = (!prc && o->help) ? 0 : 1;
+		const int ret = 1;
 		mm_opt_destroy(o); return ret;
 	}
 	double t0 = now_ms();

@@ -1,0 +1,200 @@
+"""One read set over N GPUs: one process per GPU (torch.distributed), reads sharded contiguously, the index replicated into every GPU's HBM, no
+collective on the data path (BASELINE.json north_star).  Output order = rank order, as the reference's drain keeps input order
+(mm_align_drain, minialign.c:4633-4645).
+
+The one thing reads share in the reference is `self->rlen` of its thread buffer (minialign.c:3864, DESIGN.md 5: the `apos >= rlen` test of
+mm_search_load_pos reads the length of the reference sequence the *previous* read loaded last).  A shard therefore starts from the value the shard in
+front of it ends with.  Every rank maps its shard right away with a guess for that value, the ranks then exchange what their shards ended with (one tiny
+all_gather), and a rank whose guess was wrong asks the library what the true value changes (mm_carry_check, from the `apos`, the decision and the reference
+of the first reads): almost always nothing; otherwise the head of the shard is mapped again from the first read that decides differently, in a window that
+is doubled until the chain of values meets the old one again (mm_carry_after), and the new records replace the old ones.  A changed end value travels on to
+the next rank in the next sweep; N - 1 sweeps at most, one in practice.
+
+    python -m torch.distributed.run --nproc-per-node N -m minialign_amd.multi [-x preset ...] ref.fa reads.fa > out.sam
+
+This module holds the host logic only; the hot path is libminialign_amd.so (HIP), reached through the C-ABI of include/minialign.h."""
+import ctypes, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64)
+
+
+def load_library(path=None):
+    path = path or os.environ.get('MM_LIB_OVERRIDE') or os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')
+    if not os.path.exists(path):
+        raise RuntimeError('libminialign_amd.so is not built (run __graft_entry__.build()); there is no CPU fallback')
+    L = ctypes.CDLL(path)
+    for f in ('mm_opt_init', 'mm_idx_gen', 'mm_align_init', 'mm_reads_load', 'mm_batch_pack'): getattr(L, f).restype = ctypes.c_void_p
+    L.mm_reads_bases.restype = ctypes.c_uint64; L.mm_reads_name.restype = ctypes.c_char_p
+    L.mm_reads_name.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    L.mm_reads_bases.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    L.mm_reads_count.argtypes = [ctypes.c_void_p]; L.mm_reads_append.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.mm_align_get_carry.argtypes = [ctypes.c_void_p]; L.mm_align_get_carry.restype = ctypes.c_uint32
+    L.mm_align_set_carry.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_align_set_carry.restype = None
+    L.mm_carry_check.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    L.mm_carry_after.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_carry_after.restype = ctypes.c_uint32
+    L.mm_map_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, SINK, ctypes.c_void_p]
+    L.mm_map_packed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, SINK, ctypes.c_void_p]
+    L.mm_batch_pack_all.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]; L.mm_batch_pack_all.restype = ctypes.c_uint32
+    L.mm_batch_free.argtypes = [ctypes.c_void_p]; L.mm_batch_free.restype = None
+    L.mm_idx_max_len.argtypes = [ctypes.c_void_p]; L.mm_idx_max_len.restype = ctypes.c_uint32
+    return L
+
+
+def shard_bounds(n_units, rank, world):
+    """contiguous, as-even-as-possible split of n_units; rank r gets [lo, hi)"""
+    base, rem = divmod(n_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class Collector:
+    """the sink of the streaming entries: keeps the text (keep = None: all of it; keep = N: the first N bytes only) and counts everything"""
+    def __init__(self, keep=None):
+        self.keep = keep; self.pieces = []; self.kept = 0; self.total = 0
+        self.cb = SINK(self._sink)
+    def _sink(self, opaque, batch, ptr, n):
+        self.total += n
+        if self.keep is None or self.kept < self.keep:
+            self.pieces.append(ctypes.string_at(ptr, n)); self.kept += n
+        return 0
+    def complete(self): return self.keep is None or self.total == self.kept
+    def text(self): return b''.join(self.pieces)
+
+
+def _head_cut(text, names):
+    """byte offset behind the records of the reads named in `names` at the start of `text` (a read's records are consecutive lines that start with its name;
+    a read may have no record at all); None when the text ends inside them"""
+    pos = 0
+    while pos < len(text):
+        tab = text.find(b'\t', pos); eol = text.find(b'\n', pos)
+        if eol < 0: return None
+        q = text[pos:tab if 0 <= tab < eol else eol]
+        if q not in names: return pos
+        pos = eol + 1
+    return None
+
+
+class ShardMapper:
+    """maps reads [first, first + n) of a loaded read set on this process' device and settles the carried value with the other ranks"""
+    def __init__(self, L, al, reads, first, n, lanes=0, packed=None, keep=None, guess=0):
+        self.L, self.al, self.reads, self.first, self.n, self.lanes, self.packed, self.keep, self.guess = L, al, reads, first, n, lanes, packed, keep, guess
+        self.col = None; self.carry_in = None; self.carry_out = None; self._stale = False; self.stats = dict(sweeps=0, checks=0, remapped_reads=0, full_remaps=0)
+
+    def _map(self, first, n, carry_in, keep, packed=None):
+        col = Collector(keep)
+        self.L.mm_align_set_carry(self.al, carry_in)
+        if packed is not None:
+            arr = (ctypes.c_void_p * len(packed))(*packed)
+            rc = self.L.mm_map_packed(self.al, arr, len(packed), self.lanes, col.cb, None)
+        else:
+            rc = self.L.mm_map_reads(self.al, self.reads, first, n, self.lanes, col.cb, None)
+        if rc != 0: raise RuntimeError('mapping failed (rc %d)' % rc)
+        return col, self.L.mm_align_get_carry(self.al)
+
+    def map(self, carry_in=None):
+        self.carry_in = self.guess if carry_in is None else carry_in
+        self.col, self.carry_out = self._map(self.first, self.n, self.carry_in, self.keep, self.packed); self._stale = False
+        return self
+
+    def _name(self, j): return self.L.mm_reads_name(self.reads, self.first + j)
+
+    def _settle_local(self, truth):
+        """this shard against the true value at its start; returns True if the value at its end changed"""
+        if truth == self.carry_in: return False
+        old_out = self.carry_out
+        self.stats['checks'] += 1
+        fa = ctypes.c_uint32(0)
+        rc = 2 if self._stale else self.L.mm_carry_check(self.al, truth, ctypes.byref(fa))
+        if rc == 0: self.carry_in = truth; return False
+        if rc == 1 and self.n > 0:
+            # read i0 is the first that decides differently: map a window [i0, i0 + m) again with the true value and splice its records in as soon as the
+            # chain of values behind the window is what it was (then nothing behind it changes); m doubles while it is not
+            i0 = fa.value; limit = min(self.n, 4096)
+            ends = []; m = 64
+            while i0 + m <= limit: ends.append(m); m *= 2
+            after = {m: self.L.mm_carry_after(self.al, i0 + m - 1) for m in ends}       # read now: a window run replaces the record these come from
+            text = self.col.text(); names = set(self._name(j) for j in range(i0))
+            cut_lo = _head_cut(text, names) if i0 else 0; done = i0
+            for m in ends:
+                names.update(self._name(j) for j in range(done, i0 + m)); done = i0 + m
+                cut_hi = _head_cut(text, names)
+                if cut_lo is None or cut_hi is None: break                            # beyond the text that was kept
+                col, out = self._map(self.first + i0, m, truth, None); self._stale = True
+                self.stats['remapped_reads'] += m
+                if out == after[m]:
+                    new = col.text()
+                    self.col.pieces = [text[:cut_lo], new, text[cut_hi:]]
+                    self.col.kept += len(new) - (cut_hi - cut_lo); self.col.total += len(new) - (cut_hi - cut_lo)
+                    self.carry_in = truth
+                    return False
+        # undecided inside the recorded head, or the window outgrew what can be spliced: the whole shard again with the true value
+        self.stats['full_remaps'] += 1
+        self.col, self.carry_out = self._map(self.first, self.n, truth, self.keep, self.packed)
+        self.carry_in = truth; self._stale = False
+        return self.carry_out != old_out
+
+    def settle(self, dist=None, rank=0, world=1, initial=0, device=None):
+        """exchange end values until every shard has run with the value the shard in front of it ended with"""
+        if world == 1:
+            self._settle_local(initial); return self
+        import torch
+        for sweep in range(world):
+            t = torch.tensor([self.carry_out, 1 if self.n > 0 else 0], dtype=torch.int64, device=device or 'cpu')
+            outs = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            outs = [(int(o[0]), int(o[1])) for o in outs]
+            # the value in front of rank r: the end value of the nearest non-empty shard before it (an empty shard passes its start value on)
+            truth = initial
+            for r in range(rank):
+                if outs[r][1]: truth = outs[r][0]
+            changed = self._settle_local(truth)
+            self.stats['sweeps'] = sweep + 1
+            flag = torch.tensor([1 if changed else 0], dtype=torch.int64, device=device or 'cpu')
+            dist.all_reduce(flag)
+            if int(flag[0]) == 0: break
+        return self
+
+
+def main(argv=None):
+    """torchrun entry: every rank maps its shard, rank 0 prints header + all records in rank order"""
+    import torch, torch.distributed as dist
+    argv = list(sys.argv[1:] if argv is None else argv)
+    # the records go to the process' real standard output; whatever libraries print there meanwhile (gloo announces its connections on stdout) goes to stderr
+    sys.stdout.flush(); out_fd = os.dup(1); os.dup2(2, 1)
+    rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
+    same_dev = os.environ.get('MM_MULTI_SAME_DEVICE') is not None          # test hook: every rank on device 0, gloo group
+    dev = 0 if same_dev else local
+    if world > 1: dist.init_process_group('gloo' if same_dev else 'nccl')
+    if world > 1 and not same_dev: torch.cuda.set_device(dev)
+    L = load_library()
+    if L.mm_set_device(dev) != 0: raise RuntimeError('no HIP device %d' % dev)
+    o = ctypes.c_void_p(L.mm_opt_init())
+    args = [b'minialign'] + [a.encode() for a in argv]
+    av = (ctypes.c_char_p * len(args))(*args); files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
+    if L.mm_opt_parse(o, len(args), av, files, 8, ctypes.byref(nf)) != 0 or nf.value != 2: raise SystemExit('usage: minialign_amd.multi [options] ref.fa reads.fa')
+    mi = ctypes.c_void_p(L.mm_idx_gen(o, files[0])); al = ctypes.c_void_p(L.mm_align_init(o, mi)) if mi else None
+    if not al: raise RuntimeError('index / device context failed')
+    reads = ctypes.c_void_p(L.mm_reads_load(files[1]))
+    if not reads: raise RuntimeError('cannot read %r' % files[1])
+    lo, hi = shard_bounds(L.mm_reads_count(reads), rank, world)
+    sm = ShardMapper(L, al, reads, lo, hi - lo, guess=L.mm_idx_max_len(mi)).map()
+    sm.settle(dist if world > 1 else None, rank, world, 0, torch.device('cuda', dev) if (world > 1 and not same_dev) else None)
+    body = sm.col.text()
+    if world > 1:
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(body, parts, dst=0)
+    else: parts = [body]
+    if rank == 0:
+        libc = ctypes.CDLL(None); libc.fdopen.restype = ctypes.c_void_p; libc.fclose.argtypes = [ctypes.c_void_p]
+        fp = ctypes.c_void_p(libc.fdopen(os.dup(out_fd), b'w'))
+        L.mm_print_sam_header.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
+        L.mm_print_sam_header(al, fp, b' '.join(args)); libc.fclose(fp)
+        with os.fdopen(out_fd, 'wb') as out:
+            for p in parts: out.write(p)
+        sys.stderr.write('[minialign_amd.multi] %d rank(s); carried value: %r\n' % (world, sm.stats))
+    if world > 1: dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

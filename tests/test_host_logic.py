@@ -1,5 +1,5 @@
 """CPU tests (no GPU): the C-ABI library loads and exports every symbol the headers declare; the multi-GPU host logic
-(sharding, ordered merge, carried-state chain, timing reduction) under a 2-process gloo group."""
+(sharding, settling the carried value between ranks, merge in rank order) under 2- and 3-process gloo groups."""
 import ctypes, os, re, subprocess, sys
 import pytest
 
@@ -22,44 +22,92 @@ def test_library_exports_every_declared_symbol():
     assert not missing, 'declared in include/*.h but not exported: %r' % missing
 
 def test_shard_bounds_cover_everything_once():
-    from minialign_amd.shard import shard_bounds
-    for n in (0, 1, 7, 8, 1000, 22308):
+    from minialign_amd.multi import shard_bounds
+    for n in (0, 1, 7, 8, 16, 1000, 22308):
         for world in (1, 2, 3, 8):
             spans = [shard_bounds(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
 
-def _worker(rank, world, port, q):
+
+class FakeLib:
+    """a stand-in for libminialign_amd.so with the same carried-value structure as the mapper (minialign.c:3864): read i tests `apos0 >= carried`, its records
+    and the reference it loads last depend on that decision, the carried value behind it is the length of that reference (or unchanged when it loads none).
+    Lets the settling protocol of minialign_amd/multi.py run under a gloo group without a GPU."""
+    NIL = 0xffffffff
+    def __init__(self, n, seed):
+        import random
+        rnd = random.Random(seed)
+        self.lens = [1000 * (i + 1) for i in range(12)]
+        self.reads = [dict(name=b'r%d' % i, apos0=(self.NIL if rnd.random() < 0.1 else rnd.randrange(0, 13000)), cond0=int(rnd.random() < 0.05),
+                           r_no=(self.NIL if rnd.random() < 0.15 else rnd.randrange(12)), r_yes=rnd.randrange(12), lines=rnd.randrange(0, 3)) for i in range(n)]
+        self.carry = 0; self.head = []; self.head_in = 0
+    def _one(self, i, cur):
+        r = self.reads[i]
+        dec = r['apos0'] != self.NIL and not r['cond0'] and r['apos0'] >= cur
+        rid = r['r_yes'] if dec else r['r_no']
+        text = b''.join(b'%s\t%d\t%d\t%d\n' % (r['name'], j, int(dec), rid) for j in range(r['lines']))
+        return text, rid
+    def mm_align_set_carry(self, al, v): self.carry = v
+    def mm_align_get_carry(self, al): return self.carry
+    def mm_reads_name(self, reads, i): return self.reads[i]['name']
+    def mm_map_reads(self, al, reads, first, n, lanes, cb, opaque):
+        import ctypes
+        cur = self.carry; self.head = []; self.head_in = cur; out = []
+        for i in range(first, first + n):
+            text, rid = self._one(i, cur)
+            self.head.append((self.reads[i]['apos0'], self.reads[i]['cond0'], cur, rid)); out.append(text)
+            if rid != self.NIL: cur = self.lens[rid]
+        self.carry = cur
+        for k in range(0, len(out), 50):
+            piece = b''.join(out[k:k + 50]); buf = ctypes.create_string_buffer(piece, len(piece))
+            cb(None, k // 50, ctypes.addressof(buf), len(piece))
+        return 0
+    def mm_carry_check(self, al, truth, fa):
+        cur = truth
+        if cur == self.head_in: return 0
+        for i, (apos0, cond0, used, rid) in enumerate(self.head[:4096]):
+            if apos0 != self.NIL and not cond0 and ((apos0 >= used) != (apos0 >= cur)):
+                fa._obj.value = i; return 1
+            if rid != self.NIL: return 0
+        return 2
+    def mm_carry_after(self, al, i):
+        cur = self.head_in
+        for (_, _, _, rid) in self.head[:i + 1]:
+            if rid != self.NIL: cur = self.lens[rid]
+        return cur
+
+def _settle_worker(rank, world, port, n, seed, q):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
-    from minialign_amd.shard import shard_bounds, merge_in_order, carry_chain, reduce_timing
+    from minialign_amd import multi
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    lo, hi = shard_bounds(11, rank, world)
-    body = b''.join(b'read%d\n' % i for i in range(lo, hi))
-    gathered = [None] * world
-    dist.all_gather_object(gathered, body)
-    merged = merge_in_order(gathered)
-    # rank 0's shard ends having loaded a 1234-long reference, rank 1's shard never loads one
-    start = carry_chain(dist, 1 if rank == 0 else 0, 1234 if rank == 0 else 0, initial=77)
-    sec, units = reduce_timing(dist, 1.0 + rank, 100 * (rank + 1))
+    L = FakeLib(n, seed); lo, hi = multi.shard_bounds(n, rank, world)
+    sm = multi.ShardMapper(L, None, None, lo, hi - lo, guess=7777 if rank else 0).map()
+    sm.settle(dist, rank, world, 0, None)
+    parts = [None] * world
+    dist.all_gather_object(parts, sm.col.text())
     dist.barrier(); dist.destroy_process_group()
-    q.put((rank, merged, start, sec, units))
+    q.put((rank, b''.join(parts), sm.stats))
 
-def test_two_process_gloo_group():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize('world,n,seed', [(2, 700, 1), (3, 1000, 2), (3, 130, 3), (2, 3, 4)])
+def test_sharded_settling_protocol_under_gloo(world, n, seed):
+    """minialign_amd/multi.py over a gloo group (CPU): shards started from a guess, end values exchanged, heads re-mapped in doubling windows or whole shards
+    re-mapped, until the merged text is what one stream over all reads gives"""
+    import ctypes, torch.multiprocessing as mp
+    one = FakeLib(n, seed); got = []
+    one.mm_map_reads(None, None, 0, n, 1, lambda o, k, p, ln: got.append(ctypes.string_at(p, ln)) or 0, None)
+    want = b''.join(got)
     ctx = mp.get_context('spawn'); q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    ps = [ctx.Process(target=_settle_worker, args=(r, world, port, n, seed, q)) for r in range(world)]
     for p in ps: p.start()
-    res = sorted(q.get(timeout=120) for _ in ps)
+    res = sorted(q.get(timeout=180) for _ in ps)
     for p in ps: p.join(60)
-    want = b''.join(b'read%d\n' % i for i in range(11))
-    assert res[0][1] == want and res[1][1] == want          # contiguous shards concatenate to input order
-    assert res[0][2] == 77 and res[1][2] == 1234            # rank 1 starts from what rank 0 ended with
-    assert res[0][3] == 2.0 and res[1][3] == 2.0            # MAX over ranks
-    assert res[0][4] == 300.0 and res[1][4] == 300.0        # SUM over ranks
+    assert all(r[1] == want for r in res), [r[2] for r in res]
+    assert sum(r[2]['checks'] for r in res) > 0
 
 
 def test_product_cigar_known_answers():
@@ -247,3 +295,44 @@ def test_headers_stand_alone_and_a_c_caller_links(tmp_path):
     r = subprocess.run(['gcc', '-std=gnu99', '-Wall', '-I', inc, str(src), '-o', str(tmp_path / 'caller'), '-L', lib, '-lminialign_amd',
                         '-Wl,-rpath,' + lib, '-Wl,--allow-shlib-undefined'], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[:3000]
+
+
+def test_host_mm_sketch_matches_oracle_stream():
+    """mm_sketch (minialign.c:2410) exported on the host: the stream words (hash << 8 | strand << 7 | index in the block of w) against the oracle's restatement,
+    N runs included, and the decoded positions against the stream decoder's rule (minialign.c:2831-2835)"""
+    import numpy as np, mmlib as M
+    L = ctypes.CDLL(os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so'))
+    ora = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'liboracle.so')); ora.om_sketch.restype = ctypes.c_uint64
+    rng = np.random.default_rng(5)
+    for (w, k, n) in ((10, 15, 5000), (5, 15, 3000), (10, 15, 14), (10, 15, 15), (10, 15, 40), (3, 7, 400), (16, 21, 6000)):
+        seq = rng.integers(0, 4, n).astype(np.uint8)
+        if n > 1000: seq[700:760] = 4; seq[n // 2] = 4
+        want = np.zeros(n + 512, dtype=np.uint64)
+        nw = ora.om_sketch(w, k, seq.ctypes.data_as(ctypes.c_void_p), n, want.ctypes.data_as(ctypes.c_void_p))
+        got = np.zeros(n + 512, dtype=np.uint64); pos = np.zeros(n + 512, dtype=np.uint32)
+        ng = L.mm_sketch(seq.ctypes.data_as(ctypes.c_void_p), n, w, k, got.ctypes.data_as(ctypes.c_void_p), pos.ctypes.data_as(ctypes.c_void_p), n + 512)
+        assert ng == nw and (got[:ng] == want[:nw]).all(), (w, k, n)
+        base = -w; prev = w; dec = []
+        for v in want[:nw]:                       # the decoder of minialign.c:2831-2835
+            lu = int(v) & 0x7f
+            if lu <= prev: base += w
+            prev = lu; dec.append(base + lu)
+        assert dec == [int(p) for p in pos[:ng]], (w, k, n)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'minialign')), reason='oracle/_ref not built (needs /root/reference)')
+def test_option_words_are_walked_as_the_reference_walks_them(tmp_path):
+    """mm_opt_parse_argv (minialign.c:5786-5812) and mm_opt_atoi (:5745): clustered boolean letters, an option behind them, required arguments that look like
+    options, unparsable numbers -- same accept / reject decision as the compiled reference (`-d` runs: index only, no GPU)"""
+    import mmlib as M
+    ref = str(tmp_path / 'ref.fa'); M.gensim('genome', 31, 30000, 1, 0.0, out=ref)
+    cli = os.path.join(ROOT, 'minialign_amd', 'minialign'); refbin = os.path.join(ROOT, 'oracle', '_ref', 'minialign')
+    lines = [['-XA'], ['-PQ'], ['-Qxpacbio'], ['-XAk14'], ['-k15x'], ['-s', '-5'], ['-k', '15'], ['-PQw', '8'], ['-Z'], ['-k'], ['-w7', '-k13'], ['-r3,x'], ['-m0.3'], ['-m0,3x'],
+             ['-f0.05,0.01'], ['-f0.01,0.05'], ['-Xh'], ['-c'], ['-c', 'ctg0000'], ['-xpacbio.ccs'], ['-xont.r9.4.1dsq'], ['-xnone'], ['-t', '2'], ['-t2x'], ['-Y60', '-p5']]
+    for ln in lines:
+        rc = []
+        for exe in (refbin, cli):
+            out = str(tmp_path / ('x_%s.mai' % ('r' if exe is refbin else 'o')))
+            r = subprocess.run([exe] + ln + ['-d', out, ref], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            rc.append(r.returncode != 0)
+        assert rc[0] == rc[1], (ln, rc)

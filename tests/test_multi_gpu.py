@@ -1,0 +1,67 @@
+"""GPU: the streaming engine (several batches in flight, carried reference length verified in batch order) and the sharded multi-process path
+(minialign_amd/multi.py: one read set split over ranks, the carried value settled between them, records merged in rank order) must give the bytes the
+single stream gives -- on many-contig references, the case where the carried value (minialign.c:3864) bites."""
+import ctypes, os, subprocess, sys, tempfile
+import pytest
+import mmlib as M
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(M.ROOT, 'minialign_amd', 'minialign')
+
+def _strip_pg(sam): return b''.join(l for l in sam.splitlines(True) if not l.startswith(b'@PG'))
+def _body(sam): return b''.join(l for l in sam.splitlines(True) if not l.startswith(b'@'))
+
+@pytest.fixture(scope='module')
+def data():
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
+        M.gensim('genome', 7301, 3000000, 25, 0.08, out=ref)                          # 25 contigs of very different lengths
+        M.gensim('reads', 7302, ref, 1.2, 'pacbio', 'fa', 5000, 2000, out=rd)       # about 700 reads
+        want = subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign'), '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+        yield ref, rd, _strip_pg(want)
+
+@pytest.mark.parametrize('lanes,batch', [(1, 400000), (3, 250000), (4, 60000)])
+def test_batches_in_flight_give_the_single_stream(data, lanes, batch):
+    """many small batches on 1 / 3 / 4 lanes: every batch runs ahead with a predicted carried value and is verified in order"""
+    ref, rd, want = data
+    env = dict(os.environ, MM_BATCH_BASES=str(batch), MM_LANES=str(lanes), MM_SLAB_GB='6')
+    r = subprocess.run([CLI, '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert _strip_pg(r.stdout) == want
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_one_read_set_split_over_ranks_on_one_gpu(data, world):
+    """world_size 2 and 3 with every rank on cuda:0 (gloo group): shards mapped with a guessed carried value, settled with the true one (checks, window
+    re-maps), merged in rank order == the single stream"""
+    ref, rd, want = data
+    env = dict(os.environ, MM_MULTI_SAME_DEVICE='1', MM_SLAB_GB='4', MM_LANES='2', MM_BATCH_BASES='600000', PYTHONPATH=M.ROOT)
+    port = 29600 + os.getpid() % 1500 + world
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        '-m', 'minialign_amd.multi', '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=M.ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert _body(r.stdout) == _body(want), r.stderr.decode()[-1500:]
+
+def test_settling_a_wrong_guess_remaps_only_the_head(data):
+    """a shard started with a deliberately wrong carried value: mm_carry_check names the first read that decides differently (or says that nothing does),
+    the window re-map splices the new records in, and the text equals a run that started with the right value"""
+    from minialign_amd import multi
+    ref, rd, want = data
+    os.environ.setdefault('MM_SLAB_GB', '6')
+    L = multi.load_library(); assert L.mm_set_device(0) == 0
+    o = ctypes.c_void_p(L.mm_opt_init()); argv = (ctypes.c_char_p * 4)(b'minialign', b'-xpacbio', ref.encode(), rd.encode()); files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
+    assert L.mm_opt_parse(o, 4, argv, files, 8, ctypes.byref(nf)) == 0
+    mi = ctypes.c_void_p(L.mm_idx_gen(o, ref.encode())); al = ctypes.c_void_p(L.mm_align_init(o, mi)); assert al
+    reads = ctypes.c_void_p(L.mm_reads_load(rd.encode())); n = L.mm_reads_count(reads)
+    body = _body(want)
+    tried = 0
+    for first in (0, 97, 211, 330):
+        # the truth at `first`: what a stream over reads [0, first) leaves behind
+        sm0 = multi.ShardMapper(L, al, reads, 0, first, lanes=2).map(0); truth = sm0.carry_out
+        right = multi.ShardMapper(L, al, reads, first, n - first, lanes=2).map(truth).col.text()
+        assert sm0.col.text() + right == body
+        for guess in (0, 1, L.mm_idx_max_len(mi)):
+            sm = multi.ShardMapper(L, al, reads, first, n - first, lanes=2, guess=guess).map()
+            sm.settle(None, 0, 1, truth)
+            assert sm.col.text() == right, (first, guess, sm.stats)
+            tried += sm.stats['remapped_reads'] > 0
+    assert tried > 0, 'no case exercised the window re-map'

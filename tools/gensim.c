@@ -5,6 +5,9 @@
  *
  *   gensim genome <seed> <total_len> <n_contigs> <repeat_frac> > ref.fa
  *   gensim reads  <seed> ref.fa <depth> <pacbio|ont> [fq] [len_mean len_sd] > reads.fa
+ *   gensim reads  <seed> ref.fa <depth> <pacbio|ont> <fa|fq> <len_mean> <len_sd> <part> <n_parts> > reads.part.fa
+ *       one of n_parts independent streams (seed + part, depth / n_parts each, read names r<part>.<i>_...): the parts are generated side by side and the
+ *       read set is their concatenation in part order -- bench.py builds the 9.2 Gb set of the headline workload this way
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -77,12 +80,14 @@ static char comp(char c) { switch(c) { case 'A': return 'T'; case 'C': return 'G
 static int main_reads(int argc, char **argv)
 {
 	if(argc < 6) return 1;
-	seed_rng(strtoull(argv[2], 0, 0));
+	int part = argc > 10 ? atoi(argv[9]) : -1, n_parts = argc > 10 ? atoi(argv[10]) : 1;
+	if(n_parts < 1 || part >= n_parts) return 1;
+	seed_rng(strtoull(argv[2], 0, 0) + (part >= 0 ? 0x9e3779b97f4a7c15ULL * (uint64_t)(part + 1) : 0));
 	int nc; ctg_t *c = load_fasta(argv[3], &nc);
 	double depth = atof(argv[4]); int ont = strcmp(argv[5], "ont") == 0; int fq = argc > 6 && strcmp(argv[6], "fq") == 0;
 	double lm = argc > 8 ? atof(argv[7]) : 20000.0, lsd = argc > 8 ? atof(argv[8]) : 2000.0;
 	uint64_t total = 0; for(int i = 0; i < nc; i++) total += c[i].len;
-	uint64_t want = (uint64_t)(depth * total), made = 0, id = 0;
+	uint64_t want = (uint64_t)(depth * total / n_parts), made = 0, id = 0;
 	char *buf = malloc(4 * 1000000 + 16), *qb = malloc(4 * 1000000 + 16);
 	while(made < want) {
 		double len_d; 
@@ -109,7 +114,9 @@ static int main_reads(int argc, char **argv)
 			while(unif() < pi && n < 3900000) { buf[n++] = "ACGT"[rnd() >> 62]; }
 		}
 		buf[n] = 0;
-		char name[128]; sprintf(name, "r%lu_%s_%lu_%lu_%c_%.3f", (unsigned long)id, c[ci].name, (unsigned long)p, (unsigned long)(p + len), rev ? '-' : '+', acc);
+		char name[160];
+		if(part >= 0) sprintf(name, "r%d.%lu_%s_%lu_%lu_%c_%.3f", part, (unsigned long)id, c[ci].name, (unsigned long)p, (unsigned long)(p + len), rev ? '-' : '+', acc);
+		else sprintf(name, "r%lu_%s_%lu_%lu_%c_%.3f", (unsigned long)id, c[ci].name, (unsigned long)p, (unsigned long)(p + len), rev ? '-' : '+', acc);
 		if(fq) { for(uint64_t i = 0; i < n; i++) qb[i] = (char)('!' + 5 + below(20)); qb[n] = 0; printf("@%s\n%s\n+\n%s\n", name, buf, qb); }
 		else { printf(">%s\n%s\n", name, buf); }
 		made += n; id++;
