@@ -521,6 +521,218 @@ __global__ void __launch_bounds__(64) mm_sort_chain_kernel(K2Args a)
 	st->pred_rid = pred;
 }
 
+typedef __attribute__((address_space(3))) Seed LSeed;
+typedef __attribute__((address_space(3))) uint32_t LU32;
+/* -----------------------------------------------------------------------------------------------------
+ * K2s: radix_sort_128x (ksort.h:84-131) of the seed array, one wavefront per read, as a permutation of small indices.
+ *
+ * The reference's sort is an MSD radix sort with an in-place cycle-leader permutation per level (unstable: its exact element order decides ties) and a
+ * stable insertion sort for buckets of <= 64.  Which element ends where in one level depends on the digits alone, so the level is replayed on 4-byte
+ * entries (digit << 16 | index of the seed) in LDS instead of on the 16-byte seeds: 4 B of LDS per seed, which lets a CU hold a dozen reads instead of
+ * three -- the replay is a chain of dependent LDS round trips, and the only way to make it cheap is to have many of them in flight.  The 64-bit keys stay
+ * where K1 wrote them (HBM / L2) and are fetched once per level, 64 at a time; the stable sort of the small buckets is a rank computation (lane = element,
+ * shuffles over its bucket; a stable sort has one answer, so any stable method gives the insertion sort's); the seeds themselves move once, at the end.
+ * ----------------------------------------------------------------------------------------------------- */
+constexpr uint32_t K2S_MAX_N = 32768;                  /* seeds + sentinel a read may have here (index field of an entry, range stack); larger reads: in-HBM path of K2a */
+constexpr uint32_t K2S_STACK = 512;                    /* pending ranges (each > 64 elements, disjoint) */
+constexpr uint32_t K2S_TABLE_WORDS = 768 + 2 * K2S_STACK;
+constexpr uint64_t K2S_SENTINEL_KEY = 0x7fffffff80000000ull;      /* { upos = INT32_MIN, rid = INT32_MAX }, minialign.c:3531 */
+__host__ __device__ inline uint32_t k2s_bytes(uint32_t n_all) { return 4u * ((n_all + 63u) & ~63u) + 4u * K2S_TABLE_WORDS; }
+struct K2sArgs {
+	ReadState *st; const uint32_t *work; uint32_t n_work;
+	Seed *seed_pool;
+	uint32_t lds_bytes, n_lo, n_hi;   /* this launch takes the reads with n_lo < k2s_bytes(n + 1) <= n_hi */
+	uint32_t *counter;
+	unsigned long long *prof;         /* [0] wave cycles */
+};
+__device__ __forceinline__ uint64_t k2s_key(const Seed *gs, uint32_t src, uint32_t n)
+{
+	if(src >= n) { return K2S_SENTINEL_KEY; }
+	const uint2 v = *(const uint2 *)&gs[src];          /* { upos, rid } */
+	return (uint64_t)v.x | ((uint64_t)v.y << 32);
+}
+/* stable sort by the full key of every bucket of 2 .. 64 elements in [beg, end); bs / be = bucket begin / end by digit, e = entries (digit << 16 | index) */
+__device__ __forceinline__ void k2s_small_buckets(LU32 *e, const LU32 *bs, const LU32 *be, uint32_t beg, uint32_t end, const Seed *gs, uint32_t n, int lane)
+{
+	uint32_t pos = beg;
+	while(pos < end) {
+		const uint32_t slot = pos + (uint32_t)lane; const bool valid = slot < end;
+		const uint32_t x = valid ? e[slot] : 0u, d = x >> 16;
+		const uint32_t b0 = valid ? bs[d] : 0u, b1 = valid ? be[d] : 0u;
+		const uint64_t m_inc = __ballot(valid && b1 > pos + 64);
+		uint32_t cut = m_inc ? pos + (uint32_t)__builtin_ctzll(m_inc) : (pos + 64 < end ? pos + 64 : end);
+		if(cut == pos) { pos = (uint32_t)rdfirst((int)b1); continue; }           /* a bucket of more than 64 (it went on the stack): step over it */
+		const bool act = slot < cut && b1 - b0 >= 2;
+		uint32_t rank = 0;
+		if(__ballot(act)) {
+			const uint64_t key = act ? k2s_key(gs, x & 0xffffu, n) : 0ull;
+			const uint32_t size = act ? b1 - b0 : 0u;
+			for(uint32_t j = 0; __ballot(j < size); j++) {
+				const int ol = (int)(b0 + j - pos) & 63;
+				const uint64_t ok = ((uint64_t)(uint32_t)__shfl((int)(key >> 32), ol) << 32) | (uint32_t)__shfl((int)key, ol);
+				if(j < size && (ok < key || (ok == key && b0 + j < slot))) { rank++; }
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if(act) { e[b0 + rank] = x; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		pos = cut;
+	}
+}
+__global__ void __launch_bounds__(64) mm_sort_kernel(K2sArgs a)
+{
+	extern __shared__ uint8_t lds_raw[];
+	LU32 *e = (LU32 *)lds_raw;
+	LU32 *cnt = (LU32 *)(lds_raw + a.lds_bytes - 4 * K2S_TABLE_WORDS), *bb = cnt + 256, *be = bb + 256, *stk = be + 256, *stsh = stk + K2S_STACK;
+	const int lane = lane_id();
+	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
+	while(true) {
+		uint32_t wi = 0;
+		if(lane == 0) { wi = atomicAdd(a.counter, 1u); }
+		wi = (uint32_t)rdfirst((int)wi);
+		if(wi >= a.n_work) { break; }
+		ReadState *st = &a.st[a.work[wi]];
+		const uint32_t n = (uint32_t)rdfirst((int)st->seed_n0), n_all = n + 1;
+		if(n == 0 || n_all > K2S_MAX_N) { continue; }
+		const uint32_t need = k2s_bytes(n_all);
+		if(need <= a.n_lo || need > a.n_hi) { continue; }                    /* another size class */
+		Seed *gs = a.seed_pool + rdfirst64(st->seed_off);
+		uint32_t err = 0;
+		for(uint32_t i = (uint32_t)lane; i < n_all; i += 64) { e[i] = i; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		uint32_t sp = 0;
+		if(n_all <= 64) {
+			/* one insertion sort over everything (ksort.h:126): a single "bucket" */
+			if(lane == 0) { bb[0] = 0; be[0] = n_all; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			k2s_small_buckets(e, bb, be, 0, n_all, gs, n, lane);
+		} else {
+			if(lane == 0) { stk[0] = 0u | (n_all << 16); stsh[0] = 56; }
+			sp = 1;
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		}
+		while(sp > 0) {
+			sp--;
+			const uint32_t rg = (uint32_t)rdfirst((int)stk[sp]); const int sh = rdfirst((int)stsh[sp]);
+			const uint32_t beg = rg & 0xffffu, end = rg >> 16, m = end - beg;
+			/* digits of this level, histogram */
+			for(int k = lane; k < 256; k += 64) { cnt[k] = 0; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			for(uint32_t i = beg + (uint32_t)lane; i < end; i += 64) {
+				const uint32_t src = e[i] & 0xffffu;
+				const uint32_t d = (uint32_t)(k2s_key(gs, src, n) >> sh) & 255u;
+				e[i] = d << 16 | src;
+				atomicAdd((uint32_t *)&cnt[d], 1u);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			const uint32_t d0 = (uint32_t)rdfirst((int)e[beg]) >> 16;
+			if((uint32_t)rdfirst((int)cnt[d0]) == m) {
+				/* every element has the same digit: the level leaves the range as it is */
+				if(sh) { if(lane == 0) { stk[sp] = rg; stsh[sp] = (uint32_t)(sh > 8 ? sh - 8 : 0); } sp++; }
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				continue;
+			}
+			/* bucket bounds: each lane owns four consecutive buckets, one wave-wide exclusive scan */
+			const uint32_t c0 = cnt[4 * lane], c1 = cnt[4 * lane + 1], c2 = cnt[4 * lane + 2], c3 = cnt[4 * lane + 3];
+			{
+				uint32_t incl = c0 + c1 + c2 + c3;
+				for(int dd = 1; dd < 64; dd <<= 1) { uint32_t o = (uint32_t)__shfl_up((int)incl, dd); if(lane >= dd) { incl += o; } }
+				uint32_t acc = beg + incl - (c0 + c1 + c2 + c3);
+				bb[4 * lane] = acc; acc += c0; be[4 * lane] = acc; bb[4 * lane + 1] = acc; acc += c1; be[4 * lane + 1] = acc;
+				bb[4 * lane + 2] = acc; acc += c2; be[4 * lane + 2] = acc; bb[4 * lane + 3] = acc; acc += c3; be[4 * lane + 3] = acc;
+			}
+			/* non-empty buckets as four 64-bit masks (bucket 4 * lane + j -> bit lane of mask j) */
+			const uint64_t nz0 = __ballot(c0 != 0), nz1 = __ballot(c1 != 0), nz2 = __ballot(c2 != 0), nz3 = __ballot(c3 != 0);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			/* how many elements already sit in their bucket decides how the permutation is replayed */
+			uint32_t n_home = 0;
+			for(uint32_t i0 = beg; i0 < end; i0 += 64) {
+				const uint32_t i = i0 + (uint32_t)lane; bool home = false;
+				if(i < end) { const uint32_t d = e[i] >> 16; home = i >= bb[d] && i < be[d]; }
+				n_home += (uint32_t)__popcll(__ballot(home));
+			}
+			/*
+			 * The in-place cycle-leader permutation (ksort.h:101-116), literally, on the 4-byte entries.  Buckets in ascending order; inside a bucket the
+			 * cursor walks to its end, and every element that is not at home starts a cycle: it goes to the cursor of its own bucket, the element it
+			 * displaces goes to the cursor of *its* bucket (whether it was at home there or not), until an element of the current bucket turns up.
+			 */
+			if(2 * n_home <= m) {
+				/* mostly displaced elements: one lane, no hand-overs */
+				if(lane == 0) {
+					for(int l4 = 0; l4 < 64; l4++) {
+						const uint32_t any = (uint32_t)((nz0 >> l4) & 1) | (uint32_t)((nz1 >> l4) & 1) << 1 | (uint32_t)((nz2 >> l4) & 1) << 2 | (uint32_t)((nz3 >> l4) & 1) << 3;
+						for(int j = 0; j < 4; j++) {
+							if(!((any >> j) & 1)) { continue; }
+							const uint32_t k = (uint32_t)(4 * l4 + j);
+							uint32_t b = bb[k]; const uint32_t ee = be[k];
+							while(b != ee) {
+								const uint32_t x = e[b];
+								if((x >> 16) == k) { b++; continue; }
+								uint32_t tmp = x, l_ = x >> 16;
+								do { const uint32_t p = bb[l_]; const uint32_t y = e[p]; e[p] = tmp; bb[l_] = p + 1; tmp = y; l_ = y >> 16; } while(l_ != k);
+								e[b] = tmp; b++;
+							}
+						}
+					}
+				}
+			} else {
+				/* mostly at home (seeds of one strand arrive in diagonal order): stretches at home are stepped over 64 at a time, lane 0 runs the cycles */
+				for(int l4 = 0; l4 < 64; l4++) {
+					const uint32_t any = (uint32_t)((nz0 >> l4) & 1) | (uint32_t)((nz1 >> l4) & 1) << 1 | (uint32_t)((nz2 >> l4) & 1) << 2 | (uint32_t)((nz3 >> l4) & 1) << 3;
+					for(int j = 0; j < 4; j++) {
+						if(!((any >> j) & 1)) { continue; }
+						const uint32_t k = (uint32_t)(4 * l4 + j);
+						uint32_t b = (uint32_t)rdfirst((int)bb[k]); const uint32_t ee = (uint32_t)rdfirst((int)be[k]);
+						while(b != ee) {
+							const uint32_t idx = b + (uint32_t)lane;
+							const bool away = idx < ee && (e[idx] >> 16) != k;
+							const uint64_t m_away = __ballot(away);
+							if(m_away == 0) { b = b + 64 < ee ? b + 64 : ee; continue; }
+							b += (uint32_t)__builtin_ctzll(m_away);
+							if(lane == 0) {
+								uint32_t tmp = e[b], l_ = tmp >> 16;
+								do { const uint32_t p = bb[l_]; const uint32_t y = e[p]; e[p] = tmp; bb[l_] = p + 1; tmp = y; l_ = y >> 16; } while(l_ != k);
+								e[b] = tmp;
+							}
+							__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+							b++;
+						}
+					}
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			for(int k = lane; k < 256; k += 64) { bb[k] = k == 0 ? beg : be[k - 1]; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			if(sh) {
+				const int ns = sh > 8 ? sh - 8 : 0;
+				/* large buckets go back on the stack (order of siblings is irrelevant), small ones are sorted by rank */
+				for(int k0 = 0; k0 < 256; k0 += 64) {
+					const int k = k0 + lane; const uint32_t nb = be[k] - bb[k];
+					const uint64_t mm = __ballot(nb > 64);
+					const uint32_t slot = sp + (uint32_t)__popcll(mm & ((1ull << lane) - 1));
+					if(nb > 64) { if(slot < K2S_STACK) { stk[slot] = bb[k] | (be[k] << 16); stsh[slot] = (uint32_t)ns; } else { err |= ERR_STACK; } }
+					sp += (uint32_t)__popcll(mm);
+				}
+				if(sp > K2S_STACK) { sp = K2S_STACK; }
+				k2s_small_buckets(e, bb, be, beg, end, gs, n, lane);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		}
+		/* the seeds move once: through the (still unused) leaf half of the read's region, then back in order */
+		for(uint32_t i = (uint32_t)lane; i < n_all; i += 64) {
+			const uint32_t src = e[i] & 0xffffu;
+			Seed v = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu };
+			if(src < n) { v = gs[src]; }
+			gs[n_all + i] = v;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		for(uint32_t i = (uint32_t)lane; i < n_all; i += 64) { gs[i] = gs[n_all + i]; }
+		if(__ballot(err != 0) && lane == 0) { st->err |= ERR_STACK; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+	if(lane == 0) { atomicAdd(&a.prof[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
+}
+
 /* -----------------------------------------------------------------------------------------------------
  * K2a: the same stage, one *wavefront* per read with the seed / leaf array staged in LDS (first round only; reads whose
  * arrays do not fit the LDS budget, and the rescue rounds, take the lane-per-read kernel above).
@@ -536,18 +748,18 @@ struct K2aArgs {
 	uint32_t lds_bytes;               /* dynamic LDS of this launch (tables included); <= 1536 * 4: sort in place in HBM */
 	uint32_t n_lo, n_hi;              /* this launch takes the reads with n_lo < k2a_bytes(seed_n) <= n_hi (size class, bytes) */
 	uint32_t retry;                   /* 1: take the reads whose leaf area overflowed in their class (flagged n_root = ~0), with room for 2 (n + 1) */
+	uint32_t leaf_shift;              /* first attempt: a leaf area of (n + 1) >> leaf_shift elements (2: a quarter; the host lowers it when a batch needed many retries) */
+	uint32_t presorted;               /* 1: mm_sort_kernel has already sorted the seed arrays of the reads it takes (n + 1 <= K2S_MAX_N) */
 	uint32_t *counter;                /* work-list cursor of this launch */
 	uint32_t twlen; double mcoef; uint32_t min_score;
 	const uint32_t *seq_len; const uint8_t *seq_circ;   /* reference lengths and circular flags (NULL: no circular reference) for mm_circularize */
-	unsigned long long *prof;         /* [0] sort [1] chain [2] whole wave (s_memtime ticks) [3] reads that did not fit the LDS */
+	unsigned long long *prof;         /* [0] sort [1] chain [2] whole wave (s_memtime ticks) [3] reads that did not fit the LDS [5] reads whose leaf area overflowed (retried) */
 };
 /* elements a read is given in its first attempt: the seeds, the sentinel and a leaf area of a quarter of that (the worst case of
  * one leaf per seed is left to the retry launch) */
-__host__ __device__ inline uint32_t k2a_need(uint32_t seed_n) { return (seed_n + 1) + (seed_n + 1) / 4 + 64; }
+__host__ __device__ inline uint32_t k2a_need(uint32_t seed_n, uint32_t leaf_shift) { return (seed_n + 1) + ((seed_n + 1) >> leaf_shift) + 64; }
 /* LDS bytes of a read: 16 B per element + the two u32 step tables of the chain sweep + the sort tables */
 __host__ __device__ inline uint32_t k2a_bytes(uint32_t seed_n, uint32_t elems) { return 16u * elems + 8u * (seed_n + 1) + 1536u * 4u; }
-typedef __attribute__((address_space(3))) Seed LSeed;
-typedef __attribute__((address_space(3))) uint32_t LU32;
 
 __device__ __forceinline__ uint64_t lkey(const LSeed *p) { return (uint64_t)p->upos | ((uint64_t)p->rid << 32); }
 __device__ __forceinline__ Seed lds_ld(const LSeed *p) { Seed r; r.upos = p->upos; r.rid = p->rid; r.vpos = p->vpos; r.lid = p->lid; return r; }
@@ -572,12 +784,13 @@ __device__ __forceinline__ void lds_ins_sort(S *beg, S *end)
 template<typename S>
 __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t seed_n, LU32 *cnt, LU32 *bb, LU32 *be, LU32 *stack,
 	Root *c, const K2aArgs &a, int lane, uint32_t &nlid_out, uint32_t &ncid_out, unsigned long long &cy_sort, unsigned long long &cy_chain,
-	const bool pre, LU32 *succ, LU32 *seen)
+	const bool pre, LU32 *succ, LU32 *seen, const bool sorted)
 {
 	const uint32_t n_all = seed_n + 1;
 	const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
 		/* ---- radix_sort_128x ---- */
-		if(n_all <= 64) { if(lane == 0) { lds_ins_sort(s, s + n_all); } }
+		if(sorted) { /* done by mm_sort_kernel */ }
+		else if(n_all <= 64) { if(lane == 0) { lds_ins_sort(s, s + n_all); } }
 		else {
 			uint32_t sp = 1;
 			if(lane == 0) { stack[0] = 0; stack[1] = n_all; stack[2] = 56; }
@@ -794,7 +1007,7 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 			if((uint32_t)rdfirst((int)st->n_root) != 0xffffffffu) { continue; }
 			fits = k2a_bytes(seed_n, 2 * (seed_n + 1)) <= a.lds_bytes;
 		} else {
-			const uint32_t need = k2a_bytes(seed_n, k2a_need(seed_n));
+			const uint32_t need = k2a_bytes(seed_n, k2a_need(seed_n, a.leaf_shift));
 			if(need <= a.n_lo || need > a.n_hi) { continue; }              /* another size class */
 			fits = a.lds_bytes > 1536 * 4;
 		}
@@ -809,18 +1022,18 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 			for(uint32_t i = (uint32_t)lane; i < seed_n; i += 64) { lds_st(&ls[i], gs[i]); }
 			if(lane == 0) { lds_st(&ls[seed_n], Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }); }      /* sentinel, minialign.c:3531 */
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-			ok = sort_chain_wave<LSeed>(ls, lcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain, true, succ, seen);
+			ok = sort_chain_wave<LSeed>(ls, lcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain, true, succ, seen, a.presorted && seed_n + 1 <= K2S_MAX_N);
 			if(ok) { for(uint32_t i = (uint32_t)lane; i < nlid; i += 64) { gs[i] = lds_ld(&ls[i]); } }
 		} else {
 			/* too large for LDS: same algorithm in place in HBM */
 			if(lane == 0) { gs[seed_n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }; }
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			n_big++;
-			ok = sort_chain_wave<Seed>(gs, gcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain, false, succ, seen);
+			ok = sort_chain_wave<Seed>(gs, gcap, seed_n, cnt, bb, be, stack, c, a, lane, nlid, ncid, cy_sort, cy_chain, false, succ, seen, a.presorted && seed_n + 1 <= K2S_MAX_N);
 		}
 		if(!ok) {
 			/* leaf area exhausted: the seed array in HBM is untouched (LDS case), so the retry launch redoes the read with full room */
-			if(lane == 0) { if(!a.retry && fits) { st->n_root = 0xffffffffu; } else { st->err |= ERR_SEED_CAP; } }
+			if(lane == 0) { if(!a.retry && fits) { st->n_root = 0xffffffffu; atomicAdd(&a.prof[5], 1ull); } else { st->err |= ERR_SEED_CAP; } }
 			continue;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

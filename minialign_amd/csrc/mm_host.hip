@@ -772,7 +772,7 @@ struct mm_align_s {
 	gaba_arena_t *ref_ar = nullptr;
 	uint32_t twlen, tglen; double mcoef, xcoef;
 	hipStream_t stream; hipEvent_t ev0, ev1;
-	hipStream_t k2s[12]; hipEvent_t k2e[12]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
+	hipStream_t k2s[12]; hipEvent_t k2e[16]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
 	uint32_t qlen_hint = 0;                                    /* longest read of the input being mapped, when known (mm_align_file) */
 	uint32_t k3_waves = 0; uint64_t slab_stride = 0;      /* extension kernel: persistent waves actually launched and the DP workspace of each */
@@ -792,6 +792,7 @@ struct mm_align_s {
 	mm_stats_t st; double t_wall0;
 	/* knobs (grown on overflow) */
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
+	uint32_t k2_leaf_shift = 2;            /* leaf area of the first chaining attempt: (n + 1) >> shift; lowered when more than 2 % of a batch had to be retried */
 };
 
 namespace {
@@ -851,8 +852,31 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(!attr_set) { CK(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
 			K2aArgs ka; ka.st = a->d_st.p; ka.work = a->d_work.p; ka.n_work = (uint32_t)work.size(); ka.seed_pool = a->seed_pool.p; ka.root_pool = a->root_pool.p;
 			ka.prof = tops + 24; ka.twlen = a->twlen; ka.mcoef = a->mcoef; ka.min_score = a->o.min_score; ka.seq_len = a->dix.seq_len; ka.seq_circ = a->dix.seq_circ;
-			CK(hipMemsetAsync(a->d_k2cnt.p, 0, 16 * 4, a->stream));
+			CK(hipMemsetAsync(a->d_k2cnt.p, 0, 32 * 4, a->stream));
 			CK(hipEventRecord(a->ev0, a->stream));          /* re-recorded behind the memset: the side streams start from here */
+			/* the sort first (mm_sort_kernel: 4 B of LDS per seed, a dozen reads per CU), in size classes by LDS need on the side streams; every stream of the
+			 * chain launches below then waits for all of them (a read's sort class is not its chain class) */
+			const bool presort = getenv("MM_K2_NO_PRESORT") == NULL && getenv("MM_K2_FORCE_HBM") == NULL;
+			if(presort) {
+				static bool sattr = false;
+				if(!sattr) { CK(hipFuncSetAttribute((const void *)mm_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
+				static const uint32_t s_kb[] = { 10, 14, 20, 32, 64, 140 };
+				const int n_s = (int)(sizeof(s_kb) / sizeof(s_kb[0]));
+				K2sArgs ks; ks.st = a->d_st.p; ks.work = a->d_work.p; ks.n_work = (uint32_t)work.size(); ks.seed_pool = a->seed_pool.p; ks.prof = tops + 28;
+				const uint32_t n_cu = a->n_waves / (4 * MM_K3_WAVES_PER_SIMD);
+				for(int si = 0; si < n_s; si++) {
+					ks.lds_bytes = s_kb[si] * 1024u; ks.n_lo = si ? s_kb[si - 1] * 1024u : 0u; ks.n_hi = ks.lds_bytes; ks.counter = a->d_k2cnt.p + 16 + si;
+					const uint32_t per_cu = std::min<uint32_t>(16u, 160u / s_kb[si]);
+					const uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), n_cu * per_cu);
+					hipStream_t sq = a->k2s[si % 4];
+					if(si < 4) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
+					hipLaunchKernelGGL(mm_sort_kernel, dim3(grid), dim3(64), ks.lds_bytes, sq, ks);
+					CK(hipGetLastError());
+				}
+				for(int j = 0; j < 4; j++) { CK(hipEventRecord(a->k2e[12 + j], a->k2s[j])); }
+				for(int j = 0; j < 4; j++) { for(int i = 0; i < 4; i++) { if(i != j) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[12 + i], 0)); } } }
+			}
+			ka.presorted = presort ? 1u : 0u; ka.leaf_shift = a->k2_leaf_shift;
 			auto bytes_of = [](uint32_t div) -> uint32_t { return div ? ((160u * 1024u / div) & ~255u) : 0u; };
 			for(int ci = 0; ci <= n_cls; ci++) {
 				/* ci < n_cls: size classes, largest first; ci == n_cls: retry of the reads whose leaf area overflowed, at 160 KB */
@@ -1270,7 +1294,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	uint32_t kw = (uint32_t)std::min<uint64_t>(lane_waves, std::max<uint64_t>(256, budget / slab)) & ~3u;
 	if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
 	else { ok &= a->slabs.ensure(slab * kw); if(ok) { a->slab_stride = a->slabs.n / kw; a->k3_waves = kw; } }
-	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(16);
+	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(32);
 	return ok;
 }
 
@@ -1289,7 +1313,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	double mc = 0, xc = 0; for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 3)) mc += o->p.score_matrix[0]; else xc += o->p.score_matrix[0]; }
 	a->mcoef = mc / 4.0; a->xcoef = xc / 12.0;
 	if(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) { delete a; return NULL; }
-	for(int i = 0; i < 12; i++) { if(hipStreamCreateWithFlags(&a->k2s[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) { delete a; return NULL; } }
+	for(int i = 0; i < 16; i++) { if((i < 12 && hipStreamCreateWithFlags(&a->k2s[i], hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) { delete a; return NULL; } }
 	a->k2s_ok = true;
 	/* reference: one arena, per-sequence offsets */
 	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
@@ -1338,7 +1362,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
-	if(a->k2s_ok) { for(int i = 0; i < 12; i++) { (void)hipStreamDestroy(a->k2s[i]); (void)hipEventDestroy(a->k2e[i]); } }
+	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < 12) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
 	delete a;
 }
 extern "C" void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line)
@@ -1538,7 +1562,8 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
 	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->k3_waves; a->st.k3_cycles_next += tops[19];
-	a->st.k2_cycles_sort += tops[24]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26]; a->st.k2_reads_hbm += tops[27];
+	if(a->k2_leaf_shift > 0 && tops[29] * 50 > (unsigned long long)n_reads) { for(mm_align_t *q = a; q; q = q->sib) { if(q->k2_leaf_shift > 0) q->k2_leaf_shift--; } }
+	a->st.k2_cycles_sort += tops[24] + tops[28]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26] + tops[28]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
 	/* host copies of the result pools (uninitialised storage: the copies fill them) */
@@ -1682,9 +1707,9 @@ static mm_align_t *align_lane(mm_align_t *a)
 	mm_align_t *q = new mm_align_s();
 	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off; q->d_seq_circ = a->d_seq_circ;
 	q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
-	q->qlen_hint = a->qlen_hint; q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
+	q->qlen_hint = a->qlen_hint; q->k2_leaf_shift = a->k2_leaf_shift; q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
 	if(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess) { delete q; return NULL; }
-	for(int i = 0; i < 12; i++) { if(hipStreamCreateWithFlags(&q->k2s[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&q->k2e[i], hipEventDisableTiming) != hipSuccess) { delete q; return NULL; } }
+	for(int i = 0; i < 16; i++) { if((i < 12 && hipStreamCreateWithFlags(&q->k2s[i], hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&q->k2e[i], hipEventDisableTiming) != hipSuccess) { delete q; return NULL; } }
 	q->k2s_ok = true;
 	memset(&q->st, 0, sizeof(q->st)); q->t_wall0 = now_ms();
 	a->sib = q;
