@@ -784,6 +784,11 @@ struct mm_align_s {
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
+	/* reusable host buffers of the streaming engine (primary context only): pinned result buffers for the D2H of a batch, text pieces with their capacity */
+	struct PinSet { void *p[5] = { nullptr, nullptr, nullptr, nullptr, nullptr }; size_t cap[5] = { 0, 0, 0, 0, 0 };
+		void *get(int i, size_t bytes) { if(bytes > cap[i]) { if(p[i]) (void)hipHostFree(p[i]); p[i] = nullptr; cap[i] = 0; size_t want = bytes + bytes / 4 + (1u << 20); if(hipHostMalloc(&p[i], want, hipHostMallocDefault) != hipSuccess) return nullptr; cap[i] = want; } return p[i]; }
+		~PinSet() { for(int i = 0; i < 5; i++) if(p[i]) (void)hipHostFree(p[i]); } };
+	std::vector<PinSet *> pin_free; std::vector<std::vector<std::string>> piece_free; std::mutex pool_mu;
 	/* the head of the last stream mapped through this context (mm_map_*): what decides whether another carried value at its start changes anything */
 	struct HeadRec { uint32_t apos0, cond0, used, rid_last; };
 	std::vector<HeadRec> head; uint32_t head_carry_in = 0;
@@ -1044,19 +1049,31 @@ void post_map(const mm_align_t *a, const ReadState &rs, Root *res, uint64_t *bin
 inline uint64_t path_u64(const uint64_t *ptr, int64_t pos) { int64_t rem = pos & 63; return (ptr[pos >> 6] >> rem) | ((ptr[(pos >> 6) + 1] << (63 - rem)) << 1); }
 inline uint64_t lzc(uint64_t x) { return x ? (uint64_t)__builtin_clzll(x) : 64; }
 inline void put_num(std::string &s, uint64_t v) { char b[24]; int n = 0; if(!v) b[n++] = '0'; while(v) { b[n++] = (char)('0' + v % 10); v /= 10; } while(n) s.push_back(b[--n]); }
+/* the same into a raw buffer (most run lengths have one or two digits) */
+inline char *put_num_p(char *p, uint64_t v)
+{
+	if(v < 10) { *p++ = (char)('0' + v); return p; }
+	if(v < 100) { *p++ = (char)('0' + v / 10); *p++ = (char)('0' + v % 10); return p; }
+	char b[24]; int n = 0; while(v) { b[n++] = (char)('0' + v % 10); v /= 10; } while(n) *p++ = b[--n];
+	return p;
+}
 void cigar_reverse(std::string &out, const uint32_t *path, uint64_t offset, uint64_t len)
 {
 	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
 	uint64_t ofs = (uint64_t)((int64_t)offset + (((uintptr_t)path & 4) ? 32 : 0) - 64), idx = len;
+	/* written through a raw pointer into room reserved for the worst case (every path bit its own run: 2 characters per bit and change) */
+	const size_t o = out.size(); out.resize(o + 2 * len + 64);
+	char *w = &out[o];
 	while((int64_t)idx > 0) {
 		uint64_t m = lzc(path_u64(p, (int64_t)(ofs + idx))), c = std::min(idx, m - (m > 0));
-		idx -= c; if(c) { put_num(out, c); out.push_back('D'); }
+		idx -= c; if(c) { w = put_num_p(w, c); *w++ = 'D'; }
 		m = lzc(~path_u64(p, (int64_t)(ofs + idx))); c = std::min(idx, m);
-		idx -= c; if(c) { put_num(out, c); out.push_back('I'); }
+		idx -= c; if(c) { w = put_num_p(w, c); *w++ = 'I'; }
 		uint64_t sidx = idx;
 		do { m = lzc(path_u64(p, (int64_t)(ofs + idx)) ^ 0x5555555555555555ull); c = std::min(idx, m) & ~1ull; idx -= c; } while(c == 64);
-		if((sidx - idx) >> 1) { put_num(out, (sidx - idx) >> 1); out.push_back('M'); }
+		if((sidx - idx) >> 1) { w = put_num_p(w, (sidx - idx) >> 1); *w++ = 'M'; }
 	}
+	out.resize((size_t)(w - out.data()));
 }
 
 /* ---- SAM (minialign.c:5127-5198, 5390-5426), default tag set ---- */
@@ -1064,8 +1081,9 @@ void sam_seq(std::string &s, const uint8_t *q, uint32_t n, bool rev)
 {
 	static const char fw[] = "ACGTN\0\0\0\0\0\0\0\0\0\0\0", rv[] = "TGCAN\0\0\0\0\0\0\0\0\0\0\0";
 	size_t o = s.size(); s.resize(o + n);
-	if(!rev) for(uint32_t i = 0; i < n; i++) s[o + i] = fw[q[i] & 15];
-	else for(uint32_t i = 0; i < n; i++) s[o + i] = rv[q[n - 1 - i] & 15];
+	char *d = &s[o];
+	if(!rev) for(uint32_t i = 0; i < n; i++) d[i] = fw[q[i] & 15];
+	else { const uint8_t *e = q + n - 1; for(uint32_t i = 0; i < n; i++) d[i] = rv[e[-(int64_t)i] & 15]; }
 }
 /* walks the path bits in the order of _parser_loop_rv (gaba_parse.h:168-188); fn(op, count) sees every nonzero run ('D', 'I', 'M') */
 template<typename F> void path_walk_reverse(const uint32_t *path, uint64_t offset, uint64_t len, F fn)
@@ -1354,6 +1372,8 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 {
 	if(!a) return;
 	if(a->sib) { mm_align_destroy(a->sib); a->sib = nullptr; }
+	for(auto *ps : a->pin_free) delete ps;
+	a->pin_free.clear();
 	if(!a->is_sib) {
 		(void)hipFree(a->d_slot); (void)hipFree(a->d_val); (void)hipFree(a->d_seq_len); (void)hipFree(a->d_seq_off); if(a->d_seq_circ) (void)hipFree(a->d_seq_circ);
 		gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
@@ -1549,7 +1569,9 @@ mm_reg_t *build_reg(const OutReg &reg, const AlnRec *alns, const gaba::Segment *
 /* finish, first half (needs the lane's device pools): counters, then the result pools of the batch copied to the host */
 struct Fetched {
 	unsigned long long tops[32];
-	std::unique_ptr<Root[]> root; std::unique_ptr<uint64_t[]> bin; std::unique_ptr<AlnRec[]> aln; std::unique_ptr<gaba::Segment[]> seg; std::unique_ptr<uint32_t[]> path;
+	Root *root = nullptr; uint64_t *bin = nullptr; AlnRec *aln = nullptr; gaba::Segment *seg = nullptr; uint32_t *path = nullptr;
+	std::unique_ptr<uint8_t[]> own[5];          /* plain host memory when no pinned set is given */
+	mm_align_s::PinSet *pin = nullptr;          /* pinned set the pointers live in (returned to the pool by the caller) */
 };
 bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 {
@@ -1566,15 +1588,22 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	a->st.k2_cycles_sort += tops[24] + tops[28]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26] + tops[28]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
-	/* host copies of the result pools (uninitialised storage: the copies fill them) */
-	f.root.reset(new Root[std::max<uint64_t>(tops[2], 1)]); f.bin.reset(new uint64_t[std::max<uint64_t>(tops[3], 1)]);
-	f.aln.reset(new AlnRec[std::max<uint64_t>(tops[4], 1)]);
-	f.seg.reset(new gaba::Segment[std::max<uint64_t>(tops[5], 1)]); f.path.reset(new uint32_t[std::max<uint64_t>(tops[6], 2) + 8]);
-	CK(hipMemcpyAsync(f.root.get(), a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(f.bin.get(), a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(f.aln.get(), a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(f.seg.get(), a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(f.path.get(), a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost, a->stream));
+	/* host copies of the result pools (uninitialised storage: the copies fill them); pinned when the caller lends a set */
+	{
+		const size_t need[5] = { (size_t)std::max<uint64_t>(tops[2], 1) * sizeof(Root), (size_t)std::max<uint64_t>(tops[3], 1) * 8, (size_t)std::max<uint64_t>(tops[4], 1) * sizeof(AlnRec),
+			(size_t)std::max<uint64_t>(tops[5], 1) * sizeof(gaba::Segment), (size_t)(std::max<uint64_t>(tops[6], 2) + 8) * 4 };
+		void *ptr[5];
+		for(int i = 0; i < 5; i++) {
+			ptr[i] = f.pin ? f.pin->get(i, need[i]) : nullptr;
+			if(!ptr[i]) { f.own[i].reset(new uint8_t[need[i] + 16]); ptr[i] = f.own[i].get(); }
+		}
+		f.root = (Root *)ptr[0]; f.bin = (uint64_t *)ptr[1]; f.aln = (AlnRec *)ptr[2]; f.seg = (gaba::Segment *)ptr[3]; f.path = (uint32_t *)ptr[4];
+	}
+	CK(hipMemcpyAsync(f.root, a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.bin, a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.aln, a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.seg, a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.path, a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost, a->stream));
 	CK(hipStreamSynchronize(a->stream));
 	a->st.host_post_ms += now_ms() - t0;
 	return true;
@@ -1586,8 +1615,9 @@ void batch_format(const mm_align_t *a, Batch &b, const Fetched &f, std::vector<s
 	const uint32_t n_reads = b.n; const std::vector<ReadState> &hst = b.hst;
 	const uint32_t want = max_threads ? max_threads : (a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 32));
 	const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(1, n_reads / 64)));
-	std::vector<std::string> piece(nth);
-	Root *root = f.root.get(); uint64_t *bin = f.bin.get(); const AlnRec *aln = f.aln.get(); const gaba::Segment *seg = f.seg.get(); const uint32_t *path = f.path.get();
+	std::vector<std::string> piece(std::move(piece_out)); piece_out.clear();          /* strings handed in keep their capacity */
+	piece.resize(nth); for(auto &x : piece) x.clear();
+	Root *root = f.root; uint64_t *bin = f.bin; const AlnRec *aln = f.aln; const gaba::Segment *seg = f.seg; const uint32_t *path = f.path;
 	/* spans of equal bases (not equal read counts): the text of a read grows with its length */
 	std::vector<uint32_t> cut(nth + 1, n_reads);
 	{ uint64_t tot = 0; for(uint32_t i = 0; i < n_reads; i++) tot += b.lens[i] + 256; uint64_t acc = 0; uint32_t t = 0; cut[0] = 0; for(uint32_t i = 0; i < n_reads && t + 1 < nth; i++) { acc += b.lens[i] + 256; if(acc * nth >= tot * (t + 1)) { cut[++t] = i + 1; } } }
@@ -1814,6 +1844,11 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 	std::map<uint32_t, Item *> formatted;              /* waiting for the writer */
 	uint32_t lanes_done = 0, fin_done = 0; bool head_open = true;
 	const uint32_t max_pending = (uint32_t)lanes + 2;
+	/* an item leaves: its pinned set and its text pieces (emptied, capacity kept) go back to the pools of the context */
+	auto drop_item = [&](Item *it) {
+		{ std::lock_guard<std::mutex> lk(a->pool_mu); if(it->f.pin) { a->pin_free.push_back(it->f.pin); } if(!it->piece.empty() && a->piece_free.size() < 16) { a->piece_free.emplace_back(std::move(it->piece)); } }
+		delete it;
+	};
 
 	auto lane_main = [&](int li) {
 		mm_align_t *c = ctx[li];
@@ -1859,9 +1894,11 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 				}
 				if(ok) {
 					Item *it = new Item(); it->h = h; it->k = k;
+					{ std::lock_guard<std::mutex> lk(a->pool_mu); if(!a->pin_free.empty()) { it->f.pin = a->pin_free.back(); a->pin_free.pop_back(); } if(!a->piece_free.empty()) { it->piece = std::move(a->piece_free.back()); a->piece_free.pop_back(); } }
+					if(!it->f.pin) it->f.pin = new mm_align_s::PinSet();
 					ok = batch_fetch(c, b, it->f);
 					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): D2H %.1f ms\n", k, li, now_ms() - tv); }
-					if(ok) { std::lock_guard<std::mutex> lk(mu); fetched.push_back(it); } else { delete it; std::lock_guard<std::mutex> lk(mu); pending--; }
+					if(ok) { std::lock_guard<std::mutex> lk(mu); fetched.push_back(it); } else { drop_item(it); std::lock_guard<std::mutex> lk(mu); pending--; }
 					cv.notify_all();
 				}
 			}
@@ -1883,7 +1920,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 			}
 			double tv = now_ms();
 			batch_format(it->h->ctx, it->h->b, it->f, it->piece, std::max<uint32_t>(1, fmt_total / n_fin));
-			it->f = Fetched();
+			{ std::lock_guard<std::mutex> lk(a->pool_mu); if(it->f.pin) { a->pin_free.push_back(it->f.pin); it->f.pin = nullptr; } }
 			{ std::lock_guard<std::mutex> lk(mu); it->h->ctx->st.host_sam_ms += now_ms() - tv; formatted[it->k] = it; }
 			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: post-map + text %.1f ms\n", it->k, now_ms() - tv); }
 			cv.notify_all();
@@ -1904,20 +1941,20 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 			double tv = now_ms(); size_t nb = 0; for(auto &x : it->piece) nb += x.size();
 			const bool ok = rc == 0 ? sink(it->k, it->piece) : true;
 			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: written %.1f MB in %.1f ms\n", it->k, nb * 1e-6, now_ms() - tv); }
-			release(it->h); delete it;
+			release(it->h); drop_item(it);
 			{ std::lock_guard<std::mutex> lk(mu); next_write++; pending--; if(!ok) rc = 1; }
 			cv.notify_all();
 		}
 		/* whatever is left after an error */
 		std::lock_guard<std::mutex> lk(mu);
-		for(auto &kv : formatted) { release(kv.second->h); delete kv.second; } formatted.clear();
+		for(auto &kv : formatted) { release(kv.second->h); drop_item(kv.second); } formatted.clear();
 	};
 	std::vector<std::thread> th;
 	for(int i = 0; i < lanes; i++) th.emplace_back(lane_main, i);
 	for(int i = 0; i < n_fin; i++) th.emplace_back(fin_main);
 	th.emplace_back(writer_main);
 	for(auto &t : th) t.join();
-	for(Item *it : fetched) { release(it->h); delete it; }
+	for(Item *it : fetched) { release(it->h); drop_item(it); }
 	if(rc == 0) { for(mm_align_t *q = a; q; q = q->sib) q->rlen_carry = carry; }
 	return rc;
 }
