@@ -734,6 +734,175 @@ __global__ void __launch_bounds__(64) mm_sort_kernel(K2sArgs a)
 }
 
 /* -----------------------------------------------------------------------------------------------------
+ * K2p + K2c: mm_chain_seeds (minialign.c:3547-3625) over the sorted seed array, in two launches.
+ *
+ *   K2p  mm_chain_scan_kernel   What one step of the chain sweep finds from seed i -- the last seed inside the shrinking window (succ, 0 = none) and the
+ *                               first seed it passes over (seen) -- depends on the sorted array alone, not on what earlier chains have marked.  So the
+ *                               window scans of all seeds run first, one seed per lane, straight from HBM / L2 (neighbouring lanes scan overlapping
+ *                               stretches), with no LDS and therefore at full occupancy.  pdiff() of the reference is evaluated on the window it has just
+ *                               updated and is always 0: "the largest (pdiff, sid)" is simply the last accepted sid.  Results go to the (still unused) leaf
+ *                               half of the read's seed region, 8 B per seed.
+ *   K2c  mm_chain_kernel        the sequential sweep itself -- a pointer chase over those tables, one lane per read does it -- on a compact image of the read
+ *                               in LDS: 10 B per seed (succ | seen << 16, upos + vpos, the leaf mark) and 12 B per leaf / chain, a third of what the
+ *                               16-byte seeds and leaves took, so that a CU holds four to six reads; nothing in the loop touches HBM.  Seeds' marks, leaves
+ *                               and chain roots are written out afterwards, in parallel; mm_circularize, the root sort and the prediction for the carried
+ *                               reference length follow as before.
+ * ----------------------------------------------------------------------------------------------------- */
+typedef __attribute__((address_space(3))) uint16_t LU16;
+struct K2pArgs { ReadState *st; const uint32_t *work; uint32_t n_work; Seed *seed_pool; uint32_t twlen; uint32_t *counter; unsigned long long *prof; };
+__global__ void __launch_bounds__(64) mm_chain_scan_kernel(K2pArgs a)
+{
+	const int lane = lane_id();
+	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
+	const int32_t tw = (int32_t)a.twlen;
+	while(true) {
+		uint32_t wi = 0;
+		if(lane == 0) { wi = atomicAdd(a.counter, 1u); }
+		wi = (uint32_t)rdfirst((int)wi);
+		if(wi >= a.n_work) { break; }
+		const ReadState *st = &a.st[a.work[wi]];
+		const uint32_t n = (uint32_t)rdfirst((int)st->seed_n0), n_all = n + 1;
+		if(n == 0 || n_all > K2S_MAX_N) { continue; }
+		const Seed *s = a.seed_pool + rdfirst64(st->seed_off);
+		uint2 *ss = (uint2 *)(a.seed_pool + rdfirst64(st->seed_off) + n_all);
+		const uint32_t tsid = n;
+		for(uint32_t i0 = 0; i0 < tsid; i0 += 64) {
+			const uint32_t i = i0 + (uint32_t)lane;
+			if(i < tsid) {
+				V4 wv = add_win(load_pv(s[i]), tw);
+				uint32_t last = 0, first_out = 0xffffffffu;
+				for(uint32_t jx = i + 1; jx <= tsid; jx++) {          /* the sentinel at tsid always ends the scan */
+					const V4 fv = load_pv(s[jx]);
+					if(inside_wv(wv, fv)) { wv = update_wv(wv, fv); last = jx; continue; }
+					first_out = first_out < jx ? first_out : jx;
+					if(!inside_uub(wv, fv)) { break; }
+				}
+				ss[i] = uint2{ last, first_out };
+			}
+		}
+	}
+	if(lane == 0) { atomicAdd(&a.prof[1], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
+}
+struct K2cArgs {
+	ReadState *st; const uint32_t *work; uint32_t n_work;
+	Seed *seed_pool; Root *root_pool;
+	uint32_t lds_bytes, n_lo, n_hi;   /* this launch takes the reads with n_lo < k2c_bytes(...) <= n_hi */
+	uint32_t retry, leaf_shift;       /* first attempt: room for (n + 1) >> leaf_shift leaves; retry = 1: the reads whose leaves did not fit (n_root = ~0), with room for n + 1 */
+	uint32_t *counter;
+	double mcoef; uint32_t min_score, twlen;
+	const uint32_t *seq_len; const uint8_t *seq_circ;
+	unsigned long long *prof;         /* [1] wave cycles, [5] reads whose leaf area overflowed */
+};
+__host__ __device__ inline uint32_t k2c_leafcap(uint32_t n_all, uint32_t shift) { return (n_all >> shift) + 64; }
+__host__ __device__ inline uint32_t k2c_bytes(uint32_t n_all, uint32_t leafcap) { return 10u * ((n_all + 63u) & ~63u) + 12u * ((leafcap + 63u) & ~63u) + 1536u * 4u; }
+__global__ void __launch_bounds__(64) mm_chain_kernel(K2cArgs a)
+{
+	extern __shared__ uint8_t lds_raw[];
+	const int lane = lane_id();
+	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
+	LU32 *tab = (LU32 *)(lds_raw + a.lds_bytes - 1536 * 4);       /* scratch of the root sort */
+	while(true) {
+		uint32_t wi = 0;
+		if(lane == 0) { wi = atomicAdd(a.counter, 1u); }
+		wi = (uint32_t)rdfirst((int)wi);
+		if(wi >= a.n_work) { break; }
+		ReadState *st = &a.st[a.work[wi]];
+		const uint32_t n = (uint32_t)rdfirst((int)st->seed_n0), n_all = n + 1;
+		if(n == 0) { if(a.n_lo == 0 && !a.retry && lane == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; } continue; }
+		if(n_all > K2S_MAX_N) { continue; }                               /* the in-HBM path of K2a takes these */
+		if(a.retry && (uint32_t)rdfirst((int)st->n_root) != 0xffffffffu) { continue; }
+		const uint32_t lcap = a.retry ? n_all : k2c_leafcap(n_all, a.leaf_shift);
+		const uint32_t need = k2c_bytes(n_all, lcap);
+		if(need <= a.n_lo || need > a.n_hi) { continue; }                /* another size class */
+		const uint32_t N = (n_all + 63u) & ~63u, C = (lcap + 63u) & ~63u;
+		LU32 *sv = (LU32 *)lds_raw, *uv = sv + N;
+		LU16 *mark = (LU16 *)(uv + N), *lrs = mark + N, *lls = lrs + C, *lcid = lls + C, *rlid = lcid + C;
+		LU32 *rplen = (LU32 *)(rlid + C);
+		Seed *gs = a.seed_pool + rdfirst64(st->seed_off);
+		Root *c = a.root_pool + rdfirst64(st->root_off);
+		const uint2 *ss = (const uint2 *)(gs + n_all);
+		for(uint32_t i = (uint32_t)lane; i < n; i += 64) {
+			const uint2 x = ss[i]; const Seed sd = gs[i];
+			sv[i] = (x.x & 0xffffu) | ((x.y == 0xffffffffu ? 0xffffu : (x.y & 0xffffu)) << 16);
+			uv[i] = sd.upos + sd.vpos; mark[i] = 0xffffu;
+		}
+		if(lane == 0) { st->n_seed = n; st->n_root = 0; st->pred_rid = gaba::NIL; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		/* ---- the sweep (minialign.c:3560-3622): one lane, everything it touches is in LDS ---- */
+		uint32_t ncid = 0, nleaf = 0; uint32_t over = 0;
+		if(lane == 0) {
+			uint32_t nlsid = 0; const uint32_t tsid = n;
+			while(nlsid < tsid) {
+				const uint32_t lf = nleaf++;                     /* leaf number; its id in the array is n_all + lf */
+				if(lf >= lcap) { over = 1; break; }
+				const uint32_t lsid0 = nlsid;
+				const uint32_t plen0 = uv[nlsid]; uint32_t scnt = 1;
+				lrs[lf] = (uint16_t)nlsid; lls[lf] = (uint16_t)nlsid; lcid[lf] = 0xffffu;
+				uint32_t nrsid = nlsid; nlsid = 0xffffffffu;
+				while(true) {
+					const uint32_t rsid = nrsid;
+					const uint32_t x = sv[rsid]; const uint32_t nx = x & 0xffffu; uint32_t sm = x >> 16; if(sm == 0xffffu) { sm = 0xffffffffu; }
+					nlsid = nlsid < sm ? nlsid : sm;
+					if(nx == 0) { nrsid = rsid; break; }
+					const uint32_t cl = mark[nx];
+					nrsid = nx;
+					if(cl != 0xffffu) { break; }
+					mark[nx] = (uint16_t)lf;
+					scnt++;
+					if(nlsid <= nx) { nlsid = 0xffffffffu; }
+				}
+				if(nrsid == lsid0) { continue; }
+				uint32_t cid = 0xffffu;
+				const uint32_t hl = mark[nrsid];                 /* leaf that marked the end seed (0xffff: none, i.e. INT32_MAX in the reference, never < lid) */
+				if(hl != 0xffffu && hl < lf) {
+					nrsid = lrs[hl];                              /* leaf.rsid */
+					cid = lcid[mark[nrsid] & 0x7fffu];            /* leaf.cid of the leaf that marks it */
+				}
+				bool fresh = false;
+				if(cid == 0xffffu) { cid = ncid++; fresh = true; }
+				const uint32_t eu = uv[nrsid];
+				const uint32_t plen = (uint32_t)OFS((int32_t)d2u32((1.0 - 1.0 / (double)scnt) * (double)(uint32_t)(eu - plen0)));
+				if(fresh) { rplen[cid] = (uint32_t)OFS(0); rlid[cid] = (uint16_t)lf; }
+				lcid[lf] = (uint16_t)cid; lrs[lf] = (uint16_t)nrsid;
+				if(plen < rplen[cid]) { rplen[cid] = plen; rlid[cid] = (uint16_t)lf; }
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		over = (uint32_t)rdfirst((int)over); ncid = (uint32_t)rdfirst((int)ncid); nleaf = (uint32_t)rdfirst((int)nleaf);
+		if(over) {
+			/* leaf area exhausted: nothing has been written, the retry launch redoes the read with room for one leaf per seed */
+			if(lane == 0) { if(!a.retry) { st->n_root = k2c_bytes(n_all, n_all) <= 160u * 1024u ? 0xffffffffu : 0xfffffffeu; atomicAdd(&a.prof[5], 1ull); } else { st->err |= ERR_SEED_CAP; } }
+			continue;
+		}
+		/* write out: the seeds' marks, the sentinel, the leaves { rsid, rid, lsid, cid }, the chain roots */
+		for(uint32_t i = (uint32_t)lane; i < n; i += 64) { const uint32_t mk = mark[i]; gs[i].lid = mk == 0xffffu ? 0x7fffffffu : n_all + mk; }
+		for(uint32_t lf = (uint32_t)lane; lf < nleaf; lf += 64) {
+			const uint32_t ls = lls[lf], ci = lcid[lf];
+			gs[n_all + lf] = Seed{ (uint32_t)lrs[lf], gs[ls].rid, ls, ci == 0xffffu ? 0xffffffffu : ci };
+		}
+		for(uint32_t ci = (uint32_t)lane; ci < ncid; ci += 64) { c[ci] = Root{ rplen[ci], n_all + (uint32_t)rlid[ci] }; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if(lane == 0) {
+			const uint32_t nlid = n_all + nleaf;
+			st->seed_n = nlid; st->n_root = ncid;
+			if(ncid) {
+				if(a.seq_circ) { circularize(gs, c, n, nlid, ncid, a.seq_len, a.seq_circ, a.twlen); }
+				if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)tab, 1536)) { st->err |= ERR_STACK; }              /* longest first (minialign.c:3719) */
+				uint32_t pred = gaba::NIL;
+				for(uint32_t kq = 0; kq < ncid; kq++) {
+					uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
+					if(pl * a.mcoef < 2.0 * a.min_score) { break; }
+					pred = gs[gs[c[kq].lid].upos].rid;
+				}
+				st->pred_rid = pred;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+	if(lane == 0) { atomicAdd(&a.prof[1], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
+}
+
+/* -----------------------------------------------------------------------------------------------------
  * K2a: the same stage, one *wavefront* per read with the seed / leaf array staged in LDS (first round only; reads whose
  * arrays do not fit the LDS budget, and the rescue rounds, take the lane-per-read kernel above).
  *   - radix levels whose digit is constant over the range are identity permutations and are skipped (one parallel
@@ -749,6 +918,7 @@ struct K2aArgs {
 	uint32_t n_lo, n_hi;              /* this launch takes the reads with n_lo < k2a_bytes(seed_n) <= n_hi (size class, bytes) */
 	uint32_t retry;                   /* 1: take the reads whose leaf area overflowed in their class (flagged n_root = ~0), with room for 2 (n + 1) */
 	uint32_t leaf_shift;              /* first attempt: a leaf area of (n + 1) >> leaf_shift elements (2: a quarter; the host lowers it when a batch needed many retries) */
+	uint32_t big_only;                /* 1: only the reads mm_sort_kernel / mm_chain_kernel leave out (n + 1 > K2S_MAX_N) */
 	uint32_t presorted;               /* 1: mm_sort_kernel has already sorted the seed arrays of the reads it takes (n + 1 <= K2S_MAX_N) */
 	uint32_t *counter;                /* work-list cursor of this launch */
 	uint32_t twlen; double mcoef; uint32_t min_score;
@@ -1001,6 +1171,8 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 		if(wi >= a.n_work) { break; }
 		ReadState *st = &a.st[a.work[wi]];
 		const uint32_t seed_n = (uint32_t)rdfirst((int)st->seed_n0);     /* not seed_n: launches of other classes update that concurrently */
+		/* big_only: what mm_chain_kernel cannot take -- more than K2S_MAX_N seeds, an LDS image of more than 160 KB, or leaves that did not fit even the retry */
+		if(a.big_only && seed_n + 1 <= K2S_MAX_N && k2c_bytes(seed_n + 1, k2c_leafcap(seed_n + 1, a.leaf_shift)) <= 160u * 1024u && (uint32_t)rdfirst((int)st->n_root) != 0xfffffffeu) { continue; }
 		if(seed_n == 0) { if(a.n_lo == 0 && !a.retry && lane == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; } continue; }
 		bool fits; uint32_t lcap = 0;
 		if(a.retry) {
@@ -1075,6 +1247,10 @@ struct K3Args {
 	const ReadIn *in; ReadState *st; const uint32_t *work; uint32_t n_work;
 	Seed *seed_pool; Root *root_pool;
 	uint8_t *slabs; uint64_t slab_bytes;                 /* DP workspace per wave */
+	/* non-NULL: the workspaces are shared by every launch of every lane -- a wave takes a free one when it starts and gives it back when it ends.  One ring of
+	 * free workspace numbers per XCD (a wave only ever takes from the ring of the XCD it runs on, HW_REG_XCC_ID): the L2s of different XCDs are not coherent
+	 * with each other inside a launch, so a workspace must not wander between them while kernels are running */
+	unsigned long long *ring_ctr; uint32_t *ring; uint32_t ring_n;      /* per XCD x: ring_ctr[2x] = takes, [2x + 1] = returns; ring[x * ring_n ..] = numbers (~0 = taken) */
 	KhSlot *kh_pool; uint32_t kh_cap;                    /* per read (work index) */
 	uint32_t round;
 	uint64_t *next_pool; uint32_t next_cap;              /* per wave: (pdiff, sid) */
@@ -1213,7 +1389,18 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 	const int lane = x.lane;
 	uint32_t wave = (uint32_t)rdfirst((int)(blockIdx.x * 4 + threadIdx.x / 64));
-	x.slab = a.slabs + (uint64_t)wave * a.slab_bytes; x.cap = (uint32_t)a.slab_bytes; x.top = gaba::SLAB_HEAD;
+	uint32_t slab_no = wave; uint32_t xcc = 0;
+	if(a.ring) {
+		xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;          /* HW_REG_XCC_ID, bits 3:0 */
+		uint32_t v = 0;
+		if(lane == 0) {
+			const unsigned long long t = atomicAdd(&a.ring_ctr[2 * xcc], 1ull);
+			uint32_t *slot = &a.ring[(uint64_t)xcc * a.ring_n + (uint32_t)(t % a.ring_n)];
+			while((v = atomicExch(slot, 0xffffffffu)) == 0xffffffffu) { __builtin_amdgcn_s_sleep(16); }       /* every workspace of this XCD is in use: one comes back when a wave ends */
+		}
+		slab_no = (uint32_t)rdfirst((int)v);
+	}
+	x.slab = a.slabs + (uint64_t)slab_no * a.slab_bytes; x.cap = (uint32_t)a.slab_bytes; x.top = gaba::SLAB_HEAD;
 	for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	Kh kh; kh.cap = a.kh_cap;
@@ -1508,6 +1695,11 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 		atomicAdd(&a.stats[12], cy_fill); atomicAdd(&a.stats[13], cy_leaf); atomicAdd(&a.stats[14], cy_trace); atomicAdd(&a.stats[11], cy_next);
 		atomicAdd(&a.stats[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
 		atomicMax(&a.stats[9], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));      /* longest-living wave: load balance */
+		if(a.ring) {
+			const unsigned long long t = atomicAdd(&a.ring_ctr[2 * xcc + 1], 1ull);
+			uint32_t *slot = &a.ring[(uint64_t)xcc * a.ring_n + (uint32_t)(t % a.ring_n)];
+			while(atomicCAS(slot, 0xffffffffu, slab_no) != 0xffffffffu) { __builtin_amdgcn_s_sleep(4); }        /* (the taker of this slot's previous turn has not picked its number up yet) */
+		}
 	}
 }
 

@@ -782,6 +782,9 @@ struct mm_align_s {
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
+	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
+	mm_align_s *root = nullptr;            /* the primary context of a lane (NULL on the primary itself) */
+	bool shared_slabs = false; DBuf<uint32_t> slab_ring; DBuf<unsigned long long> slab_ring_ctr; uint32_t slab_ring_n = 0;
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
 	/* reusable host buffers of the streaming engine (primary context only): pinned result buffers for the D2H of a batch, text pieces with their capacity */
@@ -797,6 +800,7 @@ struct mm_align_s {
 	mm_stats_t st; double t_wall0;
 	/* knobs (grown on overflow) */
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
+	void *pin_stage = nullptr; size_t pin_stage_cap = 0;      /* pinned staging buffer of the lane: the per-read state records and the packed reads cross PCIe through it (one DMA each instead of a train of staged blits) */
 	uint32_t k2_leaf_shift = 2;            /* leaf area of the first chaining attempt: (n + 1) >> shift; lowered when more than 2 % of a batch had to be retried */
 };
 
@@ -811,8 +815,28 @@ struct BatchOut {                       /* host copies of what post-map / SAM ne
 /* copies / memsets of the run path go to the lane's own (non-blocking) stream and wait on that stream only: the legacy default
  * stream would serialise every lane against every other */
 #define CPY(_a, _dst, _src, _n, _kind) do { CK(hipMemcpyAsync((_dst), (_src), (_n), (_kind), (_a)->stream)); CK(hipStreamSynchronize((_a)->stream)); } while(0)
+#define MM_SIDE 2          /* side streams per lane: every stream wants a hardware queue of its own (streams that share one run in order: the extension kernel of one lane
+                            * then blocks the sort + chain launches of another), and with GPU_MAX_HW_QUEUES=16 five lanes of 1 + 2 streams still get one each */
 #define CK(_e) do { hipError_t _r = (_e); if(_r != hipSuccess) { fprintf(stderr, "[minialign_amd] HIP error %s at %s:%d\n", hipGetErrorString(_r), __FILE__, __LINE__); return false; } } while(0)
 
+inline void *lane_stage(mm_align_t *a, size_t bytes)
+{
+	if(bytes > a->pin_stage_cap) { if(a->pin_stage) (void)hipHostFree(a->pin_stage); a->pin_stage = nullptr; a->pin_stage_cap = 0; size_t want = bytes + bytes / 4 + (1u << 20); if(hipHostMalloc(&a->pin_stage, want, hipHostMallocDefault) != hipSuccess) return nullptr; a->pin_stage_cap = want; }
+	return a->pin_stage;
+}
+/* host <-> device copies of a lane through its pinned staging buffer (falls back to the plain copy when pinning fails) */
+bool lane_d2h(mm_align_t *a, void *dst, const void *src, size_t n)
+{
+	void *st = lane_stage(a, n);
+	if(!st) { CPY(a, dst, src, n, hipMemcpyDeviceToHost); return true; }
+	CPY(a, st, src, n, hipMemcpyDeviceToHost); memcpy(dst, st, n); return true;
+}
+bool lane_h2d(mm_align_t *a, void *dst, const void *src, size_t n)
+{
+	void *st = lane_stage(a, n);
+	if(!st) { CPY(a, dst, src, n, hipMemcpyHostToDevice); return true; }
+	memcpy(st, src, n); CPY(a, dst, st, n, hipMemcpyHostToDevice); return true;
+}
 /* run K1..K3 over `work` (indices into the batch) with rlen_in already stored in d_st[].rlen */
 bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &work_in, bool run_k1, std::vector<ReadState> &hst,
 	const std::vector<uint32_t> *rlen_fixed, const std::vector<uint32_t> &qlens)
@@ -873,18 +897,50 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 					ks.lds_bytes = s_kb[si] * 1024u; ks.n_lo = si ? s_kb[si - 1] * 1024u : 0u; ks.n_hi = ks.lds_bytes; ks.counter = a->d_k2cnt.p + 16 + si;
 					const uint32_t per_cu = std::min<uint32_t>(16u, 160u / s_kb[si]);
 					const uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), n_cu * per_cu);
-					hipStream_t sq = a->k2s[si % 4];
-					if(si < 4) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
+					hipStream_t sq = a->k2s[si % MM_SIDE];
+					if(si < MM_SIDE) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
 					hipLaunchKernelGGL(mm_sort_kernel, dim3(grid), dim3(64), ks.lds_bytes, sq, ks);
 					CK(hipGetLastError());
 				}
-				for(int j = 0; j < 4; j++) { CK(hipEventRecord(a->k2e[12 + j], a->k2s[j])); }
-				for(int j = 0; j < 4; j++) { for(int i = 0; i < 4; i++) { if(i != j) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[12 + i], 0)); } } }
+				for(int j = 0; j < MM_SIDE; j++) { CK(hipEventRecord(a->k2e[12 + j], a->k2s[j])); }
+				for(int j = 0; j < MM_SIDE; j++) { for(int i = 0; i < MM_SIDE; i++) { if(i != j) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[12 + i], 0)); } } }
 			}
-			ka.presorted = presort ? 1u : 0u; ka.leaf_shift = a->k2_leaf_shift;
+			ka.presorted = presort ? 1u : 0u; ka.leaf_shift = a->k2_leaf_shift; ka.big_only = 0;
+			if(presort) {
+				/* chaining in two launches: the window scans of all seeds at full occupancy (mm_chain_scan_kernel, no LDS), then the sequential sweep on a
+				 * compact LDS image of each read (mm_chain_kernel, size classes by LDS need); what the old kernel is left with are reads too large for these */
+				static bool cattr = false;
+				if(!cattr) { CK(hipFuncSetAttribute((const void *)mm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); cattr = true; }
+				const uint32_t n_cu = a->n_waves / (4 * MM_K3_WAVES_PER_SIMD);
+				K2pArgs kp; kp.st = a->d_st.p; kp.work = a->d_work.p; kp.n_work = (uint32_t)work.size(); kp.seed_pool = a->seed_pool.p; kp.twlen = a->twlen; kp.counter = a->d_k2cnt.p + 24; kp.prof = tops + 24;
+				hipLaunchKernelGGL(mm_chain_scan_kernel, dim3(std::min<uint32_t>((uint32_t)work.size(), n_cu * 32u)), dim3(64), 0, a->k2s[0], kp);
+				CK(hipGetLastError());
+				CK(hipEventRecord(a->k2e[14], a->k2s[0]));
+				for(int j = 1; j < MM_SIDE; j++) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[14], 0)); }
+				static const uint32_t c_kb[] = { 12, 16, 24, 32, 48, 64, 96, 160 };
+				const int n_c = (int)(sizeof(c_kb) / sizeof(c_kb[0]));
+				K2cArgs kc; kc.st = a->d_st.p; kc.work = a->d_work.p; kc.n_work = (uint32_t)work.size(); kc.seed_pool = a->seed_pool.p; kc.root_pool = a->root_pool.p;
+				kc.leaf_shift = a->k2_leaf_shift ? 1u : 0u; kc.mcoef = a->mcoef; kc.min_score = a->o.min_score; kc.twlen = a->twlen; kc.seq_len = a->dix.seq_len; kc.seq_circ = a->dix.seq_circ; kc.prof = tops + 24;
+				for(int ci = 0; ci <= n_c; ci++) {
+					/* ci < n_c: size classes; ci == n_c: the reads whose leaves did not fit, with room for one leaf per seed, any size */
+					kc.retry = ci == n_c;
+					kc.lds_bytes = (ci == n_c ? 160u : c_kb[ci]) * 1024u; kc.n_lo = (ci == n_c || ci == 0) ? 0u : c_kb[ci - 1] * 1024u; kc.n_hi = kc.lds_bytes; kc.counter = a->d_k2cnt.p + ci;
+					const uint32_t per_cu = std::min<uint32_t>(16u, 160u * 1024u / kc.lds_bytes);
+					const uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), n_cu * per_cu);
+					hipStream_t sq = ci == n_c ? a->stream : a->k2s[ci % MM_SIDE];
+					if(ci == n_c) { for(int j = 0; j < MM_SIDE; j++) { CK(hipStreamWaitEvent(a->stream, a->k2e[j], 0)); } }
+					hipLaunchKernelGGL(mm_chain_kernel, dim3(grid), dim3(64), kc.lds_bytes, sq, kc);
+					CK(hipGetLastError());
+					if(ci == n_c - 1 || ci == n_c - 2) { CK(hipEventRecord(a->k2e[ci % MM_SIDE], sq)); }          /* the last launch on each side stream */
+				}
+				/* reads with more than K2S_MAX_N seeds: the old kernel's in-HBM form, behind everything else on the main stream */
+				ka.big_only = 1; ka.retry = 0; ka.leaf_shift = kc.leaf_shift; ka.lds_bytes = 1536 * 4; ka.n_lo = 0; ka.n_hi = 0xffffffffu; ka.counter = a->d_k2cnt.p + 12;
+				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(std::min<uint32_t>((uint32_t)work.size(), n_cu)), dim3(64), 1536 * 4, a->stream, ka);
+				CK(hipGetLastError());
+			}
 			auto bytes_of = [](uint32_t div) -> uint32_t { return div ? ((160u * 1024u / div) & ~255u) : 0u; };
-			for(int ci = 0; ci <= n_cls; ci++) {
-				/* ci < n_cls: size classes, largest first; ci == n_cls: retry of the reads whose leaf area overflowed, at 160 KB */
+			for(int ci = 0; ci <= n_cls && !presort; ci++) {
+				/* (the one-kernel form, kept behind MM_K2_NO_PRESORT / MM_K2_FORCE_HBM) ci < n_cls: size classes, largest first; ci == n_cls: retry of the reads whose leaf area overflowed, at 160 KB */
 				const uint32_t div = ci == n_cls ? 1u : cls_div[ci];
 				const uint32_t bytes = bytes_of(div);
 				ka.retry = ci == n_cls;
@@ -896,8 +952,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				const uint32_t per_cu = div ? div : 8;
 				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / (4 * MM_K3_WAVES_PER_SIMD)) * per_cu);
 				/* the classes are independent: each goes to its own stream behind ev0 so that their tails overlap; the retry waits for all */
-				hipStream_t sq = ci == n_cls ? a->stream : a->k2s[ci % 4];      /* four side streams: every stream wants a hardware queue, and those are few */
-				if(ci < n_cls && ci < 4) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
+				hipStream_t sq = ci == n_cls ? a->stream : a->k2s[ci % MM_SIDE];
+				if(ci < n_cls && ci < MM_SIDE) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
 				else { for(int j = 0; j < n_cls; j++) { CK(hipStreamWaitEvent(a->stream, a->k2e[j], 0)); } }
 				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(grid), dim3(64), bytes ? bytes : 1536 * 4, sq, ka);
 				CK(hipGetLastError());
@@ -912,7 +968,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		if(round == 0) {
 			/* seed the carried reference-length state (see ReadIn.rlen_in): either given exactly (re-runs), or predicted from
 			 * the chain lists: read i starts with the length of the last reference read i - 1 loads */
-			CPY(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
+			if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
 			if(rlen_fixed) { for(size_t i = 0; i < work.size(); i++) hst[work[i]].rlen = (*rlen_fixed)[i]; }
 			else {
 				uint32_t cur = a->rlen_carry;
@@ -922,7 +978,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				}
 			}
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
-			CPY(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState), hipMemcpyHostToDevice);
+			if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;
 		}
 		uint32_t k3_work_override = 0;
 		{
@@ -952,6 +1008,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		K3Args k3; k3.idx = a->dix; k3.gc = a->gctx->hc; k3.roots = a->gctx->droots; k3.ar_ref = gaba::SeqArena{ a->ref_ar->pk, a->ref_ar->nm }; k3.ar_q = gaba::SeqArena{ a->q_pk.p, a->q_nm.p };
 		k3.in = a->d_in.p; k3.st = a->d_st.p; k3.work = a->d_work.p; k3.n_work = k3_work_override ? k3_work_override : (uint32_t)work.size();
 		k3.seed_pool = a->seed_pool.p; k3.root_pool = a->root_pool.p; k3.slabs = a->slabs.p; k3.slab_bytes = a->slab_stride;
+		k3.ring = nullptr; k3.ring_ctr = nullptr; k3.ring_n = 0;
+		{ const mm_align_s *P = a->root ? a->root : a; if(P->shared_slabs) { k3.slabs = P->slabs.p; k3.slab_bytes = P->slab_stride; k3.ring = P->slab_ring.p; k3.ring_ctr = P->slab_ring_ctr.p; k3.ring_n = P->slab_ring_n; } }
 		k3.kh_pool = a->kh_pool.p; k3.kh_cap = a->kh_cap; k3.round = round; k3.next_pool = a->next_pool.p; k3.next_cap = a->next_cap;
 		k3.bin_pool = a->bin_pool.p; k3.bin_pool_cap = a->bin_pool.n; k3.bin_top = tops + 3; k3.bin_cap_per_read = a->bin_cap;
 		k3.aln_pool = a->aln_pool.p; k3.aln_pool_cap = a->aln_pool.n; k3.aln_top = tops + 4; k3.aln_cap_per_read = a->aln_cap;
@@ -970,7 +1028,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
-		CPY(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
+		if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
 		std::vector<uint32_t> nxt;
 		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u)) nxt.push_back(wi);
 		work.swap(nxt);
@@ -1310,10 +1368,37 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	const uint64_t budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 48ull) << 30;
 	const uint32_t lane_waves = a->is_sib ? (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u : a->n_waves;      /* lanes other than the first never launch more (run_rounds) */
 	uint32_t kw = (uint32_t)std::min<uint64_t>(lane_waves, std::max<uint64_t>(256, budget / slab)) & ~3u;
-	if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
+	mm_align_s *P = a->root ? a->root : a;
+	if(P->shared_slabs) {
+		/* the engine sized the shared workspaces for the longest read of the input before the lanes started */
+		if(P->slab_stride < slab) { fprintf(stderr, "[minialign_amd] a read longer than announced (%u bases) does not fit the shared DP workspaces\n", max_qlen); ok = false; }
+		a->k3_waves = lane_waves & ~3u;
+	}
+	else if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
 	else { ok &= a->slabs.ensure(slab * kw); if(ok) { a->slab_stride = a->slabs.n / kw; a->k3_waves = kw; } }
 	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(32);
 	return ok;
+}
+/* one set of DP workspaces for all lanes of a context (the streaming engine calls this before its lane threads start, with the longest read of the input):
+ * as many as waves can be resident (n_waves), fewer when MM_SLAB_GB (default 64) says so -- waves then wait for one to come back */
+bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
+{
+	max_qlen = (std::max(max_qlen, P->qlen_hint) + 8191u) & ~8191u;
+	const uint64_t blocks = 2 * ((2ull * max_qlen + 8192) / 32 + 64);
+	const uint64_t slab = (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull;
+	const uint64_t budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
+	const uint32_t n_xcd = 8;
+	uint32_t per = (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(32, budget / slab / n_xcd));
+	if(P->shared_slabs && P->slab_stride >= slab && P->slab_ring_n >= per) return true;
+	/* (re)allocation: only between runs -- nothing is in flight when the engine calls */
+	if(hipDeviceSynchronize() != hipSuccess) return false;
+	if(!P->slabs.ensure(slab * per * n_xcd) || !P->slab_ring.ensure((uint64_t)per * n_xcd) || !P->slab_ring_ctr.ensure(2 * n_xcd)) return false;
+	P->slab_stride = slab; P->slab_ring_n = per; P->k3_waves = P->n_waves;
+	std::vector<uint32_t> ring((size_t)per * n_xcd); for(size_t i = 0; i < ring.size(); i++) ring[i] = (uint32_t)i;
+	std::vector<unsigned long long> ctr(2 * n_xcd); for(uint32_t x = 0; x < n_xcd; x++) { ctr[2 * x] = 0; ctr[2 * x + 1] = per; }
+	if(hipMemcpy(P->slab_ring.p, ring.data(), ring.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(P->slab_ring_ctr.p, ctr.data(), ctr.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return false;
+	P->shared_slabs = true;
+	return true;
 }
 
 } /* anonymous */
@@ -1331,7 +1416,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	double mc = 0, xc = 0; for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 3)) mc += o->p.score_matrix[0]; else xc += o->p.score_matrix[0]; }
 	a->mcoef = mc / 4.0; a->xcoef = xc / 12.0;
 	if(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) { delete a; return NULL; }
-	for(int i = 0; i < 16; i++) { if((i < 12 && hipStreamCreateWithFlags(&a->k2s[i], hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) { delete a; return NULL; } }
+	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithFlags(&a->k2s[i], hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) { delete a; return NULL; } }
 	a->k2s_ok = true;
 	/* reference: one arena, per-sequence offsets */
 	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
@@ -1379,10 +1464,11 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 		gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
-	a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
+	a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
+	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
-	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < 12) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
+	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < MM_SIDE) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
 	delete a;
 }
 extern "C" void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line)
@@ -1441,9 +1527,9 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		/* unmappable reads are skipped outright (minialign.c:4434) */
 		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
 	}
-	CPY(a, a->q_pk.p, b.pk.data(), b.pk.size() * 4, hipMemcpyHostToDevice); CPY(a, a->q_nm.p, b.nm.data(), b.nm.size() * 4, hipMemcpyHostToDevice);
-	CPY(a, a->d_in.p, b.in.data(), b.n * sizeof(ReadIn), hipMemcpyHostToDevice);
-	CPY(a, a->d_st.p, b.hst.data(), b.n * sizeof(ReadState), hipMemcpyHostToDevice);
+	if(!lane_h2d(a, a->q_pk.p, b.pk.data(), b.pk.size() * 4) || !lane_h2d(a, a->q_nm.p, b.nm.data(), b.nm.size() * 4)) return false;
+	if(!lane_h2d(a, a->d_in.p, b.in.data(), b.n * sizeof(ReadIn))) return false;
+	if(!lane_h2d(a, a->d_st.p, b.hst.data(), b.n * sizeof(ReadState))) return false;
 	CK(hipMemsetAsync(a->d_tops.p, 0, 32 * 8, a->stream)); CK(hipStreamSynchronize(a->stream));
 	if(verbose) { fprintf(stderr, "[minialign_amd]   host state + H2D %.1f ms\n", now_ms() - tv); }
 	b.uploaded = true; b.ran = false;
@@ -1491,7 +1577,7 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 			hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL;
 			used[i] = redo_rlen[j];
 		}
-		if(hipMemcpyAsync(a->d_st.p, hst.data(), n_reads * sizeof(ReadState), hipMemcpyHostToDevice, a->stream) != hipSuccess || hipStreamSynchronize(a->stream) != hipSuccess) return -1;
+		if(!lane_h2d(a, a->d_st.p, hst.data(), n_reads * sizeof(ReadState))) return -1;
 		if(!run_rounds(a, n_reads, redo, true, hst, &redo_rlen, b.lens)) return -1;
 	}
 	return overflow ? 1 : 0;
@@ -1736,10 +1822,10 @@ static mm_align_t *align_lane(mm_align_t *a)
 	while(a->is_sib && false) {}
 	mm_align_t *q = new mm_align_s();
 	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off; q->d_seq_circ = a->d_seq_circ;
-	q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
+	q->root = a->root ? a->root : a; q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
 	q->qlen_hint = a->qlen_hint; q->k2_leaf_shift = a->k2_leaf_shift; q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
 	if(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess) { delete q; return NULL; }
-	for(int i = 0; i < 16; i++) { if((i < 12 && hipStreamCreateWithFlags(&q->k2s[i], hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&q->k2e[i], hipEventDisableTiming) != hipSuccess) { delete q; return NULL; } }
+	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithFlags(&q->k2s[i], hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&q->k2e[i], hipEventDisableTiming) != hipSuccess) { delete q; return NULL; } }
 	q->k2s_ok = true;
 	memset(&q->st, 0, sizeof(q->st)); q->t_wall0 = now_ms();
 	a->sib = q;
@@ -1833,6 +1919,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 	const int lanes = (int)std::max<uint32_t>(1, std::min<uint32_t>({ (uint32_t)lanes_want, n_batches, 8u }));
 	std::vector<mm_align_t *> ctx; { mm_align_t *q = a; for(int i = 0; i < lanes && q; i++) { ctx.push_back(q); if(i + 1 < lanes) q = align_lane(q); } }
 	if((int)ctx.size() < lanes || !ctx.back()) return 1;
+	if(!getenv("MM_NO_SHARED_SLABS") && !ensure_shared_slabs(a, a->qlen_hint)) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); return 1; }
 	/* host threads for post-map + text: -t when given, MM_HOST_THREADS, else up to 96; two finishers share them */
 	const uint32_t hw = std::max<uint32_t>(1, std::thread::hardware_concurrency());
 	const uint32_t fmt_total = getenv("MM_HOST_THREADS") ? (uint32_t)std::max(1, atoi(getenv("MM_HOST_THREADS"))) : (a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(hw, 96));
