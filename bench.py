@@ -141,10 +141,13 @@ def main():
         if getattr(args, k) is not None: w[k] = getattr(args, k); custom = True
     import torch
     dist = None; device = None
+    same_dev = os.environ.get('MM_BENCH_SAME_DEVICE') is not None      # test hook: every rank on device 0 with a gloo group (one-GPU boxes)
+    if same_dev: local = 0
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local); device = torch.device('cuda', local)
-        dist.init_process_group('nccl')
+        torch.cuda.set_device(local); device = None if same_dev else torch.device('cuda', local)
+        dist.init_process_group('gloo' if same_dev else 'nccl')
+    tdev = 'cpu' if same_dev else 'cuda'                                # where the few scalars of the reductions live
     from minialign_amd import multi
     lib = os.environ.get('MM_LIB_OVERRIDE') or os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')     # override: kernel experiments only
     if not os.path.exists(lib):
@@ -203,8 +206,8 @@ def main():
     st = Stats(); L.mm_stats(al, ctypes.byref(st), 0)
     sam_bytes = sm.col.total if sm else 0
     if dist:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        v = torch.tensor([float(bases), float(n_reads), float(sam_bytes), st.k1_ms, st.k2_ms, st.k3_ms, float(st.vectors), float(st.trace_steps), float(st.k3_launches), float(sm.stats['checks']), float(sm.stats['remapped_reads']), float(sm.stats['full_remaps'])], device='cuda', dtype=torch.float64)
+        t = torch.tensor([dt], device=tdev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        v = torch.tensor([float(bases), float(n_reads), float(sam_bytes), st.k1_ms, st.k2_ms, st.k3_ms, float(st.vectors), float(st.trace_steps), float(st.k3_launches), float(sm.stats['checks']), float(sm.stats['remapped_reads']), float(sm.stats['full_remaps'])], device=tdev, dtype=torch.float64)
         dist.all_reduce(v); tot = [float(x) for x in v.tolist()]
     else:
         tot = [float(bases), float(n_reads), float(sam_bytes), st.k1_ms, st.k2_ms, st.k3_ms, float(st.vectors), float(st.trace_steps), float(st.k3_launches), float(sm.stats['checks']), float(sm.stats['remapped_reads']), float(sm.stats['full_remaps'])]

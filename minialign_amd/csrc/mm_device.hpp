@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(64) mm_sort_kernel(K2sArgs a)
  *                               updated and is always 0: "the largest (pdiff, sid)" is simply the last accepted sid.  Results go to the (still unused) leaf
  *                               half of the read's seed region, 8 B per seed.
  *   K2c  mm_chain_kernel        the sequential sweep itself -- a pointer chase over those tables, one lane per read does it -- on a compact image of the read
- *                               in LDS: 10 B per seed (succ | seen << 16, upos + vpos, the leaf mark) and 12 B per leaf / chain, a third of what the
+ *                               in LDS: 12 B per seed ({ succ | seen << 16, leaf mark } read in one piece, upos + vpos) and 12 B per leaf / chain, half of what the
  *                               16-byte seeds and leaves took, so that a CU holds four to six reads; nothing in the loop touches HBM.  Seeds' marks, leaves
  *                               and chain roots are written out afterwards, in parallel; mm_circularize, the root sort and the prediction for the carried
  *                               reference length follow as before.
@@ -794,7 +794,7 @@ struct K2cArgs {
 	unsigned long long *prof;         /* [1] wave cycles, [5] reads whose leaf area overflowed */
 };
 __host__ __device__ inline uint32_t k2c_leafcap(uint32_t n_all, uint32_t shift) { return (n_all >> shift) + 64; }
-__host__ __device__ inline uint32_t k2c_bytes(uint32_t n_all, uint32_t leafcap) { return 10u * ((n_all + 63u) & ~63u) + 12u * ((leafcap + 63u) & ~63u) + 1536u * 4u; }
+__host__ __device__ inline uint32_t k2c_bytes(uint32_t n_all, uint32_t leafcap) { return 12u * ((n_all + 63u) & ~63u) + 12u * ((leafcap + 63u) & ~63u) + 1536u * 4u; }
 __global__ void __launch_bounds__(64) mm_chain_kernel(K2cArgs a)
 {
 	extern __shared__ uint8_t lds_raw[];
@@ -815,20 +815,24 @@ __global__ void __launch_bounds__(64) mm_chain_kernel(K2cArgs a)
 		const uint32_t need = k2c_bytes(n_all, lcap);
 		if(need <= a.n_lo || need > a.n_hi) { continue; }                /* another size class */
 		const uint32_t N = (n_all + 63u) & ~63u, C = (lcap + 63u) & ~63u;
-		LU32 *sv = (LU32 *)lds_raw, *uv = sv + N;
-		LU16 *mark = (LU16 *)(uv + N), *lrs = mark + N, *lls = lrs + C, *lcid = lls + C, *rlid = lcid + C;
+		/* per seed: ent = { succ | seen << 16, mark } (one 8-byte read gives everything the sweep wants to know about a seed), uv = upos + vpos;
+		 * per leaf: rsid, lsid, cid; per chain: lid, plen */
+		typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+		typedef __attribute__((address_space(3))) u32x2 LU64;
+		LU64 *ent = (LU64 *)lds_raw; LU32 *uv = (LU32 *)(ent + N);
+		LU16 *lrs = (LU16 *)(uv + N), *lls = lrs + C, *lcid = lls + C, *rlid = lcid + C;
 		LU32 *rplen = (LU32 *)(rlid + C);
 		Seed *gs = a.seed_pool + rdfirst64(st->seed_off);
 		Root *c = a.root_pool + rdfirst64(st->root_off);
 		const uint2 *ss = (const uint2 *)(gs + n_all);
 		for(uint32_t i = (uint32_t)lane; i < n; i += 64) {
 			const uint2 x = ss[i]; const Seed sd = gs[i];
-			sv[i] = (x.x & 0xffffu) | ((x.y == 0xffffffffu ? 0xffffu : (x.y & 0xffffu)) << 16);
-			uv[i] = sd.upos + sd.vpos; mark[i] = 0xffffu;
+			u32x2 ev; ev.x = (x.x & 0xffffu) | ((x.y == 0xffffffffu ? 0xffffu : (x.y & 0xffffu)) << 16); ev.y = 0xffffffffu; ent[i] = ev;
+			uv[i] = sd.upos + sd.vpos;
 		}
 		if(lane == 0) { st->n_seed = n; st->n_root = 0; st->pred_rid = gaba::NIL; }
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		/* ---- the sweep (minialign.c:3560-3622): one lane, everything it touches is in LDS ---- */
+		/* ---- the sweep (minialign.c:3560-3622): one lane, everything it touches is in LDS, one dependent read per chained seed ---- */
 		uint32_t ncid = 0, nleaf = 0; uint32_t over = 0;
 		if(lane == 0) {
 			uint32_t nlsid = 0; const uint32_t tsid = n;
@@ -836,35 +840,37 @@ __global__ void __launch_bounds__(64) mm_chain_kernel(K2cArgs a)
 				const uint32_t lf = nleaf++;                     /* leaf number; its id in the array is n_all + lf */
 				if(lf >= lcap) { over = 1; break; }
 				const uint32_t lsid0 = nlsid;
-				const uint32_t plen0 = uv[nlsid]; uint32_t scnt = 1;
-				lrs[lf] = (uint16_t)nlsid; lls[lf] = (uint16_t)nlsid; lcid[lf] = 0xffffu;
-				uint32_t nrsid = nlsid; nlsid = 0xffffffffu;
+				const u32x2 e0 = ent[lsid0]; const uint32_t plen0 = uv[lsid0]; uint32_t scnt = 1;
+				lrs[lf] = (uint16_t)lsid0; lls[lf] = (uint16_t)lsid0; lcid[lf] = 0xffffu;
+				uint32_t nrsid = lsid0, x = e0.x, hl = e0.y;    /* hl: the mark of the seed the chain stands on when it stops */
+				nlsid = 0xffffffffu;
 				while(true) {
-					const uint32_t rsid = nrsid;
-					const uint32_t x = sv[rsid]; const uint32_t nx = x & 0xffffu; uint32_t sm = x >> 16; if(sm == 0xffffu) { sm = 0xffffffffu; }
+					const uint32_t nx = x & 0xffffu; uint32_t sm = x >> 16; if(sm == 0xffffu) { sm = 0xffffffffu; }
 					nlsid = nlsid < sm ? nlsid : sm;
-					if(nx == 0) { nrsid = rsid; break; }
-					const uint32_t cl = mark[nx];
-					nrsid = nx;
-					if(cl != 0xffffu) { break; }
-					mark[nx] = (uint16_t)lf;
+					if(nx == 0) { break; }                        /* nothing inside the window: the chain ends on the seed it stands on */
+					const u32x2 en = ent[nx];
+					nrsid = nx; hl = en.y;
+					if(en.y != 0xffffffffu) { break; }            /* marked by an earlier leaf: the chain runs into that one */
+					((LU32 *)&ent[nx])[1] = lf; hl = lf;
 					scnt++;
 					if(nlsid <= nx) { nlsid = 0xffffffffu; }
+					x = en.x;
 				}
 				if(nrsid == lsid0) { continue; }
 				uint32_t cid = 0xffffu;
-				const uint32_t hl = mark[nrsid];                 /* leaf that marked the end seed (0xffff: none, i.e. INT32_MAX in the reference, never < lid) */
-				if(hl != 0xffffu && hl < lf) {
+				if(hl != 0xffffffffu && hl < lf) {
 					nrsid = lrs[hl];                              /* leaf.rsid */
-					cid = lcid[mark[nrsid] & 0x7fffu];            /* leaf.cid of the leaf that marks it */
+					cid = lcid[ent[nrsid].y & 0x7fffu];           /* leaf.cid of the leaf that marks it */
 				}
 				bool fresh = false;
 				if(cid == 0xffffu) { cid = ncid++; fresh = true; }
 				const uint32_t eu = uv[nrsid];
 				const uint32_t plen = (uint32_t)OFS((int32_t)d2u32((1.0 - 1.0 / (double)scnt) * (double)(uint32_t)(eu - plen0)));
-				if(fresh) { rplen[cid] = (uint32_t)OFS(0); rlid[cid] = (uint16_t)lf; }
+				uint32_t best = fresh ? (uint32_t)OFS(0) : rplen[cid];
+				if(fresh) { rlid[cid] = (uint16_t)lf; }
 				lcid[lf] = (uint16_t)cid; lrs[lf] = (uint16_t)nrsid;
-				if(plen < rplen[cid]) { rplen[cid] = plen; rlid[cid] = (uint16_t)lf; }
+				if(plen < best) { best = plen; rlid[cid] = (uint16_t)lf; }
+				if(fresh || plen == best) { rplen[cid] = best; }
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -875,7 +881,7 @@ __global__ void __launch_bounds__(64) mm_chain_kernel(K2cArgs a)
 			continue;
 		}
 		/* write out: the seeds' marks, the sentinel, the leaves { rsid, rid, lsid, cid }, the chain roots */
-		for(uint32_t i = (uint32_t)lane; i < n; i += 64) { const uint32_t mk = mark[i]; gs[i].lid = mk == 0xffffu ? 0x7fffffffu : n_all + mk; }
+		for(uint32_t i = (uint32_t)lane; i < n; i += 64) { const uint32_t mk = ent[i].y; gs[i].lid = mk == 0xffffffffu ? 0x7fffffffu : n_all + mk; }
 		for(uint32_t lf = (uint32_t)lane; lf < nleaf; lf += 64) {
 			const uint32_t ls = lls[lf], ci = lcid[lf];
 			gs[n_all + lf] = Seed{ (uint32_t)lrs[lf], gs[ls].rid, ls, ci == 0xffffu ? 0xffffffffu : ci };

@@ -65,3 +65,21 @@ def test_settling_a_wrong_guess_remaps_only_the_head(data):
             assert sm.col.text() == right, (first, guess, sm.stats)
             tried += sm.stats['remapped_reads'] > 0
     assert tried > 0, 'no case exercised the window re-map'
+
+def test_bench_line_with_two_ranks_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), here with both ranks on cuda:0 and a gloo group: one read set
+    split over the ranks, the carried value settled, ONE JSON line from rank 0 with the strong-scaling fields, and the records of the first reads identical to
+    the CPU reference / oracle (--check)"""
+    import json
+    env = dict(os.environ, MM_BENCH_SAME_DEVICE='1', MM_SLAB_GB='8', PYTHONPATH=M.ROOT)
+    port = 29800 + os.getpid() % 1500
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(M.ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', 'dm6', '--genome-len', '6000000', '--contigs', '40', '--depth', '8', '--lanes', '2', '--check', '--check-reads', '300', '--baseline-reads', '600'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=M.ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['value'] > 0 and d['unit'] == 'Gbases/s'
+    assert d['sam_identical'] is True, d.get('sam_check')
+    assert d['roofline']['achieved'] > 0 and 'cpu_baseline' not in d
