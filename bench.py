@@ -129,7 +129,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=2); ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='hg38', choices=sorted(WORKLOADS))
     ap.add_argument('--depth', type=float); ap.add_argument('--genome-len', type=int); ap.add_argument('--contigs', type=int); ap.add_argument('--repeat-frac', type=float)
-    ap.add_argument('--lanes', type=int, default=3, help='batches in flight per GPU (lanes of the device context)')
+    ap.add_argument('--lanes', type=int, default=4, help='batches in flight per GPU (lanes of the device context)')
     ap.add_argument('--check', action='store_true', help='verify the records of the first reads against the CPU reference also when N > 1')
     ap.add_argument('--check-reads', type=int, default=2000); ap.add_argument('--baseline-reads', type=int, default=60000)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU legs (baseline and identity check)')
@@ -231,7 +231,7 @@ def main():
                        'device_only_gbases_per_s (sum of kernel time, lanes overlap)': total_bases * K / max(1e-9, (k1_ms + k2_ms + k3_ms) * 1e-3) * 1e-9 / 1.0,
                        'kernel_ms_per_step (summed over lanes and ranks)': {'sketch_seed': k1_ms / K, 'sort_chain': k2_ms / K, 'extend': k3_ms / K},
                        'host_ms_per_step (rank 0, summed over its threads\' critical paths)': {'d2h': st.host_post_ms / K, 'post_map_and_sam_text': st.host_sam_ms / K},
-                       'extend_wave_time_split': {k: getattr(st, 'k3_cycles_' + k) / max(1, st.k3_cycles_total) for k in ('fill', 'leaf', 'trace', 'next')},
+                       'extend_wave_time_split': ({k: getattr(st, 'k3_cycles_' + k) / max(1, st.k3_cycles_total) for k in ('fill', 'leaf', 'trace', 'next')} if st.k3_cycles_fill else 'not compiled in (libminialign_amd_prof.so through MM_LIB_OVERRIDE has it)'),
                        'extend_wave_balance (mean / max lifetime)': st.k3_cycles_total / max(1, st.k3_cycles_max * st.k3_waves),
                        'sort_chain_wave_time_split': {'sort_cycles_per_seed': st.k2_cycles_sort / max(1, st.seeds), 'chain_cycles_per_seed': st.k2_cycles_chain / max(1, st.seeds), 'seeds_per_read': st.seeds / max(1, st.reads), 'reads_not_in_lds': st.k2_reads_hbm},
                        'dp_vectors_per_base': vec / max(1.0, total_bases * K), 'trace_steps_per_base': trs / max(1.0, total_bases * K), 'reruns_per_step (rank 0)': st.reruns / K,

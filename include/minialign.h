@@ -108,7 +108,7 @@ int mm_set_device(int dev);
 /* the streaming form main_align uses (minialign.c:6413-6436 with the pipeline of mm_align_file, :4725): the batches of a read set go through `lanes` lanes of
  * the device context, several in flight, with pack / H2D in front and D2H / post-map / text behind overlapped on host threads, and the text is handed to `sink`
  * in input order (a nonzero return from the sink stops the run).  mm_batch_pack prepares a batch ahead of time (2-bit packing on the host, no device work), so a
- * caller can time the map phase from packed reads in host memory to text in host memory; mm_map_reads packs on the fly.  lanes <= 0: the default (3).
+ * caller can time the map phase from packed reads in host memory to text in host memory; mm_map_reads packs on the fly.  lanes <= 0: the default (4).
  * Returns 0 on success.  The carried reference length (mm_align_get_carry) enters at the first batch and is left at its value after the last read. */
 typedef int (*mm_sam_sink_t)(void *opaque, uint32_t batch, char const *text, uint64_t len);
 mm_batch_t *mm_batch_pack(mm_reads_t const *r, uint32_t first, uint32_t n);

@@ -960,7 +960,7 @@ __device__ __forceinline__ void lds_ins_sort(S *beg, S *end)
 template<typename S>
 __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t seed_n, LU32 *cnt, LU32 *bb, LU32 *be, LU32 *stack,
 	Root *c, const K2aArgs &a, int lane, uint32_t &nlid_out, uint32_t &ncid_out, unsigned long long &cy_sort, unsigned long long &cy_chain,
-	const bool pre, LU32 *succ, LU32 *seen, const bool sorted)
+	const bool pre, LU32 *succ, LU32 *seen, const bool sorted, const bool chain = true)
 {
 	const uint32_t n_all = seed_n + 1;
 	const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
@@ -1041,6 +1041,7 @@ __device__ __forceinline__ bool sort_chain_wave(S *s, uint32_t cap, uint32_t see
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		const unsigned long long cy1 = __builtin_amdgcn_s_memtime(); cy_sort += cy1 - cy0;
+		if(!chain) { nlid_out = seed_n + 1; ncid_out = 0; return true; }
 
 		/* ---- mm_chain_seeds (minialign.c:3547-3625) ---- */
 		uint32_t ncid = 0, nlid = seed_n + 1, nlsid = 0; const uint32_t tsid = seed_n;
@@ -1266,6 +1267,11 @@ struct K3Args {
 	uint32_t *path_pool; uint64_t path_pool_cap; unsigned long long *path_top;
 	uint32_t tglen; double mcoef; float min_ratio; uint32_t min_score;
 	uint32_t *counter; unsigned long long *stats;        /* [2] fills, [3] vectors, [4] blocks, [5] traces, [6] trace steps */
+	/* rounds in the kernel: a read left without a result goes straight on to the next occurrence threshold on the wave that holds it (mm_align_seq's loop,
+	 * minialign.c:4444-4448) -- rescued minimizers expanded, seeds sorted and chained again in HBM by that wave, then extended -- instead of coming back
+	 * through the host for another round of launches */
+	uint32_t inkernel_rounds; Resc *resc_pool; uint32_t twlen;
+	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 };
 
 /* the per-read position hash, kh_t (minialign.c:341-683), literal */
@@ -1385,11 +1391,85 @@ __device__ __attribute__((noinline)) TraceOut k3_trace(DpIn in, uint32_t tail, g
 	return o;
 }
 
+/*
+ * mm_seed for iteration >= 1 + mm_chain (minialign.c:3509-3535, 3702-3725) for one read, by the wavefront that holds it: the rescue list is sorted once
+ * (key qs | n << 32, the same unstable radix sort), the minimizers whose occurrence count the new threshold admits are expanded behind the seeds, the whole
+ * array is sorted and chained again in place in HBM (sort_chain_wave, the form the largest reads take in K2a), chains circularised, roots sorted.  tab:
+ * 1536 words of LDS of this wave (bucket tables and range stack of the sort, scratch of the root sort).
+ */
+__device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uint32_t round, Seed *gs, Root *c, Resc *resc, DevIndex ix, uint32_t twlen, double mcoef, uint32_t min_score, LU32 *tab)
+{
+	const int lane = lane_id();
+	LU32 *cnt = tab, *bb = tab + 256, *be = tab + 512, *stack = tab + 768;
+	unsigned long long cs = 0, cc = 0; uint32_t nlid = 0, ncid = 0; uint32_t err = 0;
+	K2aArgs ka; ka.twlen = twlen;
+	const uint32_t n_resc = (uint32_t)rdfirst((int)st->n_resc);
+	if(round == 1 && n_resc > 1) {
+		/* n_resc elements, none of them a sentinel: the sort takes "seed_n + 1" elements as they are */
+		if(!sort_chain_wave<Seed>((Seed *)resc, n_resc, n_resc - 1, cnt, bb, be, stack, c, ka, lane, nlid, ncid, cs, cc, false, nullptr, nullptr, false, false)) { err |= ERR_STACK; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	}
+	uint32_t seed_n = (uint32_t)rdfirst((int)st->n_seed);
+	const uint32_t half = (uint32_t)rdfirst((int)st->seed_cap) / 2;
+	for(uint32_t i = (uint32_t)lane; i < seed_n; i += 64) { gs[i].lid = 0x7fffffffu; }
+	uint32_t p = (uint32_t)rdfirst((int)st->presc);
+	const uint32_t occ = ix.occ[round];
+	while(p < n_resc) {
+		const uint32_t qs = (uint32_t)rdfirst((int)resc[p].qs), mn = (uint32_t)rdfirst((int)resc[p].n); const uint64_t ref = rdfirst64(resc[p].ref);
+		if(mn > occ) { break; }
+		for(uint32_t j0 = 0; j0 < mn; j0 += 64) {
+			const uint32_t j = j0 + (uint32_t)lane;
+			if(j < mn) {
+				const uint64_t hit = (int64_t)ref >= 0 ? ref : ix.val[((ref & 0x7fffffffffffffffull) >> 24) + j];
+				const uint32_t rid = (uint32_t)(hit >> 32), rs = (uint32_t)hit;
+				const uint32_t rmask = (uint32_t)-(int32_t)(rid & 1);
+				const int32_t _rs = (int32_t)(rs + (ix.k & rmask)), _qs = (int32_t)(qs ^ rmask);
+				/* a hit that finds no room is dropped and flagged, the ones behind it move up (minialign.c: the reference reserves; here the host redoes the batch) */
+				if(seed_n + j + 2 < half) { gs[seed_n + j] = Seed{ U_(_rs, _qs), rid >> 1, V_(_rs, _qs), 0x7fffffffu }; }
+			}
+		}
+		if(seed_n + mn + 1 < half) { seed_n += mn; } else { err |= ERR_SEED_CAP; seed_n = seed_n + 2 < half ? half - 2 : seed_n; }
+		p++;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	if(lane == 0) { st->presc = p; st->n_seed = seed_n; st->n_root = 0; st->pred_rid = gaba::NIL; }
+	if(seed_n == 0 || (err & ERR_SEED_CAP)) { if(lane == 0) { st->seed_n = 0; } return err; }
+	if(lane == 0) { gs[seed_n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu }; }      /* sentinel, minialign.c:3531 */
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	if(!sort_chain_wave<Seed>(gs, 2 * half, seed_n, cnt, bb, be, stack, c, ka, lane, nlid, ncid, cs, cc, false, nullptr, nullptr, false, true)) { err |= ERR_SEED_CAP; return err; }
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	if(lane == 0) {
+		st->seed_n = nlid; st->n_root = ncid;
+		if(ncid) {
+			if(ix.seq_circ) { circularize(gs, c, seed_n, nlid, ncid, ix.seq_len, ix.seq_circ, twlen); }
+			if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)tab, 1536)) { err |= ERR_STACK; }
+			uint32_t pred = gaba::NIL;
+			for(uint32_t kq = 0; kq < ncid; kq++) {
+				uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
+				if(pl * mcoef < 2.0 * min_score) { break; }
+				pred = gs[gs[c[kq].lid].upos].rid;
+			}
+			st->pred_rid = pred;
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	return (uint32_t)rdfirst((int)err);
+}
+
 #ifndef MM_K3_WAVES_PER_SIMD
 #define MM_K3_WAVES_PER_SIMD 8
 #endif
+/* per-phase timing of the extension kernel (s_memtime around every fill / search / traceback, per-read ticks): compiled in with -DMM_K3_PROF only
+ * (__graft_entry__.build() makes libminialign_amd_prof.so that way; bench.py / tools take it through MM_LIB_OVERRIDE); the production kernel reads the clock
+ * twice per wave, for the load-balance figure */
+#ifdef MM_K3_PROF
+#define MM_TICK() __builtin_amdgcn_s_memtime()
+#else
+#define MM_TICK() 0ull
+#endif
 __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3Args a)
 {
+	__shared__ uint32_t k3_tab[4][1536];       /* per wave: tables of the in-kernel sort + chain of the rescue rounds (k3_rescue_round) */
 	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
 	gaba::Ctx x;
 	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
@@ -1410,7 +1490,11 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 	for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	Kh kh; kh.cap = a.kh_cap;
-	uint64_t *next = a.next_pool + (uint64_t)wave * (a.next_cap + MM_NEXT_SCRATCH);      /* [next_cap entries][radix-sort scratch] */
+	/* with shared workspaces a wave maps ONE read and ends (grid = reads / 4): wave slots then come free read by read, and the launches of the other lanes --
+	 * sketch, sort, chain, copies, the next extension launch -- get theirs within a read's time instead of waiting for a whole persistent launch to drain;
+	 * the per-wave scratch is numbered like the workspace.  Without the ring (per-call entries): persistent waves stealing reads from a counter, as before. */
+	const bool persistent = a.persistent != 0 || a.ring == nullptr;
+	uint64_t *next = a.next_pool + (uint64_t)(a.ring ? slab_no : wave) * (a.next_cap + MM_NEXT_SCRATCH);      /* [next_cap entries][radix-sort scratch] */
 	uint32_t *next_scratch = (uint32_t *)(next + a.next_cap);
 	const DevIndex &ix = a.idx;
 	unsigned long long n_fill = 0, n_trace = 0;
@@ -1419,13 +1503,19 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
 
 	while(true) {
-		uint32_t wi = 0;
-		if(lane == 0) { wi = atomicAdd(a.counter, 1u); }
-		wi = (uint32_t)rdfirst((int)wi);
+		uint32_t wi = wave;
+		if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
 		if(wi >= a.n_work) { break; }
 		const uint32_t r = (uint32_t)rdfirst((int)a.work[wi]);
 		ReadState *st = &a.st[r];
-		const unsigned long long cy_read0 = __builtin_amdgcn_s_memtime(); const uint32_t vec_read0 = x.n_vec; const unsigned long long cyf_read0 = cy_fill, cyt_read0 = cy_trace;
+		for(uint32_t round = a.round; ; round++) {
+		if(round != a.round) {
+			/* the next occurrence threshold for this read, here and now */
+			const uint32_t e2 = k3_rescue_round(st, round, a.seed_pool + rdfirst64(st->seed_off), a.root_pool + rdfirst64(st->root_off), a.resc_pool + rdfirst64(st->resc_off),
+				a.idx, a.twlen, a.mcoef, a.min_score, (LU32 *)&k3_tab[threadIdx.x / 64][0]);
+			if(e2) { if(lane == 0) { st->err |= e2; } break; }
+		}
+		const unsigned long long cy_read0 = MM_TICK(); const uint32_t vec_read0 = x.n_vec; const unsigned long long cyf_read0 = cy_fill, cyt_read0 = cy_trace;
 		const uint32_t n_root = (uint32_t)rdfirst((int)st->n_root);
 		/* reads with many chains run several extension trials and are the critical path of the launch (one of them can cost
 		 * three times a wave's fair share): their waves get issue priority so that they move at uncontended speed while the
@@ -1448,14 +1538,14 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 			if(lane == 0) { bo = atomicAdd(a.bin_top, (unsigned long long)a.bin_cap_per_read); ao = atomicAdd(a.aln_top, (unsigned long long)a.aln_cap_per_read); }
 			bin_off = rdfirst64(bo); aln_off = rdfirst64(ao); n_bin = 0; n_aln = 0;
 			/* no room in the pools: the read is given up for this pass (the host grows the pools and redoes the batch); it must not touch another read's region */
-			if(bin_off + a.bin_cap_per_read > a.bin_pool_cap || aln_off + a.aln_cap_per_read > a.aln_pool_cap) { if(lane == 0) { st->err |= ERR_BIN_CAP; } continue; }
+			if(bin_off + a.bin_cap_per_read > a.bin_pool_cap || aln_off + a.aln_cap_per_read > a.aln_pool_cap) { if(lane == 0) { st->err |= ERR_BIN_CAP; } break; }
 			/* first round of this read: mm_tbuf_clear (minialign.c:4402) */
 		}
 		uint64_t *bin = a.bin_pool + bin_off;
 		AlnRec *alns = a.aln_pool + aln_off;
 		/* the hash is cleared once per read (mm_tbuf_clear, minialign.c:4402) and shared by the rounds of that read */
 		kh.a = a.kh_pool + (uint64_t)r * a.kh_cap;
-		if(a.round == 0) { if(lane == 0) { kh_clear(kh); } }
+		if(round == 0) { if(lane == 0) { kh_clear(kh); } }
 		else { kh.mask = (uint32_t)rdfirst((int)st->kh_mask); kh.cnt = (uint32_t)rdfirst((int)st->kh_cnt); kh.ub = (uint32_t)rdfirst((int)st->kh_ub); }
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		x.err = 0;
@@ -1503,7 +1593,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 
 			bool first_iter = true;
 			while(true) {
-				const unsigned long long cy_n0 = __builtin_amdgcn_s_memtime();
+				const unsigned long long cy_n0 = MM_TICK();
 				if(!first_iter) {
 					/* mm_search_load_next (minialign.c:3888-3946) */
 					if(sr.srem == 0) { /* nothing */ }
@@ -1551,7 +1641,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 						}
 					}
 				}
-				cy_next += __builtin_amdgcn_s_memtime() - cy_n0;
+				cy_next += MM_TICK() - cy_n0;
 				first_iter = false;
 				if(!(sr.srem > 0 && sr.prem > 0)) { break; }
 
@@ -1567,10 +1657,10 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 					gaba::Sec cb = ((sr.rev != 0) == (pass == 0)) ? qsec_r : qsec_f;
 					uint32_t sa = pass == 0 ? sr.cp_a : rlen - sr.tp_a, sb = pass == 0 ? sr.cp_b : qlen - sr.tp_b;
 					DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
-					const unsigned long long cy0 = __builtin_amdgcn_s_memtime();
+					const unsigned long long cy0 = MM_TICK();
 					/* the downward pass is only searched for its maximum (the walk-back runs on the upward pass): no traceback masks */
 					ExtOut eo = k3_extend_core(din, bw, ca, sa, cb, sb, pass == 0, rcirc);
-					const unsigned long long cy1 = __builtin_amdgcn_s_memtime(); cy_fill += cy1 - cy0;
+					const unsigned long long cy1 = MM_TICK(); cy_fill += cy1 - cy0;
 					x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk);
 					m = (uint32_t)rdfirst((int)eo.m); mmax = (int64_t)rdfirst64((uint64_t)eo.mmax); n_fill += (uint32_t)rdfirst((int)eo.n_fill);
 					if(x.err) { skip = true; break; }
@@ -1578,7 +1668,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 					/* leaf_search: for pass 0 this is gaba_dp_search_max, for pass 1 the head of gaba_dp_trace */
 					din.top = x.top;
 					LeafOut lo = k3_leaf_search(din, m, pass == 0);
-					cy_leaf += __builtin_amdgcn_s_memtime() - cy1;
+					cy_leaf += MM_TICK() - cy1;
 					tlf = lo.lf; tplen = rdfirst64(lo.plen);
 					if(pass == 0) {
 						gaba::PosPair pp = lo.pp;
@@ -1614,9 +1704,9 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 				if(po + need_words + 2 > a.path_pool_cap || so_ + 8 > a.seg_pool_cap) { err |= ERR_PATH_CAP; break; }
 				uint32_t *path = a.path_pool + po + 2;
 				DpIn din2; din2.c = x.c; din2.ar0 = ar[0]; din2.ar1 = ar[1]; din2.slab = x.slab; din2.top = x.top; din2.cap = x.cap;
-				const unsigned long long cy2 = __builtin_amdgcn_s_memtime();
+				const unsigned long long cy2 = MM_TICK();
 				TraceOut to = k3_trace(din2, m, tlf, tplen, path, a.seg_pool + so_);
-				cy_trace += __builtin_amdgcn_s_memtime() - cy2;
+				cy_trace += MM_TICK() - cy2;
 				gaba::AlnOut ao = to.ao; x.err = rdfirst(to.d.err); x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr);
 				ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
 				n_trace++;
@@ -1690,10 +1780,14 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 			st->n_bin = n_bin; st->bin_off = bin_off; st->n_aln = n_aln; st->aln_off = aln_off;
 			st->kh_mask = kh.mask; st->kh_cnt = kh.cnt; st->kh_ub = kh.ub;
 			st->err |= err;
-			st->k3_ticks += (uint32_t)(__builtin_amdgcn_s_memtime() - cy_read0); st->k3_vec += x.n_vec - vec_read0;
+			st->k3_ticks += (uint32_t)(MM_TICK() - cy_read0); st->k3_vec += x.n_vec - vec_read0;
 			st->k3_fill_ticks += (uint32_t)(cy_fill - cyf_read0); st->k3_trace_ticks += (uint32_t)(cy_trace - cyt_read0);
 			if(n_res > 0) { st->done = 1; }
 		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if(!a.inkernel_rounds || n_res > 0 || err != 0 || round + 1 >= ix.n_occ) { break; }
+		}
+		if(!persistent) { break; }
 	}
 	if(lane == 0) {
 		atomicAdd(&a.stats[2], n_fill); atomicAdd(&a.stats[3], (unsigned long long)x.n_vec); atomicAdd(&a.stats[4], (unsigned long long)x.n_blk);

@@ -1017,6 +1017,11 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.path_pool = a->path_pool.p; k3.path_pool_cap = a->path_pool.n; k3.path_top = tops + 6;
 		k3.tglen = a->tglen; k3.mcoef = a->mcoef; k3.min_ratio = a->o.min_ratio; k3.min_score = a->o.min_score;
 		k3.counter = (uint32_t *)(tops + 16); k3.stats = tops + 8;
+		/* MM_K3_INKERNEL_ROUNDS: a read without a result goes on to the next occurrence threshold on the wave that holds it (k3_rescue_round) instead of coming
+		 * back for another round of launches.  Measured equal within noise on the headline workload (the device is bound by the extension work
+		 * itself either way), so the rounds stay separate launches by default -- each launch then is what its name says in a profile */
+		const bool inkernel = getenv("MM_K3_INKERNEL_ROUNDS") != NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL;
+		k3.inkernel_rounds = inkernel ? 1u : 0u; k3.resc_pool = a->resc_pool.p; k3.twlen = a->twlen;
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
 		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
 		/* several batches in flight (lanes): 5 persistent waves per SIMD keep the integer VALU as busy as 8 do (a wave issues at most every 4th cycle, about two
@@ -1024,6 +1029,11 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * tail of this launch: +4 % on the bench workload with 3 in flight (4.33 against 4.15 G bases/s), -10 % for a launch running alone */
 		else if(a->is_sib || a->sib) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u); }
 		CK(hipEventRecord(a->ev0, a->stream));
+		/* persistent waves stealing reads from a counter, never more of them than there are workspaces.  MM_K3_ONE_READ_PER_WAVE (with a workspace for every wave
+		 * the device can hold): grid = reads / 4, a wave maps one read and ends -- wave slots then come free read by read for the other lanes' launches; measured
+		 * slower on the headline workload (3.7 against 3.2 s per step), kept as an experiment */
+		k3.persistent = 1;
+		if(k3.ring) { if((uint64_t)k3.ring_n * 8 >= a->n_waves && getenv("MM_K3_ONE_READ_PER_WAVE")) { k3.persistent = 0; waves = (uint32_t)((k3.n_work + 3) & ~3u); } else { waves = std::min<uint32_t>(waves, (k3.ring_n * 8u) & ~3u); } }
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k3);
 		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
@@ -1032,6 +1042,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		std::vector<uint32_t> nxt;
 		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u)) nxt.push_back(wi);
 		work.swap(nxt);
+		if(inkernel) { break; }          /* every round of every read has run inside that launch */
 		if(getenv("MM_EXPERIMENT_K3_HEAVY")) { break; }
 	}
 	return true;
@@ -2063,7 +2074,7 @@ static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *
 	}
 	return sp;
 }
-static int default_lanes() { return getenv("MM_LANES") ? std::max(1, atoi(getenv("MM_LANES"))) : 3; }
+static int default_lanes() { return getenv("MM_LANES") ? std::max(1, atoi(getenv("MM_LANES"))) : 4; }
 /* maps a parsed read set (consumed unless keep) and writes its records */
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 {

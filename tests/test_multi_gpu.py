@@ -83,3 +83,18 @@ def test_bench_line_with_two_ranks_on_one_gpu():
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['value'] > 0 and d['unit'] == 'Gbases/s'
     assert d['sam_identical'] is True, d.get('sam_check')
     assert d['roofline']['achieved'] > 0 and 'cpu_baseline' not in d
+
+@pytest.mark.parametrize('env', [dict(MM_K3_INKERNEL_ROUNDS='1'), dict(MM_K3_INKERNEL_ROUNDS='1', MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1')],
+                         ids=['rounds-in-kernel', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain'])
+def test_alternative_schedules_give_the_same_bytes(env):
+    """the forms kept behind environment switches -- the occurrence-threshold rounds inside the extension kernel (k3_rescue_round), one read per wave, per-lane DP
+    workspaces, the one-kernel sort + chain -- on a repeat-rich set with a high seed threshold, where many reads need the rescue rounds"""
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
+        M.gensim('genome', 7401, 1500000, 6, 0.45, out=ref); M.gensim('reads', 7402, ref, 3.0, 'pacbio', 'fa', 6000, 2500, out=rd)
+        opts = ['-xpacbio', '-f0.2,0.05,0.002']
+        want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+        r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='8', MM_BATCH_BASES='3000000', **env), timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert _strip_pg(r.stdout) == want
+        assert b're-run' in r.stderr
