@@ -103,6 +103,10 @@ int mm_batch_run_async(mm_align_t *a, mm_batch_t *b);
 int mm_batch_wait(mm_align_t *a, mm_batch_t *b);
 int mm_batch_finish(mm_align_t *a, mm_batch_t *b, char **sam, uint64_t *sam_len);
 void mm_batch_free(mm_batch_t *b);
+/* stage taps (tests): runs sketch + lookup + expansion and the first round's sort + chain over the batch and stops; then, for one read, the number of minimizers,
+ * its seed array as mm_seed leaves it (minialign.c:3500: sorted, sentinel last; 4 words per seed: upos, rid, vpos, lid = INT32_MAX) and its chain roots as
+ * mm_chain leaves them (minialign.c:3702: plen | lid << 32, longest first).  0 on success; the batch can be run normally afterwards. */
+int mm_batch_tap(mm_align_t *a, mm_batch_t *b, uint32_t read, uint32_t *n_min, uint32_t *seeds, uint32_t seeds_cap, uint32_t *n_seeds, uint64_t *roots, uint32_t roots_cap, uint32_t *n_roots);
 int mm_set_device(int dev);
 
 /* the streaming form main_align uses (minialign.c:6413-6436 with the pipeline of mm_align_file, :4725): the batches of a read set go through `lanes` lanes of

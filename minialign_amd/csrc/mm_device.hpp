@@ -1469,7 +1469,8 @@ __device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uin
 #endif
 __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3Args a)
 {
-	__shared__ uint32_t k3_tab[4][1536];       /* per wave: tables of the in-kernel sort + chain of the rescue rounds (k3_rescue_round) */
+	extern __shared__ uint32_t k3_tab[];       /* launched with 4 x 1536 words when the rounds run in the kernel (per wave: tables of k3_rescue_round's sort + chain), else with none:
+	                                            * a static array would make the compiler trade the 8 waves per SIMD of the launch bounds for registers */
 	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
 	gaba::Ctx x;
 	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
@@ -1512,7 +1513,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 		if(round != a.round) {
 			/* the next occurrence threshold for this read, here and now */
 			const uint32_t e2 = k3_rescue_round(st, round, a.seed_pool + rdfirst64(st->seed_off), a.root_pool + rdfirst64(st->root_off), a.resc_pool + rdfirst64(st->resc_off),
-				a.idx, a.twlen, a.mcoef, a.min_score, (LU32 *)&k3_tab[threadIdx.x / 64][0]);
+				a.idx, a.twlen, a.mcoef, a.min_score, (LU32 *)&k3_tab[(threadIdx.x / 64) * 1536]);
 			if(e2) { if(lane == 0) { st->err |= e2; } break; }
 		}
 		const unsigned long long cy_read0 = MM_TICK(); const uint32_t vec_read0 = x.n_vec; const unsigned long long cyf_read0 = cy_fill, cyt_read0 = cy_trace;

@@ -801,6 +801,7 @@ struct mm_align_s {
 	/* knobs (grown on overflow) */
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
 	void *pin_stage = nullptr; size_t pin_stage_cap = 0;      /* pinned staging buffer of the lane: the per-read state records and the packed reads cross PCIe through it (one DMA each instead of a train of staged blits) */
+	bool tap_stop = false;                 /* mm_batch_tap: stop behind the sort + chain stage of the first round */
 	uint32_t k2_leaf_shift = 2;            /* leaf area of the first chaining attempt: (n + 1) >> shift; lowered when more than 2 % of a batch had to be retried */
 };
 
@@ -980,6 +981,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
 			if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;
 		}
+		if(a->tap_stop) { return true; }
 		uint32_t k3_work_override = 0;
 		{
 			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
@@ -1017,10 +1019,10 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.path_pool = a->path_pool.p; k3.path_pool_cap = a->path_pool.n; k3.path_top = tops + 6;
 		k3.tglen = a->tglen; k3.mcoef = a->mcoef; k3.min_ratio = a->o.min_ratio; k3.min_score = a->o.min_score;
 		k3.counter = (uint32_t *)(tops + 16); k3.stats = tops + 8;
-		/* MM_K3_INKERNEL_ROUNDS: a read without a result goes on to the next occurrence threshold on the wave that holds it (k3_rescue_round) instead of coming
-		 * back for another round of launches.  Measured equal within noise on the headline workload (the device is bound by the extension work
-		 * itself either way), so the rounds stay separate launches by default -- each launch then is what its name says in a profile */
-		const bool inkernel = getenv("MM_K3_INKERNEL_ROUNDS") != NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL;
+		/* a read without a result goes on to the next occurrence threshold on the wave that holds it (k3_rescue_round) instead of coming back through the host
+		 * for another round of launches: 2.77 against 3.20 s per step on the headline workload (the latency-bound rescue launches -- a serial sort + chain and
+		 * an extension launch of some eighty waves, twice -- took half of a lane's time per batch).  MM_K3_HOST_ROUNDS: the rounds as separate launches */
+		const bool inkernel = getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL;
 		k3.inkernel_rounds = inkernel ? 1u : 0u; k3.resc_pool = a->resc_pool.p; k3.twlen = a->twlen;
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
 		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
@@ -1031,10 +1033,10 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		CK(hipEventRecord(a->ev0, a->stream));
 		/* persistent waves stealing reads from a counter, never more of them than there are workspaces.  MM_K3_ONE_READ_PER_WAVE (with a workspace for every wave
 		 * the device can hold): grid = reads / 4, a wave maps one read and ends -- wave slots then come free read by read for the other lanes' launches; measured
-		 * slower on the headline workload (3.7 against 3.2 s per step), kept as an experiment */
+		 * no faster on the headline workload (2.86 against 2.77 s per step with the rounds in the kernel, 3.7 against 3.2 without), kept as an experiment */
 		k3.persistent = 1;
 		if(k3.ring) { if((uint64_t)k3.ring_n * 8 >= a->n_waves && getenv("MM_K3_ONE_READ_PER_WAVE")) { k3.persistent = 0; waves = (uint32_t)((k3.n_work + 3) & ~3u); } else { waves = std::min<uint32_t>(waves, (k3.ring_n * 8u) & ~3u); } }
-		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k3);
+		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), inkernel ? 4 * 1536 * 4 : 0, a->stream, k3);
 		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
@@ -1897,6 +1899,37 @@ extern "C" int mm_batch_wait(mm_align_t *a, mm_batch_t *h)
 	return h->rc;
 }
 extern "C" void mm_batch_free(mm_batch_t *h) { if(h && h->running) { h->th.join(); } delete h; }
+/* stage taps (tests): sketch + lookup + expansion (K1) and sort + chain (K2s, K2p, K2c) of the first round over the batch, nothing behind them; then for one
+ * read the number of minimizers K1 emitted, its seed array as mm_seed leaves it (sorted, sentinel last, lid = INT32_MAX; four words per seed: upos, rid,
+ * vpos, lid -- mm_seed_t, minialign.c:3187) and its chain roots as mm_chain leaves them (plen | lid << 32, longest first; mm_root_t :3202).  0 on success. */
+extern "C" int mm_batch_tap(mm_align_t *a, mm_batch_t *h, uint32_t read, uint32_t *n_min, uint32_t *seeds, uint32_t seeds_cap, uint32_t *n_seeds, uint64_t *roots, uint32_t roots_cap, uint32_t *n_roots)
+{
+	mm_align_t *c = h->ctx ? h->ctx : a; Batch &b = h->b;
+	if(read >= b.n) return -1;
+	if(!b.packed) batch_pack(b);
+	if(!batch_upload(c, b)) return -1;
+	c->tap_stop = true;
+	const bool ok = run_rounds(c, b.n, b.work, true, b.hst, nullptr, b.lens);
+	c->tap_stop = false;
+	if(!ok) return -1;
+	const ReadState &rs = b.hst[read];
+	if(rs.err) return -2;
+	if(n_min) *n_min = rs.n_min;
+	const uint32_t ns = rs.n_seed ? rs.n_seed + 1 : 0;
+	if(n_seeds) *n_seeds = ns;
+	if(seeds && ns) {
+		std::vector<Seed> tmp(ns);
+		if(hipMemcpy(tmp.data(), c->seed_pool.p + rs.seed_off, (size_t)ns * sizeof(Seed), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+		for(uint32_t i = 0; i < ns && i < seeds_cap; i++) { seeds[4 * i] = tmp[i].upos; seeds[4 * i + 1] = tmp[i].rid; seeds[4 * i + 2] = tmp[i].vpos; seeds[4 * i + 3] = 0x7fffffffu; }
+	}
+	if(n_roots) *n_roots = rs.n_root;
+	if(roots && rs.n_root) {
+		std::vector<Root> tmp(rs.n_root);
+		if(hipMemcpy(tmp.data(), c->root_pool.p + rs.root_off, (size_t)rs.n_root * sizeof(Root), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+		for(uint32_t i = 0; i < rs.n_root && i < roots_cap; i++) roots[i] = (uint64_t)tmp[i].plen | ((uint64_t)tmp[i].lid << 32);
+	}
+	return 0;
+}
 extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
 
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = false);
@@ -1921,6 +1954,25 @@ extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
  * The only value that couples batches, the carried reference length, is final for batch k as soon as batch k - 1 has been verified; a batch that ran ahead
  * with a guess re-runs the reads whose `apos >= rlen` decision the true value changes (batch_verify_carry), which is what a single stream would have computed.
  */
+/* a batch that does not fit the device pools however they are grown (settings under which every minimizer has thousands of hits): its reads in halves,
+ * one after the other on the same lane, down to single reads -- slow, but the run goes on where the reference's would (it just grinds) */
+static bool map_split(mm_align_t *c, const Batch &b, uint32_t lo, uint32_t hi, std::vector<std::string> &pieces)
+{
+	Batch sub;
+	for(uint32_t i = lo; i < hi; i++) { sub.lens.push_back(b.lens[i]); sub.seq.push_back(b.seq[i]); sub.names.push_back(b.names[i]); if(i < b.rec.size()) sub.rec.push_back(b.rec[i]); }
+	const uint32_t carry_in = c->rlen_carry;
+	const bool pretend = getenv("MM_TEST_SPLIT") && hi - lo >= 8;          /* test hook: as if nothing of 8 reads or more fitted */
+	if(!pretend && batch_prepare(c, sub) && batch_run(c, sub)) {
+		std::vector<std::string> part;          /* (batch_format takes over whatever strings it is handed, for their capacity) */
+		if(!batch_finish_pieces(c, sub, part)) return false;
+		for(auto &x : part) pieces.emplace_back(std::move(x));
+		return true;
+	}
+	if(hi - lo < 2) { fprintf(stderr, "[minialign_amd] read `%s' does not fit the device pools\n", b.names[lo].c_str()); return false; }
+	c->rlen_carry = carry_in;
+	const uint32_t mid = lo + (hi - lo) / 2;
+	return map_split(c, b, lo, mid, pieces) && map_split(c, b, mid, hi, pieces);
+}
 typedef std::function<bool(uint32_t, std::vector<std::string> &)> PieceSink;          /* (batch, pieces) in batch order; false = stop */
 static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_batch_t *(uint32_t)> &make, const std::function<void(mm_batch_t *)> &release,
 	const PieceSink &sink, int lanes_want)
@@ -1964,19 +2016,33 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 				ok = batch_upload(c, b);
 				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): pack + upload %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
 				/* run ahead with the predicted carry; pools that overflow are grown here, before anybody waits for this batch */
-				while(ok) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0 || !batch_grow(c, b) || !batch_upload(c, b)) ok = false; }
+				bool split = false;
+				if(getenv("MM_TEST_SPLIT") && b.n >= 8) { split = true; }          /* test hook: take the path of a batch the pools cannot hold */
+				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) ok = false; }
 				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): run %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
 				uint32_t truth = 0;
 				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return verified == k || rc != 0; }); if(rc) ok = false; truth = carry; }
-				while(ok) {
+				while(ok && !split) {
 					c->rlen_carry = truth;
 					int r = batch_verify_carry(c, b);
 					if(r == 0) break;
 					/* an overflow among the re-runs: the whole batch again with larger pools, now with the true value from the start */
-					if(r < 0 || !batch_grow(c, b) || !batch_upload(c, b)) { ok = false; break; }
+					if(r < 0) { ok = false; break; }
+					if(!batch_grow(c, b)) { split = true; break; }
+					if(!batch_upload(c, b)) { ok = false; break; }
 					r = batch_run_spec(c, b); if(r < 0) { ok = false; }
 				}
-				if(ok) {
+				if(ok && split) {
+					/* the pools cannot hold this batch: its reads in halves on this lane, in order, with the true carried value; the text goes straight to the writer */
+					Item *it = new Item(); it->h = h; it->k = k;
+					c->rlen_carry = truth; b.scale = 1;
+					ok = map_split(c, b, 0, b.n, it->piece);
+					if(ok) {
+						{ std::lock_guard<std::mutex> lk(mu); carry = c->rlen_carry; verified = k + 1; pending++; formatted[k] = it; if(k == 0) { a->head.clear(); a->head_carry_in = truth; head_open = false; } }
+						cv.notify_all();
+					} else { delete it; }
+				}
+				else if(ok) {
 					b.ran = true;
 					const uint32_t out = batch_carry_out(c, b, truth);
 					{
@@ -1990,7 +2056,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 					/* the batch that is written next never waits here: everything queued in front of the writer is behind it */
 					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return pending < max_pending || k == next_write || rc != 0; }); if(rc) ok = false; else pending++; }
 				}
-				if(ok) {
+				if(ok && !split) {
 					Item *it = new Item(); it->h = h; it->k = k;
 					{ std::lock_guard<std::mutex> lk(a->pool_mu); if(!a->pin_free.empty()) { it->f.pin = a->pin_free.back(); a->pin_free.pop_back(); } if(!a->piece_free.empty()) { it->piece = std::move(a->piece_free.back()); a->piece_free.pop_back(); } }
 					if(!it->f.pin) it->f.pin = new mm_align_s::PinSet();
