@@ -43,8 +43,7 @@ class Stats(ctypes.Structure):
                 ('host_post_ms', ctypes.c_double), ('host_sam_ms', ctypes.c_double), ('wall_ms', ctypes.c_double),
                 ('k3_cycles_fill', ctypes.c_uint64), ('k3_cycles_leaf', ctypes.c_uint64), ('k3_cycles_trace', ctypes.c_uint64),
                 ('k3_cycles_total', ctypes.c_uint64), ('k3_cycles_next', ctypes.c_uint64), ('k3_cycles_max', ctypes.c_uint64), ('k3_waves', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
-                ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64),
-                ('spec_ms', ctypes.c_double), ('spec_launches', ctypes.c_uint64), ('spec_jobs', ctypes.c_uint64), ('spec_hits', ctypes.c_uint64), ('spec_vectors', ctypes.c_uint64), ('spec_trace_steps', ctypes.c_uint64)]
+                ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64)]
 
 def gensim_exe():
     exe = os.path.join(ROOT, 'tools', 'gensim')
@@ -236,7 +235,6 @@ def main():
                        'extend_wave_balance (mean / max lifetime)': st.k3_cycles_total / max(1, st.k3_cycles_max * st.k3_waves),
                        'sort_chain_wave_time_split': {'sort_cycles_per_seed': st.k2_cycles_sort / max(1, st.seeds), 'chain_cycles_per_seed': st.k2_cycles_chain / max(1, st.seeds), 'seeds_per_read': st.seeds / max(1, st.reads), 'reads_not_in_lds': st.k2_reads_hbm},
                        'dp_vectors_per_base': vec / max(1.0, total_bases * K), 'trace_steps_per_base': trs / max(1.0, total_bases * K), 'reruns_per_step (rank 0)': st.reruns / K,
-                       'first_trials_ahead (rank 0; mm_spec_extend_kernel, reads with 6 chains or more)': {'ms_per_step': st.spec_ms / K, 'jobs_per_step': st.spec_jobs / K, 'taken_by_the_extension_kernel': st.spec_hits / K, 'dp_vectors': st.spec_vectors / K, 'trace_steps': st.spec_trace_steps / K},
                        'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
                        'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'parse_and_pack_s': t_load},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -137,9 +137,6 @@ typedef struct {
 	uint64_t k3_cycles_max, k3_waves;       /* lifetime of the longest-living wave (summed over launches), persistent waves per launch */
 	/* the same for the first-round sort + chain kernel, and the number of reads whose seed array did not fit the LDS */
 	uint64_t k2_cycles_sort, k2_cycles_chain, k2_cycles_total, k2_reads_hbm;
-	/* first trials of the chains of many-chain reads computed ahead (mm_spec_extend_kernel): launches and their summed time, jobs, jobs whose result the extension
-	 * kernel took, DP vectors and traceback steps computed there (vectors / trace_steps above are the extension kernel's own) */
-	double spec_ms; uint64_t spec_launches, spec_jobs, spec_hits, spec_vectors, spec_trace_steps;
 } mm_stats_t;
 void mm_stats(mm_align_t *a, mm_stats_t *out, int reset);
 

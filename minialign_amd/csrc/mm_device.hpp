@@ -67,7 +67,6 @@ struct ReadState {
 	uint32_t k3_ticks, k3_vec, k3_fill_ticks, k3_trace_ticks;   /* diagnostics: s_memtime ticks (whole / DP fill / traceback) and DP vectors the extension kernel spent on this read */
 	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
 	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
-	uint32_t spec_off, spec_n;                        /* first trials of this read's chains computed ahead (SpecMemo entries), 0: none */
 };
 enum : uint32_t { ERR_SEED_CAP = 1, ERR_DP_SLAB = 2, ERR_PATH_CAP = 4, ERR_SEG_CAP = 8, ERR_KH_CAP = 16, ERR_BIN_CAP = 32, ERR_ALN_CAP = 64, ERR_NEXT_CAP = 128, ERR_STACK = 256 };
 
@@ -1250,7 +1249,6 @@ struct AlnRec {                /* what the host needs of a gaba_alignment_t (gab
 	uint32_t seg_off;          /* index into the segment pool */
 	uint64_t path_off;         /* word offset into the path pool; two header words {plen, 0x40000000} precede it (gaba.h:217) */
 };
-struct SpecMemo;
 struct K3Args {
 	DevIndex idx; gaba::Consts gc; const uint8_t *roots; gaba::SeqArena ar_ref, ar_q;
 	const ReadIn *in; ReadState *st; const uint32_t *work; uint32_t n_work;
@@ -1273,7 +1271,6 @@ struct K3Args {
 	 * minialign.c:4444-4448) -- rescued minimizers expanded, seeds sorted and chained again in HBM by that wave, then extended -- instead of coming back
 	 * through the host for another round of launches */
 	uint32_t inkernel_rounds; Resc *resc_pool; uint32_t twlen;
-	const SpecMemo *memo; const uint32_t *spath; const gaba::Segment *sseg;      /* first trials computed ahead (mm_spec_extend_kernel), NULL: none */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 };
 
@@ -1462,165 +1459,6 @@ __device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uin
 #ifndef MM_K3_WAVES_PER_SIMD
 #define MM_K3_WAVES_PER_SIMD 8
 #endif
-/* -----------------------------------------------------------------------------------------------------
- * Speculative first trials (the chain level of parallelism inside a read).
- *
- * mm_extend walks the chains of a read one after the other, and on a read with dozens of chains (repeats; the long tail of an ONT-like length distribution) that
- * walk is the critical path of a whole launch: one wave, one chain at a time.  What couples the chains is small: the carried reference length (known from the root
- * list), the position hash and the result bins (a trial's *inputs* do not depend on them, only what is done with its results).  The first trial of a chain -- the
- * downward extension from its root seed, the max search, the upward extension from the max and the traceback -- is a pure function of (reference, cp_a, cp_b,
- * strand, band) and the scoring constants.  So for reads with many chains these first trials are computed ahead, all chains of a read side by side on as many
- * waves (mm_spec_jobs_kernel enumerates them exactly as mm_search_load_root / load_pos would set them up, mm_spec_extend_kernel runs them into a memo and a
- * staging area), and the extension kernel proper, still walking the chains in order with the real hash and bins, takes a memoised result wherever the inputs of
- * the trial it is about to run are the memo's -- the duplicate test, the narrowing, the bookkeeping all run as ever on it; anything else is computed on the spot.
- * Results are the same by construction; a chain whose first trial turns out a duplicate cost an upward pass for nothing.
- * ----------------------------------------------------------------------------------------------------- */
-struct SpecJob { uint32_t r, aid, cp_a, cp_b, rev, rlen, rcirc, pad; };
-struct SpecMemo {
-	uint32_t state;                  /* bit 0: downward pass + max search valid, bit 1: upward pass (+ traceback when mmax1 >= min_score) valid */
-	uint32_t aid, cp_a, cp_b, rev;   /* the inputs it was computed for */
-	uint32_t pp_apos, pp_bpos; uint64_t pp_plen; int64_t mmax0;
-	int64_t mmax1; uint64_t tplen; uint64_t path_off; uint32_t seg_off;
-	gaba::AlnOut ao;
-	uint32_t n_vec0, n_blk0, n_fill0, n_vec1, n_blk1, n_fill1, n_tr;
-};
-struct SpecArgs {
-	DevIndex idx; gaba::Consts gc; const uint8_t *roots; gaba::SeqArena ar_ref, ar_q;
-	const ReadIn *in; ReadState *st; const uint32_t *work; uint32_t n_work;
-	Seed *seed_pool; Root *root_pool;
-	uint8_t *slabs; uint64_t slab_bytes; unsigned long long *ring_ctr; uint32_t *ring; uint32_t ring_n;
-	double mcoef; uint32_t min_score, min_roots;
-	SpecJob *jobs; SpecMemo *memo; uint64_t job_cap; unsigned long long *job_top;       /* job_top[0] = jobs enumerated, [1] = work cursor of the extend kernel, [2] path words, [3] segments, [4] DP vectors, [5] traceback steps computed */
-	uint32_t *spath; uint64_t spath_cap; gaba::Segment *sseg; uint64_t sseg_cap;
-};
-/* one thread per read: the chains mm_extend will visit (root order, up to the length test of mm_search_load_root, minialign.c:3849) with the positions
- * mm_search_load_pos gives their root seeds -- the `apos >= rlen` test sees the length of the reference the chain in front loaded (minialign.c:3864) */
-__global__ void __launch_bounds__(64) mm_spec_jobs_kernel(SpecArgs a)
-{
-	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if(t >= a.n_work) { return; }
-	const uint32_t r = a.work[t];
-	ReadState *st = &a.st[r];
-	st->spec_n = 0; st->spec_off = 0;
-	const uint32_t n_root = st->n_root;
-	if(n_root < a.min_roots || n_root == 0xffffffffu) { return; }
-	const DevIndex &ix = a.idx;
-	const Seed *s = a.seed_pool + st->seed_off; const Root *root = a.root_pool + st->root_off;
-	const uint32_t qlen = a.in[r].qlen;
-	uint32_t cnt = 0;
-	for(uint32_t kq = 0; kq < n_root; kq++) { const uint32_t plen = (uint32_t)OFS((int32_t)root[kq].plen); if(plen * a.mcoef < 2.0 * a.min_score) { break; } cnt++; }
-	if(cnt < a.min_roots) { return; }
-	const unsigned long long off = atomicAdd(&a.job_top[0], (unsigned long long)cnt);
-	if(off + cnt > a.job_cap) { return; }
-	uint32_t rlen = st->rlen;
-	for(uint32_t kq = 0; kq < cnt; kq++) {
-		const uint32_t lid = root[kq].lid, rsid = s[lid].upos; const Seed p = s[rsid];
-		const int32_t bs = BS(p); const uint32_t rev = bs < 0;
-		uint32_t cpa = (uint32_t)AS(p), cpb = (uint32_t)(bs + ((bs >> 31) & (int32_t)qlen));
-		if(cpa >= rlen || cpb >= qlen) { cpa -= min(cpa, ix.k); cpb -= min(cpb, ix.k); }
-		rlen = ix.seq_len[p.rid];
-		a.jobs[off + kq] = SpecJob{ r, p.rid, cpa, cpb, rev, rlen, ix.seq_circ ? (uint32_t)ix.seq_circ[p.rid] : 0u, 0u };
-		a.memo[off + kq].state = 0;
-	}
-	st->spec_off = (uint32_t)off; st->spec_n = cnt;
-}
-__global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_spec_extend_kernel(SpecArgs a)
-{
-	gaba::SeqArena ar[2] = { a.ar_ref, a.ar_q };
-	gaba::Ctx x;
-	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
-	const int lane = x.lane;
-	const unsigned long long n_jobs = min(rdfirst64(a.job_top[0]), (unsigned long long)a.job_cap);
-	if(n_jobs == 0) { return; }
-	/* a workspace of this XCD's ring (K3Args.ring) */
-	const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
-	uint32_t slab_no = 0;
-	{
-		uint32_t v = 0;
-		if(lane == 0) {
-			const unsigned long long t = atomicAdd(&a.ring_ctr[2 * xcc], 1ull);
-			uint32_t *slot = &a.ring[(uint64_t)xcc * a.ring_n + (uint32_t)(t % a.ring_n)];
-			while((v = atomicExch(slot, 0xffffffffu)) == 0xffffffffu) { __builtin_amdgcn_s_sleep(16); }
-		}
-		slab_no = (uint32_t)rdfirst((int)v);
-	}
-	x.slab = a.slabs + (uint64_t)slab_no * a.slab_bytes; x.cap = (uint32_t)a.slab_bytes; x.top = gaba::SLAB_HEAD;
-	for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	const DevIndex &ix = a.idx;
-	unsigned long long sv_vec = 0, sv_tr = 0;          /* DP vectors / traceback steps this wave computed */
-	while(true) {
-		unsigned long long ji = 0;
-		if(lane == 0) { ji = atomicAdd(&a.job_top[1], 1ull); }
-		ji = rdfirst64(ji);
-		if(ji >= n_jobs) { break; }
-		const SpecJob j = a.jobs[ji];
-		const uint32_t r = (uint32_t)rdfirst((int)j.r), aid = (uint32_t)rdfirst((int)j.aid), cp_a = (uint32_t)rdfirst((int)j.cp_a), cp_b = (uint32_t)rdfirst((int)j.cp_b);
-		const uint32_t rev = (uint32_t)rdfirst((int)j.rev), rlen = (uint32_t)rdfirst((int)j.rlen); const int rcirc = rdfirst((int)j.rcirc);
-		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen); const uint64_t q_off = rdfirst64(a.in[r].q_off), roff = rdfirst64(ix.seq_off[aid]);
-		const gaba::Sec rsec_f = gaba::Sec{ aid << 1, rlen, roff, 0, 0 }, rsec_r = gaba::Sec{ (aid << 1) + 1, rlen, roff, 0, 1 };
-		const gaba::Sec qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }, qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
-		SpecMemo mo; mo.state = 0; mo.aid = aid; mo.cp_a = cp_a; mo.cp_b = cp_b; mo.rev = rev; mo.mmax0 = 0; mo.mmax1 = 0; mo.tplen = 0; mo.path_off = 0; mo.seg_off = 0;
-		mo.pp_apos = mo.pp_bpos = 0; mo.pp_plen = 0; mo.n_vec0 = mo.n_blk0 = mo.n_fill0 = mo.n_vec1 = mo.n_blk1 = mo.n_fill1 = mo.n_tr = 0;
-		mo.ao.status = 0; mo.ao.score = 0; mo.ao.identity = 0; mo.ao.agcnt = mo.ao.bgcnt = mo.ao.dcnt = mo.ao.slen = mo.ao.plen = 0;
-		gaba::dp_flush(x); x.err = 0;
-		/* downward pass + max search */
-		DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
-		ExtOut eo = k3_extend_core(din, 0, rsec_f, cp_a, rev ? qsec_r : qsec_f, cp_b, 1, rcirc);
-		x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err);
-		mo.n_vec0 = (uint32_t)rdfirst((int)eo.d.n_vec); mo.n_blk0 = (uint32_t)rdfirst((int)eo.d.n_blk); mo.n_fill0 = (uint32_t)rdfirst((int)eo.n_fill);
-		uint32_t m = (uint32_t)rdfirst((int)eo.m); int64_t mmax = (int64_t)rdfirst64((uint64_t)eo.mmax);
-		bool go = x.err == 0;
-		if(go) {
-			mo.mmax0 = mmax; mo.state = 1;
-			if(mmax == 0) { go = false; }
-		}
-		if(go) {
-			din.top = x.top;
-			LeafOut lo = k3_leaf_search(din, m, 1);
-			gaba::PosPair pp = lo.pp;
-			mo.pp_apos = (uint32_t)rdfirst((int)pp.apos); mo.pp_bpos = (uint32_t)rdfirst((int)pp.bpos); mo.pp_plen = rdfirst64(pp.plen);
-			const uint32_t tp_a = (uint32_t)max(1, min((int32_t)mo.pp_apos, (int32_t)rlen)), tp_b = (uint32_t)max(1, min((int32_t)mo.pp_bpos, (int32_t)qlen));
-			/* upward pass from the max + max search */
-			din.top = x.top;
-			ExtOut e1 = k3_extend_core(din, 0, rsec_r, rlen - tp_a, rev ? qsec_f : qsec_r, qlen - tp_b, 0, rcirc);
-			x.top = (uint32_t)rdfirst((int)e1.d.top); x.err = rdfirst(e1.d.err);
-			mo.n_vec1 = (uint32_t)rdfirst((int)e1.d.n_vec); mo.n_blk1 = (uint32_t)rdfirst((int)e1.d.n_blk); mo.n_fill1 = (uint32_t)rdfirst((int)e1.n_fill);
-			m = (uint32_t)rdfirst((int)e1.m); mmax = (int64_t)rdfirst64((uint64_t)e1.mmax);
-			if(x.err == 0) {
-				mo.mmax1 = mmax;
-				if(mmax < (int64_t)a.min_score) { mo.state |= 2; }
-				else {
-					din.top = x.top;
-					LeafOut l1 = k3_leaf_search(din, m, 0);
-					const uint64_t tplen = rdfirst64(l1.plen);
-					const uint64_t need_words = (tplen + 31) / 32 + 2;
-					unsigned long long po = 0, so_ = 0;
-					if(lane == 0) { po = atomicAdd(&a.job_top[2], (unsigned long long)need_words); so_ = atomicAdd(&a.job_top[3], 8ull); }
-					po = rdfirst64(po); so_ = rdfirst64(so_);
-					if(po + need_words <= a.spath_cap && so_ + 8 <= a.sseg_cap) {
-						DpIn din2; din2.c = x.c; din2.ar0 = ar[0]; din2.ar1 = ar[1]; din2.slab = x.slab; din2.top = x.top; din2.cap = x.cap;
-						TraceOut to = k3_trace(din2, m, l1.lf, tplen, a.spath + po, a.sseg + so_);
-						gaba::AlnOut ao = to.ao;
-						ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
-						if(rdfirst(to.d.err) == 0) { mo.ao = ao; mo.tplen = tplen; mo.path_off = po; mo.seg_off = (uint32_t)so_; mo.n_tr = (uint32_t)rdfirst((int)to.d.n_tr); mo.state |= 2; }
-					}
-				}
-			}
-		}
-		sv_vec += (unsigned long long)mo.n_vec0 + mo.n_vec1; sv_tr += mo.n_tr;
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		if(lane == 0) { a.memo[ji] = mo; }
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	}
-	if(lane == 0) {
-		atomicAdd(&a.job_top[4], sv_vec); atomicAdd(&a.job_top[5], sv_tr);
-		const unsigned long long t = atomicAdd(&a.ring_ctr[2 * xcc + 1], 1ull);
-		uint32_t *slot = &a.ring[(uint64_t)xcc * a.ring_n + (uint32_t)(t % a.ring_n)];
-		while(atomicCAS(slot, 0xffffffffu, slab_no) != 0xffffffffu) { __builtin_amdgcn_s_sleep(4); }
-	}
-}
-
 /* per-phase timing of the extension kernel (s_memtime around every fill / search / traceback, per-read ticks): compiled in with -DMM_K3_PROF only
  * (__graft_entry__.build() makes libminialign_amd_prof.so that way; bench.py / tools take it through MM_LIB_OVERRIDE); the production kernel reads the clock
  * twice per wave, for the load-balance figure */
@@ -1660,7 +1498,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 	uint64_t *next = a.next_pool + (uint64_t)(a.ring ? slab_no : wave) * (a.next_cap + MM_NEXT_SCRATCH);      /* [next_cap entries][radix-sort scratch] */
 	uint32_t *next_scratch = (uint32_t *)(next + a.next_cap);
 	const DevIndex &ix = a.idx;
-	unsigned long long n_fill = 0, n_trace = 0, n_hit = 0;
+	unsigned long long n_fill = 0, n_trace = 0;
 	unsigned long long cy_fill = 0, cy_leaf = 0, cy_trace = 0;        /* wave cycles spent in the three DP phases (s_memtime) */
 	unsigned long long cy_next = 0;                                  /* ... and in mm_search_load_next */
 	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
@@ -1680,7 +1518,6 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 		}
 		const unsigned long long cy_read0 = MM_TICK(); const uint32_t vec_read0 = x.n_vec; const unsigned long long cyf_read0 = cy_fill, cyt_read0 = cy_trace;
 		const uint32_t n_root = (uint32_t)rdfirst((int)st->n_root);
-		const uint32_t spec_n = (a.memo != nullptr && round == 0) ? (uint32_t)rdfirst((int)st->spec_n) : 0u, spec_off = (uint32_t)rdfirst((int)st->spec_off);
 		/* reads with many chains run several extension trials and are the critical path of the launch (one of them can cost
 		 * three times a wave's fair share): their waves get issue priority so that they move at uncontended speed while the
 		 * ordinary reads fill the slots in between */
@@ -1755,7 +1592,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 			rsec_f = gaba::Sec{ sr.aid << 1, rlen, roff, 0, 0 }; rsec_r = gaba::Sec{ (sr.aid << 1) + 1, rlen, roff, 0, 1 };
 			rcirc = ix.seq_circ ? rdfirst((int)ix.seq_circ[sr.aid]) : 0;          /* rtp = circular ? r : t (minialign.c:3753) */
 
-			bool first_iter = true, chain_first = true;
+			bool first_iter = true;
 			while(true) {
 				const unsigned long long cy_n0 = MM_TICK();
 				if(!first_iter) {
@@ -1816,27 +1653,10 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 				const int bw = (int)sr.narrow;               /* _dp(x) ignores its argument (minialign.c:4123) */
 				uint32_t m = gaba::NIL; int64_t mmax = 0; gaba::Leaf tlf; uint64_t tplen = 0;
 				bool skip = false;
-				/* the first trial of a chain may have been computed ahead (mm_spec_extend_kernel): taken if it was computed for exactly these inputs */
-				const SpecMemo *smp = a.memo + (spec_off + kq); bool memo0 = false, memo1 = false, memo_trace = false;          /* (fields are read where they are used: uniform loads) */
-				if(chain_first && bw == 0 && kq < spec_n) {
-					const uint32_t stt = (uint32_t)rdfirst((int)smp->state);
-					if((stt & 1u) && (uint32_t)rdfirst((int)smp->aid) == sr.aid && (uint32_t)rdfirst((int)smp->cp_a) == sr.cp_a && (uint32_t)rdfirst((int)smp->cp_b) == sr.cp_b && (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u)) { memo0 = true; memo1 = (stt & 2u) != 0; }
-				}
-				chain_first = false;
 				for(int pass = 0; pass < 2 && !skip; pass++) {
 					gaba::Sec ca = pass == 0 ? rsec_f : rsec_r;
 					gaba::Sec cb = ((sr.rev != 0) == (pass == 0)) ? qsec_r : qsec_f;
 					uint32_t sa = pass == 0 ? sr.cp_a : rlen - sr.tp_a, sb = pass == 0 ? sr.cp_b : qlen - sr.tp_b;
-					gaba::PosPair pp; pp.aid = pp.bid = 0; pp.apos = pp.bpos = 0; pp.plen = 0;
-					if(pass == 0 ? memo0 : memo1) {
-						/* memoised pass: its work counters, its maximum, and -- pass 0 -- the position of the maximum / -- pass 1 -- the path length for the pools */
-						/* (its vectors were counted by the launch that computed them) */
-						if(pass == 0) { n_hit++; }
-						mmax = (int64_t)rdfirst64((uint64_t)(pass == 0 ? smp->mmax0 : smp->mmax1)); m = gaba::NIL;
-						if(pass == 0 ? (mmax == 0) : (mmax < (int64_t)a.min_score)) { skip = true; break; }
-						if(pass == 0) { pp.apos = (uint32_t)rdfirst((int)smp->pp_apos); pp.bpos = (uint32_t)rdfirst((int)smp->pp_bpos); pp.plen = rdfirst64(smp->pp_plen); }
-						else { tplen = rdfirst64(smp->tplen); memo_trace = true; }
-					} else {
 					DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
 					const unsigned long long cy0 = MM_TICK();
 					/* the downward pass is only searched for its maximum (the walk-back runs on the upward pass): no traceback masks */
@@ -1851,9 +1671,9 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 					LeafOut lo = k3_leaf_search(din, m, pass == 0);
 					cy_leaf += MM_TICK() - cy1;
 					tlf = lo.lf; tplen = rdfirst64(lo.plen);
-					if(pass == 0) { pp = lo.pp; pp.apos = (uint32_t)rdfirst((int)pp.apos); pp.bpos = (uint32_t)rdfirst((int)pp.bpos); pp.plen = rdfirst64(pp.plen); }
-					}
 					if(pass == 0) {
+						gaba::PosPair pp = lo.pp;
+						pp.apos = (uint32_t)rdfirst((int)pp.apos); pp.bpos = (uint32_t)rdfirst((int)pp.bpos); pp.plen = rdfirst64(pp.plen);
 						/* mm_search_test_dup (minialign.c:3953-3982) */
 						uint64_t key = mm_key((uint64_t)pp.apos | ((uint64_t)pp.bpos << 32), (uint64_t)sr.aid | ((uint64_t)sr.bid << 32));
 						uint64_t prev = 0;
@@ -1884,23 +1704,12 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 				po = rdfirst64(po); so_ = rdfirst64(so_);
 				if(po + need_words + 2 > a.path_pool_cap || so_ + 8 > a.seg_pool_cap) { err |= ERR_PATH_CAP; break; }
 				uint32_t *path = a.path_pool + po + 2;
-				gaba::AlnOut ao;
-				if(memo_trace) {
-					/* the traceback was done ahead: its path words and segments move from the staging area into the pools */
-					const uint32_t *sp = a.spath + rdfirst64(smp->path_off); const gaba::Segment *sg = a.sseg + (uint32_t)rdfirst((int)smp->seg_off);
-					for(uint64_t i = (uint64_t)lane; i < need_words; i += 64) { path[i] = sp[i]; }
-					ao = smp->ao; ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
-					for(uint32_t i = (uint32_t)lane; i < ao.slen && i < 8; i += 64) { a.seg_pool[so_ + i] = sg[i]; }
-					x.err = 0;
-					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-				} else {
 				DpIn din2; din2.c = x.c; din2.ar0 = ar[0]; din2.ar1 = ar[1]; din2.slab = x.slab; din2.top = x.top; din2.cap = x.cap;
 				const unsigned long long cy2 = MM_TICK();
 				TraceOut to = k3_trace(din2, m, tlf, tplen, path, a.seg_pool + so_);
 				cy_trace += MM_TICK() - cy2;
-				ao = to.ao; x.err = rdfirst(to.d.err); x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr);
+				gaba::AlnOut ao = to.ao; x.err = rdfirst(to.d.err); x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr);
 				ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
-				}
 				n_trace++;
 				if(x.err) { err |= (x.err == 1 ? ERR_DP_SLAB : (x.err == 2 ? ERR_PATH_CAP : ERR_SEG_CAP)); break; }
 				if(ao.status != 1) { continue; }           /* NULL alignment: path left the band */
@@ -1983,7 +1792,7 @@ __global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3
 	}
 	if(lane == 0) {
 		atomicAdd(&a.stats[2], n_fill); atomicAdd(&a.stats[3], (unsigned long long)x.n_vec); atomicAdd(&a.stats[4], (unsigned long long)x.n_blk);
-		atomicAdd(&a.stats[5], n_trace); atomicAdd(&a.stats[6], (unsigned long long)x.n_tr); if(n_hit) { atomicAdd(&a.stats[10], n_hit); }
+		atomicAdd(&a.stats[5], n_trace); atomicAdd(&a.stats[6], (unsigned long long)x.n_tr);
 		atomicAdd(&a.stats[12], cy_fill); atomicAdd(&a.stats[13], cy_leaf); atomicAdd(&a.stats[14], cy_trace); atomicAdd(&a.stats[11], cy_next);
 		atomicAdd(&a.stats[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
 		atomicMax(&a.stats[9], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));      /* longest-living wave: load balance */

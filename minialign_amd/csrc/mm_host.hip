@@ -782,7 +782,6 @@ struct mm_align_s {
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
-	DBuf<SpecJob> spec_job; DBuf<SpecMemo> spec_memo; DBuf<uint32_t> spec_path; DBuf<gaba::Segment> spec_seg; DBuf<unsigned long long> d_spec_top; hipEvent_t evs = nullptr;   /* speculative first trials (mm_spec_*_kernel) */
 	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
 	mm_align_s *root = nullptr;            /* the primary context of a lane (NULL on the primary itself) */
 	bool shared_slabs = false; DBuf<uint32_t> slab_ring; DBuf<unsigned long long> slab_ring_ctr; uint32_t slab_ring_n = 0;
@@ -1031,23 +1030,6 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * thirds of its instructions are VALU) and leave wave slots for the sketch and sort + chain kernels of the other lanes, which otherwise wait for the
 		 * tail of this launch: +4 % on the bench workload with 3 in flight (4.33 against 4.15 G bases/s), -10 % for a launch running alone */
 		else if(a->is_sib || a->sib) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u); }
-		k3.memo = nullptr; k3.spath = nullptr; k3.sseg = nullptr;
-		if(k3.ring && round == 0 && !getenv("MM_NO_SPEC")) {
-			/* reads with many chains: the first trial of every chain ahead of the extension kernel, the chains of a read side by side (see mm_spec_extend_kernel) */
-			if(!a->evs) { CK(hipEventCreate(&a->evs)); }
-			SpecArgs sa; sa.idx = a->dix; sa.gc = k3.gc; sa.roots = k3.roots; sa.ar_ref = k3.ar_ref; sa.ar_q = k3.ar_q; sa.in = k3.in; sa.st = k3.st; sa.work = k3.work; sa.n_work = k3.n_work;
-			sa.seed_pool = k3.seed_pool; sa.root_pool = k3.root_pool; sa.slabs = k3.slabs; sa.slab_bytes = k3.slab_bytes; sa.ring_ctr = k3.ring_ctr; sa.ring = k3.ring; sa.ring_n = k3.ring_n;
-			sa.mcoef = a->mcoef; sa.min_score = a->o.min_score; sa.min_roots = getenv("MM_SPEC_MIN_ROOTS") ? (uint32_t)std::max(1, atoi(getenv("MM_SPEC_MIN_ROOTS"))) : 6u;
-			sa.jobs = a->spec_job.p; sa.memo = a->spec_memo.p; sa.job_cap = a->spec_job.n; sa.job_top = a->d_spec_top.p; sa.spath = a->spec_path.p; sa.spath_cap = a->spec_path.n; sa.sseg = a->spec_seg.p; sa.sseg_cap = a->spec_seg.n;
-			CK(hipMemsetAsync(a->d_spec_top.p, 0, 8 * 8, a->stream));
-			CK(hipEventRecord(a->evs, a->stream));
-			hipLaunchKernelGGL(mm_spec_jobs_kernel, dim3((sa.n_work + 63) / 64), dim3(64), 0, a->stream, sa);
-			CK(hipGetLastError());
-			const uint32_t sw = std::min<uint32_t>(std::min<uint32_t>(a->k3_waves, (k3.ring_n * 8u) & ~3u), a->n_waves);
-			hipLaunchKernelGGL(mm_spec_extend_kernel, dim3(std::max<uint32_t>(sw, 4) / 4), dim3(256), 0, a->stream, sa);
-			CK(hipGetLastError());
-			k3.memo = a->spec_memo.p; k3.spath = a->spec_path.p; k3.sseg = a->spec_seg.p;
-		}
 		CK(hipEventRecord(a->ev0, a->stream));
 		/* persistent waves stealing reads from a counter, never more of them than there are workspaces.  MM_K3_ONE_READ_PER_WAVE (with a workspace for every wave
 		 * the device can hold): grid = reads / 4, a wave maps one read and ends -- wave slots then come free read by read for the other lanes' launches; measured
@@ -1057,7 +1039,6 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), inkernel ? 4 * 1536 * 4 : 0, a->stream, k3);
 		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
-		if(k3.memo) { CK(hipEventElapsedTime(&ms, a->evs, a->ev0)); a->st.spec_ms += ms; a->st.spec_launches++; }
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
 		if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
 		std::vector<uint32_t> nxt;
@@ -1409,7 +1390,6 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	else if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
 	else { ok &= a->slabs.ensure(slab * kw); if(ok) { a->slab_stride = a->slabs.n / kw; a->k3_waves = kw; } }
 	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(32);
-	{ const uint64_t J = std::max<uint64_t>(1u << 16, 4ull * n_reads); ok &= a->spec_job.ensure(J); ok &= a->spec_memo.ensure(J); ok &= a->spec_seg.ensure(8 * J); ok &= a->spec_path.ensure((bases / 4 + 1024ull * n_reads) * scale + (1ull << 20)); ok &= a->d_spec_top.ensure(8); }
 	return ok;
 }
 /* one set of DP workspaces for all lanes of a context (the streaming engine calls this before its lane threads start, with the longest read of the input):
@@ -1497,7 +1477,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 		gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
-	a->spec_job.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->d_spec_top.release(); if(a->evs) (void)hipEventDestroy(a->evs); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
+	a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
@@ -1523,7 +1503,6 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 			out->traces += q.traces; out->trace_steps += q.trace_steps; out->reruns += q.reruns; out->host_post_ms += q.host_post_ms; out->host_sam_ms += q.host_sam_ms;
 			out->k3_cycles_fill += q.k3_cycles_fill; out->k3_cycles_leaf += q.k3_cycles_leaf; out->k3_cycles_trace += q.k3_cycles_trace; out->k3_cycles_total += q.k3_cycles_total;
 			out->k3_cycles_next += q.k3_cycles_next; out->k3_cycles_max += q.k3_cycles_max;             /* summed over launches; k3_waves stays the per-launch count */
-			out->spec_ms += q.spec_ms; out->spec_launches += q.spec_launches; out->spec_jobs += q.spec_jobs; out->spec_hits += q.spec_hits; out->spec_vectors += q.spec_vectors; out->spec_trace_steps += q.spec_trace_steps;
 			out->k2_cycles_sort += q.k2_cycles_sort; out->k2_cycles_chain += q.k2_cycles_chain; out->k2_cycles_total += q.k2_cycles_total; out->k2_reads_hbm += q.k2_reads_hbm;
 		}
 	}
@@ -1703,7 +1682,6 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	}
 	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
-	{ unsigned long long stp[8] = { 0 }; if(a->d_spec_top.p) { CPY(a, stp, a->d_spec_top.p, sizeof(stp), hipMemcpyDeviceToHost); } a->st.spec_jobs += std::min<unsigned long long>(stp[0], a->spec_job.n); a->st.spec_vectors += stp[4]; a->st.spec_trace_steps += stp[5]; a->st.spec_hits += tops[18]; }
 	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->k3_waves; a->st.k3_cycles_next += tops[19];
 	if(a->k2_leaf_shift > 0 && tops[29] * 50 > (unsigned long long)n_reads) { for(mm_align_t *q = a; q; q = q->sib) { if(q->k2_leaf_shift > 0) q->k2_leaf_shift--; } }
 	a->st.k2_cycles_sort += tops[24] + tops[28]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26] + tops[28]; a->st.k2_reads_hbm += tops[27];

@@ -84,13 +84,12 @@ def test_bench_line_with_two_ranks_on_one_gpu():
     assert d['sam_identical'] is True, d.get('sam_check')
     assert d['roofline']['achieved'] > 0 and 'cpu_baseline' not in d
 
-@pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1'), dict(MM_SPEC_MIN_ROOTS='1'), dict(MM_NO_SPEC='1')],
-                         ids=['rounds-through-the-host', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain', 'batch-split-on-pool-exhaustion', 'first-trials-ahead-for-every-read', 'no-first-trials-ahead'])
+@pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1')],
+                         ids=['rounds-through-the-host', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain', 'batch-split-on-pool-exhaustion'])
 def test_alternative_schedules_give_the_same_bytes(env):
     """the forms kept behind environment switches -- the occurrence-threshold rounds as separate launches through the host (the default runs them inside the
     extension kernel, k3_rescue_round), one read per wave, per-lane DP
-    workspaces, the one-kernel sort + chain, the fallback for a batch the device pools cannot hold (its reads in halves, down to fewer than 8), and the first trials
-    of the chains computed ahead for every read (default: reads with 6 chains or more) or for none -- on a repeat-rich set with a high seed threshold, where many reads need the rescue rounds"""
+    workspaces, the one-kernel sort + chain, and the fallback for a batch the device pools cannot hold (its reads in halves, down to fewer than 8) -- on a repeat-rich set with a high seed threshold, where many reads need the rescue rounds"""
     with tempfile.TemporaryDirectory() as d:
         ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
         M.gensim('genome', 7401, 1500000, 6, 0.45, out=ref); M.gensim('reads', 7402, ref, 3.0, 'pacbio', 'fa', 6000, 2500, out=rd)
