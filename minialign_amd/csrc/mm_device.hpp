@@ -1467,7 +1467,10 @@ __device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uin
 #else
 #define MM_TICK() 0ull
 #endif
-__global__ void __launch_bounds__(256, MM_K3_WAVES_PER_SIMD) mm_extend_kernel(K3Args a)
+#ifndef MM_K3_LAUNCH_BOUND
+#define MM_K3_LAUNCH_BOUND MM_K3_WAVES_PER_SIMD          /* waves per SIMD the register budget of the kernel is set for */
+#endif
+__global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Args a)
 {
 	extern __shared__ uint32_t k3_tab[];       /* launched with 4 x 1536 words when the rounds run in the kernel (per wave: tables of k3_rescue_round's sort + chain), else with none:
 	                                            * a static array would make the compiler trade the 8 waves per SIMD of the launch bounds for registers */
