@@ -1258,6 +1258,9 @@ struct K3Args {
 	 * free workspace numbers per XCD (a wave only ever takes from the ring of the XCD it runs on, HW_REG_XCC_ID): the L2s of different XCDs are not coherent
 	 * with each other inside a launch, so a workspace must not wander between them while kernels are running */
 	unsigned long long *ring_ctr; uint32_t *ring; uint32_t ring_n;      /* per XCD x: ring_ctr[2x] = takes, [2x + 1] = returns; ring[x * ring_n ..] = numbers (~0 = taken) */
+	/* a second, small set of LARGE workspaces (ring_n2 > 0) for the reads longer than qlen_small: a long tail of read lengths (ONT) would otherwise size every
+	 * workspace for the longest read and leave room for a fifth of the waves; a wave changes class when the read it takes asks for the other one */
+	uint8_t *slabs2; uint64_t slab_bytes2; unsigned long long *ring_ctr2; uint32_t *ring2; uint32_t ring_n2; uint32_t qlen_small;
 	KhSlot *kh_pool; uint32_t kh_cap;                    /* per read (work index) */
 	uint32_t round;
 	uint64_t *next_pool; uint32_t next_cap;              /* per wave: (pdiff, sid) */
@@ -1479,26 +1482,29 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 	const int lane = x.lane;
 	uint32_t wave = (uint32_t)rdfirst((int)(blockIdx.x * 4 + threadIdx.x / 64));
-	uint32_t slab_no = wave; uint32_t xcc = 0;
-	if(a.ring) {
-		xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;          /* HW_REG_XCC_ID, bits 3:0 */
-		uint32_t v = 0;
-		if(lane == 0) {
-			const unsigned long long t = atomicAdd(&a.ring_ctr[2 * xcc], 1ull);
-			uint32_t *slot = &a.ring[(uint64_t)xcc * a.ring_n + (uint32_t)(t % a.ring_n)];
-			while((v = atomicExch(slot, 0xffffffffu)) == 0xffffffffu) { __builtin_amdgcn_s_sleep(16); }       /* every workspace of this XCD is in use: one comes back when a wave ends */
-		}
-		slab_no = (uint32_t)rdfirst((int)v);
+	uint32_t slab_no = wave; uint32_t xcc = 0; int slab_cls = -1;          /* class of the workspace held: -1 none yet (ring mode), 0 ordinary, 1 large */
+	if(a.ring) { xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }          /* HW_REG_XCC_ID, bits 3:0 */
+	else {
+		x.slab = a.slabs + (uint64_t)slab_no * a.slab_bytes; x.cap = (uint32_t)a.slab_bytes; x.top = gaba::SLAB_HEAD; slab_cls = 0;
+		for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	}
-	x.slab = a.slabs + (uint64_t)slab_no * a.slab_bytes; x.cap = (uint32_t)a.slab_bytes; x.top = gaba::SLAB_HEAD;
-	for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	/* take / return a workspace of class c on this XCD's ring */
+	#define K3_RING_TAKE(_c, _out) { uint32_t _v = 0; if(lane == 0) { \
+		unsigned long long *_ctr = (_c) ? a.ring_ctr2 : a.ring_ctr; uint32_t *_rg = (_c) ? a.ring2 : a.ring; const uint32_t _n = (_c) ? a.ring_n2 : a.ring_n; \
+		const unsigned long long _t = atomicAdd(&_ctr[2 * xcc], 1ull); uint32_t *_slot = &_rg[(uint64_t)xcc * _n + (uint32_t)(_t % _n)]; \
+		while((_v = atomicExch(_slot, 0xffffffffu)) == 0xffffffffu) { __builtin_amdgcn_s_sleep(16); } }          /* every workspace of this XCD in use: one comes back when a wave is done with it */ \
+		(_out) = (uint32_t)rdfirst((int)_v); }
+	#define K3_RING_GIVE(_c, _no) { if(lane == 0) { \
+		unsigned long long *_ctr = (_c) ? a.ring_ctr2 : a.ring_ctr; uint32_t *_rg = (_c) ? a.ring2 : a.ring; const uint32_t _n = (_c) ? a.ring_n2 : a.ring_n; \
+		const unsigned long long _t = atomicAdd(&_ctr[2 * xcc + 1], 1ull); uint32_t *_slot = &_rg[(uint64_t)xcc * _n + (uint32_t)(_t % _n)]; \
+		while(atomicCAS(_slot, 0xffffffffu, (_no)) != 0xffffffffu) { __builtin_amdgcn_s_sleep(4); } } }          /* (the taker of this slot's previous turn has not picked its number up yet) */
 	Kh kh; kh.cap = a.kh_cap;
 	/* with shared workspaces a wave maps ONE read and ends (grid = reads / 4): wave slots then come free read by read, and the launches of the other lanes --
 	 * sketch, sort, chain, copies, the next extension launch -- get theirs within a read's time instead of waiting for a whole persistent launch to drain;
 	 * the per-wave scratch is numbered like the workspace.  Without the ring (per-call entries): persistent waves stealing reads from a counter, as before. */
 	const bool persistent = a.persistent != 0 || a.ring == nullptr;
-	uint64_t *next = a.next_pool + (uint64_t)(a.ring ? slab_no : wave) * (a.next_cap + MM_NEXT_SCRATCH);      /* [next_cap entries][radix-sort scratch] */
+	uint64_t *next = a.next_pool + (uint64_t)wave * (a.next_cap + MM_NEXT_SCRATCH);      /* [next_cap entries][radix-sort scratch]; one-read-per-wave launches: re-pointed below by workspace number */
 	uint32_t *next_scratch = (uint32_t *)(next + a.next_cap);
 	const DevIndex &ix = a.idx;
 	unsigned long long n_fill = 0, n_trace = 0;
@@ -1527,6 +1533,19 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		if(n_root >= 8) { __builtin_amdgcn_s_setprio(3); } else if(n_root >= 5) { __builtin_amdgcn_s_setprio(2); } else { __builtin_amdgcn_s_setprio(0); }
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
+		if(a.ring) {
+			/* the workspace this read needs: the large class for reads longer than qlen_small (when there is one), else the ordinary one; kept from read to read
+			 * while the class stays (the work list runs longest first, so a wave changes at most once) */
+			const int want = (a.ring_n2 != 0 && qlen > a.qlen_small) ? 1 : 0;
+			if(want != slab_cls) {
+				if(slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); }
+				K3_RING_TAKE(want, slab_no); slab_cls = want;
+				x.slab = (want ? a.slabs2 : a.slabs) + (uint64_t)slab_no * (want ? a.slab_bytes2 : a.slab_bytes); x.cap = (uint32_t)(want ? a.slab_bytes2 : a.slab_bytes); x.top = gaba::SLAB_HEAD;
+				for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
+				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + (want ? a.ring_n * 8u : 0u)) * (a.next_cap + MM_NEXT_SCRATCH); next_scratch = (uint32_t *)(next + a.next_cap); }
+			}
+		}
 		Seed *s = a.seed_pool + rdfirst64(st->seed_off);
 		Root *root = a.root_pool + rdfirst64(st->root_off);
 		uint32_t rlen = (uint32_t)rdfirst((int)st->rlen);
@@ -1799,12 +1818,10 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		atomicAdd(&a.stats[12], cy_fill); atomicAdd(&a.stats[13], cy_leaf); atomicAdd(&a.stats[14], cy_trace); atomicAdd(&a.stats[11], cy_next);
 		atomicAdd(&a.stats[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
 		atomicMax(&a.stats[9], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));      /* longest-living wave: load balance */
-		if(a.ring) {
-			const unsigned long long t = atomicAdd(&a.ring_ctr[2 * xcc + 1], 1ull);
-			uint32_t *slot = &a.ring[(uint64_t)xcc * a.ring_n + (uint32_t)(t % a.ring_n)];
-			while(atomicCAS(slot, 0xffffffffu, slab_no) != 0xffffffffu) { __builtin_amdgcn_s_sleep(4); }        /* (the taker of this slot's previous turn has not picked its number up yet) */
-		}
 	}
+	if(a.ring && slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); }
+	#undef K3_RING_TAKE
+	#undef K3_RING_GIVE
 }
 
 } /* namespace mm */

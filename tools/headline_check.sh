@@ -11,7 +11,7 @@ t() { date +%s.%N; }
 [ -x tools/gensim ] || gcc -O2 -o tools/gensim tools/gensim.c -lm
 t0=$(t); tools/gensim genome 0x5eed0001 "$GL" "$NC" 0.05 > "$W/ref.fa"; tools/gensim reads 0x5eed0002 "$W/ref.fa" "$DEPTH" $KIND fa 20000 2000 > "$W/rd.fa"; t1=$(t)
 echo "generate: $(awk "BEGIN{print $t1-$t0}") s; reads: $(grep -c '>' "$W/rd.fa"); cores: $(nproc); mem: $(free -g | awk 'NR==2{print $2}') GB; tmp: $(df -h /tmp | awk 'NR==2{print $4}')" | tee "$OUT/log.txt"
-t0=$(t); MM_VERBOSE=1 minialign_amd/minialign -x$PRE "$W/ref.fa" "$W/rd.fa" 2> "$OUT/ours.err" | tee >(head -c 600000000 > "$W/ours_head.sam"; cat > /dev/null) | wc -c > "$OUT/ours_bytes.txt"; echo "ours rc=${PIPESTATUS[0]} $(awk "BEGIN{print $(t)-$t0}") s, $(cat "$OUT/ours_bytes.txt") bytes" | tee -a "$OUT/log.txt"
+t0=$(t); MM_VERBOSE=1 minialign_amd/minialign -x$PRE "$W/ref.fa" "$W/rd.fa" 2> "$OUT/ours.err" | tee >(head -c ${HEAD_BYTES:-600000000} > "$W/ours_head.sam"; cat > /dev/null) | wc -c > "$OUT/ours_bytes.txt"; echo "ours rc=${PIPESTATUS[0]} $(awk "BEGIN{print $(t)-$t0}") s, $(cat "$OUT/ours_bytes.txt") bytes" | tee -a "$OUT/log.txt"
 grep -E "main_align|M::main\]|index:" "$OUT/ours.err" | tee -a "$OUT/log.txt"
 awk -v n="$NCHK" '/^>/{c++} c<=n' "$W/rd.fa" > "$W/chk.fa"; awk -v n="$NTIME" '/^>/{c++} c<=n' "$W/rd.fa" > "$W/time.fa"
 t0=$(t); oracle/_ref/minialign -x$PRE -t32 -d "$W/ref.mai" "$W/ref.fa" 2> "$OUT/ref.err"; echo "ref index -t32 rc=$? $(awk "BEGIN{print $(t)-$t0}") s" | tee -a "$OUT/log.txt"
