@@ -574,11 +574,12 @@ extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 		}, 64);
 		lap("sketch");
 		/* hist[j][bi] -> first write position of stretch j in bucket bi (row by row: the rows are contiguous) */
-		for(size_t j = 0; j < task.size(); j++) { const uint32_t *h = &hist[j * nb]; for(uint64_t bi = 0; bi < nb; bi++) bofs[bi + 1] += h[bi]; }
+		/* (columns of the stretch x bucket histogram, a range of buckets per thread) */
+		host_parallel(64, [&](uint32_t t, uint32_t nth) { for(uint64_t bi = nb * t / nth, be_ = nb * (t + 1) / nth; bi < be_; bi++) { uint64_t acc = 0; for(size_t j = 0; j < task.size(); j++) acc += hist[j * nb + bi]; bofs[bi + 1] = acc; } }, 64);
 		for(uint64_t bi = 0; bi < nb; bi++) bofs[bi + 1] += bofs[bi];
 		flat.resize(bofs[nb]);
 		std::vector<uint64_t> wpos((size_t)task.size() * nb);
-		{ std::vector<uint64_t> run(bofs.begin(), bofs.end() - 1); for(size_t j = 0; j < task.size(); j++) { const uint32_t *h = &hist[j * nb]; uint64_t *w = &wpos[j * nb]; for(uint64_t bi = 0; bi < nb; bi++) { w[bi] = run[bi]; run[bi] += h[bi]; } } }
+		host_parallel(64, [&](uint32_t t, uint32_t nth) { for(uint64_t bi = nb * t / nth, be_ = nb * (t + 1) / nth; bi < be_; bi++) { uint64_t run = bofs[bi]; for(size_t j = 0; j < task.size(); j++) { wpos[j * nb + bi] = run; run += hist[j * nb + bi]; } } }, 64);
 		lap("bucket offsets");
 		host_parallel((uint32_t)task.size(), [&](uint32_t t, uint32_t nth) {
 			for(size_t j = t; j < task.size(); j += nth) {
@@ -608,13 +609,25 @@ extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 	}
 	lap("bucket sort");
 	/* thresholds: (1 - frq)-quantile of the per-key counts, + 1 (minialign.c:2981-2986) */
-	for(uint32_t i = 0; i < o->n_frq; i++) {
-		if(o->frq[i] <= 0.0) { mi->occ[i] = UINT32_MAX; continue; }
-		uint32_t kk = (uint32_t)((1.0 - o->frq[i]) * cnt.size());
-		if(cnt.empty()) { mi->occ[i] = 1; continue; }
-		auto nth_it = cnt.begin() + std::min<size_t>(kk, cnt.size() - 1);
-		std::nth_element(cnt.begin(), nth_it, cnt.end());            /* the k-th smallest count; the order of cnt itself carries no meaning */
-		mi->occ[i] = *nth_it + 1;
+	{
+		/* the k-th smallest count from a histogram of the counts (nearly all are small; the few above the table fall back to selection among themselves) */
+		const uint32_t HB = 1u << 16; std::vector<uint64_t> ch(HB + 1, 0); std::vector<uint32_t> big;
+		{
+			std::vector<std::vector<uint64_t>> ph(32, std::vector<uint64_t>(HB + 1, 0)); std::vector<std::vector<uint32_t>> pb(32);
+			host_parallel(32, [&](uint32_t t, uint32_t nth) { for(size_t i = cnt.size() * t / nth, e = cnt.size() * (t + 1) / nth; i < e; i++) { const uint32_t c = cnt[i]; if(c < HB) ph[t][c]++; else { ph[t][HB]++; pb[t].push_back(c); } } }, 32);
+			for(auto &h : ph) for(uint32_t c = 0; c <= HB; c++) ch[c] += h[c];
+			for(auto &b2 : pb) big.insert(big.end(), b2.begin(), b2.end());
+		}
+		for(uint32_t i = 0; i < o->n_frq; i++) {
+			if(o->frq[i] <= 0.0) { mi->occ[i] = UINT32_MAX; continue; }
+			uint32_t kk = (uint32_t)((1.0 - o->frq[i]) * cnt.size());
+			if(cnt.empty()) { mi->occ[i] = 1; continue; }
+			const size_t kth = std::min<size_t>(kk, cnt.size() - 1);
+			uint64_t acc = 0; uint32_t v = 0; bool found = false;
+			for(uint32_t c = 0; c < HB; c++) { acc += ch[c]; if(acc > kth) { v = c; found = true; break; } }
+			if(!found) { auto it = big.begin() + (kth - acc); std::nth_element(big.begin(), it, big.end()); v = *it; }
+			mi->occ[i] = v + 1;
+		}
 	}
 	/* key -> value-list map (minialign.c:2905-2944).  The reference stops advancing its fill cursor at the first key of a
 	 * bucket that exceeds the last threshold, which silently drops every later key of that bucket: kept.  Buckets are independent: keys and list
