@@ -89,6 +89,11 @@ void mm_align_set_carry(mm_align_t *a, uint32_t rlen);
 typedef struct mm_reads_s mm_reads_t;
 typedef struct mm_batch_s mm_batch_t;
 mm_reads_t *mm_reads_load(char const *fn);
+/* the same, keeping the text of the file: batches cut from such a set are 2-bit packed on the device from that text (the table of minialign.c:223-229 applied to every
+ * byte of a record's sequence lines but '\n'), which is what the command-line program does; mm_pack_check compares that with the host packing over the whole set and
+ * returns the number of differing arena words (0 = identical, -1 = no text / failure) */
+mm_reads_t *mm_reads_load_text(char const *fn);
+int64_t mm_pack_check(mm_align_t *a, mm_reads_t const *r);
 void mm_reads_free(mm_reads_t *r);
 int mm_reads_append(mm_reads_t *r, char const *fn);          /* another file behind the reads already loaded; 0 on success */
 char const *mm_reads_name(mm_reads_t const *r, uint32_t i);

@@ -78,6 +78,48 @@ __device__ __forceinline__ int32_t AS(const Seed &p) { return (int32_t)(((p.upos
 __device__ __forceinline__ int32_t BS(const Seed &p) { return (int32_t)(((p.vpos - (uint32_t)OFS(0)) << 1) + (p.upos - (uint32_t)OFS(0))) / 3; }
 
 /* =====================================================================================================
+ * K0: reads from their text.  bseq_read_fasta's base conversion (minialign.c:1996-2090 with the table encaf, :223-229: the low nibble of the byte picks
+ * A / a -> 0, C / c -> 1, G / g -> 2, T / t / U / u -> 3, N / n -> 4 and EVERY other byte -> 0) and the 2-bit packing, from the raw text of the file in HBM:
+ * the host parser only finds where each record's sequence lines begin and end; every byte of that extent except '\n' is a base (a CR too).
+ *   mm_text_codes_kernel   wave per read: 64 text bytes at a time, newlines squeezed out by ballot + popcount, one code byte per base into the arena image
+ *   mm_codes_pack_kernel   thread per 32 bases of the arena: two 2-bit words and one N-mask word (what pack_bases builds on the host)
+ * ===================================================================================================== */
+struct TextRead { uint64_t t_off; uint32_t t_len; uint32_t pad; uint64_t q_off; };      /* extent in the uploaded text, first base in the arena */
+__global__ void __launch_bounds__(256) mm_text_codes_kernel(const uint8_t *text, const TextRead *tr, uint32_t n_reads, uint8_t *codes, uint32_t *n_bases)
+{
+	const int lane = lane_id();
+	const uint32_t r = (uint32_t)rdfirst((int)(blockIdx.x * 4 + threadIdx.x / 64));
+	if(r >= n_reads) { return; }
+	const uint64_t t0 = rdfirst64(tr[r].t_off), q0 = rdfirst64(tr[r].q_off); const uint32_t tl = (uint32_t)rdfirst((int)tr[r].t_len);
+	const uint64_t lut = 0x0400000020331000ull;          /* 4 bits per low nibble: 'A' & 15 = 1 -> 0, 'C' = 3 -> 1, 'T' = 4 -> 3, 'U' = 5 -> 3, 'G' = 7 -> 2, 'N' = 14 -> 4, everything else 0 */
+	uint32_t out = 0;
+	for(uint32_t i0 = 0; i0 < tl; i0 += 64) {
+		const uint32_t i = i0 + (uint32_t)lane;
+		const uint8_t c = i < tl ? text[t0 + i] : (uint8_t)'\n';
+		const bool keep = c != (uint8_t)'\n';
+		const uint64_t m = __ballot(keep);
+		if(keep) { codes[q0 + out + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint8_t)((lut >> (4 * (c & 15))) & 15); }
+		out += (uint32_t)__popcll(m);
+	}
+	if(lane == 0) { n_bases[r] = out; }
+}
+__global__ void __launch_bounds__(256) mm_codes_pack_kernel(const uint8_t *codes, uint64_t n_words32, uint32_t *pk, uint32_t *nm)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;          /* one N-mask word = 32 bases = two 2-bit words */
+	if(w >= n_words32) { return; }
+	const uint4 c0 = ((const uint4 *)codes)[2 * w], c1 = ((const uint4 *)codes)[2 * w + 1];
+	const uint32_t cw[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+	uint32_t w0 = 0, w1 = 0, m = 0;
+	for(int j = 0; j < 32; j++) {
+		const uint32_t c = (cw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+		const uint32_t two = c <= 3 ? c : 0u;
+		if(j < 16) { w0 |= two << (2 * j); } else { w1 |= two << (2 * (j - 16)); }
+		m |= (uint32_t)(c > 3) << j;
+	}
+	pk[2 * w] = w0; pk[2 * w + 1] = w1; nm[w] = m;
+}
+
+/* =====================================================================================================
  * K1: sketch + lookup + expand
  * ===================================================================================================== */
 __device__ __forceinline__ uint32_t crc32c_u64(uint32_t crc, uint64_t v)        /* _mm_crc32_u64; only reached for k > 16 */

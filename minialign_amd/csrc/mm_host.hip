@@ -91,7 +91,8 @@ inline void sort_res(ResEnt *p, size_t n) { auto key = [](const ResEnt &m) { ret
 /* ---------------------------------------------------------------------------------------------
  * sequences
  * --------------------------------------------------------------------------------------------- */
-struct HSeq { std::string name; std::vector<uint8_t> seq; std::string qual, comment; bool has_comment = false; bool circular = false; };     /* qual / comment: kept on request only (-Q, -T CO) */
+struct HSeq { std::string name; std::vector<uint8_t> seq; std::string qual, comment; bool has_comment = false; bool circular = false;
+	uint64_t t_off = 0; uint32_t t_len = 0; int32_t t_id = -1; };          /* where the bases stand in the text of the file (when that is kept): every byte of the extent but '\n' is a base */     /* qual / comment: kept on request only (-Q, -T CO) */
 
 /* run fn(t, nth) on up to `cap` (default 32) host threads (reads / records are independent in every host stage that uses this) */
 template<typename F> static void host_parallel(uint32_t want, F fn, uint32_t cap = 32)
@@ -134,37 +135,38 @@ static const char *parse_header(const char *p, const char *end, HSeq &r, bool ke
 	return p;
 }
 /* sequence lines at p up to the delimiter dv anywhere in a line (returns its position) or the end of the text */
-static const char *parse_bases(const char *p, const char *end, char dv, const uint8_t *enc, std::vector<uint8_t> &sq, bool &at_delim)
+static const char *parse_bases(const char *p, const char *end, char dv, const uint8_t *enc, std::vector<uint8_t> &sq, bool &at_delim, const char *base = nullptr, HSeq *rec = nullptr)
 {
 	at_delim = false;
+	if(rec) { rec->t_off = (uint64_t)(p - base); rec->t_len = 0; }
 	while(p < end) {
 		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
 		const char *dl = (const char *)memchr(p, dv, (size_t)(le - p)); const char *stop = dl ? dl : le;
 		const size_t n = (size_t)(stop - p), o = sq.size();
-		if(n) { sq.resize(o + n); uint8_t *d = sq.data() + o; for(size_t i = 0; i < n; i++) d[i] = enc[p[i] & 15]; }
+		if(n) { sq.resize(o + n); uint8_t *d = sq.data() + o; for(size_t i = 0; i < n; i++) d[i] = enc[p[i] & 15]; if(rec) { rec->t_len = (uint32_t)((uint64_t)(stop - base) - rec->t_off); } }
 		if(dl) { at_delim = true; return dl; }
 		p = nl ? nl + 1 : end;
 	}
 	return p;
 }
 /* one FASTA stretch (starts at a '>', holds whole records) */
-static void parse_fasta_span(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out, bool keep_comment)
+static void parse_fasta_span(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out, bool keep_comment, const char *base = nullptr)
 {
 	while(p < end) {
 		p++;                                         /* the '>' */
 		out.emplace_back(); HSeq &r = out.back();
 		p = parse_header(p, end, r, keep_comment);
-		bool at; p = parse_bases(p, end, '>', enc, r.seq, at);
+		bool at; p = parse_bases(p, end, '>', enc, r.seq, at, base, base ? &r : nullptr);
 	}
 }
 /* FASTQ, in sequence; false when a record does not start with '@' where one must */
-static bool parse_fastq(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out, bool keep_qual, bool keep_comment)
+static bool parse_fastq(const char *p, const char *end, const uint8_t *enc, std::vector<HSeq> &out, bool keep_qual, bool keep_comment, const char *base = nullptr)
 {
 	while(p < end) {
 		if(*p++ != '@') return false;
 		out.emplace_back(); HSeq &r = out.back();
 		p = parse_header(p, end, r, keep_comment);
-		bool at; p = parse_bases(p, end, '+', enc, r.seq, at);
+		bool at; p = parse_bases(p, end, '+', enc, r.seq, at, base, base ? &r : nullptr);
 		if(!at) break;
 		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p)); p = nl ? nl + 1 : end;      /* the '+' line */
 		uint64_t acc = 0; const uint64_t lim = r.seq.size();
@@ -180,7 +182,7 @@ static bool parse_fastq(const char *p, const char *end, const uint8_t *enc, std:
 	}
 	return true;
 }
-bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1, bool keep_qual = false, bool keep_comment = false)
+bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1, bool keep_qual = false, bool keep_comment = false, std::vector<char> *keep_text = nullptr, int32_t text_id = -1)
 {
 	FILE *fp = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
 	if(!fp) return false;
@@ -238,15 +240,16 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1,
 			cut.push_back(end);
 			part.resize(cut.size() - 1);
 		}
-		host_parallel((uint32_t)part.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < part.size(); i += nth) parse_fasta_span(cut[i], cut[i + 1], enc, part[i], keep_comment); });
+		host_parallel((uint32_t)part.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < part.size(); i += nth) parse_fasta_span(cut[i], cut[i + 1], enc, part[i], keep_comment, keep_text ? base : nullptr); });
 		size_t tot = 0; for(auto &v : part) tot += v.size();
 		out.reserve(out.size() + tot);
 		for(auto &v : part) for(auto &r : v) out.emplace_back(std::move(r));
-	} else if(!parse_fastq(data.data() + first, data.data() + data.size(), enc, out, keep_qual, keep_comment)) {
+	} else if(!parse_fastq(data.data() + first, data.data() + data.size(), enc, out, keep_qual, keep_comment, keep_text ? data.data() : nullptr)) {
 		fprintf(stderr, "[minialign_amd] `%s': broken FASTQ record\n", fn); return false;       /* the reference gives up on the run (exit 1) */
 	}
 	/* -L (default 1, minialign.c:2077, 6145): records shorter than the limit are dropped, reference and query side alike */
 	out.erase(std::remove_if(out.begin(), out.end(), [min_len](const HSeq &s) { return s.seq.size() < min_len; }), out.end());
+	if(keep_text) { for(HSeq &q : out) { if(q.t_id == -1 && (q.t_len != 0 || q.seq.empty())) q.t_id = text_id; } keep_text->swap(data); }          /* (records of this file only: those of earlier files carry their id already) */
 	return true;
 }
 
@@ -795,6 +798,7 @@ struct mm_align_s {
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
+	DBuf<uint8_t> d_text, d_codes; DBuf<TextRead> d_tinfo; DBuf<uint32_t> d_tn;      /* packing on the device: text range of the batch, per-read extents, code bytes of the arena, bases found per read */
 	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
 	mm_align_s *root = nullptr;            /* the primary context of a lane (NULL on the primary itself) */
 	bool shared_slabs = false; DBuf<uint32_t> slab_ring; DBuf<unsigned long long> slab_ring_ctr; uint32_t slab_ring_n = 0;
@@ -1506,7 +1510,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 		gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
-	a->slabs2.release(); a->slab_ring2.release(); a->slab_ring_ctr2.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
+	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); a->slabs2.release(); a->slab_ring2.release(); a->slab_ring_ctr2.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
@@ -1542,7 +1546,7 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
  * a batch in three phases: upload (H2D of packed reads), run (the hot path: K1..K3 in rounds plus the re-runs the
  * carried reference-length state asks for; results stay in HBM), finish (D2H, post-map, SAM text)
  * --------------------------------------------------------------------------------------------- */
-struct mm_reads_s { std::vector<HSeq> r; uint64_t bases = 0; };
+struct mm_reads_s { std::vector<HSeq> r; uint64_t bases = 0; std::vector<std::shared_ptr<std::vector<char>>> text; };          /* text: the files' text when kept (reads then carry where their bases stand in it: the device packs from there) */
 struct Batch {
 	uint32_t n = 0; uint64_t total = 0; uint32_t max_qlen = 0;
 	std::vector<uint32_t> lens; std::vector<uint64_t> qoff; std::vector<const uint8_t *> seq; std::vector<std::string> names;
@@ -1551,6 +1555,8 @@ struct Batch {
 	std::vector<uint32_t> pk, nm; std::vector<ReadIn> in; std::vector<ReadState> hst; std::vector<uint32_t> work;
 	uint64_t scale = 1; bool packed = false, uploaded = false, ran = false;
 	std::vector<uint32_t> used;            /* the carried reference length each read actually ran with */
+	std::shared_ptr<std::vector<char>> text;   /* when every read of the batch stands in this one text: 2-bit packing on the device from it (batch_upload) */
+	const std::vector<std::shared_ptr<std::vector<char>>> *text_src = nullptr;      /* the texts of the read set the batch was cut from */
 };
 namespace {
 bool batch_upload(mm_align_t *a, Batch &b)
@@ -1569,7 +1575,26 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		/* unmappable reads are skipped outright (minialign.c:4434) */
 		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
 	}
-	if(!lane_h2d(a, a->q_pk.p, b.pk.data(), b.pk.size() * 4) || !lane_h2d(a, a->q_nm.p, b.nm.data(), b.nm.size() * 4)) return false;
+	if(b.text) {
+		/* K0: the stretch of the file's text that holds the batch goes up as it is; newlines are squeezed out, bases coded and packed on the device */
+		uint64_t lo = ~0ull, hi = 0; for(uint32_t i = 0; i < b.n; i++) { lo = std::min<uint64_t>(lo, b.rec[i]->t_off); hi = std::max<uint64_t>(hi, b.rec[i]->t_off + b.rec[i]->t_len); }
+		if(lo > hi) { lo = hi = 0; }
+		std::vector<TextRead> tr(b.n); for(uint32_t i = 0; i < b.n; i++) tr[i] = TextRead{ b.rec[i]->t_off - lo, b.rec[i]->t_len, 0, b.qoff[i] };
+		const uint64_t arena = (b.total + 64 + 63) & ~63ull;
+		if(!a->d_text.ensure(hi - lo + 64) || !a->d_tinfo.ensure(b.n) || !a->d_codes.ensure(arena + 64) || !a->d_tn.ensure(b.n)) return false;
+		if(hi > lo && !lane_h2d(a, a->d_text.p, b.text->data() + lo, hi - lo)) return false;
+		if(!lane_h2d(a, a->d_tinfo.p, tr.data(), b.n * sizeof(TextRead))) return false;
+		CK(hipMemsetAsync(a->d_codes.p, 0, arena + 64, a->stream));
+		hipLaunchKernelGGL(mm_text_codes_kernel, dim3((b.n + 3) / 4), dim3(256), 0, a->stream, a->d_text.p, a->d_tinfo.p, b.n, a->d_codes.p, a->d_tn.p);
+		CK(hipGetLastError());
+		const uint64_t nw = (b.total + 64 + 31) / 32;
+		hipLaunchKernelGGL(mm_codes_pack_kernel, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, a->stream, a->d_codes.p, nw, a->q_pk.p, a->q_nm.p);
+		CK(hipGetLastError());
+		/* the parser and the device must agree on how many bases a read has */
+		std::vector<uint32_t> tn(b.n); CPY(a, tn.data(), a->d_tn.p, b.n * 4, hipMemcpyDeviceToHost);
+		for(uint32_t i = 0; i < b.n; i++) if(tn[i] != b.lens[i]) { fprintf(stderr, "[minialign_amd] read `%s': %u bases in its text on the device, %u from the parser\n", b.names[i].c_str(), tn[i], b.lens[i]); return false; }
+	}
+	else if(!lane_h2d(a, a->q_pk.p, b.pk.data(), b.pk.size() * 4) || !lane_h2d(a, a->q_nm.p, b.nm.data(), b.nm.size() * 4)) return false;
 	if(!lane_h2d(a, a->d_in.p, b.in.data(), b.n * sizeof(ReadIn))) return false;
 	if(!lane_h2d(a, a->d_st.p, b.hst.data(), b.n * sizeof(ReadState))) return false;
 	CK(hipMemsetAsync(a->d_tops.p, 0, 32 * 8, a->stream)); CK(hipStreamSynchronize(a->stream));
@@ -1578,14 +1603,22 @@ bool batch_upload(mm_align_t *a, Batch &b)
 	return true;
 }
 /* host side of a batch: arena offsets and the 2-bit / N-mask words of its reads (no device work) */
-void batch_pack(Batch &b)
+void batch_pack(Batch &b, bool on_host = true)
 {
 	b.n = (uint32_t)b.lens.size(); b.total = 0; b.max_qlen = 0; b.qoff.resize(b.n); b.in.resize(b.n);
-	for(uint32_t i = 0; i < b.n; i++) { b.qoff[i] = b.total; b.total += ((uint64_t)b.lens[i] + 63) & ~63ull; b.max_qlen = std::max(b.max_qlen, b.lens[i]); }
+	for(uint32_t i = 0; i < b.n; i++) { b.qoff[i] = b.total; b.total += ((uint64_t)b.lens[i] + 63) & ~63ull; b.max_qlen = std::max(b.max_qlen, b.lens[i]); b.in[i] = ReadIn{ b.qoff[i], b.lens[i], 0 }; }
+	/* the reads of a batch that come from one file whose text was kept are packed on the device, from that text (batch_upload) */
+	b.text.reset();
+	if(!on_host && !b.rec.empty() && b.rec.size() == b.n && b.text_src && !getenv("MM_HOST_PACK")) {
+		bool all = true; for(uint32_t i = 0; i < b.n && all; i++) all = b.rec[i]->t_id == b.rec[0]->t_id && b.rec[i]->t_id >= 0 && (size_t)b.rec[i]->t_id < b.text_src->size();
+		if(all && b.n) b.text = (*b.text_src)[b.rec[0]->t_id];
+	}
+	if(!b.text) {
 	b.pk.assign((b.total + 64) / 16 + 8, 0); b.nm.assign((b.total + 64) / 32 + 8, 0);
 	host_parallel(b.n / 64 + 1, [&](uint32_t t, uint32_t nth) {          /* reads occupy disjoint, word-aligned stretches of the arena */
-		for(uint32_t i = (uint32_t)((uint64_t)b.n * t / nth); i < (uint32_t)((uint64_t)b.n * (t + 1) / nth); i++) { pack_bases(b.seq[i], b.lens[i], b.pk, b.nm, b.qoff[i]); b.in[i] = ReadIn{ b.qoff[i], b.lens[i], 0 }; }
+		for(uint32_t i = (uint32_t)((uint64_t)b.n * t / nth); i < (uint32_t)((uint64_t)b.n * (t + 1) / nth); i++) { pack_bases(b.seq[i], b.lens[i], b.pk, b.nm, b.qoff[i]); }
 	});
+	}
 	b.scale = 1; b.packed = true;
 	if(getenv("MM_VERBOSE")) { fprintf(stderr, "[minialign_amd]   pack done\n"); }
 }
@@ -1832,12 +1865,15 @@ extern "C" void mm_align_set_carry(mm_align_t *a, uint32_t rlen) { for(mm_align_
 
 
 /* phase-split entry points over a parsed read set (bench.py times mm_batch_run alone: inputs resident in HBM) */
-static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual = false, bool keep_comment = false);
+static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual = false, bool keep_comment = false, bool keep_text = false);
 extern "C" mm_reads_t *mm_reads_load(char const *fn) { return reads_load(fn, 1); }
-static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual, bool keep_comment)
+extern "C" mm_reads_t *mm_reads_load_text(char const *fn) { return reads_load(fn, 1, false, false, true); }          /* keeps the text of the file: batches cut from it are packed on the device */
+static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual, bool keep_comment, bool keep_text)
 {
 	mm_reads_t *r = new mm_reads_s();
-	if(!read_seq_file(fn, r->r, min_len, keep_qual, keep_comment)) { delete r; return NULL; }
+	std::shared_ptr<std::vector<char>> tx = keep_text ? std::make_shared<std::vector<char>>() : nullptr;
+	if(!read_seq_file(fn, r->r, min_len, keep_qual, keep_comment, tx.get(), 0)) { delete r; return NULL; }
+	if(tx) r->text.push_back(tx);
 	for(const HSeq &s : r->r) r->bases += s.seq.size();
 	return r;
 }
@@ -1965,7 +2001,7 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = 
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
 	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
-	mm_reads_t *reads = reads_load(reads_fn, a->o.min_len, a->o.keep_qual, (a->o.ptags() >> 1) & 1);
+	mm_reads_t *reads = reads_load(reads_fn, a->o.min_len, a->o.keep_qual, (a->o.ptags() >> 1) & 1, getenv("MM_HOST_PACK") == NULL);
 	if(!reads) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
 	if(verbose) { fprintf(stderr, "[minialign_amd] parse %.1f ms\n", now_ms() - tv); }
 	return align_reads(a, reads, out);
@@ -2040,7 +2076,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 			bool ok = h != nullptr;
 			if(ok) {
 				h->ctx = c; Batch &b = h->b;
-				if(!b.packed) batch_pack(b);
+				if(!b.packed) batch_pack(b, false);
 				c->rlen_carry = guess;
 				ok = batch_upload(c, b);
 				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): pack + upload %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
@@ -2153,6 +2189,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 }
 static void batch_fill(mm_batch_t *h, mm_reads_t const *r, uint32_t first, uint32_t last)
 {
+	h->b.text_src = r->text.empty() ? nullptr : &r->text;
 	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); h->b.rec.push_back(&r->r[i]); }
 }
 /* batch boundaries of a read set: bounded by bases (so that the device pools stay modest) and by reads */
@@ -2194,6 +2231,28 @@ extern "C" mm_batch_t *mm_batch_pack(mm_reads_t const *r, uint32_t first, uint32
 	return h;
 }
 extern "C" uint32_t mm_batch_reads(mm_batch_t const *h) { return h->b.n; }
+/* test entry for the packing on the device (K0): every read of a set loaded with mm_reads_load_text as one batch, packed once on the host (pack_bases over the
+ * parser's base codes) and once on the device from the text of the file; returns how many words of the two arenas (2-bit words and N-mask words) differ, -1 when
+ * the set has no text or something failed */
+extern "C" int64_t mm_pack_check(mm_align_t *a, mm_reads_t const *r)
+{
+	if(r->text.empty() || r->r.empty()) return -1;
+	mm_batch_t *h = new mm_batch_s(); batch_fill(h, r, 0, (uint32_t)r->r.size());
+	Batch &b = h->b;
+	batch_pack(b, true);
+	std::vector<uint32_t> pk(b.pk), nm(b.nm);
+	b.packed = false; batch_pack(b, false);
+	int64_t rc = -1;
+	if(b.text && batch_upload(a, b)) {
+		std::vector<uint32_t> dpk(pk.size(), 0), dnm(nm.size(), 0);
+		const size_t npk = std::min<size_t>(pk.size(), (b.total + 64) / 16), nnm = std::min<size_t>(nm.size(), (b.total + 64) / 32);
+		if(hipMemcpy(dpk.data(), a->q_pk.p, npk * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(dnm.data(), a->q_nm.p, nnm * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+			rc = 0; for(size_t i = 0; i < npk; i++) rc += dpk[i] != pk[i]; for(size_t i = 0; i < nnm; i++) rc += dnm[i] != nm[i];
+		}
+	}
+	delete h;
+	return rc;
+}
 /* every batch of reads [first, first + n) packed ahead of time, with the boundaries the streaming entries use; returns the count (at most max are made) */
 extern "C" uint32_t mm_batch_pack_all(mm_reads_t const *r, uint32_t first, uint32_t n, mm_batch_t **out, uint32_t max)
 {
@@ -2295,7 +2354,7 @@ extern "C" int mm_main(int argc, char **argv)
 	if(qh == nf) { fprintf(stderr, "[M::main_align] query-side input redirected to stdin.\n"); files[nf++] = "-"; }     /* minialign.c:6380-6384 */
 	/* the first query file is parsed on a thread of its own while the index is built or loaded */
 	mm_reads_t *first_reads = NULL;
-	std::thread rt([&]() { if(strcmp(files[qh], "-") != 0) first_reads = reads_load(files[qh], o->min_len, o->keep_qual, (o->ptags() >> 1) & 1); });
+	std::thread rt([&]() { if(strcmp(files[qh], "-") != 0) first_reads = reads_load(files[qh], o->min_len, o->keep_qual, (o->ptags() >> 1) & 1, getenv("MM_HOST_PACK") == NULL); });
 	std::thread hw([]() { int n = 0; if(hipGetDeviceCount(&n) == hipSuccess && n > 0) { (void)hipFree(0); } });      /* bring the HIP runtime up meanwhile */
 	const bool keep_first = prebuilt || n_ref > 1;      /* the parsed first query file serves every index */
 	FILE *pg = prebuilt ? fopen(files[0], "rb") : NULL;
