@@ -1291,6 +1291,7 @@ struct AlnRec {                /* what the host needs of a gaba_alignment_t (gab
 	uint32_t seg_off;          /* index into the segment pool */
 	uint64_t path_off;         /* word offset into the path pool; two header words {plen, 0x40000000} precede it (gaba.h:217) */
 };
+struct K3Class { uint8_t *slabs; uint64_t bytes; unsigned long long *ctr; uint32_t *ring; uint32_t n; uint32_t qmax; uint32_t next_base; uint32_t pad; };      /* ctr / ring as K3Args.ring_ctr / ring; next_base: first per-wave scratch number of the class */
 struct K3Args {
 	DevIndex idx; gaba::Consts gc; const uint8_t *roots; gaba::SeqArena ar_ref, ar_q;
 	const ReadIn *in; ReadState *st; const uint32_t *work; uint32_t n_work;
@@ -1300,9 +1301,10 @@ struct K3Args {
 	 * free workspace numbers per XCD (a wave only ever takes from the ring of the XCD it runs on, HW_REG_XCC_ID): the L2s of different XCDs are not coherent
 	 * with each other inside a launch, so a workspace must not wander between them while kernels are running */
 	unsigned long long *ring_ctr; uint32_t *ring; uint32_t ring_n;      /* per XCD x: ring_ctr[2x] = takes, [2x + 1] = returns; ring[x * ring_n ..] = numbers (~0 = taken) */
-	/* a second, small set of LARGE workspaces (ring_n2 > 0) for the reads longer than qlen_small: a long tail of read lengths (ONT) would otherwise size every
-	 * workspace for the longest read and leave room for a fifth of the waves; a wave changes class when the read it takes asks for the other one */
-	uint8_t *slabs2; uint64_t slab_bytes2; unsigned long long *ring_ctr2; uint32_t *ring2; uint32_t ring_n2; uint32_t qlen_small;
+	/* workspace classes (ring mode; table in device memory, n_cls >= 1, class 0 = the fields above): class c serves the reads of up to cls[c].qmax bases, the last one
+	 * the longest read of the input.  A long tail of read lengths (ONT) would otherwise size every workspace for the longest read and leave room for a
+	 * fraction of the waves; a wave changes class when the read it takes asks for another one */
+	const K3Class *cls; uint32_t n_cls;
 	KhSlot *kh_pool; uint32_t kh_cap;                    /* per read (work index) */
 	uint32_t round;
 	uint64_t *next_pool; uint32_t next_cap;              /* per wave: (pdiff, sid) */
@@ -1524,7 +1526,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	x.c = a.gc; x.ar = ar; x.lane = lane_id(); x.err = 0; x.no_trace = false; x.n_vec = x.n_blk = x.n_tr = 0;
 	const int lane = x.lane;
 	uint32_t wave = (uint32_t)rdfirst((int)(blockIdx.x * 4 + threadIdx.x / 64));
-	uint32_t slab_no = wave; uint32_t xcc = 0; int slab_cls = -1;          /* class of the workspace held: -1 none yet (ring mode), 0 ordinary, 1 large */
+	uint32_t slab_no = wave; uint32_t xcc = 0; int slab_cls = -1;          /* class of the workspace held: -1 none yet (ring mode) */
 	if(a.ring) { xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }          /* HW_REG_XCC_ID, bits 3:0 */
 	else {
 		x.slab = a.slabs + (uint64_t)slab_no * a.slab_bytes; x.cap = (uint32_t)a.slab_bytes; x.top = gaba::SLAB_HEAD; slab_cls = 0;
@@ -1533,12 +1535,12 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	}
 	/* take / return a workspace of class c on this XCD's ring */
 	#define K3_RING_TAKE(_c, _out) { uint32_t _v = 0; if(lane == 0) { \
-		unsigned long long *_ctr = (_c) ? a.ring_ctr2 : a.ring_ctr; uint32_t *_rg = (_c) ? a.ring2 : a.ring; const uint32_t _n = (_c) ? a.ring_n2 : a.ring_n; \
+		unsigned long long *_ctr = a.cls[_c].ctr; uint32_t *_rg = a.cls[_c].ring; const uint32_t _n = a.cls[_c].n; \
 		const unsigned long long _t = atomicAdd(&_ctr[2 * xcc], 1ull); uint32_t *_slot = &_rg[(uint64_t)xcc * _n + (uint32_t)(_t % _n)]; \
 		while((_v = atomicExch(_slot, 0xffffffffu)) == 0xffffffffu) { __builtin_amdgcn_s_sleep(16); } }          /* every workspace of this XCD in use: one comes back when a wave is done with it */ \
 		(_out) = (uint32_t)rdfirst((int)_v); }
 	#define K3_RING_GIVE(_c, _no) { if(lane == 0) { \
-		unsigned long long *_ctr = (_c) ? a.ring_ctr2 : a.ring_ctr; uint32_t *_rg = (_c) ? a.ring2 : a.ring; const uint32_t _n = (_c) ? a.ring_n2 : a.ring_n; \
+		unsigned long long *_ctr = a.cls[_c].ctr; uint32_t *_rg = a.cls[_c].ring; const uint32_t _n = a.cls[_c].n; \
 		const unsigned long long _t = atomicAdd(&_ctr[2 * xcc + 1], 1ull); uint32_t *_slot = &_rg[(uint64_t)xcc * _n + (uint32_t)(_t % _n)]; \
 		while(atomicCAS(_slot, 0xffffffffu, (_no)) != 0xffffffffu) { __builtin_amdgcn_s_sleep(4); } } }          /* (the taker of this slot's previous turn has not picked its number up yet) */
 	Kh kh; kh.cap = a.kh_cap;
@@ -1576,16 +1578,16 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
 		if(a.ring) {
-			/* the workspace this read needs: the large class for reads longer than qlen_small (when there is one), else the ordinary one; kept from read to read
+			/* the workspace this read needs: the smallest class that holds it; kept from read to read
 			 * while the class stays (the work list runs longest first, so a wave changes at most once) */
-			const int want = (a.ring_n2 != 0 && qlen > a.qlen_small) ? 1 : 0;
+			int want = 0; while(want + 1 < (int)a.n_cls && qlen > a.cls[want].qmax) { want++; }
 			if(want != slab_cls) {
 				if(slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); }
 				K3_RING_TAKE(want, slab_no); slab_cls = want;
-				x.slab = (want ? a.slabs2 : a.slabs) + (uint64_t)slab_no * (want ? a.slab_bytes2 : a.slab_bytes); x.cap = (uint32_t)(want ? a.slab_bytes2 : a.slab_bytes); x.top = gaba::SLAB_HEAD;
+				x.slab = a.cls[want].slabs + (uint64_t)slab_no * a.cls[want].bytes; x.cap = (uint32_t)a.cls[want].bytes; x.top = gaba::SLAB_HEAD;
 				for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-				if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + (want ? a.ring_n * 8u : 0u)) * (a.next_cap + MM_NEXT_SCRATCH); next_scratch = (uint32_t *)(next + a.next_cap); }
+				if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[want].next_base) * (a.next_cap + MM_NEXT_SCRATCH); next_scratch = (uint32_t *)(next + a.next_cap); }
 			}
 		}
 		Seed *s = a.seed_pool + rdfirst64(st->seed_off);

@@ -802,7 +802,9 @@ struct mm_align_s {
 	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
 	mm_align_s *root = nullptr;            /* the primary context of a lane (NULL on the primary itself) */
 	bool shared_slabs = false; DBuf<uint32_t> slab_ring; DBuf<unsigned long long> slab_ring_ctr; uint32_t slab_ring_n = 0;
-	DBuf<uint8_t> slabs2; uint64_t slab_stride2 = 0; DBuf<uint32_t> slab_ring2; DBuf<unsigned long long> slab_ring_ctr2; uint32_t slab_ring_n2 = 0, qlen_small = 0;      /* the large class (reads longer than qlen_small), when the input has a long tail of lengths */
+	/* the classes above the ordinary one (reads of more than 32 k bases), when the input has a long tail of lengths; h_cls[0] describes slabs / slab_ring */
+	static const uint32_t MAX_CLS = 8;
+	DBuf<uint8_t> xslabs[MAX_CLS]; DBuf<uint32_t> xring[MAX_CLS]; DBuf<unsigned long long> xctr[MAX_CLS]; std::vector<K3Class> h_cls; DBuf<K3Class> d_cls; uint32_t slab_total = 0; uint64_t slab_max = 0;
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
 	/* reusable host buffers of the streaming engine (primary context only): pinned result buffers for the D2H of a batch, text pieces with their capacity */
@@ -1029,9 +1031,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.in = a->d_in.p; k3.st = a->d_st.p; k3.work = a->d_work.p; k3.n_work = k3_work_override ? k3_work_override : (uint32_t)work.size();
 		k3.seed_pool = a->seed_pool.p; k3.root_pool = a->root_pool.p; k3.slabs = a->slabs.p; k3.slab_bytes = a->slab_stride;
 		k3.ring = nullptr; k3.ring_ctr = nullptr; k3.ring_n = 0;
-		k3.slabs2 = nullptr; k3.slab_bytes2 = 0; k3.ring2 = nullptr; k3.ring_ctr2 = nullptr; k3.ring_n2 = 0; k3.qlen_small = 0xffffffffu;
+		k3.cls = nullptr; k3.n_cls = 0;
 		{ const mm_align_s *P = a->root ? a->root : a; if(P->shared_slabs) { k3.slabs = P->slabs.p; k3.slab_bytes = P->slab_stride; k3.ring = P->slab_ring.p; k3.ring_ctr = P->slab_ring_ctr.p; k3.ring_n = P->slab_ring_n;
-			if(P->slab_ring_n2) { k3.slabs2 = P->slabs2.p; k3.slab_bytes2 = P->slab_stride2; k3.ring2 = P->slab_ring2.p; k3.ring_ctr2 = P->slab_ring_ctr2.p; k3.ring_n2 = P->slab_ring_n2; k3.qlen_small = P->qlen_small; } } }
+			k3.cls = P->d_cls.p; k3.n_cls = (uint32_t)P->h_cls.size(); } }
 		k3.kh_pool = a->kh_pool.p; k3.kh_cap = a->kh_cap; k3.round = round; k3.next_pool = a->next_pool.p; k3.next_cap = a->next_cap;
 		k3.bin_pool = a->bin_pool.p; k3.bin_pool_cap = a->bin_pool.n; k3.bin_top = tops + 3; k3.bin_cap_per_read = a->bin_cap;
 		k3.aln_pool = a->aln_pool.p; k3.aln_pool_cap = a->aln_pool.n; k3.aln_top = tops + 4; k3.aln_cap_per_read = a->aln_cap;
@@ -1386,7 +1388,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
 	ok &= a->resc_pool.ensure(min_total * std::min<uint64_t>(scale, 4));
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
-	ok &= a->next_pool.ensure((uint64_t)(a->n_waves + ((a->root ? a->root : a)->slab_ring_n2 * 8u)) * (a->next_cap + MM_NEXT_SCRATCH));
+	ok &= a->next_pool.ensure((uint64_t)std::max(a->n_waves, (a->root ? a->root : a)->slab_total) * (a->next_cap + MM_NEXT_SCRATCH));
 	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap);
 	ok &= a->aln_pool.ensure(((uint64_t)n_reads + 2048) * a->aln_cap);
 	ok &= a->seg_pool.ensure((uint64_t)n_reads * a->aln_cap * 2 + 4096);
@@ -1404,7 +1406,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	mm_align_s *P = a->root ? a->root : a;
 	if(P->shared_slabs) {
 		/* the engine sized the shared workspaces for the longest read of the input before the lanes started */
-		if(std::max(P->slab_stride, P->slab_stride2) < slab) { fprintf(stderr, "[minialign_amd] a read longer than announced (%u bases) does not fit the shared DP workspaces\n", max_qlen); ok = false; }
+		if(P->slab_max < slab) { fprintf(stderr, "[minialign_amd] a read longer than announced (%u bases) does not fit the shared DP workspaces\n", max_qlen); ok = false; }
 		a->k3_waves = lane_waves & ~3u;
 	}
 	else if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
@@ -1427,22 +1429,38 @@ bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
 	const uint64_t budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
 	const uint32_t n_xcd = 8;
 	/* reads up to 32 k bases (the PacBio-like sets whole, nine tenths of an ONT-like one) take the ordinary class, one workspace for every wave the device can hold if
-	 * the budget allows; a longer maximum gets a second class sized for it out of a third of the budget (MM_SLAB_GB, default 64 + 32) */
+	 * the budget allows (MM_SLAB_GB, default 64); a longer maximum adds classes of 64 k, 128 k, ... bases up to it, out of half the budget again: half of that for
+	 * the first one, a quarter for the next ... (read counts fall faster than that with length in the sets seen) */
 	const uint32_t q_small = 32768;
-	const bool two = max_qlen > q_small && !getenv("MM_ONE_SLAB_CLASS");
-	const uint64_t slab = slab_of(two ? q_small : max_qlen), slab2 = two ? slab_of(max_qlen) : 0;
-	const uint32_t per = (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(32, budget / slab / n_xcd));
-	const uint32_t per2 = two ? (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(8, (budget / 2) / slab2 / n_xcd)) : 0;
-	if(P->shared_slabs && P->slab_stride >= slab && P->slab_ring_n >= per && (two ? (P->slab_stride2 >= slab2 && P->slab_ring_n2 >= per2 && P->qlen_small == q_small) : P->slab_ring_n2 == 0)) return true;
+	std::vector<uint32_t> qmax;
+	if(max_qlen > q_small && !getenv("MM_ONE_SLAB_CLASS")) {
+		for(uint32_t q = q_small; ; q *= 2) { if(q >= max_qlen || qmax.size() + 1 == mm_align_s::MAX_CLS) { qmax.push_back(max_qlen); break; } qmax.push_back(q); }
+		if(getenv("MM_TWO_SLAB_CLASSES")) { qmax.resize(1); qmax.push_back(max_qlen); }
+	} else { qmax.push_back(max_qlen); }
+	std::vector<uint64_t> bytes(qmax.size()); std::vector<uint32_t> per(qmax.size());
+	uint64_t share = budget / 2;
+	for(size_t c = 0; c < qmax.size(); c++) {
+		bytes[c] = slab_of(qmax[c]);
+		if(c == 0) { per[c] = (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(32, budget / bytes[c] / n_xcd)); continue; }
+		if(c + 1 < qmax.size()) share /= 2;          /* (the last class takes what the one before it took) */
+		per[c] = (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(4, share / bytes[c] / n_xcd));
+	}
+	bool same = P->shared_slabs && P->h_cls.size() == qmax.size();
+	for(size_t c = 0; same && c < qmax.size(); c++) same = P->h_cls[c].bytes >= bytes[c] && P->h_cls[c].n >= per[c] && (c + 1 == qmax.size() || P->h_cls[c].qmax == qmax[c]);
+	if(same) return true;
 	/* (re)allocation: only between runs -- nothing is in flight when the engine calls */
 	if(hipDeviceSynchronize() != hipSuccess) return false;
-	if(!P->slabs.ensure(slab * per * n_xcd) || !fill_ring(P->slab_ring, P->slab_ring_ctr, per, n_xcd)) return false;
-	P->slab_stride = slab; P->slab_ring_n = per; P->k3_waves = P->n_waves;
-	P->slab_ring_n2 = 0; P->slab_stride2 = 0; P->qlen_small = 0xffffffffu;
-	if(two) {
-		if(!P->slabs2.ensure(slab2 * per2 * n_xcd) || !fill_ring(P->slab_ring2, P->slab_ring_ctr2, per2, n_xcd)) return false;
-		P->slab_stride2 = slab2; P->slab_ring_n2 = per2; P->qlen_small = q_small;
+	P->h_cls.clear(); P->slab_total = 0; P->slab_max = 0;
+	for(size_t c = 0; c < qmax.size(); c++) {
+		DBuf<uint8_t> &sl = c ? P->xslabs[c] : P->slabs; DBuf<uint32_t> &rg = c ? P->xring[c] : P->slab_ring; DBuf<unsigned long long> &ct = c ? P->xctr[c] : P->slab_ring_ctr;
+		if(!sl.ensure(bytes[c] * per[c] * n_xcd) || !fill_ring(rg, ct, per[c], n_xcd)) return false;
+		K3Class k; k.slabs = sl.p; k.bytes = bytes[c]; k.ctr = ct.p; k.ring = rg.p; k.n = per[c]; k.qmax = qmax[c]; k.next_base = P->slab_total; k.pad = 0;
+		P->h_cls.push_back(k); P->slab_total += per[c] * n_xcd; P->slab_max = bytes[c];
 	}
+	for(size_t c = qmax.size(); c < mm_align_s::MAX_CLS; c++) { if(c) { P->xslabs[c].release(); P->xring[c].release(); P->xctr[c].release(); } }
+	if(!P->d_cls.ensure(P->h_cls.size()) || hipMemcpy(P->d_cls.p, P->h_cls.data(), P->h_cls.size() * sizeof(K3Class), hipMemcpyHostToDevice) != hipSuccess) return false;
+	P->slab_stride = bytes[0]; P->slab_ring_n = per[0]; P->k3_waves = P->n_waves;
+	if(getenv("MM_VERBOSE_SLABS")) { for(auto &k : P->h_cls) fprintf(stderr, "[minialign_amd] workspace class: reads up to %u bases, %u x %.1f MB\n", k.qmax, k.n * n_xcd, k.bytes / 1048576.0); }
 	P->shared_slabs = true;
 	return true;
 }
@@ -1510,7 +1528,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 		gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
-	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); a->slabs2.release(); a->slab_ring2.release(); a->slab_ring_ctr2.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
+	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
