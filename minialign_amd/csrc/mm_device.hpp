@@ -1517,6 +1517,8 @@ __device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uin
 #ifndef MM_K3_LAUNCH_BOUND
 #define MM_K3_LAUNCH_BOUND MM_K3_WAVES_PER_SIMD          /* waves per SIMD the register budget of the kernel is set for */
 #endif
+#define K3_TAB_WORDS 1536u
+#define K3_LDS_BYTES ((K3_TAB_WORDS + 16u) * 4u)          /* dynamic LDS of a launch with the rounds in the kernel: the tables of k3_rescue_round + their lock */
 __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Args a)
 {
 	extern __shared__ uint32_t k3_tab[];       /* launched with 4 x 1536 words when the rounds run in the kernel (per wave: tables of k3_rescue_round's sort + chain), else with none:
@@ -1555,6 +1557,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	unsigned long long cy_fill = 0, cy_leaf = 0, cy_trace = 0;        /* wave cycles spent in the three DP phases (s_memtime) */
 	unsigned long long cy_next = 0;                                  /* ... and in mm_search_load_next */
 	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
+	if(a.inkernel_rounds) { if(threadIdx.x == 0) { k3_tab[K3_TAB_WORDS] = 0; } __syncthreads(); }          /* the lock of the tables */
 
 	while(true) {
 		uint32_t wi = wave;
@@ -1565,8 +1568,14 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		for(uint32_t round = a.round; ; round++) {
 		if(round != a.round) {
 			/* the next occurrence threshold for this read, here and now */
+			/* ONE set of tables per workgroup, taken in turn by its four waves: the rounds are rare (a few per cent of the reads), and 24 KB of LDS per workgroup held
+			 * six workgroups' worth of a CU's LDS for the whole launch -- the sort and chain kernels of the other lanes, which live on LDS, ran 2.3 x slower beside it */
+			if(lane == 0) { while(atomicCAS((unsigned int *)&k3_tab[K3_TAB_WORDS], 0u, 1u) != 0u) { __builtin_amdgcn_s_sleep(32); } }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			const uint32_t e2 = k3_rescue_round(st, round, a.seed_pool + rdfirst64(st->seed_off), a.root_pool + rdfirst64(st->root_off), a.resc_pool + rdfirst64(st->resc_off),
-				a.idx, a.twlen, a.mcoef, a.min_score, (LU32 *)&k3_tab[(threadIdx.x / 64) * 1536]);
+				a.idx, a.twlen, a.mcoef, a.min_score, (LU32 *)&k3_tab[0]);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+			if(lane == 0) { atomicExch((unsigned int *)&k3_tab[K3_TAB_WORDS], 0u); }
 			if(e2) { if(lane == 0) { st->err |= e2; } break; }
 		}
 		const unsigned long long cy_read0 = MM_TICK(); const uint32_t vec_read0 = x.n_vec; const unsigned long long cyf_read0 = cy_fill, cyt_read0 = cy_trace;

@@ -788,6 +788,7 @@ struct mm_align_s {
 	gaba_arena_t *ref_ar = nullptr;
 	uint32_t twlen, tglen; double mcoef, xcoef;
 	hipStream_t stream; hipEvent_t ev0, ev1;
+	hipStream_t k3s = nullptr; hipEvent_t k3e = nullptr;      /* the extension launches' own stream (lowest priority; the others are created with the highest), see make_streams */
 	hipStream_t k2s[12]; hipEvent_t k2e[16]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
 	uint32_t qlen_hint = 0;                                    /* longest read of the input being mapped, when known (mm_align_file) */
@@ -1052,14 +1053,16 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * thirds of its instructions are VALU) and leave wave slots for the sketch and sort + chain kernels of the other lanes, which otherwise wait for the
 		 * tail of this launch: +4 % on the bench workload with 3 in flight (4.33 against 4.15 G bases/s), -10 % for a launch running alone */
 		else if(a->is_sib || a->sib) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u); }
-		CK(hipEventRecord(a->ev0, a->stream));
+		hipStream_t xs = a->stream;
+		if(a->k3s && (a->is_sib || a->sib)) { xs = a->k3s; CK(hipEventRecord(a->k3e, a->stream)); CK(hipStreamWaitEvent(xs, a->k3e, 0)); }      /* (the host waits for the launch below before it queues anything else) */
+		CK(hipEventRecord(a->ev0, xs));
 		/* persistent waves stealing reads from a counter, never more of them than there are workspaces.  MM_K3_ONE_READ_PER_WAVE (with a workspace for every wave
 		 * the device can hold): grid = reads / 4, a wave maps one read and ends -- wave slots then come free read by read for the other lanes' launches; measured
 		 * no faster on the headline workload (2.86 against 2.77 s per step with the rounds in the kernel, 3.7 against 3.2 without), kept as an experiment */
 		k3.persistent = 1;
 		if(k3.ring) { if((uint64_t)k3.ring_n * 8 >= a->n_waves && getenv("MM_K3_ONE_READ_PER_WAVE")) { k3.persistent = 0; waves = (uint32_t)((k3.n_work + 3) & ~3u); } else { waves = std::min<uint32_t>(waves, (k3.ring_n * 8u) & ~3u); } }
-		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), inkernel ? 4 * 1536 * 4 : 0, a->stream, k3);
-		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
+		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), inkernel ? K3_LDS_BYTES : 0, xs, k3);
+		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, xs)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
 		if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
@@ -1380,6 +1383,12 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_qlen, uint64_t scale)
 {
 	bool ok = true;
+	/* sized with an eighth to spare, in steps of 8 192 reads / 32 Mb: the batches of a run differ by a few per cent, and a pool that grows in the middle of a run
+	 * costs a hipFree -- which waits for every stream of the device, the other lanes' extension launches included (seen as 100 - 450 ms "upload" times of single
+	 * batches, with the lanes behind them waiting for their turn at the carried value) */
+	{ const uint64_t rq = n_reads >= 8192 ? 8192 : 256, bq = bases >= (32ull << 20) ? (32ull << 20) : (1ull << 20);          /* (small steps for small batches: tests, the per-read entries) */
+	  n_reads = (uint32_t)std::min<uint64_t>(0xffffe000u, ((uint64_t)n_reads + n_reads / 8 + rq - 1) / rq * rq);
+	  bases = (bases + bases / 8 + bq - 1) / bq * bq; }
 	ok &= a->d_in.ensure(n_reads); ok &= a->d_st.ensure(n_reads); ok &= a->d_work.ensure(n_reads);
 	ok &= a->q_pk.ensure(bases / 16 + 8); ok &= a->q_nm.ensure(bases / 32 + 8);
 	const uint64_t min_total = ((a->mi->w < 4 || scale > 1) ? bases : bases / 2) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
@@ -1467,6 +1476,20 @@ bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
 
 } /* anonymous */
 
+/* the streams of a context.  MM_STREAM_PRIO (experiment, off by default): everything but the extension launch on streams of the highest priority and the extension on one
+ * of the lowest, so that the dispatcher hands a wave slot that comes free to the short, latency-bound kernels of the other lanes first.  Measured on the headline
+ * workload: nothing at 4 lanes (2.74 / 2.81 against 2.74 / 2.72 s per step), worse at 6 (3.15 against 2.84: 6 x 4 streams no longer get a hardware queue each) --
+ * the extension launch runs persistent waves, which give their slots back at its end only, and with one read per wave (MM_K3_ONE_READ_PER_WAVE) the lanes fall into step */
+static bool make_streams(mm_align_s *a)
+{
+	int least = 0, greatest = 0;
+	if(getenv("MM_STREAM_PRIO") == NULL || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+	if(hipStreamCreateWithPriority(&a->stream, hipStreamNonBlocking, greatest) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) return false;
+	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithPriority(&a->k2s[i], hipStreamNonBlocking, greatest) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) return false; }
+	a->k2s_ok = true;
+	if(least != greatest) { if(hipStreamCreateWithPriority(&a->k3s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) return false; }
+	return true;
+}
 extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 {
 	int ndev = 0;
@@ -1479,9 +1502,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	/* mcoef / xcoef: both accumulate score_matrix[0] in the reference (minialign.c:4676-4681); kept */
 	double mc = 0, xc = 0; for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 3)) mc += o->p.score_matrix[0]; else xc += o->p.score_matrix[0]; }
 	a->mcoef = mc / 4.0; a->xcoef = xc / 12.0;
-	if(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) { delete a; return NULL; }
-	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithFlags(&a->k2s[i], hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) { delete a; return NULL; } }
-	a->k2s_ok = true;
+	if(!make_streams(a)) { delete a; return NULL; }
 	/* reference: one arena, per-sequence offsets */
 	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
 	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
@@ -1531,7 +1552,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
-	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
+	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
 	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < MM_SIDE) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
 	delete a;
 }
@@ -1920,9 +1941,7 @@ static mm_align_t *align_lane(mm_align_t *a)
 	q->o = a->o; q->mi = a->mi; q->gctx = a->gctx; q->dix = a->dix; q->d_slot = a->d_slot; q->d_val = a->d_val; q->d_seq_len = a->d_seq_len; q->d_seq_off = a->d_seq_off; q->d_seq_circ = a->d_seq_circ;
 	q->root = a->root ? a->root : a; q->ref_ar = a->ref_ar; q->twlen = a->twlen; q->tglen = a->tglen; q->mcoef = a->mcoef; q->xcoef = a->xcoef; q->n_waves = a->n_waves; q->is_sib = true; q->dev = a->dev;
 	q->qlen_hint = a->qlen_hint; q->k2_leaf_shift = a->k2_leaf_shift; q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
-	if(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&q->ev0) != hipSuccess || hipEventCreate(&q->ev1) != hipSuccess) { delete q; return NULL; }
-	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithFlags(&q->k2s[i], hipStreamNonBlocking) != hipSuccess) || hipEventCreateWithFlags(&q->k2e[i], hipEventDisableTiming) != hipSuccess) { delete q; return NULL; } }
-	q->k2s_ok = true;
+	if(!make_streams(q)) { delete q; return NULL; }
 	memset(&q->st, 0, sizeof(q->st)); q->t_wall0 = now_ms();
 	a->sib = q;
 	return q;
@@ -2083,6 +2102,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 		delete it;
 	};
 
+	const double t_engine0 = now_ms();
 	auto lane_main = [&](int li) {
 		mm_align_t *c = ctx[li];
 		if(hipSetDevice(a->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); rc = 1; lanes_done++; cv.notify_all(); return; }
@@ -2097,12 +2117,12 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 				if(!b.packed) batch_pack(b, false);
 				c->rlen_carry = guess;
 				ok = batch_upload(c, b);
-				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): pack + upload %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): pack + upload %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 				/* run ahead with the predicted carry; pools that overflow are grown here, before anybody waits for this batch */
 				bool split = false;
 				if(getenv("MM_TEST_SPLIT") && b.n >= 8) { split = true; }          /* test hook: take the path of a batch the pools cannot hold */
 				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) ok = false; }
-				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): run %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): run %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 				uint32_t truth = 0;
 				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return verified == k || rc != 0; }); if(rc) ok = false; truth = carry; }
 				while(ok && !split) {
@@ -2135,16 +2155,17 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 						if(a->head.size() >= 4096) head_open = false;
 					}
 					cv.notify_all();
-					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): carry wait + verify %.1f ms\n", k, li, now_ms() - tv); tv = now_ms(); }
+					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): carry wait + verify %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 					/* the batch that is written next never waits here: everything queued in front of the writer is behind it */
 					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return pending < max_pending || k == next_write || rc != 0; }); if(rc) ok = false; else pending++; }
+					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): wait for the writer %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 				}
 				if(ok && !split) {
 					Item *it = new Item(); it->h = h; it->k = k;
 					{ std::lock_guard<std::mutex> lk(a->pool_mu); if(!a->pin_free.empty()) { it->f.pin = a->pin_free.back(); a->pin_free.pop_back(); } if(!a->piece_free.empty()) { it->piece = std::move(a->piece_free.back()); a->piece_free.pop_back(); } }
 					if(!it->f.pin) it->f.pin = new mm_align_s::PinSet();
 					ok = batch_fetch(c, b, it->f);
-					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): D2H %.1f ms\n", k, li, now_ms() - tv); }
+					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): D2H %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); }
 					if(ok) { std::lock_guard<std::mutex> lk(mu); fetched.push_back(it); } else { drop_item(it); std::lock_guard<std::mutex> lk(mu); pending--; }
 					cv.notify_all();
 				}
@@ -2210,12 +2231,25 @@ static void batch_fill(mm_batch_t *h, mm_reads_t const *r, uint32_t first, uint3
 	h->b.text_src = r->text.empty() ? nullptr : &r->text;
 	for(uint32_t i = first; i < last; i++) { h->b.lens.push_back((uint32_t)r->r[i].seq.size()); h->b.seq.push_back(r->r[i].seq.data()); h->b.names.push_back(r->r[i].name); h->b.rec.push_back(&r->r[i]); }
 }
+static int default_lanes() { return getenv("MM_LANES") ? std::max(1, atoi(getenv("MM_LANES"))) : 4; }
 /* batch boundaries of a read set: bounded by bases (so that the device pools stay modest) and by reads */
 static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *reads, uint32_t first, uint32_t n)
 {
-	const uint64_t max_bases = getenv("MM_BATCH_BASES") ? (uint64_t)atoll(getenv("MM_BATCH_BASES")) : (512ull << 20);      /* env: test hook (many small batches) */
 	const uint32_t max_reads = 1u << 17;
 	const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)first + n, reads->r.size());
+	/* 300 Mb per batch: on the whole hg38-size x3 set anything between 250 and 512 Mb measures the same, on an eighth or a quarter of it (one rank's shard of
+	 * the multi-GPU job) the smaller batches give every lane one and are 8 - 13 % faster; a set smaller than lanes x 300 Mb is cut into one batch per lane, not
+	 * below 64 Mb.  A set with very long reads wants larger batches: an extension launch lasts at least as long as its longest read (one wave, ~0.8 us per base), and
+	 * every batch pays that tail again -- 2 500 bases of batch per base of the longest read, up to 1 Gb (ONT-like set, longest read 385 kb: 2.40 s per step at 300 Mb,
+	 * 1.58 at 512 Mb, 1.46 at 800 Mb; profiles/round2_batch_size.txt).  MM_BATCH_BASES: test hook (many small batches) */
+	uint64_t max_bases = 300000000ull;
+	if(getenv("MM_BATCH_BASES")) { max_bases = (uint64_t)atoll(getenv("MM_BATCH_BASES")); }
+	else {
+		uint64_t total = 0, longest = 0; for(uint32_t i = first; i < end; i++) { total += reads->r[i].seq.size(); longest = std::max<uint64_t>(longest, reads->r[i].seq.size()); }
+		max_bases = std::min<uint64_t>(1000000000ull, std::max<uint64_t>(max_bases, longest * 2500));
+		const uint64_t lanes = (uint64_t)default_lanes();
+		if(total < lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, total / lanes + (1ull << 20));
+	}
 	std::vector<std::pair<uint32_t, uint32_t>> sp;
 	for(uint32_t i = first; i < end;) {
 		uint32_t j = i; uint64_t nb = 0;
@@ -2224,7 +2258,6 @@ static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *
 	}
 	return sp;
 }
-static int default_lanes() { return getenv("MM_LANES") ? std::max(1, atoi(getenv("MM_LANES"))) : 4; }
 /* maps a parsed read set (consumed unless keep) and writes its records */
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 {
