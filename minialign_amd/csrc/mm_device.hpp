@@ -154,6 +154,7 @@ __device__ __forceinline__ uint32_t q_code(const gaba::SeqArena &ar, uint64_t p)
 
 __global__ void __launch_bounds__(256) mm_sketch_seed_kernel(K1Args a)
 {
+	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
 	const int lane = lane_id();
 	const DevIndex &ix = a.idx;
 	const uint32_t k = ix.k, w = ix.w;
@@ -575,7 +576,7 @@ typedef __attribute__((address_space(3))) uint32_t LU32;
  * where K1 wrote them (HBM / L2) and are fetched once per level, 64 at a time; the stable sort of the small buckets is a rank computation (lane = element,
  * shuffles over its bucket; a stable sort has one answer, so any stable method gives the insertion sort's); the seeds themselves move once, at the end.
  * ----------------------------------------------------------------------------------------------------- */
-constexpr uint32_t K2S_MAX_N = 32768;                  /* seeds + sentinel a read may have here (index field of an entry, range stack); larger reads: in-HBM path of K2a */
+constexpr uint32_t K2S_MAX_N = 24576;                  /* seeds + sentinel a read may have here (104 KB of LDS: what a CU has left beside eight extension workgroups, see K2C_MAX_LDS_KB); larger reads: in-HBM path of K2a */
 constexpr uint32_t K2S_STACK = 512;                    /* pending ranges (each > 64 elements, disjoint) */
 constexpr uint32_t K2S_TABLE_WORDS = 768 + 2 * K2S_STACK;
 constexpr uint64_t K2S_SENTINEL_KEY = 0x7fffffff80000000ull;      /* { upos = INT32_MIN, rid = INT32_MAX }, minialign.c:3531 */
@@ -623,6 +624,7 @@ __device__ __forceinline__ void k2s_small_buckets(LU32 *e, const LU32 *bs, const
 }
 __global__ void __launch_bounds__(64) mm_sort_kernel(K2sArgs a)
 {
+	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
 	extern __shared__ uint8_t lds_raw[];
 	LU32 *e = (LU32 *)lds_raw;
 	LU32 *cnt = (LU32 *)(lds_raw + a.lds_bytes - 4 * K2S_TABLE_WORDS), *bb = cnt + 256, *be = bb + 256, *stk = be + 256, *stsh = stk + K2S_STACK;
@@ -835,10 +837,16 @@ struct K2cArgs {
 	const uint32_t *seq_len; const uint8_t *seq_circ;
 	unsigned long long *prof;         /* [1] wave cycles, [5] reads whose leaf area overflowed */
 };
+/* the largest LDS image mm_chain_kernel takes: what a CU has left beside eight workgroups of the extension kernel (K3_LDS_BYTES each) -- a launch that asks for all
+ * 160 KB finds no CU to start on until an extension launch of another lane ends, whether it has a read to sweep or not; larger reads go the in-HBM way of K2a */
+#ifndef K2C_MAX_LDS_KB
+#define K2C_MAX_LDS_KB 108u
+#endif
 __host__ __device__ inline uint32_t k2c_leafcap(uint32_t n_all, uint32_t shift) { return (n_all >> shift) + 64; }
 __host__ __device__ inline uint32_t k2c_bytes(uint32_t n_all, uint32_t leafcap) { return 12u * ((n_all + 63u) & ~63u) + 12u * ((leafcap + 63u) & ~63u) + 1536u * 4u; }
 __global__ void __launch_bounds__(64) mm_chain_kernel(K2cArgs a)
 {
+	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
 	extern __shared__ uint8_t lds_raw[];
 	const int lane = lane_id();
 	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
@@ -919,7 +927,7 @@ __global__ void __launch_bounds__(64) mm_chain_kernel(K2cArgs a)
 		over = (uint32_t)rdfirst((int)over); ncid = (uint32_t)rdfirst((int)ncid); nleaf = (uint32_t)rdfirst((int)nleaf);
 		if(over) {
 			/* leaf area exhausted: nothing has been written, the retry launch redoes the read with room for one leaf per seed */
-			if(lane == 0) { if(!a.retry) { st->n_root = k2c_bytes(n_all, n_all) <= 160u * 1024u ? 0xffffffffu : 0xfffffffeu; atomicAdd(&a.prof[5], 1ull); } else { st->err |= ERR_SEED_CAP; } }
+			if(lane == 0) { if(!a.retry) { st->n_root = k2c_bytes(n_all, n_all) <= K2C_MAX_LDS_KB * 1024u ? 0xffffffffu : 0xfffffffeu; atomicAdd(&a.prof[5], 1ull); } else { st->err |= ERR_SEED_CAP; } }
 			continue;
 		}
 		/* write out: the seeds' marks, the sentinel, the leaves { rsid, rid, lsid, cid }, the chain roots */
@@ -1221,7 +1229,7 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 		ReadState *st = &a.st[a.work[wi]];
 		const uint32_t seed_n = (uint32_t)rdfirst((int)st->seed_n0);     /* not seed_n: launches of other classes update that concurrently */
 		/* big_only: what mm_chain_kernel cannot take -- more than K2S_MAX_N seeds, an LDS image of more than 160 KB, or leaves that did not fit even the retry */
-		if(a.big_only && seed_n + 1 <= K2S_MAX_N && k2c_bytes(seed_n + 1, k2c_leafcap(seed_n + 1, a.leaf_shift)) <= 160u * 1024u && (uint32_t)rdfirst((int)st->n_root) != 0xfffffffeu) { continue; }
+		if(a.big_only && seed_n + 1 <= K2S_MAX_N && k2c_bytes(seed_n + 1, k2c_leafcap(seed_n + 1, a.leaf_shift)) <= K2C_MAX_LDS_KB * 1024u && (uint32_t)rdfirst((int)st->n_root) != 0xfffffffeu) { continue; }
 		if(seed_n == 0) { if(a.n_lo == 0 && !a.retry && lane == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; } continue; }
 		bool fits; uint32_t lcap = 0;
 		if(a.retry) {

@@ -911,7 +911,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(presort) {
 				static bool sattr = false;
 				if(!sattr) { CK(hipFuncSetAttribute((const void *)mm_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
-				static const uint32_t s_kb[] = { 10, 14, 20, 32, 64, 140 };
+				static const uint32_t s_kb[] = { 10, 14, 20, 32, 64, 104 };          /* k2s_bytes(K2S_MAX_N) <= 104 KB */
 				const int n_s = (int)(sizeof(s_kb) / sizeof(s_kb[0]));
 				K2sArgs ks; ks.st = a->d_st.p; ks.work = a->d_work.p; ks.n_work = (uint32_t)work.size(); ks.seed_pool = a->seed_pool.p; ks.prof = tops + 28;
 				const uint32_t n_cu = a->n_waves / (4 * MM_K3_WAVES_PER_SIMD);
@@ -932,21 +932,21 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				/* chaining in two launches: the window scans of all seeds at full occupancy (mm_chain_scan_kernel, no LDS), then the sequential sweep on a
 				 * compact LDS image of each read (mm_chain_kernel, size classes by LDS need); what the old kernel is left with are reads too large for these */
 				static bool cattr = false;
-				if(!cattr) { CK(hipFuncSetAttribute((const void *)mm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); cattr = true; }
+				if(!cattr) { CK(hipFuncSetAttribute((const void *)mm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K2C_MAX_LDS_KB * 1024)); cattr = true; }
 				const uint32_t n_cu = a->n_waves / (4 * MM_K3_WAVES_PER_SIMD);
 				K2pArgs kp; kp.st = a->d_st.p; kp.work = a->d_work.p; kp.n_work = (uint32_t)work.size(); kp.seed_pool = a->seed_pool.p; kp.twlen = a->twlen; kp.counter = a->d_k2cnt.p + 24; kp.prof = tops + 24;
 				hipLaunchKernelGGL(mm_chain_scan_kernel, dim3(std::min<uint32_t>((uint32_t)work.size(), n_cu * 32u)), dim3(64), 0, a->k2s[0], kp);
 				CK(hipGetLastError());
 				CK(hipEventRecord(a->k2e[14], a->k2s[0]));
 				for(int j = 1; j < MM_SIDE; j++) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[14], 0)); }
-				static const uint32_t c_kb[] = { 12, 16, 24, 32, 48, 64, 96, 160 };
+				static const uint32_t c_kb[] = { 12, 16, 24, 32, 48, 64, 84, K2C_MAX_LDS_KB };
 				const int n_c = (int)(sizeof(c_kb) / sizeof(c_kb[0]));
 				K2cArgs kc; kc.st = a->d_st.p; kc.work = a->d_work.p; kc.n_work = (uint32_t)work.size(); kc.seed_pool = a->seed_pool.p; kc.root_pool = a->root_pool.p;
 				kc.leaf_shift = a->k2_leaf_shift ? 1u : 0u; kc.mcoef = a->mcoef; kc.min_score = a->o.min_score; kc.twlen = a->twlen; kc.seq_len = a->dix.seq_len; kc.seq_circ = a->dix.seq_circ; kc.prof = tops + 24;
 				for(int ci = 0; ci <= n_c; ci++) {
 					/* ci < n_c: size classes; ci == n_c: the reads whose leaves did not fit, with room for one leaf per seed, any size */
 					kc.retry = ci == n_c;
-					kc.lds_bytes = (ci == n_c ? 160u : c_kb[ci]) * 1024u; kc.n_lo = (ci == n_c || ci == 0) ? 0u : c_kb[ci - 1] * 1024u; kc.n_hi = kc.lds_bytes; kc.counter = a->d_k2cnt.p + ci;
+					kc.lds_bytes = (ci == n_c ? K2C_MAX_LDS_KB : c_kb[ci]) * 1024u; kc.n_lo = (ci == n_c || ci == 0) ? 0u : c_kb[ci - 1] * 1024u; kc.n_hi = kc.lds_bytes; kc.counter = a->d_k2cnt.p + ci;
 					const uint32_t per_cu = std::min<uint32_t>(16u, 160u * 1024u / kc.lds_bytes);
 					const uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), n_cu * per_cu);
 					hipStream_t sq = ci == n_c ? a->stream : a->k2s[ci % MM_SIDE];
