@@ -114,13 +114,17 @@ def reference_runs(w, ref_fa, parts, work, n_check, n_time, want_check):
     if want_check and r.returncode == 0: out.update(check_sam=strip_header(r.stdout), check_reads=ns, check_kind='oracle/ora_minialign (plain-C restatement)')
     return out
 
-def pmc_traffic(wname, world):
-    """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes of the same workload (tools/pmc_traffic.sh), else None"""
+def pmc_traffic(wname, world, alg_bytes_per_launch):
+    """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes of the same workload (tools/pmc_traffic.sh), else None.  The PMC run maps
+    a tenth of the set on one lane; its traffic per launch is scaled by the algorithmic bytes per launch of this run over those of that run (same kernel, same reads:
+    traffic per vector is what the counters measured)."""
     fn = os.path.join(ROOT, 'profiles', 'round2_pmc.json')
     if world != 1 or not os.path.exists(fn): return None
     try:
         with open(fn) as f: d = json.load(f)
-        return d['mm_extend_kernel_per_launch']['hbm_bytes'] if d.get('workload') == wname else None
+        per = d['mm_extend_kernel_per_launch']
+        if d.get('workload') != wname: return None
+        return per['hbm_bytes'] * alg_bytes_per_launch / per['alg_bytes_per_launch'] if per.get('alg_bytes_per_launch') else per['hbm_bytes']
     except Exception:
         return None
 
@@ -238,7 +242,7 @@ def main():
                        'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
                        'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'parse_and_pack_s': t_load},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args.workload if not custom else 'custom', world),
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args.workload if not custom else 'custom', world, alg_bytes / max(1.0, k3_launches)),
                          'alg_bytes_per_launch': alg_bytes / max(1.0, k3_launches), 'avg_launch_ms': k3_launch_ms, 'launches': k3_launches,
                          # launches of different lanes share the chip, so one launch lasts longer than it would alone: the same bytes over the wall time of the timed region
                          'achieved_all_lanes': alg_bytes / dt * 1e-9 / world,

@@ -85,6 +85,11 @@ __device__ __forceinline__ int32_t BS(const Seed &p) { return (int32_t)(((p.vpos
  *   mm_codes_pack_kernel   thread per 32 bases of the arena: two 2-bit words and one N-mask word (what pack_bases builds on the host)
  * ===================================================================================================== */
 struct TextRead { uint64_t t_off; uint32_t t_len; uint32_t pad; uint64_t q_off; };      /* extent in the uploaded text, first base in the arena */
+/* register budget of the short kernels (sketch, sort, chain sweep): 64 VGPRs, the extension kernel's own -- they start in the wave slots that extension waves of
+ * the other lanes leave, and a slot left by a 64-VGPR wave holds nothing larger (at 74 / 75 VGPRs the sketch and the sweep had to wait for two to come free on one SIMD) */
+#ifndef MM_SHORT_KERNEL_WAVES
+#define MM_SHORT_KERNEL_WAVES 8
+#endif
 __global__ void __launch_bounds__(256) mm_text_codes_kernel(const uint8_t *text, const TextRead *tr, uint32_t n_reads, uint8_t *codes, uint32_t *n_bases)
 {
 	const int lane = lane_id();
@@ -152,7 +157,7 @@ __device__ __forceinline__ uint32_t q_code(const gaba::SeqArena &ar, uint64_t p)
 	return n ? 4 : c;
 }
 
-__global__ void __launch_bounds__(256) mm_sketch_seed_kernel(K1Args a)
+__global__ void __launch_bounds__(256, MM_SHORT_KERNEL_WAVES) mm_sketch_seed_kernel(K1Args a)
 {
 	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
 	const int lane = lane_id();
@@ -622,7 +627,7 @@ __device__ __forceinline__ void k2s_small_buckets(LU32 *e, const LU32 *bs, const
 		pos = cut;
 	}
 }
-__global__ void __launch_bounds__(64) mm_sort_kernel(K2sArgs a)
+__global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_sort_kernel(K2sArgs a)
 {
 	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
 	extern __shared__ uint8_t lds_raw[];
@@ -844,7 +849,7 @@ struct K2cArgs {
 #endif
 __host__ __device__ inline uint32_t k2c_leafcap(uint32_t n_all, uint32_t shift) { return (n_all >> shift) + 64; }
 __host__ __device__ inline uint32_t k2c_bytes(uint32_t n_all, uint32_t leafcap) { return 12u * ((n_all + 63u) & ~63u) + 12u * ((leafcap + 63u) & ~63u) + 1536u * 4u; }
-__global__ void __launch_bounds__(64) mm_chain_kernel(K2cArgs a)
+__global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_kernel(K2cArgs a)
 {
 	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
 	extern __shared__ uint8_t lds_raw[];
@@ -1527,6 +1532,9 @@ __device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uin
 #endif
 #define K3_TAB_WORDS 1536u
 #define K3_LDS_BYTES ((K3_TAB_WORDS + 16u) * 4u)          /* dynamic LDS of a launch with the rounds in the kernel: the tables of k3_rescue_round + their lock */
+#ifdef MM_K3_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(MM_K3_NUM_VGPR)))
+#endif
 __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Args a)
 {
 	extern __shared__ uint32_t k3_tab[];       /* launched with 4 x 1536 words when the rounds run in the kernel (per wave: tables of k3_rescue_round's sort + chain), else with none:
