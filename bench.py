@@ -128,6 +128,25 @@ def pmc_traffic(wname, world, alg_bytes_per_launch):
     except Exception:
         return None
 
+def valu_position(vectors, wall_s, world):
+    """Where the run sits against the integer-VALU issue limit of the chip (the real bound of mm_extend_kernel): the VALU cycles per DP vector that the SQ
+    counters measured (tools/pmc_sq.sh -> profiles/round2_pmc_sq.json, SQ_ACTIVE_INST_VALU) x the vectors of this run, over SIMDs x clock x wall time."""
+    fn = os.path.join(ROOT, 'profiles', 'round2_pmc_sq.json')
+    try:
+        with open(fn) as f: per = json.load(f)['mm_extend_kernel_per_dp_vector']
+        simds, clock = 256 * 4, 2.4e9          # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz maximum engine clock (MI355X_MICROARCH.md)
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(0); simds = int(pr.multi_processor_count) * 4
+            if getattr(pr, 'clock_rate', 0): clock = float(pr.clock_rate) * 1e3
+        except Exception:
+            pass
+        busy_s = per['valu_busy_cycles_per_dp_vector'] * vectors / world / simds / clock
+        return {'valu_busy_cycles_per_dp_vector': per['valu_busy_cycles_per_dp_vector'], 'simds': simds, 'clock_hz (device maximum)': clock, 'valu_busy_s_per_step_per_gpu': busy_s, 'frac_of_wall': busy_s / wall_s,
+                'note': 'fraction of the step during which the vector ALUs of the chip are issuing mm_extend_kernel instructions, at the maximum clock (the sustained clock is lower, so this is a lower bound)'}
+    except Exception as e:
+        return {'error': repr(e)}
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=2); ap.add_argument('--warmup', type=int, default=1)
@@ -139,6 +158,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU legs (baseline and identity check)')
     ap.add_argument('--keep', action='store_true', help='keep the generated data (prints the directory)')
     args = ap.parse_args()
+    os.environ['MM_LANES'] = str(args.lanes)          # the batch rule of the library (one batch per lane for a small set) sees the lanes this run uses
     rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
     w = dict(WORKLOADS[args.workload]); custom = False
     for k in ('depth', 'genome_len', 'contigs', 'repeat_frac'):
@@ -246,7 +266,8 @@ def main():
                          'alg_bytes_per_launch': alg_bytes / max(1.0, k3_launches), 'avg_launch_ms': k3_launch_ms, 'launches': k3_launches,
                          # launches of different lanes share the chip, so one launch lasts longer than it would alone: the same bytes over the wall time of the timed region
                          'achieved_all_lanes': alg_bytes / dt * 1e-9 / world,
-                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4); achieved = algorithmic bytes per launch / mean launch time, achieved_all_lanes = per GPU over the wall time'},
+                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4); achieved = algorithmic bytes per launch / mean launch time, achieved_all_lanes = per GPU over the wall time',
+                         'valu_issue': valu_position(vec / K, dt / K, world)},
         }
         if (world == 1 or args.check) and not args.no_cpu:
             cpu = reference_runs(w, ref_fa, parts, work, args.check_reads, args.baseline_reads, True)

@@ -30,7 +30,19 @@ for k, cs in res.items():
                'frac_active_valu': g('SQ_ACTIVE_INST_VALU') / wc, 'frac_active_scalar': g('SQ_ACTIVE_INST_SCA') / wc,
                'valu_insts': g('SQ_INSTS_VALU'), 'salu_insts': g('SQ_INSTS_SALU'), 'vmem_rd': g('SQ_INSTS_VMEM_RD'), 'vmem_wr': g('SQ_INSTS_VMEM_WR'), 'lds': g('SQ_INSTS_LDS'), 'smem': g('SQ_INSTS_SMEM'),
                'waves': g('SQ_WAVES'), 'busy_cycles': g('SQ_BUSY_CYCLES'), 'gui_active': g('GRBM_GUI_ACTIVE')}
-json.dump({'command': 'rocprofv3 --kernel-trace --pmc <two passes of SQ counters> --output-format csv -- python bench.py ' + args, 'per_kernel': summ, 'raw': res}, open(out, 'w'), indent=1)
+# the DP vectors of the same run (bench.py's JSON line in the log of the first pass): VALU time per vector, which bench.py turns into the VALU-issue position of the runs it times
+ext = {}
+try:
+    line = [l for l in open('%s/p1.log' % d) if l.startswith('{')][-1]; b = json.loads(line)
+    vec = b['config']['dp_vectors_per_base'] * b['config']['bases_total'] * b['steps']
+    k3 = summ['mm::mm_extend_kernel']
+    ext = {'dp_vectors': vec, 'valu_busy_cycles_per_dp_vector': k3['frac_active_valu'] * k3['wave_cycles_quad'] * 4 / vec, 'scalar_busy_cycles_per_dp_vector': k3['frac_active_scalar'] * k3['wave_cycles_quad'] * 4 / vec,
+           'valu_insts_per_dp_vector': k3['valu_insts'] / vec, 'salu_insts_per_dp_vector': k3['salu_insts'] / vec,
+           'note': 'SQ_ACTIVE_INST_VALU / SQ_ACTIVE_INST_SCA count quad-cycles summed over waves (MI355X_MICROARCH.md); x 4 = SIMD cycles the pipe was held; everything mm_extend_kernel does (fill, traceback, driver) over its DP vectors'}
+except Exception as e:
+    ext = {'error': str(e)}
+json.dump({'command': 'rocprofv3 --kernel-trace --pmc <two passes of SQ counters> --output-format csv -- python bench.py ' + args, 'mm_extend_kernel_per_dp_vector': ext, 'per_kernel': summ, 'raw': res}, open(out, 'w'), indent=1)
+print('mm_extend_kernel per DP vector:', ext)
 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['wave_cycles_quad'])[:6]:
     print(k, {a: (round(b, 3) if isinstance(b, float) and b < 10 else b) for a, b in v.items()})
 PY
