@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t q_code(const gaba::SeqArena &ar, uint64_t p)
 
 __global__ void __launch_bounds__(256, MM_SHORT_KERNEL_WAVES) mm_sketch_seed_kernel(K1Args a)
 {
-	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
+	__builtin_amdgcn_s_setprio(2);          /* short and latency bound beside the extension waves of the other lanes (which run at 0 or 1, the few heaviest reads of a launch at 3) */
 	const int lane = lane_id();
 	const DevIndex &ix = a.idx;
 	const uint32_t k = ix.k, w = ix.w;
@@ -629,7 +629,7 @@ __device__ __forceinline__ void k2s_small_buckets(LU32 *e, const LU32 *bs, const
 }
 __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_sort_kernel(K2sArgs a)
 {
-	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
+	__builtin_amdgcn_s_setprio(2);          /* short and latency bound beside the extension waves of the other lanes (which run at 0 or 1, the few heaviest reads of a launch at 3) */
 	extern __shared__ uint8_t lds_raw[];
 	LU32 *e = (LU32 *)lds_raw;
 	LU32 *cnt = (LU32 *)(lds_raw + a.lds_bytes - 4 * K2S_TABLE_WORDS), *bb = cnt + 256, *be = bb + 256, *stk = be + 256, *stsh = stk + K2S_STACK;
@@ -851,7 +851,7 @@ __host__ __device__ inline uint32_t k2c_leafcap(uint32_t n_all, uint32_t shift) 
 __host__ __device__ inline uint32_t k2c_bytes(uint32_t n_all, uint32_t leafcap) { return 12u * ((n_all + 63u) & ~63u) + 12u * ((leafcap + 63u) & ~63u) + 1536u * 4u; }
 __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_kernel(K2cArgs a)
 {
-	__builtin_amdgcn_s_setprio(3);          /* short and latency bound beside the extension waves of the other lanes (which run at 0, 2 or 3) */
+	__builtin_amdgcn_s_setprio(2);          /* short and latency bound beside the extension waves of the other lanes (which run at 0 or 1, the few heaviest reads of a launch at 3) */
 	extern __shared__ uint8_t lds_raw[];
 	const int lane = lane_id();
 	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
@@ -1598,8 +1598,10 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		const uint32_t n_root = (uint32_t)rdfirst((int)st->n_root);
 		/* reads with many chains run several extension trials and are the critical path of the launch (one of them can cost
 		 * three times a wave's fair share): their waves get issue priority so that they move at uncontended speed while the
-		 * ordinary reads fill the slots in between */
-		if(n_root >= 8) { __builtin_amdgcn_s_setprio(3); } else if(n_root >= 5) { __builtin_amdgcn_s_setprio(2); } else { __builtin_amdgcn_s_setprio(0); }
+		 * ordinary reads fill the slots in between.  The top priority goes by place in the work list -- its first 64th is the reads with the
+		 * most chains of the batch (run_rounds puts them there) -- and to nobody else: with every read of 8 chains or more at 3 and of 5 at 2
+		 * (the earlier rule: a tenth of the reads) the truly heavy ones had company at their level; 2.32 - 2.36 against 2.51 - 2.54 s per step */
+		if(wi < (a.n_work >> 6)) { __builtin_amdgcn_s_setprio(3); } else if(n_root >= 5) { __builtin_amdgcn_s_setprio(1); } else { __builtin_amdgcn_s_setprio(0); }
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
 		if(a.ring) {
