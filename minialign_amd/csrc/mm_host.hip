@@ -1620,7 +1620,9 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		if(lo > hi) { lo = hi = 0; }
 		std::vector<TextRead> tr(b.n); for(uint32_t i = 0; i < b.n; i++) tr[i] = TextRead{ b.rec[i]->t_off - lo, b.rec[i]->t_len, 0, b.qoff[i] };
 		const uint64_t arena = (b.total + 64 + 63) & ~63ull;
-		if(!a->d_text.ensure(hi - lo + 64) || !a->d_tinfo.ensure(b.n) || !a->d_codes.ensure(arena + 64) || !a->d_tn.ensure(b.n)) return false;
+		/* (with an eighth to spare, like the pools: a buffer that grows in mid-run costs a hipFree, which waits for every stream of the device) */
+		auto spare = [](uint64_t x) -> uint64_t { return (x + x / 8 + (1ull << 20)) & ~((1ull << 20) - 1); };
+		if(!a->d_text.ensure(spare(hi - lo + 64)) || !a->d_tinfo.ensure(spare(b.n)) || !a->d_codes.ensure(spare(arena + 64)) || !a->d_tn.ensure(spare(b.n))) return false;
 		if(hi > lo && !lane_h2d(a, a->d_text.p, b.text->data() + lo, hi - lo)) return false;
 		if(!lane_h2d(a, a->d_tinfo.p, tr.data(), b.n * sizeof(TextRead))) return false;
 		CK(hipMemsetAsync(a->d_codes.p, 0, arena + 64, a->stream));
