@@ -336,3 +336,47 @@ def test_option_words_are_walked_as_the_reference_walks_them(tmp_path):
             r = subprocess.run([exe] + ln + ['-d', out, ref], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
             rc.append(r.returncode != 0)
         assert rc[0] == rc[1], (ln, rc)
+
+def test_batches_are_cut_by_bases_lanes_and_the_longest_read(tmp_path):
+    """batch_spans (mm_host.hip) through mm_batch_pack_all, host only: contiguous spans in input order that cover every read once; a set smaller than lanes x 300 Mb
+    is cut into one batch per lane but not below 64 Mi bases; MM_LANES and MM_BATCH_BASES are read at call time"""
+    import mmlib as M
+    ref = str(tmp_path / 'ref.fa'); rd = str(tmp_path / 'rd.fa')
+    M.gensim('genome', 8101, 3000000, 1, 0.0, out=ref); M.gensim('reads', 8102, ref, 24.0, 'pacbio', 'fa', 6000, 2500, out=rd)
+    lens = []
+    for l in open(rd):
+        if l.startswith('>'): lens.append(0)
+        else: lens[-1] += len(l.strip())
+    total = sum(lens); assert 60e6 < total < 4 * (64 << 20)
+    L = ctypes.CDLL(os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so'))
+    L.mm_reads_load.restype = ctypes.c_void_p; L.mm_reads_load.argtypes = [ctypes.c_char_p]
+    L.mm_reads_count.restype = ctypes.c_uint32; L.mm_reads_count.argtypes = [ctypes.c_void_p]
+    L.mm_batch_pack_all.restype = ctypes.c_uint32; L.mm_batch_pack_all.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32]
+    L.mm_batch_reads.restype = ctypes.c_uint32; L.mm_batch_reads.argtypes = [ctypes.c_void_p]
+    L.mm_batch_free.argtypes = [ctypes.c_void_p]; L.mm_reads_free.argtypes = [ctypes.c_void_p]
+    reads = L.mm_reads_load(rd.encode()); assert reads and L.mm_reads_count(reads) == len(lens)
+    def spans(first=0, n=None, **env):
+        old = {k: os.environ.get(k) for k in ('MM_LANES', 'MM_BATCH_BASES')}
+        for k in old: os.environ.pop(k, None)
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            arr = (ctypes.c_void_p * 256)(); nb = L.mm_batch_pack_all(reads, first, len(lens) - first if n is None else n, arr, 256); assert 0 < nb <= 256
+            cnt = [L.mm_batch_reads(arr[k]) for k in range(nb)]
+            for k in range(nb): L.mm_batch_free(arr[k])
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None: os.environ[k] = v
+        out = []; at = first
+        for c in cnt: out.append(sum(lens[at:at + c])); at += c
+        assert at == first + (len(lens) - first if n is None else n)          # every read once, in order
+        return out
+    floor = 64 << 20
+    b4 = spans()                                     # 4 lanes: total / 4 is below the floor of 64 Mi bases
+    assert len(b4) == 2 and b4[0] <= floor < b4[0] + max(lens) and sum(b4) == total
+    assert spans(MM_LANES=1) == [total]              # one lane: one batch
+    small = spans(MM_BATCH_BASES=10000000)
+    assert len(small) >= total // 10000000 and all(x <= 10000000 for x in small) and sum(small) == total
+    part = spans(first=100, n=500, MM_BATCH_BASES=1000000)
+    assert sum(part) == sum(lens[100:600]) and all(x <= 1000000 or x <= max(lens) for x in part)
+    L.mm_reads_free(reads)
