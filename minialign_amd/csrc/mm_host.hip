@@ -1051,7 +1051,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
 		/* several batches in flight (lanes): 5 persistent waves per SIMD keep the integer VALU as busy as 8 do (a wave issues at most every 4th cycle, about two
 		 * thirds of its instructions are VALU) and leave wave slots for the sketch and sort + chain kernels of the other lanes, which otherwise wait for the
-		 * tail of this launch: +4 % on the bench workload with 3 in flight (4.33 against 4.15 G bases/s), -10 % for a launch running alone */
+		 * tail of this launch: +4 % on round 1's bench workload with 3 in flight, -10 % for a launch running alone; 2 / 3 / 4 / 6 measure the same on the headline workload of
+		 * round 2 */
 		else if(a->is_sib || a->sib) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u); }
 		hipStream_t xs = a->stream;
 		if(a->k3s && (a->is_sib || a->sib)) { xs = a->k3s; CK(hipEventRecord(a->k3e, a->stream)); CK(hipStreamWaitEvent(xs, a->k3e, 0)); }      /* (the host waits for the launch below before it queues anything else) */
