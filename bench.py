@@ -154,7 +154,7 @@ def main():
     ap.add_argument('--depth', type=float); ap.add_argument('--genome-len', type=int); ap.add_argument('--contigs', type=int); ap.add_argument('--repeat-frac', type=float)
     ap.add_argument('--lanes', type=int, default=4, help='batches in flight per GPU (lanes of the device context)')
     ap.add_argument('--check', action='store_true', help='verify the records of the first reads against the CPU reference also when N > 1')
-    ap.add_argument('--check-reads', type=int, default=2000); ap.add_argument('--baseline-reads', type=int, default=60000)
+    ap.add_argument('--check-reads', type=int, default=4000); ap.add_argument('--baseline-reads', type=int, default=60000)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU legs (baseline and identity check)')
     ap.add_argument('--keep', action='store_true', help='keep the generated data (prints the directory)')
     args = ap.parse_args()
@@ -165,13 +165,13 @@ def main():
         if getattr(args, k) is not None: w[k] = getattr(args, k); custom = True
     import torch
     dist = None; device = None
-    same_dev = os.environ.get('MM_BENCH_SAME_DEVICE') is not None      # test hook: every rank on device 0 with a gloo group (one-GPU boxes)
+    same_dev = os.environ.get('MM_BENCH_SAME_DEVICE') is not None      # test hook: every rank on device 0 (one-GPU boxes)
     if same_dev: local = 0
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local); device = None if same_dev else torch.device('cuda', local)
-        dist.init_process_group('gloo' if same_dev else 'nccl')
-    tdev = 'cpu' if same_dev else 'cuda'                                # where the few scalars of the reductions live
+        torch.cuda.set_device(local)
+        dist.init_process_group('gloo')                                 # a few integers per step (the carried value, the reductions of the report): no RCCL on this path (north_star)
+    tdev = 'cpu'                                                        # where the few scalars of the reductions live
     from minialign_amd import multi
     lib = os.environ.get('MM_LIB_OVERRIDE') or os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')     # override: kernel experiments only
     if not os.path.exists(lib):
@@ -273,12 +273,9 @@ def main():
             cpu = reference_runs(w, ref_fa, parts, work, args.check_reads, args.baseline_reads, True)
             if world == 1: out['cpu_baseline'] = cpu['cpu_baseline']
             if cpu['check_sam'] is not None:
-                names = set()
-                with open(os.path.join(work, 'check.fa' if cpu['check_kind'].startswith('oracle/_ref') else 'small.fa'), 'rb') as f:
-                    for line in f:
-                        if line.startswith(b'>'): names.add(line[1:].split()[0].rstrip(b'\n'))
-                text = sm.col.text(); cut = multi._head_cut(text, names)
-                ours = text[:cut] if cut is not None else None
+                # the records of the first check_reads reads of the stream: the library recorded where those of read check_reads begin (mm_head_offset)
+                cut = L.mm_head_offset(al, cpu['check_reads']) if not sm._stale else multi.NO_OFFSET
+                ours = sm.col.head(cut) if cut != multi.NO_OFFSET else None
                 out['sam_identical'] = bool(ours is not None and ours == cpu['check_sam'])
                 out['sam_check'] = 'records of the first %d reads (%d bytes) against %s' % (cpu['check_reads'], len(cpu['check_sam']), cpu['check_kind'])
             else:

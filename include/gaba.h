@@ -61,6 +61,7 @@ struct gaba_segment_s {            /* gaba.h:193-200 */
 	uint64_t ppos;
 };
 typedef struct gaba_segment_s gaba_path_section_t;
+#define gaba_plen(seg)                ( (seg)->alen + (seg)->blen )          /* gaba.h:200: path length of a segment */
 
 struct gaba_section_s {            /* gaba.h:131-135; base >= GABA_EOU selects the mirrored (reverse-complement) view */
 	uint32_t id, len;
@@ -69,6 +70,7 @@ struct gaba_section_s {            /* gaba.h:131-135; base >= GABA_EOU selects t
 typedef struct gaba_section_s gaba_section_t;
 #define GABA_EOU                    ( (uint8_t const *)0x800000000000 )
 #define gaba_mirror(base, len)      ( GABA_EOU + (uint64_t)GABA_EOU - (uint64_t)(base) - (uint64_t)(len) )
+#define gaba_rev(pos, len)          ( (len) + (uint64_t)(len) - (uint64_t)(pos) - 1 )          /* gaba.h:155 (deprecated there; kept for callers that still use it) */
 #define gaba_build_section(_id, _base, _len)  ( (struct gaba_section_s){ .id = (_id), .len = (_len), .base = (uint8_t const *)(_base) } )
 
 struct gaba_alignment_s {          /* gaba.h:205-220 */

@@ -94,6 +94,12 @@ mm_reads_t *mm_reads_load(char const *fn);
  * returns the number of differing arena words (0 = identical, -1 = no text / failure) */
 mm_reads_t *mm_reads_load_text(char const *fn);
 int64_t mm_pack_check(mm_align_t *a, mm_reads_t const *r);
+/* the same set packed on the device and brought back: one code byte per base (0..3, 4 = N) read after read into codes, bases per read into lens; returns the number of
+ * reads, -1 on failure.  For checkers with a reader of their own (tests/test_pack_gpu.py compares with the oracle's). */
+int64_t mm_pack_fetch(mm_align_t *a, mm_reads_t const *r, uint8_t *codes, uint64_t cap, uint32_t *lens, uint32_t max_reads);
+/* part `part` of `n_parts` of a read file (one rank's shard of a set): a plain FASTA file is cut by bytes where a '>' starts a line and only that stretch is read;
+ * anything else (gzip, FASTQ, stdin) is read whole and the part keeps its share of the records.  The parts, in order, are the file. */
+mm_reads_t *mm_reads_load_part(char const *fn, uint32_t part, uint32_t n_parts);
 void mm_reads_free(mm_reads_t *r);
 int mm_reads_append(mm_reads_t *r, char const *fn);          /* another file behind the reads already loaded; 0 on success */
 char const *mm_reads_name(mm_reads_t const *r, uint32_t i);
@@ -112,6 +118,8 @@ void mm_batch_free(mm_batch_t *b);
  * its seed array as mm_seed leaves it (minialign.c:3500: sorted, sentinel last; 4 words per seed: upos, rid, vpos, lid = INT32_MAX) and its chain roots as
  * mm_chain leaves them (minialign.c:3702: plen | lid << 32, longest first).  0 on success; the batch can be run normally afterwards. */
 int mm_batch_tap(mm_align_t *a, mm_batch_t *b, uint32_t read, uint32_t *n_min, uint32_t *seeds, uint32_t seeds_cap, uint32_t *n_seeds, uint64_t *roots, uint32_t roots_cap, uint32_t *n_roots);
+/* the minimizer stream words of that read (minialign.c:2402) as K1 computed them; after mm_batch_tap on the same batch.  Returns the count (writes at most cap), -1 on error */
+int64_t mm_batch_tap_sketch(mm_align_t *a, mm_batch_t *b, uint32_t read, uint64_t *words, uint32_t cap);
 int mm_set_device(int dev);
 
 /* the streaming form main_align uses (minialign.c:6413-6436 with the pipeline of mm_align_file, :4725): the batches of a read set go through `lanes` lanes of
@@ -126,7 +134,11 @@ uint32_t mm_batch_pack_all(mm_reads_t const *r, uint32_t first, uint32_t n, mm_b
 /* a read set split over several contexts: what another carried reference length at the start of the stream mapped last would change -- 0 nothing, 1 read
  * *first_affected decides differently (re-map from there), 2 undecided within the recorded head (re-map the part); mm_carry_after(i): the value behind read i */
 int mm_carry_check(mm_align_t const *a, uint32_t truth, uint32_t *first_affected);
-uint32_t mm_carry_after(mm_align_t const *a, uint32_t i);
+uint32_t mm_carry_after(mm_align_t const *a, uint32_t i);          /* UINT32_MAX when read i lies beyond the recorded head (4 096 reads; fewer when a batch had to be split) */
+/* where, in the text the last stream handed to its sink, the records of read i begin (for a stream of n <= 4 096 reads, i = n gives the end of the text); UINT64_MAX
+ * beyond what was recorded.  A caller that replaces the records of reads [i, j) -- the window re-map of minialign_amd/multi.py -- cuts the text at these offsets,
+ * whatever the output format and the read names are. */
+uint64_t mm_head_offset(mm_align_t const *a, uint32_t i);
 int mm_map_packed(mm_align_t *a, mm_batch_t *const *batches, uint32_t n_batches, int lanes, mm_sam_sink_t sink, void *opaque);
 int mm_map_reads(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n, int lanes, mm_sam_sink_t sink, void *opaque);
 

@@ -147,6 +147,7 @@ struct K1Args {
 	uint32_t *counter;
 	unsigned long long *stats;     /* [0] minimizers probed, [1] seeds */
 	const uint32_t *work;          /* read indices to process (n_reads entries) */
+	uint64_t *tap;                 /* stage tap (tests): when set, the stream word of every minimizer (hash << 8 | strand << 7 | position mod w, minialign.c:2402) beside its record */
 };
 
 /* code (0..3, 4 = N) of base p of the read */
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(256, MM_SHORT_KERNEL_WAVES) mm_sketch_seed_ker
 				}
 				uint32_t pos = (uint32_t)((qpos + (k & (uint32_t)-(int32_t)fr)) ^ (uint32_t)-(int32_t)fr);   /* minialign.c:3482 */
 				uint32_t slot_i = n_rec + my;
-				if(slot_i < min_cap) { rec[slot_i] = MinRec{ pos, n > max_occ ? 0u : n, ref }; }
+				if(slot_i < min_cap) { rec[slot_i] = MinRec{ pos, n > max_occ ? 0u : n, ref }; if(a.tap) { a.tap[(uint64_t)(rec - a.min_pool) + slot_i] = hh << 8 | fr << 7 | (uint64_t)(qpos % w); } }
 			}
 			n_rec += (uint32_t)__popcll(em);
 			n_probe += (unsigned long long)__popcll(em);

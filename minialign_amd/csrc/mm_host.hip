@@ -182,15 +182,54 @@ static bool parse_fastq(const char *p, const char *end, const uint8_t *enc, std:
 	}
 	return true;
 }
-bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1, bool keep_qual = false, bool keep_comment = false, std::vector<char> *keep_text = nullptr, int32_t text_id = -1)
+/* part `part` of `n_parts` of a plain FASTA file, cut where a '>' starts a line (such a '>' always starts a record, see parse_fasta_span): only the bytes of the part are
+ * read.  false when the file is not plain FASTA (gzip, FASTQ, stdin: the caller reads it whole and takes its share of the records) or cannot be read */
+static bool read_fasta_part(const char *fn, uint32_t part, uint32_t n_parts, std::vector<char> &data)
 {
-	FILE *fp = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
+	if(strcmp(fn, "-") == 0) return false;
+	FILE *fp = fopen(fn, "rb");
 	if(!fp) return false;
+	bool ok = false;
+	do {
+		uint8_t head[4]; const size_t hn = fread(head, 1, 4, fp);
+		bool fasta = false; for(size_t i = 0; i < hn; i++) { if(head[i] == '>') { fasta = true; break; } if(head[i] == '@' || (i == 0 && head[i] == 0x1f)) break; }
+		if(!fasta || fseek(fp, 0, SEEK_END) != 0) break;
+		const int64_t size = ftell(fp); if(size < 0) break;
+		/* boundary b -> the first line start at or behind it that holds a '>' (0 stays 0, the end stays the end) */
+		auto cut = [&](int64_t b) -> int64_t {
+			if(b <= 0) return 0;
+			if(b >= size) return size;
+			std::vector<char> buf(1 << 20); int64_t at = b - 1;          /* the byte in front decides whether b itself starts a line */
+			while(at < size) {
+				if(fseek(fp, (long)at, SEEK_SET) != 0) return -1;
+				const size_t got = fread(buf.data(), 1, buf.size(), fp); if(got == 0) return -1;
+				for(size_t i = 0; i + 1 < got; i++) if(buf[i] == '\n' && buf[i + 1] == '>') return at + (int64_t)i + 1;
+				at += (int64_t)got - 1;                                    /* the last byte is looked at again as the first of the next piece */
+				if(got < 2) break;
+			}
+			return size;
+		};
+		const int64_t lo = cut(size * (int64_t)part / n_parts), hi = cut(size * (int64_t)(part + 1) / n_parts);
+		if(lo < 0 || hi < 0) break;
+		data.resize((size_t)(hi - lo));
+		if(hi > lo && (fseek(fp, (long)lo, SEEK_SET) != 0 || fread(data.data(), 1, data.size(), fp) != data.size())) break;
+		ok = true;
+	} while(0);
+	fclose(fp);
+	return ok;
+}
+bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1, bool keep_qual = false, bool keep_comment = false, std::vector<char> *keep_text = nullptr, int32_t text_id = -1, uint32_t part = 0, uint32_t n_parts = 1)
+{
+	std::vector<char> data;
+	const bool ranged = n_parts > 1 && read_fasta_part(fn, part, n_parts, data);
+	if(ranged && data.empty()) { if(keep_text) keep_text->clear(); return true; }          /* a part without a record */
+	const size_t out0 = out.size();
+	FILE *fp = ranged ? NULL : (strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb"));
+	if(!fp && !ranged) return false;
 	uint8_t enc[16] = { 0 };
 	enc['A' & 15] = 0; enc['C' & 15] = 1; enc['G' & 15] = 2; enc['T' & 15] = 3; enc['U' & 15] = 3; enc['N' & 15] = 4;
 	/* the whole file in memory first (the reads are kept in memory anyway) */
-	std::vector<char> data;
-	{
+	if(!ranged) {
 		size_t cap = 1 << 22, len = 0; 
 		if(fp != stdin && fseek(fp, 0, SEEK_END) == 0) { long sz = ftell(fp); if(sz > 0) cap = (size_t)sz + 1; rewind(fp); }
 		data.resize(cap);
@@ -198,7 +237,7 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1,
 		while((got = fread(data.data() + len, 1, data.size() - len, fp)) > 0) { len += got; if(len == data.size()) data.resize(data.size() * 2); }
 		data.resize(len);
 	}
-	if(fp != stdin) fclose(fp);
+	if(fp && fp != stdin) fclose(fp);
 	/* gzip input is inflated in memory (the reference reads through gzread, minialign.c:1184-1363: plain and gzip text alike, members back to back) */
 	if(data.size() >= 2 && (uint8_t)data[0] == 0x1f && (uint8_t)data[1] == 0x8b) {
 		std::vector<char> raw; raw.resize(std::max<size_t>(data.size() * 4, 1 << 16));
@@ -248,7 +287,12 @@ bool read_seq_file(const char *fn, std::vector<HSeq> &out, uint32_t min_len = 1,
 		fprintf(stderr, "[minialign_amd] `%s': broken FASTQ record\n", fn); return false;       /* the reference gives up on the run (exit 1) */
 	}
 	/* -L (default 1, minialign.c:2077, 6145): records shorter than the limit are dropped, reference and query side alike */
-	out.erase(std::remove_if(out.begin(), out.end(), [min_len](const HSeq &s) { return s.seq.size() < min_len; }), out.end());
+	out.erase(std::remove_if(out.begin() + out0, out.end(), [min_len](const HSeq &s) { return s.seq.size() < min_len; }), out.end());
+	/* a part of a file that could not be cut by bytes: its share of the records */
+	if(n_parts > 1 && !ranged) {
+		const size_t n = out.size() - out0, lo = n * part / n_parts, hi = n * (part + 1) / n_parts;
+		out.erase(out.begin() + out0 + hi, out.end()); out.erase(out.begin() + out0, out.begin() + out0 + lo);
+	}
 	if(keep_text) { for(HSeq &q : out) { if(q.t_id == -1 && (q.t_len != 0 || q.seq.empty())) q.t_id = text_id; } keep_text->swap(data); }          /* (records of this file only: those of earlier files carry their id already) */
 	return true;
 }
@@ -799,6 +843,7 @@ struct mm_align_s {
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
+	DBuf<uint64_t> tap_words;              /* mm_batch_tap: the minimizer stream words of the batch, parallel to min_pool */
 	DBuf<uint8_t> d_text, d_codes; DBuf<TextRead> d_tinfo; DBuf<uint32_t> d_tn;      /* packing on the device: text range of the batch, per-read extents, code bytes of the arena, bases found per read */
 	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
 	mm_align_s *root = nullptr;            /* the primary context of a lane (NULL on the primary itself) */
@@ -816,6 +861,8 @@ struct mm_align_s {
 	/* the head of the last stream mapped through this context (mm_map_*): what decides whether another carried value at its start changes anything */
 	struct HeadRec { uint32_t apos0, cond0, used, rid_last; };
 	std::vector<HeadRec> head; uint32_t head_carry_in = 0;
+	std::vector<uint64_t> head_off; bool head_off_closed = false;      /* byte offset of the first record of read i in the text of that stream (one more entry = the end, when the stream is shorter than the head) */
+	bool streaming = false;                /* stream_map is running on this context (the shared workspaces cannot be re-sized then) */
 	mm_align_s *sib = nullptr;             /* second lane: own streams and pools, shares index / reference / DP constants (see mm_batch_run) */
 	bool is_sib = false; int dev = 0;
 	mm_stats_t st; double t_wall0;
@@ -874,7 +921,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k1.min_pool = a->min_pool.p; k1.seed_pool = a->seed_pool.p; k1.seed_pool_cap = a->seed_pool.n; k1.seed_top = tops + 0;
 		k1.resc_pool = a->resc_pool.p; k1.resc_pool_cap = a->resc_pool.n; k1.resc_top = tops + 1;
 		k1.root_pool = a->root_pool.p; k1.root_pool_cap = a->root_pool.n; k1.root_top = tops + 2;
-		k1.counter = (uint32_t *)(tops + 16); k1.stats = tops + 8; k1.work = a->d_work.p;
+		k1.counter = (uint32_t *)(tops + 16); k1.stats = tops + 8; k1.work = a->d_work.p; k1.tap = nullptr;
+		if(a->tap_stop) { if(!a->tap_words.ensure(a->min_pool.n)) return false; k1.tap = a->tap_words.p; }
 		uint32_t waves = std::min<uint32_t>(a->n_waves, (uint32_t)((work.size() + 3) & ~3ull));
 		CK(hipEventRecord(a->ev0, a->stream));
 		hipLaunchKernelGGL(mm_sketch_seed_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k1);
@@ -899,8 +947,6 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			 * whatever exceeds 160 KB is sorted in place in HBM by the same code. */
 			static const uint32_t cls_div[] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12 };     /* blocks per CU of each class; 0 = HBM */
 			const int n_cls = (int)(sizeof(cls_div) / sizeof(cls_div[0]));
-			static bool attr_set = false;
-			if(!attr_set) { CK(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
 			K2aArgs ka; ka.st = a->d_st.p; ka.work = a->d_work.p; ka.n_work = (uint32_t)work.size(); ka.seed_pool = a->seed_pool.p; ka.root_pool = a->root_pool.p;
 			ka.prof = tops + 24; ka.twlen = a->twlen; ka.mcoef = a->mcoef; ka.min_score = a->o.min_score; ka.seq_len = a->dix.seq_len; ka.seq_circ = a->dix.seq_circ;
 			CK(hipMemsetAsync(a->d_k2cnt.p, 0, 32 * 4, a->stream));
@@ -909,8 +955,6 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			 * chain launches below then waits for all of them (a read's sort class is not its chain class) */
 			const bool presort = getenv("MM_K2_NO_PRESORT") == NULL && getenv("MM_K2_FORCE_HBM") == NULL;
 			if(presort) {
-				static bool sattr = false;
-				if(!sattr) { CK(hipFuncSetAttribute((const void *)mm_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); sattr = true; }
 				static const uint32_t s_kb[] = { 10, 14, 20, 32, 64, 104 };          /* k2s_bytes(K2S_MAX_N) <= 104 KB */
 				const int n_s = (int)(sizeof(s_kb) / sizeof(s_kb[0]));
 				K2sArgs ks; ks.st = a->d_st.p; ks.work = a->d_work.p; ks.n_work = (uint32_t)work.size(); ks.seed_pool = a->seed_pool.p; ks.prof = tops + 28;
@@ -931,8 +975,6 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(presort) {
 				/* chaining in two launches: the window scans of all seeds at full occupancy (mm_chain_scan_kernel, no LDS), then the sequential sweep on a
 				 * compact LDS image of each read (mm_chain_kernel, size classes by LDS need); what the old kernel is left with are reads too large for these */
-				static bool cattr = false;
-				if(!cattr) { CK(hipFuncSetAttribute((const void *)mm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K2C_MAX_LDS_KB * 1024)); cattr = true; }
 				const uint32_t n_cu = a->n_waves / (4 * MM_K3_WAVES_PER_SIMD);
 				K2pArgs kp; kp.st = a->d_st.p; kp.work = a->d_work.p; kp.n_work = (uint32_t)work.size(); kp.seed_pool = a->seed_pool.p; kp.twlen = a->twlen; kp.counter = a->d_k2cnt.p + 24; kp.prof = tops + 24;
 				hipLaunchKernelGGL(mm_chain_scan_kernel, dim3(std::min<uint32_t>((uint32_t)work.size(), n_cu * 32u)), dim3(64), 0, a->k2s[0], kp);
@@ -1381,6 +1423,7 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 	}
 }
 
+bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen);
 bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_qlen, uint64_t scale)
 {
 	bool ok = true;
@@ -1416,6 +1459,8 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	mm_align_s *P = a->root ? a->root : a;
 	if(P->shared_slabs) {
 		/* the engine sized the shared workspaces for the longest read of the input before the lanes started */
+		/* outside the streaming engine nothing is in flight on the context (the per-call entries after a stream): the workspaces are simply sized again */
+		if(P->slab_max < slab && !P->streaming) { ok &= ensure_shared_slabs(P, max_qlen); }
 		if(P->slab_max < slab) { fprintf(stderr, "[minialign_amd] a read longer than announced (%u bases) does not fit the shared DP workspaces\n", max_qlen); ok = false; }
 		a->k3_waves = lane_waves & ~3u;
 	}
@@ -1504,6 +1549,9 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	double mc = 0, xc = 0; for(int i = 0; i < 16; i++) { if((i & 3) == (i >> 3)) mc += o->p.score_matrix[0]; else xc += o->p.score_matrix[0]; }
 	a->mcoef = mc / 4.0; a->xcoef = xc / 12.0;
 	if(!make_streams(a)) { delete a; return NULL; }
+	/* dynamic LDS limits of the sort / chain kernels: per device, set with every context (lane threads only launch) */
+	if(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess || hipFuncSetAttribute((const void *)mm_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess
+		|| hipFuncSetAttribute((const void *)mm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K2C_MAX_LDS_KB * 1024) != hipSuccess) { fprintf(stderr, "[minialign_amd] mm_align_init: kernel attributes rejected\n"); delete a; return NULL; }
 	/* reference: one arena, per-sequence offsets */
 	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
 	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
@@ -1551,7 +1599,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
-	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
 	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < MM_SIDE) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
@@ -1559,6 +1607,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 }
 extern "C" void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line)
 {
+	if(a->o.format != 0) return;          /* only SAM has a header (minialign.c:5666-5671) */
 	fputs("@HD\tVN:1.0\tSO:unsorted\n", out);
 	for(const HSeq &s : a->mi->seq) fprintf(out, "@SQ\tSN:%s\tLN:%u\n", s.name.c_str(), (uint32_t)s.seq.size());
 	if((a->o.ptags() & 1) && !a->o.rg_line.empty()) fprintf(out, "%s\n", a->o.rg_line.c_str());       /* minialign.c:5111 */
@@ -1813,13 +1862,14 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 }
 /* finish, second half (host only): post-map and the output text of every read.  Reads are independent: host threads take contiguous spans, the pieces are
  * joined in input order (mm_align_drain keeps the same order with its heap, minialign.c:4633-4645).  max_threads = 0: -t, or up to 32. */
-void batch_format(const mm_align_t *a, Batch &b, const Fetched &f, std::vector<std::string> &piece_out, uint32_t max_threads)
+void batch_format(const mm_align_t *a, Batch &b, const Fetched &f, std::vector<std::string> &piece_out, uint32_t max_threads, std::vector<std::vector<uint32_t>> *read_off = nullptr)
 {
 	const uint32_t n_reads = b.n; const std::vector<ReadState> &hst = b.hst;
 	const uint32_t want = max_threads ? max_threads : (a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(std::max<uint32_t>(1, std::thread::hardware_concurrency()), 32));
 	const uint32_t nth = std::max<uint32_t>(1, std::min<uint32_t>(want, std::max<uint32_t>(1, n_reads / 64)));
 	std::vector<std::string> piece(std::move(piece_out)); piece_out.clear();          /* strings handed in keep their capacity */
 	piece.resize(nth); for(auto &x : piece) x.clear();
+	if(read_off) { read_off->assign(nth, std::vector<uint32_t>()); }          /* where the records of each read begin in its piece (the head of a stream: mm_head_offset) */
 	Root *root = f.root; uint64_t *bin = f.bin; const AlnRec *aln = f.aln; const gaba::Segment *seg = f.seg; const uint32_t *path = f.path;
 	/* spans of equal bases (not equal read counts): the text of a read grows with its length */
 	std::vector<uint32_t> cut(nth + 1, n_reads);
@@ -1830,6 +1880,7 @@ void batch_format(const mm_align_t *a, Batch &b, const Fetched &f, std::vector<s
 		uint64_t est = 0; for(uint32_t i = lo; i < hi; i++) est += b.lens[i];
 		out.reserve(est + est / 2 + 4096);
 		for(uint32_t i = lo; i < hi; i++) {
+			if(read_off) { (*read_off)[t].push_back((uint32_t)out.size()); }
 			OutReg reg; const ReadState &rs = hst[i];
 			const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln;
 			if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
@@ -1907,14 +1958,17 @@ extern "C" void mm_align_set_carry(mm_align_t *a, uint32_t rlen) { for(mm_align_
 
 
 /* phase-split entry points over a parsed read set (bench.py times mm_batch_run alone: inputs resident in HBM) */
-static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual = false, bool keep_comment = false, bool keep_text = false);
+static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual = false, bool keep_comment = false, bool keep_text = false, uint32_t part = 0, uint32_t n_parts = 1);
 extern "C" mm_reads_t *mm_reads_load(char const *fn) { return reads_load(fn, 1); }
 extern "C" mm_reads_t *mm_reads_load_text(char const *fn) { return reads_load(fn, 1, false, false, true); }          /* keeps the text of the file: batches cut from it are packed on the device */
-static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual, bool keep_comment, bool keep_text)
+/* part `part` of `n_parts` of a read file (one rank's shard, minialign_amd/multi.py): a plain FASTA file is cut by bytes at record starts and only that stretch is read;
+ * anything else is read whole and the part keeps its share of the records.  The parts in order are the file. */
+extern "C" mm_reads_t *mm_reads_load_part(char const *fn, uint32_t part, uint32_t n_parts) { return (n_parts == 0 || part >= n_parts) ? NULL : reads_load(fn, 1, false, false, false, part, n_parts); }
+static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual, bool keep_comment, bool keep_text, uint32_t part, uint32_t n_parts)
 {
 	mm_reads_t *r = new mm_reads_s();
 	std::shared_ptr<std::vector<char>> tx = keep_text ? std::make_shared<std::vector<char>>() : nullptr;
-	if(!read_seq_file(fn, r->r, min_len, keep_qual, keep_comment, tx.get(), 0)) { delete r; return NULL; }
+	if(!read_seq_file(fn, r->r, min_len, keep_qual, keep_comment, tx.get(), 0, part, n_parts)) { delete r; return NULL; }
 	if(tx) r->text.push_back(tx);
 	for(const HSeq &s : r->r) r->bases += s.seq.size();
 	return r;
@@ -2035,6 +2089,18 @@ extern "C" int mm_batch_tap(mm_align_t *a, mm_batch_t *h, uint32_t read, uint32_
 	}
 	return 0;
 }
+/* ... and the minimizer stream of that read as mm_sketch leaves it (minialign.c:2402: hash << 8 | strand << 7 | index inside the block of w), straight out of K1; call
+ * after mm_batch_tap on the same batch.  Returns the count (at most cap words are written), -1 on error. */
+extern "C" int64_t mm_batch_tap_sketch(mm_align_t *a, mm_batch_t *h, uint32_t read, uint64_t *words, uint32_t cap)
+{
+	mm_align_t *c = h->ctx ? h->ctx : a; Batch &b = h->b;
+	if(read >= b.n || b.hst.size() != b.n || !c->tap_words.p) return -1;
+	const ReadState &rs = b.hst[read];
+	if(rs.min_off + rs.n_min > c->tap_words.n) return -1;
+	const uint32_t n = std::min(rs.n_min, cap);
+	if(n && hipMemcpy(words, c->tap_words.p + rs.min_off, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return rs.n_min;
+}
 extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
 
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = false);
@@ -2082,7 +2148,7 @@ typedef std::function<bool(uint32_t, std::vector<std::string> &)> PieceSink;    
 static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_batch_t *(uint32_t)> &make, const std::function<void(mm_batch_t *)> &release,
 	const PieceSink &sink, int lanes_want)
 {
-	if(n_batches == 0) return 0;
+	if(n_batches == 0) { a->head.clear(); a->head_off.assign(1, 0); a->head_off_closed = false; a->head_carry_in = a->rlen_carry; return 0; }
 	const bool verbose = getenv("MM_VERBOSE") != NULL;
 	const int lanes = (int)std::max<uint32_t>(1, std::min<uint32_t>({ (uint32_t)lanes_want, n_batches, 8u }));
 	std::vector<mm_align_t *> ctx; { mm_align_t *q = a; for(int i = 0; i < lanes && q; i++) { ctx.push_back(q); if(i + 1 < lanes) q = align_lane(q); } }
@@ -2092,12 +2158,14 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 	const uint32_t hw = std::max<uint32_t>(1, std::thread::hardware_concurrency());
 	const uint32_t fmt_total = getenv("MM_HOST_THREADS") ? (uint32_t)std::max(1, atoi(getenv("MM_HOST_THREADS"))) : (a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(hw, 96));
 	const int n_fin = fmt_total >= 8 ? 2 : 1;
-	struct Item { mm_batch_t *h = nullptr; Fetched f; std::vector<std::string> piece; uint32_t k = 0; };
+	struct Item { mm_batch_t *h = nullptr; Fetched f; std::vector<std::string> piece; std::vector<std::vector<uint32_t>> roff; bool split = false; uint32_t k = 0; };
 	std::mutex mu; std::condition_variable cv;
 	uint32_t next_k = 0, verified = 0, next_write = 0, pending = 0; uint32_t carry = a->rlen_carry; int rc = 0;
 	std::vector<Item *> fetched;                       /* waiting for a finisher */
 	std::map<uint32_t, Item *> formatted;              /* waiting for the writer */
 	uint32_t lanes_done = 0, fin_done = 0; bool head_open = true;
+	a->head.clear(); a->head_off.clear(); a->head_off_closed = false; a->head_carry_in = a->rlen_carry; a->streaming = true;
+	uint64_t written = 0;                              /* bytes handed to the sink so far (writer thread only) */
 	const uint32_t max_pending = (uint32_t)lanes + 2;
 	/* an item leaves: its pinned set and its text pieces (emptied, capacity kept) go back to the pools of the context */
 	auto drop_item = [&](Item *it) {
@@ -2140,11 +2208,11 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 				}
 				if(ok && split) {
 					/* the pools cannot hold this batch: its reads in halves on this lane, in order, with the true carried value; the text goes straight to the writer */
-					Item *it = new Item(); it->h = h; it->k = k;
+					Item *it = new Item(); it->h = h; it->k = k; it->split = true;
 					c->rlen_carry = truth; b.scale = 1;
 					ok = map_split(c, b, 0, b.n, it->piece);
 					if(ok) {
-						{ std::lock_guard<std::mutex> lk(mu); carry = c->rlen_carry; verified = k + 1; pending++; formatted[k] = it; if(k == 0) { a->head.clear(); a->head_carry_in = truth; head_open = false; } }
+						{ std::lock_guard<std::mutex> lk(mu); carry = c->rlen_carry; verified = k + 1; pending++; formatted[k] = it; if(k == 0) { a->head.clear(); a->head_carry_in = truth; } head_open = false; }          /* (the reads of a split batch are not recorded: the head ends in front of them) */
 						cv.notify_all();
 					} else { delete it; }
 				}
@@ -2190,7 +2258,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 				it = fetched[best]; fetched.erase(fetched.begin() + best);
 			}
 			double tv = now_ms();
-			batch_format(it->h->ctx, it->h->b, it->f, it->piece, std::max<uint32_t>(1, fmt_total / n_fin));
+			batch_format(it->h->ctx, it->h->b, it->f, it->piece, std::max<uint32_t>(1, fmt_total / n_fin), &it->roff);
 			{ std::lock_guard<std::mutex> lk(a->pool_mu); if(it->f.pin) { a->pin_free.push_back(it->f.pin); it->f.pin = nullptr; } }
 			{ std::lock_guard<std::mutex> lk(mu); it->h->ctx->st.host_sam_ms += now_ms() - tv; formatted[it->k] = it; }
 			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: post-map + text %.1f ms\n", it->k, now_ms() - tv); }
@@ -2210,7 +2278,14 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 				it = f->second; formatted.erase(f);
 			}
 			double tv = now_ms(); size_t nb = 0; for(auto &x : it->piece) nb += x.size();
-			const bool ok = rc == 0 ? sink(it->k, it->piece) : true;
+			/* where the records of the first reads of the stream begin (mm_head_offset): as long as every batch so far came with its per-read offsets */
+			if(!a->head_off_closed) {
+				if(it->split || it->roff.size() != it->piece.size()) { a->head_off_closed = true; }
+				else { uint64_t at = written; for(size_t t = 0; t < it->piece.size() && a->head_off.size() <= 4096; t++) { for(uint32_t o : it->roff[t]) { if(a->head_off.size() > 4096) break; a->head_off.push_back(at + o); } at += it->piece[t].size(); } }
+			}
+			written += nb;
+			bool failed; { std::lock_guard<std::mutex> lk(mu); failed = rc != 0; }
+			const bool ok = !failed ? sink(it->k, it->piece) : true;
 			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: written %.1f MB in %.1f ms\n", it->k, nb * 1e-6, now_ms() - tv); }
 			release(it->h); drop_item(it);
 			{ std::lock_guard<std::mutex> lk(mu); next_write++; pending--; if(!ok) rc = 1; }
@@ -2227,6 +2302,8 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 	for(auto &t : th) t.join();
 	for(Item *it : fetched) { release(it->h); drop_item(it); }
 	if(rc == 0) { for(mm_align_t *q = a; q; q = q->sib) q->rlen_carry = carry; }
+	if(!a->head_off_closed && a->head_off.size() <= 4096) { a->head_off.push_back(written); }          /* a stream shorter than the head: its end */
+	a->streaming = false;
 	return rc;
 }
 static void batch_fill(mm_batch_t *h, mm_reads_t const *r, uint32_t first, uint32_t last)
@@ -2307,6 +2384,32 @@ extern "C" int64_t mm_pack_check(mm_align_t *a, mm_reads_t const *r)
 	delete h;
 	return rc;
 }
+/* test entry: the reads of a set loaded with mm_reads_load_text packed on the device from the text (K0) as one batch, then the arena brought back and unpacked: codes gets
+ * one byte per base (0..3, 4 = N) read after read, lens the number of bases the device found per read.  Returns the number of reads, -1 on failure (no text, codes too small).
+ * Nothing of the host parser's base codes enters: a checker compares with its own reader's (tests/test_pack_gpu.py: the oracle's). */
+extern "C" int64_t mm_pack_fetch(mm_align_t *a, mm_reads_t const *r, uint8_t *codes, uint64_t cap, uint32_t *lens, uint32_t max_reads)
+{
+	if(r->text.empty() || r->r.empty() || r->r.size() > max_reads) return -1;
+	mm_batch_t *h = new mm_batch_s(); batch_fill(h, r, 0, (uint32_t)r->r.size());
+	Batch &b = h->b;
+	batch_pack(b, false);
+	int64_t rc = -1;
+	if(b.text && batch_upload(a, b)) {
+		std::vector<uint32_t> pk((b.total + 64) / 16 + 8), nm((b.total + 64) / 32 + 8), tn(b.n);
+		if(hipMemcpy(pk.data(), a->q_pk.p, ((b.total + 64) / 16) * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(nm.data(), a->q_nm.p, ((b.total + 64) / 32) * 4, hipMemcpyDeviceToHost) == hipSuccess
+			&& hipMemcpy(tn.data(), a->d_tn.p, (size_t)b.n * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+			uint64_t at = 0; rc = b.n;
+			for(uint32_t i = 0; i < b.n && rc >= 0; i++) {
+				lens[i] = tn[i];
+				if(at + tn[i] > cap || tn[i] > b.lens[i]) { rc = -1; break; }          /* (the arena holds what the parser announced: batch_upload has compared the counts) */
+				for(uint32_t j = 0; j < tn[i]; j++) { const uint64_t p = b.qoff[i] + j; codes[at + j] = ((nm[p >> 5] >> (p & 31)) & 1) ? 4 : (uint8_t)((pk[p >> 4] >> (2 * (p & 15))) & 3); }
+				at += tn[i];
+			}
+		}
+	}
+	delete h;
+	return rc;
+}
 /* every batch of reads [first, first + n) packed ahead of time, with the boundaries the streaming entries use; returns the count (at most max are made) */
 extern "C" uint32_t mm_batch_pack_all(mm_reads_t const *r, uint32_t first, uint32_t n, mm_batch_t **out, uint32_t max)
 {
@@ -2336,10 +2439,14 @@ extern "C" int mm_carry_check(mm_align_t const *a, uint32_t truth, uint32_t *fir
 }
 extern "C" uint32_t mm_carry_after(mm_align_t const *a, uint32_t i)
 {
+	if(i >= a->head.size()) return 0xffffffffu;          /* beyond the recorded head: unknown */
 	uint32_t cur = a->head_carry_in;
 	for(size_t j = 0; j <= i && j < a->head.size(); j++) { if(a->head[j].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[a->head[j].rid_last].seq.size(); }
 	return cur;
 }
+/* byte offset, in the text the last stream handed to its sink, of the first record of read i (i = the number of reads of a stream shorter than the recorded
+ * head: the end of the text); UINT64_MAX beyond what was recorded (the first 4 096 reads, fewer when a batch had to be split) */
+extern "C" uint64_t mm_head_offset(mm_align_t const *a, uint32_t i) { return i < a->head_off.size() ? a->head_off[i] : ~0ull; }
 extern "C" int mm_map_packed(mm_align_t *a, mm_batch_t *const *batches, uint32_t n_batches, int lanes, mm_sam_sink_t sink, void *opaque)
 {
 	uint32_t mx = 0; for(uint32_t k = 0; k < n_batches; k++) mx = std::max(mx, batches[k]->b.max_qlen);

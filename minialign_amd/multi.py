@@ -1,14 +1,16 @@
 """One read set over N GPUs: one process per GPU (torch.distributed), reads sharded contiguously, the index replicated into every GPU's HBM, no
-collective on the data path (BASELINE.json north_star).  Output order = rank order, as the reference's drain keeps input order
-(mm_align_drain, minialign.c:4633-4645).
+collective on the data path and no RCCL (BASELINE.json north_star): the process group is gloo and carries three integers per rank.
+Output order = rank order, as the reference's drain keeps input order (mm_align_drain, minialign.c:4633-4645): every rank writes its own records to the
+job's standard output when the rank in front of it has finished writing (a token handed from rank to rank), or -- MM_MULTI_PARTS=prefix -- to a file of its
+own, `prefix.<rank>`, all ranks at once (`cat prefix.*` is the output).  Nothing is funnelled through one process.
 
 The one thing reads share in the reference is `self->rlen` of its thread buffer (minialign.c:3864, DESIGN.md 5: the `apos >= rlen` test of
 mm_search_load_pos reads the length of the reference sequence the *previous* read loaded last).  A shard therefore starts from the value the shard in
 front of it ends with.  Every rank maps its shard right away with a guess for that value, the ranks then exchange what their shards ended with (one tiny
 all_gather), and a rank whose guess was wrong asks the library what the true value changes (mm_carry_check, from the `apos`, the decision and the reference
 of the first reads): almost always nothing; otherwise the head of the shard is mapped again from the first read that decides differently, in a window that
-is doubled until the chain of values meets the old one again (mm_carry_after), and the new records replace the old ones.  A changed end value travels on to
-the next rank in the next sweep; N - 1 sweeps at most, one in practice.
+is doubled until the chain of values meets the old one again (mm_carry_after), and the new records replace the old ones at the byte offsets the library
+recorded for them (mm_head_offset).  A changed end value travels on to the next rank in the next sweep; N - 1 sweeps at most, one in practice.
 
     python -m torch.distributed.run --nproc-per-node N -m minialign_amd.multi [-x preset ...] ref.fa reads.fa > out.sam
 
@@ -17,6 +19,8 @@ import ctypes, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SINK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64)
+NO_OFFSET = 0xffffffffffffffff          # mm_head_offset beyond what was recorded
+NO_CARRY = 0xffffffff                   # mm_carry_after beyond the recorded head
 
 
 def load_library(path=None):
@@ -24,15 +28,17 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise RuntimeError('libminialign_amd.so is not built (run __graft_entry__.build()); there is no CPU fallback')
     L = ctypes.CDLL(path)
-    for f in ('mm_opt_init', 'mm_idx_gen', 'mm_align_init', 'mm_reads_load', 'mm_batch_pack'): getattr(L, f).restype = ctypes.c_void_p
+    for f in ('mm_opt_init', 'mm_idx_gen', 'mm_align_init', 'mm_reads_load', 'mm_reads_load_text', 'mm_batch_pack'): getattr(L, f).restype = ctypes.c_void_p
     L.mm_reads_bases.restype = ctypes.c_uint64; L.mm_reads_name.restype = ctypes.c_char_p
     L.mm_reads_name.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
     L.mm_reads_bases.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
     L.mm_reads_count.argtypes = [ctypes.c_void_p]; L.mm_reads_append.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.mm_reads_load_part.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32]; L.mm_reads_load_part.restype = ctypes.c_void_p
     L.mm_align_get_carry.argtypes = [ctypes.c_void_p]; L.mm_align_get_carry.restype = ctypes.c_uint32
     L.mm_align_set_carry.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_align_set_carry.restype = None
     L.mm_carry_check.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     L.mm_carry_after.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_carry_after.restype = ctypes.c_uint32
+    L.mm_head_offset.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_head_offset.restype = ctypes.c_uint64
     L.mm_map_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, SINK, ctypes.c_void_p]
     L.mm_map_packed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, SINK, ctypes.c_void_p]
     L.mm_batch_pack_all.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]; L.mm_batch_pack_all.restype = ctypes.c_uint32
@@ -49,7 +55,8 @@ def shard_bounds(n_units, rank, world):
 
 
 class Collector:
-    """the sink of the streaming entries: keeps the text (keep = None: all of it; keep = N: the first N bytes only) and counts everything"""
+    """the sink of the streaming entries: keeps the text as the pieces it arrives in (keep = None: all of it; keep = N: pieces until N bytes are held) and
+    counts everything"""
     def __init__(self, keep=None):
         self.keep = keep; self.pieces = []; self.kept = 0; self.total = 0
         self.cb = SINK(self._sink)
@@ -60,19 +67,32 @@ class Collector:
         return 0
     def complete(self): return self.keep is None or self.total == self.kept
     def text(self): return b''.join(self.pieces)
-
-
-def _head_cut(text, names):
-    """byte offset behind the records of the reads named in `names` at the start of `text` (a read's records are consecutive lines that start with its name;
-    a read may have no record at all); None when the text ends inside them"""
-    pos = 0
-    while pos < len(text):
-        tab = text.find(b'\t', pos); eol = text.find(b'\n', pos)
-        if eol < 0: return None
-        q = text[pos:tab if 0 <= tab < eol else eol]
-        if q not in names: return pos
-        pos = eol + 1
-    return None
+    def head(self, n):
+        """the first n bytes of the text (None when fewer were kept)"""
+        if n > self.kept: return None
+        out = []; left = n
+        for p in self.pieces:
+            if left <= 0: break
+            out.append(p[:left]); left -= len(out[-1])
+        return b''.join(out)
+    def splice(self, lo, hi, new_pieces):
+        """bytes [lo, hi) of the kept text replaced by new_pieces; the pieces outside the cut are not copied"""
+        assert 0 <= lo <= hi <= self.kept
+        out = []; at = 0; put = False
+        for p in self.pieces:
+            end = at + len(p)
+            if end <= lo: out.append(p)
+            elif at >= hi:
+                if not put: out.extend(new_pieces); put = True
+                out.append(p)
+            else:
+                if at < lo: out.append(p[:lo - at])
+                if not put: out.extend(new_pieces); put = True
+                if end > hi: out.append(p[hi - at:])
+            at = end
+        if not put: out.extend(new_pieces)
+        d = sum(len(x) for x in new_pieces) - (hi - lo)
+        self.pieces = out; self.kept += d; self.total += d
 
 
 class ShardMapper:
@@ -97,8 +117,6 @@ class ShardMapper:
         self.col, self.carry_out = self._map(self.first, self.n, self.carry_in, self.keep, self.packed); self._stale = False
         return self
 
-    def _name(self, j): return self.L.mm_reads_name(self.reads, self.first + j)
-
     def _settle_local(self, truth):
         """this shard against the true value at its start; returns True if the value at its end changed"""
         if truth == self.carry_in: return False
@@ -109,23 +127,23 @@ class ShardMapper:
         if rc == 0: self.carry_in = truth; return False
         if rc == 1 and self.n > 0:
             # read i0 is the first that decides differently: map a window [i0, i0 + m) again with the true value and splice its records in as soon as the
-            # chain of values behind the window is what it was (then nothing behind it changes); m doubles while it is not
+            # chain of values behind the window is what it was (then nothing behind it changes); m doubles while it is not.  Where the records of a read begin
+            # in the text comes from the library (mm_head_offset, recorded by the writer of the stream), not from reading the text: formats other than SAM
+            # and read names that repeat are cut just as well
             i0 = fa.value; limit = min(self.n, 4096)
             ends = []; m = 64
             while i0 + m <= limit: ends.append(m); m *= 2
-            after = {m: self.L.mm_carry_after(self.al, i0 + m - 1) for m in ends}       # read now: a window run replaces the record these come from
-            text = self.col.text(); names = set(self._name(j) for j in range(i0))
-            cut_lo = _head_cut(text, names) if i0 else 0; done = i0
+            # read now: a window run replaces the stream these come from
+            after = {m: self.L.mm_carry_after(self.al, i0 + m - 1) for m in ends}
+            offs = {m: self.L.mm_head_offset(self.al, i0 + m) for m in ends}
+            cut_lo = self.L.mm_head_offset(self.al, i0)
             for m in ends:
-                names.update(self._name(j) for j in range(done, i0 + m)); done = i0 + m
-                cut_hi = _head_cut(text, names)
-                if cut_lo is None or cut_hi is None: break                            # beyond the text that was kept
+                cut_hi = offs[m]
+                if cut_lo == NO_OFFSET or cut_hi == NO_OFFSET or cut_hi > self.col.kept or after[m] == NO_CARRY: break      # beyond what was recorded / kept
                 col, out = self._map(self.first + i0, m, truth, None); self._stale = True
                 self.stats['remapped_reads'] += m
                 if out == after[m]:
-                    new = col.text()
-                    self.col.pieces = [text[:cut_lo], new, text[cut_hi:]]
-                    self.col.kept += len(new) - (cut_hi - cut_lo); self.col.total += len(new) - (cut_hi - cut_lo)
+                    self.col.splice(cut_lo, cut_hi, col.pieces)
                     self.carry_in = truth
                     return False
         # undecided inside the recorded head, or the window outgrew what can be spliced: the whole shard again with the true value
@@ -156,17 +174,27 @@ class ShardMapper:
         return self
 
 
+def write_in_rank_order(dist, rank, world, fd, chunks):
+    """rank r writes `chunks` to fd once rank r - 1 has finished writing (a one-integer token from rank to rank): the ordered drain of minialign.c:4633-4645
+    across processes, every rank writing its own records"""
+    import torch
+    tok = torch.zeros(1, dtype=torch.int64)
+    if world > 1 and rank > 0: dist.recv(tok, src=rank - 1)
+    for c in chunks:
+        v = memoryview(c)
+        while len(v): v = v[os.write(fd, v):]
+    if world > 1 and rank + 1 < world: dist.send(tok, dst=rank + 1)
+
+
 def main(argv=None):
-    """torchrun entry: every rank maps its shard, rank 0 prints header + all records in rank order"""
-    import torch, torch.distributed as dist
+    """torchrun entry: every rank maps its shard and writes its own records, in rank order (rank 0 writes the header first)"""
+    import torch.distributed as dist
     argv = list(sys.argv[1:] if argv is None else argv)
     # the records go to the process' real standard output; whatever libraries print there meanwhile (gloo announces its connections on stdout) goes to stderr
     sys.stdout.flush(); out_fd = os.dup(1); os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
-    same_dev = os.environ.get('MM_MULTI_SAME_DEVICE') is not None          # test hook: every rank on device 0, gloo group
-    dev = 0 if same_dev else local
-    if world > 1: dist.init_process_group('gloo' if same_dev else 'nccl')
-    if world > 1 and not same_dev: torch.cuda.set_device(dev)
+    dev = 0 if os.environ.get('MM_MULTI_SAME_DEVICE') is not None else local          # test hook: every rank on device 0 (one-GPU boxes)
+    if world > 1: dist.init_process_group('gloo')          # three integers per rank and a token: no RCCL on this path
     L = load_library()
     if L.mm_set_device(dev) != 0: raise RuntimeError('no HIP device %d' % dev)
     o = ctypes.c_void_p(L.mm_opt_init())
@@ -175,24 +203,29 @@ def main(argv=None):
     if L.mm_opt_parse(o, len(args), av, files, 8, ctypes.byref(nf)) != 0 or nf.value != 2: raise SystemExit('usage: minialign_amd.multi [options] ref.fa reads.fa')
     mi = ctypes.c_void_p(L.mm_idx_gen(o, files[0])); al = ctypes.c_void_p(L.mm_align_init(o, mi)) if mi else None
     if not al: raise RuntimeError('index / device context failed')
-    reads = ctypes.c_void_p(L.mm_reads_load(files[1]))
+    # this rank's part of the read file only (a plain FASTA file is cut by bytes at record starts; the parts in rank order are the file)
+    reads = ctypes.c_void_p(L.mm_reads_load_part(files[1], rank, world))
     if not reads: raise RuntimeError('cannot read %r' % files[1])
-    lo, hi = shard_bounds(L.mm_reads_count(reads), rank, world)
-    sm = ShardMapper(L, al, reads, lo, hi - lo, guess=L.mm_idx_max_len(mi)).map()
-    sm.settle(dist if world > 1 else None, rank, world, 0, torch.device('cuda', dev) if (world > 1 and not same_dev) else None)
-    body = sm.col.text()
-    if world > 1:
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(body, parts, dst=0)
-    else: parts = [body]
+    sm = ShardMapper(L, al, reads, 0, L.mm_reads_count(reads), guess=L.mm_idx_max_len(mi)).map()
+    sm.settle(dist if world > 1 else None, rank, world, 0, None)
+    head = []
     if rank == 0:
-        libc = ctypes.CDLL(None); libc.fdopen.restype = ctypes.c_void_p; libc.fclose.argtypes = [ctypes.c_void_p]
-        fp = ctypes.c_void_p(libc.fdopen(os.dup(out_fd), b'w'))
+        r, w = os.pipe()          # the header through the library's own printer
+        libc = ctypes.CDLL(None); libc.fdopen.restype = ctypes.c_void_p; libc.fdopen.argtypes = [ctypes.c_int, ctypes.c_char_p]; libc.fclose.argtypes = [ctypes.c_void_p]
+        import threading
+        got = []; t = threading.Thread(target=lambda: got.append(os.fdopen(r, 'rb').read())); t.start()
+        fp = ctypes.c_void_p(libc.fdopen(w, b'w'))
         L.mm_print_sam_header.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p]
-        L.mm_print_sam_header(al, fp, b' '.join(args)); libc.fclose(fp)
-        with os.fdopen(out_fd, 'wb') as out:
-            for p in parts: out.write(p)
-        sys.stderr.write('[minialign_amd.multi] %d rank(s); carried value: %r\n' % (world, sm.stats))
+        L.mm_print_sam_header(al, fp, b' '.join(args)); libc.fclose(fp); t.join()
+        head = got
+    prefix = os.environ.get('MM_MULTI_PARTS')
+    if prefix:
+        with open('%s.%04d' % (prefix, rank), 'wb') as f:
+            for c in head + sm.col.pieces: f.write(c)
+    else:
+        write_in_rank_order(dist if world > 1 else None, rank, world, out_fd, head + sm.col.pieces)
+    os.close(out_fd)
+    if rank == 0: sys.stderr.write('[minialign_amd.multi] %d rank(s); carried value (rank 0): %r\n' % (world, sm.stats))
     if world > 1: dist.barrier(); dist.destroy_process_group()
 
 

@@ -16,6 +16,7 @@ def test_device_stages_match_the_reference_stage_vectors(s):
     from minialign_amd import multi
     os.environ.setdefault('MM_SLAB_GB', '6')
     L = multi.load_library(); assert L.mm_set_device(0) == 0
+    L.mm_batch_tap_sketch.restype = ctypes.c_int64; L.mm_batch_tap_sketch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
     L.mm_batch_tap.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
     with tempfile.TemporaryDirectory() as d:
         ref, rd = make_inputs(s, d)
@@ -33,6 +34,10 @@ def test_device_stages_match_the_reference_stage_vectors(s):
             n_min = ctypes.c_uint32(0); n_seeds = ctypes.c_uint32(0); n_roots = ctypes.c_uint32(0)
             assert L.mm_batch_tap(al, h, i, ctypes.byref(n_min), seeds.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n_seeds), roots.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n_roots)) == 0
             assert n_min.value == st['sketch_n'], (st['read'], n_min.value, st['sketch_n'])
+            words = np.zeros(n_min.value + 8, dtype=np.uint64)
+            assert L.mm_batch_tap_sketch(al, h, i, words.ctypes.data_as(ctypes.c_void_p), len(words)) == st['sketch_n']
+            assert [int(x) for x in words[:8]] == st['sketch_head'], st['read']
+            assert hashlib.md5(words[:n_min.value].tobytes()).hexdigest() == st['sketch_md5'], st['read']          # K1's minimizer stream, word for word
             assert n_seeds.value == st['seed_n']
             assert hashlib.md5(seeds[:n_seeds.value].tobytes()).hexdigest() == st['seed_md5'], st['read']
             assert [int(x) for x in roots[:n_roots.value]] == st['chain'], st['read']
