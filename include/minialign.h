@@ -101,6 +101,13 @@ int64_t mm_pack_fetch(mm_align_t *a, mm_reads_t const *r, uint8_t *codes, uint64
  * anything else (gzip, FASTQ, stdin) is read whole and the part keeps its share of the records.  The parts, in order, are the file. */
 mm_reads_t *mm_reads_load_part(char const *fn, uint32_t part, uint32_t n_parts);
 void mm_reads_free(mm_reads_t *r);
+/* the records of a file as the DEVICE reader finds them (mm_device.hpp K0r: record scanning; K0: base conversion + packing), nothing mapped: names / comments / qualities
+ * read off the text at the offsets the scan gave, base codes brought back from the packed arena.  *host_scanned = records that went through the host's sequential FASTQ
+ * reader (any FASTQ shape other than four lines per record).  NULL when the file cannot be read or is rejected.  For checkers (tests/test_reader_gpu.py: the oracle's reader). */
+mm_reads_t *mm_reads_scan(mm_align_t *a, char const *fn, int keep_qual, int keep_comment, uint64_t *host_scanned);
+uint32_t mm_reads_codes(mm_reads_t const *r, uint32_t i, uint8_t *out, uint32_t cap);          /* base codes (0..3, 4 = N) of read i; returns its length */
+char const *mm_reads_qual(mm_reads_t const *r, uint32_t i);          /* "" when not kept */
+char const *mm_reads_comment(mm_reads_t const *r, uint32_t i);       /* NULL when the record has none / not kept */
 int mm_reads_append(mm_reads_t *r, char const *fn);          /* another file behind the reads already loaded; 0 on success */
 char const *mm_reads_name(mm_reads_t const *r, uint32_t i);
 uint32_t mm_reads_count(mm_reads_t const *r);
@@ -141,6 +148,11 @@ uint32_t mm_carry_after(mm_align_t const *a, uint32_t i);          /* UINT32_MAX
 uint64_t mm_head_offset(mm_align_t const *a, uint32_t i);
 int mm_map_packed(mm_align_t *a, mm_batch_t *const *batches, uint32_t n_batches, int lanes, mm_sam_sink_t sink, void *opaque);
 int mm_map_reads(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n, int lanes, mm_sam_sink_t sink, void *opaque);
+/* the whole input path on the device: the FASTA / FASTQ text of a read set in host memory (mm_map_text) or a file (mm_map_file: plain files are mapped, gzip / stdin are
+ * read) goes to HBM as it is, records are found there (bseq_read_fasta's scanning, minialign.c:1996-2090), bases converted and packed there, and the batches stream through
+ * the lanes as the reader cuts them; this is what mm_align_file and the command-line program run.  -L, -Q and -T CO of the options apply.  0 on success. */
+int mm_map_text(mm_align_t *a, char const *text, uint64_t len, int lanes, mm_sam_sink_t sink, void *opaque);
+int mm_map_file(mm_align_t *a, char const *fn, int lanes, mm_sam_sink_t sink, void *opaque);
 
 /* timing / work counters of everything run since the last reset */
 typedef struct {

@@ -13,6 +13,12 @@
  */
 #include <hip/hip_runtime.h>
 #include <zlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <deque>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -863,6 +869,7 @@ struct mm_align_s {
 	std::vector<HeadRec> head; uint32_t head_carry_in = 0;
 	std::vector<uint64_t> head_off; bool head_off_closed = false;      /* byte offset of the first record of read i in the text of that stream (one more entry = the end, when the stream is shorter than the head) */
 	bool streaming = false;                /* stream_map is running on this context (the shared workspaces cannot be re-sized then) */
+	struct ChunkPool *chunk_pool = nullptr; /* device buffers of the text reader (primary context) */
 	mm_align_s *sib = nullptr;             /* second lane: own streams and pools, shares index / reference / DP constants (see mm_batch_run) */
 	bool is_sib = false; int dev = 0;
 	mm_stats_t st; double t_wall0;
@@ -1424,6 +1431,8 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 }
 
 bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen);
+/* DP workspace of a wave for reads up to qlen bases (a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors), qlen in steps of 8 k */
+uint64_t slab_bytes_for(uint32_t qlen) { qlen = (qlen + 8191u) & ~8191u; const uint64_t blocks = 2 * ((2ull * qlen + 8192) / 32 + 64); return (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull; }
 bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_qlen, uint64_t scale)
 {
 	bool ok = true;
@@ -1587,6 +1596,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms();
 	return a;
 }
+static void free_chunk_pool(struct ChunkPool *p);
 extern "C" void mm_align_destroy(mm_align_t *a)
 {
 	if(!a) return;
@@ -1601,6 +1611,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
+	free_chunk_pool(a->chunk_pool); a->chunk_pool = nullptr;
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
 	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < MM_SIDE) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
 	delete a;
@@ -1636,8 +1647,32 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
  * carried reference-length state asks for; results stay in HBM), finish (D2H, post-map, SAM text)
  * --------------------------------------------------------------------------------------------- */
 struct mm_reads_s { std::vector<HSeq> r; uint64_t bases = 0; std::vector<std::shared_ptr<std::vector<char>>> text; };          /* text: the files' text when kept (reads then carry where their bases stand in it: the device packs from there) */
+/* ---- the text of an input file in host memory (a mapping of the file, or what stdin / gzip gave) and its records as the device reader finds them ---- */
+struct TextSrc {
+	const char *p = nullptr; uint64_t n = 0; char delim = 0; uint64_t first = 0;      /* delim / first: the record delimiter and where the first record starts (minialign.c:1784-1792) */
+	void *map = nullptr; uint64_t map_len = 0; std::vector<char> own;
+	~TextSrc() { if(map) munmap(map, map_len); }
+};
+struct RRec { uint64_t start, hdr_end, t_off; uint32_t t_len, n_bases; uint64_t q_off; uint32_t q_len; };      /* absolute offsets in the text: delimiter, end of the header line, sequence extent, quality extent */
+struct DevChunk { uint8_t *d = nullptr; uint64_t cap = 0; uint64_t off = 0; uint32_t n = 0; };                  /* a stretch of the text in HBM: text[off, off + n) */
+struct ChunkPool {          /* device buffers for stretches of text, reused while a context lives (a hipFree in mid-run would stall every stream of the device) */
+	std::mutex mu; std::vector<DevChunk *> idle, all;
+	DevChunk *get(uint64_t bytes)
+	{
+		{ std::lock_guard<std::mutex> lk(mu); for(size_t i = 0; i < idle.size(); i++) { if(idle[i]->cap >= bytes) { DevChunk *c = idle[i]; idle.erase(idle.begin() + i); return c; } } }
+		DevChunk *c = new DevChunk(); if(hipMalloc(&c->d, bytes) != hipSuccess) { delete c; return nullptr; } c->cap = bytes;
+		std::lock_guard<std::mutex> lk(mu); all.push_back(c); return c;
+	}
+	void put(DevChunk *c) { std::lock_guard<std::mutex> lk(mu); idle.push_back(c); }
+	~ChunkPool() { for(DevChunk *c : all) { (void)hipFree(c->d); delete c; } }
+};
 struct Batch {
 	uint32_t n = 0; uint64_t total = 0; uint32_t max_qlen = 0;
+	/* reads that stand in a text the device reader scanned: no parsed record, no base codes on the host -- names, bases and qualities are read off the text when a
+	 * record is printed (materialize).  dch: the stretches in HBM that hold the reads (first read, count), until the batch has been packed */
+	std::shared_ptr<TextSrc> tsrc; std::vector<RRec> trec;
+	struct Piece { std::shared_ptr<DevChunk> ch; uint32_t first, n; };
+	std::vector<Piece> dch;
 	std::vector<uint32_t> lens; std::vector<uint64_t> qoff; std::vector<const uint8_t *> seq; std::vector<std::string> names;
 	std::vector<const HSeq *> rec;         /* the parsed records (qualities, comments) when the batch comes from a file; empty for in-memory batches */
 	mm_reg_t **regs = nullptr;             /* when set: one mm_reg_t per read (NULL = unmapped) instead of text (mm_align_batch_regs) */
@@ -1664,7 +1699,41 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		/* unmappable reads are skipped outright (minialign.c:4434) */
 		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
 	}
-	if(b.text) {
+	if(b.tsrc) {
+		/* K0 over reads the device reader found: their text is in HBM already (the stretches the reader scanned), or -- a batch that is uploaded again after its
+		 * pools overflowed -- goes up once more from the host's copy */
+		auto spare = [](uint64_t x) -> uint64_t { return (x + x / 8 + (1ull << 20)) & ~((1ull << 20) - 1); };
+		const uint64_t arena = (b.total + 64 + 63) & ~63ull;
+		if(!a->d_tinfo.ensure(spare(b.n)) || !a->d_codes.ensure(spare(arena + 64)) || !a->d_tn.ensure(spare(b.n))) return false;
+		std::vector<TextRead> tr(b.n);
+		CK(hipMemsetAsync(a->d_codes.p, 0, arena + 64, a->stream));
+		if(!b.dch.empty()) {
+			for(const Batch::Piece &pc : b.dch) for(uint32_t i = pc.first; i < pc.first + pc.n; i++) tr[i] = TextRead{ b.trec[i].t_off - pc.ch->off, b.trec[i].t_len, 0, b.qoff[i] };
+			if(!lane_h2d(a, a->d_tinfo.p, tr.data(), b.n * sizeof(TextRead))) return false;
+			for(const Batch::Piece &pc : b.dch) {
+				if(pc.n == 0) continue;
+				hipLaunchKernelGGL(mm_text_codes_kernel, dim3((pc.n + 3) / 4), dim3(256), 0, a->stream, pc.ch->d, a->d_tinfo.p + pc.first, pc.n, a->d_codes.p, a->d_tn.p + pc.first);
+				CK(hipGetLastError());
+			}
+		} else {
+			uint64_t lo = ~0ull, hi = 0; for(uint32_t i = 0; i < b.n; i++) { lo = std::min<uint64_t>(lo, b.trec[i].t_off); hi = std::max<uint64_t>(hi, b.trec[i].t_off + b.trec[i].t_len); }
+			if(lo > hi) { lo = hi = 0; }
+			for(uint32_t i = 0; i < b.n; i++) tr[i] = TextRead{ b.trec[i].t_off - lo, b.trec[i].t_len, 0, b.qoff[i] };
+			if(!a->d_text.ensure(spare(hi - lo + 64))) return false;
+			if(hi > lo && !lane_h2d(a, a->d_text.p, b.tsrc->p + lo, hi - lo)) return false;
+			if(!lane_h2d(a, a->d_tinfo.p, tr.data(), b.n * sizeof(TextRead))) return false;
+			hipLaunchKernelGGL(mm_text_codes_kernel, dim3((b.n + 3) / 4), dim3(256), 0, a->stream, a->d_text.p, a->d_tinfo.p, b.n, a->d_codes.p, a->d_tn.p);
+			CK(hipGetLastError());
+		}
+		const uint64_t nw = (b.total + 64 + 31) / 32;
+		hipLaunchKernelGGL(mm_codes_pack_kernel, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, a->stream, a->d_codes.p, nw, a->q_pk.p, a->q_nm.p);
+		CK(hipGetLastError());
+		/* the scan and the packing must agree on how many bases a read has */
+		std::vector<uint32_t> tn(b.n); CPY(a, tn.data(), a->d_tn.p, b.n * 4, hipMemcpyDeviceToHost);
+		for(uint32_t i = 0; i < b.n; i++) if(tn[i] != b.lens[i]) { fprintf(stderr, "[minialign_amd] read %u of a batch: %u bases in its text when packed, %u when scanned\n", i, tn[i], b.lens[i]); return false; }
+		b.dch.clear();          /* the stretches go back to the reader's pool */
+	}
+	else if(b.text) {
 		/* K0: the stretch of the file's text that holds the batch goes up as it is; newlines are squeezed out, bases coded and packed on the device */
 		uint64_t lo = ~0ull, hi = 0; for(uint32_t i = 0; i < b.n; i++) { lo = std::min<uint64_t>(lo, b.rec[i]->t_off); hi = std::max<uint64_t>(hi, b.rec[i]->t_off + b.rec[i]->t_len); }
 		if(lo > hi) { lo = hi = 0; }
@@ -1700,6 +1769,7 @@ void batch_pack(Batch &b, bool on_host = true)
 	for(uint32_t i = 0; i < b.n; i++) { b.qoff[i] = b.total; b.total += ((uint64_t)b.lens[i] + 63) & ~63ull; b.max_qlen = std::max(b.max_qlen, b.lens[i]); b.in[i] = ReadIn{ b.qoff[i], b.lens[i], 0 }; }
 	/* the reads of a batch that come from one file whose text was kept are packed on the device, from that text (batch_upload) */
 	b.text.reset();
+	if(b.tsrc) { b.scale = 1; b.packed = true; return; }          /* reads in a scanned text: packed on the device (batch_upload) */
 	if(!on_host && !b.rec.empty() && b.rec.size() == b.n && b.text_src && !getenv("MM_HOST_PACK")) {
 		bool all = true; for(uint32_t i = 0; i < b.n && all; i++) all = b.rec[i]->t_id == b.rec[0]->t_id && b.rec[i]->t_id >= 0 && (size_t)b.rec[i]->t_id < b.text_src->size();
 		if(all && b.n) b.text = (*b.text_src)[b.rec[0]->t_id];
@@ -1860,6 +1930,21 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	a->st.host_post_ms += now_ms() - t0;
 	return true;
 }
+/* a read of a scanned text as the printers want it: name, comment, base codes and qualities read off the text, as bseq_read_fasta leaves them (minialign.c:1996-2090) */
+void materialize(const Batch &b, uint32_t i, HSeq &r, bool keep_qual, bool keep_comment)
+{
+	static const uint8_t enc[16] = { 0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 4, 0 };          /* low nibble: A 1, C 3, T 4, U 5, G 7, N 14 (minialign.c:223-229) */
+	const RRec &q = b.trec[i]; const char *t = b.tsrc->p, *end = t + b.tsrc->n;
+	r.name.clear(); r.comment.clear(); r.has_comment = false; r.qual.clear();
+	parse_header(t + q.start + 1, end, r, keep_comment);
+	r.seq.resize(q.n_bases);
+	{ uint8_t *d = r.seq.data(); const char *p = t + q.t_off, *e = p + q.t_len; uint32_t k = 0; for(; p < e && k < q.n_bases; p++) { if(*p != '\n') d[k++] = enc[*p & 15]; } }
+	if(keep_qual && q.q_len) {
+		/* quality lines: a CR at the end of a line is dropped, lines are joined (minialign.c:2060-2068) */
+		const char *p = t + q.q_off, *e = p + q.q_len;
+		while(p < e) { const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p)); const char *le = nl ? nl : e; size_t kl = (size_t)(le - p); if(kl > 0 && p[kl - 1] == '\r') kl--; r.qual.append(p, kl); p = nl ? nl + 1 : e; }
+	}
+}
 /* finish, second half (host only): post-map and the output text of every read.  Reads are independent: host threads take contiguous spans, the pieces are
  * joined in input order (mm_align_drain keeps the same order with its heap, minialign.c:4633-4645).  max_threads = 0: -t, or up to 32. */
 void batch_format(const mm_align_t *a, Batch &b, const Fetched &f, std::vector<std::string> &piece_out, uint32_t max_threads, std::vector<std::vector<uint32_t>> *read_off = nullptr)
@@ -1879,14 +1964,18 @@ void batch_format(const mm_align_t *a, Batch &b, const Fetched &f, std::vector<s
 		std::string &out = piece[t];
 		uint64_t est = 0; for(uint32_t i = lo; i < hi; i++) est += b.lens[i];
 		out.reserve(est + est / 2 + 4096);
+		HSeq tmp;
 		for(uint32_t i = lo; i < hi; i++) {
 			if(read_off) { (*read_off)[t].push_back((uint32_t)out.size()); }
 			OutReg reg; const ReadState &rs = hst[i];
 			const AlnRec *alns = rs.bin_off != ~0ull ? &aln[rs.aln_off] : aln;
 			if(rs.n_res > 0) post_map(a, rs, &root[rs.root_off], &bin[rs.bin_off], alns, reg);
 			if(b.regs) { b.regs[i] = build_reg(reg, alns, seg, path); continue; }
-			if(a->o.format == 0) sam_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg, path, i < b.rec.size() ? b.rec[i] : nullptr);
-			else alt_record(a, out, b.names[i].c_str(), b.seq[i], b.lens[i], reg, alns, seg, path);
+			const char *qname; const uint8_t *qseq; const HSeq *qrec;
+			if(b.tsrc) { materialize(b, i, tmp, a->o.keep_qual, (a->o.ptags() >> 1) & 1); qname = tmp.name.c_str(); qseq = tmp.seq.data(); qrec = &tmp; }
+			else { qname = b.names[i].c_str(); qseq = b.seq[i]; qrec = i < b.rec.size() ? b.rec[i] : nullptr; }
+			if(a->o.format == 0) sam_record(a, out, qname, qseq, b.lens[i], reg, alns, seg, path, qrec);
+			else alt_record(a, out, qname, qseq, b.lens[i], reg, alns, seg, path);
 		}
 	};
 	std::vector<std::thread> th;
@@ -2104,9 +2193,17 @@ extern "C" int64_t mm_batch_tap_sketch(mm_align_t *a, mm_batch_t *h, uint32_t re
 extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
 
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = false);
+static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const std::function<bool(uint32_t, std::vector<std::string> &)> &sink, int lanes);
+static std::shared_ptr<TextSrc> open_text_once(const char *fn);
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
 	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
+	if(!getenv("MM_HOST_READER") && !getenv("MM_HOST_PACK")) {
+		/* the text of the file goes to the device as it is; records are found there (K0r), bases packed there (K0) */
+		std::shared_ptr<TextSrc> src = open_text_once(reads_fn);
+		if(!src) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
+		return align_text(a, src, [&](uint32_t, std::vector<std::string> &piece) { for(auto &x : piece) { if(fwrite(x.data(), 1, x.size(), out) != x.size()) return false; } return true; }, 0);
+	}
 	mm_reads_t *reads = reads_load(reads_fn, a->o.min_len, a->o.keep_qual, (a->o.ptags() >> 1) & 1, getenv("MM_HOST_PACK") == NULL);
 	if(!reads) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
 	if(verbose) { fprintf(stderr, "[minialign_amd] parse %.1f ms\n", now_ms() - tv); }
@@ -2129,8 +2226,12 @@ extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
  * one after the other on the same lane, down to single reads -- slow, but the run goes on where the reference's would (it just grinds) */
 static bool map_split(mm_align_t *c, const Batch &b, uint32_t lo, uint32_t hi, std::vector<std::string> &pieces)
 {
-	Batch sub;
-	for(uint32_t i = lo; i < hi; i++) { sub.lens.push_back(b.lens[i]); sub.seq.push_back(b.seq[i]); sub.names.push_back(b.names[i]); if(i < b.rec.size()) sub.rec.push_back(b.rec[i]); }
+	Batch sub; std::vector<HSeq> held;          /* (reads of a scanned text are read off the text for this rare path) */
+	if(b.tsrc) { held.resize(hi - lo); for(uint32_t i = lo; i < hi; i++) materialize(b, i, held[i - lo], c->o.keep_qual, (c->o.ptags() >> 1) & 1); }
+	for(uint32_t i = lo; i < hi; i++) {
+		if(b.tsrc) { const HSeq &q = held[i - lo]; sub.lens.push_back((uint32_t)q.seq.size()); sub.seq.push_back(q.seq.data()); sub.names.push_back(q.name); sub.rec.push_back(&q); }
+		else { sub.lens.push_back(b.lens[i]); sub.seq.push_back(b.seq[i]); sub.names.push_back(b.names[i]); if(i < b.rec.size()) sub.rec.push_back(b.rec[i]); }
+	}
 	const uint32_t carry_in = c->rlen_carry;
 	const bool pretend = getenv("MM_TEST_SPLIT") && hi - lo >= 8;          /* test hook: as if nothing of 8 reads or more fitted */
 	if(!pretend && batch_prepare(c, sub) && batch_run(c, sub)) {
@@ -2139,12 +2240,273 @@ static bool map_split(mm_align_t *c, const Batch &b, uint32_t lo, uint32_t hi, s
 		for(auto &x : part) pieces.emplace_back(std::move(x));
 		return true;
 	}
-	if(hi - lo < 2) { fprintf(stderr, "[minialign_amd] read `%s' does not fit the device pools\n", b.names[lo].c_str()); return false; }
+	if(hi - lo < 2) { fprintf(stderr, "[minialign_amd] read `%s' does not fit the device pools\n", sub.names.empty() ? "?" : sub.names[0].c_str()); return false; }
 	c->rlen_carry = carry_in;
 	const uint32_t mid = lo + (hi - lo) / 2;
 	return map_split(c, b, lo, mid, pieces) && map_split(c, b, mid, hi, pieces);
 }
+
+/* =============================================================================================
+ * the reader: the text of a query file -> records -> batches, with the record scanning on the device (K0r, mm_device.hpp).
+ * The host maps the file (or holds what stdin / gzip gave) and brings its bytes to HBM in stretches of 256 MB through pinned staging buffers; a stretch starts
+ * where a record starts and is scanned by the kernels, which leave a table of records (delimiter, end of the header line, sequence extent, number of bases);
+ * the last, possibly incomplete record of a stretch opens the next one.  The stretches stay in HBM until the batches cut from them have been packed (K0 reads
+ * the bases from there), and no base of a read is touched by the host until its record is printed.  FASTQ in any shape other than four lines per record is
+ * scanned by the host's sequential reader (host_find_fastq): that grammar -- the number of quality lines depends on the number of bases -- is sequential.
+ * ============================================================================================= */
+static void free_chunk_pool(struct ChunkPool *p) { delete p; }
+namespace {
+/* text of a file: a read-only mapping of a plain file (page cache, nothing copied), or memory for stdin and gzip input */
+std::shared_ptr<TextSrc> open_text(const char *fn)
+{
+	auto t = std::make_shared<TextSrc>();
+	bool mapped = false;
+	if(strcmp(fn, "-") != 0) {
+		const int fd = open(fn, O_RDONLY);
+		if(fd < 0) return nullptr;
+		struct stat sb; uint8_t mg[2] = { 0, 0 };
+		if(fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(fd, mg, 2, 0) == 2 && !(mg[0] == 0x1f && mg[1] == 0x8b)) {
+			void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+			if(m != MAP_FAILED) { (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL); t->map = m; t->map_len = (uint64_t)sb.st_size; t->p = (const char *)m; t->n = (uint64_t)sb.st_size; mapped = true; }
+		}
+		close(fd);
+	}
+	if(!mapped) {
+		FILE *fp = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
+		if(!fp) return nullptr;
+		std::vector<char> data(1 << 22); size_t len = 0, got;
+		while((got = fread(data.data() + len, 1, data.size() - len, fp)) > 0) { len += got; if(len == data.size()) data.resize(data.size() * 2); }
+		data.resize(len);
+		if(fp != stdin) fclose(fp);
+		if(data.size() >= 2 && (uint8_t)data[0] == 0x1f && (uint8_t)data[1] == 0x8b) {          /* gzip members back to back (the reference reads through gzread) */
+			std::vector<char> raw(std::max<size_t>(data.size() * 4, 1 << 16));
+			z_stream zs; memset(&zs, 0, sizeof(zs));
+			if(inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return nullptr;
+			zs.next_in = (Bytef *)data.data(); size_t in_left = data.size(), out_len = 0; bool ok = true;
+			while(ok) {
+				zs.avail_in = (uInt)std::min<size_t>(in_left, 1u << 30); const size_t in_before = zs.avail_in;
+				if(raw.size() - out_len < (1u << 16)) raw.resize(raw.size() * 2);
+				zs.next_out = (Bytef *)raw.data() + out_len; zs.avail_out = (uInt)std::min<size_t>(raw.size() - out_len, 1u << 30); const size_t out_before = zs.avail_out;
+				const int rc = inflate(&zs, Z_NO_FLUSH);
+				in_left -= in_before - zs.avail_in; out_len += out_before - zs.avail_out;
+				if(rc == Z_STREAM_END) { if(in_left < 2 || (uint8_t)zs.next_in[0] != 0x1f || (uint8_t)zs.next_in[1] != 0x8b) break; if(inflateReset(&zs) != Z_OK) ok = false; }
+				else if(rc != Z_OK && !(rc == Z_BUF_ERROR && zs.avail_out == 0)) ok = false;
+				else if(in_left == 0 && zs.avail_out != 0) ok = false;
+			}
+			inflateEnd(&zs);
+			if(!ok) { fprintf(stderr, "[minialign_amd] broken gzip stream in `%s'\n", fn); return nullptr; }
+			raw.resize(out_len); data.swap(raw);
+		}
+		t->own.swap(data); t->p = t->own.data(); t->n = t->own.size();
+	}
+	/* the file type is the first '>' or '@' among the first four bytes; what stands in front of it is dropped (minialign.c:1784-1792) */
+	for(int i = 0; i < 4 && t->first < t->n; i++) { if(t->p[t->first] == '>' || t->p[t->first] == '@') { t->delim = t->p[t->first]; break; } t->first++; }
+	if(!t->delim) { fprintf(stderr, "[minialign_amd] `%s' is neither FASTA nor FASTQ\n", fn); return nullptr; }
+	return t;
+}
+/* FASTQ records of text[0, n) one after the other, as parse_fastq reads them, offsets only (relative to t).  A record the text ends in (last == false: the next
+ * stretch brings the rest) is left out and *consumed stops in front of it.  false when a record does not start with '@' where one must (the reference gives up). */
+bool host_find_fastq(const char *t, uint64_t n, bool last, bool keep_qual, std::vector<RRec> &out, uint64_t &consumed)
+{
+	const char *p = t, *end = t + n;
+	consumed = 0;
+	while(p < end) {
+		const char *rs = p;
+		if(*p++ != '@') return false;
+		RRec r; memset(&r, 0, sizeof(r)); r.start = (uint64_t)(rs - t);
+		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+		if(!nl) { if(!last) break; r.hdr_end = n; r.t_off = n; out.push_back(r); p = end; consumed = n; break; }
+		r.hdr_end = (uint64_t)(nl - t); p = nl + 1;
+		r.t_off = (uint64_t)(p - t); const char *t_end = p; uint64_t nb = 0; bool at = false;
+		while(p < end) {
+			nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
+			const char *dl = (const char *)memchr(p, '+', (size_t)(le - p)); const char *stop = dl ? dl : le;
+			if(stop > p) { nb += (uint64_t)(stop - p); t_end = stop; }
+			if(dl) { at = true; p = dl; break; }
+			p = nl ? nl + 1 : end;
+		}
+		r.t_len = (uint32_t)((uint64_t)(t_end - t) - r.t_off); r.n_bases = (uint32_t)nb;
+		if(!at) { if(!last) break; out.push_back(r); consumed = n; p = end; break; }
+		nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+		if(!nl && !last) break;
+		p = nl ? nl + 1 : end;
+		r.q_off = (uint64_t)(p - t); uint64_t acc = 0;
+		while(p < end) {
+			nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end; size_t ll = (size_t)(le - p);
+			if(keep_qual) { if(ll > 0 && p[ll - 1] == '\r') ll--; }
+			acc += ll; p = le;
+			if(p >= end || acc >= nb) break;
+			p++;
+		}
+		r.q_len = (uint32_t)((uint64_t)(p - t) - r.q_off);
+		if(!last && p >= end) break;          /* the quality line may go on in the next stretch */
+		out.push_back(r);
+		while(p < end && *p == '\n') p++;
+		consumed = (uint64_t)(p - t);
+	}
+	return true;
+}
+struct TextReader {
+	mm_align_t *a; std::shared_ptr<TextSrc> src; uint32_t min_len; bool keep_qual; int lanes;
+	uint64_t chunk_bytes = 256ull << 20;
+	hipStream_t st = nullptr; void *pin[2] = { nullptr, nullptr }; size_t pin_cap = 0; hipEvent_t pev[2] = { nullptr, nullptr };
+	DBuf<uint64_t> d_ma, d_mb; DBuf<uint32_t> d_blk, d_pos, d_cum, d_flag; DBuf<TextRec> d_rec;
+	/* batches cut so far, in order; lanes take them by number */
+	std::mutex mu; std::condition_variable cv; std::deque<mm_batch_t *> ready; uint32_t first_k = 0; bool done = false, failed = false, stop = false;
+	uint64_t max_bases = 300000000ull; uint32_t longest = 0;
+	std::thread th;
+	mm_batch_t *cur = nullptr; uint64_t cur_bases = 0;
+	uint64_t n_records = 0, n_host_scanned = 0, n_stretches = 0; double t_io = 0, t_scan = 0;
+
+	~TextReader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if(th.joinable()) th.join(); for(mm_batch_t *h : ready) delete h; delete cur;
+		if(st) (void)hipStreamDestroy(st); for(int i = 0; i < 2; i++) { if(pin[i]) (void)hipHostFree(pin[i]); if(pev[i]) (void)hipEventDestroy(pev[i]); }
+		d_ma.release(); d_mb.release(); d_blk.release(); d_pos.release(); d_cum.release(); d_flag.release(); d_rec.release(); }
+	void push_batch()
+	{
+		if(!cur) return;
+		mm_batch_t *h = cur; cur = nullptr; cur_bases = 0;
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [&]() { return stop || ready.size() < (size_t)lanes + 2; });          /* not further ahead of the lanes than this */
+		if(stop) { delete h; return; }
+		ready.push_back(h); lk.unlock(); cv.notify_all();
+	}
+	void add(const RRec &r, const std::shared_ptr<DevChunk> &ch)
+	{
+		if(r.n_bases < min_len) return;          /* -L (minialign.c:2077) */
+		if(r.n_bases > longest) { longest = r.n_bases; if(!getenv("MM_BATCH_BASES")) max_bases = std::min<uint64_t>(1000000000ull, std::max<uint64_t>(max_bases, (uint64_t)longest * 2500)); }
+		if(cur && (cur->b.lens.size() >= (1u << 17) || (cur_bases && cur_bases + r.n_bases > max_bases))) push_batch();
+		if(!cur) { cur = new mm_batch_s(); cur->b.tsrc = src; }
+		Batch &b = cur->b;
+		if(b.dch.empty() || b.dch.back().ch != ch) b.dch.push_back(Batch::Piece{ ch, (uint32_t)b.lens.size(), 0 });
+		b.dch.back().n++; b.lens.push_back(r.n_bases); b.trec.push_back(r); cur_bases += r.n_bases;
+	}
+	bool scan_stretch(uint64_t at, uint64_t len, bool last, DevChunk *c, std::vector<RRec> &recs, uint64_t &consumed, bool &grow)
+	{
+		const bool fastq = src->delim == '@'; grow = false; consumed = 0;
+		const double t0 = now_ms();
+		/* host text -> pinned staging (a few host threads) -> HBM, 32 MB at a time on the reader's stream */
+		const size_t piece = 32u << 20;
+		for(uint64_t o = 0, k = 0; o < len; o += piece, k++) {
+			const size_t nb = (size_t)std::min<uint64_t>(piece, len - o); const int pi = (int)(k & 1);
+			CK(hipEventSynchronize(pev[pi]));
+			const char *sp = src->p + at + o; char *dp = (char *)pin[pi];
+			host_parallel(8, [&](uint32_t t, uint32_t nth) { const size_t lo = nb * t / nth, hi = nb * (t + 1) / nth; memcpy(dp + lo, sp + lo, hi - lo); }, 8);
+			CK(hipMemcpyAsync(c->d + o, pin[pi], nb, hipMemcpyHostToDevice, st));
+			CK(hipEventRecord(pev[pi], st));
+		}
+		const uint32_t n = (uint32_t)len, n_words = (n + 63) / 64, n_blk = (n_words + 255) / 256;
+		const uint32_t pos_cap = n / 8 + 1024;
+		if(!d_ma.ensure(n_words) || !d_mb.ensure(n_words) || !d_cum.ensure(n_words) || !d_blk.ensure(2 * (uint64_t)n_blk + 2) || !d_pos.ensure(pos_cap) || !d_flag.ensure(4)) return false;
+		ScanArgs sa; memset(&sa, 0, sizeof(sa));
+		sa.text = c->d; sa.n = n; sa.fastq = fastq ? 1u : 0u; sa.ma = d_ma.p; sa.mb = d_mb.p; sa.blk = d_blk.p; sa.n_blk = n_blk; sa.pos = d_pos.p; sa.pos_cap = pos_cap; sa.cum = d_cum.p;
+		sa.last = last ? 1u : 0u; sa.keep_qual = keep_qual ? 1u : 0u; sa.flag = d_flag.p;
+		CK(hipMemsetAsync(d_flag.p, 0, 16, st));
+		if(fastq) { CK(hipMemsetAsync(d_pos.p, 0, 4, st)); }          /* the first line starts at 0 */
+		hipLaunchKernelGGL(mm_text_marks_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
+		hipLaunchKernelGGL(mm_text_blocks_kernel, dim3(1), dim3(1024), 0, st, sa); CK(hipGetLastError());
+		hipLaunchKernelGGL(mm_text_emit_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
+		uint32_t tot[2], flag[4];
+		CK(hipMemcpyAsync(tot, d_blk.p + 2 * (uint64_t)n_blk, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(flag, d_flag.p, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+		t_io += now_ms() - t0; const double t1 = now_ms();
+		const char *tx = src->p + at;
+		bool on_host = fastq && (flag[1] != 0 || getenv("MM_HOST_SCAN") != NULL);
+		uint32_t n_rec = 0;
+		if(!fastq) {
+			if(flag[1]) { fprintf(stderr, "[minialign_amd] reader: more record starts than one per 8 bytes in a stretch of `%c' records\n", src->delim); return false; }
+			const uint32_t n_starts = tot[1];
+			n_rec = last ? n_starts : (n_starts ? n_starts - 1 : 0);
+			if(!last && n_rec == 0) { grow = true; return true; }
+			if(!last) { uint32_t q = 0; CK(hipMemcpyAsync(&q, d_pos.p + (n_starts - 1), 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); consumed = q; } else consumed = len;
+		} else if(!on_host) {
+			/* complete lines; at the end of the text a last line without '\n' counts, and lines left over behind the last record must be empty (the reference skips them) */
+			uint64_t lines = tot[0] + ((last && len > 0 && tx[len - 1] != '\n') ? 1u : 0u);
+			n_rec = (uint32_t)(lines / 4);
+			if(!last && n_rec == 0) { grow = true; return true; }
+			if(!last) { uint32_t q = 0; CK(hipMemcpyAsync(&q, d_pos.p + 4 * (uint64_t)n_rec, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); consumed = q; }
+			else {
+				consumed = len;
+				if(lines % 4) { std::vector<uint32_t> ls(lines % 4 + 1, (uint32_t)len); CK(hipMemcpyAsync(ls.data(), d_pos.p + 4 * (uint64_t)n_rec, (lines % 4) * 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+					for(uint32_t q = ls[0]; q < len; q++) if(tx[q] != '\n') { on_host = true; break; } }
+			}
+		}
+		if(!on_host && n_rec) {
+			if(!d_rec.ensure(n_rec)) return false;
+			sa.rec = d_rec.p; sa.n_rec = n_rec;
+			if(fastq) hipLaunchKernelGGL(mm_text_fastq_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, st, sa); else hipLaunchKernelGGL(mm_text_fasta_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, st, sa);
+			CK(hipGetLastError());
+			std::vector<TextRec> tr(n_rec);
+			CK(hipMemcpyAsync(tr.data(), d_rec.p, (size_t)n_rec * sizeof(TextRec), hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(flag, d_flag.p, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+			if(fastq && flag[0]) on_host = true;
+			else { recs.resize(n_rec); for(uint32_t i = 0; i < n_rec; i++) { const TextRec &q = tr[i]; recs[i] = RRec{ at + q.start, at + q.hdr_end, at + q.t_off, q.t_len, q.n_bases, at + q.q_off, q.q_len }; } }
+		}
+		if(on_host) {
+			/* a FASTQ stretch in another shape than four lines per record: the sequential reader, over the host's copy of the same bytes */
+			recs.clear(); uint64_t used = 0;
+			if(!host_find_fastq(tx, len, last, keep_qual, recs, used)) { fprintf(stderr, "[minialign_amd] broken FASTQ record\n"); return false; }          /* the reference gives up on the run (exit 1) */
+			if(!last && recs.empty()) { grow = true; return true; }
+			for(RRec &q : recs) { q.start += at; q.hdr_end += at; q.t_off += at; q.q_off += at; }
+			consumed = last ? len : used; n_host_scanned += recs.size();
+		}
+		t_scan += now_ms() - t1;
+		return true;
+	}
+	void run()
+	{
+		bool ok = hipSetDevice(a->dev) == hipSuccess;
+		ChunkPool *pool = a->chunk_pool;
+		uint64_t at = src->first, want = chunk_bytes;
+		while(ok && at < src->n) {
+			{ std::lock_guard<std::mutex> lk(mu); if(stop) break; }
+			const uint64_t len = std::min<uint64_t>(want, src->n - at); const bool last = at + len == src->n;
+			if(len > 0x7fff0000ull) { fprintf(stderr, "[minialign_amd] reader: a record of more than 2 GB\n"); ok = false; break; }
+			DevChunk *c = pool->get(std::max<uint64_t>(chunk_bytes, (len + 63) & ~63ull) + 64);
+			if(!c) { ok = false; break; }
+			c->off = at; c->n = (uint32_t)len;
+			std::shared_ptr<DevChunk> ch(c, [pool](DevChunk *q) { pool->put(q); });
+			std::vector<RRec> recs; uint64_t consumed = 0; bool grow = false;
+			if(!scan_stretch(at, len, last, c, recs, consumed, grow)) { ok = false; break; }
+			if(grow) { want *= 2; continue; }          /* a record longer than the stretch */
+			n_stretches++; n_records += recs.size();
+			for(const RRec &r : recs) add(r, ch);
+			at += consumed; want = chunk_bytes;
+			if(consumed == 0) { ok = false; break; }
+		}
+		if(ok) push_batch();
+		{ std::lock_guard<std::mutex> lk(mu); done = true; failed = !ok; }
+		cv.notify_all();
+		if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd] reader: %lu records in %lu stretches (%lu through the host's sequential FASTQ reader), text to HBM + marks %.1f ms, record tables %.1f ms\n",
+			(unsigned long)n_records, (unsigned long)n_stretches, (unsigned long)n_host_scanned, t_io, t_scan);
+	}
+	bool start()
+	{
+		if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
+		if(const char *e = getenv("MM_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) & ~63ull;          /* test hook: small stretches */
+		pin_cap = 32u << 20;
+		if(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+		for(int i = 0; i < 2; i++) { if(hipHostMalloc(&pin[i], pin_cap, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&pev[i], hipEventDisableTiming) != hipSuccess) return false; }
+		/* batch size as batch_spans: 300 Mb; a text smaller than lanes x that is cut into one batch per lane (its bases are a little fewer than its bytes) */
+		if(getenv("MM_BATCH_BASES")) max_bases = (uint64_t)atoll(getenv("MM_BATCH_BASES"));
+		else if(src->n < (uint64_t)lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, src->n / (uint64_t)lanes + (1ull << 20));
+		th = std::thread([this]() { run(); });
+		return true;
+	}
+	/* batch k (lanes ask in order); NULL when the text has no batch k, *err when the reader failed */
+	mm_batch_t *take(uint32_t k, bool *err)
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [&]() { return done || first_k + ready.size() > k; });
+		if(first_k + ready.size() <= k) { if(failed && err) *err = true; return nullptr; }
+		/* lanes take batches strictly in order of k */
+		mm_batch_t *h = ready.front(); ready.pop_front(); first_k++;
+		lk.unlock(); cv.notify_all();
+		batch_pack(h->b, false);
+		return h;
+	}
+};
+} /* anonymous */
 typedef std::function<bool(uint32_t, std::vector<std::string> &)> PieceSink;          /* (batch, pieces) in batch order; false = stop */
+/* n_batches = MM_OPEN_ENDED: as many as make() gives (it returns NULL behind the last one; lanes ask strictly in order of k) */
+#define MM_OPEN_ENDED 0xffffffffu
 static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_batch_t *(uint32_t)> &make, const std::function<void(mm_batch_t *)> &release,
 	const PieceSink &sink, int lanes_want)
 {
@@ -2161,6 +2523,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 	struct Item { mm_batch_t *h = nullptr; Fetched f; std::vector<std::string> piece; std::vector<std::vector<uint32_t>> roff; bool split = false; uint32_t k = 0; };
 	std::mutex mu; std::condition_variable cv;
 	uint32_t next_k = 0, verified = 0, next_write = 0, pending = 0; uint32_t carry = a->rlen_carry; int rc = 0;
+	const bool open_ended = n_batches == MM_OPEN_ENDED; std::mutex claim_mu; uint32_t active = 0;      /* active: lanes between taking a batch and the end of its D2H */
 	std::vector<Item *> fetched;                       /* waiting for a finisher */
 	std::map<uint32_t, Item *> formatted;              /* waiting for the writer */
 	uint32_t lanes_done = 0, fin_done = 0; bool head_open = true;
@@ -2179,9 +2542,26 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 		if(hipSetDevice(a->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); rc = 1; lanes_done++; cv.notify_all(); return; }
 		while(true) {
 			uint32_t k, guess;
-			{ std::lock_guard<std::mutex> lk(mu); if(rc || next_k >= n_batches) break; k = next_k++; guess = carry; }
 			double tv = now_ms();
-			mm_batch_t *h = make(k);
+			mm_batch_t *h = nullptr;
+			{
+				/* batches are taken one lane at a time, in order: an open-ended source hands them out as its reader cuts them, and a batch with a longer read than the
+				 * shared DP workspaces were sized for has them sized again before any later batch starts -- once the batches in front of it have left the device */
+				std::lock_guard<std::mutex> cl(claim_mu);
+				{ std::lock_guard<std::mutex> lk(mu); if(rc || next_k >= n_batches) break; k = next_k++; }
+				tv = now_ms();
+				h = make(k);
+				if(!h && open_ended) { std::lock_guard<std::mutex> lk(mu); n_batches = std::min(n_batches, k); cv.notify_all(); break; }
+				if(h && a->shared_slabs && slab_bytes_for(std::max(h->b.max_qlen, a->qlen_hint)) > a->slab_max) {
+					std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return active == 0 || rc != 0; });
+					const uint32_t want = h->b.max_qlen;
+					if(rc == 0 && !ensure_shared_slabs(a, want)) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); rc = 1; }
+					for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, want);
+					if(verbose) fprintf(stderr, "[minialign_amd] batch %u: a read of %u bases, DP workspaces sized again\n", k, h->b.max_qlen);
+				}
+				std::lock_guard<std::mutex> lk(mu); active++; guess = carry;
+			}
+			struct Leave { std::mutex &m; std::condition_variable &c; uint32_t &n; bool armed = true; void now() { if(armed) { { std::lock_guard<std::mutex> lk(m); n--; } c.notify_all(); armed = false; } } ~Leave() { now(); } } leave{ mu, cv, active };
 			bool ok = h != nullptr;
 			if(ok) {
 				h->ctx = c; Batch &b = h->b;
@@ -2236,6 +2616,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 					{ std::lock_guard<std::mutex> lk(a->pool_mu); if(!a->pin_free.empty()) { it->f.pin = a->pin_free.back(); a->pin_free.pop_back(); } if(!a->piece_free.empty()) { it->piece = std::move(a->piece_free.back()); a->piece_free.pop_back(); } }
 					if(!it->f.pin) it->f.pin = new mm_align_s::PinSet();
 					ok = batch_fetch(c, b, it->f);
+					leave.now();
 					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): D2H %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); }
 					if(ok) { std::lock_guard<std::mutex> lk(mu); fetched.push_back(it); } else { drop_item(it); std::lock_guard<std::mutex> lk(mu); pending--; }
 					cv.notify_all();
@@ -2354,6 +2735,77 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 }
 /* the same engine behind the C-ABI: packed batches prepared ahead of time (bench.py: the timed region then starts from packed reads in host memory) or packed on
  * the fly, text handed to a callback in input order */
+static int default_lanes();
+static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const PieceSink &sink, int lanes)
+{
+	if(lanes <= 0) lanes = default_lanes();
+	TextReader rd; rd.a = a; rd.src = src; rd.min_len = a->o.min_len; rd.keep_qual = a->o.keep_qual; rd.lanes = lanes;
+	if(!rd.start()) { fprintf(stderr, "[minialign_amd] reader: no stream / staging memory\n"); return 1; }
+	bool err = false;
+	int rc = stream_map(a, MM_OPEN_ENDED, [&](uint32_t k) { return rd.take(k, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes);
+	{ std::lock_guard<std::mutex> lk(rd.mu); if(err || rd.failed) rc = 1; }
+	return rc;
+}
+/* standard input can be read once: its text is kept for the case that it is mapped onto several indices (-X, index files with several blocks) */
+static std::shared_ptr<TextSrc> open_text_once(const char *fn)
+{
+	static std::shared_ptr<TextSrc> from_stdin;
+	if(strcmp(fn, "-") != 0) return open_text(fn);
+	if(!from_stdin) from_stdin = open_text(fn);
+	return from_stdin;
+}
+/* the streaming engine over a text in host memory / over a file (mapped): records found and packed on the device, text to the sink in input order.  0 on success */
+extern "C" int mm_map_text(mm_align_t *a, char const *text, uint64_t len, int lanes, mm_sam_sink_t sink, void *opaque)
+{
+	auto src = std::make_shared<TextSrc>(); src->p = text; src->n = len;
+	for(int i = 0; i < 4 && src->first < src->n; i++) { if(text[src->first] == '>' || text[src->first] == '@') { src->delim = text[src->first]; break; } src->first++; }
+	if(!src->delim) { if(len == 0) return 0; fprintf(stderr, "[minialign_amd] mm_map_text: neither FASTA nor FASTQ\n"); return 1; }
+	return align_text(a, src, [&](uint32_t k, std::vector<std::string> &piece) { for(auto &x : piece) { if(sink && sink(opaque, k, x.data(), x.size())) return false; } return true; }, lanes);
+}
+extern "C" int mm_map_file(mm_align_t *a, char const *fn, int lanes, mm_sam_sink_t sink, void *opaque)
+{
+	std::shared_ptr<TextSrc> src = open_text_once(fn);
+	if(!src) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", fn); return 1; }
+	return align_text(a, src, [&](uint32_t k, std::vector<std::string> &piece) { for(auto &x : piece) { if(sink && sink(opaque, k, x.data(), x.size())) return false; } return true; }, lanes);
+}
+/* test entry for the device reader: the records of a file as K0r finds them and K0 packs them, nothing mapped -- names / comments / qualities read off the text at the
+ * offsets the scan gave, base codes brought back from the packed arena in HBM.  *host_scanned = records that went through the host's sequential FASTQ reader.  NULL when
+ * the file cannot be read or is rejected (a FASTQ record that does not start with '@': the reference gives up on the run). */
+extern "C" mm_reads_t *mm_reads_scan(mm_align_t *a, char const *fn, int keep_qual, int keep_comment, uint64_t *host_scanned)
+{
+	std::shared_ptr<TextSrc> src = open_text(fn);
+	if(!src) return NULL;
+	TextReader rd; rd.a = a; rd.src = src; rd.min_len = 1; rd.keep_qual = keep_qual != 0; rd.lanes = 1;
+	if(!rd.start()) return NULL;
+	mm_reads_t *out = new mm_reads_s(); bool err = false;
+	for(uint32_t k = 0; ; k++) {
+		mm_batch_t *h = rd.take(k, &err);
+		if(!h) break;
+		Batch &b = h->b;
+		if(!batch_upload(a, b)) { err = true; delete h; break; }
+		std::vector<uint32_t> pk((b.total + 64) / 16 + 8), nm((b.total + 64) / 32 + 8);
+		if(hipMemcpy(pk.data(), a->q_pk.p, ((b.total + 64) / 16) * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(nm.data(), a->q_nm.p, ((b.total + 64) / 32) * 4, hipMemcpyDeviceToHost) != hipSuccess) { err = true; delete h; break; }
+		for(uint32_t i = 0; i < b.n; i++) {
+			out->r.emplace_back(); HSeq &q = out->r.back();
+			materialize(b, i, q, keep_qual != 0, keep_comment != 0);
+			for(uint32_t j = 0; j < b.lens[i]; j++) { const uint64_t p = b.qoff[i] + j; q.seq[j] = ((nm[p >> 5] >> (p & 31)) & 1) ? 4 : (uint8_t)((pk[p >> 4] >> (2 * (p & 15))) & 3); }          /* the device's codes, not the host's */
+			out->bases += q.seq.size();
+		}
+		delete h;
+	}
+	{ std::lock_guard<std::mutex> lk(rd.mu); if(rd.failed) err = true; }
+	if(host_scanned) *host_scanned = rd.n_host_scanned;
+	if(err) { delete out; return NULL; }
+	return out;
+}
+extern "C" uint32_t mm_reads_codes(mm_reads_t const *r, uint32_t i, uint8_t *out, uint32_t cap)
+{
+	if(i >= r->r.size()) return 0;
+	const uint32_t n = (uint32_t)r->r[i].seq.size(); if(out) memcpy(out, r->r[i].seq.data(), std::min(n, cap));
+	return n;
+}
+extern "C" char const *mm_reads_qual(mm_reads_t const *r, uint32_t i) { return i < r->r.size() ? r->r[i].qual.c_str() : NULL; }
+extern "C" char const *mm_reads_comment(mm_reads_t const *r, uint32_t i) { return (i < r->r.size() && r->r[i].has_comment) ? r->r[i].comment.c_str() : NULL; }
 extern "C" mm_batch_t *mm_batch_pack(mm_reads_t const *r, uint32_t first, uint32_t n)
 {
 	mm_batch_t *h = new mm_batch_s();
@@ -2515,7 +2967,8 @@ extern "C" int mm_main(int argc, char **argv)
 	if(qh == nf) { fprintf(stderr, "[M::main_align] query-side input redirected to stdin.\n"); files[nf++] = "-"; }     /* minialign.c:6380-6384 */
 	/* the first query file is parsed on a thread of its own while the index is built or loaded */
 	mm_reads_t *first_reads = NULL;
-	std::thread rt([&]() { if(strcmp(files[qh], "-") != 0) first_reads = reads_load(files[qh], o->min_len, o->keep_qual, (o->ptags() >> 1) & 1, getenv("MM_HOST_PACK") == NULL); });
+	const bool host_reader = getenv("MM_HOST_READER") != NULL || getenv("MM_HOST_PACK") != NULL;          /* the host's parser instead of the device reader (kept for comparison) */
+	std::thread rt([&]() { if(host_reader && strcmp(files[qh], "-") != 0) first_reads = reads_load(files[qh], o->min_len, o->keep_qual, (o->ptags() >> 1) & 1, getenv("MM_HOST_PACK") == NULL); });
 	std::thread hw([]() { int n = 0; if(hipGetDeviceCount(&n) == hipSuccess && n > 0) { (void)hipFree(0); } });      /* bring the HIP runtime up meanwhile */
 	const bool keep_first = prebuilt || n_ref > 1;      /* the parsed first query file serves every index */
 	FILE *pg = prebuilt ? fopen(files[0], "rb") : NULL;

@@ -10,7 +10,7 @@ tools/gensim genome 0x5eed0001 "$GL" "$NC" 0.05 > "$W/ref.fa"
 for p in $(seq 0 15); do tools/gensim reads 0x5eed0002 "$W/ref.fa" "$DEPTH" $KIND fa 20000 2000 $p 16 > "$W/rd.$p" & done; wait
 for p in $(seq 0 15); do cat "$W/rd.$p"; rm "$W/rd.$p"; done > "$W/rd.fa"
 for rep in 1 2; do
-  /usr/bin/time -v env MM_VERBOSE=1 ${CLI_ENV:-} minialign_amd/minialign -x$PRE "$W/ref.fa" "$W/rd.fa" > /dev/null 2> "$OUT/run$rep.err"
+  t0=$(date +%s.%N); env MM_VERBOSE=1 ${CLI_ENV:-} minialign_amd/minialign -x$PRE "$W/ref.fa" "$W/rd.fa" > /dev/null 2> "$OUT/run$rep.err"; echo "rc=$? wall $(awk "BEGIN{print $(date +%s.%N)-$t0}") s" | tee -a "$OUT/log.txt"
   grep -E "M::main_align|M::main\]" "$OUT/run$rep.err" | tee -a "$OUT/log.txt"
   awk '/loaded\/built index/{split($1,a,"::"); t0=a[3]+0} /finished mapping/{split($1,a,"::"); t1=a[3]+0} END{printf "map phase %.3f s\n", t1-t0}' "$OUT/run$rep.err" | tee -a "$OUT/log.txt"
 done
