@@ -7,9 +7,12 @@ on.  `--workload dm6 | ecoli | ont` give the other BASELINE shapes (D.melanogast
 `-xont.1dsq`), `--genome-len / --contigs / --depth / --repeat-frac` any other.  Data comes from the repo's own seeded generator (tools/gensim.c, 16 parts
 generated side by side; the set is their concatenation).
 
-A step = the whole read set once through the map phase of the reference (minialign.c:6417-6431): the timed region starts from 2-bit packed reads in host
-memory and ends with the SAM text of every read in host memory -- H2D, K1 sketch + lookup, K2 sort + chain, K3 banded extension (in rounds, several batches
-in flight on the lanes of the device context), D2H, post-map, SAM formatting.  Index construction and FASTA parsing are outside (as in the README's figure).
+A step = the whole read set once through the map phase of the reference (minialign.c:6417-6431; its reader bseq_read_fasta :1996 included): the timed region
+starts from the FASTA TEXT of the read set in host memory and ends with the SAM text of every read in host memory -- text to HBM, K0r record scanning, K0 base
+conversion + 2-bit packing, K1 sketch + lookup, K2 sort + chain, K3 banded extension (in rounds, several batches in flight on the lanes of the device context),
+D2H, post-map, SAM formatting.  Only index construction is outside (as in the README's figure).  `config.value_from_packed` keeps the earlier rounds' figure (the
+same steps from reads parsed and 2-bit packed ahead of time), `config.cli_map_phase_s` is the map phase of the command-line program itself over the same set
+(`minialign_amd/minialign ref.fa reads.fa > /dev/null`, between its "loaded/built index" and "finished mapping" stamps as minialign.c:6417,6431 puts them).
 With N > 1 GPUs (torch.distributed.run, one process per GPU) the SAME read set is split over the ranks (strong scaling): rank r maps parts r*16/N .. of
 the set against its own replica of the index, the ranks settle the one value reads share (the carried reference length, minialign_amd/multi.py) with one
 tiny all_gather, and value = total bases / max over ranks of the time.  No collective on the data path.
@@ -114,6 +117,24 @@ def reference_runs(w, ref_fa, parts, work, n_check, n_time, want_check):
     if want_check and r.returncode == 0: out.update(check_sam=strip_header(r.stdout), check_reads=ns, check_kind='oracle/ora_minialign (plain-C restatement)')
     return out
 
+def cli_map_phase(w, ref_fa, parts, work):
+    """the drop-in itself: `minialign -x<preset> ref.fa reads.fa > /dev/null` over the same set (the parts as one file); map phase = "finished mapping" - "loaded/built index" stamps"""
+    cli = os.path.join(ROOT, 'minialign_amd', 'minialign'); rd = os.path.join(work, 'reads_all.fa')
+    try:
+        with open(rd, 'wb') as g:
+            for p in parts:
+                with open(p, 'rb') as f: shutil.copyfileobj(f, g, 64 << 20)
+        t0 = time.time()
+        with open(os.devnull, 'wb') as dn: r = subprocess.run([cli, '-x' + w['preset'], ref_fa, rd], stdout=dn, stderr=subprocess.PIPE)
+        wall = time.time() - t0
+        ts = [float(m.group(1)) for m in re.finditer(rb'\[M::main_align::([0-9.]+)\]', r.stderr)]
+        return {'cli_map_phase_s': (ts[-1] - ts[0]) if (r.returncode == 0 and len(ts) >= 2) else None, 'cli_wall_s (index build included)': wall, 'cli_index_s': ts[0] if ts else None}
+    except Exception as e:
+        return {'cli_map_phase_s': None, 'cli_error': repr(e)}
+    finally:
+        try: os.unlink(rd)
+        except OSError: pass
+
 def pmc_traffic(wname, world, alg_bytes_per_launch):
     """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes of the same workload (tools/pmc_traffic.sh), else None.  The PMC run maps
     a tenth of the set on one lane; its traffic per launch is scaled by the algorithmic bytes per launch of this run over those of that run (same kernel, same reads:
@@ -156,6 +177,7 @@ def main():
     ap.add_argument('--check', action='store_true', help='verify the records of the first reads against the CPU reference also when N > 1')
     ap.add_argument('--check-reads', type=int, default=4000); ap.add_argument('--baseline-reads', type=int, default=60000)
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU legs (baseline and identity check)')
+    ap.add_argument('--no-packed', action='store_true', help='skip the value_from_packed leg'); ap.add_argument('--no-cli', action='store_true', help='skip the command-line run')
     ap.add_argument('--keep', action='store_true', help='keep the generated data (prints the directory)')
     args = ap.parse_args()
     os.environ['MM_LANES'] = str(args.lanes)          # the batch rule of the library (one batch per lane for a small set) sees the lanes this run uses
@@ -202,22 +224,23 @@ def main():
     t_index = time.time() - t0
     # this rank's shard: parts [p0, p1) of the set (PARTS is a multiple of every N the driver uses; otherwise the split is by parts, as even as it gets)
     p0, p1 = multi.shard_bounds(PARTS, rank, world)
+    # the FASTA text of the shard in host memory (what a reader of the file finds in the page cache)
     t0 = time.time()
-    reads = ctypes.c_void_p(L.mm_reads_load(parts[p0].encode())) if p1 > p0 else None
-    for p in range(p0 + 1, p1): assert L.mm_reads_append(reads, parts[p].encode()) == 0
-    n_reads = L.mm_reads_count(reads) if reads else 0; bases = L.mm_reads_bases(reads, 0, n_reads) if reads else 0
-    cap = 4096; arr = (ctypes.c_void_p * cap)()
-    nb = L.mm_batch_pack_all(reads, 0, n_reads, arr, cap) if reads else 0
-    packed = [arr[i] for i in range(nb)]
+    sizes = [os.path.getsize(parts[p]) for p in range(p0, p1)]; text = bytearray(sum(sizes)); at = 0
+    for p, sz in zip(range(p0, p1), sizes):
+        with open(parts[p], 'rb') as f: assert f.readinto(memoryview(text)[at:at + sz]) == sz
+        at += sz
+    text_addr = ctypes.addressof((ctypes.c_char * max(1, len(text))).from_buffer(text)) if len(text) else 0
     t_load = time.time() - t0
     guess = L.mm_idx_max_len(mi)
-    keep_bytes = 96 << 20          # text kept per step: enough for the identity check and for a spliced head window
+    keep_bytes = 160 << 20          # text kept per step: enough for the identity check and for a spliced head window
 
     def sync():
         torch.cuda.synchronize()
         if dist: dist.barrier()
-    def one_step():
-        sm = multi.ShardMapper(L, al, reads, 0, n_reads, lanes=args.lanes, packed=packed, keep=keep_bytes, guess=0 if rank == 0 else guess)
+    def one_step(packed=None, reads=None, n_reads=0):
+        if packed is not None: sm = multi.ShardMapper(L, al, reads, 0, n_reads, lanes=args.lanes, packed=packed, keep=keep_bytes, guess=0 if rank == 0 else guess)
+        else: sm = multi.ShardMapper(L, al, None, 0, 0, lanes=args.lanes, keep=keep_bytes, guess=0 if rank == 0 else guess, text=(text_addr, len(text)))
         sm.map()
         sm.settle(dist, rank, world, 0, device)
         return sm
@@ -229,6 +252,26 @@ def main():
     sync(); dt = time.perf_counter() - t0
     st = Stats(); L.mm_stats(al, ctypes.byref(st), 0)
     sam_bytes = sm.col.total if sm else 0
+    K = max(1, args.steps)
+    bases = st.bases // K; n_reads = st.reads // K; nb = int(round(st.k1_launches / K))          # per step, counted by the library (re-runs of the carried value add a few launches)
+    # ... and the earlier rounds' figure: the same steps from reads parsed and 2-bit packed ahead of time (N = 1 only: a report, not the value)
+    from_packed = None; t_pack = None
+    if world == 1 and not args.no_packed:
+        tq = time.time()
+        reads = ctypes.c_void_p(L.mm_reads_load(parts[p0].encode())) if p1 > p0 else None
+        for p in range(p0 + 1, p1): assert L.mm_reads_append(reads, parts[p].encode()) == 0
+        nr = L.mm_reads_count(reads) if reads else 0
+        cap = 4096; arr = (ctypes.c_void_p * cap)()
+        npk = L.mm_batch_pack_all(reads, 0, nr, arr, cap) if reads else 0
+        packed = [arr[i] for i in range(npk)]; t_pack = time.time() - tq
+        one_step(packed, reads, nr)
+        sync(); tq = time.perf_counter()
+        for _ in range(2): one_step(packed, reads, nr)
+        sync(); from_packed = L.mm_reads_bases(reads, 0, nr) * 2 / (time.perf_counter() - tq) * 1e-9
+        for h in packed: L.mm_batch_free(h)
+        L.mm_reads_free(reads)
+        sm_check = one_step()          # (the identity check below reads the head of the last text stream)
+        sm = sm_check
     if dist:
         t = torch.tensor([dt], device=tdev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         v = torch.tensor([float(bases), float(n_reads), float(sam_bytes), st.k1_ms, st.k2_ms, st.k3_ms, float(st.vectors), float(st.trace_steps), float(st.k3_launches), float(sm.stats['checks']), float(sm.stats['remapped_reads']), float(sm.stats['full_remaps'])], device=tdev, dtype=torch.float64)
@@ -238,20 +281,20 @@ def main():
     total_bases, total_reads, total_sam, k1_ms, k2_ms, k3_ms, vec, trs, k3_launches, n_checks, n_remap, n_full = tot
 
     if rank == 0:
-        K = max(1, args.steps)
         # the dominant kernel: algorithmic bytes (units counted by the kernel itself, SURVEY.md 8d per-unit figures) over its launch time (HIP events on the launch streams)
         alg_bytes = vec * 40.5 + trs * 32.0                      # all launches of the timed region, all ranks
         k3_launch_ms = k3_ms / max(1.0, k3_launches)
         achieved = (alg_bytes / max(1.0, k3_launches)) / (k3_launch_ms * 1e-3) / 1e9 if k3_ms > 0 else None
         out = {
-            'metric': 'aligned Gbases/sec (whole node), map phase end to end: packed reads in host memory -> SAM text in host memory',
+            'metric': 'aligned Gbases/sec (whole node), map phase end to end: FASTA text of the reads in host memory -> SAM text in host memory',
             'value': total_bases * args.steps / dt * 1e-9, 'unit': 'Gbases/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'i8',
             'data': 'synthetic (tools/gensim.c, seed 0x5eed0001: %.2f Mb reference in %d contig(s) with %g %% planted repeats; %s-like reads in %d parts)' % (w['genome_len'] / 1e6, w['contigs'], w['repeat_frac'] * 100, 'ONT' if w['kind'] == 'ont' else 'PBSIM-CLR', PARTS),
             'config': {'workload': '%s%s x %s x%g (%.2f Gb, %d reads) -x%s, one read set split over %d MI355X' % (w['name'], ' [custom shape]' if custom else '', 'ONT-like' if w['kind'] == 'ont' else 'PBSIM-like', w['depth'], total_bases / 1e9, int(total_reads), w['preset'], world),
                        'workload_key': args.workload if not custom else 'custom', 'reads_total': int(total_reads), 'bases_total': int(total_bases), 'batches_per_rank0': nb, 'lanes': args.lanes,
                        'parallelism': 'reads sharded contiguously, index replicated (no data-path collective; one all_gather of 2 integers per step for the carried value)',
-                       'timed_region': 'H2D + K1 sketch/lookup + K2 sort/chain + K3 extension (rounds, carried-value verification) + D2H + post-map + SAM text; index build, FASTA parse and 2-bit packing outside',
+                       'timed_region': 'text H2D + K0r record scan + K0 base conversion / 2-bit pack + K1 sketch/lookup + K2 sort/chain + K3 extension (rounds, carried-value verification) + D2H + post-map + SAM text; only the index build is outside',
+                       'value_from_packed': from_packed, 'value_from_packed_note': 'the same steps from reads parsed and 2-bit packed on the host ahead of time (the timed region of rounds 1-2), 2 steps',
                        'device_only_gbases_per_s (sum of kernel time, lanes overlap)': total_bases * K / max(1e-9, (k1_ms + k2_ms + k3_ms) * 1e-3) * 1e-9 / 1.0,
                        'kernel_ms_per_step (summed over lanes and ranks)': {'sketch_seed': k1_ms / K, 'sort_chain': k2_ms / K, 'extend': k3_ms / K},
                        'host_ms_per_step (rank 0, summed over its threads\' critical paths)': {'d2h': st.host_post_ms / K, 'post_map_and_sam_text': st.host_sam_ms / K},
@@ -260,7 +303,7 @@ def main():
                        'sort_chain_wave_time_split': {'sort_cycles_per_seed': st.k2_cycles_sort / max(1, st.seeds), 'chain_cycles_per_seed': st.k2_cycles_chain / max(1, st.seeds), 'seeds_per_read': st.seeds / max(1, st.reads), 'reads_not_in_lds': st.k2_reads_hbm},
                        'dp_vectors_per_base': vec / max(1.0, total_bases * K), 'trace_steps_per_base': trs / max(1.0, total_bases * K), 'reruns_per_step (rank 0)': st.reruns / K,
                        'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
-                       'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'parse_and_pack_s': t_load},
+                       'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'text_load_s (outside)': t_load, 'host_parse_and_pack_s (value_from_packed only)': t_pack},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args.workload if not custom else 'custom', world, alg_bytes / max(1.0, k3_launches)),
                          'alg_bytes_per_launch': alg_bytes / max(1.0, k3_launches), 'avg_launch_ms': k3_launch_ms, 'launches': k3_launches,
@@ -280,8 +323,9 @@ def main():
                 out['sam_check'] = 'records of the first %d reads (%d bytes) against %s' % (cpu['check_reads'], len(cpu['check_sam']), cpu['check_kind'])
             else:
                 out['sam_identical'] = None; out['sam_check'] = 'not run'
+        if world == 1 and not args.no_cli:
+            out['config'].update(cli_map_phase(w, ref_fa, parts, work))
         print(json.dumps(out), flush=True)
-    for h in packed: L.mm_batch_free(h)
     if dist: dist.barrier()
     if rank == 0:
         if args.keep: sys.stderr.write('[bench] data kept in %s\n' % work)

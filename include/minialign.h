@@ -146,6 +146,9 @@ uint32_t mm_carry_after(mm_align_t const *a, uint32_t i);          /* UINT32_MAX
  * beyond what was recorded.  A caller that replaces the records of reads [i, j) -- the window re-map of minialign_amd/multi.py -- cuts the text at these offsets,
  * whatever the output format and the read names are. */
 uint64_t mm_head_offset(mm_align_t const *a, uint32_t i);
+/* for a stream over a text (mm_map_text / mm_map_file): where the record of read i begins in that text, so that a window of reads can be mapped again as a slice of it */
+uint64_t mm_head_text_offset(mm_align_t const *a, uint32_t i);
+uint32_t mm_head_count(mm_align_t const *a);          /* reads of the last stream whose head was recorded (at most 4 096; 0 = the stream had no read) */
 int mm_map_packed(mm_align_t *a, mm_batch_t *const *batches, uint32_t n_batches, int lanes, mm_sam_sink_t sink, void *opaque);
 int mm_map_reads(mm_align_t *a, mm_reads_t const *r, uint32_t first, uint32_t n, int lanes, mm_sam_sink_t sink, void *opaque);
 /* the whole input path on the device: the FASTA / FASTQ text of a read set in host memory (mm_map_text) or a file (mm_map_file: plain files are mapped, gzip / stdin are

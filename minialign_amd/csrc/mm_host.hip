@@ -867,6 +867,7 @@ struct mm_align_s {
 	/* the head of the last stream mapped through this context (mm_map_*): what decides whether another carried value at its start changes anything */
 	struct HeadRec { uint32_t apos0, cond0, used, rid_last; };
 	std::vector<HeadRec> head; uint32_t head_carry_in = 0;
+	std::vector<uint64_t> head_txt; uint64_t head_txt_end = 0;      /* for a stream over a text (mm_map_text / mm_map_file): where the record of read i starts in that text; the length of the text */
 	std::vector<uint64_t> head_off; bool head_off_closed = false;      /* byte offset of the first record of read i in the text of that stream (one more entry = the end, when the stream is shorter than the head) */
 	bool streaming = false;                /* stream_map is running on this context (the shared workspaces cannot be re-sized then) */
 	struct ChunkPool *chunk_pool = nullptr; /* device buffers of the text reader (primary context) */
@@ -2527,7 +2528,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 	std::vector<Item *> fetched;                       /* waiting for a finisher */
 	std::map<uint32_t, Item *> formatted;              /* waiting for the writer */
 	uint32_t lanes_done = 0, fin_done = 0; bool head_open = true;
-	a->head.clear(); a->head_off.clear(); a->head_off_closed = false; a->head_carry_in = a->rlen_carry; a->streaming = true;
+	a->head.clear(); a->head_txt.clear(); a->head_txt_end = 0; a->head_off.clear(); a->head_off_closed = false; a->head_carry_in = a->rlen_carry; a->streaming = true;
 	uint64_t written = 0;                              /* bytes handed to the sink so far (writer thread only) */
 	const uint32_t max_pending = (uint32_t)lanes + 2;
 	/* an item leaves: its pinned set and its text pieces (emptied, capacity kept) go back to the pools of the context */
@@ -2601,8 +2602,9 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 					const uint32_t out = batch_carry_out(c, b, truth);
 					{
 						std::lock_guard<std::mutex> lk(mu); carry = out; verified = k + 1;
-						if(k == 0) { a->head.clear(); a->head_carry_in = truth; }
-						for(uint32_t i = 0; i < b.n && a->head.size() < 4096 && head_open; i++) { a->head.push_back(mm_align_s::HeadRec{ b.hst[i].apos0, b.hst[i].cond0, b.used[i], b.hst[i].rid_last }); }
+						if(k == 0) { a->head.clear(); a->head_txt.clear(); a->head_carry_in = truth; }
+						if(b.tsrc) { a->head_txt_end = b.tsrc->n; }
+						for(uint32_t i = 0; i < b.n && a->head.size() < 4096 && head_open; i++) { a->head.push_back(mm_align_s::HeadRec{ b.hst[i].apos0, b.hst[i].cond0, b.used[i], b.hst[i].rid_last }); a->head_txt.push_back(b.tsrc ? (uint64_t)(b.trec[i].start) : ~0ull); }
 						if(a->head.size() >= 4096) head_open = false;
 					}
 					cv.notify_all();
@@ -2898,6 +2900,9 @@ extern "C" uint32_t mm_carry_after(mm_align_t const *a, uint32_t i)
 }
 /* byte offset, in the text the last stream handed to its sink, of the first record of read i (i = the number of reads of a stream shorter than the recorded
  * head: the end of the text); UINT64_MAX beyond what was recorded (the first 4 096 reads, fewer when a batch had to be split) */
+/* ... and, for a stream over a text, where the record of read i starts in that text (i = the number of reads of a stream shorter than the head: the length of the text) */
+extern "C" uint64_t mm_head_text_offset(mm_align_t const *a, uint32_t i) { return i < a->head_txt.size() ? a->head_txt[i] : (i == a->head_txt.size() && i == a->head.size() && i < 4096 && !a->head_off_closed ? a->head_txt_end : ~0ull); }
+extern "C" uint32_t mm_head_count(mm_align_t const *a) { return (uint32_t)a->head.size(); }          /* reads of the last stream that were recorded (at most 4 096) */
 extern "C" uint64_t mm_head_offset(mm_align_t const *a, uint32_t i) { return i < a->head_off.size() ? a->head_off[i] : ~0ull; }
 extern "C" int mm_map_packed(mm_align_t *a, mm_batch_t *const *batches, uint32_t n_batches, int lanes, mm_sam_sink_t sink, void *opaque)
 {

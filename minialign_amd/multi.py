@@ -39,6 +39,10 @@ def load_library(path=None):
     L.mm_carry_check.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     L.mm_carry_after.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_carry_after.restype = ctypes.c_uint32
     L.mm_head_offset.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_head_offset.restype = ctypes.c_uint64
+    L.mm_head_text_offset.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_head_text_offset.restype = ctypes.c_uint64
+    L.mm_head_count.argtypes = [ctypes.c_void_p]; L.mm_head_count.restype = ctypes.c_uint32
+    L.mm_map_text.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, SINK, ctypes.c_void_p]
+    L.mm_map_file.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, SINK, ctypes.c_void_p]
     L.mm_map_reads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, SINK, ctypes.c_void_p]
     L.mm_map_packed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, SINK, ctypes.c_void_p]
     L.mm_batch_pack_all.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]; L.mm_batch_pack_all.restype = ctypes.c_uint32
@@ -96,15 +100,22 @@ class Collector:
 
 
 class ShardMapper:
-    """maps reads [first, first + n) of a loaded read set on this process' device and settles the carried value with the other ranks"""
-    def __init__(self, L, al, reads, first, n, lanes=0, packed=None, keep=None, guess=0):
-        self.L, self.al, self.reads, self.first, self.n, self.lanes, self.packed, self.keep, self.guess = L, al, reads, first, n, lanes, packed, keep, guess
+    """maps one shard of a read set on this process' device and settles the carried value with the other ranks.  The shard is either reads [first, first + n) of a
+    loaded (host-parsed) read set -- optionally as batches packed ahead of time --, or `text = (address, length)`: the FASTA / FASTQ text of the shard in host
+    memory, which the library's device reader scans and packs (mm_map_text: the whole input path inside the call)"""
+    def __init__(self, L, al, reads, first, n, lanes=0, packed=None, keep=None, guess=0, text=None):
+        self.L, self.al, self.reads, self.first, self.n, self.lanes, self.packed, self.keep, self.guess, self.text = L, al, reads, first, n, lanes, packed, keep, guess, text
         self.col = None; self.carry_in = None; self.carry_out = None; self._stale = False; self.stats = dict(sweeps=0, checks=0, remapped_reads=0, full_remaps=0)
 
-    def _map(self, first, n, carry_in, keep, packed=None):
+    def _map(self, first, n, carry_in, keep, packed=None, whole=False):
+        """reads [first, first + n) of the shard (whole = all of it, the only form the packed batches and a text whose records are not known yet allow)"""
         col = Collector(keep)
         self.L.mm_align_set_carry(self.al, carry_in)
-        if packed is not None:
+        if self.text is not None:
+            lo, hi = (0, self.text[1]) if whole else (self.L.mm_head_text_offset(self.al, first), self.L.mm_head_text_offset(self.al, first + n))
+            if lo == NO_OFFSET or hi == NO_OFFSET: raise RuntimeError('window beyond the recorded head')
+            rc = self.L.mm_map_text(self.al, ctypes.c_void_p(self.text[0] + lo), hi - lo, self.lanes, col.cb, None)
+        elif packed is not None:
             arr = (ctypes.c_void_p * len(packed))(*packed)
             rc = self.L.mm_map_packed(self.al, arr, len(packed), self.lanes, col.cb, None)
         else:
@@ -114,7 +125,8 @@ class ShardMapper:
 
     def map(self, carry_in=None):
         self.carry_in = self.guess if carry_in is None else carry_in
-        self.col, self.carry_out = self._map(self.first, self.n, self.carry_in, self.keep, self.packed); self._stale = False
+        self.col, self.carry_out = self._map(self.first, self.n, self.carry_in, self.keep, self.packed, whole=True); self._stale = False
+        if self.text is not None: self.n = self.L.mm_head_count(self.al)          # (the reads of a text are known once it has been scanned; only the head matters here)
         return self
 
     def _settle_local(self, truth):
@@ -137,10 +149,19 @@ class ShardMapper:
             after = {m: self.L.mm_carry_after(self.al, i0 + m - 1) for m in ends}
             offs = {m: self.L.mm_head_offset(self.al, i0 + m) for m in ends}
             cut_lo = self.L.mm_head_offset(self.al, i0)
+            if self.text is not None:          # the windows as slices of the text
+                txt = {m: (self.L.mm_head_text_offset(self.al, i0), self.L.mm_head_text_offset(self.al, i0 + m)) for m in ends}
             for m in ends:
                 cut_hi = offs[m]
                 if cut_lo == NO_OFFSET or cut_hi == NO_OFFSET or cut_hi > self.col.kept or after[m] == NO_CARRY: break      # beyond what was recorded / kept
-                col, out = self._map(self.first + i0, m, truth, None); self._stale = True
+                if self.text is not None:
+                    if NO_OFFSET in txt[m]: break
+                    col = Collector(None); self.L.mm_align_set_carry(self.al, truth)
+                    if self.L.mm_map_text(self.al, ctypes.c_void_p(self.text[0] + txt[m][0]), txt[m][1] - txt[m][0], self.lanes, col.cb, None) != 0: raise RuntimeError('mapping failed')
+                    out = self.L.mm_align_get_carry(self.al)
+                else:
+                    col, out = self._map(self.first + i0, m, truth, None)
+                self._stale = True
                 self.stats['remapped_reads'] += m
                 if out == after[m]:
                     self.col.splice(cut_lo, cut_hi, col.pieces)
@@ -148,7 +169,7 @@ class ShardMapper:
                     return False
         # undecided inside the recorded head, or the window outgrew what can be spliced: the whole shard again with the true value
         self.stats['full_remaps'] += 1
-        self.col, self.carry_out = self._map(self.first, self.n, truth, self.keep, self.packed)
+        self.col, self.carry_out = self._map(self.first, self.n, truth, self.keep, self.packed, whole=True)
         self.carry_in = truth; self._stale = False
         return self.carry_out != old_out
 
@@ -172,6 +193,27 @@ class ShardMapper:
             dist.all_reduce(flag)
             if int(flag[0]) == 0: break
         return self
+
+
+def text_part(fn, rank, world):
+    """this rank's stretch of a plain FASTA file as (keepalive, address, length): the file is mapped and cut by bytes where a '>' starts a line (such a '>' always
+    starts a record for the reader, minialign.c:1996-2090), so the stretches in rank order are the file and nothing is read twice; None for anything else (gzip,
+    FASTQ, stdin: the caller falls back to mm_reads_load_part)"""
+    import mmap, numpy as np
+    if fn == '-' or not os.path.isfile(fn): return None
+    with open(fn, 'rb') as f:
+        head = f.read(4); size = os.fstat(f.fileno()).st_size
+        first = next((c for c in head if c in b'>@'), None)
+        if size == 0 or first != ord('>'): return None
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    def cut(b):
+        if b <= 0: return 0
+        if b >= size: return size
+        q = mm.find(b'\n>', b - 1)
+        return size if q < 0 else q + 1
+    lo, hi = cut(size * rank // world), cut(size * (rank + 1) // world)
+    arr = np.frombuffer(mm, dtype=np.uint8)
+    return (mm, arr), arr.ctypes.data + lo, hi - lo
 
 
 def write_in_rank_order(dist, rank, world, fd, chunks):
@@ -203,10 +245,15 @@ def main(argv=None):
     if L.mm_opt_parse(o, len(args), av, files, 8, ctypes.byref(nf)) != 0 or nf.value != 2: raise SystemExit('usage: minialign_amd.multi [options] ref.fa reads.fa')
     mi = ctypes.c_void_p(L.mm_idx_gen(o, files[0])); al = ctypes.c_void_p(L.mm_align_init(o, mi)) if mi else None
     if not al: raise RuntimeError('index / device context failed')
-    # this rank's part of the read file only (a plain FASTA file is cut by bytes at record starts; the parts in rank order are the file)
-    reads = ctypes.c_void_p(L.mm_reads_load_part(files[1], rank, world))
-    if not reads: raise RuntimeError('cannot read %r' % files[1])
-    sm = ShardMapper(L, al, reads, 0, L.mm_reads_count(reads), guess=L.mm_idx_max_len(mi)).map()
+    # this rank's part of the read file only: a plain FASTA file is mapped and cut by bytes at record starts, and the stretch goes to the device as text (records
+    # found and packed there); anything else through the host's parser, the part keeping its share of the records.  The parts in rank order are the file.
+    tp = text_part(files[1].decode(), rank, world) if not os.environ.get('MM_HOST_READER') else None
+    if tp is not None:
+        sm = ShardMapper(L, al, None, 0, 0, guess=L.mm_idx_max_len(mi), text=(tp[1], tp[2])).map()
+    else:
+        reads = ctypes.c_void_p(L.mm_reads_load_part(files[1], rank, world))
+        if not reads: raise RuntimeError('cannot read %r' % files[1])
+        sm = ShardMapper(L, al, reads, 0, L.mm_reads_count(reads), guess=L.mm_idx_max_len(mi)).map()
     sm.settle(dist if world > 1 else None, rank, world, 0, None)
     head = []
     if rank == 0:
