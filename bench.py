@@ -214,6 +214,8 @@ def main():
     ref_fa = os.path.join(work, 'ref.fa'); parts = [os.path.join(work, 'reads_%02d.fa' % p) for p in range(PARTS)]
     t_gen = time.time() - t_gen0
 
+    # the drop-in itself first, while this process holds nothing on the device (two processes with a dozen streams each would take turns on the hardware queues)
+    cli_info = cli_map_phase(w, ref_fa, parts, work) if (rank == 0 and world == 1 and not args.no_cli) else {}
     o = ctypes.c_void_p(L.mm_opt_init())
     argv = (ctypes.c_char_p * 4)(b'minialign', ('-x' + w['preset']).encode(), ref_fa.encode(), b'reads.fa')
     files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
@@ -323,8 +325,7 @@ def main():
                 out['sam_check'] = 'records of the first %d reads (%d bytes) against %s' % (cpu['check_reads'], len(cpu['check_sam']), cpu['check_kind'])
             else:
                 out['sam_identical'] = None; out['sam_check'] = 'not run'
-        if world == 1 and not args.no_cli:
-            out['config'].update(cli_map_phase(w, ref_fa, parts, work))
+        out['config'].update(cli_info)
         print(json.dumps(out), flush=True)
     if dist: dist.barrier()
     if rank == 0:

@@ -316,6 +316,64 @@ __device__ __forceinline__ uint32_t q_code(const gaba::SeqArena &ar, uint64_t p)
 	return n ? 4 : c;
 }
 
+/* h of position p of a sequence at `off` in a packed arena (~0 where no k-mer ends): hash << 8 | (k-mer start mod w) | strand << 7 (minialign.c:2394-2402) */
+__device__ __forceinline__ uint64_t sketch_h(const gaba::SeqArena &ar, uint64_t q_off, uint32_t p, uint32_t qlen, uint32_t k, uint32_t w, uint64_t kmask)
+{
+	uint64_t h = ~0ull;
+	if(p >= k - 1 && p < qlen) {
+		/* forward / reverse k-mers ending at p.  N is pushed as 4 (minialign.c:2391-2392): it ORs into the neighbouring
+		 * 2-bit slots, and k1 is never masked, so the recurrence is replayed over the k + 1 bases that can still
+		 * influence the registers at p (one base before the window leaves one bit behind in k1) */
+		uint64_t k0 = 0, k1 = 0;
+		uint32_t start = p >= k ? p - k : 0;
+		/* without an N among those k + 1 bases the two registers are plain functions of the k packed bases ending at p:
+		 * k1 = their complement in array order, k0 = the same 2-bit groups in reverse order -- two word loads instead of
+		 * replaying the recurrence base by base (the replay stays for windows that contain an N, and for k > 16) */
+		bool plain = false;
+		if(k <= 16) {
+			const uint64_t nb = q_off + start, nn = (uint64_t)(p - start + 1);                    /* N bits of bases [start, p] */
+			const uint64_t nw = (uint64_t)ar.nm[nb >> 5] | ((uint64_t)ar.nm[(nb >> 5) + 1] << 32);
+			plain = ((nw >> (nb & 31)) & ((1ull << nn) - 1)) == 0;
+		}
+		if(plain) {
+			const uint64_t fb = q_off + p - (k - 1);
+			const uint64_t ww = (uint64_t)ar.pk[fb >> 4] | ((uint64_t)ar.pk[(fb >> 4) + 1] << 32);
+			const uint64_t W = (ww >> (2 * (fb & 15))) & kmask;
+			k1 = ~W & kmask;
+			uint64_t rv = __brevll(W) >> (64 - 2 * k);                                            /* bit i -> bit 2k - 1 - i */
+			k0 = ((rv >> 1) & 0x5555555555555555ull) | ((rv & 0x5555555555555555ull) << 1);      /* ... and the two bits of each base back in order */
+		} else {
+			for(uint32_t j = start; j <= p; j++) {
+				uint64_t c = q_code(ar, q_off + j);
+				k0 = (k0 << 2 | c) & kmask;
+				k1 = (k1 >> 2) | ((3ull ^ c) << (2 * (k - 1)));
+			}
+		}
+		uint64_t km = k0 < k1 ? k0 : k1, kx = k0 < k1 ? k1 : k0, m = k0 < k1 ? 0 : 0x80;
+		/* hash64 (minialign.c:2353): a CRC32C seeded with the low word of its own input is zero unless the high word is set */
+		uint64_t crc = (kx >> 32) ? (uint64_t)crc32c_u64((uint32_t)kx, kx) : 0ull;
+		uint64_t hv = (crc ^ km) & kmask;
+		uint32_t i = (p - (k - 1)) % w;
+		h = hv << 8 | i | m;
+	}
+	return h;
+}
+/* minimum of h over the last w positions: lane i holds position base + i of the current 64, h_prev the same lanes of the 64 before */
+__device__ __forceinline__ uint64_t sketch_window_min(uint64_t h, uint64_t h_prev, uint32_t w, int lane)
+{
+	/* window minimum over the last w positions (forward-min of the current block + backward-min of the previous one,
+	 * minialign.c:2394-2421, is the minimum over [p - w + 1, p]) */
+	uint64_t v = h;
+	for(uint32_t j = 1; j < w; j++) {
+		int src_lane = lane - (int)j;
+		uint64_t from_cur = ((uint64_t)(uint32_t)__shfl((int)(h >> 32), src_lane & 63) << 32) | (uint32_t)__shfl((int)h, src_lane & 63);
+		uint64_t from_prev = ((uint64_t)(uint32_t)__shfl((int)(h_prev >> 32), src_lane & 63) << 32) | (uint32_t)__shfl((int)h_prev, src_lane & 63);
+		uint64_t src = src_lane >= 0 ? from_cur : from_prev;
+		v = src < v ? src : v;
+	}
+	return v;
+}
+
 __global__ void __launch_bounds__(256, MM_SHORT_KERNEL_WAVES) mm_sketch_seed_kernel(K1Args a)
 {
 	__builtin_amdgcn_s_setprio(2);          /* short and latency bound beside the extension waves of the other lanes (which run at 0 or 1, the few heaviest reads of a launch at 3) */
@@ -344,53 +402,8 @@ __global__ void __launch_bounds__(256, MM_SHORT_KERNEL_WAVES) mm_sketch_seed_ker
 		uint64_t v_last = 0;           /* v of the last position of the previous chunk: u of the reference, initial cap value 0 (minialign.c:2412) */
 		for(uint32_t base = 0; base < qlen; base += 64) {
 			uint32_t p = base + (uint32_t)lane;
-			uint64_t h = ~0ull;
-			if(p >= k - 1 && p < qlen) {
-				/* forward / reverse k-mers ending at p.  N is pushed as 4 (minialign.c:2391-2392): it ORs into the neighbouring
-				 * 2-bit slots, and k1 is never masked, so the recurrence is replayed over the k + 1 bases that can still
-				 * influence the registers at p (one base before the window leaves one bit behind in k1) */
-				uint64_t k0 = 0, k1 = 0;
-				uint32_t start = p >= k ? p - k : 0;
-				/* without an N among those k + 1 bases the two registers are plain functions of the k packed bases ending at p:
-				 * k1 = their complement in array order, k0 = the same 2-bit groups in reverse order -- two word loads instead of
-				 * replaying the recurrence base by base (the replay stays for windows that contain an N, and for k > 16) */
-				bool plain = false;
-				if(k <= 16) {
-					const uint64_t nb = q_off + start, nn = (uint64_t)(p - start + 1);                    /* N bits of bases [start, p] */
-					const uint64_t nw = (uint64_t)a.qar.nm[nb >> 5] | ((uint64_t)a.qar.nm[(nb >> 5) + 1] << 32);
-					plain = ((nw >> (nb & 31)) & ((1ull << nn) - 1)) == 0;
-				}
-				if(plain) {
-					const uint64_t fb = q_off + p - (k - 1);
-					const uint64_t ww = (uint64_t)a.qar.pk[fb >> 4] | ((uint64_t)a.qar.pk[(fb >> 4) + 1] << 32);
-					const uint64_t W = (ww >> (2 * (fb & 15))) & kmask;
-					k1 = ~W & kmask;
-					uint64_t rv = __brevll(W) >> (64 - 2 * k);                                            /* bit i -> bit 2k - 1 - i */
-					k0 = ((rv >> 1) & 0x5555555555555555ull) | ((rv & 0x5555555555555555ull) << 1);      /* ... and the two bits of each base back in order */
-				} else {
-					for(uint32_t j = start; j <= p; j++) {
-						uint64_t c = q_code(a.qar, q_off + j);
-						k0 = (k0 << 2 | c) & kmask;
-						k1 = (k1 >> 2) | ((3ull ^ c) << (2 * (k - 1)));
-					}
-				}
-				uint64_t km = k0 < k1 ? k0 : k1, kx = k0 < k1 ? k1 : k0, m = k0 < k1 ? 0 : 0x80;
-				/* hash64 (minialign.c:2353): a CRC32C seeded with the low word of its own input is zero unless the high word is set */
-				uint64_t crc = (kx >> 32) ? (uint64_t)crc32c_u64((uint32_t)kx, kx) : 0ull;
-				uint64_t hv = (crc ^ km) & kmask;
-				uint32_t i = (p - (k - 1)) % w;
-				h = hv << 8 | i | m;
-			}
-			/* window minimum over the last w positions (forward-min of the current block + backward-min of the previous one,
-			 * minialign.c:2394-2421, is the minimum over [p - w + 1, p]) */
-			uint64_t v = h;
-			for(uint32_t j = 1; j < w; j++) {
-				int src_lane = lane - (int)j;
-				uint64_t from_cur = ((uint64_t)(uint32_t)__shfl((int)(h >> 32), src_lane & 63) << 32) | (uint32_t)__shfl((int)h, src_lane & 63);
-				uint64_t from_prev = ((uint64_t)(uint32_t)__shfl((int)(h_prev >> 32), src_lane & 63) << 32) | (uint32_t)__shfl((int)h_prev, src_lane & 63);
-				uint64_t src = src_lane >= 0 ? from_cur : from_prev;
-				v = src < v ? src : v;
-			}
+			const uint64_t h = sketch_h(a.qar, q_off, p, qlen, k, w, kmask);
+			const uint64_t v = sketch_window_min(h, h_prev, w, lane);
 			uint64_t vp = shfl_up64(v, 1);
 			uint64_t v63 = ((uint64_t)(uint32_t)rdlane((int)(v >> 32), 63) << 32) | (uint32_t)rdlane((int)v, 63);
 			if(lane == 0) { vp = v_last; }

@@ -35,6 +35,7 @@
 #include <algorithm>
 #include "gaba_host.hpp"
 #include "mm_device.hpp"
+#include "mm_index.hpp"
 #include "../../include/minialign.h"
 
 using namespace mm;
@@ -594,7 +595,167 @@ struct mm_idx_s {
 	std::vector<IdxSlot> slot; uint64_t mask;
 	std::vector<uint64_t> val;
 	uint64_t n_keys = 0;
+	/* an index built on the device (idx_gen_device) lives there: the table, the value array (the sorted (pos | rid << 32) of every minimizer; a list is a run inside it)
+	 * and the packed reference; mm_align_init adopts them, the host copy above is fetched only when somebody asks (mm_idx_dump, mm_idx_get) */
+	bool on_device = false; int dev = 0; IdxSlot *d_slot = nullptr; uint64_t *d_val = nullptr; uint64_t n_slot = 0, n_val = 0; gaba_arena_t *ref_ar = nullptr;
+	mutable std::mutex fetch_mu;
+	double build_ms[8] = { 0 };          /* device build: arena, sketch, partition, sort, thresholds, table */
+	~mm_idx_s() { if(d_slot) (void)hipFree(d_slot); if(d_val) (void)hipFree(d_val); if(ref_ar) gaba_arena_free(ref_ar); }
 };
+/* host copy of a device-built index (for mm_idx_dump / mm_idx_get) */
+static bool idx_fetch_host(const mm_idx_s *cmi)
+{
+	mm_idx_s *mi = const_cast<mm_idx_s *>(cmi);
+	std::lock_guard<std::mutex> lk(mi->fetch_mu);
+	if(!mi->on_device || !mi->slot.empty()) return true;
+	(void)hipSetDevice(mi->dev);
+	mi->slot.resize(mi->n_slot); mi->val.resize(std::max<uint64_t>(mi->n_val, 1));
+	return hipMemcpy(mi->slot.data(), mi->d_slot, mi->n_slot * sizeof(IdxSlot), hipMemcpyDeviceToHost) == hipSuccess && (mi->n_val == 0 || hipMemcpy(mi->val.data(), mi->d_val, mi->n_val * 8, hipMemcpyDeviceToHost) == hipSuccess);
+}
+
+
+template<typename T> struct DBuf {
+	T *p = nullptr; uint64_t n = 0;
+	bool ensure(uint64_t want) { if(want <= n) return true; if(p) (void)hipFree(p); p = nullptr; n = 0; if(hipMalloc(&p, want * sizeof(T)) != hipSuccess) { fprintf(stderr, "[minialign_amd] hipMalloc of %.1f MB failed\n", want * sizeof(T) / 1e6); return false; } n = want; return true; }
+	void release() { if(p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+/* the packed reference in HBM: one arena, every sequence on a multiple of 64 bases */
+static gaba_arena_t *upload_reference(const mm_idx_s *mi, std::vector<uint64_t> *off_out, std::vector<uint32_t> *len_out)
+{
+	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
+	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
+	std::vector<uint8_t> all(total + 64, 4);
+	host_parallel((uint32_t)mi->seq.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < mi->seq.size(); i += nth) memcpy(all.data() + off[i], mi->seq[i].seq.data(), mi->seq[i].seq.size()); }, 32);
+	gaba_arena_t *ar = gaba_arena_upload(all.data(), total + 64);
+	if(ar) gaba_arena_unregister(ar);                 /* `all` is a temporary: keep it out of the per-call API's section lookup */
+	if(off_out) off_out->swap(off);
+	if(len_out) len_out->swap(len);
+	return ar;
+}
+/* mm_idx_gen on the device (mm_index.hpp): sketch of the reference, stable partition into the 2^b buckets in reference order, the unstable per-bucket sort replayed,
+ * occurrence thresholds from the histogram of key counts, table fill.  The sequences are parsed by the host (mi->seq); circular ones (-c) are sketched there too
+ * (their wrap-around pass is a serial special case, mm_sketch_cap :2437) and take their place in reference order.  false: no device / out of memory / a bucket beyond
+ * what the sort's entries address -- the caller reports it (no silent host build). */
+static bool idx_gen_device(const mm_opt_s *o, mm_idx_s *mi, bool verbose)
+{
+	int ndev = 0; if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "[minialign_amd] mm_idx_gen: no HIP device (MM_HOST_INDEX=1 builds the index on the host)\n"); return false; }
+	(void)hipGetDevice(&mi->dev);
+	double tv = now_ms(); int lapi = 0;
+	auto lap = [&](const char *what) { (void)hipDeviceSynchronize(); const double t = now_ms(); if(lapi < 8) mi->build_ms[lapi++] = t - tv; if(verbose) fprintf(stderr, "[minialign_amd] index (device): %s %.1f ms\n", what, t - tv); tv = t; };
+#define IK(_e) do { hipError_t _r = (_e); if(_r != hipSuccess) { fprintf(stderr, "[minialign_amd] index (device): HIP error %s at line %d\n", hipGetErrorString(_r), __LINE__); return false; } } while(0)
+	std::vector<uint64_t> off; std::vector<uint32_t> len;
+	mi->ref_ar = upload_reference(mi, &off, &len);
+	if(!mi->ref_ar) return false;
+	lap("reference arena");
+	const uint32_t bbits = mi->b, nb = 1u << bbits, k = mi->k, w = mi->w;
+	/* stretches: 2^18 positions each; a circular sequence is one stretch, sketched on the host */
+	std::vector<RefStretch> st; std::vector<std::vector<HMin>> hostmin;
+	const uint32_t chunk = 1u << 18;
+	for(uint32_t i = 0; i < mi->seq.size(); i++) {
+		const uint32_t L = len[i];
+		if(mi->seq[i].circular) { st.push_back(RefStretch{ off[i], L, 0, L, i, 0, 1, (uint32_t)hostmin.size() }); hostmin.emplace_back(); continue; }
+		for(uint32_t bg = 0; bg < L; bg += chunk) st.push_back(RefStretch{ off[i], L, bg, std::min(L, bg + chunk), i, 0, 0, 0 });
+	}
+	if(!hostmin.empty()) {
+		std::vector<uint32_t> which; for(uint32_t t = 0; t < st.size(); t++) if(st[t].host) which.push_back(t);
+		host_parallel((uint32_t)which.size(), [&](uint32_t t, uint32_t nth) { for(size_t j = t; j < which.size(); j += nth) { const RefStretch &q = st[which[j]]; const HSeq &sq = mi->seq[q.seq]; sketch_host_circular(sq.seq.data(), (uint32_t)sq.seq.size(), k, w, hostmin[q.pad]); } }, 32);
+	}
+	const uint32_t n_st = (uint32_t)st.size();
+	DBuf<RefStretch> d_st; DBuf<uint32_t> d_cnt, d_ctr; DBuf<IdxMini> d_min, d_flat;
+	if(!d_st.ensure(std::max<uint32_t>(n_st, 1)) || !d_cnt.ensure(std::max<uint32_t>(n_st, 1)) || !d_ctr.ensure(16)) return false;
+	IK(hipMemcpy(d_st.p, st.data(), (size_t)n_st * sizeof(RefStretch), hipMemcpyHostToDevice)); IK(hipMemset(d_ctr.p, 0, 64)); IK(hipMemset(d_cnt.p, 0, (size_t)std::max<uint32_t>(n_st, 1) * 4));
+	hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, mi->dev);
+	const uint32_t waves = (uint32_t)prop.multiProcessorCount * 32u;
+	I1Args i1; i1.ar = gaba::SeqArena{ mi->ref_ar->pk, mi->ref_ar->nm }; i1.st = d_st.p; i1.n = n_st; i1.k = k; i1.w = w; i1.out = nullptr; i1.count = d_cnt.p; i1.emit = 0; i1.counter = d_ctr.p;
+	if(n_st) { hipLaunchKernelGGL(mm_ref_sketch_kernel, dim3(std::min<uint32_t>((n_st + 3) / 4, waves / 4)), dim3(256), 0, 0, i1); IK(hipGetLastError()); }
+	std::vector<uint32_t> cnt(n_st);
+	if(n_st) IK(hipMemcpy(cnt.data(), d_cnt.p, (size_t)n_st * 4, hipMemcpyDeviceToHost));
+	uint64_t N = 0;
+	for(uint32_t t = 0; t < n_st; t++) { if(st[t].host) cnt[t] = (uint32_t)hostmin[st[t].pad].size(); st[t].out = N; N += cnt[t]; }
+	if(!d_min.ensure(N + 64) || !d_flat.ensure(N + 64)) return false;
+	if(n_st) {
+		IK(hipMemcpy(d_st.p, st.data(), (size_t)n_st * sizeof(RefStretch), hipMemcpyHostToDevice)); IK(hipMemset(d_ctr.p, 0, 64));
+		i1.out = d_min.p; i1.emit = 1;
+		hipLaunchKernelGGL(mm_ref_sketch_kernel, dim3(std::min<uint32_t>((n_st + 3) / 4, waves / 4)), dim3(256), 0, 0, i1); IK(hipGetLastError());
+		for(uint32_t t = 0; t < n_st; t++) {
+			if(!st[t].host || cnt[t] == 0) continue;
+			std::vector<IdxMini> tmp(cnt[t]); const std::vector<HMin> &hm = hostmin[st[t].pad];
+			for(uint32_t j = 0; j < cnt[t]; j++) tmp[j] = IdxMini{ hm[j].hash, hm[j].pos, (st[t].seq << 1) + hm[j].strand };
+			IK(hipMemcpy(d_min.p + st[t].out, tmp.data(), (size_t)cnt[t] * sizeof(IdxMini), hipMemcpyHostToDevice));
+		}
+	}
+	lap("sketch");
+	/* stable partition into buckets */
+	const uint32_t tile = 1u << 16, n_tiles = (uint32_t)((N + tile - 1) / tile);
+	DBuf<uint32_t> d_hist; DBuf<uint64_t> d_bofs;
+	if(!d_hist.ensure((uint64_t)std::max<uint32_t>(n_tiles, 1) * nb) || !d_bofs.ensure(nb + 2)) return false;
+	I2Args i2; i2.in = d_min.p; i2.n = N; i2.tile = tile; i2.n_tiles = n_tiles; i2.bbits = bbits; i2.hist = d_hist.p; i2.bofs = d_bofs.p; i2.out = d_flat.p;
+	std::vector<uint64_t> bofs(nb + 1, 0);
+	if(n_tiles) { hipLaunchKernelGGL(mm_idx_hist_kernel, dim3(n_tiles), dim3(64), 0, 0, i2); IK(hipGetLastError()); }
+	hipLaunchKernelGGL(mm_idx_colscan_kernel, dim3((nb + 255) / 256), dim3(256), 0, 0, i2); IK(hipGetLastError());
+	IK(hipMemcpy(bofs.data(), d_bofs.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost));
+	bofs[0] = 0; for(uint32_t bi = 0; bi < nb; bi++) bofs[bi + 1] += bofs[bi];
+	IK(hipMemcpy(d_bofs.p, bofs.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice));
+	if(n_tiles) { hipLaunchKernelGGL(mm_idx_scatter_kernel, dim3(n_tiles), dim3(64), 0, 0, i2); IK(hipGetLastError()); }
+	lap("bucket partition");
+	d_hist.release(); d_min.release();
+	/* per-bucket sort, records moved into (hrem, val) */
+	DBuf<uint32_t> d_ent, d_err; DBuf<uint64_t> d_hrem;
+	uint64_t *d_val = nullptr;
+	if(!d_ent.ensure(N + 64) || !d_hrem.ensure(N + 64) || !d_err.ensure(4) || hipMalloc(&d_val, (N + 64) * 8) != hipSuccess) return false;
+	mi->d_val = d_val; mi->n_val = N;
+	IK(hipMemset(d_ctr.p, 0, 64)); IK(hipMemset(d_err.p, 0, 16));
+	I3Args i3; i3.in = d_flat.p; i3.bofs = d_bofs.p; i3.n_buckets = nb; i3.key_bits = 64; i3.ent = d_ent.p; i3.hrem = d_hrem.p; i3.val = d_val; i3.counter = d_ctr.p; i3.err = d_err.p;
+	hipLaunchKernelGGL(mm_idx_sort_kernel, dim3(std::min<uint32_t>(nb, waves)), dim3(64), 0, 0, i3); IK(hipGetLastError());
+	uint32_t serr = 0; IK(hipMemcpy(&serr, d_err.p, 4, hipMemcpyDeviceToHost));
+	if(serr) { fprintf(stderr, "[minialign_amd] index (device): a bucket beyond what the sort addresses (flags %u)\n", serr); return false; }
+	lap("bucket sort");
+	d_flat.release(); d_ent.release();
+	/* key counts -> thresholds (minialign.c:2981-2986) */
+	DBuf<uint32_t> d_run, d_big; DBuf<unsigned long long> d_h; DBuf<uint64_t> d_cut;
+	const uint32_t big_cap = 1u << 20;
+	if(!d_run.ensure(N + 64) || !d_big.ensure(big_cap + 4) || !d_h.ensure(IDX_HB + 4) || !d_cut.ensure(nb + 1)) return false;
+	IK(hipMemset(d_h.p, 0, (size_t)(IDX_HB + 4) * 8)); IK(hipMemset(d_big.p + big_cap, 0, 16));
+	I4Args i4; memset(&i4, 0, sizeof(i4));
+	i4.hrem = d_hrem.p; i4.val = d_val; i4.n = N; i4.bofs = d_bofs.p; i4.n_buckets = nb; i4.bbits = bbits; i4.runlen = d_run.p; i4.hist = d_h.p; i4.big = d_big.p; i4.big_cap = big_cap; i4.n_big = d_big.p + big_cap;
+	i4.cut = d_cut.p; i4.n_keys = d_h.p + IDX_HB + 2;
+	const uint32_t grid_n = (uint32_t)((N + 255) / 256);
+	if(N) { hipLaunchKernelGGL(mm_idx_runs_kernel, dim3(grid_n), dim3(256), 0, 0, i4); IK(hipGetLastError()); }
+	std::vector<unsigned long long> ch(IDX_HB + 1); uint32_t n_big = 0;
+	IK(hipMemcpy(ch.data(), d_h.p, (size_t)(IDX_HB + 1) * 8, hipMemcpyDeviceToHost)); IK(hipMemcpy(&n_big, d_big.p + big_cap, 4, hipMemcpyDeviceToHost));
+	if(n_big > big_cap) { fprintf(stderr, "[minialign_amd] index (device): more than %u keys with %u occurrences and more\n", big_cap, IDX_HB); return false; }
+	std::vector<uint32_t> big(n_big); if(n_big) IK(hipMemcpy(big.data(), d_big.p, (size_t)n_big * 4, hipMemcpyDeviceToHost));
+	uint64_t n_cnt = 0; for(uint32_t c = 0; c <= IDX_HB; c++) n_cnt += ch[c];
+	for(uint32_t i = 0; i < o->n_frq; i++) {
+		if(o->frq[i] <= 0.0) { mi->occ[i] = UINT32_MAX; continue; }
+		if(n_cnt == 0) { mi->occ[i] = 1; continue; }
+		const uint32_t kk = (uint32_t)((1.0 - o->frq[i]) * n_cnt);
+		const uint64_t kth = std::min<uint64_t>(kk, n_cnt - 1);
+		uint64_t acc = 0; uint32_t v = 0; bool found = false;
+		for(uint32_t c = 0; c < IDX_HB; c++) { acc += ch[c]; if(acc > kth) { v = c; found = true; break; } }
+		if(!found) { auto it = big.begin() + (kth - acc); std::nth_element(big.begin(), it, big.end()); v = *it; }
+		mi->occ[i] = v + 1;
+	}
+	lap("key counts + thresholds");
+	/* cut (the reference's fill cursor stops at the first over-frequent key of a bucket), number of keys, table */
+	i4.max_cnt = mi->occ[mi->n_occ - 1];
+	IK(hipMemcpy(d_cut.p, bofs.data() + 1, (size_t)nb * 8, hipMemcpyHostToDevice));          /* cut[b] = end of the bucket unless a key exceeds the threshold */
+	if(N) { hipLaunchKernelGGL(mm_idx_cut_kernel, dim3(grid_n), dim3(256), 0, 0, i4); IK(hipGetLastError()); }
+	i4.slot = nullptr;
+	if(N) { hipLaunchKernelGGL(mm_idx_fill_kernel, dim3(grid_n), dim3(256), 0, 0, i4); IK(hipGetLastError()); }
+	unsigned long long n_keys = 0; IK(hipMemcpy(&n_keys, i4.n_keys, 8, hipMemcpyDeviceToHost));
+	uint64_t tsize = 1024; while(tsize < n_keys * 2) tsize <<= 1;
+	if(hipMalloc(&mi->d_slot, tsize * sizeof(IdxSlot)) != hipSuccess) return false;
+	IK(hipMemset(mi->d_slot, 0, tsize * sizeof(IdxSlot)));
+	mi->n_slot = tsize; mi->mask = tsize - 1; mi->n_keys = n_keys;
+	i4.slot = mi->d_slot; i4.mask = mi->mask;
+	if(N) { hipLaunchKernelGGL(mm_idx_fill_kernel, dim3(grid_n), dim3(256), 0, 0, i4); IK(hipGetLastError()); }
+	lap("table");
+#undef IK
+	mi->on_device = true;
+	return true;
+}
 
 extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 {
@@ -606,6 +767,11 @@ extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 	uint32_t b = std::min(o->k * 2, o->b);
 	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq;
 	if(o->circ_set) for(HSeq &q : mi->seq) q.circular = o->circ_names.empty() || std::find(o->circ_names.begin(), o->circ_names.end(), q.name) != o->circ_names.end();
+	if(!getenv("MM_HOST_INDEX")) {
+		/* the build runs on the device (mm_index.hpp); MM_HOST_INDEX=1 keeps it on the host threads below (machines without a GPU that only write index files; comparison) */
+		if(!idx_gen_device(o, mi, verbose)) { fprintf(stderr, "[minialign_amd] mm_idx_gen: the device build failed\n"); delete mi; return NULL; }
+		return mi;
+	}
 	const uint64_t nb = 1ull << b, bmask = nb - 1;
 	/* sketch every sequence and put (hrem, pos, rid) into its bucket in reference order (minialign.c:2790-2860): stretches of the sequences are
 	 * sketched on host threads, a histogram per stretch turns into write positions (stretch order inside a bucket = reference order), and the
@@ -752,6 +918,7 @@ struct MaiHead { uint32_t b, w, k, n_occ, occ[8]; uint64_t n_seq, n_slot, n_val,
 }
 extern "C" int mm_idx_dump(mm_idx_t const *mi, FILE *fp)
 {
+	if(!idx_fetch_host(mi)) return 1;
 	bool ok = true;
 	auto put = [&](const void *p, size_t n) { ok = ok && (n == 0 || fwrite(p, 1, n, fp) == n); };
 	MaiHead h; memset(&h, 0, sizeof(h));
@@ -796,6 +963,7 @@ extern "C" uint32_t mm_idx_max_len(mm_idx_t const *mi) { uint32_t m = 0; for(con
 extern "C" uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t max)
 {
 	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
+	if(!idx_fetch_host(mi)) return 0;
 	uint64_t s = hash(minier) & mi->mask;
 	while(mi->slot[s].key != 0) {
 		if(mi->slot[s].key == minier + 1) {
@@ -825,11 +993,6 @@ extern "C" uint32_t mm_sketch(uint8_t const *seq, uint32_t len, uint32_t w, uint
 /* =============================================================================================
  * device context + batch pipeline
  * ============================================================================================= */
-template<typename T> struct DBuf {
-	T *p = nullptr; uint64_t n = 0;
-	bool ensure(uint64_t want) { if(want <= n) return true; if(p) (void)hipFree(p); p = nullptr; n = 0; if(hipMalloc(&p, want * sizeof(T)) != hipSuccess) { fprintf(stderr, "[minialign_amd] hipMalloc of %.1f MB failed\n", want * sizeof(T) / 1e6); return false; } n = want; return true; }
-	void release() { if(p) (void)hipFree(p); p = nullptr; n = 0; }
-};
 
 struct mm_align_s {
 	mm_opt_s o; const mm_idx_s *mi;
@@ -872,7 +1035,7 @@ struct mm_align_s {
 	bool streaming = false;                /* stream_map is running on this context (the shared workspaces cannot be re-sized then) */
 	struct ChunkPool *chunk_pool = nullptr; /* device buffers of the text reader (primary context) */
 	mm_align_s *sib = nullptr;             /* second lane: own streams and pools, shares index / reference / DP constants (see mm_batch_run) */
-	bool is_sib = false; int dev = 0;
+	bool is_sib = false; int dev = 0; bool own_index = true;
 	mm_stats_t st; double t_wall0;
 	/* knobs (grown on overflow) */
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
@@ -1563,20 +1726,23 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	if(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess || hipFuncSetAttribute((const void *)mm_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess
 		|| hipFuncSetAttribute((const void *)mm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K2C_MAX_LDS_KB * 1024) != hipSuccess) { fprintf(stderr, "[minialign_amd] mm_align_init: kernel attributes rejected\n"); delete a; return NULL; }
 	/* reference: one arena, per-sequence offsets */
-	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
-	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
-	std::vector<uint8_t> all(total + 64, 4);
-	for(size_t i = 0; i < mi->seq.size(); i++) memcpy(all.data() + off[i], mi->seq[i].seq.data(), mi->seq[i].seq.size());
-	a->ref_ar = gaba_arena_upload(all.data(), total + 64);
-	if(!a->ref_ar) { delete a; return NULL; }
-	gaba_arena_unregister(a->ref_ar);                 /* `all` is a temporary: keep it out of the per-call API's section lookup */
+	std::vector<uint64_t> off; std::vector<uint32_t> len;
 	bool ok = true;
-	ok &= hipMalloc(&a->d_slot, mi->slot.size() * sizeof(IdxSlot)) == hipSuccess;
-	ok &= hipMalloc(&a->d_val, mi->val.size() * 8) == hipSuccess;
+	if(mi->on_device) {
+		/* an index built on this device: the packed reference, the table and the value array are there already */
+		int cur = 0; (void)hipGetDevice(&cur);
+		if(cur != mi->dev) { fprintf(stderr, "[minialign_amd] mm_align_init: the index was built on device %d, the context is on device %d\n", mi->dev, cur); delete a; return NULL; }
+		uint64_t total = 0; for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
+		a->ref_ar = mi->ref_ar; a->d_slot = mi->d_slot; a->d_val = mi->d_val; a->own_index = false;
+	} else {
+		a->ref_ar = upload_reference(mi, &off, &len);
+		if(!a->ref_ar) { delete a; return NULL; }
+		ok &= hipMalloc(&a->d_slot, mi->slot.size() * sizeof(IdxSlot)) == hipSuccess;
+		ok &= hipMalloc(&a->d_val, mi->val.size() * 8) == hipSuccess;
+		if(ok) { (void)hipMemcpy(a->d_slot, mi->slot.data(), mi->slot.size() * sizeof(IdxSlot), hipMemcpyHostToDevice); (void)hipMemcpy(a->d_val, mi->val.data(), mi->val.size() * 8, hipMemcpyHostToDevice); }
+	}
 	ok &= hipMalloc(&a->d_seq_len, len.size() * 4) == hipSuccess && hipMalloc(&a->d_seq_off, off.size() * 8) == hipSuccess;
 	if(!ok) { fprintf(stderr, "[minialign_amd] mm_align_init: index upload failed\n"); delete a; return NULL; }
-	(void)hipMemcpy(a->d_slot, mi->slot.data(), mi->slot.size() * sizeof(IdxSlot), hipMemcpyHostToDevice);
-	(void)hipMemcpy(a->d_val, mi->val.data(), mi->val.size() * 8, hipMemcpyHostToDevice);
 	(void)hipMemcpy(a->d_seq_len, len.data(), len.size() * 4, hipMemcpyHostToDevice);
 	(void)hipMemcpy(a->d_seq_off, off.data(), off.size() * 8, hipMemcpyHostToDevice);
 	a->dix.slot = a->d_slot; a->dix.mask = mi->mask; a->dix.val = a->d_val; a->dix.seq_len = a->d_seq_len; a->dix.seq_off = a->d_seq_off;
@@ -1605,8 +1771,9 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	for(auto *ps : a->pin_free) delete ps;
 	a->pin_free.clear();
 	if(!a->is_sib) {
-		(void)hipFree(a->d_slot); (void)hipFree(a->d_val); (void)hipFree(a->d_seq_len); (void)hipFree(a->d_seq_off); if(a->d_seq_circ) (void)hipFree(a->d_seq_circ);
-		gaba_arena_free(a->ref_ar); gaba_clean(a->gctx);
+		if(a->own_index) { (void)hipFree(a->d_slot); (void)hipFree(a->d_val); gaba_arena_free(a->ref_ar); }          /* (a device-built index keeps its own, mm_idx_destroy) */
+		(void)hipFree(a->d_seq_len); (void)hipFree(a->d_seq_off); if(a->d_seq_circ) (void)hipFree(a->d_seq_circ);
+		gaba_clean(a->gctx);
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
@@ -2391,7 +2558,7 @@ struct TextReader {
 			const size_t nb = (size_t)std::min<uint64_t>(piece, len - o); const int pi = (int)(k & 1);
 			CK(hipEventSynchronize(pev[pi]));
 			const char *sp = src->p + at + o; char *dp = (char *)pin[pi];
-			host_parallel(8, [&](uint32_t t, uint32_t nth) { const size_t lo = nb * t / nth, hi = nb * (t + 1) / nth; memcpy(dp + lo, sp + lo, hi - lo); }, 8);
+			host_parallel(24, [&](uint32_t t, uint32_t nth) { const size_t lo = nb * t / nth, hi = nb * (t + 1) / nth; memcpy(dp + lo, sp + lo, hi - lo); }, 24);
 			CK(hipMemcpyAsync(c->d + o, pin[pi], nb, hipMemcpyHostToDevice, st));
 			CK(hipEventRecord(pev[pi], st));
 		}
@@ -2455,7 +2622,8 @@ struct TextReader {
 	{
 		bool ok = hipSetDevice(a->dev) == hipSuccess;
 		ChunkPool *pool = a->chunk_pool;
-		uint64_t at = src->first, want = chunk_bytes;
+		/* (the first stretches are short, so that the first lanes have a batch to work on as early as possible) */
+		uint64_t at = src->first, want = std::min<uint64_t>(chunk_bytes, 64ull << 20);
 		while(ok && at < src->n) {
 			{ std::lock_guard<std::mutex> lk(mu); if(stop) break; }
 			const uint64_t len = std::min<uint64_t>(want, src->n - at); const bool last = at + len == src->n;
@@ -2469,7 +2637,7 @@ struct TextReader {
 			if(grow) { want *= 2; continue; }          /* a record longer than the stretch */
 			n_stretches++; n_records += recs.size();
 			for(const RRec &r : recs) add(r, ch);
-			at += consumed; want = chunk_bytes;
+			at += consumed; want = n_stretches < 3 ? std::min<uint64_t>(chunk_bytes, 64ull << 20) : chunk_bytes;
 			if(consumed == 0) { ok = false; break; }
 		}
 		if(ok) push_batch();

@@ -14,6 +14,11 @@ def _declared(header):
         names.add(m.group(1))
     return names
 
+@pytest.fixture(autouse=True)
+def _index_on_the_host(monkeypatch):
+    """no GPU in these tests: the index is built by the host threads (MM_HOST_INDEX; the default is the device build of mm_index.hpp, tests/test_index_gpu.py)"""
+    monkeypatch.setenv('MM_HOST_INDEX', '1')
+
 def test_library_exports_every_declared_symbol():
     lib = os.path.join(ROOT, 'minialign_amd', 'libminialign_amd.so')
     assert os.path.exists(lib), 'run __graft_entry__.build() first'
