@@ -99,7 +99,9 @@ inline void sort_res(ResEnt *p, size_t n) { auto key = [](const ResEnt &m) { ret
  * sequences
  * --------------------------------------------------------------------------------------------- */
 struct HSeq { std::string name; std::vector<uint8_t> seq; std::string qual, comment; bool has_comment = false; bool circular = false;
-	uint64_t t_off = 0; uint32_t t_len = 0; int32_t t_id = -1; };          /* where the bases stand in the text of the file (when that is kept): every byte of the extent but '\n' is a base */     /* qual / comment: kept on request only (-Q, -T CO) */
+	uint64_t t_off = 0; uint32_t t_len = 0; int32_t t_id = -1;
+	uint32_t len = 0;          /* a reference sequence whose bases stayed in the text (device build of the index): its length; seq is filled when a printer asks (ref_codes) */
+	uint32_t blen() const { return len ? len : (uint32_t)seq.size(); } };          /* where the bases stand in the text of the file (when that is kept): every byte of the extent but '\n' is a base */     /* qual / comment: kept on request only (-Q, -T CO) */
 
 /* run fn(t, nth) on up to `cap` (default 32) host threads (reads / records are independent in every host stage that uses this) */
 template<typename F> static void host_parallel(uint32_t want, F fn, uint32_t cap = 32)
@@ -588,6 +590,25 @@ extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char
 /* =============================================================================================
  * index (host): mm_idx_gen, minialign.c:2951-3040
  * ============================================================================================= */
+/* ---- the text of an input file in host memory (a mapping of the file, or what stdin / gzip gave) and its records as the device reader finds them ---- */
+struct TextSrc {
+	const char *p = nullptr; uint64_t n = 0; char delim = 0; uint64_t first = 0;      /* delim / first: the record delimiter and where the first record starts (minialign.c:1784-1792) */
+	void *map = nullptr; uint64_t map_len = 0; std::vector<char> own;
+	~TextSrc() { if(map) munmap(map, map_len); }
+};
+struct RRec { uint64_t start, hdr_end, t_off; uint32_t t_len, n_bases; uint64_t q_off; uint32_t q_len; };      /* absolute offsets in the text: delimiter, end of the header line, sequence extent, quality extent */
+struct DevChunk { uint8_t *d = nullptr; uint64_t cap = 0; uint64_t off = 0; uint32_t n = 0; };                  /* a stretch of the text in HBM: text[off, off + n) */
+struct ChunkPool {          /* device buffers for stretches of text, reused while a context lives (a hipFree in mid-run would stall every stream of the device) */
+	std::mutex mu; std::vector<DevChunk *> idle, all;
+	DevChunk *get(uint64_t bytes)
+	{
+		{ std::lock_guard<std::mutex> lk(mu); for(size_t i = 0; i < idle.size(); i++) { if(idle[i]->cap >= bytes) { DevChunk *c = idle[i]; idle.erase(idle.begin() + i); return c; } } }
+		DevChunk *c = new DevChunk(); if(hipMalloc(&c->d, bytes) != hipSuccess) { delete c; return nullptr; } c->cap = bytes;
+		std::lock_guard<std::mutex> lk(mu); all.push_back(c); return c;
+	}
+	void put(DevChunk *c) { std::lock_guard<std::mutex> lk(mu); idle.push_back(c); }
+	~ChunkPool() { for(DevChunk *c : all) { (void)hipFree(c->d); delete c; } }
+};
 struct mm_idx_s {
 	uint32_t b, w, k, n_occ; uint32_t occ[8];
 	std::vector<HSeq> seq;
@@ -597,6 +618,7 @@ struct mm_idx_s {
 	uint64_t n_keys = 0;
 	/* an index built on the device (idx_gen_device) lives there: the table, the value array (the sorted (pos | rid << 32) of every minimizer; a list is a run inside it)
 	 * and the packed reference; mm_align_init adopts them, the host copy above is fetched only when somebody asks (mm_idx_dump, mm_idx_get) */
+	std::shared_ptr<TextSrc> rtext; std::vector<RRec> rrec;          /* the reference's text and records when the device reader scanned it (the sequences' base codes are then made on demand, ref_codes) */
 	bool on_device = false; int dev = 0; IdxSlot *d_slot = nullptr; uint64_t *d_val = nullptr; uint64_t n_slot = 0, n_val = 0; gaba_arena_t *ref_ar = nullptr;
 	mutable std::mutex fetch_mu;
 	double build_ms[8] = { 0 };          /* device build: arena, sketch, partition, sort, thresholds, table */
@@ -620,13 +642,30 @@ template<typename T> struct DBuf {
 	void release() { if(p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+/* base codes (0..3, 4 = N) of reference sequence i.  A reference the device reader scanned keeps its bases in the text; the few consumers on the host (MD:Z, MAF rows,
+ * index files, the wrap-around sketch of a circular sequence) have them made here, once */
+static const std::vector<uint8_t> &ref_codes(const mm_idx_s *cmi, uint32_t i)
+{
+	mm_idx_s *mi = const_cast<mm_idx_s *>(cmi); HSeq &q = mi->seq[i];
+	if(!mi->rtext || q.len == 0) return q.seq;
+	std::lock_guard<std::mutex> lk(mi->fetch_mu);
+	if(q.seq.empty()) {
+		static const uint8_t enc[16] = { 0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 4, 0 };
+		const RRec &r = mi->rrec[i]; std::vector<uint8_t> c(r.n_bases);
+		const char *p = mi->rtext->p + r.t_off, *e = p + r.t_len; uint32_t k = 0;
+		for(; p < e && k < r.n_bases; p++) { if(*p != '\n') c[k++] = enc[*p & 15]; }
+		q.seq.swap(c);
+	}
+	return q.seq;
+}
+static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::vector<uint64_t> &off, std::vector<uint32_t> &len);
 /* the packed reference in HBM: one arena, every sequence on a multiple of 64 bases */
 static gaba_arena_t *upload_reference(const mm_idx_s *mi, std::vector<uint64_t> *off_out, std::vector<uint32_t> *len_out)
 {
 	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
-	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
+	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back(s.blen()); total += ((uint64_t)s.blen() + 63) & ~63ull; }
 	std::vector<uint8_t> all(total + 64, 4);
-	host_parallel((uint32_t)mi->seq.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < mi->seq.size(); i += nth) memcpy(all.data() + off[i], mi->seq[i].seq.data(), mi->seq[i].seq.size()); }, 32);
+	host_parallel((uint32_t)mi->seq.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < mi->seq.size(); i += nth) { const std::vector<uint8_t> &c = ref_codes(mi, (uint32_t)i); memcpy(all.data() + off[i], c.data(), c.size()); } }, 32);
 	gaba_arena_t *ar = gaba_arena_upload(all.data(), total + 64);
 	if(ar) gaba_arena_unregister(ar);                 /* `all` is a temporary: keep it out of the per-call API's section lookup */
 	if(off_out) off_out->swap(off);
@@ -637,7 +676,7 @@ static gaba_arena_t *upload_reference(const mm_idx_s *mi, std::vector<uint64_t> 
  * occurrence thresholds from the histogram of key counts, table fill.  The sequences are parsed by the host (mi->seq); circular ones (-c) are sketched there too
  * (their wrap-around pass is a serial special case, mm_sketch_cap :2437) and take their place in reference order.  false: no device / out of memory / a bucket beyond
  * what the sort's entries address -- the caller reports it (no silent host build). */
-static bool idx_gen_device(const mm_opt_s *o, mm_idx_s *mi, bool verbose)
+static bool idx_gen_device(const mm_opt_s *o, mm_idx_s *mi, const char *ref_fasta, bool verbose)
 {
 	int ndev = 0; if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "[minialign_amd] mm_idx_gen: no HIP device (MM_HOST_INDEX=1 builds the index on the host)\n"); return false; }
 	(void)hipGetDevice(&mi->dev);
@@ -645,9 +684,10 @@ static bool idx_gen_device(const mm_opt_s *o, mm_idx_s *mi, bool verbose)
 	auto lap = [&](const char *what) { (void)hipDeviceSynchronize(); const double t = now_ms(); if(lapi < 8) mi->build_ms[lapi++] = t - tv; if(verbose) fprintf(stderr, "[minialign_amd] index (device): %s %.1f ms\n", what, t - tv); tv = t; };
 #define IK(_e) do { hipError_t _r = (_e); if(_r != hipSuccess) { fprintf(stderr, "[minialign_amd] index (device): HIP error %s at line %d\n", hipGetErrorString(_r), __LINE__); return false; } } while(0)
 	std::vector<uint64_t> off; std::vector<uint32_t> len;
-	mi->ref_ar = upload_reference(mi, &off, &len);
-	if(!mi->ref_ar) return false;
-	lap("reference arena");
+	/* the reference goes the way the reads go: its text to HBM, records found (K0r) and bases packed (K0) there, straight into the arena */
+	if(!ref_to_device(o, mi, ref_fasta, off, len) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); return false; }
+	if(o->circ_set) for(HSeq &q : mi->seq) q.circular = o->circ_names.empty() || std::find(o->circ_names.begin(), o->circ_names.end(), q.name) != o->circ_names.end();
+	lap("reference: text to HBM, records, packed arena");
 	const uint32_t bbits = mi->b, nb = 1u << bbits, k = mi->k, w = mi->w;
 	/* stretches: 2^18 positions each; a circular sequence is one stretch, sketched on the host */
 	std::vector<RefStretch> st; std::vector<std::vector<HMin>> hostmin;
@@ -659,7 +699,7 @@ static bool idx_gen_device(const mm_opt_s *o, mm_idx_s *mi, bool verbose)
 	}
 	if(!hostmin.empty()) {
 		std::vector<uint32_t> which; for(uint32_t t = 0; t < st.size(); t++) if(st[t].host) which.push_back(t);
-		host_parallel((uint32_t)which.size(), [&](uint32_t t, uint32_t nth) { for(size_t j = t; j < which.size(); j += nth) { const RefStretch &q = st[which[j]]; const HSeq &sq = mi->seq[q.seq]; sketch_host_circular(sq.seq.data(), (uint32_t)sq.seq.size(), k, w, hostmin[q.pad]); } }, 32);
+		host_parallel((uint32_t)which.size(), [&](uint32_t t, uint32_t nth) { for(size_t j = t; j < which.size(); j += nth) { const RefStretch &q = st[which[j]]; const std::vector<uint8_t> &sq = ref_codes(mi, q.seq); sketch_host_circular(sq.data(), (uint32_t)sq.size(), k, w, hostmin[q.pad]); } }, 32);
 	}
 	const uint32_t n_st = (uint32_t)st.size();
 	DBuf<RefStretch> d_st; DBuf<uint32_t> d_cnt, d_ctr; DBuf<IdxMini> d_min, d_flat;
@@ -762,16 +802,17 @@ extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
 	mm_idx_t *mi = new mm_idx_s();
 	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
 	auto lap = [&](const char *what) { if(verbose) { double t = now_ms(); fprintf(stderr, "[minialign_amd] index: %s %.1f ms\n", what, t - tv); tv = t; } };
-	if(!read_seq_file(ref_fasta, mi->seq, o->min_len) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); delete mi; return NULL; }
-	lap("read + parse");
 	uint32_t b = std::min(o->k * 2, o->b);
 	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq;
-	if(o->circ_set) for(HSeq &q : mi->seq) q.circular = o->circ_names.empty() || std::find(o->circ_names.begin(), o->circ_names.end(), q.name) != o->circ_names.end();
 	if(!getenv("MM_HOST_INDEX")) {
-		/* the build runs on the device (mm_index.hpp); MM_HOST_INDEX=1 keeps it on the host threads below (machines without a GPU that only write index files; comparison) */
-		if(!idx_gen_device(o, mi, verbose)) { fprintf(stderr, "[minialign_amd] mm_idx_gen: the device build failed\n"); delete mi; return NULL; }
+		/* the build runs on the device (mm_index.hpp), reference parsing included; MM_HOST_INDEX=1 keeps all of it on the host threads below (machines without a GPU
+		 * that only write index files; comparison) */
+		if(!idx_gen_device(o, mi, ref_fasta, verbose)) { fprintf(stderr, "[minialign_amd] mm_idx_gen: the device build failed\n"); delete mi; return NULL; }
 		return mi;
 	}
+	if(!read_seq_file(ref_fasta, mi->seq, o->min_len) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); delete mi; return NULL; }
+	lap("read + parse");
+	if(o->circ_set) for(HSeq &q : mi->seq) q.circular = o->circ_names.empty() || std::find(o->circ_names.begin(), o->circ_names.end(), q.name) != o->circ_names.end();
 	const uint64_t nb = 1ull << b, bmask = nb - 1;
 	/* sketch every sequence and put (hrem, pos, rid) into its bucket in reference order (minialign.c:2790-2860): stretches of the sequences are
 	 * sketched on host threads, a histogram per stretch turns into write positions (stretch order inside a bucket = reference order), and the
@@ -924,9 +965,10 @@ extern "C" int mm_idx_dump(mm_idx_t const *mi, FILE *fp)
 	MaiHead h; memset(&h, 0, sizeof(h));
 	h.b = mi->b; h.w = mi->w; h.k = mi->k; h.n_occ = mi->n_occ; memcpy(h.occ, mi->occ, sizeof(h.occ)); h.n_seq = mi->seq.size(); h.n_slot = mi->slot.size(); h.n_val = mi->val.size(); h.n_keys = mi->n_keys;
 	put(&MAI_MAGIC, 4); put(&h, sizeof(h));
-	for(const HSeq &q : mi->seq) {
-		uint64_t l[3] = { q.name.size(), q.seq.size(), q.circular ? 1u : 0u };
-		put(l, sizeof(l)); put(q.name.data(), l[0]); put(q.seq.data(), l[1]);
+	for(uint32_t i = 0; i < mi->seq.size(); i++) {
+		const HSeq &q = mi->seq[i]; const std::vector<uint8_t> &codes = ref_codes(mi, i);
+		uint64_t l[3] = { q.name.size(), codes.size(), q.circular ? 1u : 0u };
+		put(l, sizeof(l)); put(q.name.data(), l[0]); put(codes.data(), l[1]);
 	}
 	put(mi->slot.data(), mi->slot.size() * sizeof(IdxSlot)); put(mi->val.data(), mi->val.size() * sizeof(uint64_t));
 	return ok && fflush(fp) == 0 ? 0 : 1;
@@ -959,7 +1001,7 @@ extern "C" mm_idx_t *mm_idx_load(FILE *fp, int *at_eof)
 }
 extern "C" uint32_t mm_idx_n_seq(mm_idx_t const *mi) { return (uint32_t)mi->seq.size(); }
 extern "C" uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i) { return mi->occ[i]; }
-extern "C" uint32_t mm_idx_max_len(mm_idx_t const *mi) { uint32_t m = 0; for(const HSeq &q : mi->seq) m = std::max<uint32_t>(m, (uint32_t)q.seq.size()); return m; }
+extern "C" uint32_t mm_idx_max_len(mm_idx_t const *mi) { uint32_t m = 0; for(const HSeq &q : mi->seq) m = std::max<uint32_t>(m, q.blen()); return m; }
 extern "C" uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t max)
 {
 	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
@@ -1209,7 +1251,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				uint32_t cur = a->rlen_carry;
 				for(uint32_t i = 0; i < n_reads; i++) {
 					hst[i].rlen = cur;
-					if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size();
+					if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen();
 				}
 			}
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
@@ -1412,12 +1454,12 @@ template<typename F> void path_walk_reverse(const uint32_t *path, uint64_t offse
 }
 /* MD:Z (mm_print_sam_md, minialign.c:5243-5301): match counts, the reference base at a mismatch, ^ + reference bases at a deletion.  On the
  * reverse strand the query base is complemented by xor 3, so an N there never equals the reference's N. */
-void sam_md(std::string &s, const HSeq &r, const uint8_t *qseq, uint32_t qlen, const gaba::Segment &sg, const uint32_t *path)
+void sam_md(std::string &s, const std::vector<uint8_t> &rcodes, const uint8_t *qseq, uint32_t qlen, const gaba::Segment &sg, const uint32_t *path)
 {
 	static const char dec[] = "ACGTN\0\0\0\0\0\0\0\0\0\0\0";
 	s += "\tMD:Z:";
 	const bool rev = (~sg.bid & 1) != 0;
-	const uint8_t *rp = r.seq.data() + (r.seq.size() - sg.apos - sg.alen), *rb = rp;
+	const uint8_t *rp = rcodes.data() + (rcodes.size() - sg.apos - sg.alen), *rb = rp;
 	const uint8_t *qp = rev ? qseq + (qlen - sg.bpos) : qseq + (qlen - sg.bpos - sg.blen);
 	path_walk_reverse(path, sg.ppos, (uint64_t)sg.alen + sg.blen, [&](char op, uint64_t c) {
 		if(op == 'D') { put_num(s, (uint64_t)(rp - rb)); s.push_back('^'); rb = rp + c; for(uint64_t i = 0; i < c; i++) s.push_back(dec[*rp++ & 15]); }
@@ -1458,7 +1500,7 @@ void sam_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 		for(uint32_t j = al.slen; j > 0; j--) {
 			const gaba::Segment &sg = segs[al.seg_off + j - 1];
 			const HSeq &r = a->mi->seq[sg.aid >> 1];
-			uint32_t rs = (uint32_t)r.seq.size() - sg.apos - sg.alen;
+			uint32_t rs = r.blen() - sg.apos - sg.alen;
 			uint32_t hl = qlen - sg.bpos - sg.blen, tl = sg.bpos;
 			uint32_t qs = (flag & 0x900) ? hl : 0, qe = qlen - ((flag & 0x900) ? tl : 0);
 			s += qname; s.push_back('\t'); put_num(s, flag | ((~sg.bid & 1) << 4)); s.push_back('\t');
@@ -1480,7 +1522,7 @@ void sam_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 				if(tag(3)) { s += "\tIH:i:"; put_num(s, i); }
 				if(tag(4)) { s += "\tAS:i:"; put_int(s, al.score); }
 				if(tag(6)) { s += "\tNM:i:"; put_num(s, edit(al)); }
-				if(tag(8)) sam_md(s, r, qseq, qlen, sg, paths + al.path_off);
+				if(tag(8)) sam_md(s, ref_codes(a->mi, sg.aid >> 1), qseq, qlen, sg, paths + al.path_off);
 			}
 			if(i == 0 && j == al.slen) {
 				flag = 0x800;
@@ -1494,7 +1536,7 @@ void sam_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 							if(x == 0 && y == bl.slen) continue;
 							const gaba::Segment &sh = segs[bl.seg_off + y - 1];
 							const HSeq &rr = a->mi->seq[sh.aid >> 1];
-							s += a->mi->seq[0].name; s.push_back(','); put_num(s, (uint32_t)rr.seq.size() - sh.apos - sh.alen + 1); s.push_back(',');
+							s += a->mi->seq[0].name; s.push_back(','); put_num(s, rr.blen() - sh.apos - sh.alen + 1); s.push_back(',');
 							s.push_back((sh.bid & 1) ? '+' : '-'); s.push_back(',');
 							uint32_t h2 = qlen - sh.bpos - sh.blen, t2 = sh.bpos;
 							if(h2) { put_num(s, h2); s.push_back('H'); }
@@ -1545,12 +1587,12 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 	for(uint32_t i = 0; i < n; i++) {
 		const AlnRec &al = alns[reg.aln[i].aln];
 		const gaba::Segment &sg = segs[al.seg_off + al.slen - 1], &eg = segs[al.seg_off];
-		const HSeq &r = a->mi->seq[sg.aid >> 1]; const uint32_t rl = (uint32_t)r.seq.size();
+		const HSeq &r = a->mi->seq[sg.aid >> 1]; const uint32_t rl = r.blen();
 		const uint32_t dcnt = al.dcnt, mcnt = h_d2u32((double)dcnt * al.identity), gcnt = al.agcnt + al.bgcnt;
 		if(a->o.format == 1) {                 /* mm_print_maf_mapped, :5476 */
 			for(uint32_t j = al.slen; j > 0; j--) {
 				const gaba::Segment &g = segs[al.seg_off + j - 1];
-				const HSeq &rr = a->mi->seq[g.aid >> 1]; const uint32_t rrl = (uint32_t)rr.seq.size();
+				const HSeq &rr = a->mi->seq[g.aid >> 1]; const uint32_t rrl = rr.blen();
 				const uint32_t rs = rrl - g.apos - g.alen, qs = qlen - g.bpos - g.blen;
 				const uint64_t plen = (uint64_t)g.alen + g.blen;
 				s += "a score="; put_num(s, (uint32_t)al.score); s.push_back('\n');
@@ -1562,7 +1604,7 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 				s += "+ "; q2.push_back((g.bid & 1) ? '+' : '-'); q2.push_back(' ');
 				put_pair(s, q2, rrl, qlen); s.push_back(' '); q2.push_back(' ');
 				buf.resize(plen + 64);
-				uint64_t m = gaba_dump_seq_reverse(buf.data(), buf.size(), GABA_SEQ_A, paths + al.path_off, g.ppos, plen, rr.seq.data() + rs, '-');
+				uint64_t m = gaba_dump_seq_reverse(buf.data(), buf.size(), GABA_SEQ_A, paths + al.path_off, g.ppos, plen, ref_codes(a->mi, g.aid >> 1).data() + rs, '-');
 				s.append(buf.data(), m); s.push_back('\n');
 				s += q2;
 				m = gaba_dump_seq_reverse(buf.data(), buf.size(), GABA_SEQ_B | ((g.bid & 1) ? GABA_SEQ_FW : GABA_SEQ_RV), paths + al.path_off, g.ppos, plen,
@@ -1732,7 +1774,7 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 		/* an index built on this device: the packed reference, the table and the value array are there already */
 		int cur = 0; (void)hipGetDevice(&cur);
 		if(cur != mi->dev) { fprintf(stderr, "[minialign_amd] mm_align_init: the index was built on device %d, the context is on device %d\n", mi->dev, cur); delete a; return NULL; }
-		uint64_t total = 0; for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back((uint32_t)s.seq.size()); total += (s.seq.size() + 63) & ~63ull; }
+		uint64_t total = 0; for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back(s.blen()); total += ((uint64_t)s.blen() + 63) & ~63ull; }
 		a->ref_ar = mi->ref_ar; a->d_slot = mi->d_slot; a->d_val = mi->d_val; a->own_index = false;
 	} else {
 		a->ref_ar = upload_reference(mi, &off, &len);
@@ -1788,7 +1830,7 @@ extern "C" void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *
 {
 	if(a->o.format != 0) return;          /* only SAM has a header (minialign.c:5666-5671) */
 	fputs("@HD\tVN:1.0\tSO:unsorted\n", out);
-	for(const HSeq &s : a->mi->seq) fprintf(out, "@SQ\tSN:%s\tLN:%u\n", s.name.c_str(), (uint32_t)s.seq.size());
+	for(const HSeq &s : a->mi->seq) fprintf(out, "@SQ\tSN:%s\tLN:%u\n", s.name.c_str(), s.blen());
 	if((a->o.ptags() & 1) && !a->o.rg_line.empty()) fprintf(out, "%s\n", a->o.rg_line.c_str());       /* minialign.c:5111 */
 	fprintf(out, "@PG\tID:minialign\tPN:minialign\tVN:%s\tCL:%s\n", "0.6.0-devel", arg_line ? arg_line : "");
 }
@@ -1815,25 +1857,6 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
  * carried reference-length state asks for; results stay in HBM), finish (D2H, post-map, SAM text)
  * --------------------------------------------------------------------------------------------- */
 struct mm_reads_s { std::vector<HSeq> r; uint64_t bases = 0; std::vector<std::shared_ptr<std::vector<char>>> text; };          /* text: the files' text when kept (reads then carry where their bases stand in it: the device packs from there) */
-/* ---- the text of an input file in host memory (a mapping of the file, or what stdin / gzip gave) and its records as the device reader finds them ---- */
-struct TextSrc {
-	const char *p = nullptr; uint64_t n = 0; char delim = 0; uint64_t first = 0;      /* delim / first: the record delimiter and where the first record starts (minialign.c:1784-1792) */
-	void *map = nullptr; uint64_t map_len = 0; std::vector<char> own;
-	~TextSrc() { if(map) munmap(map, map_len); }
-};
-struct RRec { uint64_t start, hdr_end, t_off; uint32_t t_len, n_bases; uint64_t q_off; uint32_t q_len; };      /* absolute offsets in the text: delimiter, end of the header line, sequence extent, quality extent */
-struct DevChunk { uint8_t *d = nullptr; uint64_t cap = 0; uint64_t off = 0; uint32_t n = 0; };                  /* a stretch of the text in HBM: text[off, off + n) */
-struct ChunkPool {          /* device buffers for stretches of text, reused while a context lives (a hipFree in mid-run would stall every stream of the device) */
-	std::mutex mu; std::vector<DevChunk *> idle, all;
-	DevChunk *get(uint64_t bytes)
-	{
-		{ std::lock_guard<std::mutex> lk(mu); for(size_t i = 0; i < idle.size(); i++) { if(idle[i]->cap >= bytes) { DevChunk *c = idle[i]; idle.erase(idle.begin() + i); return c; } } }
-		DevChunk *c = new DevChunk(); if(hipMalloc(&c->d, bytes) != hipSuccess) { delete c; return nullptr; } c->cap = bytes;
-		std::lock_guard<std::mutex> lk(mu); all.push_back(c); return c;
-	}
-	void put(DevChunk *c) { std::lock_guard<std::mutex> lk(mu); idle.push_back(c); }
-	~ChunkPool() { for(DevChunk *c : all) { (void)hipFree(c->d); delete c; } }
-};
 struct Batch {
 	uint32_t n = 0; uint64_t total = 0; uint32_t max_qlen = 0;
 	/* reads that stand in a text the device reader scanned: no parsed record, no base codes on the host -- names, bases and qualities are read off the text when a
@@ -1971,7 +1994,7 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 			if(hst[i].err) { if(!overflow && getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   read %u (%u bases) reports err 0x%x: seed_n %u n_seed %u seed_cap %u n_root %u\n", i, b.lens[i], hst[i].err, hst[i].seed_n, hst[i].n_seed, hst[i].seed_cap, hst[i].n_root); overflow = true; }
 			uint32_t truth = cur;
 			if(truth != used[i] && hst[i].apos0 != gaba::NIL && !hst[i].cond0 && ((hst[i].apos0 >= used[i]) != (hst[i].apos0 >= truth))) { redo.push_back(i); redo_rlen.push_back(truth); }
-			cur = hst[i].rid_last != gaba::NIL ? (uint32_t)a->mi->seq[hst[i].rid_last].seq.size() : truth;
+			cur = hst[i].rid_last != gaba::NIL ? a->mi->seq[hst[i].rid_last].blen() : truth;
 		}
 		if(redo.empty() || overflow) break;
 		a->st.reruns += redo.size();
@@ -1994,7 +2017,7 @@ int batch_run_spec(mm_align_t *a, Batch &b)
 	std::vector<ReadState> &hst = b.hst;
 	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return -1;
 	b.used.assign(n_reads, 0);
-	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = (uint32_t)a->mi->seq[hst[i].pred_rid].seq.size(); } }
+	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen(); } }
 	for(uint32_t i = 0; i < n_reads; i++) if(hst[i].err) return 1;
 	return 0;
 }
@@ -2017,7 +2040,7 @@ bool batch_grow(mm_align_t *a, Batch &b)
 }
 uint32_t batch_carry_out(const mm_align_t *a, const Batch &b, uint32_t cur)
 {
-	for(uint32_t i = 0; i < b.n; i++) { if(b.hst[i].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[b.hst[i].rid_last].seq.size(); }
+	for(uint32_t i = 0; i < b.n; i++) { if(b.hst[i].rid_last != gaba::NIL) cur = a->mi->seq[b.hst[i].rid_last].blen(); }
 	return cur;
 }
 bool batch_run(mm_align_t *a, Batch &b)
@@ -2515,7 +2538,7 @@ bool host_find_fastq(const char *t, uint64_t n, bool last, bool keep_qual, std::
 	return true;
 }
 struct TextReader {
-	mm_align_t *a; std::shared_ptr<TextSrc> src; uint32_t min_len; bool keep_qual; int lanes;
+	ChunkPool *pool = nullptr; int dev = 0; std::shared_ptr<TextSrc> src; uint32_t min_len; bool keep_qual; int lanes;
 	uint64_t chunk_bytes = 256ull << 20;
 	hipStream_t st = nullptr; void *pin[2] = { nullptr, nullptr }; size_t pin_cap = 0; hipEvent_t pev[2] = { nullptr, nullptr };
 	DBuf<uint64_t> d_ma, d_mb; DBuf<uint32_t> d_blk, d_pos, d_cum, d_flag; DBuf<TextRec> d_rec;
@@ -2620,8 +2643,7 @@ struct TextReader {
 	}
 	void run()
 	{
-		bool ok = hipSetDevice(a->dev) == hipSuccess;
-		ChunkPool *pool = a->chunk_pool;
+		bool ok = hipSetDevice(dev) == hipSuccess;
 		/* (the first stretches are short, so that the first lanes have a batch to work on as early as possible) */
 		uint64_t at = src->first, want = std::min<uint64_t>(chunk_bytes, 64ull << 20);
 		while(ok && at < src->n) {
@@ -2631,7 +2653,7 @@ struct TextReader {
 			DevChunk *c = pool->get(std::max<uint64_t>(chunk_bytes, (len + 63) & ~63ull) + 64);
 			if(!c) { ok = false; break; }
 			c->off = at; c->n = (uint32_t)len;
-			std::shared_ptr<DevChunk> ch(c, [pool](DevChunk *q) { pool->put(q); });
+			ChunkPool *pl = pool; std::shared_ptr<DevChunk> ch(c, [pl](DevChunk *q) { pl->put(q); });
 			std::vector<RRec> recs; uint64_t consumed = 0; bool grow = false;
 			if(!scan_stretch(at, len, last, c, recs, consumed, grow)) { ok = false; break; }
 			if(grow) { want *= 2; continue; }          /* a record longer than the stretch */
@@ -2646,13 +2668,18 @@ struct TextReader {
 		if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd] reader: %lu records in %lu stretches (%lu through the host's sequential FASTQ reader), text to HBM + marks %.1f ms, record tables %.1f ms\n",
 			(unsigned long)n_records, (unsigned long)n_stretches, (unsigned long)n_host_scanned, t_io, t_scan);
 	}
-	bool start()
+	/* stream, staging buffers (no thread): scan_stretch can be called after this */
+	bool init()
 	{
-		if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
 		if(const char *e = getenv("MM_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) & ~63ull;          /* test hook: small stretches */
 		pin_cap = 32u << 20;
 		if(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
 		for(int i = 0; i < 2; i++) { if(hipHostMalloc(&pin[i], pin_cap, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&pev[i], hipEventDisableTiming) != hipSuccess) return false; }
+		return true;
+	}
+	bool start()
+	{
+		if(!init()) return false;
 		/* batch size as batch_spans: 300 Mb; a text smaller than lanes x that is cut into one batch per lane (its bases are a little fewer than its bytes) */
 		if(getenv("MM_BATCH_BASES")) max_bases = (uint64_t)atoll(getenv("MM_BATCH_BASES"));
 		else if(src->n < (uint64_t)lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, src->n / (uint64_t)lanes + (1ull << 20));
@@ -2673,6 +2700,63 @@ struct TextReader {
 	}
 };
 } /* anonymous */
+/* the reference through the device reader: its text in stretches of 1 GB to HBM, records found there, bases converted and packed there into ONE arena (every sequence
+ * on a multiple of 64 bases, N in between); names from the header lines; nothing of a sequence's bases is touched by the host (ref_codes makes codes for the few host
+ * consumers on demand) */
+static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::vector<uint64_t> &off, std::vector<uint32_t> &len)
+{
+	std::shared_ptr<TextSrc> src = open_text(fn);
+	if(!src) return false;
+	ChunkPool pool; TextReader rd; rd.pool = &pool; rd.dev = mi->dev; rd.src = src; rd.min_len = o->min_len; rd.keep_qual = false; rd.lanes = 1;
+	rd.chunk_bytes = 1ull << 30;
+	if(!rd.init()) return false;
+	DBuf<uint8_t> d_codes; DBuf<TextRead> d_ti; DBuf<uint32_t> d_tn;
+	const uint64_t codes_cap = src->n + (256ull << 20);          /* bases + what the alignment of the sequences to 64 adds (room for four million sequences) */
+	if(!d_codes.ensure(codes_cap) || hipMemsetAsync(d_codes.p, 4, codes_cap, rd.st) != hipSuccess) return false;
+	uint64_t at = src->first, want = rd.chunk_bytes, total = 0; bool ok = true;
+	while(ok && at < src->n) {
+		const uint64_t ln = std::min<uint64_t>(want, src->n - at); const bool last = at + ln == src->n;
+		if(ln > 0x7fff0000ull) { fprintf(stderr, "[minialign_amd] reader: a reference sequence of more than 2 GB of text\n"); ok = false; break; }
+		DevChunk *c = pool.get(((ln + 63) & ~63ull) + 64);
+		if(!c) { ok = false; break; }
+		c->off = at; c->n = (uint32_t)ln;
+		std::vector<RRec> recs; uint64_t consumed = 0; bool grow = false;
+		ok = rd.scan_stretch(at, ln, last, c, recs, consumed, grow);
+		if(ok && grow) { pool.put(c); want = std::min<uint64_t>(want * 2, 0x7fff0000ull); if(ln == 0x7fff0000ull) ok = false; continue; }
+		if(ok) {
+			std::vector<TextRead> tr;
+			for(const RRec &r : recs) {
+				if(r.n_bases < o->min_len) continue;          /* -L applies to the reference side as well (minialign.c:2077) */
+				mi->seq.emplace_back(); HSeq &q = mi->seq.back();
+				parse_header(src->p + r.start + 1, src->p + src->n, q, false); q.len = r.n_bases;
+				mi->rrec.push_back(r); off.push_back(total); len.push_back(r.n_bases);
+				tr.push_back(TextRead{ r.t_off - at, r.t_len, 0, total }); total += ((uint64_t)r.n_bases + 63) & ~63ull;
+			}
+			if(total + 64 > codes_cap) { fprintf(stderr, "[minialign_amd] reader: more reference sequences than the arena was laid out for\n"); ok = false; }
+			if(ok && !tr.empty()) {
+				ok = d_ti.ensure(tr.size()) && d_tn.ensure(tr.size()) && hipMemcpyAsync(d_ti.p, tr.data(), tr.size() * sizeof(TextRead), hipMemcpyHostToDevice, rd.st) == hipSuccess;
+				if(ok) { hipLaunchKernelGGL(mm_text_codes_kernel, dim3((uint32_t)((tr.size() + 3) / 4)), dim3(256), 0, rd.st, c->d, d_ti.p, (uint32_t)tr.size(), d_codes.p, d_tn.p); ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(rd.st) == hipSuccess; }
+			}
+		}
+		pool.put(c);
+		if(ok && consumed == 0) ok = false;
+		at += consumed; want = rd.chunk_bytes;
+	}
+	if(!ok) return false;
+	const uint64_t n = total + 64, nw = (n + 15) / 16 + 4, nn = (n + 31) / 32 + 4;
+	gaba_arena_t *ar = (gaba_arena_t *)calloc(1, sizeof(gaba_arena_t));
+	if(!ar || hipMalloc(&ar->pk, nw * 4) != hipSuccess || hipMalloc(&ar->nm, nn * 4) != hipSuccess) { if(ar) { if(ar->pk) (void)hipFree(ar->pk); free(ar); } return false; }
+	ar->n = n; ar->host = NULL;
+	(void)hipMemsetAsync(ar->pk, 0, nw * 4, rd.st); (void)hipMemsetAsync(ar->nm, 0, nn * 4, rd.st);
+	const uint64_t n32 = (n + 31) / 32;
+	hipLaunchKernelGGL(mm_codes_pack_kernel, dim3((uint32_t)((n32 + 255) / 256)), dim3(256), 0, rd.st, d_codes.p, n32, ar->pk, ar->nm);
+	ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(rd.st) == hipSuccess;
+	d_codes.release(); d_ti.release(); d_tn.release();
+	if(!ok) { gaba_arena_free(ar); return false; }
+	mi->ref_ar = ar; mi->rtext = src;
+	if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd] reference reader: %lu sequences, text to HBM + marks %.1f ms, record tables %.1f ms\n", (unsigned long)mi->seq.size(), rd.t_io, rd.t_scan);
+	return true;
+}
 typedef std::function<bool(uint32_t, std::vector<std::string> &)> PieceSink;          /* (batch, pieces) in batch order; false = stop */
 /* n_batches = MM_OPEN_ENDED: as many as make() gives (it returns NULL behind the last one; lanes ask strictly in order of k) */
 #define MM_OPEN_ENDED 0xffffffffu
@@ -2909,7 +2993,8 @@ static int default_lanes();
 static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const PieceSink &sink, int lanes)
 {
 	if(lanes <= 0) lanes = default_lanes();
-	TextReader rd; rd.a = a; rd.src = src; rd.min_len = a->o.min_len; rd.keep_qual = a->o.keep_qual; rd.lanes = lanes;
+	if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
+	TextReader rd; rd.pool = a->chunk_pool; rd.dev = a->dev; rd.src = src; rd.min_len = a->o.min_len; rd.keep_qual = a->o.keep_qual; rd.lanes = lanes;
 	if(!rd.start()) { fprintf(stderr, "[minialign_amd] reader: no stream / staging memory\n"); return 1; }
 	bool err = false;
 	int rc = stream_map(a, MM_OPEN_ENDED, [&](uint32_t k) { return rd.take(k, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes);
@@ -2945,7 +3030,8 @@ extern "C" mm_reads_t *mm_reads_scan(mm_align_t *a, char const *fn, int keep_qua
 {
 	std::shared_ptr<TextSrc> src = open_text(fn);
 	if(!src) return NULL;
-	TextReader rd; rd.a = a; rd.src = src; rd.min_len = 1; rd.keep_qual = keep_qual != 0; rd.lanes = 1;
+	if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
+	TextReader rd; rd.pool = a->chunk_pool; rd.dev = a->dev; rd.src = src; rd.min_len = 1; rd.keep_qual = keep_qual != 0; rd.lanes = 1;
 	if(!rd.start()) return NULL;
 	mm_reads_t *out = new mm_reads_s(); bool err = false;
 	for(uint32_t k = 0; ; k++) {
@@ -3063,7 +3149,7 @@ extern "C" uint32_t mm_carry_after(mm_align_t const *a, uint32_t i)
 {
 	if(i >= a->head.size()) return 0xffffffffu;          /* beyond the recorded head: unknown */
 	uint32_t cur = a->head_carry_in;
-	for(size_t j = 0; j <= i && j < a->head.size(); j++) { if(a->head[j].rid_last != gaba::NIL) cur = (uint32_t)a->mi->seq[a->head[j].rid_last].seq.size(); }
+	for(size_t j = 0; j <= i && j < a->head.size(); j++) { if(a->head[j].rid_last != gaba::NIL) cur = a->mi->seq[a->head[j].rid_last].blen(); }
 	return cur;
 }
 /* byte offset, in the text the last stream handed to its sink, of the first record of read i (i = the number of reads of a stream shorter than the recorded

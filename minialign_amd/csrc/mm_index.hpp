@@ -248,15 +248,26 @@ __device__ __forceinline__ uint32_t bucket_of(const uint64_t *bofs, uint32_t n_b
 }
 __global__ void __launch_bounds__(256) mm_idx_runs_kernel(I4Args a)
 {
+	/* nearly every key occurs once or a few times: the counts below 256 are added up in LDS first (one global atomic per block and count instead of one per key) */
+	__shared__ uint32_t lh[256];
+	lh[threadIdx.x] = 0;
+	__syncthreads();
 	const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-	if(i >= a.n) { return; }
-	const uint32_t b = bucket_of(a.bofs, a.n_buckets, i);
-	const uint64_t lo = a.bofs[b], hi = a.bofs[b + 1]; const uint64_t key = a.hrem[i];
-	if(i > lo && a.hrem[i - 1] == key) { a.runlen[i] = 0; return; }
-	uint64_t e = i + 1; while(e < hi && a.hrem[e] == key) { e++; }
-	const uint32_t len = (uint32_t)(e - i);
-	a.runlen[i] = len;
-	if(len < IDX_HB) { atomicAdd(&a.hist[len], 1ull); } else { atomicAdd(&a.hist[IDX_HB], 1ull); const uint32_t q = atomicAdd(a.n_big, 1u); if(q < a.big_cap) { a.big[q] = len; } }
+	if(i < a.n) {
+		const uint32_t b = bucket_of(a.bofs, a.n_buckets, i);
+		const uint64_t lo = a.bofs[b], hi = a.bofs[b + 1]; const uint64_t key = a.hrem[i];
+		if(i > lo && a.hrem[i - 1] == key) { a.runlen[i] = 0; }
+		else {
+			uint64_t e = i + 1; while(e < hi && a.hrem[e] == key) { e++; }
+			const uint32_t len = (uint32_t)(e - i);
+			a.runlen[i] = len;
+			if(len < 256) { atomicAdd(&lh[len], 1u); }
+			else if(len < IDX_HB) { atomicAdd(&a.hist[len], 1ull); }
+			else { atomicAdd(&a.hist[IDX_HB], 1ull); const uint32_t q = atomicAdd(a.n_big, 1u); if(q < a.big_cap) { a.big[q] = len; } }
+		}
+	}
+	__syncthreads();
+	if(lh[threadIdx.x]) { atomicAdd(&a.hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]); }
 }
 __global__ void __launch_bounds__(256) mm_idx_cut_kernel(I4Args a)
 {

@@ -75,7 +75,8 @@ def test_device_index_equals_the_host_build_for_other_settings(lib, opts):
             keys.update(int(x) >> 8 for x in words[:n])
         keys = sorted(keys)
         a = _lists(L, dev, keys); b = _lists(L, host, keys)
-        assert a == b and sum(len(v) for v in a) > len(keys) // 2
+        assert a == b
+        assert sum(len(v) > 0 for v in a) > 100          # (with k = 12 most keys of this reference are above the last threshold and dropped)
         L.mm_idx_destroy(dev); L.mm_idx_destroy(host)
 
 def test_device_index_of_circular_references_matches_the_oracle(lib):
