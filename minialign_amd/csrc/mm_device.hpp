@@ -64,6 +64,7 @@ struct ReadState {
 	uint32_t err;                                     /* sticky error flags */
 	uint32_t kh_mask, kh_cnt, kh_ub;                  /* kh_t state of the per-read position hash (persists across rounds) */
 	uint32_t seed_n0;                                 /* seed count as K1 left it: immutable, picks the size class of the first-round sort + chain */
+	uint32_t spec_off, spec_n;                        /* first trials of this read's chains computed by the other waves of the launch (SpecMemo entries), 0: none */
 	uint32_t k3_ticks, k3_vec, k3_fill_ticks, k3_trace_ticks;   /* diagnostics: s_memtime ticks (whole / DP fill / traceback) and DP vectors the extension kernel spent on this read */
 	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
 	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
@@ -242,6 +243,32 @@ __device__ __forceinline__ uint32_t bits_before(const uint64_t *m, const uint32_
 	const uint32_t w = p >> 6, n_words = (n + 63u) / 64u;
 	if(w >= n_words) { return cum[n_words - 1] + (uint32_t)__popcll(m[n_words - 1]); }
 	return cum[w] + (uint32_t)__popcll(m[w] & ((1ull << (p & 63)) - 1));
+}
+__device__ __forceinline__ uint32_t bits_before(const uint64_t *m, const uint32_t *cum, uint32_t p, uint32_t n);
+/* K0 for long sequences (a reference: a chromosome is 250 MB of text, which one wave per record would walk for seconds): a wave per tile of a record's text; where the
+ * tile's bases go in the arena follows from the number of newlines between the start of the record's extent and the tile (the scan's masks and counts, FASTA only).
+ * tile_base[r] = tiles of the records in front of r (n_reads + 1 entries) */
+__global__ void __launch_bounds__(256) mm_text_codes_tiled_kernel(const uint8_t *text, const uint64_t *ma, const uint32_t *cum, uint32_t n, const TextRead *tr, const uint32_t *tile_base,
+	uint32_t n_reads, uint32_t tile, uint8_t *codes)
+{
+	const int lane = lane_id();
+	const uint32_t g = (uint32_t)rdfirst((int)(blockIdx.x * 4 + threadIdx.x / 64));
+	if(g >= tile_base[n_reads]) { return; }
+	uint32_t lo = 0, hi = n_reads;
+	while(hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if(tile_base[mid] <= g) { lo = mid; } else { hi = mid; } }
+	const uint32_t r = lo, ti = g - (uint32_t)rdfirst((int)tile_base[r]);
+	const uint32_t t0 = (uint32_t)rdfirst64(tr[r].t_off), tl = (uint32_t)rdfirst((int)tr[r].t_len); const uint64_t q0 = rdfirst64(tr[r].q_off);
+	const uint32_t a = ti * tile, b = a + tile < tl ? a + tile : tl;
+	const uint64_t lut = 0x0400000020331000ull;
+	uint64_t out = q0 + a - (bits_before(ma, cum, t0 + a, n) - bits_before(ma, cum, t0, n));
+	for(uint32_t i0 = a; i0 < b; i0 += 64) {
+		const uint32_t i = i0 + (uint32_t)lane;
+		const uint8_t c = i < b ? text[t0 + i] : (uint8_t)'\n';
+		const bool keep = c != (uint8_t)'\n';
+		const uint64_t m = __ballot(keep);
+		if(keep) { codes[out + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint8_t)((lut >> (4 * (c & 15))) & 15); }
+		out += (uint32_t)__popcll(m);
+	}
 }
 __global__ void __launch_bounds__(256) mm_text_fasta_kernel(ScanArgs a)
 {
@@ -1503,6 +1530,13 @@ struct K3Args {
 	 * minialign.c:4444-4448) -- rescued minimizers expanded, seeds sorted and chained again in HBM by that wave, then extended -- instead of coming back
 	 * through the host for another round of launches */
 	uint32_t inkernel_rounds; Resc *resc_pool; uint32_t twlen;
+	/* chain-level parallelism inside the heaviest reads of a launch (the first 64th of the work list: dozens of chains each, one of them is the critical path of the
+	 * launch): the first trial of every chain of such a read -- downward extension from its root seed, max search, upward extension, traceback: a pure function of
+	 * (reference, cp_a, cp_b, strand) -- is a job any wave of the launch takes BEFORE the waves start on the reads; the wave that later walks the read's chains in order,
+	 * with the real hash and bins, takes a job's result where the inputs of the trial it is about to run are the job's (agent-scope release / acquire between the two
+	 * waves).  Same results by construction.  NULL: no jobs */
+	const struct SpecJob *jobs; struct SpecMemo *memo; unsigned long long *job_top;      /* job_top[0] = jobs enumerated (mm_spec_jobs_kernel), [1] = cursor, [2] staged path words, [3] staged segments, [4] memo hits */
+	uint64_t job_cap; uint32_t *spath; uint64_t spath_cap; gaba::Segment *sseg; uint64_t sseg_cap;
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 };
 
@@ -1563,6 +1597,14 @@ struct Search {                 /* mm_search_t, minialign.c:3218 */
 	int64_t prem; uint32_t pacc, crem, srem, narrow, min_score;
 };
 constexpr uint32_t MM_CREM = 50000, MM_SREM = 8;
+struct SpecJob { uint32_t r, aid, cp_a, cp_b, rev, rlen, rcirc, pad; };
+struct SpecMemo {
+	uint32_t state;                  /* 0: not done yet; bit 31: done, bit 0: downward pass + max search valid, bit 1: upward pass (+ traceback when mmax1 >= min_score) valid */
+	uint32_t aid, cp_a, cp_b, rev;   /* the inputs it was computed for */
+	uint32_t pp_apos, pp_bpos; uint64_t pp_plen; int64_t mmax0;
+	int64_t mmax1; uint64_t tplen; uint64_t path_off; uint32_t seg_off;
+	gaba::AlnOut ao;
+};
 
 /*
  * The DP phases run as real (non-inlined) device functions from the extension driver: the driver keeps ~150 scalars of
@@ -1707,6 +1749,41 @@ __device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uin
 #ifdef MM_K3_NUM_VGPR
 __attribute__((amdgpu_num_vgpr(MM_K3_NUM_VGPR)))
 #endif
+/* one thread per heavy read (the first n_heavy entries of the work list): the chains mm_extend will visit -- root order, up to the length test of
+ * mm_search_load_root (minialign.c:3849) -- with the positions mm_search_load_pos gives their root seeds; the `apos >= rlen` test sees the length of the
+ * reference the chain in front loaded (minialign.c:3864).  Reads with fewer than min_roots such chains are left alone. */
+struct SpecJobsArgs { DevIndex idx; const ReadIn *in; ReadState *st; const uint32_t *work; uint32_t n_heavy; const Seed *seed_pool; const Root *root_pool;
+	double mcoef; uint32_t min_score, min_roots; SpecJob *jobs; SpecMemo *memo; uint64_t job_cap; unsigned long long *job_top; };
+__global__ void __launch_bounds__(64) mm_spec_jobs_kernel(SpecJobsArgs a)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if(t >= a.n_heavy) { return; }
+	const uint32_t r = a.work[t];
+	ReadState *st = &a.st[r];
+	st->spec_n = 0; st->spec_off = 0;
+	const uint32_t n_root = st->n_root;
+	if(n_root < a.min_roots || n_root >= 0xfffffffeu || st->err) { return; }
+	const DevIndex &ix = a.idx;
+	const Seed *s = a.seed_pool + st->seed_off; const Root *root = a.root_pool + st->root_off;
+	const uint32_t qlen = a.in[r].qlen;
+	uint32_t cnt = 0;
+	for(uint32_t kq = 0; kq < n_root; kq++) { const uint32_t plen = (uint32_t)OFS((int32_t)root[kq].plen); if(plen * a.mcoef < 2.0 * a.min_score) { break; } cnt++; }
+	if(cnt < a.min_roots) { return; }
+	const unsigned long long off = atomicAdd(&a.job_top[0], (unsigned long long)cnt);
+	if(off + cnt > a.job_cap) { return; }          /* (the count stays above the capacity: the extension kernel clamps it) */
+	uint32_t rlen = st->rlen;
+	for(uint32_t kq = 0; kq < cnt; kq++) {
+		const uint32_t lid = root[kq].lid, rsid = s[lid].upos; const Seed p = s[rsid];
+		const int32_t bs = BS(p); const uint32_t rev = bs < 0;
+		uint32_t cpa = (uint32_t)AS(p), cpb = (uint32_t)(bs + ((bs >> 31) & (int32_t)qlen));
+		if(cpa >= rlen || cpb >= qlen) { cpa -= min(cpa, ix.k); cpb -= min(cpb, ix.k); }
+		rlen = ix.seq_len[p.rid];
+		a.jobs[off + kq] = SpecJob{ r, p.rid, cpa, cpb, rev, rlen, ix.seq_circ ? (uint32_t)ix.seq_circ[p.rid] : 0u, 0u };
+		a.memo[off + kq].state = 0;
+	}
+	st->spec_off = (uint32_t)off; st->spec_n = cnt;
+}
+
 __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Args a)
 {
 	extern __shared__ uint32_t k3_tab[];       /* launched with 4 x 1536 words when the rounds run in the kernel (per wave: tables of k3_rescue_round's sort + chain), else with none:
@@ -1747,6 +1824,88 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
 	if(a.inkernel_rounds) { if(threadIdx.x == 0) { k3_tab[K3_TAB_WORDS] = 0; } __syncthreads(); }          /* the lock of the tables */
 
+	/* the workspace a read of qlen bases needs: the smallest class that holds it; kept from read to read while the class stays */
+	#define K3_NEED_SLAB(_qlen) { \
+		int _want = 0; while(_want + 1 < (int)a.n_cls && (_qlen) > a.cls[_want].qmax) { _want++; } \
+		if(_want != slab_cls) { \
+			if(slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); } \
+			K3_RING_TAKE(_want, slab_no); slab_cls = _want; \
+			x.slab = a.cls[_want].slabs + (uint64_t)slab_no * a.cls[_want].bytes; x.cap = (uint32_t)a.cls[_want].bytes; x.top = gaba::SLAB_HEAD; \
+			for(uint32_t _i = (uint32_t)lane; _i < gaba::SLAB_HEAD / 4; _i += 64) { ((uint32_t *)x.slab)[_i] = ((const uint32_t *)a.roots)[_i]; } \
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+			if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[_want].next_base) * (a.next_cap + MM_NEXT_SCRATCH); next_scratch = (uint32_t *)(next + a.next_cap); } \
+		} }
+	/* jobs first: the first trials of the chains of the heaviest reads, one per wave at a time, by every wave of the launch (K3Args.jobs) */
+	if(a.jobs && a.ring) {
+		const unsigned long long n_jobs = min(rdfirst64(a.job_top[0]), (unsigned long long)a.job_cap);
+		__builtin_amdgcn_s_setprio(3);
+		while(n_jobs) {
+			unsigned long long ji = 0;
+			if(lane == 0) { ji = atomicAdd(&a.job_top[1], 1ull); }
+			ji = rdfirst64(ji);
+			if(ji >= n_jobs) { break; }
+			const SpecJob j = a.jobs[ji];
+			const uint32_t r = (uint32_t)rdfirst((int)j.r), aid = (uint32_t)rdfirst((int)j.aid), cp_a = (uint32_t)rdfirst((int)j.cp_a), cp_b = (uint32_t)rdfirst((int)j.cp_b);
+			const uint32_t rev = (uint32_t)rdfirst((int)j.rev), rlen = (uint32_t)rdfirst((int)j.rlen); const int rcirc = rdfirst((int)j.rcirc);
+			const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen); const uint64_t q_off = rdfirst64(a.in[r].q_off), roff = rdfirst64(a.idx.seq_off[aid]);
+			K3_NEED_SLAB(qlen);
+			const gaba::Sec rsec_f = gaba::Sec{ aid << 1, rlen, roff, 0, 0 }, rsec_r = gaba::Sec{ (aid << 1) + 1, rlen, roff, 0, 1 };
+			const gaba::Sec qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }, qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
+			SpecMemo mo; mo.state = 0; mo.aid = aid; mo.cp_a = cp_a; mo.cp_b = cp_b; mo.rev = rev; mo.mmax0 = 0; mo.mmax1 = 0; mo.tplen = 0; mo.path_off = 0; mo.seg_off = 0;
+			mo.pp_apos = mo.pp_bpos = 0; mo.pp_plen = 0;
+			mo.ao.status = 0; mo.ao.score = 0; mo.ao.identity = 0; mo.ao.agcnt = mo.ao.bgcnt = mo.ao.dcnt = mo.ao.slen = mo.ao.plen = 0;
+			gaba::dp_flush(x); x.err = 0;
+			DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
+			const unsigned long long cyj0 = MM_TICK();
+			ExtOut eo = k3_extend_core(din, 0, rsec_f, cp_a, rev ? qsec_r : qsec_f, cp_b, 1, rcirc);
+			x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk); n_fill += (uint32_t)rdfirst((int)eo.n_fill);
+			uint32_t m = (uint32_t)rdfirst((int)eo.m); int64_t mmax = (int64_t)rdfirst64((uint64_t)eo.mmax);
+			bool go = x.err == 0;
+			if(go) { mo.mmax0 = mmax; mo.state = 1; if(mmax == 0) { go = false; } }
+			if(go) {
+				din.top = x.top;
+				LeafOut lo = k3_leaf_search(din, m, 1);
+				gaba::PosPair pp = lo.pp;
+				mo.pp_apos = (uint32_t)rdfirst((int)pp.apos); mo.pp_bpos = (uint32_t)rdfirst((int)pp.bpos); mo.pp_plen = rdfirst64(pp.plen);
+				const uint32_t tp_a = (uint32_t)max(1, min((int32_t)mo.pp_apos, (int32_t)rlen)), tp_b = (uint32_t)max(1, min((int32_t)mo.pp_bpos, (int32_t)qlen));
+				din.top = x.top;
+				ExtOut e1 = k3_extend_core(din, 0, rsec_r, rlen - tp_a, rev ? qsec_f : qsec_r, qlen - tp_b, 0, rcirc);
+				x.top = (uint32_t)rdfirst((int)e1.d.top); x.err = rdfirst(e1.d.err); x.n_vec += (uint32_t)rdfirst((int)e1.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)e1.d.n_blk); n_fill += (uint32_t)rdfirst((int)e1.n_fill);
+				m = (uint32_t)rdfirst((int)e1.m); mmax = (int64_t)rdfirst64((uint64_t)e1.mmax);
+				if(x.err == 0) {
+					mo.mmax1 = mmax;
+					if(mmax < (int64_t)a.min_score) { mo.state |= 2; }
+					else {
+						din.top = x.top;
+						LeafOut l1 = k3_leaf_search(din, m, 0);
+						const uint64_t tplen = rdfirst64(l1.plen);
+						const uint64_t need_words = (tplen + 31) / 32 + 2;
+						unsigned long long po = 0, so_ = 0;
+						if(lane == 0) { po = atomicAdd(&a.job_top[2], (unsigned long long)need_words); so_ = atomicAdd(&a.job_top[3], 8ull); }
+						po = rdfirst64(po); so_ = rdfirst64(so_);
+						if(po + need_words <= a.spath_cap && so_ + 8 <= a.sseg_cap) {
+							DpIn din2; din2.c = x.c; din2.ar0 = ar[0]; din2.ar1 = ar[1]; din2.slab = x.slab; din2.top = x.top; din2.cap = x.cap;
+							TraceOut to = k3_trace(din2, m, l1.lf, tplen, a.spath + po, a.sseg + so_);
+							gaba::AlnOut ao = to.ao;
+							ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
+							if(rdfirst(to.d.err) == 0) { mo.ao = ao; mo.tplen = tplen; mo.path_off = po; mo.seg_off = (uint32_t)so_; x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr); n_trace++; mo.state |= 2; }
+						}
+					}
+				}
+			}
+			cy_fill += MM_TICK() - cyj0;
+			x.err = 0;
+			/* publish: the payload with plain stores (the path words and segments came from the traceback, the record from lane 0), an agent-scope release -- the wave
+			 * that takes it may sit on another XCD --, the drain the compiler may drop, then the flag (MI355X_MICROARCH.md, inter-workgroup visibility) */
+			const uint32_t done_state = mo.state | 0x80000000u; mo.state = 0;
+			if(lane == 0) { a.memo[ji] = mo; }
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if(lane == 0) { __hip_atomic_store(&a.memo[ji].state, done_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		}
+		__builtin_amdgcn_s_setprio(0);
+	}
+
 	while(true) {
 		uint32_t wi = wave;
 		if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
@@ -1776,19 +1935,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		if(wi < (a.n_work >> 6)) { __builtin_amdgcn_s_setprio(3); } else if(n_root >= 5) { __builtin_amdgcn_s_setprio(1); } else { __builtin_amdgcn_s_setprio(0); }
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
-		if(a.ring) {
-			/* the workspace this read needs: the smallest class that holds it; kept from read to read
-			 * while the class stays (the work list runs longest first, so a wave changes at most once) */
-			int want = 0; while(want + 1 < (int)a.n_cls && qlen > a.cls[want].qmax) { want++; }
-			if(want != slab_cls) {
-				if(slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); }
-				K3_RING_TAKE(want, slab_no); slab_cls = want;
-				x.slab = a.cls[want].slabs + (uint64_t)slab_no * a.cls[want].bytes; x.cap = (uint32_t)a.cls[want].bytes; x.top = gaba::SLAB_HEAD;
-				for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
-				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-				if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[want].next_base) * (a.next_cap + MM_NEXT_SCRATCH); next_scratch = (uint32_t *)(next + a.next_cap); }
-			}
-		}
+		if(a.ring) { K3_NEED_SLAB(qlen); }
 		Seed *s = a.seed_pool + rdfirst64(st->seed_off);
 		Root *root = a.root_pool + rdfirst64(st->root_off);
 		uint32_t rlen = (uint32_t)rdfirst((int)st->rlen);
@@ -1820,6 +1967,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		sr.crem = MM_CREM; sr.min_score = a.min_score; sr.narrow = 0; sr.srem = 0; sr.prem = 0; sr.pacc = 0;
 		sr.cp_a = sr.cp_b = sr.tp_a = sr.tp_b = 0; sr.aid = sr.bid = sr.iid = sr.eid = sr.sid = sr.rev = 0;
 		uint32_t next_n = 0;
+		const uint32_t spec_n = (a.jobs != nullptr && round == 0) ? (uint32_t)rdfirst((int)st->spec_n) : 0u, spec_off = (uint32_t)rdfirst((int)st->spec_off);
 		gaba::Sec rsec_f, rsec_r, qsec_f, qsec_r; int rcirc = 0;
 		qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }; qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
 
@@ -1857,7 +2005,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			rsec_f = gaba::Sec{ sr.aid << 1, rlen, roff, 0, 0 }; rsec_r = gaba::Sec{ (sr.aid << 1) + 1, rlen, roff, 0, 1 };
 			rcirc = ix.seq_circ ? rdfirst((int)ix.seq_circ[sr.aid]) : 0;          /* rtp = circular ? r : t (minialign.c:3753) */
 
-			bool first_iter = true;
+			bool first_iter = true, chain_first = true;
 			while(true) {
 				const unsigned long long cy_n0 = MM_TICK();
 				if(!first_iter) {
@@ -1918,10 +2066,30 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				const int bw = (int)sr.narrow;               /* _dp(x) ignores its argument (minialign.c:4123) */
 				uint32_t m = gaba::NIL; int64_t mmax = 0; gaba::Leaf tlf; uint64_t tplen = 0;
 				bool skip = false;
+				/* the first trial of a chain of a heavy read is a job another wave took (or is still working on): waited for, acquired, and taken if it was computed for
+				 * exactly the inputs of this trial (it always is unless the walk stopped differently in front) */
+				const SpecMemo *smp = a.memo + (spec_off + kq); bool memo0 = false, memo1 = false, memo_trace = false;
+				if(chain_first && bw == 0 && kq < spec_n) {
+					uint32_t stt = 0;
+					if(lane == 0) { while((stt = __hip_atomic_load(&smp->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) { __builtin_amdgcn_s_sleep(32); } }
+					stt = (uint32_t)rdfirst((int)stt);
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+					if((stt & 1u) && (uint32_t)rdfirst((int)smp->aid) == sr.aid && (uint32_t)rdfirst((int)smp->cp_a) == sr.cp_a && (uint32_t)rdfirst((int)smp->cp_b) == sr.cp_b && (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u)) { memo0 = true; memo1 = (stt & 2u) != 0; }
+					if(memo0 && lane == 0) { atomicAdd(&a.job_top[4], 1ull); }
+				}
+				chain_first = false;
 				for(int pass = 0; pass < 2 && !skip; pass++) {
 					gaba::Sec ca = pass == 0 ? rsec_f : rsec_r;
 					gaba::Sec cb = ((sr.rev != 0) == (pass == 0)) ? qsec_r : qsec_f;
 					uint32_t sa = pass == 0 ? sr.cp_a : rlen - sr.tp_a, sb = pass == 0 ? sr.cp_b : qlen - sr.tp_b;
+					gaba::PosPair pp; pp.aid = pp.bid = 0; pp.apos = pp.bpos = 0; pp.plen = 0;
+					if(pass == 0 ? memo0 : memo1) {
+						/* a pass another wave ran: its maximum and -- pass 0 -- the position of the maximum, -- pass 1 -- the path length for the pools (its vectors were counted there) */
+						mmax = (int64_t)rdfirst64((uint64_t)(pass == 0 ? smp->mmax0 : smp->mmax1)); m = gaba::NIL;
+						if(pass == 0 ? (mmax == 0) : (mmax < (int64_t)a.min_score)) { skip = true; break; }
+						if(pass == 0) { pp.apos = (uint32_t)rdfirst((int)smp->pp_apos); pp.bpos = (uint32_t)rdfirst((int)smp->pp_bpos); pp.plen = rdfirst64(smp->pp_plen); }
+						else { tplen = rdfirst64(smp->tplen); memo_trace = true; }
+					} else {
 					DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
 					const unsigned long long cy0 = MM_TICK();
 					/* the downward pass is only searched for its maximum (the walk-back runs on the upward pass): no traceback masks */
@@ -1936,9 +2104,9 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					LeafOut lo = k3_leaf_search(din, m, pass == 0);
 					cy_leaf += MM_TICK() - cy1;
 					tlf = lo.lf; tplen = rdfirst64(lo.plen);
+					if(pass == 0) { pp = lo.pp; pp.apos = (uint32_t)rdfirst((int)pp.apos); pp.bpos = (uint32_t)rdfirst((int)pp.bpos); pp.plen = rdfirst64(pp.plen); }
+					}
 					if(pass == 0) {
-						gaba::PosPair pp = lo.pp;
-						pp.apos = (uint32_t)rdfirst((int)pp.apos); pp.bpos = (uint32_t)rdfirst((int)pp.bpos); pp.plen = rdfirst64(pp.plen);
 						/* mm_search_test_dup (minialign.c:3953-3982) */
 						uint64_t key = mm_key((uint64_t)pp.apos | ((uint64_t)pp.bpos << 32), (uint64_t)sr.aid | ((uint64_t)sr.bid << 32));
 						uint64_t prev = 0;
@@ -1971,11 +2139,22 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				uint32_t *path = a.path_pool + po + 2;
 				DpIn din2; din2.c = x.c; din2.ar0 = ar[0]; din2.ar1 = ar[1]; din2.slab = x.slab; din2.top = x.top; din2.cap = x.cap;
 				const unsigned long long cy2 = MM_TICK();
+				gaba::AlnOut ao;
+				if(memo_trace) {
+					/* the traceback was done by the job: its path words and segments move from the staging area into the pools */
+					const uint32_t *sp = a.spath + rdfirst64(smp->path_off); const gaba::Segment *sg = a.sseg + (uint32_t)rdfirst((int)smp->seg_off);
+					for(uint64_t i = (uint64_t)lane; i < need_words; i += 64) { path[i] = sp[i]; }
+					ao = smp->ao; ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
+					for(uint32_t i = (uint32_t)lane; i < ao.slen && i < 8; i += 64) { a.seg_pool[so_ + i] = sg[i]; }
+					x.err = 0;
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+				} else {
 				TraceOut to = k3_trace(din2, m, tlf, tplen, path, a.seg_pool + so_);
 				cy_trace += MM_TICK() - cy2;
-				gaba::AlnOut ao = to.ao; x.err = rdfirst(to.d.err); x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr);
+				ao = to.ao; x.err = rdfirst(to.d.err); x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr);
 				ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
 				n_trace++;
+				}
 				if(x.err) { err |= (x.err == 1 ? ERR_DP_SLAB : (x.err == 2 ? ERR_PATH_CAP : ERR_SEG_CAP)); break; }
 				if(ao.status != 1) { continue; }           /* NULL alignment: path left the band */
 				uint32_t ai = n_aln++;
@@ -2063,6 +2242,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		atomicMax(&a.stats[9], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));      /* longest-living wave: load balance */
 	}
 	if(a.ring && slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); }
+	#undef K3_NEED_SLAB
 	#undef K3_RING_TAKE
 	#undef K3_RING_GIVE
 }

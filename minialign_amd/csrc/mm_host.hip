@@ -1054,6 +1054,7 @@ struct mm_align_s {
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
+	DBuf<SpecJob> spec_jobs; DBuf<SpecMemo> spec_memo; DBuf<uint32_t> spec_path; DBuf<gaba::Segment> spec_seg; DBuf<unsigned long long> spec_top;      /* chain jobs of the heaviest reads of a launch (K3Args.jobs) */
 	DBuf<uint64_t> tap_words;              /* mm_batch_tap: the minimizer stream words of the batch, parallel to min_pool */
 	DBuf<uint8_t> d_text, d_codes; DBuf<TextRead> d_tinfo; DBuf<uint32_t> d_tn;      /* packing on the device: text range of the batch, per-read extents, code bytes of the arena, bases found per read */
 	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
@@ -1258,7 +1259,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;
 		}
 		if(a->tap_stop) { return true; }
-		uint32_t k3_work_override = 0;
+		uint32_t k3_work_override = 0, n_heavy = 0;
 		{
 			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
 			std::vector<uint32_t> by_len(work);
@@ -1272,7 +1273,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				std::vector<uint32_t> nr(by_len.size()); for(size_t i = 0; i < by_len.size(); i++) nr[i] = hst[by_len[i]].n_root;
 				std::nth_element(nr.begin(), nr.begin() + (nr.size() - 1 - nr.size() / 64), nr.end());
 				const uint32_t thr = std::max<uint32_t>(nr[nr.size() - 1 - nr.size() / 64], 4);          /* top ~1.5 % */
-				std::stable_partition(by_len.begin(), by_len.end(), [&](uint32_t x) { return hst[x].n_root >= thr; });
+				auto mid = std::stable_partition(by_len.begin(), by_len.end(), [&](uint32_t x) { return hst[x].n_root >= thr; });
+				n_heavy = (uint32_t)(mid - by_len.begin());
 			}
 			if(const char *e = getenv("MM_EXPERIMENT_K3_HEAVY")) {          /* timing experiment only (results incomplete): the N reads with the most chains */
 				std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return hst[x].n_root > hst[y].n_root; });
@@ -1302,6 +1304,19 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * an extension launch of some eighty waves, twice -- took half of a lane's time per batch).  MM_K3_HOST_ROUNDS: the rounds as separate launches */
 		const bool inkernel = getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL;
 		k3.inkernel_rounds = inkernel ? 1u : 0u; k3.resc_pool = a->resc_pool.p; k3.twlen = a->twlen;
+		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0;
+		/* chain jobs: the first trials of the chains of the heaviest reads (the front of the work list), taken by all waves of the launch before the reads (K3Args.jobs) */
+		if(round == 0 && n_heavy > 0 && k3.ring && inkernel && !getenv("MM_K3_NO_JOBS")) {
+			const uint64_t job_cap = 1u << 16, path_cap = 48ull << 20;
+			if(a->spec_jobs.ensure(job_cap) && a->spec_memo.ensure(job_cap) && a->spec_path.ensure(path_cap) && a->spec_seg.ensure(job_cap * 8) && a->spec_top.ensure(8)) {
+				CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
+				SpecJobsArgs sj; sj.idx = a->dix; sj.in = a->d_in.p; sj.st = a->d_st.p; sj.work = a->d_work.p; sj.n_heavy = n_heavy; sj.seed_pool = a->seed_pool.p; sj.root_pool = a->root_pool.p;
+				sj.mcoef = a->mcoef; sj.min_score = a->o.min_score; sj.min_roots = 6; sj.jobs = a->spec_jobs.p; sj.memo = a->spec_memo.p; sj.job_cap = job_cap; sj.job_top = a->spec_top.p;
+				hipLaunchKernelGGL(mm_spec_jobs_kernel, dim3((n_heavy + 63) / 64), dim3(64), 0, a->stream, sj);
+				CK(hipGetLastError());
+				k3.jobs = a->spec_jobs.p; k3.memo = a->spec_memo.p; k3.job_top = a->spec_top.p; k3.job_cap = job_cap; k3.spath = a->spec_path.p; k3.spath_cap = path_cap; k3.sseg = a->spec_seg.p; k3.sseg_cap = job_cap * 8;
+			}
+		}
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
 		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
 		/* several batches in flight (lanes): 5 persistent waves per SIMD keep the integer VALU as busy as 8 do (a wave issues at most every 4th cycle, about two
@@ -1819,7 +1834,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
-	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	free_chunk_pool(a->chunk_pool); a->chunk_pool = nullptr;
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
@@ -2586,8 +2601,10 @@ struct TextReader {
 			CK(hipEventRecord(pev[pi], st));
 		}
 		const uint32_t n = (uint32_t)len, n_words = (n + 63) / 64, n_blk = (n_words + 255) / 256;
-		const uint32_t pos_cap = n / 8 + 1024;
-		if(!d_ma.ensure(n_words) || !d_mb.ensure(n_words) || !d_cum.ensure(n_words) || !d_blk.ensure(2 * (uint64_t)n_blk + 2) || !d_pos.ensure(pos_cap) || !d_flag.ensure(4)) return false;
+		/* the scratch arrays are sized for a whole stretch from the start: a buffer that grows in mid-run costs a hipFree, which waits for every stream of the device */
+		const uint64_t cap_n = std::max<uint64_t>(len, chunk_bytes), cap_words = (cap_n + 63) / 64, cap_blk = (cap_words + 255) / 256;
+		const uint32_t pos_cap = (uint32_t)(cap_n / 8 + 1024);
+		if(!d_ma.ensure(cap_words) || !d_mb.ensure(cap_words) || !d_cum.ensure(cap_words) || !d_blk.ensure(2 * cap_blk + 2) || !d_pos.ensure(pos_cap) || !d_flag.ensure(4)) return false;
 		ScanArgs sa; memset(&sa, 0, sizeof(sa));
 		sa.text = c->d; sa.n = n; sa.fastq = fastq ? 1u : 0u; sa.ma = d_ma.p; sa.mb = d_mb.p; sa.blk = d_blk.p; sa.n_blk = n_blk; sa.pos = d_pos.p; sa.pos_cap = pos_cap; sa.cum = d_cum.p;
 		sa.last = last ? 1u : 0u; sa.keep_qual = keep_qual ? 1u : 0u; sa.flag = d_flag.p;
@@ -2621,7 +2638,7 @@ struct TextReader {
 			}
 		}
 		if(!on_host && n_rec) {
-			if(!d_rec.ensure(n_rec)) return false;
+			if(!d_rec.ensure(std::max<uint64_t>(n_rec, d_rec.n ? 0 : chunk_bytes / 4096))) return false;          /* (room for reads of 4 kb and more from the start) */
 			sa.rec = d_rec.p; sa.n_rec = n_rec;
 			if(fastq) hipLaunchKernelGGL(mm_text_fastq_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, st, sa); else hipLaunchKernelGGL(mm_text_fasta_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, st, sa);
 			CK(hipGetLastError());
@@ -2710,7 +2727,7 @@ static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::
 	ChunkPool pool; TextReader rd; rd.pool = &pool; rd.dev = mi->dev; rd.src = src; rd.min_len = o->min_len; rd.keep_qual = false; rd.lanes = 1;
 	rd.chunk_bytes = 1ull << 30;
 	if(!rd.init()) return false;
-	DBuf<uint8_t> d_codes; DBuf<TextRead> d_ti; DBuf<uint32_t> d_tn;
+	DBuf<uint8_t> d_codes; DBuf<TextRead> d_ti; DBuf<uint32_t> d_tn, d_tb;
 	const uint64_t codes_cap = src->n + (256ull << 20);          /* bases + what the alignment of the sequences to 64 adds (room for four million sequences) */
 	if(!d_codes.ensure(codes_cap) || hipMemsetAsync(d_codes.p, 4, codes_cap, rd.st) != hipSuccess) return false;
 	uint64_t at = src->first, want = rd.chunk_bytes, total = 0; bool ok = true;
@@ -2735,7 +2752,15 @@ static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::
 			if(total + 64 > codes_cap) { fprintf(stderr, "[minialign_amd] reader: more reference sequences than the arena was laid out for\n"); ok = false; }
 			if(ok && !tr.empty()) {
 				ok = d_ti.ensure(tr.size()) && d_tn.ensure(tr.size()) && hipMemcpyAsync(d_ti.p, tr.data(), tr.size() * sizeof(TextRead), hipMemcpyHostToDevice, rd.st) == hipSuccess;
-				if(ok) { hipLaunchKernelGGL(mm_text_codes_kernel, dim3((uint32_t)((tr.size() + 3) / 4)), dim3(256), 0, rd.st, c->d, d_ti.p, (uint32_t)tr.size(), d_codes.p, d_tn.p); ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(rd.st) == hipSuccess; }
+				if(ok && src->delim == '>') {
+					/* a wave per 16 KB tile of a sequence's text (a chromosome is 250 MB: one wave per record would walk it for seconds) */
+					const uint32_t tile = 16384; std::vector<uint32_t> tb(tr.size() + 1, 0);
+					for(size_t i = 0; i < tr.size(); i++) tb[i + 1] = tb[i] + (tr[i].t_len + tile - 1) / tile;
+					ok = d_tb.ensure(tb.size()) && hipMemcpyAsync(d_tb.p, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, rd.st) == hipSuccess;
+					if(ok && tb.back()) { hipLaunchKernelGGL(mm_text_codes_tiled_kernel, dim3((tb.back() + 3) / 4), dim3(256), 0, rd.st, c->d, rd.d_ma.p, rd.d_cum.p, c->n, d_ti.p, d_tb.p, (uint32_t)tr.size(), tile, d_codes.p); ok = hipGetLastError() == hipSuccess; }
+					ok = ok && hipStreamSynchronize(rd.st) == hipSuccess;
+				}
+				else if(ok) { hipLaunchKernelGGL(mm_text_codes_kernel, dim3((uint32_t)((tr.size() + 3) / 4)), dim3(256), 0, rd.st, c->d, d_ti.p, (uint32_t)tr.size(), d_codes.p, d_tn.p); ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(rd.st) == hipSuccess; }
 			}
 		}
 		pool.put(c);
@@ -2751,7 +2776,7 @@ static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::
 	const uint64_t n32 = (n + 31) / 32;
 	hipLaunchKernelGGL(mm_codes_pack_kernel, dim3((uint32_t)((n32 + 255) / 256)), dim3(256), 0, rd.st, d_codes.p, n32, ar->pk, ar->nm);
 	ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(rd.st) == hipSuccess;
-	d_codes.release(); d_ti.release(); d_tn.release();
+	d_codes.release(); d_ti.release(); d_tn.release(); d_tb.release();
 	if(!ok) { gaba_arena_free(ar); return false; }
 	mi->ref_ar = ar; mi->rtext = src;
 	if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd] reference reader: %lu sequences, text to HBM + marks %.1f ms, record tables %.1f ms\n", (unsigned long)mi->seq.size(), rd.t_io, rd.t_scan);
@@ -2804,6 +2829,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 				{ std::lock_guard<std::mutex> lk(mu); if(rc || next_k >= n_batches) break; k = next_k++; }
 				tv = now_ms();
 				h = make(k);
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): taken after %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); }
 				if(!h && open_ended) { std::lock_guard<std::mutex> lk(mu); n_batches = std::min(n_batches, k); cv.notify_all(); break; }
 				if(h && a->shared_slabs && slab_bytes_for(std::max(h->b.max_qlen, a->qlen_hint)) > a->slab_max) {
 					std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return active == 0 || rc != 0; });
