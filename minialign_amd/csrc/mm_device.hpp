@@ -1163,6 +1163,98 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_kernel(K2c
 }
 
 /* -----------------------------------------------------------------------------------------------------
+ * K2w: the same sweep, one LANE per read, everything in HBM / L2.  The sweep is a chain of dependent look-ups (one round trip per chained seed) whichever memory
+ * it runs in; in LDS a CU holds four or five reads' images, i.e. four or five chases in flight per CU, and the launches wait for LDS and wave slots beside the
+ * extension waves of the other lanes (17 ms alone, three times that in the mix).  Here every read of the batch is in flight at once -- 64 per wave, a few hundred
+ * waves, no LDS -- and a round trip costs an HBM access instead of an LDS access: the launch lasts as long as the read with the most seeds (a few thousand steps).
+ * Per step the step table entry ss[nx] (K2p) and the mark gs[nx].lid are fetched together; marks are written in place (n_all + leaf number: what mm_chain_seeds
+ * leaves), leaves and chain roots go through a scratch area the size of the read's seed region (they would overwrite the step table where the leaves end up) and are
+ * written out behind the sweep.  Reads with more than K2S_MAX_N seeds stay with K2a.
+ * ----------------------------------------------------------------------------------------------------- */
+struct K2wArgs {
+	ReadState *st; const uint32_t *work; uint32_t n_work;
+	Seed *seed_pool; Root *root_pool; uint8_t *scratch;          /* scratch: 16 B per element of the seed pool, a read's part at 16 * seed_off */
+	uint32_t *rs_pool; uint32_t rs_slots, rs_stride; uint32_t *rs_top;      /* workspaces for the root sort of the few reads with more than 64 chains */
+	double mcoef; uint32_t min_score, twlen;
+	const uint32_t *seq_len; const uint8_t *seq_circ;
+};
+__global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_sweep_kernel(K2wArgs a)
+{
+	__builtin_amdgcn_s_setprio(2);
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if(t >= a.n_work) { return; }
+	ReadState *st = &a.st[a.work[t]];
+	const uint32_t n = st->seed_n0, n_all = n + 1;
+	if(n == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; return; }
+	if(n_all > K2S_MAX_N) { return; }
+	Seed *gs = a.seed_pool + st->seed_off; Root *c = a.root_pool + st->root_off;
+	const uint2 *ss = (const uint2 *)(gs + n_all);
+	uint16_t *lrs = (uint16_t *)(a.scratch + 16ull * st->seed_off), *lls = lrs + n_all, *lcid = lls + n_all, *rlid = lcid + n_all;
+	uint32_t *rplen = (uint32_t *)(rlid + n_all + (n_all & 1));
+	st->n_seed = n; st->n_root = 0; st->pred_rid = gaba::NIL;
+	const uint32_t UNM = 0x7fffffffu;
+	uint32_t ncid = 0, nleaf = 0, nlsid = 0; const uint32_t tsid = n;
+	while(nlsid < tsid) {
+		const uint32_t lf = nleaf++, lsid0 = nlsid;
+		uint2 x = ss[lsid0]; const Seed s0 = gs[lsid0];
+		const uint32_t plen0 = s0.upos + s0.vpos; uint32_t scnt = 1;
+		lrs[lf] = (uint16_t)lsid0; lls[lf] = (uint16_t)lsid0; lcid[lf] = 0xffffu;
+		uint32_t nrsid = lsid0, hl = s0.lid;          /* hl: the mark of the seed the chain stands on when it stops */
+		nlsid = 0xffffffffu;
+		while(true) {
+			const uint32_t nx = x.x, sm = x.y;
+			nlsid = nlsid < sm ? nlsid : sm;
+			if(nx == 0) { break; }                        /* nothing inside the window: the chain ends on the seed it stands on */
+			const uint2 ex = ss[nx]; const uint32_t ey = gs[nx].lid;          /* (two independent loads, one round trip) */
+			nrsid = nx; hl = ey;
+			if(ey != UNM) { break; }                      /* marked by an earlier leaf: the chain runs into that one */
+			gs[nx].lid = n_all + lf; hl = n_all + lf;
+			scnt++;
+			if(nlsid <= nx) { nlsid = 0xffffffffu; }
+			x = ex;
+		}
+		if(nrsid == lsid0) { continue; }
+		uint32_t cid = 0xffffu;
+		if(hl != UNM && hl - n_all < lf) {
+			nrsid = lrs[hl - n_all];                      /* leaf.rsid */
+			cid = lcid[gs[nrsid].lid - n_all];            /* leaf.cid of the leaf that marks it */
+		}
+		bool fresh = false;
+		if(cid == 0xffffu) { cid = ncid++; fresh = true; }
+		const Seed se = gs[nrsid]; const uint32_t eu = se.upos + se.vpos;
+		const uint32_t plen = (uint32_t)OFS((int32_t)d2u32((1.0 - 1.0 / (double)scnt) * (double)(uint32_t)(eu - plen0)));
+		uint32_t best = fresh ? (uint32_t)OFS(0) : rplen[cid];
+		if(fresh) { rlid[cid] = (uint16_t)lf; }
+		lcid[lf] = (uint16_t)cid; lrs[lf] = (uint16_t)nrsid;
+		if(plen < best) { best = plen; rlid[cid] = (uint16_t)lf; }
+		if(fresh || plen == best) { rplen[cid] = best; }
+	}
+	/* write out: the sentinel stays where the sort put it, the leaves { rsid, rid, lsid, cid } (over the step table, which is done with), the chain roots */
+	for(uint32_t lf = 0; lf < nleaf; lf++) {
+		const uint32_t ls = lls[lf], ci = lcid[lf];
+		gs[n_all + lf] = Seed{ (uint32_t)lrs[lf], gs[ls].rid, ls, ci == 0xffffu ? 0xffffffffu : ci };
+	}
+	for(uint32_t ci = 0; ci < ncid; ci++) { c[ci] = Root{ rplen[ci], n_all + (uint32_t)rlid[ci] }; }
+	const uint32_t nlid = n_all + nleaf;
+	st->seed_n = nlid; st->n_root = ncid;
+	if(ncid) {
+		if(a.seq_circ) { circularize(gs, c, n, nlid, ncid, a.seq_len, a.seq_circ, a.twlen); }
+		if(ncid <= 64) { ins_sort_64((U64R *)c, (U64R *)c + ncid); }          /* longest first (minialign.c:3719); radix_sort_64x is an insertion sort up to 64 elements */
+		else {
+			const uint32_t slot = atomicAdd(a.rs_top, 1u);
+			if(slot >= a.rs_slots || !radix_sort_64((U64R *)c, ncid, a.rs_pool + (uint64_t)slot * a.rs_stride, a.rs_stride)) { st->err |= ERR_STACK; }
+		}
+		uint32_t pred = gaba::NIL;
+		for(uint32_t kq = 0; kq < ncid; kq++) {
+			const uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
+			if(pl * a.mcoef < 2.0 * a.min_score) { break; }
+			pred = gs[gs[c[kq].lid].upos].rid;
+		}
+		st->pred_rid = pred;
+	}
+}
+
+/* -----------------------------------------------------------------------------------------------------
  * K2a: the same stage, one *wavefront* per read with the seed / leaf array staged in LDS (first round only; reads whose
  * arrays do not fit the LDS budget, and the rescue rounds, take the lane-per-read kernel above).
  *   - radix levels whose digit is constant over the range are identity permutations and are skipped (one parallel
@@ -1433,7 +1525,8 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 		ReadState *st = &a.st[a.work[wi]];
 		const uint32_t seed_n = (uint32_t)rdfirst((int)st->seed_n0);     /* not seed_n: launches of other classes update that concurrently */
 		/* big_only: what mm_chain_kernel cannot take -- more than K2S_MAX_N seeds, an LDS image of more than 160 KB, or leaves that did not fit even the retry */
-		if(a.big_only && seed_n + 1 <= K2S_MAX_N && k2c_bytes(seed_n + 1, k2c_leafcap(seed_n + 1, a.leaf_shift)) <= K2C_MAX_LDS_KB * 1024u && (uint32_t)rdfirst((int)st->n_root) != 0xfffffffeu) { continue; }
+		if(a.big_only == 2 && seed_n + 1 <= K2S_MAX_N) { continue; }          /* (the lane-per-read sweep took everything else) */
+		if(a.big_only == 1 && seed_n + 1 <= K2S_MAX_N && k2c_bytes(seed_n + 1, k2c_leafcap(seed_n + 1, a.leaf_shift)) <= K2C_MAX_LDS_KB * 1024u && (uint32_t)rdfirst((int)st->n_root) != 0xfffffffeu) { continue; }
 		if(seed_n == 0) { if(a.n_lo == 0 && !a.retry && lane == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; } continue; }
 		bool fits; uint32_t lcap = 0;
 		if(a.retry) {

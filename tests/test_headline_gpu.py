@@ -1,7 +1,8 @@
 """GPU, BASELINE.json configs[2..4] at FULL size, through the command-line program (the drop-in), against the compiled reference (oracle/_ref/minialign -t1:
 with several threads the reference's own output depends on which thread buffer a read lands in):
 
-  (i)   D.melanogaster dm6-size reference (143.7 Mb, 1 870 contigs) x PBSIM-like x20 (2.87 Gb): the WHOLE SAM byte for byte;
+  (i)   D.melanogaster dm6-size reference (143.7 Mb, 1 870 contigs) x PBSIM-like x20 (2.87 Gb): the WHOLE SAM byte for byte, and the same set split over 8 ranks of
+        minialign_amd.multi (all on cuda:0) identical to the single stream;
   (ii)  human hg38-size reference (3.1 Gb, 25 contigs) x PBSIM-like x3 (9.3 Gb, the headline set): size-independent properties of the whole 13 GB stream
         (tools/samcheck.c: one primary record per read in input order, every CIGAR adds up to its read and stays inside its contig, ...), the records of the
         first 45 000 reads (more than three 300 Mb batches on four lanes) byte for byte, and the same set split over 2 ranks of minialign_amd.multi on cuda:0
@@ -93,6 +94,14 @@ def test_dm6_size_x20_whole_sam_equals_the_reference(work):
     got = _md5_records(os.path.join(work, 'dm6_ours.sam')); ref_md5 = _md5_records(want)
     assert got == ref_md5, 'dm6-size x20: SAM differs from the compiled reference'
     assert got[1] == s['records']
+    # the same set over EIGHT ranks (all on cuda:0; MM_LANES=1 each): 1 870 contigs, so the carried value differs at nearly every shard boundary -- checks, window re-maps
+    # and the rank-after-rank writers all have work -- and the stream must still be the single stream's
+    env = dict(os.environ, MM_MULTI_SAME_DEVICE='1', MM_SLAB_GB='6', MM_LANES='1', MM_HOST_THREADS='24', PYTHONPATH=M.ROOT)
+    port = 29900 + os.getpid() % 1000
+    s8, err8, sec8 = _map_through_samcheck([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                                            '-m', 'minialign_amd.multi', '-xpacbio', ref, rd], rd, 0, os.devnull, env=env, cwd=M.ROOT, timeout=1200)
+    assert s8['error'] == '' and s8['digest'] == s['digest'] and s8['records'] == s['records'] and s8['bytes'] == s['bytes'], (s, s8, err8.decode()[-1500:])
+    sys.stderr.write('[headline] dm6-size x20: single stream %.1f s, eight ranks on one GPU %.1f s (index builds included)\n' % (sec, sec8))
     for f in ('dm6_ours.sam', 'dm6_ref.sam', 'dm6_rd.fa', 'dm6_ref.fa'): os.unlink(os.path.join(work, f))
 
 @pytest.fixture(scope='module')

@@ -84,15 +84,17 @@ def test_bench_line_with_two_ranks_on_one_gpu():
     assert d['sam_identical'] is True, d.get('sam_check')
     assert d['roofline']['achieved'] > 0 and 'cpu_baseline' not in d
 
-@pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1')],
-                         ids=['rounds-through-the-host', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain', 'batch-split-on-pool-exhaustion'])
+@pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1'),
+                                 dict(MM_K2_LDS_CHAIN='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_HOST_READER='1'), dict(MM_HOST_INDEX='1')],
+                         ids=['rounds-through-the-host', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain', 'batch-split-on-pool-exhaustion',
+                              'chain-sweep-in-lds', 'no-chain-jobs', 'host-reader', 'host-index'])
 def test_alternative_schedules_give_the_same_bytes(env):
     """the forms kept behind environment switches -- the occurrence-threshold rounds as separate launches through the host (the default runs them inside the
     extension kernel, k3_rescue_round), one read per wave, per-lane DP
     workspaces, the one-kernel sort + chain, and the fallback for a batch the device pools cannot hold (its reads in halves, down to fewer than 8) -- on a repeat-rich set with a high seed threshold, where many reads need the rescue rounds"""
     with tempfile.TemporaryDirectory() as d:
         ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
-        M.gensim('genome', 7401, 1500000, 6, 0.45, out=ref); M.gensim('reads', 7402, ref, 3.0, 'pacbio', 'fa', 6000, 2500, out=rd)
+        M.gensim('genome', 7401, 1500000, 6, 0.45, out=ref); M.gensim('reads', 7402, ref, 3.0, 'pacbio', 'fa', 6000, 2500, out=rd)          # 750 reads, many with dozens of chains: the chain jobs of the default run have work
         opts = ['-xpacbio', '-f0.2,0.05,0.002']
         want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
         r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='8', MM_BATCH_BASES='3000000', **env), timeout=600)
