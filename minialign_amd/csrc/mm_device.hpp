@@ -1174,7 +1174,6 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_kernel(K2c
 struct K2wArgs {
 	ReadState *st; const uint32_t *work; uint32_t n_work;
 	Seed *seed_pool; Root *root_pool; uint8_t *scratch;          /* scratch: 16 B per element of the seed pool, a read's part at 16 * seed_off */
-	uint32_t *rs_pool; uint32_t rs_slots, rs_stride; uint32_t *rs_top;      /* workspaces for the root sort of the few reads with more than 64 chains */
 	double mcoef; uint32_t min_score, twlen;
 	const uint32_t *seq_len; const uint8_t *seq_circ;
 };
@@ -1241,8 +1240,9 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_sweep_kern
 		if(a.seq_circ) { circularize(gs, c, n, nlid, ncid, a.seq_len, a.seq_circ, a.twlen); }
 		if(ncid <= 64) { ins_sort_64((U64R *)c, (U64R *)c + ncid); }          /* longest first (minialign.c:3719); radix_sort_64x is an insertion sort up to 64 elements */
 		else {
-			const uint32_t slot = atomicAdd(a.rs_top, 1u);
-			if(slot >= a.rs_slots || !radix_sort_64((U64R *)c, ncid, a.rs_pool + (uint64_t)slot * a.rs_stride, a.rs_stride)) { st->err |= ERR_STACK; }
+			/* the read's own scratch area is free again (leaves and roots are written out): 4 words per element of its seed region, i.e. at least 8 per chain -- the
+			 * 512 bucket words and 3 per pending range (at most one per 65 chains) of radix_sort_64x fit from 65 chains on */
+			if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)lrs, 4u * st->seed_cap)) { st->err |= ERR_STACK; }
 		}
 		uint32_t pred = gaba::NIL;
 		for(uint32_t kq = 0; kq < ncid; kq++) {

@@ -650,6 +650,7 @@ struct DevCache {
 		void *p = it->second; *got = it->first.second; blocks.erase(it); return p;
 	}
 	void give(int dev, size_t bytes, void *p) { std::lock_guard<std::mutex> lk(mu); blocks.emplace(std::make_pair(dev, bytes), p); }
+	void flush(int dev) { std::lock_guard<std::mutex> lk(mu); for(auto it = blocks.begin(); it != blocks.end();) { if(it->first.first == dev) { (void)hipFree(it->second); it = blocks.erase(it); } else ++it; } }          /* out of memory: everything held goes back to the driver */
 };
 static DevCache &dev_cache() { static DevCache *c = new DevCache(); return *c; }          /* (never destroyed: blocks may come back while the process winds down) */
 template<typename T> struct DBuf {
@@ -660,7 +661,7 @@ template<typename T> struct DBuf {
 		release();
 		(void)hipGetDevice(&dev);
 		size_t got = 0; void *q = dev_cache().take(dev, want * sizeof(T), &got);
-		if(!q) { got = want * sizeof(T); if(hipMalloc(&q, got) != hipSuccess) { fprintf(stderr, "[minialign_amd] hipMalloc of %.1f MB failed\n", got / 1e6); return false; } }
+		if(!q) { got = want * sizeof(T); if(hipMalloc(&q, got) != hipSuccess) { q = nullptr; dev_cache().flush(dev); if(hipMalloc(&q, got) != hipSuccess) { fprintf(stderr, "[minialign_amd] hipMalloc of %.1f MB failed\n", got / 1e6); return false; } } }
 		p = (T *)q; bytes = got; n = got / sizeof(T); return true;
 	}
 	void release() { if(p) dev_cache().give(dev, bytes, p); p = nullptr; n = 0; bytes = 0; }
@@ -702,9 +703,10 @@ static gaba_arena_t *upload_reference(const mm_idx_s *mi, std::vector<uint64_t> 
  * what the sort's entries address -- the caller reports it (no silent host build). */
 static bool idx_gen_device(const mm_opt_s *o, mm_idx_s *mi, const char *ref_fasta, bool verbose)
 {
-	int ndev = 0; if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "[minialign_amd] mm_idx_gen: no HIP device (MM_HOST_INDEX=1 builds the index on the host)\n"); return false; }
-	(void)hipGetDevice(&mi->dev);
 	double tv = now_ms(); int lapi = 0;
+	int ndev = 0; if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "[minialign_amd] mm_idx_gen: no HIP device (MM_HOST_INDEX=1 builds the index on the host)\n"); return false; }
+	(void)hipGetDevice(&mi->dev); (void)hipFree(0);
+	if(verbose) { fprintf(stderr, "[minialign_amd] index (device): HIP runtime up after %.1f ms\n", now_ms() - tv); } tv = now_ms();
 	auto lap = [&](const char *what) { (void)hipDeviceSynchronize(); const double t = now_ms(); if(lapi < 8) mi->build_ms[lapi++] = t - tv; if(verbose) fprintf(stderr, "[minialign_amd] index (device): %s %.1f ms\n", what, t - tv); tv = t; };
 #define IK(_e) do { hipError_t _r = (_e); if(_r != hipSuccess) { fprintf(stderr, "[minialign_amd] index (device): HIP error %s at line %d\n", hipGetErrorString(_r), __LINE__); return false; } } while(0)
 	std::vector<uint64_t> off; std::vector<uint32_t> len;
@@ -1078,7 +1080,7 @@ struct mm_align_s {
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
-	DBuf<uint8_t> k2w_scratch; DBuf<uint32_t> k2w_rs;          /* lane-per-read chain sweep: leaf / chain scratch (16 B per element of the seed pool), root-sort workspaces + their cursor */
+	DBuf<uint8_t> k2w_scratch;          /* lane-per-read chain sweep: leaf / chain scratch, 16 B per element of the seed pool */
 	DBuf<SpecJob> spec_jobs; DBuf<SpecMemo> spec_memo; DBuf<uint32_t> spec_path; DBuf<gaba::Segment> spec_seg; DBuf<unsigned long long> spec_top;      /* chain jobs of the heaviest reads of a launch (K3Args.jobs) */
 	DBuf<uint64_t> tap_words;              /* mm_batch_tap: the minimizer stream words of the batch, parallel to min_pool */
 	DBuf<uint8_t> d_text, d_codes; DBuf<TextRead> d_tinfo; DBuf<uint32_t> d_tn;      /* packing on the device: text range of the batch, per-read extents, code bytes of the arena, bases found per read */
@@ -1223,9 +1225,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				if(!getenv("MM_K2_LDS_CHAIN")) {
 					/* the sweep with one lane per read in HBM (mm_chain_sweep_kernel): every read of the batch in flight at once, no LDS, a few hundred waves */
 					K2wArgs kw; kw.st = a->d_st.p; kw.work = a->d_work.p; kw.n_work = (uint32_t)work.size(); kw.seed_pool = a->seed_pool.p; kw.root_pool = a->root_pool.p; kw.scratch = a->k2w_scratch.p;
-					kw.rs_stride = 512 + 3 * 1024; kw.rs_slots = 256; kw.rs_pool = a->k2w_rs.p; kw.rs_top = a->k2w_rs.p + 256ull * kw.rs_stride;
 					kw.mcoef = a->mcoef; kw.min_score = a->o.min_score; kw.twlen = a->twlen; kw.seq_len = a->dix.seq_len; kw.seq_circ = a->dix.seq_circ;
-					CK(hipMemsetAsync(kw.rs_top, 0, 4, a->k2s[0]));
 					hipLaunchKernelGGL(mm_chain_sweep_kernel, dim3(((uint32_t)work.size() + 63) / 64), dim3(64), 0, a->k2s[0], kw);
 					CK(hipGetLastError());
 					CK(hipEventRecord(a->k2e[0], a->k2s[0])); CK(hipStreamWaitEvent(a->stream, a->k2e[0], 0));
@@ -1704,7 +1704,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	const uint64_t min_total = ((a->mi->w < 4 || scale > 1) ? bases : bases / 2) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
 	ok &= a->min_pool.ensure(min_total);
 	ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
-	if(!getenv("MM_K2_LDS_CHAIN")) { ok &= a->k2w_scratch.ensure(a->seed_pool.n * 16) && a->k2w_rs.ensure(256ull * (512 + 3 * 1024) + 16); }
+	if(!getenv("MM_K2_LDS_CHAIN")) { ok &= a->k2w_scratch.ensure(a->seed_pool.n * 16); }
 	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
 	ok &= a->resc_pool.ensure(min_total * std::min<uint64_t>(scale, 4));
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
@@ -1871,7 +1871,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
-	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->k2w_rs.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	free_chunk_pool(a->chunk_pool); a->chunk_pool = nullptr;
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
