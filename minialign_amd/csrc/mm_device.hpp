@@ -64,7 +64,9 @@ struct ReadState {
 	uint32_t err;                                     /* sticky error flags */
 	uint32_t kh_mask, kh_cnt, kh_ub;                  /* kh_t state of the per-read position hash (persists across rounds) */
 	uint32_t seed_n0;                                 /* seed count as K1 left it: immutable, picks the size class of the first-round sort + chain */
+	uint32_t n_pass, w_pass;                          /* after chaining: chains that pass the length test of mm_search_load_root (minialign.c:3849), their summed lengths -- the work the extension has with this read */
 	uint32_t spec_off, spec_n;                        /* first trials of this read's chains computed by the other waves of the launch (SpecMemo entries), 0: none */
+	uint32_t k3_trials, k3_hits, k3_chains;           /* diagnostics: extension trials of the read, of which taken from a chain job, chains walked */
 	uint32_t k3_ticks, k3_vec, k3_fill_ticks, k3_trace_ticks;   /* diagnostics: s_memtime ticks (whole / DP fill / traceback) and DP vectors the extension kernel spent on this read */
 	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
 	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
@@ -759,13 +761,13 @@ __global__ void __launch_bounds__(64) mm_sort_chain_kernel(K2Args a)
 	if(!radix_sort_64((U64R *)c, ncid, scratch, a.rs_stride)) { st->err |= ERR_STACK; }      /* longest first (minialign.c:3719) */
 	/* prediction for the carried reference-length state: the last chain that passes the length test of
 	 * mm_search_load_root (minialign.c:3849) is the last one mm_init_ref sees, unless the extension loop stops early */
-	uint32_t pred = gaba::NIL;
+	uint32_t pred = gaba::NIL, n_pass = 0, w_pass = 0;          /* chains that pass the length test of mm_search_load_root and their summed lengths: what the extension will cost */
 	for(uint32_t kq = 0; kq < ncid; kq++) {
 		uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
 		if(pl * a.mcoef < 2.0 * a.min_score) { break; }
-		pred = s[ls[c[kq].lid].upos].rid;
+		pred = s[ls[c[kq].lid].upos].rid; n_pass++; w_pass += pl;
 	}
-	st->pred_rid = pred;
+	st->pred_rid = pred; st->n_pass = n_pass; st->w_pass = w_pass;
 }
 
 typedef __attribute__((address_space(3))) Seed LSeed;
@@ -1148,13 +1150,13 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_kernel(K2c
 			if(ncid) {
 				if(a.seq_circ) { circularize(gs, c, n, nlid, ncid, a.seq_len, a.seq_circ, a.twlen); }
 				if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)tab, 1536)) { st->err |= ERR_STACK; }              /* longest first (minialign.c:3719) */
-				uint32_t pred = gaba::NIL;
+				uint32_t pred = gaba::NIL, n_pass = 0, w_pass = 0;          /* chains that pass the length test of mm_search_load_root and their summed lengths: what the extension will cost */
 				for(uint32_t kq = 0; kq < ncid; kq++) {
 					uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
 					if(pl * a.mcoef < 2.0 * a.min_score) { break; }
-					pred = gs[gs[c[kq].lid].upos].rid;
+					pred = gs[gs[c[kq].lid].upos].rid; n_pass++; w_pass += pl;
 				}
-				st->pred_rid = pred;
+				st->pred_rid = pred; st->n_pass = n_pass; st->w_pass = w_pass;
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1244,13 +1246,13 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_sweep_kern
 			 * 512 bucket words and 3 per pending range (at most one per 65 chains) of radix_sort_64x fit from 65 chains on */
 			if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)lrs, 4u * st->seed_cap)) { st->err |= ERR_STACK; }
 		}
-		uint32_t pred = gaba::NIL;
+		uint32_t pred = gaba::NIL, n_pass = 0, w_pass = 0;          /* chains that pass the length test of mm_search_load_root and their summed lengths: what the extension will cost */
 		for(uint32_t kq = 0; kq < ncid; kq++) {
 			const uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
 			if(pl * a.mcoef < 2.0 * a.min_score) { break; }
-			pred = gs[gs[c[kq].lid].upos].rid;
+			pred = gs[gs[c[kq].lid].upos].rid; n_pass++; w_pass += pl;
 		}
-		st->pred_rid = pred;
+		st->pred_rid = pred; st->n_pass = n_pass; st->w_pass = w_pass;
 	}
 }
 
@@ -1568,13 +1570,13 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
 			if(ncid) {
 				if(a.seq_circ) { circularize(gs, c, seed_n, nlid, ncid, a.seq_len, a.seq_circ, a.twlen); }
 				if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)cnt, 1536)) { st->err |= ERR_STACK; }              /* longest first (minialign.c:3719); LDS tables reused as scratch */
-				uint32_t pred = gaba::NIL;
+				uint32_t pred = gaba::NIL, n_pass = 0, w_pass = 0;          /* chains that pass the length test of mm_search_load_root and their summed lengths: what the extension will cost */
 				for(uint32_t kq = 0; kq < ncid; kq++) {
 					uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
 					if(pl * a.mcoef < 2.0 * a.min_score) { break; }
-					pred = gs[gs[c[kq].lid].upos].rid;
+					pred = gs[gs[c[kq].lid].upos].rid; n_pass++; w_pass += pl;
 				}
-				st->pred_rid = pred;
+				st->pred_rid = pred; st->n_pass = n_pass; st->w_pass = w_pass;
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1810,13 +1812,13 @@ __device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uin
 		if(ncid) {
 			if(ix.seq_circ) { circularize(gs, c, seed_n, nlid, ncid, ix.seq_len, ix.seq_circ, twlen); }
 			if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)tab, 1536)) { err |= ERR_STACK; }
-			uint32_t pred = gaba::NIL;
+			uint32_t pred = gaba::NIL, n_pass = 0, w_pass = 0;          /* chains that pass the length test of mm_search_load_root and their summed lengths: what the extension will cost */
 			for(uint32_t kq = 0; kq < ncid; kq++) {
 				uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
 				if(pl * mcoef < 2.0 * min_score) { break; }
-				pred = gs[gs[c[kq].lid].upos].rid;
+				pred = gs[gs[c[kq].lid].upos].rid; n_pass++; w_pass += pl;
 			}
-			st->pred_rid = pred;
+			st->pred_rid = pred; st->n_pass = n_pass; st->w_pass = w_pass;
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -2019,7 +2021,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			if(e2) { if(lane == 0) { st->err |= e2; } break; }
 		}
 		const unsigned long long cy_read0 = MM_TICK(); const uint32_t vec_read0 = x.n_vec; const unsigned long long cyf_read0 = cy_fill, cyt_read0 = cy_trace;
-		const uint32_t n_root = (uint32_t)rdfirst((int)st->n_root);
+		const uint32_t n_root = (uint32_t)rdfirst((int)st->n_root); uint32_t dg_trials = 0, dg_hits = 0, dg_chains = 0;
 		/* reads with many chains run several extension trials and are the critical path of the launch (one of them can cost
 		 * three times a wave's fair share): their waves get issue priority so that they move at uncontended speed while the
 		 * ordinary reads fill the slots in between.  The top priority goes by place in the work list -- its first 64th is the reads with the
@@ -2077,7 +2079,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			uint32_t lid = (uint32_t)rdfirst((int)rt.lid);
 			uint32_t plen = (uint32_t)OFS((int32_t)rdfirst((int)rt.plen));
 			if(plen * a.mcoef < 2.0 * a.min_score) { break; }
-			next_n = 0;
+			next_n = 0; dg_chains++;
 			if(n_bin + 2 > a.bin_cap_per_read) { err |= ERR_BIN_CAP; break; }
 			uint32_t iid = n_bin;
 			if(lane == 0) { bin[iid] = 0; bin[iid + 1] = 0; }        /* header {n_aln, plen, lb, ub}: all-zero as in the reference *as built*  */
@@ -2169,8 +2171,9 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 					if((stt & 1u) && (uint32_t)rdfirst((int)smp->aid) == sr.aid && (uint32_t)rdfirst((int)smp->cp_a) == sr.cp_a && (uint32_t)rdfirst((int)smp->cp_b) == sr.cp_b && (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u)) { memo0 = true; memo1 = (stt & 2u) != 0; }
 					if(memo0 && lane == 0) { atomicAdd(&a.job_top[4], 1ull); }
+					dg_hits += memo0 ? 1u : 0u;
 				}
-				chain_first = false;
+				chain_first = false; dg_trials++;
 				for(int pass = 0; pass < 2 && !skip; pass++) {
 					gaba::Sec ca = pass == 0 ? rsec_f : rsec_r;
 					gaba::Sec cb = ((sr.rev != 0) == (pass == 0)) ? qsec_r : qsec_f;
@@ -2318,6 +2321,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			st->n_bin = n_bin; st->bin_off = bin_off; st->n_aln = n_aln; st->aln_off = aln_off;
 			st->kh_mask = kh.mask; st->kh_cnt = kh.cnt; st->kh_ub = kh.ub;
 			st->err |= err;
+			st->k3_trials += dg_trials; st->k3_hits += dg_hits; st->k3_chains += dg_chains;
 			st->k3_ticks += (uint32_t)(MM_TICK() - cy_read0); st->k3_vec += x.n_vec - vec_read0;
 			st->k3_fill_ticks += (uint32_t)(cy_fill - cyf_read0); st->k3_trace_ticks += (uint32_t)(cy_trace - cyt_read0);
 			if(n_res > 0) { st->done = 1; }

@@ -1306,10 +1306,14 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			 * fair share of the DP work): one of them is the critical path of the launch, so they start first.  Moving *all* reads
 			 * into chain-count order is worse (measured): the bulk of moderately heavy reads then crowds the start. */
 			if(by_len.size() >= 256) {
-				std::vector<uint32_t> nr(by_len.size()); for(size_t i = 0; i < by_len.size(); i++) nr[i] = hst[by_len[i]].n_root;
-				std::nth_element(nr.begin(), nr.begin() + (nr.size() - 1 - nr.size() / 64), nr.end());
-				const uint32_t thr = std::max<uint32_t>(nr[nr.size() - 1 - nr.size() / 64], 4);          /* top ~1.5 % */
-				auto mid = std::stable_partition(by_len.begin(), by_len.end(), [&](uint32_t x) { return hst[x].n_root >= thr; });
+				/* which reads are heavy is known once they are chained: the summed length of the chains that pass the length test of mm_search_load_root (ReadState.w_pass) is
+				 * what the extension will walk -- a read inside a repeat family has 5 - 8 such chains and costs as many full alignments, 15 DP vectors per base against 2.
+				 * (The number of chains, n_root, says nothing: every read of a human-size reference has 50 - 120 of them, nearly all too short to be tried.) */
+				std::vector<uint32_t> nr(by_len.size()); for(size_t i = 0; i < by_len.size(); i++) nr[i] = hst[by_len[i]].w_pass;
+				std::nth_element(nr.begin(), nr.begin() + (nr.size() - 1 - nr.size() / 32), nr.end());
+				const uint32_t thr = std::max<uint32_t>(nr[nr.size() - 1 - nr.size() / 32], 1);          /* top ~3 % */
+				auto mid = std::stable_partition(by_len.begin(), by_len.end(), [&](uint32_t x) { return hst[x].w_pass >= thr && hst[x].n_pass >= 2; });
+				std::stable_sort(by_len.begin(), mid, [&](uint32_t x, uint32_t y) { return hst[x].w_pass > hst[y].w_pass; });
 				n_heavy = (uint32_t)(mid - by_len.begin());
 			}
 			if(const char *e = getenv("MM_EXPERIMENT_K3_HEAVY")) {          /* timing experiment only (results incomplete): the N reads with the most chains */
@@ -1347,7 +1351,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(a->spec_jobs.ensure(job_cap) && a->spec_memo.ensure(job_cap) && a->spec_path.ensure(path_cap) && a->spec_seg.ensure(job_cap * 8) && a->spec_top.ensure(8)) {
 				CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
 				SpecJobsArgs sj; sj.idx = a->dix; sj.in = a->d_in.p; sj.st = a->d_st.p; sj.work = a->d_work.p; sj.n_heavy = n_heavy; sj.seed_pool = a->seed_pool.p; sj.root_pool = a->root_pool.p;
-				sj.mcoef = a->mcoef; sj.min_score = a->o.min_score; sj.min_roots = 6; sj.jobs = a->spec_jobs.p; sj.memo = a->spec_memo.p; sj.job_cap = job_cap; sj.job_top = a->spec_top.p;
+				sj.mcoef = a->mcoef; sj.min_score = a->o.min_score; sj.min_roots = 2; sj.jobs = a->spec_jobs.p; sj.memo = a->spec_memo.p; sj.job_cap = job_cap; sj.job_top = a->spec_top.p;
 				hipLaunchKernelGGL(mm_spec_jobs_kernel, dim3((n_heavy + 63) / 64), dim3(64), 0, a->stream, sj);
 				CK(hipGetLastError());
 				k3.jobs = a->spec_jobs.p; k3.memo = a->spec_memo.p; k3.job_top = a->spec_top.p; k3.job_cap = job_cap; k3.spath = a->spec_path.p; k3.spath_cap = path_cap; k3.sseg = a->spec_seg.p; k3.sseg_cap = job_cap * 8;
@@ -2144,7 +2148,7 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	a->rlen_carry = batch_carry_out(a, b, a->rlen_carry);
 	if(const char *fn = getenv("MM_DUMP_READ_COST")) {          /* diagnostics: per-read cost of the extension kernel */
 		std::vector<ReadState> d(n_reads); CPY(a, d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
-		if(FILE *fp = fopen(fn, "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks); fclose(fp); }
+		if(FILE *fp = fopen(fn, "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks, d[i].n_pass, d[i].w_pass, d[i].k3_chains, d[i].k3_trials, d[i].k3_hits, d[i].n_aln, d[i].spec_n); fclose(fp); }
 	}
 	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
