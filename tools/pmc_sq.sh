@@ -3,7 +3,7 @@
 # with one lane, so that every kernel runs alone.  Usage (on the GPU box): tools/pmc_sq.sh <out.json> [bench args]
 OUT=${1:-gpurun_out/pmc_sq.json}; shift; D=$(mktemp -d /tmp/pmcsq.XXXX); cd "$(dirname "$0")/.."; R=$PWD
 export TMPDIR=/tmp
-ARGS=${*:---depth 0.3 --lanes 1 --steps 1 --warmup 0 --no-cpu}
+ARGS=${*:---depth 0.3 --lanes 1 --steps 1 --warmup 0 --no-cpu --no-cli --no-packed}
 C1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_SCA"
 C2="SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"
 i=0

@@ -4,7 +4,7 @@
 OUT=${1:-gpurun_out/pmc.json}; D=$(mktemp -d /tmp/pmc.XXXX); cd "$(dirname "$0")/.."; R=$PWD
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-	( cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/$c -o p -- python $R/bench.py --depth 0.3 --lanes 1 --steps 1 --warmup 0 --no-cpu > $D/$c.log 2>&1 )
+	( cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/$c -o p -- python $R/bench.py --depth 0.3 --lanes 1 --steps 1 --warmup 0 --no-cpu --no-cli --no-packed > $D/$c.log 2>&1 )
 done
 python3 - "$D" "$OUT" <<'PY'
 import csv, glob, json, sys
@@ -30,7 +30,7 @@ try:
 except Exception as e:
     per['alg_bytes_per_launch'] = None
 per['correction'] = 'MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> doubled; WRITE_SIZE taken as is'
-json.dump({'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> --output-format csv -- python bench.py --depth 0.3 --lanes 1 --steps 1 --warmup 0 --no-cpu (separate passes)',
+json.dump({'command': 'rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> --output-format csv -- python bench.py --depth 0.3 --lanes 1 --steps 1 --warmup 0 --no-cpu --no-cli --no-packed (separate passes)',
            'workload': 'hg38', 'note': 'the headline reference (3.1 Gb, 25 contigs) with a tenth of the headline reads (depth 0.3 instead of 3: four batches of 233 Mb): per launch of mm_extend_kernel, averaged over the round-0 and the rescue-round launches in the same 1 : 2 mix as the full run',
            'counters': res, 'mm_extend_kernel_per_launch': per}, open(out, 'w'), indent=1)
 print(json.dumps(per))
