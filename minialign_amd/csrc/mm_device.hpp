@@ -1591,6 +1591,7 @@ __global__ void __launch_bounds__(64) mm_sort_chain_lds_kernel(K2aArgs a)
  * K3: extension driver, one wavefront per read
  * ===================================================================================================== */
 struct KhSlot { uint64_t k, v; };
+#define MM_NEXT_STRIDE(_cap) (2ull * (_cap) + MM_NEXT_SCRATCH)          /* per wave: next[cap], the sort's scratch, a copy of next[] for the look-ahead of the retry jobs */
 #define MM_NEXT_SCRATCH 1024u          /* u64 words behind each wave's next[] array: 512 bucket words + 512 pending ranges for radix_sort_64 */
 struct AlnRec {                /* what the host needs of a gaba_alignment_t (gaba.h:205-220) */
 	int64_t score; double identity;
@@ -1632,6 +1633,13 @@ struct K3Args {
 	 * waves).  Same results by construction.  NULL: no jobs */
 	const struct SpecJob *jobs; struct SpecMemo *memo; unsigned long long *job_top;      /* job_top[0] = jobs enumerated (mm_spec_jobs_kernel), [1] = cursor, [2] staged path words, [3] staged segments, [4] memo hits */
 	uint64_t job_cap; uint32_t *spath; uint64_t spath_cap; gaba::Segment *sseg; uint64_t sseg_cap;
+	/* retry jobs: after a recorded alignment whose chain has length to spare, mm_search_load_next hands out up to eight more seeds of the chain, one per trial, and nearly every one of
+	 * those trials is a full downward pass that ends in a maximum already in the hash (a duplicate, thrown away, minialign.c:3969) -- the tail of a launch is a read doing that on one
+	 * wave.  The start points and band widths of these trials follow from the next-seed list alone as long as each is a duplicate, so the wave that is about to run the first of them
+	 * works the list ahead on a copy, publishes the rest as jobs (rjobs / rstate / rmemo, agent-scope hand-off as for the chain jobs), and waves that have run out of reads take them
+	 * (they stay in the launch until the last read is done: reads_done).  The owner takes a result where its inputs are the trial's, runs a job itself where nobody has claimed it, and
+	 * works on a later job of its own while one it needs is in another wave's hands.  NULL: none */
+	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = helpers' cursor, [2] = reads done, [3] = results taken */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 };
 
@@ -1910,7 +1918,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	 * sketch, sort, chain, copies, the next extension launch -- get theirs within a read's time instead of waiting for a whole persistent launch to drain;
 	 * the per-wave scratch is numbered like the workspace.  Without the ring (per-call entries): persistent waves stealing reads from a counter, as before. */
 	const bool persistent = a.persistent != 0 || a.ring == nullptr;
-	uint64_t *next = a.next_pool + (uint64_t)wave * (a.next_cap + MM_NEXT_SCRATCH);      /* [next_cap entries][radix-sort scratch]; one-read-per-wave launches: re-pointed below by workspace number */
+	uint64_t *next = a.next_pool + (uint64_t)wave * MM_NEXT_STRIDE(a.next_cap);      /* [next_cap entries][radix-sort scratch]; one-read-per-wave launches: re-pointed below by workspace number */
 	uint32_t *next_scratch = (uint32_t *)(next + a.next_cap);
 	const DevIndex &ix = a.idx;
 	unsigned long long n_fill = 0, n_trace = 0;
@@ -1928,7 +1936,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			x.slab = a.cls[_want].slabs + (uint64_t)slab_no * a.cls[_want].bytes; x.cap = (uint32_t)a.cls[_want].bytes; x.top = gaba::SLAB_HEAD; \
 			for(uint32_t _i = (uint32_t)lane; _i < gaba::SLAB_HEAD / 4; _i += 64) { ((uint32_t *)x.slab)[_i] = ((const uint32_t *)a.roots)[_i]; } \
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
-			if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[_want].next_base) * (a.next_cap + MM_NEXT_SCRATCH); next_scratch = (uint32_t *)(next + a.next_cap); } \
+			if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[_want].next_base) * MM_NEXT_STRIDE(a.next_cap); next_scratch = (uint32_t *)(next + a.next_cap); } \
 		} }
 	/* jobs first: the first trials of the chains of the heaviest reads, one per wave at a time, by every wave of the launch (K3Args.jobs) */
 	if(a.jobs && a.ring) {
@@ -2000,11 +2008,67 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		}
 		__builtin_amdgcn_s_setprio(0);
 	}
+	/* a retry job (K3Args.rjobs): the downward pass of a trial and its max search, into rmemo[ji]; run by a helper wave, or by the read's own wave ahead of its turn */
+	enum : uint32_t { RJ_EMPTY = 0, RJ_READY = 1, RJ_CLAIMED = 2, RJ_DONE = 3, RJ_CANCELLED = 4 };
+	auto run_rjob = [&](uint32_t ji) {
+		const SpecJob j = a.rjobs[ji];
+		const uint32_t r = (uint32_t)rdfirst((int)j.r), aid = (uint32_t)rdfirst((int)j.aid), cp_a = (uint32_t)rdfirst((int)j.cp_a), cp_b = (uint32_t)rdfirst((int)j.cp_b);
+		const uint32_t rev = (uint32_t)rdfirst((int)j.rev), rlen = (uint32_t)rdfirst((int)j.rlen); const int rcirc = rdfirst((int)j.rcirc), bw = rdfirst((int)j.pad);
+		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen); const uint64_t q_off = rdfirst64(a.in[r].q_off), roff = rdfirst64(a.idx.seq_off[aid]);
+		K3_NEED_SLAB(qlen);
+		const gaba::Sec rsec_f = gaba::Sec{ aid << 1, rlen, roff, 0, 0 };
+		const gaba::Sec qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }, qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
+		SpecMemo mo; mo.state = 0; mo.aid = aid; mo.cp_a = cp_a; mo.cp_b = cp_b; mo.rev = rev; mo.mmax0 = 0; mo.mmax1 = 0; mo.tplen = 0; mo.path_off = 0; mo.seg_off = (uint32_t)bw;
+		mo.pp_apos = mo.pp_bpos = 0; mo.pp_plen = 0;
+		mo.ao.status = 0; mo.ao.score = 0; mo.ao.identity = 0; mo.ao.agcnt = mo.ao.bgcnt = mo.ao.dcnt = mo.ao.slen = mo.ao.plen = 0;
+		gaba::dp_flush(x); x.err = 0;
+		DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
+		ExtOut eo = k3_extend_core(din, bw, rsec_f, cp_a, rev ? qsec_r : qsec_f, cp_b, 1, rcirc);
+		x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk); n_fill += (uint32_t)rdfirst((int)eo.n_fill);
+		const uint32_t m = (uint32_t)rdfirst((int)eo.m); const int64_t mmax = (int64_t)rdfirst64((uint64_t)eo.mmax);
+		if(x.err == 0) {
+			mo.mmax0 = mmax; mo.state = 1;
+			if(mmax != 0) {
+				din.top = x.top;
+				LeafOut lo = k3_leaf_search(din, m, 1);
+				mo.pp_apos = (uint32_t)rdfirst((int)lo.pp.apos); mo.pp_bpos = (uint32_t)rdfirst((int)lo.pp.bpos); mo.pp_plen = rdfirst64(lo.pp.plen);
+			}
+		}
+		x.err = 0;
+		if(lane == 0) { a.rmemo[ji] = mo; }
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if(lane == 0) { __hip_atomic_store(&a.rstate[ji], (uint32_t)RJ_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	};
+	const bool rq_on = a.rjobs != nullptr && a.ring != nullptr && persistent;
 
 	while(true) {
 		uint32_t wi = wave;
 		if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
-		if(wi >= a.n_work) { break; }
+		if(wi >= a.n_work) {
+			/* no read left for this wave: it takes retry jobs of the reads that are still being walked until the last of them is done */
+			if(rq_on) {
+				uint32_t mine = 0xffffffffu;          /* a slot number this wave drew that has not been published yet */
+				while(true) {
+					uint32_t ji = mine, stt = 0, fin = 0;
+					if(lane == 0) {
+						if(ji == 0xffffffffu) {
+							const uint32_t cur = __hip_atomic_load(&a.rq_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), top = __hip_atomic_load(&a.rq_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							if(cur < top && cur < a.rq_cap) { ji = atomicAdd(&a.rq_ctl[1], 1u); if(ji >= a.rq_cap) { ji = 0xffffffffu; } }
+						}
+						if(ji != 0xffffffffu) { stt = __hip_atomic_load(&a.rstate[ji], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if(stt == RJ_READY) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY ? 100u : 99u; } }
+						fin = __hip_atomic_load(&a.rq_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.n_work ? 1u : 0u;
+					}
+					ji = (uint32_t)rdfirst((int)ji); stt = (uint32_t)rdfirst((int)stt); fin = (uint32_t)rdfirst((int)fin);
+					if(ji != 0xffffffffu && stt == 100u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); run_rjob(ji); mine = 0xffffffffu; continue; }
+					if(ji != 0xffffffffu && stt != RJ_EMPTY) { mine = 0xffffffffu; continue; }          /* taken by its owner, done or cancelled: the next one */
+					mine = ji;                                                                        /* drawn but not published yet (or nothing drawn) */
+					if(fin) { break; }
+					__builtin_amdgcn_s_sleep(64);
+				}
+			}
+			break;
+		}
 		const uint32_t r = (uint32_t)rdfirst((int)a.work[wi]);
 		ReadState *st = &a.st[r];
 		for(uint32_t round = a.round; ; round++) {
@@ -2062,6 +2126,8 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		sr.crem = MM_CREM; sr.min_score = a.min_score; sr.narrow = 0; sr.srem = 0; sr.prem = 0; sr.pacc = 0;
 		sr.cp_a = sr.cp_b = sr.tp_a = sr.tp_b = 0; sr.aid = sr.bid = sr.iid = sr.eid = sr.sid = sr.rev = 0;
 		uint32_t next_n = 0;
+		uint32_t rj_base = 0, rj_n = 0, rj_i = 0;          /* retry jobs published for the trials that follow (K3Args.rjobs): first slot, count, next to be used */
+		auto cancel_rjobs = [&]() { if(rj_i < rj_n && lane == 0) { for(uint32_t q = rj_i; q < rj_n; q++) { (void)atomicCAS(&a.rstate[rj_base + q], (uint32_t)RJ_READY, (uint32_t)RJ_CANCELLED); } } rj_n = rj_i = 0; };
 		const uint32_t spec_n = (a.jobs != nullptr && round == 0) ? (uint32_t)rdfirst((int)st->spec_n) : 0u, spec_off = (uint32_t)rdfirst((int)st->spec_off);
 		gaba::Sec rsec_f, rsec_r, qsec_f, qsec_r; int rcirc = 0;
 		qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }; qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
@@ -2172,6 +2238,88 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					if((stt & 1u) && (uint32_t)rdfirst((int)smp->aid) == sr.aid && (uint32_t)rdfirst((int)smp->cp_a) == sr.cp_a && (uint32_t)rdfirst((int)smp->cp_b) == sr.cp_b && (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u)) { memo0 = true; memo1 = (stt & 2u) != 0; }
 					if(memo0 && lane == 0) { atomicAdd(&a.job_top[4], 1ull); }
 					dg_hits += memo0 ? 1u : 0u;
+				}
+				if(rq_on && !chain_first) {
+					/* a trial mm_search_load_next set up.  If it was published as a job: taken where it is done, run here where nobody has claimed it, and while another wave is at it this
+					 * one works on a later job of its own */
+					if(rj_i < rj_n) {
+						const uint32_t ji = rj_base + rj_i; rj_i++;
+						const SpecJob jj = a.rjobs[ji];
+						const bool match = (uint32_t)rdfirst((int)jj.aid) == sr.aid && (uint32_t)rdfirst((int)jj.cp_a) == sr.cp_a && (uint32_t)rdfirst((int)jj.cp_b) == sr.cp_b && (uint32_t)rdfirst((int)jj.rev) == (sr.rev ? 1u : 0u) && (uint32_t)rdfirst((int)jj.pad) == (uint32_t)bw;
+						if(!match) { rj_i--; cancel_rjobs(); }
+						else {
+							while(true) {
+								uint32_t stt = 0;
+								if(lane == 0) { stt = __hip_atomic_load(&a.rstate[ji], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if(stt == RJ_READY) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CANCELLED) == RJ_READY ? (uint32_t)RJ_CANCELLED : (uint32_t)RJ_CLAIMED; } }
+								stt = (uint32_t)rdfirst((int)stt);
+								if(stt == RJ_CANCELLED) { break; }                                        /* nobody took it: computed below like any trial */
+								if(stt == RJ_DONE) {
+									__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+									smp = a.rmemo + ji; memo0 = ((uint32_t)rdfirst((int)smp->state) & 1u) != 0; memo1 = false;
+									if(memo0) { dg_hits++; if(lane == 0) { atomicAdd(&a.rq_ctl[3], 1u); } }
+									break;
+								}
+								/* another wave is working on it: one of the later jobs of this read meanwhile */
+								uint32_t take = 0xffffffffu;
+								if(lane == 0) { for(uint32_t q = rj_i; q < rj_n; q++) { if(atomicCAS(&a.rstate[rj_base + q], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY) { take = rj_base + q; break; } } }
+								take = (uint32_t)rdfirst((int)take);
+								if(take != 0xffffffffu) { run_rjob(take); gaba::dp_flush(x); } else { __builtin_amdgcn_s_sleep(32); }
+							}
+						}
+					}
+					if(rj_i >= rj_n && sr.srem > 0) {
+						/* nothing published for the trials behind this one: the next-seed list is worked ahead on a copy, as mm_search_load_next would after every duplicate, and the
+						 * trials it leads to become jobs (minialign.c:3888-3946; a trial that turns out NOT to be a duplicate cancels what is left of them) */
+						rj_n = rj_i = 0;
+						uint32_t m_jobs = 0, base = 0;
+						if(lane == 0) {
+							uint64_t *nx = next + a.next_cap + MM_NEXT_SCRATCH;
+							for(uint32_t i = 0; i < next_n; i++) { nx[i] = next[i]; }
+							uint32_t c_srem = sr.srem, c_pacc = sr.pacc, c_sid = sr.sid, c_cpa = sr.cp_a, c_cpb = sr.cp_b, c_rev = sr.rev, c_nar = sr.narrow, c_nn = next_n, c_err = 0;
+							SpecJob tmp[MM_SREM];
+							const uint64_t ofs = 2ull * a.tglen;
+							while(m_jobs < MM_SREM && c_srem > 0) {
+								c_nar = min(c_nar + 1, 2u);                 /* the trial in front was a duplicate (minialign.c:3977) */
+								c_srem--;
+								const int32_t fa = (int32_t)c_cpa, fb = (int32_t)(c_cpb - (c_rev ? qlen : 0u));
+								const V4 fv = V4{ (int32_t)U_(fa, fb), (int32_t)sr.aid, (int32_t)V_(fa, fb), (int32_t)V_(fa, fb) };
+								uint32_t ncnt = c_nn; const uint64_t plim = ofs - c_pacc;
+								if(c_pacc > ofs) { ncnt = 0; }
+								for(uint32_t i = 0; i < ncnt; i++) { const uint32_t pd = (uint32_t)nx[i]; if(pd >= plim) { ncnt = i; break; } nx[i] = (nx[i] & 0xffffffff00000000ull) | (uint32_t)(pd + c_pacc); }
+								uint64_t sid = c_sid;
+								for(uint64_t rcnt = 2ull * c_srem; sid > 0 && rcnt > 0; sid--) {
+									const V4 pv = load_pv(s[sid - 1]); const V4 wv = add_win(pv, (int32_t)a.tglen), zv = add_win(pv, 128);
+									if(!inside_uub(wv, fv)) { break; }
+									if(!inside_wv(wv, fv) || inside_wv(zv, fv)) { continue; }
+									if(ncnt < a.next_cap) { nx[ncnt++] = (uint64_t)(uint32_t)pdiff(wv, fv) | ((uint64_t)(sid - 1) << 32); } else { c_err = 1; }
+									rcnt--;
+								}
+								c_sid = (uint32_t)sid;
+								if(c_err || !radix_sort_64((U64R *)nx, ncnt, next_scratch, 2 * MM_NEXT_SCRATCH)) { break; }          /* (the real walk reports what this one only avoids) */
+								if(ncnt == 0) { break; }
+								c_nn = ncnt - 1;
+								const uint64_t e = nx[c_nn]; const uint32_t nsid = (uint32_t)(e >> 32);
+								c_pacc = (uint32_t)(ofs - (uint32_t)e);
+								const Seed ns = s[nsid]; const int32_t bs_ = BS(ns);
+								c_rev = bs_ < 0; c_cpa = (uint32_t)AS(ns); c_cpb = (uint32_t)(bs_ + ((bs_ >> 31) & (int32_t)qlen));
+								if(c_cpa >= rlen || c_cpb >= qlen) { c_cpa -= min(c_cpa, ix.k); c_cpb -= min(c_cpb, ix.k); }
+								if(!(c_srem > 0 && sr.prem > 0)) { break; }
+								tmp[m_jobs++] = SpecJob{ r, sr.aid, c_cpa, c_cpb, c_rev, rlen, (uint32_t)rcirc, c_nar };
+							}
+							if(m_jobs) {
+								base = atomicAdd(&a.rq_ctl[0], m_jobs);
+								if(base + m_jobs > a.rq_cap) { m_jobs = 0; }          /* (the queue is full: the slots stay empty, helpers step over them at the end) */
+								for(uint32_t q = 0; q < m_jobs; q++) { a.rjobs[base + q] = tmp[q]; }
+							}
+						}
+						m_jobs = (uint32_t)rdfirst((int)m_jobs); base = (uint32_t)rdfirst((int)base);
+						if(m_jobs) {
+							__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+							asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+							if(lane == 0) { for(uint32_t q = 0; q < m_jobs; q++) { __hip_atomic_store(&a.rstate[base + q], (uint32_t)RJ_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
+							rj_base = base; rj_n = m_jobs; rj_i = 0;
+						}
+					}
 				}
 				chain_first = false; dg_trials++;
 				for(int pass = 0; pass < 2 && !skip; pass++) {
@@ -2298,6 +2446,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				isnew = (uint32_t)rdfirst((int)isnew); err = (uint32_t)rdfirst((int)err);
 				n_bin += isnew;
 				sr.srem = MM_SREM; sr.narrow = 0;
+				if(rq_on) { cancel_rjobs(); }
 				{
 					float cand = (float)ao.score * a.min_ratio, cur = (float)sr.min_score;
 					sr.min_score = f2u32(cur > cand ? cur : cand);
@@ -2305,6 +2454,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 				if(!(isnew && sr.prem > 0)) { break; }
 			}
+			if(rq_on) { cancel_rjobs(); }
 			if(err & (ERR_DP_SLAB | ERR_PATH_CAP | ERR_ALN_CAP | ERR_SEG_CAP | ERR_KH_CAP)) { break; }
 			/* mm_finish_root (minialign.c:3795-3813) */
 			{
@@ -2329,6 +2479,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if(!a.inkernel_rounds || n_res > 0 || err != 0 || round + 1 >= ix.n_occ) { break; }
 		}
+		if(rq_on && lane == 0) { atomicAdd(&a.rq_ctl[2], 1u); }          /* (helper waves leave when every read is done) */
 		if(!persistent) { break; }
 	}
 	if(lane == 0) {

@@ -1081,6 +1081,7 @@ struct mm_align_s {
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
 	DBuf<uint8_t> k2w_scratch;          /* lane-per-read chain sweep: leaf / chain scratch, 16 B per element of the seed pool */
+	DBuf<SpecJob> rq_jobs; DBuf<SpecMemo> rq_memo; DBuf<uint32_t> rq_state;          /* retry jobs of a launch (K3Args.rjobs); rq_state: one word per slot, then the four control words */
 	DBuf<SpecJob> spec_jobs; DBuf<SpecMemo> spec_memo; DBuf<uint32_t> spec_path; DBuf<gaba::Segment> spec_seg; DBuf<unsigned long long> spec_top;      /* chain jobs of the heaviest reads of a launch (K3Args.jobs) */
 	DBuf<uint64_t> tap_words;              /* mm_batch_tap: the minimizer stream words of the batch, parallel to min_pool */
 	DBuf<uint8_t> d_text, d_codes; DBuf<TextRead> d_tinfo; DBuf<uint32_t> d_tn;      /* packing on the device: text range of the batch, per-read extents, code bytes of the arena, bases found per read */
@@ -1344,6 +1345,15 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * an extension launch of some eighty waves, twice -- took half of a lane's time per batch).  MM_K3_HOST_ROUNDS: the rounds as separate launches */
 		const bool inkernel = getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL;
 		k3.inkernel_rounds = inkernel ? 1u : 0u; k3.resc_pool = a->resc_pool.p; k3.twlen = a->twlen;
+		k3.rjobs = nullptr; k3.rmemo = nullptr; k3.rstate = nullptr; k3.rq_cap = 0; k3.rq_ctl = nullptr;
+		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
+		if(round == 0 && k3.ring && inkernel && work.size() >= 256 && !getenv("MM_K3_NO_RETRY_JOBS")) {
+			const uint32_t rq_cap = 1u << 17;
+			if(a->rq_jobs.ensure(rq_cap) && a->rq_memo.ensure(rq_cap) && a->rq_state.ensure(rq_cap + 16)) {
+				CK(hipMemsetAsync(a->rq_state.p, 0, ((size_t)rq_cap + 16) * 4, a->stream));
+				k3.rjobs = a->rq_jobs.p; k3.rmemo = a->rq_memo.p; k3.rstate = a->rq_state.p; k3.rq_cap = rq_cap; k3.rq_ctl = (unsigned int *)(a->rq_state.p + rq_cap);
+			}
+		}
 		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0;
 		/* chain jobs: the first trials of the chains of the heaviest reads (the front of the work list), taken by all waves of the launch before the reads (K3Args.jobs) */
 		if(round == 0 && n_heavy > 0 && k3.ring && inkernel && !getenv("MM_K3_NO_JOBS")) {
@@ -1712,7 +1722,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
 	ok &= a->resc_pool.ensure(min_total * std::min<uint64_t>(scale, 4));
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
-	ok &= a->next_pool.ensure((uint64_t)std::max(a->n_waves, (a->root ? a->root : a)->slab_total) * (a->next_cap + MM_NEXT_SCRATCH));
+	ok &= a->next_pool.ensure((uint64_t)std::max(a->n_waves, (a->root ? a->root : a)->slab_total) * MM_NEXT_STRIDE(a->next_cap));
 	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap);
 	ok &= a->aln_pool.ensure(((uint64_t)n_reads + 2048) * a->aln_cap);
 	ok &= a->seg_pool.ensure((uint64_t)n_reads * a->aln_cap * 2 + 4096);
@@ -1875,7 +1885,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
-	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	free_chunk_pool(a->chunk_pool); a->chunk_pool = nullptr;
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
