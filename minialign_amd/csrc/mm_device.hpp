@@ -203,18 +203,19 @@ __global__ void __launch_bounds__(256) mm_text_marks_kernel(ScanArgs a)
 	__syncthreads();
 	if(threadIdx.x == 0) { a.blk[2 * blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3]; a.blk[2 * blockIdx.x + 1] = sb[0] + sb[1] + sb[2] + sb[3]; }
 }
-__global__ void __launch_bounds__(1024) mm_text_blocks_kernel(ScanArgs a)
+__global__ void __launch_bounds__(256) mm_text_blocks_kernel(ScanArgs a)
 {
-	/* exclusive scan of the two interleaved columns of blk over n_blk blocks: every thread sums a contiguous slice, the 1 024 partial sums are scanned in LDS */
-	__shared__ uint32_t pa[1024], pb[1024];
-	const uint32_t t = threadIdx.x, per = (a.n_blk + 1023u) / 1024u, lo = min(a.n_blk, t * per), hi = min(a.n_blk, lo + per);
+	/* exclusive scan of the two interleaved columns of blk over n_blk blocks: every thread sums a contiguous slice, the 256 partial sums are scanned in LDS.  (One
+	 * workgroup of four waves: a block of sixteen waves waited up to 180 ms for a CU with that many free slots beside the extension waves.) */
+	__shared__ uint32_t pa[256], pb[256];
+	const uint32_t t = threadIdx.x, per = (a.n_blk + 255u) / 256u, lo = min(a.n_blk, t * per), hi = min(a.n_blk, lo + per);
 	uint32_t xa = 0, xb = 0;
 	for(uint32_t i = lo; i < hi; i++) { xa += a.blk[2 * i]; xb += a.blk[2 * i + 1]; }
 	pa[t] = xa; pb[t] = xb; __syncthreads();
-	for(uint32_t o = 1; o < 1024; o <<= 1) { uint32_t ya = t >= o ? pa[t - o] : 0, yb = t >= o ? pb[t - o] : 0; __syncthreads(); pa[t] += ya; pb[t] += yb; __syncthreads(); }
+	for(uint32_t o = 1; o < 256; o <<= 1) { uint32_t ya = t >= o ? pa[t - o] : 0, yb = t >= o ? pb[t - o] : 0; __syncthreads(); pa[t] += ya; pb[t] += yb; __syncthreads(); }
 	uint32_t ra = pa[t] - xa, rb = pb[t] - xb;          /* exclusive */
 	for(uint32_t i = lo; i < hi; i++) { const uint32_t va = a.blk[2 * i], vb = a.blk[2 * i + 1]; a.blk[2 * i] = ra; a.blk[2 * i + 1] = rb; ra += va; rb += vb; }
-	if(t == 1023) { a.blk[2 * a.n_blk] = pa[1023]; a.blk[2 * a.n_blk + 1] = pb[1023]; }
+	if(t == 255) { a.blk[2 * a.n_blk] = pa[255]; a.blk[2 * a.n_blk + 1] = pb[255]; }
 }
 __global__ void __launch_bounds__(256) mm_text_emit_kernel(ScanArgs a)
 {
@@ -1639,6 +1640,7 @@ struct K3Args {
 	 * works the list ahead on a copy, publishes the rest as jobs (rjobs / rstate / rmemo, agent-scope hand-off as for the chain jobs), and waves that have run out of reads take them
 	 * (they stay in the launch until the last read is done: reads_done).  The owner takes a result where its inputs are the trial's, runs a job itself where nobody has claimed it, and
 	 * works on a later job of its own while one it needs is in another wave's hands.  NULL: none */
+	uint32_t rq_helper_mask;             /* a wave that has run out of reads stays as a helper when (wave number & mask) == 0: one in eight -- every helper holds a wave slot the other lanes' launches wait for */
 	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = helpers' cursor, [2] = reads done, [3] = results taken */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 };
@@ -2047,7 +2049,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
 		if(wi >= a.n_work) {
 			/* no read left for this wave: it takes retry jobs of the reads that are still being walked until the last of them is done */
-			if(rq_on) {
+			if(rq_on && (wave & a.rq_helper_mask) == 0) {
 				uint32_t mine = 0xffffffffu;          /* a slot number this wave drew that has not been published yet */
 				while(true) {
 					uint32_t ji = mine, stt = 0, fin = 0;
@@ -2255,7 +2257,9 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 								if(stt == RJ_CANCELLED) { break; }                                        /* nobody took it: computed below like any trial */
 								if(stt == RJ_DONE) {
 									__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-									smp = a.rmemo + ji; memo0 = ((uint32_t)rdfirst((int)smp->state) & 1u) != 0; memo1 = false;
+									smp = a.rmemo + ji; memo1 = false;
+									memo0 = ((uint32_t)rdfirst((int)smp->state) & 1u) != 0 && (uint32_t)rdfirst((int)smp->aid) == sr.aid && (uint32_t)rdfirst((int)smp->cp_a) == sr.cp_a && (uint32_t)rdfirst((int)smp->cp_b) == sr.cp_b
+										&& (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u) && (uint32_t)rdfirst((int)smp->seg_off) == (uint32_t)bw;          /* (computed for exactly this trial: what the job said when it was run) */
 									if(memo0) { dg_hits++; if(lane == 0) { atomicAdd(&a.rq_ctl[3], 1u); } }
 									break;
 								}

@@ -1347,7 +1347,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.inkernel_rounds = inkernel ? 1u : 0u; k3.resc_pool = a->resc_pool.p; k3.twlen = a->twlen;
 		k3.rjobs = nullptr; k3.rmemo = nullptr; k3.rstate = nullptr; k3.rq_cap = 0; k3.rq_ctl = nullptr;
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
-		if(round == 0 && k3.ring && inkernel && work.size() >= 256 && !getenv("MM_K3_NO_RETRY_JOBS")) {
+		/* (only with a workspace for every wave the device can hold: a helper keeps its workspace while it waits, and with fewer workspaces than waves the reads that wait for one would wait for the helpers) */
+		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 7u;
+		if(round == 0 && k3.ring && (uint64_t)k3.ring_n * 8 >= a->n_waves && inkernel && work.size() >= 256 && !getenv("MM_K3_NO_RETRY_JOBS")) {
 			const uint32_t rq_cap = 1u << 17;
 			if(a->rq_jobs.ensure(rq_cap) && a->rq_memo.ensure(rq_cap) && a->rq_state.ensure(rq_cap + 16)) {
 				CK(hipMemsetAsync(a->rq_state.p, 0, ((size_t)rq_cap + 16) * 4, a->stream));
@@ -2662,7 +2664,7 @@ struct TextReader {
 		CK(hipMemsetAsync(d_flag.p, 0, 16, st));
 		if(fastq) { CK(hipMemsetAsync(d_pos.p, 0, 4, st)); }          /* the first line starts at 0 */
 		hipLaunchKernelGGL(mm_text_marks_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
-		hipLaunchKernelGGL(mm_text_blocks_kernel, dim3(1), dim3(1024), 0, st, sa); CK(hipGetLastError());
+		hipLaunchKernelGGL(mm_text_blocks_kernel, dim3(1), dim3(256), 0, st, sa); CK(hipGetLastError());
 		hipLaunchKernelGGL(mm_text_emit_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
 		uint32_t tot[2], flag[4];
 		CK(hipMemcpyAsync(tot, d_blk.p + 2 * (uint64_t)n_blk, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(flag, d_flag.p, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
