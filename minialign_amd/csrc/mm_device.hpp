@@ -1640,7 +1640,7 @@ struct K3Args {
 	 * works the list ahead on a copy, publishes the rest as jobs (rjobs / rstate / rmemo, agent-scope hand-off as for the chain jobs), and waves that have run out of reads take them
 	 * (they stay in the launch until the last read is done: reads_done).  The owner takes a result where its inputs are the trial's, runs a job itself where nobody has claimed it, and
 	 * works on a later job of its own while one it needs is in another wave's hands.  NULL: none */
-	uint32_t rq_helper_mask;             /* a wave that has run out of reads stays as a helper when (wave number & mask) == 0: one in eight -- every helper holds a wave slot the other lanes' launches wait for */
+	uint32_t rq_helper_mask;             /* a wave that has run out of reads stays as a helper when (wave number & mask) == 0 (one in 128 by default): every helper holds a wave slot the other lanes' launches wait for */
 	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = helpers' cursor, [2] = reads done, [3] = results taken */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 };
