@@ -1349,7 +1349,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
 		/* (only with a workspace for every wave the device can hold: a helper keeps its workspace while it waits, and with fewer workspaces than waves the reads that wait for one would wait for the helpers) */
 		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 stays as a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for */
-		if(round == 0 && k3.ring && (uint64_t)k3.ring_n * 8 >= a->n_waves && inkernel && work.size() >= 256 && !getenv("MM_K3_NO_RETRY_JOBS")) {
+		/* (and only with ONE class of workspaces: with the ladder of classes of a long-tailed set a helper would sit on a workspace of a scarce class that a read is waiting for) */
+		if(round == 0 && k3.ring && k3.n_cls == 1 && (uint64_t)k3.ring_n * 8 >= a->n_waves && inkernel && work.size() >= 256 && !getenv("MM_K3_NO_RETRY_JOBS")) {
 			const uint32_t rq_cap = 1u << 17;
 			if(a->rq_jobs.ensure(rq_cap) && a->rq_memo.ensure(rq_cap) && a->rq_state.ensure(rq_cap + 16)) {
 				CK(hipMemsetAsync(a->rq_state.p, 0, ((size_t)rq_cap + 16) * 4, a->stream));
