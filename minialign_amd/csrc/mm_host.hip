@@ -1359,7 +1359,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		}
 		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0;
 		/* chain jobs: the first trials of the chains of the heaviest reads (the front of the work list), taken by all waves of the launch before the reads (K3Args.jobs) */
-		if(round == 0 && n_heavy > 0 && k3.ring && inkernel && !getenv("MM_K3_NO_JOBS")) {
+		/* (only with a workspace for every resident wave and a single workspace class: a wave that walks a read keeps its workspace while it waits for a job's result, and the wave that
+		 * has claimed that job needs a workspace to run it -- with fewer workspaces than waves, or on the class ladder of a long-tailed set, the two would wait for each other) */
+		if(round == 0 && n_heavy > 0 && k3.ring && k3.n_cls == 1 && (uint64_t)k3.ring_n * 8 >= a->n_waves && inkernel && !getenv("MM_K3_NO_JOBS")) {
 			const uint64_t job_cap = 1u << 16, path_cap = 48ull << 20;
 			if(a->spec_jobs.ensure(job_cap) && a->spec_memo.ensure(job_cap) && a->spec_path.ensure(path_cap) && a->spec_seg.ensure(job_cap * 8) && a->spec_top.ensure(8)) {
 				CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
@@ -2753,7 +2755,7 @@ struct TextReader {
 		if(!init()) return false;
 		/* batch size as batch_spans: 300 Mb; a text smaller than lanes x that is cut into one batch per lane (its bases are a little fewer than its bytes) */
 		if(getenv("MM_BATCH_BASES")) max_bases = (uint64_t)atoll(getenv("MM_BATCH_BASES"));
-		else if(src->n < (uint64_t)lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, src->n / (uint64_t)lanes + (1ull << 20));
+		else if(src->n < (uint64_t)lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, src->n / ((uint64_t)lanes + (uint64_t)lanes / 2) + (1ull << 20));          /* (one and a half batches per lane: an eighth of the headline set maps in 313 ms in six batches, 366 in four) */
 		th = std::thread([this]() { run(); });
 		return true;
 	}
@@ -3043,7 +3045,7 @@ static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *
 		uint64_t total = 0, longest = 0; for(uint32_t i = first; i < end; i++) { total += reads->r[i].seq.size(); longest = std::max<uint64_t>(longest, reads->r[i].seq.size()); }
 		max_bases = std::min<uint64_t>(1000000000ull, std::max<uint64_t>(max_bases, longest * 2500));
 		const uint64_t lanes = (uint64_t)default_lanes();
-		if(total < lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, total / lanes + (1ull << 20));
+		if(total < lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, total / (lanes + lanes / 2) + (1ull << 20));
 	}
 	std::vector<std::pair<uint32_t, uint32_t>> sp;
 	for(uint32_t i = first; i < end;) {
