@@ -97,7 +97,7 @@ def test_alternative_schedules_give_the_same_bytes(env):
         M.gensim('genome', 7401, 1500000, 6, 0.45, out=ref); M.gensim('reads', 7402, ref, 3.0, 'pacbio', 'fa', 6000, 2500, out=rd)          # 750 reads, many with dozens of chains: the chain jobs of the default run have work
         opts = ['-xpacbio', '-f0.2,0.05,0.002']
         want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
-        r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='16', MM_BATCH_BASES='3000000', **env), timeout=600)          # (16 GB: a workspace for every resident wave at this read length, so that the chain and retry jobs of the default schedule run)
+        r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='32', MM_BATCH_BASES='3000000', **env), timeout=600)          # (32 GB: a workspace for every resident wave at this read length, so that the chain and retry jobs of the default schedule run)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert _strip_pg(r.stdout) == want
         assert b're-run' in r.stderr
