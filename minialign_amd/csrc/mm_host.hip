@@ -647,10 +647,17 @@ struct DevCache {
 		std::lock_guard<std::mutex> lk(mu);
 		auto it = blocks.lower_bound(std::make_pair(dev, want));
 		if(it == blocks.end() || it->first.first != dev || it->first.second > 4 * want + (64u << 20)) return nullptr;
-		void *p = it->second; *got = it->first.second; blocks.erase(it); return p;
+		void *p = it->second; *got = it->first.second; held -= *got; blocks.erase(it); return p;
 	}
-	void give(int dev, size_t bytes, void *p) { std::lock_guard<std::mutex> lk(mu); blocks.emplace(std::make_pair(dev, bytes), p); }
-	void flush(int dev) { std::lock_guard<std::mutex> lk(mu); for(auto it = blocks.begin(); it != blocks.end();) { if(it->first.first == dev) { (void)hipFree(it->second); it = blocks.erase(it); } else ++it; } }          /* out of memory: everything held goes back to the driver */
+	size_t held = 0;
+	/* what is held is bounded (32 GB): a block that would take it beyond that goes back to the driver after all, as do blocks of more than 16 GB (the DP workspaces of a size that is
+	 * being replaced: nothing is in flight then) -- an ONT-like run that re-sized its workspace ladder a few times had 150 GB of them waiting here and the runtime ran out of memory */
+	void give(int dev, size_t bytes, void *p)
+	{
+		{ std::lock_guard<std::mutex> lk(mu); if(bytes <= (16ull << 30) && held + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held += bytes; return; } }
+		(void)hipFree(p);
+	}
+	void flush(int dev) { std::lock_guard<std::mutex> lk(mu); for(auto it = blocks.begin(); it != blocks.end();) { if(it->first.first == dev) { (void)hipFree(it->second); held -= it->first.second; it = blocks.erase(it); } else ++it; } }          /* out of memory: everything held goes back to the driver */
 };
 static DevCache &dev_cache() { static DevCache *c = new DevCache(); return *c; }          /* (never destroyed: blocks may come back while the process winds down) */
 template<typename T> struct DBuf {
