@@ -34,7 +34,7 @@ WORKLOADS = {
     'hg38':  dict(genome_len=3100000000, contigs=25,   repeat_frac=0.05, depth=3.0,   kind='pacbio', preset='pacbio',   name='human hg38-size ref (3.1 Gb, 25 contigs)'),
     'dm6':   dict(genome_len=143700000,  contigs=1870, repeat_frac=0.05, depth=20.0,  kind='pacbio', preset='pacbio',   name='D.melanogaster dm6-size ref (143.7 Mb, 1870 contigs)'),
     'ecoli': dict(genome_len=4641652,    contigs=1,    repeat_frac=0.05, depth=100.0, kind='pacbio', preset='pacbio',   name='E.coli MG1655-size ref (4.64 Mb)'),
-    'ont':   dict(genome_len=3100000000, contigs=25,   repeat_frac=0.05, depth=1.0,   kind='ont',    preset='ont.1dsq', name='human hg38-size ref (3.1 Gb, 25 contigs), ONT-like reads'),
+    'ont':   dict(genome_len=3100000000, contigs=25,   repeat_frac=0.05, depth=1.0,   kind='ont',    preset='ont.1dsq', baseline_reads=8000, check_reads=1000, name='human hg38-size ref (3.1 Gb, 25 contigs), ONT-like reads'),
 }
 
 class Stats(ctypes.Structure):
@@ -175,7 +175,7 @@ def main():
     ap.add_argument('--depth', type=float); ap.add_argument('--genome-len', type=int); ap.add_argument('--contigs', type=int); ap.add_argument('--repeat-frac', type=float)
     ap.add_argument('--lanes', type=int, default=4, help='batches in flight per GPU (lanes of the device context)')
     ap.add_argument('--check', action='store_true', help='verify the records of the first reads against the CPU reference also when N > 1')
-    ap.add_argument('--check-reads', type=int, default=4000); ap.add_argument('--baseline-reads', type=int, default=60000)
+    ap.add_argument('--check-reads', type=int); ap.add_argument('--baseline-reads', type=int)          # defaults: 4000 / 60000 reads; the ONT-like set has 385 kb reads, on which 64 threads of the reference need a lot of host memory: 1000 / 8000
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU legs (baseline and identity check)')
     ap.add_argument('--no-packed', action='store_true', help='skip the value_from_packed leg'); ap.add_argument('--no-cli', action='store_true', help='skip the command-line run')
     ap.add_argument('--keep', action='store_true', help='keep the generated data (prints the directory)')
@@ -185,6 +185,8 @@ def main():
     w = dict(WORKLOADS[args.workload]); custom = False
     for k in ('depth', 'genome_len', 'contigs', 'repeat_frac'):
         if getattr(args, k) is not None: w[k] = getattr(args, k); custom = True
+    if args.check_reads is None: args.check_reads = w.get('check_reads', 4000)
+    if args.baseline_reads is None: args.baseline_reads = w.get('baseline_reads', 60000)
     import torch
     dist = None; device = None
     same_dev = os.environ.get('MM_BENCH_SAME_DEVICE') is not None      # test hook: every rank on device 0 (one-GPU boxes)
@@ -246,12 +248,17 @@ def main():
         sm.map()
         sm.settle(dist, rank, world, 0, device)
         return sm
+    T00 = time.time()
+    def stage(what):
+        if rank == 0: sys.stderr.write('[bench] %7.1f s  %s\n' % (time.time() - T00, what)); sys.stderr.flush()
     sm = None
     for _ in range(args.warmup): sm = one_step()
+    stage('warmup done')
     L.mm_stats(al, None, 1)
     sync(); t0 = time.perf_counter()
     for _ in range(args.steps): sm = one_step()
     sync(); dt = time.perf_counter() - t0
+    stage('timed steps done')
     st = Stats(); L.mm_stats(al, ctypes.byref(st), 0)
     sam_bytes = sm.col.total if sm else 0
     K = max(1, args.steps)
@@ -316,6 +323,7 @@ def main():
         }
         if (world == 1 or args.check) and not args.no_cpu:
             cpu = reference_runs(w, ref_fa, parts, work, args.check_reads, args.baseline_reads, True)
+            stage('CPU legs done')
             if world == 1: out['cpu_baseline'] = cpu['cpu_baseline']
             if cpu['check_sam'] is not None:
                 # the records of the first check_reads reads of the stream: the library recorded where those of read check_reads begin (mm_head_offset)
