@@ -1641,6 +1641,7 @@ struct K3Args {
 	 * (they stay in the launch until the last read is done: reads_done).  The owner takes a result where its inputs are the trial's, runs a job itself where nobody has claimed it, and
 	 * works on a later job of its own while one it needs is in another wave's hands.  NULL: none */
 	uint32_t rq_helper_mask;             /* a wave that has run out of reads stays as a helper when (wave number & mask) == 0 (one in 128 by default): every helper holds a wave slot the other lanes' launches wait for */
+	uint32_t rq_early;                   /* helpers are helpers from the start of the launch (they take no reads): the reads that publish retry jobs are at the front of the work list */
 	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = helpers' cursor, [2] = reads done, [3] = results taken */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 };
@@ -1940,6 +1941,31 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
 			if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[_want].next_base) * MM_NEXT_STRIDE(a.next_cap); next_scratch = (uint32_t *)(next + a.next_cap); } \
 		} }
+	/* the same without waiting, for a wave that is about to take somebody else's work (a retry job): a workspace of class _want if one is free on this XCD right now.  A take
+	 * ticket t is served by give ticket t (the ring starts with its n numbers given), so a ticket is drawn only while one is outstanding -- the number may still be on its way
+	 * into the slot, which is a short wait, never one for a workspace that a waiting wave holds.  The old workspace goes back after the new one is in hand. */
+	#define K3_TRY_SLAB(_want, _ok) { \
+		uint32_t _v = 0xffffffffu; \
+		if(lane == 0) { \
+			unsigned long long *_ctr = a.cls[_want].ctr; uint32_t *_rg = a.cls[_want].ring; const uint32_t _n = a.cls[_want].n; \
+			for(int _try = 0; _try < 4; _try++) { \
+				const unsigned long long _t = __hip_atomic_load(&_ctr[2 * xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), _g = __hip_atomic_load(&_ctr[2 * xcc + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+				if(_t >= _g) { break; } \
+				if(atomicCAS(&_ctr[2 * xcc], _t, _t + 1ull) != _t) { continue; } \
+				uint32_t *_slot = &_rg[(uint64_t)xcc * _n + (uint32_t)(_t % _n)]; \
+				while((_v = atomicExch(_slot, 0xffffffffu)) == 0xffffffffu) { __builtin_amdgcn_s_sleep(4); } \
+				break; \
+			} \
+		} \
+		_v = (uint32_t)rdfirst((int)_v); (_ok) = _v != 0xffffffffu; \
+		if(_ok) { \
+			if(slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); } \
+			slab_no = _v; slab_cls = (_want); \
+			x.slab = a.cls[_want].slabs + (uint64_t)slab_no * a.cls[_want].bytes; x.cap = (uint32_t)a.cls[_want].bytes; x.top = gaba::SLAB_HEAD; \
+			for(uint32_t _i = (uint32_t)lane; _i < gaba::SLAB_HEAD / 4; _i += 64) { ((uint32_t *)x.slab)[_i] = ((const uint32_t *)a.roots)[_i]; } \
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
+			if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[_want].next_base) * MM_NEXT_STRIDE(a.next_cap); next_scratch = (uint32_t *)(next + a.next_cap); } \
+		} }
 	/* jobs first: the first trials of the chains of the heaviest reads, one per wave at a time, by every wave of the launch (K3Args.jobs) */
 	if(a.jobs && a.ring) {
 		const unsigned long long n_jobs = min(rdfirst64(a.job_top[0]), (unsigned long long)a.job_cap);
@@ -2044,12 +2070,15 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	};
 	const bool rq_on = a.rjobs != nullptr && a.ring != nullptr && persistent;
 
+	/* the helpers: the first wave of one workgroup in (mask + 1) / 4, counted within an XCD (workgroup b runs on XCD b % 8: the workspaces a helper can take are its XCD's) */
+	const bool rq_helper = rq_on && (threadIdx.x >> 6) == 0 && ((blockIdx.x >> 3) & (max(a.rq_helper_mask, 3u) >> 2)) == 0;
 	while(true) {
 		uint32_t wi = wave;
-		if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
+		if(rq_helper && a.rq_early) { wi = 0xffffffffu; }
+		else if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
 		if(wi >= a.n_work) {
 			/* no read left for this wave: it takes retry jobs of the reads that are still being walked until the last of them is done */
-			if(rq_on && (wave & a.rq_helper_mask) == 0) {
+			if(rq_helper) {
 				uint32_t mine = 0xffffffffu;          /* a slot number this wave drew that has not been published yet */
 				while(true) {
 					uint32_t ji = mine, stt = 0, fin = 0;
@@ -2058,11 +2087,25 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 							const uint32_t cur = __hip_atomic_load(&a.rq_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), top = __hip_atomic_load(&a.rq_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							if(cur < top && cur < a.rq_cap) { ji = atomicAdd(&a.rq_ctl[1], 1u); if(ji >= a.rq_cap) { ji = 0xffffffffu; } }
 						}
-						if(ji != 0xffffffffu) { stt = __hip_atomic_load(&a.rstate[ji], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if(stt == RJ_READY) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY ? 100u : 99u; } }
+						if(ji != 0xffffffffu) { stt = __hip_atomic_load(&a.rstate[ji], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 						fin = __hip_atomic_load(&a.rq_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.n_work ? 1u : 0u;
 					}
 					ji = (uint32_t)rdfirst((int)ji); stt = (uint32_t)rdfirst((int)stt); fin = (uint32_t)rdfirst((int)fin);
-					if(ji != 0xffffffffu && stt == 100u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); run_rjob(ji); mine = 0xffffffffu; continue; }
+					if(ji != 0xffffffffu && stt == RJ_READY) {
+						/* the workspace the job needs comes BEFORE the claim: a claimed job is one that will be finished, whatever the waves that wait for it hold (with several
+						 * workspace classes a helper that claimed first and then waited for a workspace of a scarce class could wait for the very waves that wait for it) */
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+						const uint32_t jr = (uint32_t)rdfirst((int)a.rjobs[ji].r), jq = (uint32_t)rdfirst((int)a.in[jr].qlen);
+						int want = 0; while(want + 1 < (int)a.n_cls && jq > a.cls[want].qmax) { want++; }
+						bool have = want == slab_cls;
+						if(!have) { K3_TRY_SLAB(want, have); }
+						if(have) { if(lane == 0) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY ? 100u : 99u; } stt = (uint32_t)rdfirst((int)stt); }
+						else { stt = RJ_EMPTY; }          /* no workspace of that class free: the job stays with its owner unless one comes back before the owner gets there */
+					}
+					if(ji != 0xffffffffu && stt == 100u) {
+						/* (at the top priority: the wave that waits for this result is the critical path of the launch) */
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __builtin_amdgcn_s_setprio(3); run_rjob(ji); __builtin_amdgcn_s_setprio(0); mine = 0xffffffffu; continue;
+					}
 					if(ji != 0xffffffffu && stt != RJ_EMPTY) { mine = 0xffffffffu; continue; }          /* taken by its owner, done or cancelled: the next one */
 					mine = ji;                                                                        /* drawn but not published yet (or nothing drawn) */
 					if(fin) { break; }

@@ -640,6 +640,7 @@ static bool idx_fetch_host(const mm_idx_s *cmi)
  * lanes for 100 - 450 ms), and pages the driver has taken back are wiped before they are handed out again -- the 43 GB of DP workspaces allocated right after the
  * index build's 45 GB of temporaries had been freed took 3.7 s to arrive (1.35 s behind 20 GB), against a few milliseconds on untouched memory.  A released block
  * waits here for the next request it fits (at most four times the size asked for), per device; what is held is bounded by what the library once used. */
+#define MM_BATCH_PER_LONGEST 1700ull          /* bases of batch per base of the longest read of the input (batch_spans) */
 struct DevCache {
 	std::mutex mu; std::multimap<std::pair<int, size_t>, void *> blocks;
 	void *take(int dev, size_t want, size_t *got)
@@ -654,9 +655,23 @@ struct DevCache {
 	 * being replaced: nothing is in flight then) -- an ONT-like run that re-sized its workspace ladder a few times had 150 GB of them waiting here and the runtime ran out of memory */
 	void give(int dev, size_t bytes, void *p)
 	{
-		{ std::lock_guard<std::mutex> lk(mu); if(bytes <= (16ull << 30) && held + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held += bytes; return; } }
+		/* ... and nothing is kept while the device is short of memory (the runtime allocates the kernels' scratch memory on demand and aborts the process when it cannot) */
+		size_t fr = 0, tot = 0; const bool tight = hipMemGetInfo(&fr, &tot) != hipSuccess || fr < reserve();
+		{ std::lock_guard<std::mutex> lk(mu); if(!tight && bytes <= (16ull << 30) && held + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held += bytes; return; } }
 		(void)hipFree(p);
 	}
+	static size_t reserve() { return 24ull << 30; }
+	/* may `bytes` more be taken?  Not when less than 8 GB would be left after giving back what is held here: the runtime allocates the scratch memory of a kernel when it is first
+	 * launched on a queue (1.7 GB for the extension kernel) and aborts the process when it cannot -- an allocation that fails cleanly is the better end */
+	bool room(int dev, size_t bytes)
+	{
+		size_t fr = 0, tot = 0; if(hipMemGetInfo(&fr, &tot) != hipSuccess) return true;
+		if(fr >= bytes + (8ull << 30)) return true;
+		flush(dev); if(hipMemGetInfo(&fr, &tot) != hipSuccess) return true;
+		return fr >= bytes + (8ull << 30);
+	}
+	/* after a fresh allocation: what is held goes back to the driver when less than the reserve is left */
+	void relieve(int dev) { size_t fr = 0, tot = 0; if(held && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < reserve())) flush(dev); }
 	void flush(int dev) { std::lock_guard<std::mutex> lk(mu); for(auto it = blocks.begin(); it != blocks.end();) { if(it->first.first == dev) { (void)hipFree(it->second); held -= it->first.second; it = blocks.erase(it); } else ++it; } }          /* out of memory: everything held goes back to the driver */
 };
 static DevCache &dev_cache() { static DevCache *c = new DevCache(); return *c; }          /* (never destroyed: blocks may come back while the process winds down) */
@@ -668,8 +683,10 @@ template<typename T> struct DBuf {
 		release();
 		(void)hipGetDevice(&dev);
 		size_t got = 0; void *q = dev_cache().take(dev, want * sizeof(T), &got);
+		const bool fresh = q == nullptr;
+		if(!q && !dev_cache().room(dev, want * sizeof(T))) { fprintf(stderr, "[minialign_amd] %.1f MB more would leave the device without the memory its runtime needs (kernel scratch): fewer lanes (MM_LANES) or smaller batches (MM_BATCH_BASES) fit\n", want * sizeof(T) / 1048576.0); return false; }
 		if(!q) { got = want * sizeof(T); if(hipMalloc(&q, got) != hipSuccess) { q = nullptr; dev_cache().flush(dev); if(hipMalloc(&q, got) != hipSuccess) { fprintf(stderr, "[minialign_amd] hipMalloc of %.1f MB failed\n", got / 1e6); return false; } } }
-		p = (T *)q; bytes = got; n = got / sizeof(T); return true;
+		p = (T *)q; bytes = got; n = got / sizeof(T); if(fresh) dev_cache().relieve(dev); return true;
 	}
 	void release() { if(p) dev_cache().give(dev, bytes, p); p = nullptr; n = 0; bytes = 0; }
 };
@@ -1079,6 +1096,7 @@ struct mm_align_s {
 	hipStream_t k3s = nullptr; hipEvent_t k3e = nullptr;      /* the extension launches' own stream (lowest priority; the others are created with the highest), see make_streams */
 	hipStream_t k2s[12]; hipEvent_t k2e[16]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
+	uint64_t mem_for_batches = 0;                              /* device memory the lanes' pools may take together (measured when the first text stream starts: batch_cap_bases) */
 	uint32_t qlen_hint = 0;                                    /* longest read of the input being mapped, when known (mm_align_file) */
 	uint32_t k3_waves = 0; uint64_t slab_stride = 0;      /* extension kernel: persistent waves actually launched and the DP workspace of each */
 	/* pools */
@@ -1354,10 +1372,12 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.inkernel_rounds = inkernel ? 1u : 0u; k3.resc_pool = a->resc_pool.p; k3.twlen = a->twlen;
 		k3.rjobs = nullptr; k3.rmemo = nullptr; k3.rstate = nullptr; k3.rq_cap = 0; k3.rq_ctl = nullptr;
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
-		/* (only with a workspace for every wave the device can hold: a helper keeps its workspace while it waits, and with fewer workspaces than waves the reads that wait for one would wait for the helpers) */
+		k3.rq_early = getenv("MM_K3_LATE_HELPERS") ? 0u : 1u;
 		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 stays as a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for */
-		/* (and only with ONE class of workspaces: with the ladder of classes of a long-tailed set a helper would sit on a workspace of a scarce class that a read is waiting for) */
-		if(round == 0 && k3.ring && k3.n_cls == 1 && (uint64_t)k3.ring_n * 8 >= a->n_waves && inkernel && work.size() >= 256 && !getenv("MM_K3_NO_RETRY_JOBS")) {
+		/* (any number of workspace classes, any number of workspaces: a helper takes the workspace a job needs before it claims the job and without waiting, K3_TRY_SLAB, so the
+		 * wave that waits for a claimed job waits for one that is running; on the ONT-like set the reads that decide the launch are 60 - 160 kb long with 9 - 27 trials for
+		 * one alignment, tools/read_cost.py) */
+		if(round == 0 && k3.ring && k3.cls && inkernel && work.size() >= 256 && !getenv("MM_K3_NO_RETRY_JOBS")) {
 			const uint32_t rq_cap = 1u << 17;
 			if(a->rq_jobs.ensure(rq_cap) && a->rq_memo.ensure(rq_cap) && a->rq_state.ensure(rq_cap + 16)) {
 				CK(hipMemsetAsync(a->rq_state.p, 0, ((size_t)rq_cap + 16) * 4, a->stream));
@@ -2622,7 +2642,7 @@ struct TextReader {
 	DBuf<uint64_t> d_ma, d_mb; DBuf<uint32_t> d_blk, d_pos, d_cum, d_flag; DBuf<TextRec> d_rec;
 	/* batches cut so far, in order; lanes take them by number */
 	std::mutex mu; std::condition_variable cv; std::deque<mm_batch_t *> ready; uint32_t first_k = 0; bool done = false, failed = false, stop = false;
-	uint64_t max_bases = 300000000ull; uint32_t longest = 0;
+	uint64_t max_bases = 300000000ull, cap_bases = 1000000000ull; uint32_t longest = 0;          /* cap_bases: what the device memory allows (batch_cap_bases) */
 	std::thread th;
 	mm_batch_t *cur = nullptr; uint64_t cur_bases = 0;
 	uint64_t n_records = 0, n_host_scanned = 0, n_stretches = 0; double t_io = 0, t_scan = 0;
@@ -2642,7 +2662,7 @@ struct TextReader {
 	void add(const RRec &r, const std::shared_ptr<DevChunk> &ch)
 	{
 		if(r.n_bases < min_len) return;          /* -L (minialign.c:2077) */
-		if(r.n_bases > longest) { longest = r.n_bases; if(!getenv("MM_BATCH_BASES")) max_bases = std::min<uint64_t>(1000000000ull, std::max<uint64_t>(max_bases, (uint64_t)longest * 2500)); }
+		if(r.n_bases > longest) { longest = r.n_bases; if(!getenv("MM_BATCH_BASES")) max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(cap_bases, (uint64_t)longest * MM_BATCH_PER_LONGEST)); }
 		if(cur && (cur->b.lens.size() >= (1u << 17) || (cur_bases && cur_bases + r.n_bases > max_bases))) push_batch();
 		if(!cur) { cur = new mm_batch_s(); cur->b.tsrc = src; }
 		Batch &b = cur->b;
@@ -3028,6 +3048,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 	if(rc == 0) { for(mm_align_t *q = a; q; q = q->sib) q->rlen_carry = carry; }
 	if(!a->head_off_closed && a->head_off.size() <= 4096) { a->head_off.push_back(written); }          /* a stream shorter than the head: its end */
 	a->streaming = false;
+	if(getenv("MM_VERBOSE")) { size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot); fprintf(stderr, "[minialign_amd] device memory at the end of the stream: %.1f of %.1f GB free; %.1f GB held in recycled buffers\n", fr / 1073741824.0, tot / 1073741824.0, dev_cache().held / 1073741824.0); }
 	return rc;
 }
 static void batch_fill(mm_batch_t *h, mm_reads_t const *r, uint32_t first, uint32_t last)
@@ -3044,13 +3065,14 @@ static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *
 	/* 300 Mb per batch: on the whole hg38-size x3 set anything between 250 and 512 Mb measures the same, on an eighth or a quarter of it (one rank's shard of
 	 * the multi-GPU job) the smaller batches give every lane one and are 8 - 13 % faster; a set smaller than lanes x 300 Mb is cut into one batch per lane, not
 	 * below 64 Mb.  A set with very long reads wants larger batches: an extension launch lasts at least as long as its longest read (one wave, ~0.8 us per base), and
-	 * every batch pays that tail again -- 2 500 bases of batch per base of the longest read, up to 1 Gb (ONT-like set, longest read 385 kb: 2.40 s per step at 300 Mb,
-	 * 1.58 at 512 Mb, 1.46 at 800 Mb; profiles/round2_batch_size.txt).  MM_BATCH_BASES: test hook (many small batches) */
+	 * every batch pays that tail again -- 1 700 bases of batch per base of the longest read (ONT-like set, longest read 385 kb: round 2 measured 2.40 s per step at 300 Mb,
+	 * 1.58 at 512 Mb, 1.46 at 800 Mb, profiles/round2_batch_size.txt; with the retry jobs of round 3, 1.46 s at 480 Mb, 1.14 at 640 Mb, 1.26 at 960 Mb -- and the lanes' pools
+	 * take 46 bytes of HBM per base of batch, so 960 Mb batches on 4 lanes left 2 GB of the 288 free).  MM_BATCH_BASES: test hook (many small batches) */
 	uint64_t max_bases = 300000000ull;
 	if(getenv("MM_BATCH_BASES")) { max_bases = (uint64_t)atoll(getenv("MM_BATCH_BASES")); }
 	else {
 		uint64_t total = 0, longest = 0; for(uint32_t i = first; i < end; i++) { total += reads->r[i].seq.size(); longest = std::max<uint64_t>(longest, reads->r[i].seq.size()); }
-		max_bases = std::min<uint64_t>(1000000000ull, std::max<uint64_t>(max_bases, longest * 2500));
+		max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(700000000ull, longest * MM_BATCH_PER_LONGEST));
 		const uint64_t lanes = (uint64_t)default_lanes();
 		if(total < lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, total / (lanes + lanes / 2) + (1ull << 20));
 	}
@@ -3079,11 +3101,26 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 /* the same engine behind the C-ABI: packed batches prepared ahead of time (bench.py: the timed region then starts from packed reads in host memory) or packed on
  * the fly, text handed to a callback in input order */
 static int default_lanes();
+/* the largest batch the device memory allows on `lanes` lanes: the pools of a lane take about 52 bytes per base of its batches (seeds and the sweep's scratch are most of it,
+ * ensure_pools); what they may take together is what was free when the first stream of the context started, less the DP workspaces at their largest (1.5 x the budget:
+ * the ordinary class and the ladder above it) and 10 GB for the runtime (kernel scratch) and the text */
+static uint64_t batch_cap_bases(mm_align_t *a, int lanes)
+{
+	mm_align_s *P = a->root ? a->root : a;
+	if(!P->mem_for_batches) {
+		size_t fr = 0, tot = 0; if(hipMemGetInfo(&fr, &tot) != hipSuccess) return 1000000000ull;
+		const uint64_t avail = fr + dev_cache().held, slab_budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
+		const uint64_t taken = slab_budget + slab_budget / 2 + (10ull << 30) - std::min<uint64_t>(P->shared_slabs ? P->slabs.bytes : 0, slab_budget);          /* (workspaces already allocated are no longer in `avail`) */
+		P->mem_for_batches = avail > taken + (8ull << 30) ? avail - taken : (8ull << 30);
+	}
+	return std::max<uint64_t>(128ull << 20, P->mem_for_batches / (uint64_t)std::max(1, lanes) / 52);
+}
 static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const PieceSink &sink, int lanes)
 {
 	if(lanes <= 0) lanes = default_lanes();
 	if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
 	TextReader rd; rd.pool = a->chunk_pool; rd.dev = a->dev; rd.src = src; rd.min_len = a->o.min_len; rd.keep_qual = a->o.keep_qual; rd.lanes = lanes;
+	rd.cap_bases = std::min<uint64_t>(1000000000ull, batch_cap_bases(a, lanes));
 	if(!rd.start()) { fprintf(stderr, "[minialign_amd] reader: no stream / staging memory\n"); return 1; }
 	bool err = false;
 	int rc = stream_map(a, MM_OPEN_ENDED, [&](uint32_t k) { return rd.take(k, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes);
