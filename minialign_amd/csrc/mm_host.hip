@@ -2190,7 +2190,9 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	a->rlen_carry = batch_carry_out(a, b, a->rlen_carry);
 	if(const char *fn = getenv("MM_DUMP_READ_COST")) {          /* diagnostics: per-read cost of the extension kernel */
 		std::vector<ReadState> d(n_reads); CPY(a, d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
-		if(FILE *fp = fopen(fn, "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks, d[i].n_pass, d[i].w_pass, d[i].k3_chains, d[i].k3_trials, d[i].k3_hits, d[i].n_aln, d[i].spec_n); fclose(fp); }
+		static std::atomic<unsigned> dump_no{0};          /* one file per batch, in the order the batches are fetched (batch order): <name>, <name>.1, <name>.2 ... */
+		const unsigned dn = dump_no++; const std::string dfn = dn ? std::string(fn) + "." + std::to_string(dn) : std::string(fn);
+		if(FILE *fp = fopen(dfn.c_str(), "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks, d[i].n_pass, d[i].w_pass, d[i].k3_chains, d[i].k3_trials, d[i].k3_hits, d[i].n_aln, d[i].spec_n); fclose(fp); }
 	}
 	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];

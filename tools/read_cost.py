@@ -18,3 +18,11 @@ for r in sorted(rows, key=lambda r: -r[5])[:16]:
 for lo, hi in ((0, 32768), (32768, 65536), (65536, 131072), (131072, 262144), (262144, 1 << 30)):
     sel = [r for r in rows if lo <= r[1] < hi]
     if sel: print('length %7d..%-9d: %6d reads, %5.1f %% of the bases, %5.1f %% of the vectors, %.2f vectors per base, %.2f trials per read' % (lo, hi, len(sel), 100.0 * sum(r[1] for r in sel) / bases, 100.0 * sum(r[5] for r in sel) / max(1, tot), sum(r[5] for r in sel) / max(1, sum(r[1] for r in sel)), sum(r[11] for r in sel) / len(sel)))
+
+if any(r[4] for r in rows):
+    # profiling build: wave ticks (s_memtime, 100 MHz) a read held its wave for, with the ticks inside the fills and the tracebacks
+    tk = sorted(rows, key=lambda r: -r[4])
+    print('\nby wave time (ticks of 10 ns; total %d ms over all waves):' % (sum(r[4] for r in rows) / 1e5))
+    print('%8s %8s %6s %6s %6s %5s %10s %9s %9s %9s' % ('read', 'length', 'chains', 'trials', 'jobs', 'alns', 'vectors', 'ms', 'fill ms', 'trace ms'))
+    for r in tk[:16]:
+        print('%8d %8d %6d %6d %6d %5d %10d %9.1f %9.1f %9.1f' % (r[0], r[1], r[10], r[11], r[12], r[13], r[5], r[4] / 1e5, r[6] / 1e5, r[7] / 1e5))
