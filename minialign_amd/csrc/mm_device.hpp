@@ -68,6 +68,7 @@ struct ReadState {
 	uint32_t spec_off, spec_n;                        /* first trials of this read's chains computed by the other waves of the launch (SpecMemo entries), 0: none */
 	uint32_t k3_trials, k3_hits, k3_chains;           /* diagnostics: extension trials of the read, of which taken from a chain job, chains walked */
 	uint32_t k3_ticks, k3_vec, k3_fill_ticks, k3_trace_ticks;   /* diagnostics: s_memtime ticks (whole / DP fill / traceback) and DP vectors the extension kernel spent on this read */
+	uint32_t k3_t0, k3_wait_ticks;                              /* ... when its wave took it (s_memtime >> 8) and the ticks it waited for a DP workspace (profiling build) */
 	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
 	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
 };
@@ -1176,7 +1177,9 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_kernel(K2c
  * ----------------------------------------------------------------------------------------------------- */
 struct K2wArgs {
 	ReadState *st; const uint32_t *work; uint32_t n_work;
-	Seed *seed_pool; Root *root_pool; uint8_t *scratch;          /* scratch: 16 B per element of the seed pool, a read's part at 16 * seed_off */
+	Seed *seed_pool; Root *root_pool; uint8_t *scratch;          /* scratch: 16 B per seed of a read (its leaf tables, later the table of its root sort), handed out as the reads come */
+	unsigned long long *scratch_top; uint64_t scratch_bytes;      /* cursor (zeroed before the launch) and size: the host sizes it for a third of the seed pool's capacity -- reads carry
+	                                                               * a fifth to a twelfth of their caps -- and a read that finds it exhausted reports ERR_SEED_CAP (the batch is redone with larger pools) */
 	double mcoef; uint32_t min_score, twlen;
 	const uint32_t *seq_len; const uint8_t *seq_circ;
 };
@@ -1191,7 +1194,9 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_sweep_kern
 	if(n_all > K2S_MAX_N) { return; }
 	Seed *gs = a.seed_pool + st->seed_off; Root *c = a.root_pool + st->root_off;
 	const uint2 *ss = (const uint2 *)(gs + n_all);
-	uint16_t *lrs = (uint16_t *)(a.scratch + 16ull * st->seed_off), *lls = lrs + n_all, *lcid = lls + n_all, *rlid = lcid + n_all;
+	const unsigned long long sc_need = 16ull * n_all, sc_off = atomicAdd(a.scratch_top, sc_need);
+	if(sc_off + sc_need > a.scratch_bytes) { st->err |= ERR_SEED_CAP; st->n_seed = n; st->n_root = 0; st->pred_rid = gaba::NIL; return; }
+	uint16_t *lrs = (uint16_t *)(a.scratch + sc_off), *lls = lrs + n_all, *lcid = lls + n_all, *rlid = lcid + n_all;
 	uint32_t *rplen = (uint32_t *)(rlid + n_all + (n_all & 1));
 	st->n_seed = n; st->n_root = 0; st->pred_rid = gaba::NIL;
 	const uint32_t UNM = 0x7fffffffu;
@@ -1243,9 +1248,9 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_sweep_kern
 		if(a.seq_circ) { circularize(gs, c, n, nlid, ncid, a.seq_len, a.seq_circ, a.twlen); }
 		if(ncid <= 64) { ins_sort_64((U64R *)c, (U64R *)c + ncid); }          /* longest first (minialign.c:3719); radix_sort_64x is an insertion sort up to 64 elements */
 		else {
-			/* the read's own scratch area is free again (leaves and roots are written out): 4 words per element of its seed region, i.e. at least 8 per chain -- the
+			/* the read's own scratch area is free again (leaves and roots are written out): 4 words per seed, i.e. at least 8 per chain -- the
 			 * 512 bucket words and 3 per pending range (at most one per 65 chains) of radix_sort_64x fit from 65 chains on */
-			if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)lrs, 4u * st->seed_cap)) { st->err |= ERR_STACK; }
+			if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)lrs, 4u * n_all)) { st->err |= ERR_STACK; }
 		}
 		uint32_t pred = gaba::NIL, n_pass = 0, w_pass = 0;          /* chains that pass the length test of mm_search_load_root and their summed lengths: what the extension will cost */
 		for(uint32_t kq = 0; kq < ncid; kq++) {
@@ -1623,6 +1628,7 @@ struct K3Args {
 	uint32_t *path_pool; uint64_t path_pool_cap; unsigned long long *path_top;
 	uint32_t tglen; double mcoef; float min_ratio; uint32_t min_score;
 	uint32_t *counter; unsigned long long *stats;        /* [2] fills, [3] vectors, [4] blocks, [5] traces, [6] trace steps */
+	uint32_t seg_beg[8], seg_len[8]; uint32_t *seg_cnt;  /* the work list by workspace class: reads of class c at work[seg_beg[c] .. + seg_len[c]), cursor seg_cnt[c] (one class: everything in [0]) */
 	/* rounds in the kernel: a read left without a result goes straight on to the next occurrence threshold on the wave that holds it (mm_align_seq's loop,
 	 * minialign.c:4444-4448) -- rescued minimizers expanded, seeds sorted and chained again in HBM by that wave, then extended -- instead of coming back
 	 * through the host for another round of launches */
@@ -2075,6 +2081,28 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	while(true) {
 		uint32_t wi = wave;
 		if(rq_helper && a.rq_early) { wi = 0xffffffffu; }
+		else if(persistent && a.n_cls > 1 && a.ring) {
+			/* several workspace classes: a read of the highest class that has reads left AND a workspace at hand (held already, or free on this XCD right now); else one of
+			 * the ordinary class; when that is used up, what is left above it, waiting for a workspace as need be */
+			wi = 0xffffffffu;
+			for(int c = (int)a.n_cls - 1; c >= 1 && wi == 0xffffffffu; c--) {
+				const uint32_t len = a.seg_len[c];
+				if(len == 0) { continue; }
+				uint32_t cur = 0; if(lane == 0) { cur = __hip_atomic_load(&a.seg_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } cur = (uint32_t)rdfirst((int)cur);
+				if(cur >= len) { continue; }
+				bool have = slab_cls == c;
+				if(!have) { K3_TRY_SLAB(c, have); }
+				if(!have) { continue; }
+				uint32_t i = 0; if(lane == 0) { i = atomicAdd(&a.seg_cnt[c], 1u); } i = (uint32_t)rdfirst((int)i);
+				if(i < len) { wi = a.seg_beg[c] + i; }
+			}
+			if(wi == 0xffffffffu) { uint32_t i = 0; if(lane == 0) { i = atomicAdd(&a.seg_cnt[0], 1u); } i = (uint32_t)rdfirst((int)i); if(i < a.seg_len[0]) { wi = a.seg_beg[0] + i; } }
+			for(int c = (int)a.n_cls - 1; c >= 1 && wi == 0xffffffffu; c--) {
+				if(a.seg_len[c] == 0) { continue; }
+				uint32_t i = 0; if(lane == 0) { i = atomicAdd(&a.seg_cnt[c], 1u); } i = (uint32_t)rdfirst((int)i);
+				if(i < a.seg_len[c]) { wi = a.seg_beg[c] + i; }
+			}
+		}
 		else if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
 		if(wi >= a.n_work) {
 			/* no read left for this wave: it takes retry jobs of the reads that are still being walked until the last of them is done */
@@ -2104,7 +2132,10 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					}
 					if(ji != 0xffffffffu && stt == 100u) {
 						/* (at the top priority: the wave that waits for this result is the critical path of the launch) */
-						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __builtin_amdgcn_s_setprio(3); run_rjob(ji); __builtin_amdgcn_s_setprio(0); mine = 0xffffffffu; continue;
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __builtin_amdgcn_s_setprio(3); run_rjob(ji); __builtin_amdgcn_s_setprio(0); mine = 0xffffffffu;
+						/* a workspace of a class above the ordinary one goes back at once: the classes are small, and a helper that sat on one between jobs could be what a read is waiting for */
+						if(slab_cls >= 1) { K3_RING_GIVE(slab_cls, slab_no); slab_cls = -1; }
+						continue;
 					}
 					if(ji != 0xffffffffu && stt != RJ_EMPTY) { mine = 0xffffffffu; continue; }          /* taken by its owner, done or cancelled: the next one */
 					mine = ji;                                                                        /* drawn but not published yet (or nothing drawn) */
@@ -2140,6 +2171,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
 		if(a.ring) { K3_NEED_SLAB(qlen); }
+		const unsigned long long cy_slab = MM_TICK();
 		Seed *s = a.seed_pool + rdfirst64(st->seed_off);
 		Root *root = a.root_pool + rdfirst64(st->root_off);
 		uint32_t rlen = (uint32_t)rdfirst((int)st->rlen);
@@ -2521,6 +2553,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			st->k3_trials += dg_trials; st->k3_hits += dg_hits; st->k3_chains += dg_chains;
 			st->k3_ticks += (uint32_t)(MM_TICK() - cy_read0); st->k3_vec += x.n_vec - vec_read0;
 			st->k3_fill_ticks += (uint32_t)(cy_fill - cyf_read0); st->k3_trace_ticks += (uint32_t)(cy_trace - cyt_read0);
+			if(round == a.round) { st->k3_t0 = (uint32_t)(cy_read0 >> 8); st->k3_wait_ticks = (uint32_t)(cy_slab - cy_read0); }
 			if(n_res > 0) { st->done = 1; }
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

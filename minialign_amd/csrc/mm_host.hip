@@ -1105,7 +1105,7 @@ struct mm_align_s {
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
-	DBuf<uint8_t> k2w_scratch;          /* lane-per-read chain sweep: leaf / chain scratch, 16 B per element of the seed pool */
+	DBuf<uint8_t> k2w_scratch;          /* lane-per-read chain sweep: leaf / chain scratch, 16 B per seed found (a third of 16 B per element of the seed pool) */
 	DBuf<SpecJob> rq_jobs; DBuf<SpecMemo> rq_memo; DBuf<uint32_t> rq_state;          /* retry jobs of a launch (K3Args.rjobs); rq_state: one word per slot, then the four control words */
 	DBuf<SpecJob> spec_jobs; DBuf<SpecMemo> spec_memo; DBuf<uint32_t> spec_path; DBuf<gaba::Segment> spec_seg; DBuf<unsigned long long> spec_top;      /* chain jobs of the heaviest reads of a launch (K3Args.jobs) */
 	DBuf<uint64_t> tap_words;              /* mm_batch_tap: the minimizer stream words of the batch, parallel to min_pool */
@@ -1250,7 +1250,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				for(int j = 1; j < MM_SIDE; j++) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[14], 0)); }
 				if(!getenv("MM_K2_LDS_CHAIN")) {
 					/* the sweep with one lane per read in HBM (mm_chain_sweep_kernel): every read of the batch in flight at once, no LDS, a few hundred waves */
-					K2wArgs kw; kw.st = a->d_st.p; kw.work = a->d_work.p; kw.n_work = (uint32_t)work.size(); kw.seed_pool = a->seed_pool.p; kw.root_pool = a->root_pool.p; kw.scratch = a->k2w_scratch.p;
+					K2wArgs kw; kw.st = a->d_st.p; kw.work = a->d_work.p; kw.n_work = (uint32_t)work.size(); kw.seed_pool = a->seed_pool.p; kw.root_pool = a->root_pool.p; kw.scratch = a->k2w_scratch.p; kw.scratch_top = tops + 30; kw.scratch_bytes = a->k2w_scratch.bytes;
+					CK(hipMemsetAsync(tops + 30, 0, 8, a->k2s[0]));
 					kw.mcoef = a->mcoef; kw.min_score = a->o.min_score; kw.twlen = a->twlen; kw.seq_len = a->dix.seq_len; kw.seq_circ = a->dix.seq_circ;
 					hipLaunchKernelGGL(mm_chain_sweep_kernel, dim3(((uint32_t)work.size() + 63) / 64), dim3(64), 0, a->k2s[0], kw);
 					CK(hipGetLastError());
@@ -1321,7 +1322,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;
 		}
 		if(a->tap_stop) { return true; }
-		uint32_t k3_work_override = 0, n_heavy = 0;
+		uint32_t k3_work_override = 0, n_heavy = 0; uint32_t seg_beg[8], seg_len[8];
 		{
 			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
 			std::vector<uint32_t> by_len(work);
@@ -1347,6 +1348,23 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				by_len.resize(std::min<size_t>(by_len.size(), (size_t)atoi(e)));
 				k3_work_override = (uint32_t)by_len.size();
 			}
+			{
+				/* with several workspace classes: the reads of a class together, the highest class first (within a class the order made above).  A wave takes reads of
+				 * the highest class that has a workspace free and falls through to the ordinary class otherwise (mm_extend_kernel), instead of waiting at the front of
+				 * one list where all the long reads are: on the ONT-like set the reads of 32 - 128 kb spent four fifths of their wave time waiting for a workspace, and
+				 * the waves that waited held the wave slots of four launches */
+				const mm_align_s *P = a->root ? a->root : a;
+				for(int c = 0; c < 8; c++) { seg_beg[c] = 0; seg_len[c] = 0; }
+				seg_len[0] = (uint32_t)by_len.size();
+				if(P->shared_slabs && P->h_cls.size() > 1 && qlens.size() == n_reads && !k3_work_override && !getenv("MM_K3_ONE_WORK_LIST")) {
+					const int n_cls = (int)P->h_cls.size();
+					auto cls_of = [&](uint32_t r) { int c = 0; while(c + 1 < n_cls && qlens[r] > P->h_cls[c].qmax) { c++; } return c; };
+					std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return cls_of(x) > cls_of(y); });
+					for(int c = 0; c < 8; c++) seg_len[c] = 0;
+					for(uint32_t r : by_len) seg_len[cls_of(r)]++;
+					uint32_t at = 0; for(int c = n_cls - 1; c >= 0; c--) { seg_beg[c] = at; at += seg_len[c]; }
+				}
+			}
 			CK(hipMemcpyAsync(a->d_work.p, by_len.data(), by_len.size() * 4, hipMemcpyHostToDevice, a->stream));
 			CK(hipStreamSynchronize(a->stream));
 		}
@@ -1365,6 +1383,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.path_pool = a->path_pool.p; k3.path_pool_cap = a->path_pool.n; k3.path_top = tops + 6;
 		k3.tglen = a->tglen; k3.mcoef = a->mcoef; k3.min_ratio = a->o.min_ratio; k3.min_score = a->o.min_score;
 		k3.counter = (uint32_t *)(tops + 16); k3.stats = tops + 8;
+		for(int c = 0; c < 8; c++) { k3.seg_beg[c] = seg_beg[c]; k3.seg_len[c] = seg_len[c]; }
+		k3.seg_cnt = a->d_k2cnt.p + 32; CK(hipMemsetAsync(k3.seg_cnt, 0, 8 * 4, a->stream));
 		/* a read without a result goes on to the next occurrence threshold on the wave that holds it (k3_rescue_round) instead of coming back through the host
 		 * for another round of launches: 2.77 against 3.20 s per step on the headline workload (the latency-bound rescue launches -- a serial sort + chain and
 		 * an extension launch of some eighty waves, twice -- took half of a lane's time per batch).  MM_K3_HOST_ROUNDS: the rounds as separate launches */
@@ -1750,7 +1770,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	const uint64_t min_total = ((a->mi->w < 4 || scale > 1) ? bases : bases / 2) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
 	ok &= a->min_pool.ensure(min_total);
 	ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
-	if(!getenv("MM_K2_LDS_CHAIN")) { ok &= a->k2w_scratch.ensure(a->seed_pool.n * 16); }
+	if(!getenv("MM_K2_LDS_CHAIN")) { ok &= a->k2w_scratch.ensure(a->seed_pool.n * 16 / 3); }          /* (16 B per seed found, K2wArgs.scratch; the pool holds the reads' caps) */
 	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
 	ok &= a->resc_pool.ensure(min_total * std::min<uint64_t>(scale, 4));
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
@@ -1779,7 +1799,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	}
 	else if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
 	else { ok &= a->slabs.ensure(slab * kw); if(ok) { a->slab_stride = a->slabs.n / kw; a->k3_waves = kw; } }
-	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(32);
+	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(48);
 	return ok;
 }
 /* one set of DP workspaces for all lanes of a context (the streaming engine calls this before its lane threads start, with the longest read of the input):
@@ -1797,8 +1817,7 @@ bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
 	const uint64_t budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
 	const uint32_t n_xcd = 8;
 	/* reads up to 32 k bases (the PacBio-like sets whole, nine tenths of an ONT-like one) take the ordinary class, one workspace for every wave the device can hold if
-	 * the budget allows (MM_SLAB_GB, default 64); a longer maximum adds classes of 64 k, 128 k, ... bases up to it, out of half the budget again: half of that for
-	 * the first one, a quarter for the next ... (read counts fall faster than that with length in the sets seen) */
+	 * the budget allows (MM_SLAB_GB, default 64); a longer maximum adds classes of 64 k, 128 k, ... bases up to it, each with a share of the budget of its own (below) */
 	const uint32_t q_small = 32768;
 	std::vector<uint32_t> qmax;
 	if(max_qlen > q_small && !getenv("MM_ONE_SLAB_CLASS")) {
@@ -1806,11 +1825,13 @@ bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
 		if(getenv("MM_TWO_SLAB_CLASSES")) { qmax.resize(1); qmax.push_back(max_qlen); }
 	} else { qmax.push_back(max_qlen); }
 	std::vector<uint64_t> bytes(qmax.size()); std::vector<uint32_t> per(qmax.size());
-	uint64_t share = budget / 2;
 	for(size_t c = 0; c < qmax.size(); c++) {
 		bytes[c] = slab_of(qmax[c]);
 		if(c == 0) { per[c] = (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(32, budget / bytes[c] / n_xcd)); continue; }
-		if(c + 1 < qmax.size()) share /= 2;          /* (the last class takes what the one before it took) */
+		/* a quarter of the budget each for the two classes above the ordinary one, an eighth for every class above those.  The waves a class needs go with the share of the
+		 * DP work in its reads -- on the ONT-like set 17 % in 32 - 64 kb, 7 % in 64 - 128 kb, 1 % above -- and more at the start of a launch, where the long reads are; with
+		 * 8 GB for the 64 - 128 kb class (320 workspaces for the 2 164 such reads of a step on four lanes) its reads spent four fifths of their wave time waiting for one */
+		const uint64_t share = c <= 2 ? budget / 4 : budget / 8;
 		per[c] = (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(4, share / bytes[c] / n_xcd));
 	}
 	bool same = P->shared_slabs && P->h_cls.size() == qmax.size();
@@ -2192,7 +2213,7 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 		std::vector<ReadState> d(n_reads); CPY(a, d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
 		static std::atomic<unsigned> dump_no{0};          /* one file per batch, in the order the batches are fetched (batch order): <name>, <name>.1, <name>.2 ... */
 		const unsigned dn = dump_no++; const std::string dfn = dn ? std::string(fn) + "." + std::to_string(dn) : std::string(fn);
-		if(FILE *fp = fopen(dfn.c_str(), "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks, d[i].n_pass, d[i].w_pass, d[i].k3_chains, d[i].k3_trials, d[i].k3_hits, d[i].n_aln, d[i].spec_n); fclose(fp); }
+		if(FILE *fp = fopen(dfn.c_str(), "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks, d[i].n_pass, d[i].w_pass, d[i].k3_chains, d[i].k3_trials, d[i].k3_hits, d[i].n_aln, d[i].spec_n, d[i].k3_t0, d[i].k3_wait_ticks); fclose(fp); }
 	}
 	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
@@ -3104,15 +3125,15 @@ static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
  * the fly, text handed to a callback in input order */
 static int default_lanes();
 /* the largest batch the device memory allows on `lanes` lanes: the pools of a lane take about 52 bytes per base of its batches (seeds and the sweep's scratch are most of it,
- * ensure_pools); what they may take together is what was free when the first stream of the context started, less the DP workspaces at their largest (1.5 x the budget:
- * the ordinary class and the ladder above it) and 10 GB for the runtime (kernel scratch) and the text */
+ * ensure_pools); what they may take together is what was free when the first stream of the context started, less the DP workspaces at their largest (1.75 x the budget:
+ * the ordinary class and a ladder of four above it) and 10 GB for the runtime (kernel scratch) and the text */
 static uint64_t batch_cap_bases(mm_align_t *a, int lanes)
 {
 	mm_align_s *P = a->root ? a->root : a;
 	if(!P->mem_for_batches) {
 		size_t fr = 0, tot = 0; if(hipMemGetInfo(&fr, &tot) != hipSuccess) return 1000000000ull;
 		const uint64_t avail = fr + dev_cache().held, slab_budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
-		const uint64_t taken = slab_budget + slab_budget / 2 + (10ull << 30) - std::min<uint64_t>(P->shared_slabs ? P->slabs.bytes : 0, slab_budget);          /* (workspaces already allocated are no longer in `avail`) */
+		const uint64_t taken = slab_budget + slab_budget * 3 / 4 + (10ull << 30) - std::min<uint64_t>(P->shared_slabs ? P->slabs.bytes : 0, slab_budget);          /* (workspaces already allocated are no longer in `avail`) */
 		P->mem_for_batches = avail > taken + (8ull << 30) ? avail - taken : (8ull << 30);
 	}
 	return std::max<uint64_t>(128ull << 20, P->mem_for_batches / (uint64_t)std::max(1, lanes) / 52);

@@ -22,7 +22,15 @@ for lo, hi in ((0, 32768), (32768, 65536), (65536, 131072), (131072, 262144), (2
 if any(r[4] for r in rows):
     # profiling build: wave ticks (s_memtime, 100 MHz) a read held its wave for, with the ticks inside the fills and the tracebacks
     tk = sorted(rows, key=lambda r: -r[4])
-    print('\nby wave time (ticks of 10 ns; total %d ms over all waves):' % (sum(r[4] for r in rows) / 1e5))
-    print('%8s %8s %6s %6s %6s %5s %10s %9s %9s %9s' % ('read', 'length', 'chains', 'trials', 'jobs', 'alns', 'vectors', 'ms', 'fill ms', 'trace ms'))
-    for r in tk[:16]:
-        print('%8d %8d %6d %6d %6d %5d %10d %9.1f %9.1f %9.1f' % (r[0], r[1], r[10], r[11], r[12], r[13], r[5], r[4] / 1e5, r[6] / 1e5, r[7] / 1e5))
+    print('\nby wave time (shader clock cycles at 2.1 GHz; total %d ms over all reads):' % (sum(r[4] for r in rows) / 2.1e6))
+    CLK = 2.1e6          # cycles per ms (s_memtime runs at the shader clock)
+    t00 = min(r[15] for r in rows if r[4]) if len(rows[0]) > 15 else 0
+    print('%8s %8s %6s %6s %6s %5s %10s %9s %9s %9s %9s %9s %9s' % ('read', 'length', 'chains', 'trials', 'jobs', 'alns', 'vectors', 'ms', 'fill ms', 'trace ms', 'wait ms', 'start ms', 'end ms'))
+    def line(r):
+        st = ((r[15] - t00) & 0xffffffff) * 256 / CLK if len(r) > 15 else 0.0
+        print('%8d %8d %6d %6d %6d %5d %10d %9.1f %9.1f %9.1f %9.1f %9.1f %9.1f' % (r[0], r[1], r[10], r[11], r[12], r[13], r[5], r[4] / CLK, r[6] / CLK, r[7] / CLK, (r[16] / CLK) if len(r) > 16 else 0.0, st, st + r[4] / CLK))
+    for r in tk[:12]: line(r)
+    if len(rows[0]) > 15:
+        print('the reads that end last:')
+        for r in sorted(rows, key=lambda r: -(((r[15] - t00) & 0xffffffff) * 256 + r[4]))[:12]: line(r)
+        w = sum(r[16] for r in rows); print('waiting for a workspace: %.0f ms summed over the reads (%.1f %% of the wave time of the reads)' % (w / CLK, 100.0 * w / max(1, sum(r[4] for r in rows))))
