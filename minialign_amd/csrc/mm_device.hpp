@@ -1985,7 +1985,14 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			const uint32_t r = (uint32_t)rdfirst((int)j.r), aid = (uint32_t)rdfirst((int)j.aid), cp_a = (uint32_t)rdfirst((int)j.cp_a), cp_b = (uint32_t)rdfirst((int)j.cp_b);
 			const uint32_t rev = (uint32_t)rdfirst((int)j.rev), rlen = (uint32_t)rdfirst((int)j.rlen); const int rcirc = rdfirst((int)j.rcirc);
 			const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen); const uint64_t q_off = rdfirst64(a.in[r].q_off), roff = rdfirst64(a.idx.seq_off[aid]);
-			K3_NEED_SLAB(qlen);
+			{
+				/* the workspace without waiting: the wave holds a claimed job, and the waves that hold the workspaces of a scarce class may soon be waiting for this very job.
+				 * None free: the job is handed back undone (the read's own wave runs the trial when it gets there, as without jobs) */
+				int want = 0; while(want + 1 < (int)a.n_cls && qlen > a.cls[want].qmax) { want++; }
+				bool have = want == slab_cls;
+				if(!have) { K3_TRY_SLAB(want, have); }
+				if(!have) { if(lane == 0) { __hip_atomic_store(&a.memo[ji].state, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } continue; }
+			}
 			const gaba::Sec rsec_f = gaba::Sec{ aid << 1, rlen, roff, 0, 0 }, rsec_r = gaba::Sec{ (aid << 1) + 1, rlen, roff, 0, 1 };
 			const gaba::Sec qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }, qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
 			SpecMemo mo; mo.state = 0; mo.aid = aid; mo.cp_a = cp_a; mo.cp_b = cp_b; mo.rev = rev; mo.mmax0 = 0; mo.mmax1 = 0; mo.tplen = 0; mo.path_off = 0; mo.seg_off = 0;

@@ -1406,9 +1406,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		}
 		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0;
 		/* chain jobs: the first trials of the chains of the heaviest reads (the front of the work list), taken by all waves of the launch before the reads (K3Args.jobs) */
-		/* (only with a workspace for every resident wave and a single workspace class: a wave that walks a read keeps its workspace while it waits for a job's result, and the wave that
-		 * has claimed that job needs a workspace to run it -- with fewer workspaces than waves, or on the class ladder of a long-tailed set, the two would wait for each other) */
-		if(round == 0 && n_heavy > 0 && k3.ring && k3.n_cls == 1 && (uint64_t)k3.ring_n * 8 >= a->n_waves && inkernel && !getenv("MM_K3_NO_JOBS")) {
+		/* (a wave that has claimed a job takes the workspace for it without waiting, K3_TRY_SLAB, and hands the job back undone when none of its class is free: with fewer
+		 * workspaces than waves, or on the class ladder of a long-tailed set, the waves that hold the workspaces may be the ones that wait for the job) */
+		if(round == 0 && n_heavy > 0 && k3.ring && k3.cls && inkernel && !getenv("MM_K3_NO_JOBS")) {
 			const uint64_t job_cap = 1u << 16, path_cap = 48ull << 20;
 			if(a->spec_jobs.ensure(job_cap) && a->spec_memo.ensure(job_cap) && a->spec_path.ensure(path_cap) && a->spec_seg.ensure(job_cap * 8) && a->spec_top.ensure(8)) {
 				CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
