@@ -101,3 +101,23 @@ def test_alternative_schedules_give_the_same_bytes(env):
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert _strip_pg(r.stdout) == want
         assert b're-run' in r.stderr
+
+@pytest.fixture(scope='module')
+def long_tailed():
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
+        M.gensim('genome', 7501, 5000000, 3, 0.3, out=ref); M.gensim('reads', 7502, ref, 2.0, 'ont', 'fa', out=rd)          # 858 reads to 166 kb: 43 above 32 kb, 5 above 64 kb, 2 above 128 kb
+        opts = ['-xont.1dsq', '-f0.2,0.05,0.002']
+        want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+        yield ref, rd, opts, want
+
+@pytest.mark.parametrize('env', [dict(), dict(MM_SLAB_GB='64'), dict(MM_K3_ONE_WORK_LIST='1'), dict(MM_K3_LATE_HELPERS='1'), dict(MM_K3_HELPERS='4'), dict(MM_K3_NO_RETRY_JOBS='1', MM_K3_NO_JOBS='1'), dict(MM_ONE_SLAB_CLASS='1')],
+                         ids=['four-workspaces-per-class-and-xcd', 'full-ladder', 'one-work-list', 'late-helpers', 'one-wave-in-four-helps', 'no-jobs', 'one-class'])
+def test_workspace_ladder_with_jobs_gives_the_same_bytes(long_tailed, env):
+    """a long-tailed read set on the ladder of DP workspace classes (32 k / 64 k / 128 k / longest), with so small a budget that the classes above the ordinary one have four
+    workspaces per XCD: chain jobs and retry jobs take their workspaces without waiting (K3_TRY_SLAB), the work list is by class -- and the forms kept behind switches; a
+    hang here is the failure the first version had (helpers waiting for workspaces held by the waves that waited for them)"""
+    ref, rd, opts, want = long_tailed
+    r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **dict(dict(MM_SLAB_GB='2', MM_LANES='2', MM_BATCH_BASES='6000000'), **env)), timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert _strip_pg(r.stdout) == want
