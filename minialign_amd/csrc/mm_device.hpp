@@ -2174,7 +2174,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		 * ordinary reads fill the slots in between.  The top priority goes by place in the work list -- its first 64th is the reads with the
 		 * most chains of the batch (run_rounds puts them there) -- and to nobody else: with every read of 8 chains or more at 3 and of 5 at 2
 		 * (the earlier rule: a tenth of the reads) the truly heavy ones had company at their level; 2.32 - 2.36 against 2.51 - 2.54 s per step */
-		if(wi < (a.n_work >> 6)) { __builtin_amdgcn_s_setprio(3); } else if(n_root >= 5) { __builtin_amdgcn_s_setprio(1); } else { __builtin_amdgcn_s_setprio(0); }
+		if(wi < (a.n_work >> 6) || a.n_work < 64) { __builtin_amdgcn_s_setprio(3); }          /* (a launch of a few reads is a re-run for the carried value: its lane, and the lanes behind it, wait for it) */ else if(n_root >= 5) { __builtin_amdgcn_s_setprio(1); } else { __builtin_amdgcn_s_setprio(0); }
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
 		if(a.ring) { K3_NEED_SLAB(qlen); }
