@@ -1647,6 +1647,7 @@ struct K3Args {
 	 * (they stay in the launch until the last read is done: reads_done).  The owner takes a result where its inputs are the trial's, runs a job itself where nobody has claimed it, and
 	 * works on a later job of its own while one it needs is in another wave's hands.  NULL: none */
 	uint32_t rq_helper_mask;             /* a wave that has run out of reads stays as a helper when (wave number & mask) == 0 (one in 128 by default): every helper holds a wave slot the other lanes' launches wait for */
+	uint32_t full_n;                     /* workspaces per XCD that make a class complete: one for every wave the XCD can hold */
 	uint32_t rq_early;                   /* helpers are helpers from the start of the launch (they take no reads): the reads that publish retry jobs are at the front of the work list */
 	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = helpers' cursor, [2] = reads done, [3] = results taken */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
@@ -1954,7 +1955,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		uint32_t _v = 0xffffffffu; \
 		if(lane == 0) { \
 			unsigned long long *_ctr = a.cls[_want].ctr; uint32_t *_rg = a.cls[_want].ring; const uint32_t _n = a.cls[_want].n; \
-			for(int _try = 0; _try < 4; _try++) { \
+			for(;;) {          /* (a failed compare-and-swap means another wave drew a ticket: somebody always gets on) */ \
 				const unsigned long long _t = __hip_atomic_load(&_ctr[2 * xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), _g = __hip_atomic_load(&_ctr[2 * xcc + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
 				if(_t >= _g) { break; } \
 				if(atomicCAS(&_ctr[2 * xcc], _t, _t + 1ull) != _t) { continue; } \
@@ -1990,6 +1991,10 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				 * None free: the job is handed back undone (the read's own wave runs the trial when it gets there, as without jobs) */
 				int want = 0; while(want + 1 < (int)a.n_cls && qlen > a.cls[want].qmax) { want++; }
 				bool have = want == slab_cls;
+				/* (a class with a workspace for every wave an XCD can hold never makes anybody wait: the plain ticket, one atomic add -- the compare-and-swap of the other form,
+				 * with a thousand waves of an XCD at the same counter when the launch starts, is what a first version with a bounded number of attempts failed on: nearly every
+				 * job of an E.coli-size set was handed back, 182 -> 211 ms per step) */
+				if(!have && a.cls[want].n >= a.full_n) { K3_NEED_SLAB(qlen); have = true; }
 				if(!have) { K3_TRY_SLAB(want, have); }
 				if(!have) { if(lane == 0) { __hip_atomic_store(&a.memo[ji].state, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } continue; }
 			}

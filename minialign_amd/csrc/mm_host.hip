@@ -655,11 +655,13 @@ struct DevCache {
 	 * being replaced: nothing is in flight then) -- an ONT-like run that re-sized its workspace ladder a few times had 150 GB of them waiting here and the runtime ran out of memory */
 	void give(int dev, size_t bytes, void *p)
 	{
-		/* ... and nothing is kept while the device is short of memory (the runtime allocates the kernels' scratch memory on demand and aborts the process when it cannot) */
-		size_t fr = 0, tot = 0; const bool tight = hipMemGetInfo(&fr, &tot) != hipSuccess || fr < reserve();
-		{ std::lock_guard<std::mutex> lk(mu); if(!tight && bytes <= (16ull << 30) && held + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held += bytes; return; } }
+		/* ... and nothing is kept while the device is short of memory (the runtime allocates the kernels' scratch memory on demand and aborts the process when it cannot).
+		 * `tight` is what the last fresh allocation found: hipMemGetInfo costs about 2 ms, and a stream gives a dozen buffers back when it ends -- asked here, it made every
+		 * stream 20 ms longer, 12 % of one over an E.coli-size set */
+		{ std::lock_guard<std::mutex> lk(mu); if(!tight.load() && bytes <= (16ull << 30) && held + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held += bytes; return; } }
 		(void)hipFree(p);
 	}
+	std::atomic<bool> tight{false};
 	static size_t reserve() { return 24ull << 30; }
 	/* may `bytes` more be taken?  Not when less than 8 GB would be left after giving back what is held here: the runtime allocates the scratch memory of a kernel when it is first
 	 * launched on a queue (1.7 GB for the extension kernel) and aborts the process when it cannot -- an allocation that fails cleanly is the better end */
@@ -671,7 +673,7 @@ struct DevCache {
 		return fr >= bytes + (8ull << 30);
 	}
 	/* after a fresh allocation: what is held goes back to the driver when less than the reserve is left */
-	void relieve(int dev) { size_t fr = 0, tot = 0; if(held && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < reserve())) flush(dev); }
+	void relieve(int dev) { size_t fr = 0, tot = 0; const bool t = hipMemGetInfo(&fr, &tot) != hipSuccess || fr < reserve(); tight.store(t); if(t && held) flush(dev); }
 	void flush(int dev) { std::lock_guard<std::mutex> lk(mu); for(auto it = blocks.begin(); it != blocks.end();) { if(it->first.first == dev) { (void)hipFree(it->second); held -= it->first.second; it = blocks.erase(it); } else ++it; } }          /* out of memory: everything held goes back to the driver */
 };
 static DevCache &dev_cache() { static DevCache *c = new DevCache(); return *c; }          /* (never destroyed: blocks may come back while the process winds down) */
@@ -1393,6 +1395,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.rjobs = nullptr; k3.rmemo = nullptr; k3.rstate = nullptr; k3.rq_cap = 0; k3.rq_ctl = nullptr;
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
 		k3.rq_early = getenv("MM_K3_LATE_HELPERS") ? 0u : 1u;
+		k3.full_n = a->n_waves / 8;
 		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 stays as a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for */
 		/* (any number of workspace classes, any number of workspaces: a helper takes the workspace a job needs before it claims the job and without waiting, K3_TRY_SLAB, so the
 		 * wave that waits for a claimed job waits for one that is running; on the ONT-like set the reads that decide the launch are 60 - 160 kb long with 9 - 27 trials for
