@@ -2958,10 +2958,10 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 				ok = batch_upload(c, b);
 				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): pack + upload %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 				/* run ahead with the predicted carry; pools that overflow are grown here, before anybody waits for this batch */
-				bool split = false;
+				bool split = false; const double k1_0 = c->st.k1_ms, k2_0 = c->st.k2_ms, k3_0 = c->st.k3_ms;
 				if(getenv("MM_TEST_SPLIT") && b.n >= 8) { split = true; }          /* test hook: take the path of a batch the pools cannot hold */
 				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) ok = false; }
-				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): run %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): run %.1f ms (at %.1f): sketch %.1f, sort + chain %.1f, extension %.1f ms on the device, the rest the host's turns in between\n", k, li, now_ms() - tv, now_ms() - t_engine0, c->st.k1_ms - k1_0, c->st.k2_ms - k2_0, c->st.k3_ms - k3_0); tv = now_ms(); }
 				uint32_t truth = 0;
 				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return verified == k || rc != 0; }); if(rc) ok = false; truth = carry; }
 				while(ok && !split) {
