@@ -1396,7 +1396,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
 		k3.rq_early = getenv("MM_K3_LATE_HELPERS") ? 0u : 1u;
 		k3.full_n = a->n_waves / 8;
-		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 stays as a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for */
+		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 is a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) when helpers were the waves that had run out of reads -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for; as helpers from the start, one in 8 / 16 / 32 on the ONT-like set: 2.37 / 2.34 / 2.46 against 2.7 - 2.9 */
 		/* (any number of workspace classes, any number of workspaces: a helper takes the workspace a job needs before it claims the job and without waiting, K3_TRY_SLAB, so the
 		 * wave that waits for a claimed job waits for one that is running; on the ONT-like set the reads that decide the launch are 60 - 160 kb long with 9 - 27 trials for
 		 * one alignment, tools/read_cost.py) */
