@@ -13,9 +13,13 @@ conversion + 2-bit packing, K1 sketch + lookup, K2 sort + chain, K3 banded exten
 D2H, post-map, SAM formatting.  Only index construction is outside (as in the README's figure).  `config.value_from_packed` keeps the earlier rounds' figure (the
 same steps from reads parsed and 2-bit packed ahead of time), `config.cli_map_phase_s` is the map phase of the command-line program itself over the same set
 (`minialign_amd/minialign ref.fa reads.fa > /dev/null`, between its "loaded/built index" and "finished mapping" stamps as minialign.c:6417,6431 puts them).
-With N > 1 GPUs (torch.distributed.run, one process per GPU) the SAME read set is split over the ranks (strong scaling): rank r maps parts r*16/N .. of
-the set against its own replica of the index, the ranks settle the one value reads share (the carried reference length, minialign_amd/multi.py) with one
-tiny all_gather, and value = total bases / max over ranks of the time.  No collective on the data path.
+With N > 1 GPUs the SAME read set goes over N devices (strong scaling), either way with a replica of the index in every GPU's HBM and no collective on the data path:
+  * `python bench.py --gpus N` launched plainly: ONE process, the drop-in's own way -- the library's context spans N devices (mm_align_init, MM_DEVICES=N), its
+    streaming engine deals the batches of the one text to device x lane, verifies the carried value in batch order and writes in input order (what the command-line
+    program does with N visible GPUs);
+  * under torch.distributed.run (WORLD_SIZE = N, one process per GPU, as the driver launches N > 1): rank r maps parts r*16/N .. of the set on its own device, the
+    ranks settle the one value reads share (the carried reference length, minialign_amd/multi.py) with one tiny all_gather over gloo, value = total bases / max
+    over ranks of the time.
 
 Prints ONE JSON line: metric / value / ... as the contract asks, `roofline` for the dominant kernel (mm_extend_kernel: DP vectors x 40.5 B + traceback
 steps x 32 B, SURVEY.md 8d, counted by the kernel, over the summed launch time from HIP events on the launch streams), `cpu_baseline` (the compiled
@@ -139,7 +143,7 @@ def pmc_traffic(wname, world, alg_bytes_per_launch):
     """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes of the same workload (tools/pmc_traffic.sh; this round's, else the last round's), else None.  The PMC run maps
     a tenth of the set on one lane; its traffic per launch is scaled by the algorithmic bytes per launch of this run over those of that run (same kernel, same reads:
     traffic per vector is what the counters measured)."""
-    fn = next((f for f in (os.path.join(ROOT, 'profiles', t + '_pmc.json') for t in ('round3', 'round2')) if os.path.exists(f)), None)
+    fn = next((f for f in (os.path.join(ROOT, 'profiles', t + '_pmc.json') for t in ('round4', 'round3', 'round2')) if os.path.exists(f)), None)
     if world != 1 or fn is None: return None
     try:
         with open(fn) as f: d = json.load(f)
@@ -152,7 +156,7 @@ def pmc_traffic(wname, world, alg_bytes_per_launch):
 def valu_position(vectors, wall_s, world):
     """Where the run sits against the integer-VALU issue limit of the chip (the real bound of mm_extend_kernel): the VALU cycles per DP vector that the SQ
     counters measured (tools/pmc_sq.sh -> profiles/round2_pmc_sq.json, SQ_ACTIVE_INST_VALU) x the vectors of this run, over SIMDs x clock x wall time."""
-    fn = next((f for f in (os.path.join(ROOT, 'profiles', t + '_pmc_sq.json') for t in ('round3', 'round2')) if os.path.exists(f)), '')
+    fn = next((f for f in (os.path.join(ROOT, 'profiles', t + '_pmc_sq.json') for t in ('round4', 'round3', 'round2')) if os.path.exists(f)), '')
     try:
         with open(fn) as f: per = json.load(f)['mm_extend_kernel_per_dp_vector']
         simds, clock = 256 * 4, 2.4e9          # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz maximum engine clock (MI355X_MICROARCH.md)
@@ -182,6 +186,9 @@ def main():
     args = ap.parse_args()
     os.environ['MM_LANES'] = str(args.lanes)          # the batch rule of the library (one batch per lane for a small set) sees the lanes this run uses
     rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
+    # devices: under torch.distributed.run every rank drives ONE (its own); launched plainly, this one process drives --gpus N through the library's multi-device context
+    n_inproc = max(1, args.gpus) if world == 1 else 1
+    n_gpus = world if world > 1 else n_inproc
     w = dict(WORKLOADS[args.workload]); custom = False
     for k in ('depth', 'genome_len', 'contigs', 'repeat_frac'):
         if getattr(args, k) is not None: w[k] = getattr(args, k); custom = True
@@ -202,6 +209,12 @@ def main():
         import __graft_entry__; __graft_entry__.build()
     L = multi.load_library(lib)
     assert L.mm_set_device(local) == 0, 'no HIP device %d' % local
+    os.environ['MM_DEVICES'] = str(n_inproc)            # (read by mm_align_init: the devices the context spans, from the current one on)
+    same_box = False
+    if n_inproc > 1 and torch.cuda.device_count() < n_inproc:
+        if not same_dev: raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible (MM_BENCH_SAME_DEVICE=1 puts the %d device contexts on one GPU: a test of the path, not a measurement)' % (n_inproc, torch.cuda.device_count(), n_inproc))
+        os.environ['MM_DEVICES'] = str(max(1, torch.cuda.device_count())); os.environ['MM_DEVICE_CONTEXTS'] = str(n_inproc); same_box = True
+        os.environ.setdefault('MM_SLAB_GB', str(max(4, 48 // n_inproc)))
     if world > 1 and not os.environ.get('MM_HOST_THREADS'):
         os.environ['MM_HOST_THREADS'] = str(max(8, (os.cpu_count() or 8) // world - 4))        # the ranks share the host cores
 
@@ -217,7 +230,7 @@ def main():
     t_gen = time.time() - t_gen0
 
     # the drop-in itself first, while this process holds nothing on the device (two processes with a dozen streams each would take turns on the hardware queues)
-    cli_info = cli_map_phase(w, ref_fa, parts, work) if (rank == 0 and world == 1 and not args.no_cli) else {}
+    cli_info = cli_map_phase(w, ref_fa, parts, work) if (rank == 0 and n_gpus == 1 and not args.no_cli) else {}
     o = ctypes.c_void_p(L.mm_opt_init())
     argv = (ctypes.c_char_p * 4)(b'minialign', ('-x' + w['preset']).encode(), ref_fa.encode(), b'reads.fa')
     files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
@@ -226,6 +239,7 @@ def main():
     mi = ctypes.c_void_p(L.mm_idx_gen(o, ref_fa.encode())); assert mi
     al = ctypes.c_void_p(L.mm_align_init(o, mi)); assert al, 'mm_align_init failed (no GPU?)'
     t_index = time.time() - t0
+    assert L.mm_align_devices(al) == n_inproc, 'the context spans %d device(s), %d were asked for' % (L.mm_align_devices(al), n_inproc)
     # this rank's shard: parts [p0, p1) of the set (PARTS is a multiple of every N the driver uses; otherwise the split is by parts, as even as it gets)
     p0, p1 = multi.shard_bounds(PARTS, rank, world)
     # the FASTA text of the shard in host memory (what a reader of the file finds in the page cache)
@@ -240,7 +254,7 @@ def main():
     keep_bytes = 160 << 20          # text kept per step: enough for the identity check and for a spliced head window
 
     def sync():
-        torch.cuda.synchronize()
+        for d in range(min(n_inproc, torch.cuda.device_count())) if n_inproc > 1 else (local,): torch.cuda.synchronize(d)
         if dist: dist.barrier()
     def one_step(packed=None, reads=None, n_reads=0):
         if packed is not None: sm = multi.ShardMapper(L, al, reads, 0, n_reads, lanes=args.lanes, packed=packed, keep=keep_bytes, guess=0 if rank == 0 else guess)
@@ -265,7 +279,7 @@ def main():
     bases = st.bases // K; n_reads = st.reads // K; nb = int(round(st.k1_launches / K))          # per step, counted by the library (re-runs of the carried value add a few launches)
     # ... and the earlier rounds' figure: the same steps from reads parsed and 2-bit packed ahead of time (N = 1 only: a report, not the value)
     from_packed = None; t_pack = None
-    if world == 1 and not args.no_packed:
+    if n_gpus == 1 and not args.no_packed:
         tq = time.time()
         reads = ctypes.c_void_p(L.mm_reads_load(parts[p0].encode())) if p1 > p0 else None
         for p in range(p0 + 1, p1): assert L.mm_reads_append(reads, parts[p].encode()) == 0
@@ -296,12 +310,14 @@ def main():
         achieved = (alg_bytes / max(1.0, k3_launches)) / (k3_launch_ms * 1e-3) / 1e9 if k3_ms > 0 else None
         out = {
             'metric': 'aligned Gbases/sec (whole node), map phase end to end: FASTA text of the reads in host memory -> SAM text in host memory',
-            'value': total_bases * args.steps / dt * 1e-9, 'unit': 'Gbases/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': total_bases * args.steps / dt * 1e-9, 'unit': 'Gbases/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'i8',
             'data': 'synthetic (tools/gensim.c, seed 0x5eed0001: %.2f Mb reference in %d contig(s) with %g %% planted repeats; %s-like reads in %d parts)' % (w['genome_len'] / 1e6, w['contigs'], w['repeat_frac'] * 100, 'ONT' if w['kind'] == 'ont' else 'PBSIM-CLR', PARTS),
-            'config': {'workload': '%s%s x %s x%g (%.2f Gb, %d reads) -x%s, one read set split over %d MI355X' % (w['name'], ' [custom shape]' if custom else '', 'ONT-like' if w['kind'] == 'ont' else 'PBSIM-like', w['depth'], total_bases / 1e9, int(total_reads), w['preset'], world),
+            'config': {'workload': '%s%s x %s x%g (%.2f Gb, %d reads) -x%s, one read set split over %d MI355X' % (w['name'], ' [custom shape]' if custom else '', 'ONT-like' if w['kind'] == 'ont' else 'PBSIM-like', w['depth'], total_bases / 1e9, int(total_reads), w['preset'], n_gpus),
                        'workload_key': args.workload if not custom else 'custom', 'reads_total': int(total_reads), 'bases_total': int(total_bases), 'batches_per_rank0': nb, 'lanes': args.lanes,
-                       'parallelism': 'reads sharded contiguously, index replicated (no data-path collective; one all_gather of 2 integers per step for the carried value)',
+                       'parallelism': ('one process per GPU (torch.distributed.run, gloo): reads sharded contiguously, index replicated (no data-path collective; one all_gather of 2 integers per step for the carried value)' if world > 1 else
+                                       'one process, %d device(s): batches of the one text dealt to device x lane by the library\'s streaming engine, index replicated, carried value verified in batch order, one ordered writer (no collective)%s' % (n_inproc, ' -- ALL DEVICE CONTEXTS ON ONE GPU (MM_BENCH_SAME_DEVICE): a test of the path, not a measurement' if same_box else '')),
+                       'devices_in_process': n_inproc, 'processes': world,
                        'timed_region': 'text H2D + K0r record scan + K0 base conversion / 2-bit pack + K1 sketch/lookup + K2 sort/chain + K3 extension (rounds, carried-value verification) + D2H + post-map + SAM text; only the index build is outside',
                        'value_from_packed': from_packed, 'value_from_packed_note': 'the same steps from reads parsed and 2-bit packed on the host ahead of time (the timed region of rounds 1-2), 2 steps',
                        'device_only_gbases_per_s (sum of kernel time, lanes overlap)': total_bases * K / max(1e-9, (k1_ms + k2_ms + k3_ms) * 1e-3) * 1e-9 / 1.0,
@@ -314,17 +330,17 @@ def main():
                        'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
                        'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'text_load_s (outside)': t_load, 'host_parse_and_pack_s (value_from_packed only)': t_pack},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args.workload if not custom else 'custom', world, alg_bytes / max(1.0, k3_launches)),
+                         'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args.workload if not custom else 'custom', n_gpus, alg_bytes / max(1.0, k3_launches)),
                          'alg_bytes_per_launch': alg_bytes / max(1.0, k3_launches), 'avg_launch_ms': k3_launch_ms, 'launches': k3_launches,
                          # launches of different lanes share the chip, so one launch lasts longer than it would alone: the same bytes over the wall time of the timed region
-                         'achieved_all_lanes': alg_bytes / dt * 1e-9 / world,
-                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4); achieved = algorithmic bytes per launch / mean launch time, achieved_all_lanes = per GPU over the wall time',
-                         'valu_issue': valu_position(vec / K, dt / K, world)},
+                         'achieved_all_lanes': alg_bytes / dt * 1e-9 / n_gpus,
+                         'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4); achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch streams, this run), achieved_all_lanes = per GPU over the wall time; traffic is NOT measured in this run: it is the HBM bytes per launch of the committed rocprofv3 PMC passes of the same workload (profiles/roundN_pmc.json, FETCH_SIZE / WRITE_SIZE in separate runs) scaled by the algorithmic bytes per launch of this run over those of that one',
+                         'valu_issue': valu_position(vec / K, dt / K, n_gpus)},
         }
-        if (world == 1 or args.check) and not args.no_cpu:
+        if (n_gpus == 1 or args.check) and not args.no_cpu:
             cpu = reference_runs(w, ref_fa, parts, work, args.check_reads, args.baseline_reads, True)
             stage('CPU legs done')
-            if world == 1: out['cpu_baseline'] = cpu['cpu_baseline']
+            if n_gpus == 1: out['cpu_baseline'] = cpu['cpu_baseline']
             if cpu['check_sam'] is not None:
                 # the records of the first check_reads reads of the stream: the library recorded where those of read check_reads begin (mm_head_offset)
                 cut = L.mm_head_offset(al, cpu['check_reads']) if not sm._stale else multi.NO_OFFSET

@@ -56,9 +56,15 @@ uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t
  * one byte per base (0..3, 4 = N), and -- when pos != NULL -- the decoded k-mer start positions (minialign.c:2831-2835); returns the count, writes at most max */
 uint32_t mm_sketch(uint8_t const *seq, uint32_t len, uint32_t w, uint32_t k, uint64_t *words, uint32_t *pos, uint32_t max);
 
-/* device context: uploads the reference (2-bit + N mask) and the flattened index, builds the DP constants */
+/* device context: uploads the reference (2-bit + N mask) and the flattened index, builds the DP constants.
+ * Where the reference takes `-t N` worker threads between one source and one drain thread (minialign.c:1013-1048, 4565-4645, 4729), this context takes GPUs: it spans
+ * every visible device from the current one on (HIP_VISIBLE_DEVICES chooses them; MM_DEVICES=n in the environment takes n), with a replica of the index in each
+ * device's HBM, and the streaming entries (mm_align_file, mm_map_text, mm_map_file, mm_map_packed, mm_map_reads; the command line) deal their batches to device x
+ * lane and write in input order -- one process, no collective.  The per-batch entries below (mm_align_batch, mm_batch_*) run on the first device.
+ * mm_align_devices: how many devices the context spans. */
 mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi);
 void mm_align_destroy(mm_align_t *a);
+int mm_align_devices(mm_align_t const *a);
 /* maps every read of a FASTA / FASTQ file and prints SAM records (no header) to `out`; returns 0 on success */
 int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out);
 void mm_print_sam_header(mm_align_t const *a, FILE *out, char const *arg_line);

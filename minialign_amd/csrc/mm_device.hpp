@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(256) mm_codes_pack_kernel(const uint8_t *codes
  * ===================================================================================================== */
 struct TextRec { uint32_t start, hdr_end, t_off, t_len, n_bases, q_off, q_len; };      /* offsets inside the stretch: delimiter, the '\n' that ends the header (or the end), sequence extent, quality extent */
 struct ScanArgs {
-	const uint8_t *text; uint32_t n;       /* the stretch */
+	const uint8_t *text; uint32_t n;       /* the stretch: text[skip, n) -- `text` is 64-byte aligned, the first `skip` (< 64) bytes in front of the stretch are not part of it */
+	uint32_t skip;
 	uint32_t fastq;                        /* 0: FASTA ('>'), 1: FASTQ */
 	uint64_t *ma, *mb;                     /* per 64-byte word: '\n' mask; record-start mask (FASTA) / '+' mask (FASTQ) */
 	uint32_t *blk;                         /* per block of 256 words: [2 b] = bits of ma, [2 b + 1] = bits of mb; after the block scan: exclusive prefixes, totals at [2 n_blk], [2 n_blk + 1] */
@@ -176,6 +177,7 @@ __global__ void __launch_bounds__(256) mm_text_marks_kernel(ScanArgs a)
 		}
 		const uint32_t live = a.n - w * 64u;          /* bytes of the word inside the stretch */
 		if(live < 64u) { const uint64_t m = (1ull << live) - 1; nl &= m; dm &= m; }
+		if(w == 0 && a.skip) { const uint64_t m = ~((1ull << a.skip) - 1); nl &= m; dm &= m; }          /* (the bytes in front of the stretch: whatever the buffer held) */
 		if(!a.fastq) {
 			/* record starts: the first '>' of a line.  What came last in front of a '>' -- a '\n' (or the beginning of the stretch, which is a record start by
 			 * construction) makes it one, another '>' does not; found inside the word when it holds either, else by walking the text backwards (one step for a '>'
@@ -188,7 +190,7 @@ __global__ void __launch_bounds__(256) mm_text_marks_kernel(ScanArgs a)
 				if(below) { start = (nl >> (63 - __clzll((long long)below))) & 1; }
 				else {
 					start = true;
-					for(int64_t q = (int64_t)w * 64 + b - 1; q >= 0; q--) { const uint8_t c = a.text[q]; if(c == (uint8_t)'\n') { break; } if(c == (uint8_t)'>') { start = false; break; } }
+					for(int64_t q = (int64_t)w * 64 + b - 1; q >= (int64_t)a.skip; q--) { const uint8_t c = a.text[q]; if(c == (uint8_t)'\n') { break; } if(c == (uint8_t)'>') { start = false; break; } }
 				}
 				if(start) { st |= 1ull << b; }
 			}
@@ -1883,7 +1885,13 @@ __global__ void __launch_bounds__(64) mm_spec_jobs_kernel(SpecJobsArgs a)
 	for(uint32_t kq = 0; kq < n_root; kq++) { const uint32_t plen = (uint32_t)OFS((int32_t)root[kq].plen); if(plen * a.mcoef < 2.0 * a.min_score) { break; } cnt++; }
 	if(cnt < a.min_roots) { return; }
 	const unsigned long long off = atomicAdd(&a.job_top[0], (unsigned long long)cnt);
-	if(off + cnt > a.job_cap) { return; }          /* (the count stays above the capacity: the extension kernel clamps it) */
+	if(off + cnt > a.job_cap) {
+		/* no room for this read's jobs: it keeps spec_n = 0 and runs its trials itself.  The count stays above the capacity and the extension kernel clamps it, so the
+		 * slots this read drew below the capacity are claimed there all the same: they are marked empty (r = ~0) -- left unwritten they would hold whatever an earlier
+		 * launch put there */
+		for(unsigned long long q = off; q < a.job_cap; q++) { a.jobs[q] = SpecJob{ 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u, 0u }; a.memo[q].state = 0x80000000u; }
+		return;
+	}
 	uint32_t rlen = st->rlen;
 	for(uint32_t kq = 0; kq < cnt; kq++) {
 		const uint32_t lid = root[kq].lid, rsid = s[lid].upos; const Seed p = s[rsid];
@@ -1983,6 +1991,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			ji = rdfirst64(ji);
 			if(ji >= n_jobs) { break; }
 			const SpecJob j = a.jobs[ji];
+			if((uint32_t)rdfirst((int)j.r) == 0xffffffffu) { continue; }          /* a slot of a read whose jobs did not fit (mm_spec_jobs_kernel) */
 			const uint32_t r = (uint32_t)rdfirst((int)j.r), aid = (uint32_t)rdfirst((int)j.aid), cp_a = (uint32_t)rdfirst((int)j.cp_a), cp_b = (uint32_t)rdfirst((int)j.cp_b);
 			const uint32_t rev = (uint32_t)rdfirst((int)j.rev), rlen = (uint32_t)rdfirst((int)j.rlen); const int rcirc = rdfirst((int)j.rcirc);
 			const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen); const uint64_t q_off = rdfirst64(a.in[r].q_off), roff = rdfirst64(a.idx.seq_off[aid]);

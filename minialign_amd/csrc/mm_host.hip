@@ -622,8 +622,37 @@ struct mm_idx_s {
 	bool on_device = false; int dev = 0; IdxSlot *d_slot = nullptr; uint64_t *d_val = nullptr; uint64_t n_slot = 0, n_val = 0; gaba_arena_t *ref_ar = nullptr;
 	mutable std::mutex fetch_mu;
 	double build_ms[8] = { 0 };          /* device build: arena, sketch, partition, sort, thresholds, table */
-	~mm_idx_s() { if(d_slot) (void)hipFree(d_slot); if(d_val) (void)hipFree(d_val); if(ref_ar) gaba_arena_free(ref_ar); }
+	/* copies of a device-built index on the other devices of the node (one per device, made when a context on that device asks: idx_replica; device to device,
+	 * the host never sees the tables) -- "the minimizer index replicated into each GPU's HBM" of north_star */
+	struct Rep { int dev; IdxSlot *d_slot; uint64_t *d_val; gaba_arena_t *ref_ar; };
+	std::vector<Rep> reps; std::mutex rep_mu;
+	~mm_idx_s()
+	{
+		if(d_slot) (void)hipFree(d_slot); if(d_val) (void)hipFree(d_val); if(ref_ar) gaba_arena_free(ref_ar);
+		for(Rep &r : reps) { if(r.d_slot) (void)hipFree(r.d_slot); if(r.d_val) (void)hipFree(r.d_val); if(r.ref_ar) gaba_arena_free(r.ref_ar); }
+	}
 };
+/* the tables and the packed reference of a device-built index on device `dev` (the current device of the caller): the originals on the device that built them, a
+ * copy anywhere else.  false: out of memory / copy failed */
+static bool idx_replica(const mm_idx_s *cmi, int dev, IdxSlot **slot, uint64_t **val, gaba_arena_t **ar)
+{
+	mm_idx_s *mi = const_cast<mm_idx_s *>(cmi);
+	if(dev == mi->dev) { *slot = mi->d_slot; *val = mi->d_val; *ar = mi->ref_ar; return true; }
+	std::lock_guard<std::mutex> lk(mi->rep_mu);
+	for(const mm_idx_s::Rep &r : mi->reps) if(r.dev == dev) { *slot = r.d_slot; *val = r.d_val; *ar = r.ref_ar; return true; }
+	mm_idx_s::Rep r{ dev, nullptr, nullptr, nullptr };
+	const uint64_t n = mi->ref_ar->n, nw = (n + 15) / 16 + 4, nn = (n + 31) / 32 + 4;
+	gaba_arena_t *q = (gaba_arena_t *)calloc(1, sizeof(gaba_arena_t));
+	bool ok = q != nullptr && hipMalloc(&r.d_slot, mi->n_slot * sizeof(IdxSlot)) == hipSuccess && hipMalloc(&r.d_val, (mi->n_val + 64) * 8) == hipSuccess
+		&& hipMalloc(&q->pk, nw * 4) == hipSuccess && hipMalloc(&q->nm, nn * 4) == hipSuccess;
+	ok = ok && hipMemcpyPeer(r.d_slot, dev, mi->d_slot, mi->dev, mi->n_slot * sizeof(IdxSlot)) == hipSuccess && hipMemcpyPeer(r.d_val, dev, mi->d_val, mi->dev, (mi->n_val + 64) * 8) == hipSuccess
+		&& hipMemcpyPeer(q->pk, dev, mi->ref_ar->pk, mi->dev, nw * 4) == hipSuccess && hipMemcpyPeer(q->nm, dev, mi->ref_ar->nm, mi->dev, nn * 4) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+	if(!ok) { if(r.d_slot) (void)hipFree(r.d_slot); if(r.d_val) (void)hipFree(r.d_val); if(q) { if(q->pk) (void)hipFree(q->pk); if(q->nm) (void)hipFree(q->nm); free(q); } return false; }
+	q->n = n; q->host = NULL; r.ref_ar = q;
+	mi->reps.push_back(r);
+	*slot = r.d_slot; *val = r.d_val; *ar = r.ref_ar;
+	return true;
+}
 /* host copy of a device-built index (for mm_idx_dump / mm_idx_get) */
 static bool idx_fetch_host(const mm_idx_s *cmi)
 {
@@ -648,9 +677,12 @@ struct DevCache {
 		std::lock_guard<std::mutex> lk(mu);
 		auto it = blocks.lower_bound(std::make_pair(dev, want));
 		if(it == blocks.end() || it->first.first != dev || it->first.second > 4 * want + (64u << 20)) return nullptr;
-		void *p = it->second; *got = it->first.second; held -= *got; blocks.erase(it); return p;
+		void *p = it->second; *got = it->first.second; held[dslot(dev)] -= *got; blocks.erase(it); return p;
 	}
-	size_t held = 0;
+	static const int MAX_DEV = 16;
+	static int dslot(int dev) { return dev >= 0 && dev < MAX_DEV ? dev : MAX_DEV - 1; }
+	size_t held[MAX_DEV] = { 0 };          /* bytes waiting here, per device (read and written under mu) */
+	size_t held_on(int dev) { std::lock_guard<std::mutex> lk(mu); return held[dslot(dev)]; }
 	/* what is held is bounded (32 GB): a block that would take it beyond that goes back to the driver after all, as do blocks of more than 16 GB (the DP workspaces of a size that is
 	 * being replaced: nothing is in flight then) -- an ONT-like run that re-sized its workspace ladder a few times had 150 GB of them waiting here and the runtime ran out of memory */
 	void give(int dev, size_t bytes, void *p)
@@ -658,10 +690,11 @@ struct DevCache {
 		/* ... and nothing is kept while the device is short of memory (the runtime allocates the kernels' scratch memory on demand and aborts the process when it cannot).
 		 * `tight` is what the last fresh allocation found: hipMemGetInfo costs about 2 ms, and a stream gives a dozen buffers back when it ends -- asked here, it made every
 		 * stream 20 ms longer, 12 % of one over an E.coli-size set */
-		{ std::lock_guard<std::mutex> lk(mu); if(!tight.load() && bytes <= (16ull << 30) && held + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held += bytes; return; } }
+		{ std::lock_guard<std::mutex> lk(mu); const int d = dslot(dev); if(!tight[d].load() && bytes <= (16ull << 30) && held[d] + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held[d] += bytes; return; } }
 		(void)hipFree(p);
 	}
-	std::atomic<bool> tight{false};
+	std::atomic<bool> tight[MAX_DEV];          /* per device: one device running short of memory does not stop the others from recycling */
+	DevCache() { for(int i = 0; i < MAX_DEV; i++) tight[i].store(false); }
 	static size_t reserve() { return 24ull << 30; }
 	/* may `bytes` more be taken?  Not when less than 8 GB would be left after giving back what is held here: the runtime allocates the scratch memory of a kernel when it is first
 	 * launched on a queue (1.7 GB for the extension kernel) and aborts the process when it cannot -- an allocation that fails cleanly is the better end */
@@ -673,12 +706,15 @@ struct DevCache {
 		return fr >= bytes + (8ull << 30);
 	}
 	/* after a fresh allocation: what is held goes back to the driver when less than the reserve is left */
-	void relieve(int dev) { size_t fr = 0, tot = 0; const bool t = hipMemGetInfo(&fr, &tot) != hipSuccess || fr < reserve(); tight.store(t); if(t && held) flush(dev); }
-	void flush(int dev) { std::lock_guard<std::mutex> lk(mu); for(auto it = blocks.begin(); it != blocks.end();) { if(it->first.first == dev) { (void)hipFree(it->second); held -= it->first.second; it = blocks.erase(it); } else ++it; } }          /* out of memory: everything held goes back to the driver */
+	void relieve(int dev) { size_t fr = 0, tot = 0; const bool t = hipMemGetInfo(&fr, &tot) != hipSuccess || fr < reserve(); tight[dslot(dev)].store(t); if(t && held_on(dev)) flush(dev); }
+	void flush(int dev) { std::lock_guard<std::mutex> lk(mu); for(auto it = blocks.begin(); it != blocks.end();) { if(it->first.first == dev) { (void)hipFree(it->second); held[dslot(dev)] -= it->first.second; it = blocks.erase(it); } else ++it; } }          /* out of memory: everything held goes back to the driver */
 };
 static DevCache &dev_cache() { static DevCache *c = new DevCache(); return *c; }          /* (never destroyed: blocks may come back while the process winds down) */
 template<typename T> struct DBuf {
 	T *p = nullptr; uint64_t n = 0; size_t bytes = 0; int dev = 0;
+	DBuf() {}
+	DBuf(const DBuf &) = delete; DBuf &operator=(const DBuf &) = delete;
+	~DBuf() { release(); }          /* temporaries (index build, reference reader) go back to the cache on every way out of their function */
 	bool ensure(uint64_t want)
 	{
 		if(want <= n) return true;
@@ -1134,6 +1170,9 @@ struct mm_align_s {
 	struct ChunkPool *chunk_pool = nullptr; /* device buffers of the text reader (primary context) */
 	mm_align_s *sib = nullptr;             /* second lane: own streams and pools, shares index / reference / DP constants (see mm_batch_run) */
 	bool is_sib = false; int dev = 0; bool own_index = true;
+	/* the other devices of the node: one primary context each (own streams, lanes, pools, DP workspaces, a replica of the index), owned by the first context.  The
+	 * streaming engine deals its batches over all of them; the per-batch entries stay on the first */
+	std::vector<mm_align_s *> peers;
 	mm_stats_t st; double t_wall0;
 	/* knobs (grown on overflow) */
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
@@ -1142,6 +1181,12 @@ struct mm_align_s {
 	uint32_t k2_leaf_shift = 2;            /* leaf area of the first chaining attempt: (n + 1) >> shift; lowered when more than 2 % of a batch had to be retried */
 };
 
+/* every context that belongs to `a`: its own lanes, then the primaries of the other devices and their lanes */
+template<typename F> static void each_context(mm_align_t *a, F fn)
+{
+	for(mm_align_t *q = a; q; q = q->sib) fn(q);
+	for(mm_align_t *p : a->peers) for(mm_align_t *q = p; q; q = q->sib) fn(q);
+}
 namespace {
 
 
@@ -1412,7 +1457,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* (a wave that has claimed a job takes the workspace for it without waiting, K3_TRY_SLAB, and hands the job back undone when none of its class is free: with fewer
 		 * workspaces than waves, or on the class ladder of a long-tailed set, the waves that hold the workspaces may be the ones that wait for the job) */
 		if(round == 0 && n_heavy > 0 && k3.ring && k3.cls && inkernel && !getenv("MM_K3_NO_JOBS")) {
-			const uint64_t job_cap = 1u << 16, path_cap = 48ull << 20;
+			const uint64_t job_cap = getenv("MM_K3_JOB_CAP") ? (uint64_t)std::max(1, atoi(getenv("MM_K3_JOB_CAP"))) : (1u << 16), path_cap = 48ull << 20;          /* (MM_K3_JOB_CAP: test hook, a launch with more chain jobs than slots) */
 			if(a->spec_jobs.ensure(job_cap) && a->spec_memo.ensure(job_cap) && a->spec_path.ensure(path_cap) && a->spec_seg.ensure(job_cap * 8) && a->spec_top.ensure(8)) {
 				CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
 				SpecJobsArgs sj; sj.idx = a->dix; sj.in = a->d_in.p; sj.st = a->d_st.p; sj.work = a->d_work.p; sj.n_heavy = n_heavy; sj.seed_pool = a->seed_pool.p; sj.root_pool = a->root_pool.p;
@@ -1873,10 +1918,9 @@ static bool make_streams(mm_align_s *a)
 	if(least != greatest) { if(hipStreamCreateWithPriority(&a->k3s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) return false; }
 	return true;
 }
-extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
+/* a primary context on the current device */
+static mm_align_t *align_init_here(mm_opt_t const *o, mm_idx_t const *mi)
 {
-	int ndev = 0;
-	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "[minialign_amd] mm_align_init: no HIP device available (the device stages have no CPU path)\n"); return NULL; }
 	mm_align_t *a = new mm_align_s();
 	a->o = *o; a->mi = mi;
 	a->gctx = gaba_init(&o->p);
@@ -1893,11 +1937,11 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	std::vector<uint64_t> off; std::vector<uint32_t> len;
 	bool ok = true;
 	if(mi->on_device) {
-		/* an index built on this device: the packed reference, the table and the value array are there already */
+		/* an index built on a device: the packed reference, the table and the value array are there already -- on the device that built them; any other gets a copy, once */
 		int cur = 0; (void)hipGetDevice(&cur);
-		if(cur != mi->dev) { fprintf(stderr, "[minialign_amd] mm_align_init: the index was built on device %d, the context is on device %d\n", mi->dev, cur); delete a; return NULL; }
+		if(!idx_replica(mi, cur, &a->d_slot, &a->d_val, &a->ref_ar)) { fprintf(stderr, "[minialign_amd] mm_align_init: the index was built on device %d and could not be copied to device %d\n", mi->dev, cur); a->d_slot = nullptr; a->d_val = nullptr; a->ref_ar = nullptr; a->own_index = false; delete a; return NULL; }
 		uint64_t total = 0; for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back(s.blen()); total += ((uint64_t)s.blen() + 63) & ~63ull; }
-		a->ref_ar = mi->ref_ar; a->d_slot = mi->d_slot; a->d_val = mi->d_val; a->own_index = false;
+		a->own_index = false;
 	} else {
 		a->ref_ar = upload_reference(mi, &off, &len);
 		if(!a->ref_ar) { delete a; return NULL; }
@@ -1927,10 +1971,44 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms();
 	return a;
 }
+/* The devices a context spans.  The reference scales with `-t N` inside one process (source and drain on the main thread, workers between: minialign.c:1013-1048,
+ * 4565-4645, 4729); here the workers are the GPUs of the node: mm_align_init takes every visible device (HIP_VISIBLE_DEVICES picks them; MM_DEVICES=n takes the
+ * first n from the current one on), one primary context and one replica of the index per device, and the streaming engine (stream_map) deals batches to
+ * device x lane.  MM_DEVICE_CONTEXTS=n (test hook for one-GPU boxes): n contexts dealt round robin over the devices taken, several per device. */
+static std::vector<int> context_devices()
+{
+	int ndev = 0, cur = 0; std::vector<int> out;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return out;
+	(void)hipGetDevice(&cur);
+	int take = ndev;
+	if(const char *e = getenv("MM_DEVICES")) take = std::max(1, std::min(ndev, atoi(e)));
+	int n_ctx = take;
+	if(const char *e = getenv("MM_DEVICE_CONTEXTS")) n_ctx = std::max(1, std::min(16, atoi(e)));
+	for(int i = 0; i < n_ctx; i++) out.push_back((cur + i % take) % ndev);
+	return out;
+}
+extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
+{
+	const std::vector<int> devs = context_devices();
+	if(devs.empty()) { fprintf(stderr, "[minialign_amd] mm_align_init: no HIP device available (the device stages have no CPU path)\n"); return NULL; }
+	mm_align_t *a = align_init_here(o, mi);
+	if(!a || devs.size() == 1) return a;
+	/* the other devices side by side (a replica of a human-size index is 20 GB over xGMI) */
+	std::vector<mm_align_t *> pe(devs.size(), nullptr); std::vector<std::thread> th;
+	for(size_t i = 1; i < devs.size(); i++) th.emplace_back([&, i]() { if(hipSetDevice(devs[i]) == hipSuccess) pe[i] = align_init_here(o, mi); });
+	for(auto &t : th) t.join();
+	bool ok = true; for(size_t i = 1; i < devs.size(); i++) ok &= pe[i] != nullptr;
+	if(!ok) { fprintf(stderr, "[minialign_amd] mm_align_init: a context on one of %d devices could not be made\n", (int)devs.size()); for(size_t i = 1; i < devs.size(); i++) if(pe[i]) mm_align_destroy(pe[i]); mm_align_destroy(a); (void)hipSetDevice(devs[0]); return NULL; }
+	for(size_t i = 1; i < devs.size(); i++) a->peers.push_back(pe[i]);
+	(void)hipSetDevice(devs[0]);
+	return a;
+}
+extern "C" int mm_align_devices(mm_align_t const *a) { return 1 + (int)a->peers.size(); }
 static void free_chunk_pool(struct ChunkPool *p);
 extern "C" void mm_align_destroy(mm_align_t *a)
 {
 	if(!a) return;
+	if(!a->peers.empty()) { int cur = 0; (void)hipGetDevice(&cur); for(mm_align_s *p : a->peers) { (void)hipSetDevice(p->dev); mm_align_destroy(p); } a->peers.clear(); (void)hipSetDevice(cur); }
 	if(a->sib) { mm_align_destroy(a->sib); a->sib = nullptr; }
 	for(auto *ps : a->pin_free) delete ps;
 	a->pin_free.clear();
@@ -1961,7 +2039,8 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 	a->st.wall_ms = now_ms() - a->t_wall0;
 	if(out) {
 		*out = a->st;
-		for(mm_align_t *ln = a->sib; ln; ln = ln->sib) {            /* all lanes: counters add up; kernel times add up too (the lanes overlap in wall time) */
+		each_context(a, [&](mm_align_t *ln) {            /* all lanes of all devices: counters add up; kernel times add up too (the lanes overlap in wall time) */
+			if(ln == a) return;
 			const mm_stats_t &q = ln->st;
 			out->k1_ms += q.k1_ms; out->k2_ms += q.k2_ms; out->k3_ms += q.k3_ms; out->k1_launches += q.k1_launches; out->k2_launches += q.k2_launches; out->k3_launches += q.k3_launches;
 			out->reads += q.reads; out->bases += q.bases; out->minimizers += q.minimizers; out->seeds += q.seeds; out->fills += q.fills; out->vectors += q.vectors; out->blocks += q.blocks;
@@ -1969,9 +2048,9 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 			out->k3_cycles_fill += q.k3_cycles_fill; out->k3_cycles_leaf += q.k3_cycles_leaf; out->k3_cycles_trace += q.k3_cycles_trace; out->k3_cycles_total += q.k3_cycles_total;
 			out->k3_cycles_next += q.k3_cycles_next; out->k3_cycles_max += q.k3_cycles_max;             /* summed over launches; k3_waves stays the per-launch count */
 			out->k2_cycles_sort += q.k2_cycles_sort; out->k2_cycles_chain += q.k2_cycles_chain; out->k2_cycles_total += q.k2_cycles_total; out->k2_reads_hbm += q.k2_reads_hbm;
-		}
+		});
 	}
-	if(reset) { memset(&a->st, 0, sizeof(a->st)); a->t_wall0 = now_ms(); for(mm_align_t *ln = a->sib; ln; ln = ln->sib) { memset(&ln->st, 0, sizeof(ln->st)); } }
+	if(reset) { a->t_wall0 = now_ms(); each_context(a, [](mm_align_t *ln) { memset(&ln->st, 0, sizeof(ln->st)); }); }
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -2358,7 +2437,7 @@ extern "C" mm_reg_t const *mm_align_seq(mm_align_t *a, uint32_t l_seq, uint8_t c
 /* the one value reads share (minialign.c:3864): the length of the reference sequence the previous read loaded last.  A caller that splits one
  * read set over several contexts (processes, devices) hands it from the end of one part to the start of the next. */
 extern "C" uint32_t mm_align_get_carry(mm_align_t const *a) { return a->rlen_carry; }
-extern "C" void mm_align_set_carry(mm_align_t *a, uint32_t rlen) { for(mm_align_t *q = a; q; q = q->sib) q->rlen_carry = rlen; }
+extern "C" void mm_align_set_carry(mm_align_t *a, uint32_t rlen) { each_context(a, [rlen](mm_align_t *q) { q->rlen_carry = rlen; }); }
 
 
 /* phase-split entry points over a parsed read set (bench.py times mm_batch_run alone: inputs resident in HBM) */
@@ -2393,7 +2472,7 @@ extern "C" uint64_t mm_reads_bases(mm_reads_t const *r, uint32_t first, uint32_t
  * reference and DP constants shared).  Batches on different lanes overlap on the device: the launch tail and the latency-bound
  * stages of one are filled by the other.  The one piece of state reads share, the carried reference length, is
  * handed from batch to batch by whoever sequences them (align_reads below). */
-struct mm_batch_s { Batch b; mm_align_t *ctx = nullptr; std::thread th; int rc = 0; bool running = false; };
+struct mm_batch_s { Batch b; mm_align_t *ctx = nullptr; std::thread th; int rc = 0; bool running = false; uint32_t k = 0; };          /* k: the batch's number in the order of its stream */
 static mm_align_t *align_lane(mm_align_t *a)
 {
 	if(a->sib) return a->sib;
@@ -2661,89 +2740,111 @@ bool host_find_fastq(const char *t, uint64_t n, bool last, bool keep_qual, std::
 	}
 	return true;
 }
-struct TextReader {
-	ChunkPool *pool = nullptr; int dev = 0; std::shared_ptr<TextSrc> src; uint32_t min_len; bool keep_qual; int lanes;
-	uint64_t chunk_bytes = 256ull << 20;
-	hipStream_t st = nullptr; void *pin[2] = { nullptr, nullptr }; size_t pin_cap = 0; hipEvent_t pev[2] = { nullptr, nullptr };
-	DBuf<uint64_t> d_ma, d_mb; DBuf<uint32_t> d_blk, d_pos, d_cum, d_flag; DBuf<TextRec> d_rec;
-	/* batches cut so far, in order; lanes take them by number */
-	std::mutex mu; std::condition_variable cv; std::deque<mm_batch_t *> ready; uint32_t first_k = 0; bool done = false, failed = false, stop = false;
-	uint64_t max_bases = 300000000ull, cap_bases = 1000000000ull; uint32_t longest = 0;          /* cap_bases: what the device memory allows (batch_cap_bases) */
-	std::thread th;
-	mm_batch_t *cur = nullptr; uint64_t cur_bases = 0;
-	uint64_t n_records = 0, n_host_scanned = 0, n_stretches = 0; double t_io = 0, t_scan = 0;
-
-	~TextReader() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if(th.joinable()) th.join(); for(mm_batch_t *h : ready) delete h; delete cur;
-		if(st) (void)hipStreamDestroy(st); for(int i = 0; i < 2; i++) { if(pin[i]) (void)hipHostFree(pin[i]); if(pev[i]) (void)hipEventDestroy(pev[i]); }
-		d_ma.release(); d_mb.release(); d_blk.release(); d_pos.release(); d_cum.release(); d_flag.release(); d_rec.release(); }
-	void push_batch()
+/* host threads that stay for the life of a reader: a piece of text is copied into a pinned staging buffer by all of them, a slice each (threads made per 32 MB piece
+ * cost more than the copy) */
+struct CopyPool {
+	std::vector<std::thread> th; std::mutex mu; std::condition_variable cv, dcv;
+	const char *src = nullptr; char *dst = nullptr; size_t n = 0; uint64_t gen = 0; uint32_t left = 0, nth = 0; bool stop = false;
+	void start(uint32_t want) { nth = want; for(uint32_t t = 0; t < nth; t++) th.emplace_back([this, t]() { run(t); }); }
+	void run(uint32_t t)
 	{
-		if(!cur) return;
-		mm_batch_t *h = cur; cur = nullptr; cur_bases = 0;
-		std::unique_lock<std::mutex> lk(mu);
-		cv.wait(lk, [&]() { return stop || ready.size() < (size_t)lanes + 2; });          /* not further ahead of the lanes than this */
-		if(stop) { delete h; return; }
-		ready.push_back(h); lk.unlock(); cv.notify_all();
-	}
-	void add(const RRec &r, const std::shared_ptr<DevChunk> &ch)
-	{
-		if(r.n_bases < min_len) return;          /* -L (minialign.c:2077) */
-		if(r.n_bases > longest) { longest = r.n_bases; if(!getenv("MM_BATCH_BASES")) max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(cap_bases, (uint64_t)longest * MM_BATCH_PER_LONGEST)); }
-		if(cur && (cur->b.lens.size() >= (1u << 17) || (cur_bases && cur_bases + r.n_bases > max_bases))) push_batch();
-		if(!cur) { cur = new mm_batch_s(); cur->b.tsrc = src; }
-		Batch &b = cur->b;
-		if(b.dch.empty() || b.dch.back().ch != ch) b.dch.push_back(Batch::Piece{ ch, (uint32_t)b.lens.size(), 0 });
-		b.dch.back().n++; b.lens.push_back(r.n_bases); b.trec.push_back(r); cur_bases += r.n_bases;
-	}
-	bool scan_stretch(uint64_t at, uint64_t len, bool last, DevChunk *c, std::vector<RRec> &recs, uint64_t &consumed, bool &grow)
-	{
-		const bool fastq = src->delim == '@'; grow = false; consumed = 0;
-		const double t0 = now_ms();
-		/* host text -> pinned staging (a few host threads) -> HBM, 32 MB at a time on the reader's stream */
-		const size_t piece = 32u << 20;
-		for(uint64_t o = 0, k = 0; o < len; o += piece, k++) {
-			const size_t nb = (size_t)std::min<uint64_t>(piece, len - o); const int pi = (int)(k & 1);
-			CK(hipEventSynchronize(pev[pi]));
-			const char *sp = src->p + at + o; char *dp = (char *)pin[pi];
-			host_parallel(24, [&](uint32_t t, uint32_t nth) { const size_t lo = nb * t / nth, hi = nb * (t + 1) / nth; memcpy(dp + lo, sp + lo, hi - lo); }, 24);
-			CK(hipMemcpyAsync(c->d + o, pin[pi], nb, hipMemcpyHostToDevice, st));
-			CK(hipEventRecord(pev[pi], st));
+		uint64_t seen = 0;
+		while(true) {
+			std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || gen != seen; }); if(stop) return;
+			seen = gen; const char *sp = src; char *dp = dst; const size_t bytes = n; lk.unlock();
+			const size_t lo = (bytes * t / nth) & ~(size_t)63, hi = t + 1 == nth ? bytes : ((bytes * (t + 1) / nth) & ~(size_t)63);
+			if(hi > lo) memcpy(dp + lo, sp + lo, hi - lo);
+			lk.lock(); if(--left == 0) dcv.notify_all();
 		}
-		const uint32_t n = (uint32_t)len, n_words = (n + 63) / 64, n_blk = (n_words + 255) / 256;
+	}
+	void copy(char *d, const char *sp, size_t bytes)
+	{
+		if(nth == 0 || bytes < (1u << 20)) { memcpy(d, sp, bytes); return; }
+		std::unique_lock<std::mutex> lk(mu); src = sp; dst = d; n = bytes; left = nth; gen++; cv.notify_all();
+		dcv.wait(lk, [&]() { return left == 0; });
+	}
+	~CopyPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for(auto &t : th) t.join(); }
+};
+/* the reader's side of ONE device: the way of the text into its HBM (pinned staging ring + copy threads + an upload stream) and the record scan of a stretch there */
+struct ReaderDev {
+	int dev = 0; ChunkPool *pool = nullptr; bool fastq = false, keep_qual = false;
+	hipStream_t st = nullptr, up = nullptr;          /* scan stream; upload stream */
+	static const int RING = 4; void *pin[RING] = { nullptr, nullptr, nullptr, nullptr }; hipEvent_t pev[RING] = { nullptr, nullptr, nullptr, nullptr }; size_t pin_cap = 32u << 20; uint64_t pin_k = 0;
+	CopyPool cp;
+	DBuf<uint64_t> d_ma, d_mb; DBuf<uint32_t> d_blk, d_pos, d_cum, d_flag; DBuf<TextRec> d_rec;
+	uint64_t chunk_bytes = 256ull << 20;          /* what the scan's scratch arrays are sized for from the start */
+	uint64_t n_host_scanned = 0, bytes_up = 0; double t_io = 0, t_scan = 0;
+	~ReaderDev()
+	{
+		if(st || up) (void)hipSetDevice(dev);
+		if(st) (void)hipStreamDestroy(st); if(up) (void)hipStreamDestroy(up);
+		for(int i = 0; i < RING; i++) { if(pin[i]) (void)hipHostFree(pin[i]); if(pev[i]) (void)hipEventDestroy(pev[i]); }
+		d_ma.release(); d_mb.release(); d_blk.release(); d_pos.release(); d_cum.release(); d_flag.release(); d_rec.release();
+	}
+	/* streams, staging ring, copy threads; the calling thread is on the device */
+	bool init(uint32_t copy_threads)
+	{
+		if(hipGetDevice(&dev) != hipSuccess) return false;
+		if(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) return false;
+		for(int i = 0; i < RING; i++) { if(hipHostMalloc(&pin[i], pin_cap, hipHostMallocPortable) != hipSuccess || hipEventCreateWithFlags(&pev[i], hipEventDisableTiming) != hipSuccess) return false; }
+		cp.start(copy_threads);
+		return true;
+	}
+	/* host text -> pinned staging (the copy threads) -> HBM, 32 MB at a time on stream q; returns when the last piece has been queued (the caller waits for q) */
+	std::mutex up_mu;          /* (the uploader thread and the scan's slow way share the ring) */
+	bool upload(uint8_t *dst, const char *sp, uint64_t len, hipStream_t q)
+	{
+		const double t0 = now_ms();
+		for(uint64_t o = 0; o < len; o += pin_cap) {
+			std::lock_guard<std::mutex> lk(up_mu);
+			const size_t nb = (size_t)std::min<uint64_t>(pin_cap, len - o); const int pi = (int)(pin_k++ % RING);
+			CK(hipEventSynchronize(pev[pi]));
+			cp.copy((char *)pin[pi], sp + o, nb);
+			CK(hipMemcpyAsync(dst + o, pin[pi], nb, hipMemcpyHostToDevice, q));
+			CK(hipEventRecord(pev[pi], q));
+		}
+		bytes_up += len; t_io += now_ms() - t0;
+		return true;
+	}
+	/* records of the stretch text[at, at + len) (host copy: tx), which stands in HBM at base + skip (base 64-byte aligned, skip < 64).  Offsets come back absolute;
+	 * consumed: bytes of the stretch up to where the next one starts (all of them at the end of the text); grow: not one complete record in it */
+	bool scan(const char *tx, const uint8_t *base, uint32_t skip, uint64_t at, uint64_t len, bool last, std::vector<RRec> &recs, uint64_t &consumed, bool &grow)
+	{
+		grow = false; consumed = 0; recs.clear();
+		const double t1 = now_ms();
+		const uint32_t n = (uint32_t)(len + skip), n_words = (n + 63) / 64, n_blk = (n_words + 255) / 256;
 		/* the scratch arrays are sized for a whole stretch from the start: a buffer that grows in mid-run costs a hipFree, which waits for every stream of the device */
-		const uint64_t cap_n = std::max<uint64_t>(len, chunk_bytes), cap_words = (cap_n + 63) / 64, cap_blk = (cap_words + 255) / 256;
+		const uint64_t cap_n = std::max<uint64_t>(len + 64, chunk_bytes + 64), cap_words = (cap_n + 63) / 64, cap_blk = (cap_words + 255) / 256;
 		const uint32_t pos_cap = (uint32_t)(cap_n / 8 + 1024);
 		if(!d_ma.ensure(cap_words) || !d_mb.ensure(cap_words) || !d_cum.ensure(cap_words) || !d_blk.ensure(2 * cap_blk + 2) || !d_pos.ensure(pos_cap) || !d_flag.ensure(4)) return false;
 		ScanArgs sa; memset(&sa, 0, sizeof(sa));
-		sa.text = c->d; sa.n = n; sa.fastq = fastq ? 1u : 0u; sa.ma = d_ma.p; sa.mb = d_mb.p; sa.blk = d_blk.p; sa.n_blk = n_blk; sa.pos = d_pos.p; sa.pos_cap = pos_cap; sa.cum = d_cum.p;
+		sa.text = base; sa.n = n; sa.skip = skip; sa.fastq = fastq ? 1u : 0u; sa.ma = d_ma.p; sa.mb = d_mb.p; sa.blk = d_blk.p; sa.n_blk = n_blk; sa.pos = d_pos.p; sa.pos_cap = pos_cap; sa.cum = d_cum.p;
 		sa.last = last ? 1u : 0u; sa.keep_qual = keep_qual ? 1u : 0u; sa.flag = d_flag.p;
 		CK(hipMemsetAsync(d_flag.p, 0, 16, st));
-		if(fastq) { CK(hipMemsetAsync(d_pos.p, 0, 4, st)); }          /* the first line starts at 0 */
+		if(fastq) { CK(hipMemcpyAsync(d_pos.p, &skip, 4, hipMemcpyHostToDevice, st)); CK(hipStreamSynchronize(st)); }          /* the first line starts where the stretch starts */
 		hipLaunchKernelGGL(mm_text_marks_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
 		hipLaunchKernelGGL(mm_text_blocks_kernel, dim3(1), dim3(256), 0, st, sa); CK(hipGetLastError());
 		hipLaunchKernelGGL(mm_text_emit_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
 		uint32_t tot[2], flag[4];
 		CK(hipMemcpyAsync(tot, d_blk.p + 2 * (uint64_t)n_blk, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(flag, d_flag.p, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-		t_io += now_ms() - t0; const double t1 = now_ms();
-		const char *tx = src->p + at;
 		bool on_host = fastq && (flag[1] != 0 || getenv("MM_HOST_SCAN") != NULL);
 		uint32_t n_rec = 0;
 		if(!fastq) {
-			if(flag[1]) { fprintf(stderr, "[minialign_amd] reader: more record starts than one per 8 bytes in a stretch of `%c' records\n", src->delim); return false; }
+			if(flag[1]) { fprintf(stderr, "[minialign_amd] reader: more record starts than one per 8 bytes in a stretch of `>' records\n"); return false; }
 			const uint32_t n_starts = tot[1];
 			n_rec = last ? n_starts : (n_starts ? n_starts - 1 : 0);
-			if(!last && n_rec == 0) { grow = true; return true; }
-			if(!last) { uint32_t q = 0; CK(hipMemcpyAsync(&q, d_pos.p + (n_starts - 1), 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); consumed = q; } else consumed = len;
+			if(!last && n_rec == 0) { grow = true; t_scan += now_ms() - t1; return true; }
+			if(!last) { uint32_t q = 0; CK(hipMemcpyAsync(&q, d_pos.p + (n_starts - 1), 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); consumed = q - skip; } else consumed = len;
 		} else if(!on_host) {
 			/* complete lines; at the end of the text a last line without '\n' counts, and lines left over behind the last record must be empty (the reference skips them) */
 			uint64_t lines = tot[0] + ((last && len > 0 && tx[len - 1] != '\n') ? 1u : 0u);
 			n_rec = (uint32_t)(lines / 4);
-			if(!last && n_rec == 0) { grow = true; return true; }
-			if(!last) { uint32_t q = 0; CK(hipMemcpyAsync(&q, d_pos.p + 4 * (uint64_t)n_rec, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); consumed = q; }
+			if(!last && n_rec == 0) { grow = true; t_scan += now_ms() - t1; return true; }
+			if(!last) { uint32_t q = 0; CK(hipMemcpyAsync(&q, d_pos.p + 4 * (uint64_t)n_rec, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); consumed = q - skip; }
 			else {
 				consumed = len;
-				if(lines % 4) { std::vector<uint32_t> ls(lines % 4 + 1, (uint32_t)len); CK(hipMemcpyAsync(ls.data(), d_pos.p + 4 * (uint64_t)n_rec, (lines % 4) * 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-					for(uint32_t q = ls[0]; q < len; q++) if(tx[q] != '\n') { on_host = true; break; } }
+				if(lines % 4) { std::vector<uint32_t> ls(lines % 4 + 1, (uint32_t)(len + skip)); CK(hipMemcpyAsync(ls.data(), d_pos.p + 4 * (uint64_t)n_rec, (lines % 4) * 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+					for(uint64_t q = ls[0] - skip; q < len; q++) if(tx[q] != '\n') { on_host = true; break; } }
 			}
 		}
 		if(!on_host && n_rec) {
@@ -2754,72 +2855,196 @@ struct TextReader {
 			std::vector<TextRec> tr(n_rec);
 			CK(hipMemcpyAsync(tr.data(), d_rec.p, (size_t)n_rec * sizeof(TextRec), hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(flag, d_flag.p, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
 			if(fastq && flag[0]) on_host = true;
-			else { recs.resize(n_rec); for(uint32_t i = 0; i < n_rec; i++) { const TextRec &q = tr[i]; recs[i] = RRec{ at + q.start, at + q.hdr_end, at + q.t_off, q.t_len, q.n_bases, at + q.q_off, q.q_len }; } }
+			else { const uint64_t o = at - skip; recs.resize(n_rec); for(uint32_t i = 0; i < n_rec; i++) { const TextRec &q = tr[i]; recs[i] = RRec{ o + q.start, o + q.hdr_end, o + q.t_off, q.t_len, q.n_bases, o + q.q_off, q.q_len }; } }
 		}
 		if(on_host) {
 			/* a FASTQ stretch in another shape than four lines per record: the sequential reader, over the host's copy of the same bytes */
 			recs.clear(); uint64_t used = 0;
 			if(!host_find_fastq(tx, len, last, keep_qual, recs, used)) { fprintf(stderr, "[minialign_amd] broken FASTQ record\n"); return false; }          /* the reference gives up on the run (exit 1) */
-			if(!last && recs.empty()) { grow = true; return true; }
+			if(!last && recs.empty()) { grow = true; t_scan += now_ms() - t1; return true; }
 			for(RRec &q : recs) { q.start += at; q.hdr_end += at; q.t_off += at; q.q_off += at; }
 			consumed = last ? len : used; n_host_scanned += recs.size();
 		}
 		t_scan += now_ms() - t1;
 		return true;
 	}
+};
+/* The reader of a query text over the devices of a context.  The text is cut into PIECES at fixed byte offsets (the first ones 64 MB, then 256 MB; piece s goes to device
+ * s mod N), so every device's uploader thread brings its pieces to HBM without waiting for anybody -- record boundaries are found afterwards, by the scan, in order:
+ * the stretch that piece s closes starts where the scan of the stretch before it stopped (the record that was cut by the boundary), and those few bytes -- the tail
+ * of piece s - 1 -- are put in FRONT of piece s in its buffer (every buffer keeps `prefix` bytes of room there), so that the stretch is contiguous in the HBM of the
+ * device that scans and packs it.  The sequential part of the reader is thereby the scan alone (four short launches and a few words of D2H per stretch); the uploads
+ * run side by side, one PCIe link each.  A record longer than the room in front (or than a piece) takes the slow way: its stretch goes up again as a whole.
+ * Batches are cut from the records as before; with several devices a batch never holds reads of two stretches on different devices. */
+struct TextReader {
+	std::shared_ptr<TextSrc> src; uint32_t min_len = 1; bool keep_qual = false; int lanes = 4;
+	std::vector<mm_align_t *> dctx;          /* the device slots of the engine: one primary context each (set by the caller) */
+	std::vector<ReaderDev *> rdev;
+	uint64_t chunk_bytes = 256ull << 20, prefix = 1ull << 20;
+	std::vector<uint64_t> B;          /* piece s = text[B[s], B[s + 1]) */
+	struct PieceSt { DevChunk *c = nullptr; int state = 0; };          /* 0 untouched, 1 in HBM, 2 failed, 3 not wanted (its stretch went the slow way), 4 on its way */
+	std::vector<PieceSt> pieces;
+	std::mutex mu; std::condition_variable cv;
+	uint32_t scanned = 0;          /* pieces the scan is done with: the uploaders stay at most `ahead` pieces per device in front of it */
+	static const uint32_t ahead = 2;
+	std::vector<std::deque<mm_batch_t *>> ready; uint32_t n_cut = 0; bool done = false, failed = false, stop = false;
+	uint64_t max_bases = 300000000ull, cap_bases = 1000000000ull; uint32_t longest = 0;          /* cap_bases: what the device memory allows (batch_cap_bases) */
+	std::vector<std::thread> th;
+	mm_batch_t *cur = nullptr; uint64_t cur_bases = 0; int cur_slot = 0;
+	uint64_t n_records = 0, n_host_scanned = 0, n_stretches = 0, n_slow = 0; double t_start = 0;
+
+	~TextReader()
+	{
+		{ std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all();
+		for(auto &t : th) if(t.joinable()) t.join();
+		for(auto &q : ready) for(mm_batch_t *h : q) delete h;
+		delete cur;
+		for(size_t i = 0; i < pieces.size(); i++) if(pieces[i].c) { rdev[i % rdev.size()]->pool->put(pieces[i].c); pieces[i].c = nullptr; }
+		for(ReaderDev *r : rdev) delete r;
+	}
+	void push_batch()
+	{
+		if(!cur) return;
+		mm_batch_t *h = cur; cur = nullptr; cur_bases = 0;
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait(lk, [&]() { return stop || ready[cur_slot].size() < (size_t)lanes + 2; });          /* not further ahead of the lanes of that device than this */
+		if(stop) { delete h; return; }
+		h->k = n_cut++; ready[cur_slot].push_back(h); lk.unlock(); cv.notify_all();
+	}
+	void add(const RRec &r, const std::shared_ptr<DevChunk> &ch, int slot)
+	{
+		if(r.n_bases < min_len) return;          /* -L (minialign.c:2077) */
+		if(r.n_bases > longest) { longest = r.n_bases; if(!getenv("MM_BATCH_BASES")) max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(cap_bases, (uint64_t)longest * MM_BATCH_PER_LONGEST)); }
+		if(cur && (slot != cur_slot || cur->b.lens.size() >= (1u << 17) || (cur_bases && cur_bases + r.n_bases > max_bases))) push_batch();
+		if(!cur) { cur = new mm_batch_s(); cur->b.tsrc = src; cur_slot = slot; }
+		Batch &b = cur->b;
+		if(b.dch.empty() || b.dch.back().ch != ch) b.dch.push_back(Batch::Piece{ ch, (uint32_t)b.lens.size(), 0 });
+		b.dch.back().n++; b.lens.push_back(r.n_bases); b.trec.push_back(r); cur_bases += r.n_bases;
+	}
+	/* the uploader of device slot di: its pieces in order, each into a buffer with `prefix` bytes of room in front */
+	void upload_main(int di)
+	{
+		ReaderDev *R = rdev[di]; const uint32_t nd = (uint32_t)rdev.size();
+		bool ok = hipSetDevice(R->dev) == hipSuccess;
+		for(uint32_t s = (uint32_t)di; s + 1 < B.size(); s += nd) {
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&]() { return stop || s < scanned + ahead * nd; });
+				if(stop) return;
+				if(pieces[s].state == 3) continue;
+				pieces[s].state = 4;
+			}
+			const uint64_t len = B[s + 1] - B[s];
+			DevChunk *c = ok ? R->pool->get(prefix + std::max<uint64_t>(chunk_bytes, (len + 63) & ~63ull) + 128) : nullptr;
+			bool up = c != nullptr;
+			if(up) { c->off = B[s] - prefix; c->n = 0; up = R->upload(c->d + prefix, src->p + B[s], len, R->up) && hipStreamSynchronize(R->up) == hipSuccess; }
+			{ std::lock_guard<std::mutex> lk(mu); pieces[s].c = c; pieces[s].state = up ? 1 : 2; }
+			cv.notify_all();
+		}
+	}
+	/* waits for piece s to be in HBM (or settled otherwise); its state */
+	int piece_wait(uint32_t s) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || (pieces[s].state != 0 && pieces[s].state != 4); }); return stop ? 2 : pieces[s].state; }
 	void run()
 	{
-		bool ok = hipSetDevice(dev) == hipSuccess;
-		/* (the first stretches are short, so that the first lanes have a batch to work on as early as possible) */
-		uint64_t at = src->first, want = std::min<uint64_t>(chunk_bytes, 64ull << 20);
-		while(ok && at < src->n) {
+		const uint32_t nd = (uint32_t)rdev.size(), n_pieces = (uint32_t)B.size() - 1;
+		bool ok = true; uint64_t at = src->first; uint32_t s = 0;
+		while(ok && at < src->n && s < n_pieces) {
 			{ std::lock_guard<std::mutex> lk(mu); if(stop) break; }
-			const uint64_t len = std::min<uint64_t>(want, src->n - at); const bool last = at + len == src->n;
-			if(len > 0x7fff0000ull) { fprintf(stderr, "[minialign_amd] reader: a record of more than 2 GB\n"); ok = false; break; }
-			DevChunk *c = pool->get(std::max<uint64_t>(chunk_bytes, (len + 63) & ~63ull) + 64);
-			if(!c) { ok = false; break; }
-			c->off = at; c->n = (uint32_t)len;
-			ChunkPool *pl = pool; std::shared_ptr<DevChunk> ch(c, [pl](DevChunk *q) { pl->put(q); });
-			std::vector<RRec> recs; uint64_t consumed = 0; bool grow = false;
-			if(!scan_stretch(at, len, last, c, recs, consumed, grow)) { ok = false; break; }
-			if(grow) { want *= 2; continue; }          /* a record longer than the stretch */
+			uint32_t e = s + 1, span = 1; int slot = 0;
+			std::vector<RRec> recs; uint64_t consumed = 0; std::shared_ptr<DevChunk> ch;
+			while(ok) {
+				const uint64_t end = B[e], len = end - at; const bool last = end == src->n; bool grow = false;
+				if(len + 64 > 0x7fff0000ull) { fprintf(stderr, "[minialign_amd] reader: a record of more than 2 GB\n"); ok = false; break; }
+				if(e == s + 1 && B[s] - at <= prefix) {
+					/* the common way: piece s is (being) brought up by its device's uploader; the bytes of the record its boundary cut go in front of it */
+					slot = (int)(s % nd); ReaderDev *R = rdev[slot];
+					if(piece_wait(s) != 1 || hipSetDevice(R->dev) != hipSuccess) { ok = false; break; }
+					DevChunk *c = pieces[s].c; const uint64_t tail = B[s] - at;
+					if(tail && (hipMemcpyAsync(c->d + prefix - tail, src->p + at, tail, hipMemcpyHostToDevice, R->st) != hipSuccess || hipStreamSynchronize(R->st) != hipSuccess)) { ok = false; break; }
+					const uint64_t o = prefix - tail;
+					ok = R->scan(src->p + at, c->d + (o & ~63ull), (uint32_t)(o & 63), at, len, last, recs, consumed, grow);
+					if(ok && !grow) { pieces[s].c = nullptr; ChunkPool *pl = R->pool; ch = std::shared_ptr<DevChunk>(c, [pl](DevChunk *q) { pl->put(q); }); }
+				} else {
+					/* the slow way (a record longer than the room in front of a piece, or than a piece): what the uploaders brought or will bring of pieces s .. e - 1 is not
+					 * wanted, the stretch goes up as a whole on the device of its last piece */
+					for(uint32_t j = s; j < e; j++) {
+						{ std::lock_guard<std::mutex> lk(mu); if(pieces[j].state == 0) { pieces[j].state = 3; continue; } if(pieces[j].state == 3) continue; }
+						(void)piece_wait(j);
+						if(pieces[j].c) { rdev[j % nd]->pool->put(pieces[j].c); pieces[j].c = nullptr; }
+					}
+					slot = (int)((e - 1) % nd); ReaderDev *R = rdev[slot]; n_slow++;
+					if(hipSetDevice(R->dev) != hipSuccess) { ok = false; break; }
+					DevChunk *c = R->pool->get(((len + 63) & ~63ull) + 128);
+					if(!c) { ok = false; break; }
+					c->off = at; c->n = 0;
+					ok = R->upload(c->d, src->p + at, len, R->st) && hipStreamSynchronize(R->st) == hipSuccess && R->scan(src->p + at, c->d, 0, at, len, last, recs, consumed, grow);
+					if(ok && !grow) { ChunkPool *pl = R->pool; ch = std::shared_ptr<DevChunk>(c, [pl](DevChunk *q) { pl->put(q); }); } else { R->pool->put(c); }
+				}
+				if(!ok || !grow) break;
+				if(e == n_pieces) { ok = false; break; }          /* (cannot happen: the stretch that ends the text is complete by definition) */
+				e = std::min<uint32_t>(n_pieces, e + span); span *= 2;          /* a record longer than the stretch: more pieces */
+			}
+			if(!ok) break;
 			n_stretches++; n_records += recs.size();
-			for(const RRec &r : recs) add(r, ch);
-			at += consumed; want = n_stretches < 3 ? std::min<uint64_t>(chunk_bytes, 64ull << 20) : chunk_bytes;
+			for(const RRec &r : recs) add(r, ch, slot);
 			if(consumed == 0) { ok = false; break; }
+			at += consumed; s = e;
+			{ std::lock_guard<std::mutex> lk(mu); scanned = s; } cv.notify_all();
+			if(nd > 1) push_batch();          /* several devices: the next stretch is another device's */
 		}
 		if(ok) push_batch();
 		{ std::lock_guard<std::mutex> lk(mu); done = true; failed = !ok; }
 		cv.notify_all();
-		if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd] reader: %lu records in %lu stretches (%lu through the host's sequential FASTQ reader), text to HBM + marks %.1f ms, record tables %.1f ms\n",
-			(unsigned long)n_records, (unsigned long)n_stretches, (unsigned long)n_host_scanned, t_io, t_scan);
-	}
-	/* stream, staging buffers (no thread): scan_stretch can be called after this */
-	bool init()
-	{
-		if(const char *e = getenv("MM_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) & ~63ull;          /* test hook: small stretches */
-		pin_cap = 32u << 20;
-		if(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
-		for(int i = 0; i < 2; i++) { if(hipHostMalloc(&pin[i], pin_cap, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&pev[i], hipEventDisableTiming) != hipSuccess) return false; }
-		return true;
+		for(ReaderDev *R : rdev) n_host_scanned += R->n_host_scanned;
+		if(getenv("MM_VERBOSE")) {
+			double io = 0, sc = 0; uint64_t up = 0; for(ReaderDev *R : rdev) { io += R->t_io; sc += R->t_scan; up += R->bytes_up; }
+			fprintf(stderr, "[minialign_amd] reader: %lu records in %lu stretches on %u device(s) (%lu the slow way; %lu records through the host's sequential FASTQ reader), %.2f GB of text to HBM in %.1f ms of uploader time (%.1f GB/s per uploader), scans %.1f ms, done %.1f ms after the start\n",
+				(unsigned long)n_records, (unsigned long)n_stretches, nd, (unsigned long)n_slow, (unsigned long)n_host_scanned, up * 1e-9, io, io > 0 ? up * 1e-6 / io : 0.0, sc, now_ms() - t_start);
+		}
 	}
 	bool start()
 	{
-		if(!init()) return false;
-		/* batch size as batch_spans: 300 Mb; a text smaller than lanes x that is cut into one batch per lane (its bases are a little fewer than its bytes) */
+		if(dctx.empty()) return false;
+		if(const char *e = getenv("MM_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) & ~63ull;          /* test hook: small stretches */
+		prefix = std::min<uint64_t>(1ull << 20, chunk_bytes);
+		if(const char *e = getenv("MM_CHUNK_PREFIX")) prefix = std::max<uint64_t>(64, (uint64_t)atoll(e)) & ~63ull;          /* test hook: the slow way for records longer than this */
+		const uint32_t nd = (uint32_t)dctx.size();
+		/* copy threads per device: the staging copy wants a handful of cores (a core copies 5 - 10 GB/s; PCIe takes 50) */
+		const uint32_t hw = std::max<uint32_t>(1, std::thread::hardware_concurrency());
+		const uint32_t cpt = getenv("MM_COPY_THREADS") ? (uint32_t)std::max(0, atoi(getenv("MM_COPY_THREADS"))) : std::max<uint32_t>(2, std::min<uint32_t>(12, hw / (4 * nd)));
+		int cur_dev = 0; (void)hipGetDevice(&cur_dev);
+		for(uint32_t d = 0; d < nd; d++) {
+			mm_align_t *P = dctx[d];
+			if(!P->chunk_pool) P->chunk_pool = new ChunkPool();
+			ReaderDev *R = new ReaderDev(); rdev.push_back(R);
+			R->pool = P->chunk_pool; R->fastq = src->delim == '@'; R->keep_qual = keep_qual; R->chunk_bytes = chunk_bytes + prefix;
+			if(hipSetDevice(P->dev) != hipSuccess || !R->init(cpt)) { (void)hipSetDevice(cur_dev); return false; }
+		}
+		(void)hipSetDevice(cur_dev);
+		ready.resize(nd);
+		/* batch size as batch_spans: 300 Mb; a text smaller than lanes x that (per device) is cut into one and a half batches per lane (its bases are a little fewer than its bytes) */
+		const uint64_t all_lanes = (uint64_t)lanes * nd;
 		if(getenv("MM_BATCH_BASES")) max_bases = (uint64_t)atoll(getenv("MM_BATCH_BASES"));
-		else if(src->n < (uint64_t)lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, src->n / ((uint64_t)lanes + (uint64_t)lanes / 2) + (1ull << 20));          /* (one and a half batches per lane: an eighth of the headline set maps in 313 ms in six batches, 366 in four) */
-		th = std::thread([this]() { run(); });
+		else if(src->n < all_lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, src->n / (all_lanes + all_lanes / 2) + (1ull << 20));          /* (an eighth of the headline set maps in 313 ms in six batches, 366 in four) */
+		/* pieces: the first three per device short (64 MB), so that the first lanes have a batch to work on early; several devices: no longer than a batch */
+		uint64_t first_len = std::min<uint64_t>(chunk_bytes, 64ull << 20), later_len = chunk_bytes;
+		if(nd > 1 && !getenv("MM_CHUNK_BYTES")) { later_len = std::min<uint64_t>(later_len, std::max<uint64_t>(1ull << 20, max_bases)); first_len = std::min(first_len, later_len); }
+		B.push_back(src->first);
+		while(B.back() < src->n) { const uint64_t ln = (B.size() - 1 < 3ull * nd) ? first_len : later_len; B.push_back(std::min<uint64_t>(src->n, B.back() + ln)); }
+		pieces.assign(B.size() - 1, PieceSt());
+		t_start = now_ms();
+		for(uint32_t d = 0; d < nd; d++) th.emplace_back([this, d]() { upload_main((int)d); });
+		th.emplace_back([this]() { run(); });
 		return true;
 	}
-	/* batch k (lanes ask in order); NULL when the text has no batch k, *err when the reader failed */
-	mm_batch_t *take(uint32_t k, bool *err)
+	/* the next batch of device slot di (lanes of a device ask in order); its number in the order of the text in h->k; NULL when the text has no more for this device,
+	 * *err when the reader failed */
+	mm_batch_t *take(int di, bool *err)
 	{
 		std::unique_lock<std::mutex> lk(mu);
-		cv.wait(lk, [&]() { return done || first_k + ready.size() > k; });
-		if(first_k + ready.size() <= k) { if(failed && err) *err = true; return nullptr; }
-		/* lanes take batches strictly in order of k */
-		mm_batch_t *h = ready.front(); ready.pop_front(); first_k++;
+		cv.wait(lk, [&]() { return done || !ready[di].empty(); });
+		if(ready[di].empty()) { if(failed && err) *err = true; return nullptr; }
+		mm_batch_t *h = ready[di].front(); ready[di].pop_front();
 		lk.unlock(); cv.notify_all();
 		batch_pack(h->b, false);
 		return h;
@@ -2833,9 +3058,9 @@ static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::
 {
 	std::shared_ptr<TextSrc> src = open_text(fn);
 	if(!src) return false;
-	ChunkPool pool; TextReader rd; rd.pool = &pool; rd.dev = mi->dev; rd.src = src; rd.min_len = o->min_len; rd.keep_qual = false; rd.lanes = 1;
+	ChunkPool pool; ReaderDev rd; rd.pool = &pool; rd.fastq = src->delim == '@'; rd.keep_qual = false;
 	rd.chunk_bytes = 1ull << 30;
-	if(!rd.init()) return false;
+	if(!rd.init(std::max<uint32_t>(2, std::min<uint32_t>(12, std::thread::hardware_concurrency() / 4)))) return false;
 	DBuf<uint8_t> d_codes; DBuf<TextRead> d_ti; DBuf<uint32_t> d_tn, d_tb;
 	const uint64_t codes_cap = src->n + (256ull << 20);          /* bases + what the alignment of the sequences to 64 adds (room for four million sequences) */
 	if(!d_codes.ensure(codes_cap) || hipMemsetAsync(d_codes.p, 4, codes_cap, rd.st) != hipSuccess) return false;
@@ -2847,7 +3072,7 @@ static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::
 		if(!c) { ok = false; break; }
 		c->off = at; c->n = (uint32_t)ln;
 		std::vector<RRec> recs; uint64_t consumed = 0; bool grow = false;
-		ok = rd.scan_stretch(at, ln, last, c, recs, consumed, grow);
+		ok = rd.upload(c->d, src->p + at, ln, rd.st) && hipStreamSynchronize(rd.st) == hipSuccess && rd.scan(src->p + at, c->d, 0, at, ln, last, recs, consumed, grow);
 		if(ok && grow) { pool.put(c); want = std::min<uint64_t>(want * 2, 0x7fff0000ull); if(ln == 0x7fff0000ull) ok = false; continue; }
 		if(ok) {
 			std::vector<TextRead> tr;
@@ -2892,76 +3117,112 @@ static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::
 	return true;
 }
 typedef std::function<bool(uint32_t, std::vector<std::string> &)> PieceSink;          /* (batch, pieces) in batch order; false = stop */
-/* n_batches = MM_OPEN_ENDED: as many as make() gives (it returns NULL behind the last one; lanes ask strictly in order of k) */
+/* where the lanes get their batches: take(device slot) hands out the next batch for a lane of that device with its number in the order of the stream (h->k; the numbers
+ * of a stream are 0, 1, 2 ... without gaps, the lanes of one device get theirs in rising order), NULL when there is nothing more for that device.  A source over host
+ * data (packed or parsed reads) gives any batch to any device; the text reader gives a device the batches whose text is in its HBM. */
+typedef std::function<mm_batch_t *(int)> BatchSource;
+static BatchSource counted_source(uint32_t n_batches, const std::function<mm_batch_t *(uint32_t)> &make)
+{
+	auto st = std::make_shared<std::pair<std::mutex, uint32_t>>(); st->second = 0;
+	return [st, n_batches, make](int) -> mm_batch_t * {
+		std::lock_guard<std::mutex> lk(st->first);
+		if(st->second >= n_batches) return nullptr;
+		const uint32_t k = st->second++; mm_batch_t *h = make(k); if(h) h->k = k;
+		return h;
+	};
+}
+/* the primary contexts of the devices `a` spans, in slot order */
+static std::vector<mm_align_t *> device_slots(mm_align_t *a) { std::vector<mm_align_t *> v; v.push_back(a); for(mm_align_t *p : a->peers) v.push_back(p); return v; }
+/* n_batches: how many the source holds when that is known (the lanes made are no more than that), 0xffffffff otherwise */
 #define MM_OPEN_ENDED 0xffffffffu
-static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_batch_t *(uint32_t)> &make, const std::function<void(mm_batch_t *)> &release,
+static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &source, const std::function<void(mm_batch_t *)> &release,
 	const PieceSink &sink, int lanes_want)
 {
 	if(n_batches == 0) { a->head.clear(); a->head_off.assign(1, 0); a->head_off_closed = false; a->head_carry_in = a->rlen_carry; return 0; }
 	const bool verbose = getenv("MM_VERBOSE") != NULL;
-	const int lanes = (int)std::max<uint32_t>(1, std::min<uint32_t>({ (uint32_t)lanes_want, n_batches, 8u }));
-	std::vector<mm_align_t *> ctx; { mm_align_t *q = a; for(int i = 0; i < lanes && q; i++) { ctx.push_back(q); if(i + 1 < lanes) q = align_lane(q); } }
-	if((int)ctx.size() < lanes || !ctx.back()) return 1;
-	if(!getenv("MM_NO_SHARED_SLABS") && !ensure_shared_slabs(a, a->qlen_hint)) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); return 1; }
-	/* host threads for post-map + text: -t when given, MM_HOST_THREADS, else up to 96; two finishers share them */
+	/* device slots: every device the context spans (fewer when the source holds fewer batches than that), `lanes` lanes each */
+	std::vector<mm_align_t *> prim = device_slots(a);
+	if(n_batches < prim.size()) prim.resize(n_batches);
+	const int n_dev = (int)prim.size();
+	const int lanes = (int)std::max<uint32_t>(1, std::min<uint32_t>({ (uint32_t)lanes_want, (n_batches + (uint32_t)n_dev - 1) / (uint32_t)n_dev, 8u }));
+	struct DevSt { mm_align_t *P = nullptr; std::vector<mm_align_t *> ctx; std::mutex claim_mu; uint32_t active = 0; };      /* active: lanes of the device between taking a batch and the end of its D2H */
+	std::vector<std::unique_ptr<DevSt>> dv;
+	int cur_dev = 0; (void)hipGetDevice(&cur_dev);
+	for(int d = 0; d < n_dev; d++) {
+		dv.emplace_back(new DevSt()); DevSt &D = *dv.back(); D.P = prim[d];
+		if(hipSetDevice(D.P->dev) != hipSuccess) { (void)hipSetDevice(cur_dev); return 1; }
+		mm_align_t *q = D.P; for(int i = 0; i < lanes && q; i++) { D.ctx.push_back(q); if(i + 1 < lanes) q = align_lane(q); }
+		if((int)D.ctx.size() < lanes || !D.ctx.back()) { (void)hipSetDevice(cur_dev); return 1; }
+	}
+	if(!getenv("MM_NO_SHARED_SLABS")) {
+		/* the shared DP workspaces of every device, side by side (tens of GB each: seconds on memory nobody has touched yet) */
+		std::vector<int> okv(n_dev, 1); std::vector<std::thread> st;
+		for(int d = 0; d < n_dev; d++) st.emplace_back([&, d]() { okv[d] = hipSetDevice(dv[d]->P->dev) == hipSuccess && ensure_shared_slabs(dv[d]->P, dv[d]->P->qlen_hint); });
+		for(auto &t : st) t.join();
+		for(int d = 0; d < n_dev; d++) if(!okv[d]) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); (void)hipSetDevice(cur_dev); return 1; }
+	}
+	(void)hipSetDevice(cur_dev);
+	/* host threads for post-map + text: -t when given, MM_HOST_THREADS, else up to 96 per device; two finishers per device share them */
 	const uint32_t hw = std::max<uint32_t>(1, std::thread::hardware_concurrency());
-	const uint32_t fmt_total = getenv("MM_HOST_THREADS") ? (uint32_t)std::max(1, atoi(getenv("MM_HOST_THREADS"))) : (a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(hw, 96));
-	const int n_fin = fmt_total >= 8 ? 2 : 1;
+	const uint32_t fmt_total = getenv("MM_HOST_THREADS") ? (uint32_t)std::max(1, atoi(getenv("MM_HOST_THREADS"))) : (a->o.nth > 1 ? a->o.nth : std::min<uint32_t>(hw, 96u * (uint32_t)n_dev));
+	const int n_fin = fmt_total >= 8 ? std::min<int>(2 * n_dev, (int)(fmt_total / 4)) : 1;
 	struct Item { mm_batch_t *h = nullptr; Fetched f; std::vector<std::string> piece; std::vector<std::vector<uint32_t>> roff; bool split = false; uint32_t k = 0; };
 	std::mutex mu; std::condition_variable cv;
-	uint32_t next_k = 0, verified = 0, next_write = 0, pending = 0; uint32_t carry = a->rlen_carry; int rc = 0;
-	const bool open_ended = n_batches == MM_OPEN_ENDED; std::mutex claim_mu; uint32_t active = 0;      /* active: lanes between taking a batch and the end of its D2H */
+	uint32_t verified = 0, next_write = 0, pending = 0; uint32_t carry = a->rlen_carry; int rc = 0;
 	std::vector<Item *> fetched;                       /* waiting for a finisher */
 	std::map<uint32_t, Item *> formatted;              /* waiting for the writer */
 	uint32_t lanes_done = 0, fin_done = 0; bool head_open = true;
-	a->head.clear(); a->head_txt.clear(); a->head_txt_end = 0; a->head_off.clear(); a->head_off_closed = false; a->head_carry_in = a->rlen_carry; a->streaming = true;
+	const uint32_t lanes_total = (uint32_t)(lanes * n_dev);
+	a->head.clear(); a->head_txt.clear(); a->head_txt_end = 0; a->head_off.clear(); a->head_off_closed = false; a->head_carry_in = a->rlen_carry;
+	for(auto &D : dv) D->P->streaming = true;
 	uint64_t written = 0;                              /* bytes handed to the sink so far (writer thread only) */
-	const uint32_t max_pending = (uint32_t)lanes + 2;
+	const uint32_t max_pending = lanes_total + 2;
 	/* an item leaves: its pinned set and its text pieces (emptied, capacity kept) go back to the pools of the context */
 	auto drop_item = [&](Item *it) {
-		{ std::lock_guard<std::mutex> lk(a->pool_mu); if(it->f.pin) { a->pin_free.push_back(it->f.pin); } if(!it->piece.empty() && a->piece_free.size() < 16) { a->piece_free.emplace_back(std::move(it->piece)); } }
+		{ std::lock_guard<std::mutex> lk(a->pool_mu); if(it->f.pin) { a->pin_free.push_back(it->f.pin); } if(!it->piece.empty() && a->piece_free.size() < 16u * (uint32_t)n_dev) { a->piece_free.emplace_back(std::move(it->piece)); } }
 		delete it;
 	};
 
 	const double t_engine0 = now_ms();
-	auto lane_main = [&](int li) {
-		mm_align_t *c = ctx[li];
-		if(hipSetDevice(a->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); rc = 1; lanes_done++; cv.notify_all(); return; }
+	auto lane_main = [&](int di, int li) {
+		DevSt &D = *dv[di]; mm_align_t *P = D.P; mm_align_t *c = D.ctx[li];
+		if(hipSetDevice(P->dev) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); rc = 1; lanes_done++; cv.notify_all(); return; }
 		while(true) {
-			uint32_t k, guess;
+			uint32_t k = 0, guess;
 			double tv = now_ms();
 			mm_batch_t *h = nullptr;
 			{
-				/* batches are taken one lane at a time, in order: an open-ended source hands them out as its reader cuts them, and a batch with a longer read than the
-				 * shared DP workspaces were sized for has them sized again before any later batch starts -- once the batches in front of it have left the device */
-				std::lock_guard<std::mutex> cl(claim_mu);
-				{ std::lock_guard<std::mutex> lk(mu); if(rc || next_k >= n_batches) break; k = next_k++; }
+				/* the batches of a device are taken one lane at a time, in order: a batch with a longer read than the shared DP workspaces of the device were sized for has
+				 * them sized again before any later batch starts there -- once the batches in front of it have left the device */
+				std::lock_guard<std::mutex> cl(D.claim_mu);
+				{ std::lock_guard<std::mutex> lk(mu); if(rc) break; }
 				tv = now_ms();
-				h = make(k);
-				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): taken after %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); }
-				if(!h && open_ended) { std::lock_guard<std::mutex> lk(mu); n_batches = std::min(n_batches, k); cv.notify_all(); break; }
-				if(h && a->shared_slabs && slab_bytes_for(std::max(h->b.max_qlen, a->qlen_hint)) > a->slab_max) {
-					std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return active == 0 || rc != 0; });
+				h = source(di);
+				if(!h) break;
+				k = h->k;
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): taken after %.1f ms (at %.1f)\n", k, di, li, now_ms() - tv, now_ms() - t_engine0); }
+				if(P->shared_slabs && slab_bytes_for(std::max(h->b.max_qlen, P->qlen_hint)) > P->slab_max) {
+					std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return D.active == 0 || rc != 0; });
 					const uint32_t want = h->b.max_qlen;
-					if(rc == 0 && !ensure_shared_slabs(a, want)) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); rc = 1; }
-					for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, want);
-					if(verbose) fprintf(stderr, "[minialign_amd] batch %u: a read of %u bases, DP workspaces sized again\n", k, h->b.max_qlen);
+					if(rc == 0 && !ensure_shared_slabs(P, want)) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); rc = 1; }
+					for(mm_align_t *ln = P; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, want);
+					if(verbose) fprintf(stderr, "[minialign_amd] batch %u: a read of %u bases, DP workspaces of device %d sized again\n", k, h->b.max_qlen, di);
 				}
-				std::lock_guard<std::mutex> lk(mu); active++; guess = carry;
+				std::lock_guard<std::mutex> lk(mu); D.active++; guess = carry;
 			}
-			struct Leave { std::mutex &m; std::condition_variable &c; uint32_t &n; bool armed = true; void now() { if(armed) { { std::lock_guard<std::mutex> lk(m); n--; } c.notify_all(); armed = false; } } ~Leave() { now(); } } leave{ mu, cv, active };
-			bool ok = h != nullptr;
-			if(ok) {
+			struct Leave { std::mutex &m; std::condition_variable &c; uint32_t &n; bool armed = true; void now() { if(armed) { { std::lock_guard<std::mutex> lk(m); n--; } c.notify_all(); armed = false; } } ~Leave() { now(); } } leave{ mu, cv, D.active };
+			bool ok = true;
+			{
 				h->ctx = c; Batch &b = h->b;
 				if(!b.packed) batch_pack(b, false);
 				c->rlen_carry = guess;
 				ok = batch_upload(c, b);
-				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): pack + upload %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): pack + upload %.1f ms (at %.1f)\n", k, di, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 				/* run ahead with the predicted carry; pools that overflow are grown here, before anybody waits for this batch */
 				bool split = false; const double k1_0 = c->st.k1_ms, k2_0 = c->st.k2_ms, k3_0 = c->st.k3_ms;
 				if(getenv("MM_TEST_SPLIT") && b.n >= 8) { split = true; }          /* test hook: take the path of a batch the pools cannot hold */
 				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) ok = false; }
-				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): run %.1f ms (at %.1f): sketch %.1f, sort + chain %.1f, extension %.1f ms on the device, the rest the host's turns in between\n", k, li, now_ms() - tv, now_ms() - t_engine0, c->st.k1_ms - k1_0, c->st.k2_ms - k2_0, c->st.k3_ms - k3_0); tv = now_ms(); }
+				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): run %.1f ms (at %.1f): sketch %.1f, sort + chain %.1f, extension %.1f ms on the device, the rest the host's turns in between\n", k, di, li, now_ms() - tv, now_ms() - t_engine0, c->st.k1_ms - k1_0, c->st.k2_ms - k2_0, c->st.k3_ms - k3_0); tv = now_ms(); }
 				uint32_t truth = 0;
 				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return verified == k || rc != 0; }); if(rc) ok = false; truth = carry; }
 				while(ok && !split) {
@@ -2995,10 +3256,10 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 						if(a->head.size() >= 4096) head_open = false;
 					}
 					cv.notify_all();
-					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): carry wait + verify %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
+					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): carry wait + verify %.1f ms (at %.1f)\n", k, di, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 					/* the batch that is written next never waits here: everything queued in front of the writer is behind it */
 					{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return pending < max_pending || k == next_write || rc != 0; }); if(rc) ok = false; else pending++; }
-					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): wait for the writer %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
+					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): wait for the writer %.1f ms (at %.1f)\n", k, di, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 				}
 				if(ok && !split) {
 					Item *it = new Item(); it->h = h; it->k = k;
@@ -3006,12 +3267,12 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 					if(!it->f.pin) it->f.pin = new mm_align_s::PinSet();
 					ok = batch_fetch(c, b, it->f);
 					leave.now();
-					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (lane %d): D2H %.1f ms (at %.1f)\n", k, li, now_ms() - tv, now_ms() - t_engine0); }
+					if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): D2H %.1f ms (at %.1f)\n", k, di, li, now_ms() - tv, now_ms() - t_engine0); }
 					if(ok) { std::lock_guard<std::mutex> lk(mu); fetched.push_back(it); } else { drop_item(it); std::lock_guard<std::mutex> lk(mu); pending--; }
 					cv.notify_all();
 				}
 			}
-			if(!ok) { std::lock_guard<std::mutex> lk(mu); rc = 1; if(h) release(h); cv.notify_all(); break; }
+			if(!ok) { std::lock_guard<std::mutex> lk(mu); rc = 1; release(h); cv.notify_all(); break; }
 		}
 		{ std::lock_guard<std::mutex> lk(mu); lanes_done++; }
 		cv.notify_all();
@@ -3021,7 +3282,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 			Item *it = nullptr;
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv.wait(lk, [&]() { return !fetched.empty() || lanes_done == (uint32_t)lanes; });
+				cv.wait(lk, [&]() { return !fetched.empty() || lanes_done == lanes_total; });
 				if(fetched.empty()) break;
 				/* the oldest batch first */
 				size_t best = 0; for(size_t i = 1; i < fetched.size(); i++) if(fetched[i]->k < fetched[best]->k) best = i;
@@ -3066,15 +3327,16 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const std::function<mm_
 		for(auto &kv : formatted) { release(kv.second->h); drop_item(kv.second); } formatted.clear();
 	};
 	std::vector<std::thread> th;
-	for(int i = 0; i < lanes; i++) th.emplace_back(lane_main, i);
+	for(int d = 0; d < n_dev; d++) for(int i = 0; i < lanes; i++) th.emplace_back(lane_main, d, i);
 	for(int i = 0; i < n_fin; i++) th.emplace_back(fin_main);
 	th.emplace_back(writer_main);
 	for(auto &t : th) t.join();
 	for(Item *it : fetched) { release(it->h); drop_item(it); }
-	if(rc == 0) { for(mm_align_t *q = a; q; q = q->sib) q->rlen_carry = carry; }
+	if(rc == 0) { each_context(a, [carry](mm_align_t *q) { q->rlen_carry = carry; }); }
 	if(!a->head_off_closed && a->head_off.size() <= 4096) { a->head_off.push_back(written); }          /* a stream shorter than the head: its end */
-	a->streaming = false;
-	if(getenv("MM_VERBOSE")) { size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot); fprintf(stderr, "[minialign_amd] device memory at the end of the stream: %.1f of %.1f GB free; %.1f GB held in recycled buffers\n", fr / 1073741824.0, tot / 1073741824.0, dev_cache().held / 1073741824.0); }
+	for(auto &D : dv) D->P->streaming = false;
+	if(getenv("MM_VERBOSE")) { for(auto &D : dv) { (void)hipSetDevice(D->P->dev); size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot); fprintf(stderr, "[minialign_amd] device %d memory at the end of the stream: %.1f of %.1f GB free; %.1f GB held in recycled buffers\n", D->P->dev, fr / 1073741824.0, tot / 1073741824.0, dev_cache().held_on(D->P->dev) / 1073741824.0); } }
+	(void)hipSetDevice(cur_dev);
 	return rc;
 }
 static void batch_fill(mm_batch_t *h, mm_reads_t const *r, uint32_t first, uint32_t last)
@@ -3114,10 +3376,10 @@ static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep)
 {
 	const uint32_t n = mm_reads_count(reads);
-	{ uint32_t mx = 0; for(const HSeq &q : reads->r) mx = std::max<uint32_t>(mx, (uint32_t)q.seq.size()); for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, mx); }
+	{ uint32_t mx = 0; for(const HSeq &q : reads->r) mx = std::max<uint32_t>(mx, (uint32_t)q.seq.size()); each_context(a, [mx](mm_align_t *ln) { ln->qlen_hint = std::max(ln->qlen_hint, mx); }); }
 	const auto sp = batch_spans(reads, 0, n);
 	const int rc = stream_map(a, (uint32_t)sp.size(),
-		[&](uint32_t k) { mm_batch_t *h = new mm_batch_s(); batch_fill(h, reads, sp[k].first, sp[k].second); return h; },
+		counted_source((uint32_t)sp.size(), [&](uint32_t k) { mm_batch_t *h = new mm_batch_s(); batch_fill(h, reads, sp[k].first, sp[k].second); return h; }),
 		[](mm_batch_t *h) { mm_batch_free(h); },
 		[&](uint32_t, std::vector<std::string> &piece) { for(auto &x : piece) { if(fwrite(x.data(), 1, x.size(), out) != x.size()) return false; } return true; },
 		default_lanes());
@@ -3135,7 +3397,7 @@ static uint64_t batch_cap_bases(mm_align_t *a, int lanes)
 	mm_align_s *P = a->root ? a->root : a;
 	if(!P->mem_for_batches) {
 		size_t fr = 0, tot = 0; if(hipMemGetInfo(&fr, &tot) != hipSuccess) return 1000000000ull;
-		const uint64_t avail = fr + dev_cache().held, slab_budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
+		const uint64_t avail = fr + dev_cache().held_on(P->dev), slab_budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
 		const uint64_t taken = slab_budget + slab_budget * 3 / 4 + (10ull << 30) - std::min<uint64_t>(P->shared_slabs ? P->slabs.bytes : 0, slab_budget);          /* (workspaces already allocated are no longer in `avail`) */
 		P->mem_for_batches = avail > taken + (8ull << 30) ? avail - taken : (8ull << 30);
 	}
@@ -3145,11 +3407,11 @@ static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const 
 {
 	if(lanes <= 0) lanes = default_lanes();
 	if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
-	TextReader rd; rd.pool = a->chunk_pool; rd.dev = a->dev; rd.src = src; rd.min_len = a->o.min_len; rd.keep_qual = a->o.keep_qual; rd.lanes = lanes;
+	TextReader rd; rd.dctx = device_slots(a); rd.src = src; rd.min_len = a->o.min_len; rd.keep_qual = a->o.keep_qual; rd.lanes = lanes;
 	rd.cap_bases = std::min<uint64_t>(1000000000ull, batch_cap_bases(a, lanes));
 	if(!rd.start()) { fprintf(stderr, "[minialign_amd] reader: no stream / staging memory\n"); return 1; }
 	bool err = false;
-	int rc = stream_map(a, MM_OPEN_ENDED, [&](uint32_t k) { return rd.take(k, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes);
+	int rc = stream_map(a, MM_OPEN_ENDED, [&](int di) { return rd.take(di, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes);
 	{ std::lock_guard<std::mutex> lk(rd.mu); if(err || rd.failed) rc = 1; }
 	return rc;
 }
@@ -3182,12 +3444,11 @@ extern "C" mm_reads_t *mm_reads_scan(mm_align_t *a, char const *fn, int keep_qua
 {
 	std::shared_ptr<TextSrc> src = open_text(fn);
 	if(!src) return NULL;
-	if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
-	TextReader rd; rd.pool = a->chunk_pool; rd.dev = a->dev; rd.src = src; rd.min_len = 1; rd.keep_qual = keep_qual != 0; rd.lanes = 1;
+	TextReader rd; rd.dctx.push_back(a); rd.src = src; rd.min_len = 1; rd.keep_qual = keep_qual != 0; rd.lanes = 1;
 	if(!rd.start()) return NULL;
 	mm_reads_t *out = new mm_reads_s(); bool err = false;
 	for(uint32_t k = 0; ; k++) {
-		mm_batch_t *h = rd.take(k, &err);
+		mm_batch_t *h = rd.take(0, &err);
 		if(!h) break;
 		Batch &b = h->b;
 		if(!batch_upload(a, b)) { err = true; delete h; break; }
@@ -3313,17 +3574,17 @@ extern "C" uint64_t mm_head_offset(mm_align_t const *a, uint32_t i) { return i <
 extern "C" int mm_map_packed(mm_align_t *a, mm_batch_t *const *batches, uint32_t n_batches, int lanes, mm_sam_sink_t sink, void *opaque)
 {
 	uint32_t mx = 0; for(uint32_t k = 0; k < n_batches; k++) mx = std::max(mx, batches[k]->b.max_qlen);
-	for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, mx);
-	return stream_map(a, n_batches, [&](uint32_t k) { return batches[k]; }, [](mm_batch_t *) {},
+	each_context(a, [mx](mm_align_t *ln) { ln->qlen_hint = std::max(ln->qlen_hint, mx); });
+	return stream_map(a, n_batches, counted_source(n_batches, [&](uint32_t k) { return batches[k]; }), [](mm_batch_t *) {},
 		[&](uint32_t k, std::vector<std::string> &piece) { for(auto &x : piece) { if(sink && sink(opaque, k, x.data(), x.size())) return false; } return true; }, lanes > 0 ? lanes : default_lanes());
 }
 extern "C" int mm_map_reads(mm_align_t *a, mm_reads_t const *reads, uint32_t first, uint32_t n, int lanes, mm_sam_sink_t sink, void *opaque)
 {
 	const auto sp = batch_spans(reads, first, n);
 	uint32_t mx = 0; for(auto &q : sp) for(uint32_t i = q.first; i < q.second; i++) mx = std::max<uint32_t>(mx, (uint32_t)reads->r[i].seq.size());
-	for(mm_align_t *ln = a; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, mx);
+	each_context(a, [mx](mm_align_t *ln) { ln->qlen_hint = std::max(ln->qlen_hint, mx); });
 	return stream_map(a, (uint32_t)sp.size(),
-		[&](uint32_t k) { mm_batch_t *h = new mm_batch_s(); batch_fill(h, reads, sp[k].first, sp[k].second); return h; },
+		counted_source((uint32_t)sp.size(), [&](uint32_t k) { mm_batch_t *h = new mm_batch_s(); batch_fill(h, reads, sp[k].first, sp[k].second); return h; }),
 		[](mm_batch_t *h) { mm_batch_free(h); },
 		[&](uint32_t k, std::vector<std::string> &piece) { for(auto &x : piece) { if(sink && sink(opaque, k, x.data(), x.size())) return false; } return true; }, lanes > 0 ? lanes : default_lanes());
 }

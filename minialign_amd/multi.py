@@ -48,6 +48,7 @@ def load_library(path=None):
     L.mm_batch_pack_all.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]; L.mm_batch_pack_all.restype = ctypes.c_uint32
     L.mm_batch_free.argtypes = [ctypes.c_void_p]; L.mm_batch_free.restype = None
     L.mm_idx_max_len.argtypes = [ctypes.c_void_p]; L.mm_idx_max_len.restype = ctypes.c_uint32
+    L.mm_align_devices.argtypes = [ctypes.c_void_p]; L.mm_align_devices.restype = ctypes.c_int
     return L
 
 
@@ -236,7 +237,9 @@ def main(argv=None):
     sys.stdout.flush(); out_fd = os.dup(1); os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
     dev = 0 if os.environ.get('MM_MULTI_SAME_DEVICE') is not None else local          # test hook: every rank on device 0 (one-GPU boxes)
-    if world > 1: dist.init_process_group('gloo')          # three integers per rank and a token: no RCCL on this path
+    if world > 1:
+        dist.init_process_group('gloo')          # three integers per rank and a token: no RCCL on this path
+        os.environ['MM_DEVICES'] = '1'           # one process per GPU here: the context of a rank stays on its own device (a lone process spans all it sees)
     L = load_library()
     if L.mm_set_device(dev) != 0: raise RuntimeError('no HIP device %d' % dev)
     o = ctypes.c_void_p(L.mm_opt_init())

@@ -29,6 +29,43 @@ def test_batches_in_flight_give_the_single_stream(data, lanes, batch):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert _strip_pg(r.stdout) == want
 
+@pytest.mark.parametrize('n_ctx,lanes,batch,chunk', [(2, 2, 250000, None), (3, 1, 90000, 200000), (4, 2, 60000, 65536), (4, 1, None, 1 << 20)])
+def test_batches_dealt_over_device_contexts_give_the_single_stream(data, n_ctx, lanes, batch, chunk):
+    """the command-line program over several device contexts in ONE process (mm_align_init spans the visible devices; here MM_DEVICE_CONTEXTS puts 2 / 3 / 4 of them
+    on the one GPU of the box): pieces of the text go to the devices round robin, the scan finds the records in order, batches are dealt to device x lane, the carried
+    value is verified in batch order across devices, one writer -- the bytes of the single stream"""
+    ref, rd, want = data
+    env = dict(os.environ, MM_DEVICE_CONTEXTS=str(n_ctx), MM_LANES=str(lanes), MM_SLAB_GB='4')
+    if batch: env['MM_BATCH_BASES'] = str(batch)
+    if chunk: env['MM_CHUNK_BYTES'] = str(chunk)
+    r = subprocess.run([CLI, '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert _strip_pg(r.stdout) == want
+
+def test_device_contexts_through_the_c_abi(data):
+    """mm_map_text (text in host memory -> sink in input order) and mm_map_reads (parsed reads, any batch to any device) over three device contexts"""
+    from minialign_amd import multi
+    ref, rd, want = data
+    env_keep = {k: os.environ.get(k) for k in ('MM_DEVICE_CONTEXTS', 'MM_SLAB_GB', 'MM_BATCH_BASES')}
+    os.environ.update(MM_DEVICE_CONTEXTS='3', MM_SLAB_GB='4', MM_BATCH_BASES='200000')
+    try:
+        L = multi.load_library(); assert L.mm_set_device(0) == 0
+        o = ctypes.c_void_p(L.mm_opt_init()); argv = (ctypes.c_char_p * 4)(b'minialign', b'-xpacbio', ref.encode(), rd.encode()); files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
+        assert L.mm_opt_parse(o, 4, argv, files, 8, ctypes.byref(nf)) == 0
+        mi = ctypes.c_void_p(L.mm_idx_gen(o, ref.encode())); al = ctypes.c_void_p(L.mm_align_init(o, mi)); assert al
+        assert L.mm_align_devices(al) == 3
+        text = open(rd, 'rb').read(); body = _body(want)
+        sm = multi.ShardMapper(L, al, None, 0, 0, lanes=2, text=(ctypes.cast(ctypes.c_char_p(text), ctypes.c_void_p).value, len(text))).map(0)
+        assert sm.col.text() == body
+        reads = ctypes.c_void_p(L.mm_reads_load(rd.encode())); n = L.mm_reads_count(reads)
+        sm = multi.ShardMapper(L, al, reads, 0, n, lanes=2).map(0)
+        assert sm.col.text() == body
+        L.mm_reads_free(reads); L.mm_align_destroy(al); L.mm_idx_destroy(mi)
+    finally:
+        for k, v in env_keep.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_one_read_set_split_over_ranks_on_one_gpu(data, world):
     """world_size 2 and 3 with every rank on cuda:0 (gloo group): shards mapped with a guessed carried value, settled with the true one (checks, window
@@ -85,9 +122,9 @@ def test_bench_line_with_two_ranks_on_one_gpu():
     assert d['roofline']['achieved'] > 0 and 'cpu_baseline' not in d
 
 @pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1'),
-                                 dict(MM_K2_LDS_CHAIN='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_HOST_READER='1'), dict(MM_HOST_INDEX='1')],
+                                 dict(MM_K2_LDS_CHAIN='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_HOST_READER='1'), dict(MM_HOST_INDEX='1'), dict(MM_K3_JOB_CAP='7'), dict(MM_DEVICE_CONTEXTS='2', MM_SLAB_GB='14')],
                          ids=['rounds-through-the-host', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain', 'batch-split-on-pool-exhaustion',
-                              'chain-sweep-in-lds', 'no-chain-jobs', 'host-reader', 'host-index'])
+                              'chain-sweep-in-lds', 'no-chain-jobs', 'host-reader', 'host-index', 'more-chain-jobs-than-slots', 'two-device-contexts'])
 def test_alternative_schedules_give_the_same_bytes(env):
     """the forms kept behind environment switches -- the occurrence-threshold rounds as separate launches through the host (the default runs them inside the
     extension kernel, k3_rescue_round), one read per wave, per-lane DP
@@ -97,7 +134,7 @@ def test_alternative_schedules_give_the_same_bytes(env):
         M.gensim('genome', 7401, 1500000, 6, 0.45, out=ref); M.gensim('reads', 7402, ref, 3.0, 'pacbio', 'fa', 6000, 2500, out=rd)          # 750 reads, many with dozens of chains: the chain jobs of the default run have work
         opts = ['-xpacbio', '-f0.2,0.05,0.002']
         want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
-        r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='32', MM_BATCH_BASES='3000000', **env), timeout=600)          # (32 GB: a workspace for every resident wave at this read length, so that the chain and retry jobs of the default schedule run)
+        r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **dict(dict(MM_SLAB_GB='32', MM_BATCH_BASES='3000000'), **env)), timeout=600)          # (32 GB: a workspace for every resident wave at this read length, so that the chain and retry jobs of the default schedule run)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert _strip_pg(r.stdout) == want
         assert b're-run' in r.stderr
