@@ -38,6 +38,7 @@ WORKLOADS = {
     'hg38':  dict(genome_len=3100000000, contigs=25,   repeat_frac=0.05, depth=3.0,   kind='pacbio', preset='pacbio',   name='human hg38-size ref (3.1 Gb, 25 contigs)'),
     'dm6':   dict(genome_len=143700000,  contigs=1870, repeat_frac=0.05, depth=20.0,  kind='pacbio', preset='pacbio',   name='D.melanogaster dm6-size ref (143.7 Mb, 1870 contigs)'),
     'ecoli': dict(genome_len=4641652,    contigs=1,    repeat_frac=0.05, depth=100.0, kind='pacbio', preset='pacbio',   name='E.coli MG1655-size ref (4.64 Mb)'),
+    'hg38hard': dict(genome_len=3100000000, contigs=25, repeat_frac=0.45, depth=1.0,  kind='pacbio', preset='pacbio',  hard=True, baseline_reads=20000, check_reads=2000, name='human-size ref with mammalian repeat structure (3.1 Gb, 25 contigs: tools/gensim.c genomehard -- SINE / LINE-like families of 10^5 .. 10^6 copies, 200 mid-size families, segmental duplications, satellite arrays, N gaps)'),
     'ont':   dict(genome_len=3100000000, contigs=25,   repeat_frac=0.05, depth=1.0,   kind='ont',    preset='ont.1dsq', baseline_reads=8000, check_reads=1000, name='human hg38-size ref (3.1 Gb, 25 contigs), ONT-like reads'),
 }
 
@@ -50,7 +51,8 @@ class Stats(ctypes.Structure):
                 ('host_post_ms', ctypes.c_double), ('host_sam_ms', ctypes.c_double), ('wall_ms', ctypes.c_double),
                 ('k3_cycles_fill', ctypes.c_uint64), ('k3_cycles_leaf', ctypes.c_uint64), ('k3_cycles_trace', ctypes.c_uint64),
                 ('k3_cycles_total', ctypes.c_uint64), ('k3_cycles_next', ctypes.c_uint64), ('k3_cycles_max', ctypes.c_uint64), ('k3_waves', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
-                ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64)]
+                ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64), ('pool_grows', ctypes.c_uint64), ('batch_splits', ctypes.c_uint64),
+                ('text_bytes', ctypes.c_uint64), ('reader_ms', ctypes.c_double)]
 
 def gensim_exe():
     exe = os.path.join(ROOT, 'tools', 'gensim')
@@ -61,7 +63,7 @@ def gensim_exe():
 def generate(work, w, seed=0x5eed0001):
     """reference + the PARTS read files of the set (generated side by side)"""
     exe = gensim_exe(); ref_fa = os.path.join(work, 'ref.fa')
-    with open(ref_fa, 'wb') as f: subprocess.check_call([exe, 'genome', str(seed), str(w['genome_len']), str(w['contigs']), str(w['repeat_frac'])], stdout=f)
+    with open(ref_fa, 'wb') as f: subprocess.check_call([exe, 'genomehard' if w.get('hard') else 'genome', str(seed), str(w['genome_len']), str(w['contigs']), str(w['repeat_frac'])], stdout=f)
     parts = [os.path.join(work, 'reads_%02d.fa' % p) for p in range(PARTS)]; procs = []
     for p, fn in enumerate(parts):
         f = open(fn, 'wb')
@@ -312,7 +314,7 @@ def main():
             'metric': 'aligned Gbases/sec (whole node), map phase end to end: FASTA text of the reads in host memory -> SAM text in host memory',
             'value': total_bases * args.steps / dt * 1e-9, 'unit': 'Gbases/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'i8',
-            'data': 'synthetic (tools/gensim.c, seed 0x5eed0001: %.2f Mb reference in %d contig(s) with %g %% planted repeats; %s-like reads in %d parts)' % (w['genome_len'] / 1e6, w['contigs'], w['repeat_frac'] * 100, 'ONT' if w['kind'] == 'ont' else 'PBSIM-CLR', PARTS),
+            'data': 'synthetic (tools/gensim.c, seed 0x5eed0001: %.2f Mb reference in %d contig(s) with %g %% repeats; %s-like reads in %d parts)' % (w['genome_len'] / 1e6, w['contigs'], w['repeat_frac'] * 100, 'ONT' if w['kind'] == 'ont' else 'PBSIM-CLR', PARTS),
             'config': {'workload': '%s%s x %s x%g (%.2f Gb, %d reads) -x%s, one read set split over %d MI355X' % (w['name'], ' [custom shape]' if custom else '', 'ONT-like' if w['kind'] == 'ont' else 'PBSIM-like', w['depth'], total_bases / 1e9, int(total_reads), w['preset'], n_gpus),
                        'workload_key': args.workload if not custom else 'custom', 'reads_total': int(total_reads), 'bases_total': int(total_bases), 'batches_per_rank0': nb, 'lanes': args.lanes,
                        'parallelism': ('one process per GPU (torch.distributed.run, gloo): reads sharded contiguously, index replicated (no data-path collective; one all_gather of 2 integers per step for the carried value)' if world > 1 else
@@ -327,6 +329,8 @@ def main():
                        'extend_wave_balance (mean / max lifetime)': st.k3_cycles_total / max(1, st.k3_cycles_max * st.k3_waves),
                        'sort_chain_wave_time_split': {'sort_cycles_per_seed': st.k2_cycles_sort / max(1, st.seeds), 'chain_cycles_per_seed': st.k2_cycles_chain / max(1, st.seeds), 'seeds_per_read': st.seeds / max(1, st.reads), 'reads_not_in_lds': st.k2_reads_hbm},
                        'dp_vectors_per_base': vec / max(1.0, total_bases * K), 'trace_steps_per_base': trs / max(1.0, total_bases * K), 'reruns_per_step (rank 0)': st.reruns / K,
+                       'pool_overflows (batches run again with larger device pools, rank 0, timed steps)': int(st.pool_grows), 'batch_splits (rank 0, timed steps)': int(st.batch_splits),
+                       'reader_gb_per_s (text to HBM, per uploader thread while it copies; one uploader per device)': (st.text_bytes * 1e-6 / st.reader_ms) if st.reader_ms > 0 else None,
                        'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
                        'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'text_load_s (outside)': t_load, 'host_parse_and_pack_s (value_from_packed only)': t_pack},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -687,6 +687,10 @@ struct DevCache {
 	 * being replaced: nothing is in flight then) -- an ONT-like run that re-sized its workspace ladder a few times had 150 GB of them waiting here and the runtime ran out of memory */
 	void give(int dev, size_t bytes, void *p)
 	{
+		/* MM_POISON_CACHE (diagnostics): a block that comes back is overwritten, so that anything still reading it -- a kernel of another lane, a copy in flight, a pointer
+		 * kept in a descriptor -- computes garbage instead of the right bytes by luck */
+		static const bool poison = getenv("MM_POISON_CACHE") != NULL;
+		if(poison) { (void)hipMemset(p, 0xab, bytes); (void)hipDeviceSynchronize(); }
 		/* ... and nothing is kept while the device is short of memory (the runtime allocates the kernels' scratch memory on demand and aborts the process when it cannot).
 		 * `tight` is what the last fresh allocation found: hipMemGetInfo costs about 2 ms, and a stream gives a dozen buffers back when it ends -- asked here, it made every
 		 * stream 20 ms longer, 12 % of one over an E.coli-size set */
@@ -1173,6 +1177,8 @@ struct mm_align_s {
 	/* the other devices of the node: one primary context each (own streams, lanes, pools, DP workspaces, a replica of the index), owned by the first context.  The
 	 * streaming engine deals its batches over all of them; the per-batch entries stay on the first */
 	std::vector<mm_align_s *> peers;
+	/* experiment (MM_K3_CONCURRENT=n): at most n extension launches of this device in flight at a time, the lanes queue for their turn */
+	std::mutex k3_gate_mu; std::condition_variable k3_gate_cv; int k3_in_flight = 0;
 	mm_stats_t st; double t_wall0;
 	/* knobs (grown on overflow) */
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
@@ -1482,8 +1488,13 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * no faster on the headline workload (2.86 against 2.77 s per step with the rounds in the kernel, 3.7 against 3.2 without), kept as an experiment */
 		k3.persistent = 1;
 		if(k3.ring) { if((uint64_t)k3.ring_n * 8 >= a->n_waves && getenv("MM_K3_ONE_READ_PER_WAVE")) { k3.persistent = 0; waves = (uint32_t)((k3.n_work + 3) & ~3u); } else { waves = std::min<uint32_t>(waves, (k3.ring_n * 8u) & ~3u); } }
+		const int k3_conc = getenv("MM_K3_CONCURRENT") ? std::max(1, atoi(getenv("MM_K3_CONCURRENT"))) : 0;
+		mm_align_s *GP = a->root ? a->root : a;
+		if(k3_conc) { std::unique_lock<std::mutex> lk(GP->k3_gate_mu); GP->k3_gate_cv.wait(lk, [&]() { return GP->k3_in_flight < k3_conc; }); GP->k3_in_flight++; CK(hipEventRecord(a->ev0, xs)); }
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), inkernel ? K3_LDS_BYTES : 0, xs, k3);
-		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, xs)); CK(hipEventSynchronize(a->ev1));
+		{ const hipError_t le = hipGetLastError(); hipError_t se = le == hipSuccess ? hipEventRecord(a->ev1, xs) : le; if(se == hipSuccess) se = hipEventSynchronize(a->ev1);
+		  if(k3_conc) { { std::lock_guard<std::mutex> lk(GP->k3_gate_mu); GP->k3_in_flight--; } GP->k3_gate_cv.notify_all(); }
+		  CK(se); }
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
 		if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
@@ -2048,6 +2059,7 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 			out->k3_cycles_fill += q.k3_cycles_fill; out->k3_cycles_leaf += q.k3_cycles_leaf; out->k3_cycles_trace += q.k3_cycles_trace; out->k3_cycles_total += q.k3_cycles_total;
 			out->k3_cycles_next += q.k3_cycles_next; out->k3_cycles_max += q.k3_cycles_max;             /* summed over launches; k3_waves stays the per-launch count */
 			out->k2_cycles_sort += q.k2_cycles_sort; out->k2_cycles_chain += q.k2_cycles_chain; out->k2_cycles_total += q.k2_cycles_total; out->k2_reads_hbm += q.k2_reads_hbm;
+			out->pool_grows += q.pool_grows; out->batch_splits += q.batch_splits; out->text_bytes += q.text_bytes; out->reader_ms += q.reader_ms;
 		});
 	}
 	if(reset) { a->t_wall0 = now_ms(); each_context(a, [](mm_align_t *ln) { memset(&ln->st, 0, sizeof(ln->st)); }); }
@@ -2235,6 +2247,7 @@ int batch_run_once(mm_align_t *a, Batch &b)
 bool batch_grow(mm_align_t *a, Batch &b)
 {
 	if(b.scale >= 256) { fprintf(stderr, "[minialign_amd] batch does not fit the device pools\n"); return false; }
+	a->st.pool_grows++;
 	b.scale *= 4; a->bin_cap *= 2; a->aln_cap *= 2; a->kh_cap *= 4; a->next_cap *= 2; a->rs_stride = 512 + (a->rs_stride - 512) * 4;
 	fprintf(stderr, "[minialign_amd] device pools overflowed, retrying the batch with scale %lu\n", (unsigned long)b.scale);
 	return true;
@@ -3238,7 +3251,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 				if(ok && split) {
 					/* the pools cannot hold this batch: its reads in halves on this lane, in order, with the true carried value; the text goes straight to the writer */
 					Item *it = new Item(); it->h = h; it->k = k; it->split = true;
-					c->rlen_carry = truth; b.scale = 1;
+					c->rlen_carry = truth; b.scale = 1; c->st.batch_splits++;
 					ok = map_split(c, b, 0, b.n, it->piece);
 					if(ok) {
 						{ std::lock_guard<std::mutex> lk(mu); carry = c->rlen_carry; verified = k + 1; pending++; formatted[k] = it; if(k == 0) { a->head.clear(); a->head_carry_in = truth; } head_open = false; }          /* (the reads of a split batch are not recorded: the head ends in front of them) */
@@ -3413,6 +3426,7 @@ static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const 
 	bool err = false;
 	int rc = stream_map(a, MM_OPEN_ENDED, [&](int di) { return rd.take(di, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes);
 	{ std::lock_guard<std::mutex> lk(rd.mu); if(err || rd.failed) rc = 1; }
+	for(ReaderDev *R : rd.rdev) { a->st.text_bytes += R->bytes_up; a->st.reader_ms += R->t_io; }
 	return rc;
 }
 /* standard input can be read once: its text is kept for the case that it is mapped onto several indices (-X, index files with several blocks) */

@@ -4,12 +4,12 @@ with several threads the reference's own output depends on which thread buffer a
   (i)   D.melanogaster dm6-size reference (143.7 Mb, 1 870 contigs) x PBSIM-like x20 (2.87 Gb): the WHOLE SAM byte for byte, and the same set split over 8 ranks of
         minialign_amd.multi (all on cuda:0) identical to the single stream;
   (ii)  human hg38-size reference (3.1 Gb, 25 contigs) x PBSIM-like x3 (9.3 Gb, the headline set): size-independent properties of the whole 13 GB stream
-        (tools/samcheck.c: one primary record per read in input order, every CIGAR adds up to its read and stays inside its contig, ...), the records of the
-        first 45 000 reads (more than three 300 Mb batches on four lanes) byte for byte, and the same set split over 2 ranks of minialign_amd.multi on cuda:0
-        (shards by bytes, carried value settled over gloo, every rank writing its own records in rank order) identical to the single stream;
-  (iii) the hg38-size reference x ONT-like reads (3.1 Gb) with -xont.1dsq: properties of the whole stream, the records of the first 20 000 reads byte for byte.
+        (tools/samcheck.c: one primary record per read in input order, every CIGAR adds up to its read and stays inside its contig, ...), EVERY record of it against
+        the compiled reference (all 446 956 reads: the reference maps the 16 parts of the set in 16 -t1 processes side by side, each primed with the last reads of the
+        part in front; a digest per part), and the same set over 2 and 4 device contexts of ONE process (the multi-GPU form of the drop-in) identical to the single stream;
+  (iii) the hg38-size reference x ONT-like reads (3.1 Gb) with -xont.1dsq: properties of the whole stream, every record of it against the compiled reference likewise.
 
-The reference runs (index files, then -t1 over the sample) go on in the background on host cores while the device maps.  Skipped where the compiled reference
+The reference runs (index files, then the -t1 processes) go on in the background on host cores while the device maps.  Skipped where the compiled reference
 did not travel with the snapshot (it does with gpurun; /root/reference itself is never read here)."""
 import hashlib, json, os, shutil, subprocess, sys, tempfile, time
 import pytest
@@ -26,10 +26,10 @@ def _samcheck():
     if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src): subprocess.check_call(['gcc', '-O2', '-o', exe, src])
     return exe
 
-def _generate(d, tag, genome, reads, rd_tag='rd'):
-    """reference (made once per tag) + read set (16 parts side by side, then one file); returns (ref.fa, reads.fa)"""
+def _generate(d, tag, genome, reads, rd_tag='rd', keep_parts=False, hard=False):
+    """reference (made once per tag) + read set (16 parts side by side, then one file); returns (ref.fa, reads.fa) -- and the part files when they are kept"""
     ref = os.path.join(d, tag + '_ref.fa'); rd = os.path.join(d, '%s_%s.fa' % (tag, rd_tag))
-    if not os.path.exists(ref): M.gensim('genome', *genome, out=ref)
+    if not os.path.exists(ref): M.gensim('genomehard' if hard else 'genome', *genome, out=ref)
     seed, depth, kind = reads
     procs = []
     for p in range(PARTS):
@@ -37,11 +37,44 @@ def _generate(d, tag, genome, reads, rd_tag='rd'):
         procs.append((subprocess.Popen([GENSIM, 'reads', str(seed), ref, str(depth), kind, 'fa', '20000', '2000', str(p), str(PARTS)], stdout=f), f))
     for pr, f in procs:
         assert pr.wait() == 0; f.close()
+    parts = ['%s.%02d' % (rd, p) for p in range(PARTS)]
     with open(rd, 'wb') as g:
-        for p in range(PARTS):
-            with open('%s.%02d' % (rd, p), 'rb') as f: shutil.copyfileobj(f, g, 64 << 20)
-            os.unlink('%s.%02d' % (rd, p))
-    return ref, rd
+        for fn in parts:
+            with open(fn, 'rb') as f: shutil.copyfileobj(f, g, 64 << 20)
+            if not keep_parts: os.unlink(fn)
+    return (ref, rd, parts) if keep_parts else (ref, rd)
+
+def _last_records(fn, n, window):
+    """the last n FASTA records of a file (read off its last `window` bytes)"""
+    with open(fn, 'rb') as f:
+        f.seek(0, 2); size = f.tell(); f.seek(max(0, size - window)); tail = f.read()
+    starts = [i + 1 for i in range(len(tail) - 1) if tail[i:i + 2] == b'\n>']
+    assert len(starts) >= n, 'window too small for %d records' % n
+    return tail[starts[-n]:]
+
+def _reference_by_parts(preset, ref, parts, out, threads=32, primer=4, window=8 << 20):
+    """The compiled reference over a WHOLE set, part by part: its index file (with `threads` threads), then one -t1 process per part, side by side, each fed the last
+    `primer` reads of the part in front and then its own part -- so that its thread buffer holds, at the first read of the part, what a single -t1 stream over the whole
+    set would hold there (the carried reference length) -- through tools/samcheck --parts (a digest and a record count per part).  Returns the Popen of the
+    shell that runs it all; part p's line lands in out.<p>.json"""
+    mai = out + '.mai'; sc = _samcheck()
+    lines = ['%s -x%s -t%d -d %s %s 2> %s.idx.err || exit 1' % (REFBIN, preset, threads, mai, ref, out)]
+    for p, fn in enumerate(parts):
+        pf = '%s.primer.%02d.fa' % (out, p)
+        with open(pf, 'wb') as g:
+            if p: g.write(_last_records(parts[p - 1], primer, window))
+        lines.append('( cat %s %s | %s -x%s -t1 %s 2> %s.%02d.err | %s --parts > %s.%02d.json ) &' % (pf, fn, REFBIN, preset, mai, out, p, sc, out, p))
+    lines.append('wait; rm -f %s' % mai)
+    return subprocess.Popen(['bash', '-c', '\n'.join(lines)])
+
+def _parts_of(out, n):
+    """[(records, digest)] of parts 0 .. n - 1 as the reference processes left them: part p from the process that mapped part p"""
+    got = []
+    for p in range(n):
+        with open('%s.%02d.json' % (out, p)) as f: d = json.loads(f.read().strip().splitlines()[-1])
+        assert len(d['parts']) > p, ('part %d' % p, d)
+        got.append(tuple(d['parts'][p]))
+    return got
 
 def _head_fasta(rd, n, out):
     k = 0
@@ -76,6 +109,9 @@ def _map_through_samcheck(cmd, rd, n_head, head_out, env=None, cwd=None, timeout
     assert rc == 0, err.decode()[-3000:]
     return json.loads(out.decode().strip().splitlines()[-1]), err, time.time() - t0
 
+def _contexts_env(n, slab_gb, lanes):
+    return dict(os.environ, MM_DEVICE_CONTEXTS=str(n), MM_SLAB_GB=str(slab_gb), MM_LANES=str(lanes))
+
 @pytest.fixture(scope='module')
 def work():
     if not os.path.exists(REFBIN): pytest.skip('oracle/_ref not built')
@@ -94,6 +130,12 @@ def test_dm6_size_x20_whole_sam_equals_the_reference(work):
     got = _md5_records(os.path.join(work, 'dm6_ours.sam')); ref_md5 = _md5_records(want)
     assert got == ref_md5, 'dm6-size x20: SAM differs from the compiled reference'
     assert got[1] == s['records']
+    # the same set through the command-line program spanning 2 and 4 device contexts in ONE process (all on the one GPU of the box): pieces of the text dealt to the
+    # devices, batches to device x lane, the carried value (which changes at nearly every read of this set) verified in batch order across devices, one writer
+    for n, gb, lanes in ((2, 24, 2), (4, 12, 2)):
+        sn, errn, secn = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull, env=_contexts_env(n, gb, lanes))
+        assert sn['error'] == '' and sn['digest'] == s['digest'] and sn['records'] == s['records'] and sn['bytes'] == s['bytes'], (n, s, sn, errn.decode()[-1500:])
+        sys.stderr.write('[headline] dm6-size x20: one context %.1f s, %d contexts on one GPU %.1f s (index build included)\n' % (sec, n, secn))
     # the same set over EIGHT ranks (all on cuda:0; MM_LANES=1 each): 1 870 contigs, so the carried value differs at nearly every shard boundary -- checks, window re-maps
     # and the rank-after-rank writers all have work -- and the stream must still be the single stream's
     env = dict(os.environ, MM_MULTI_SAME_DEVICE='1', MM_SLAB_GB='6', MM_LANES='1', MM_HOST_THREADS='24', PYTHONPATH=M.ROOT)
@@ -106,42 +148,42 @@ def test_dm6_size_x20_whole_sam_equals_the_reference(work):
 
 @pytest.fixture(scope='module')
 def hg38(work):
-    """the headline set and, running in the background, the reference's records for its first 45 000 reads (and for the first 20 000 of the ONT-like set)"""
+    """the headline set and the ONT-like set in 16 parts each, and -- running in the background on host cores -- the compiled reference over BOTH whole sets, part by part"""
     genome = (0x5eed0001, 3100000000, 25, 0.05)
-    ref, rd = _generate(work, 'hg38', genome, (0x5eed0002, 3.0, 'pacbio'))
-    pb_sample = _head_fasta(rd, 45000, os.path.join(work, 'pb_sample.fa'))
-    bg_pb = _reference_in_background('pacbio', ref, pb_sample, os.path.join(work, 'pb_ref.sam'))
-    _, ont_rd = _generate(work, 'hg38', genome, (0x5eed0003, 1.0, 'ont'), rd_tag='ont')
-    ont_sample = _head_fasta(ont_rd, 20000, os.path.join(work, 'ont_sample.fa'))
-    bg_ont = _reference_in_background('ont.1dsq', ref, ont_sample, os.path.join(work, 'ont_ref.sam'))
+    ref, rd, pb_parts = _generate(work, 'hg38', genome, (0x5eed0002, 3.0, 'pacbio'), keep_parts=True)
+    bg_pb = _reference_by_parts('pacbio', ref, pb_parts, os.path.join(work, 'pb_ref'))
+    _, ont_rd, ont_parts = _generate(work, 'hg38', genome, (0x5eed0003, 1.0, 'ont'), rd_tag='ont', keep_parts=True)
+    bg_ont = _reference_by_parts('ont.1dsq', ref, ont_parts, os.path.join(work, 'ont_ref'), window=64 << 20)
     yield dict(ref=ref, rd=rd, ont=ont_rd, bg_pb=bg_pb, bg_ont=bg_ont)
     for b in (bg_pb, bg_ont):
         if b.poll() is None: b.kill()
 
-def test_hg38_size_x3_properties_head_parity_and_two_ranks(work, hg38):
+def test_hg38_size_x3_whole_set_equals_the_reference_and_device_contexts(work, hg38):
+    """BASELINE.json's headline configuration, every read of it: properties of the 13 GB stream, every part's records against the compiled reference at -t1 (all 446 956
+    reads), and the same set over 2 and 4 device contexts in one process"""
     ref, rd = hg38['ref'], hg38['rd']
-    head = os.path.join(work, 'pb_head.sam')
-    s, err, sec = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 45000, head)
+    s, err, sec = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull)
     assert s['error'] == '' and s['reads'] == s['primary'] and s['contigs'] == 25, s
     assert s['bases_mapped'] > 8.8e9 and s['mapped'] > 0.98 * s['reads'] and s['bytes'] > 12e9, s          # the whole 9.3 Gb set
-    # the same set over two ranks (both on cuda:0): byte shards, carried value settled, records written rank after rank == the single stream
-    env = dict(os.environ, MM_MULTI_SAME_DEVICE='1', MM_SLAB_GB='24', MM_LANES='2', MM_HOST_THREADS='48', PYTHONPATH=M.ROOT)
-    port = 29700 + os.getpid() % 1500
-    s2, err2, sec2 = _map_through_samcheck([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
-                                            '-m', 'minialign_amd.multi', '-xpacbio', ref, rd], rd, 0, os.devnull, env=env, cwd=M.ROOT, timeout=1200)
-    assert s2['error'] == '' and s2['digest'] == s['digest'] and s2['records'] == s['records'] and s2['bytes'] == s['bytes'], (s, s2, err2.decode()[-1500:])
-    # the first 45 000 reads against the compiled reference at -t1
-    assert hg38['bg_pb'].wait(timeout=900) == 0, open(os.path.join(work, 'pb_ref.sam.err')).read()[-2000:]
-    got = _md5_records(head); want = _md5_records(os.path.join(work, 'pb_ref.sam'))
-    assert got == want and got[1] >= 45000, 'hg38-size x3: the records of the first 45 000 reads differ from the compiled reference'
-    sys.stderr.write('[headline] hg38-size x3: single stream %.1f s, two ranks %.1f s (index builds included)\n' % (sec, sec2))
+    for n, gb, lanes in ((2, 24, 2), (4, 12, 1)):
+        sn, errn, secn = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull, env=_contexts_env(n, gb, lanes), timeout=1200)
+        assert sn['error'] == '' and sn['digest'] == s['digest'] and sn['records'] == s['records'] and sn['bytes'] == s['bytes'], (n, s, sn, errn.decode()[-1500:])
+        sys.stderr.write('[headline] hg38-size x3: one context %.1f s, %d contexts on one GPU %.1f s (index build included)\n' % (sec, n, secn))
+    # every part against the compiled reference
+    assert hg38['bg_pb'].wait(timeout=900) == 0, open(os.path.join(work, 'pb_ref.idx.err')).read()[-2000:]
+    want = _parts_of(os.path.join(work, 'pb_ref'), PARTS); got = [tuple(x) for x in s['parts']]
+    assert len(got) == PARTS and sum(x[0] for x in got) == s['records'], s
+    bad = [p for p in range(PARTS) if got[p] != want[p]]
+    assert not bad, 'hg38-size x3: parts %r differ from the compiled reference (ours %r, reference %r)' % (bad, [got[p] for p in bad], [want[p] for p in bad])
+    assert sum(x[0] for x in want) == s['records'] and s['reads'] > 440000          # all of the set
 
-def test_hg38_size_ont_like_properties_and_head_parity(work, hg38):
+def test_hg38_size_ont_like_whole_set_equals_the_reference(work, hg38):
     ref, rd = hg38['ref'], hg38['ont']
-    head = os.path.join(work, 'ont_head.sam')
-    s, err, sec = _map_through_samcheck([CLI, '-xont.1dsq', ref, rd], rd, 20000, head)
+    s, err, sec = _map_through_samcheck([CLI, '-xont.1dsq', ref, rd], rd, 0, os.devnull)
     assert s['error'] == '' and s['reads'] == s['primary'] and s['contigs'] == 25, s
     assert s['bases_mapped'] > 2.5e9, s                                             # the whole 3.1 Gb set
-    assert hg38['bg_ont'].wait(timeout=900) == 0, open(os.path.join(work, 'ont_ref.sam.err')).read()[-2000:]
-    got = _md5_records(head); want = _md5_records(os.path.join(work, 'ont_ref.sam'))
-    assert got == want and got[1] >= 20000, 'hg38-size ONT-like set: the records of the first 20 000 reads differ from the compiled reference'
+    assert hg38['bg_ont'].wait(timeout=1200) == 0, open(os.path.join(work, 'ont_ref.idx.err')).read()[-2000:]
+    want = _parts_of(os.path.join(work, 'ont_ref'), PARTS); got = [tuple(x) for x in s['parts']]
+    bad = [p for p in range(PARTS) if got[p] != want[p]]
+    assert not bad, 'hg38-size ONT-like set: parts %r differ from the compiled reference (ours %r, reference %r)' % (bad, [got[p] for p in bad], [want[p] for p in bad])
+    assert sum(x[0] for x in want) == s['records'] and s['reads'] > 250000

@@ -4,6 +4,10 @@
  * Own PRNG (xoshiro256** seeded by splitmix64) so that streams are identical on every box.
  *
  *   gensim genome <seed> <total_len> <n_contigs> <repeat_frac> > ref.fa
+ *   gensim genomehard <seed> <total_len> <n_contigs> [repeat_frac = 0.45] > ref.fa
+ *       a reference with the repeat structure of a mammalian genome rather than a few planted families: SINE-like and LINE-like families with 10^4 .. 10^6 copies that
+ *       diverge 3 - 20 % from their consensus (LINE copies 5'-truncated), two hundred middle-sized families of 10 .. 10^4 copies, segmental duplications of 10 - 200 kb
+ *       at 95 - 99.5 % identity, satellite arrays (171-base units in higher-order blocks, tens of kb to megabases), microsatellites, and per contig one long N gap
  *   gensim reads  <seed> ref.fa <depth> <pacbio|ont> [fq] [len_mean len_sd] > reads.fa
  *   gensim reads  <seed> ref.fa <depth> <pacbio|ont> <fa|fq> <len_mean> <len_sd> <part> <n_parts> > reads.part.fa
  *       one of n_parts independent streams (seed + part, depth / n_parts each, read names r<part>.<i>_...): the parts are generated side by side and the
@@ -58,6 +62,97 @@ static int main_genome(int argc, char **argv)
 		for(uint64_t i = ul; i < ul * n; i++) g[pos + i] = g[pos + (i % ul)];
 	}
 	/* N runs */
+	for(int t = 0; t < (int)(total / 2000000) + 1 && total > 100000; t++) { uint64_t pos = below(total - 2000), l = 10 + below(500); memset(g + pos, 'N', l); }
+	for(int i = 0; i < nc; i++) { char name[64]; sprintf(name, "ctg%04d len=%lu", i, (unsigned long)(cs[i + 1] - cs[i])); put_fasta(stdout, name, g + cs[i], cs[i + 1] - cs[i]); }
+	return 0;
+}
+
+/* one copy of an element (consensus[from, len)) at dst, on a random strand, `div` of its bases substituted and a few short indels (an inserted / dropped base per 1 / div0 bases) */
+static char comp(char c);
+static void plant(char *g, uint64_t total, uint64_t dst, const char *cons, uint64_t from, uint64_t len, double div)
+{
+	if(dst + len + 8 > total) return;
+	const int rev = (int)(rnd() >> 63); uint64_t o = 0;
+	for(uint64_t i = 0; i < len && o < len; i++) {
+		char ch = rev ? comp(cons[from + len - 1 - i]) : cons[from + i];
+		const double x = unif();
+		if(x < div * 0.8) { ch = "ACGT"[rnd() >> 62]; }
+		else if(x < div * 0.9) { continue; }                                     /* base dropped */
+		else if(x < div) { g[dst + o++] = "ACGT"[rnd() >> 62]; if(o >= len) break; }      /* base inserted in front */
+		g[dst + o++] = ch;
+	}
+}
+static int main_genome_hard(int argc, char **argv)
+{
+	if(argc < 5) return 1;
+	seed_rng(strtoull(argv[2], 0, 0));
+	const uint64_t total = strtoull(argv[3], 0, 0); const int nc = atoi(argv[4]); const double rf = argc > 5 ? atof(argv[5]) : 0.45;
+	char *g = malloc(total + 16);
+	for(uint64_t i = 0; i < total; i++) g[i] = "ACGT"[rnd() >> 62];
+	uint64_t *cs = malloc(sizeof(uint64_t) * (nc + 1)); double *wts = malloc(sizeof(double) * nc), ws = 0;
+	for(int i = 0; i < nc; i++) { wts[i] = 0.2 + unif(); ws += wts[i]; }
+	cs[0] = 0; for(int i = 0; i < nc; i++) { cs[i + 1] = cs[i] + (uint64_t)(wts[i] / ws * total); } cs[nc] = total;
+	const uint64_t budget = (uint64_t)(rf * total);
+	char *cons = malloc(8192 + 16);
+	/* SINE-like: a few families of ~300-base elements, each copy 5 - 18 % off its consensus (22 % of the repeat budget: hundreds of thousands of copies in a 3 Gb genome) */
+	{
+		const int n_fam = 3; uint64_t left = budget * 22 / 100;
+		for(int f = 0; f < n_fam; f++) {
+			const uint64_t el = 270 + below(60), share = left / (uint64_t)(n_fam - f); const double age = 0.05 + 0.10 * unif();
+			for(uint64_t i = 0; i < el; i++) cons[i] = "ACGT"[rnd() >> 62];
+			for(uint64_t done = 0; done < share && total > 4 * el; done += el) plant(g, total, below(total - el - 8), cons, 0, el, age + 0.03 * unif());
+			left -= share;
+		}
+	}
+	/* LINE-like: 6 kb elements, copies truncated at their 5' end (most of them short), 3 - 20 % off */
+	{
+		const int n_fam = 4; uint64_t left = budget * 38 / 100;
+		for(int f = 0; f < n_fam; f++) {
+			const uint64_t el = 5000 + below(1500), share = left / (uint64_t)(n_fam - f); const double age = 0.03 + 0.14 * unif();
+			for(uint64_t i = 0; i < el; i++) cons[i] = "ACGT"[rnd() >> 62];
+			for(uint64_t done = 0; done < share && total > 4 * el;) { const double u = unif(); uint64_t ln = 300 + (uint64_t)((double)(el - 300) * u * u * u); plant(g, total, below(total - ln - 8), cons, el - ln, ln, age + 0.03 * unif()); done += ln; }
+			left -= share;
+		}
+	}
+	/* middle-sized families: 10 .. 10^4 copies (log-uniform) of 500 - 8 000-base elements, one age per family */
+	{
+		const int n_fam = 200; uint64_t left = budget * 20 / 100;
+		for(int f = 0; f < n_fam && left > 0; f++) {
+			const uint64_t el = 500 + below(7500); uint64_t copies = (uint64_t)exp(log(10.0) + unif() * (log(10000.0) - log(10.0)));
+			const double age = 0.01 + 0.18 * unif();
+			if(copies * el > left / (uint64_t)(n_fam - f) * 6) copies = left / (uint64_t)(n_fam - f) * 6 / el;
+			if(copies < 2 || total < 8 * el) continue;
+			for(uint64_t i = 0; i < el; i++) cons[i] = "ACGT"[rnd() >> 62];
+			for(uint64_t c = 0; c < copies; c++) plant(g, total, below(total - el - 8), cons, 0, el, age + 0.02 * unif());
+			left -= copies * el > left ? left : copies * el;
+		}
+	}
+	/* segmental duplications: 10 - 200 kb stretches (repeats and all) copied elsewhere at 95 - 99.5 % identity */
+	{
+		uint64_t left = budget * 8 / 100; const uint64_t lmax = total / 64 < 200000 ? total / 64 : 200000, lmin = lmax / 20 + 1;
+		while(left > lmin && lmax > 2000) {
+			const uint64_t ln = lmin + below(lmax - lmin), src = below(total - ln), dst = below(total - ln); const double id = 0.95 + 0.045 * unif();
+			if(src + ln > dst && dst + ln > src) continue;
+			for(uint64_t i = 0; i < ln; i++) { char ch = g[src + i]; if(unif() > id) ch = "ACGT"[rnd() >> 62]; g[dst + i] = ch; }
+			left -= ln > left ? left : ln;
+		}
+	}
+	/* satellite arrays: a 171-base unit, 12 variants of it (1 - 3 % apart) as one higher-order block, the block repeated with 0.2 - 1 % noise over tens of kb to megabases */
+	{
+		uint64_t left = budget * 10 / 100; const uint64_t amax = total / 40 < 3000000 ? total / 40 : 3000000;
+		char unit[256], *hor = malloc(12 * 256);
+		while(left > 20000 && amax > 20000) {
+			const uint64_t ul = 160 + below(24), alen = 20000 + below(amax - 20000), pos = below(total - alen - 1); const double noise = 0.002 + 0.008 * unif();
+			for(uint64_t i = 0; i < ul; i++) unit[i] = "ACGT"[rnd() >> 62];
+			for(int v = 0; v < 12; v++) for(uint64_t i = 0; i < ul; i++) hor[v * ul + i] = unif() < 0.02 ? "ACGT"[rnd() >> 62] : unit[i];
+			for(uint64_t i = 0; i < alen; i++) { char ch = hor[i % (12 * ul)]; if(unif() < noise) ch = "ACGT"[rnd() >> 62]; g[pos + i] = ch; }
+			left -= alen > left ? left : alen;
+		}
+	}
+	/* microsatellites */
+	for(uint64_t t = 0; t < total / 8000 + 1 && total > 10000; t++) { const uint64_t ul = 1 + below(6), n = 10 + below(50), pos = below(total - ul * n - 1); for(uint64_t i = ul; i < ul * n; i++) g[pos + i] = g[pos + (i % ul)]; }
+	/* N: one long gap per contig (half a per cent to two per cent of it), and short runs */
+	for(int i = 0; i < nc; i++) { const uint64_t cl = cs[i + 1] - cs[i]; if(cl < 20000) continue; const uint64_t l = cl / 200 + below(cl / 66), pos = cs[i] + cl / 4 + below(cl / 2 - l); memset(g + pos, 'N', l); }
 	for(int t = 0; t < (int)(total / 2000000) + 1 && total > 100000; t++) { uint64_t pos = below(total - 2000), l = 10 + below(500); memset(g + pos, 'N', l); }
 	for(int i = 0; i < nc; i++) { char name[64]; sprintf(name, "ctg%04d len=%lu", i, (unsigned long)(cs[i + 1] - cs[i])); put_fasta(stdout, name, g + cs[i], cs[i + 1] - cs[i]); }
 	return 0;
@@ -127,6 +222,7 @@ static int main_reads(int argc, char **argv)
 int main(int argc, char **argv)
 {
 	if(argc > 1 && strcmp(argv[1], "genome") == 0) return main_genome(argc, argv);
+	if(argc > 1 && strcmp(argv[1], "genomehard") == 0) return main_genome_hard(argc, argv);
 	if(argc > 1 && strcmp(argv[1], "reads") == 0) return main_reads(argc, argv);
 	fprintf(stderr, "usage: gensim genome <seed> <total_len> <n_contigs> <repeat_frac> | gensim reads <seed> ref.fa <depth> <pacbio|ont> [fq|fa] [len_mean len_sd]\n");
 	return 1;

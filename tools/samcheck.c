@@ -10,6 +10,11 @@
  *     inside the reference sequence the @SQ header announced
  * The records of the first N reads are copied to head.sam (for a byte comparison with the compiled reference at -t1).  Prints one JSON line: counts, the
  * first violation if any, and an order-dependent 2 x 64-bit digest of every record line (two streams of the same set must agree on it).
+ * Reads named r<p>.<i>_... (the parts tools/gensim writes side by side) also get a digest and a record count per part p ("parts": [[records, "digest"], ...]), so that
+ * the stream of a whole set can be compared with the compiled reference part by part:
+ *   cat last_reads_of_part_p-1.fa part_p.fa | oracle/_ref/minialign -t1 ref.mai | tools/samcheck --parts
+ * prints only those (no read file, no property checks); the few reads in front carry the state the reference's thread buffer would be in at the start of part p
+ * (DESIGN.md 5), their own records count under part p - 1 and are ignored by the caller.
  * Test infrastructure only; nothing in the product uses it.
  */
 #include <stdio.h>
@@ -30,8 +35,38 @@ static void line_hash(const char *p, size_t n, uint64_t *a, uint64_t *b)
 	*a = mix(h1); *b = mix(h2);
 }
 
+#define MAX_PARTS 64
+static uint64_t pd1[MAX_PARTS], pd2[MAX_PARTS], pn[MAX_PARTS];
+/* the part of a record by its QNAME (r<p>.<i>_...), -1 for any other name */
+static int part_of(const char *q, size_t n)
+{
+	if(n < 3 || q[0] != 'r') return -1;
+	int p = 0; size_t i = 1;
+	for(; i < n && q[i] >= '0' && q[i] <= '9' && i < 4; i++) p = p * 10 + (q[i] - '0');
+	if(i == 1 || i >= n || q[i] != '.' || p >= MAX_PARTS) return -1;
+	return p;
+}
+static void part_add(const char *line, size_t ln, uint64_t a, uint64_t b)
+{
+	const char *t = memchr(line, '\t', ln); const int p = part_of(line, t ? (size_t)(t - line) : ln);
+	if(p < 0) return;
+	pd1[p] = pd1[p] * 0x9e3779b97f4a7c15ull + a; pd2[p] = (pd2[p] ^ b) * 0xff51afd7ed558ccdull + 1; pn[p]++;
+}
+static void parts_print(FILE *out)
+{
+	int last = -1; for(int p = 0; p < MAX_PARTS; p++) if(pn[p]) last = p;
+	fprintf(out, "\"parts\": [");
+	for(int p = 0; p <= last; p++) fprintf(out, "%s[%lu, \"%016lx%016lx\"]", p ? ", " : "", (unsigned long)pn[p], (unsigned long)pd1[p], (unsigned long)pd2[p]);
+	fprintf(out, "]");
+}
 int main(int argc, char **argv)
 {
+	if(argc >= 2 && !strcmp(argv[1], "--parts")) {
+		char *line = NULL; size_t lcap = 0; ssize_t ln; uint64_t n_rec = 0;
+		while((ln = getline(&line, &lcap, stdin)) > 0) { if(line[0] == '@') continue; uint64_t a, b; line_hash(line, (size_t)ln, &a, &b); part_add(line, (size_t)ln, a, b); n_rec++; }
+		printf("{\"records\": %lu, ", (unsigned long)n_rec); parts_print(stdout); printf("}\n");
+		return 0;
+	}
 	if(argc < 4) { fprintf(stderr, "usage: samcheck reads.fa n_head head.sam < sam\n"); return 2; }
 	const uint64_t n_head = strtoull(argv[2], NULL, 10);
 	/* reads: names and lengths */
@@ -74,7 +109,7 @@ int main(int argc, char **argv)
 			continue;
 		}
 		bytes += (uint64_t)ln; n_rec++;
-		{ uint64_t a, b; line_hash(line, (size_t)ln, &a, &b); d1 = d1 * 0x9e3779b97f4a7c15ull + a; d2 = (d2 ^ b) * 0xff51afd7ed558ccdull + 1; }
+		{ uint64_t a, b; line_hash(line, (size_t)ln, &a, &b); d1 = d1 * 0x9e3779b97f4a7c15ull + a; d2 = (d2 ^ b) * 0xff51afd7ed558ccdull + 1; part_add(line, (size_t)ln, a, b); }
 		if(err[0]) continue;
 		/* fields */
 		char *f[11]; int nf = 0; char *p = line; f[nf++] = p;
@@ -119,7 +154,8 @@ int main(int argc, char **argv)
 	fclose(hf);
 	if(!err[0] && (uint64_t)(cur + 1) != n_rd) snprintf(err, sizeof(err), "%lu primary records for %lu reads", (unsigned long)n_prim, (unsigned long)n_rd);
 	for(char *q = err; *q; q++) if(*q == '"' || *q == '\\') *q = '\'';
-	printf("{\"reads\": %lu, \"records\": %lu, \"primary\": %lu, \"mapped\": %lu, \"unmapped\": %lu, \"secondary\": %lu, \"supplementary\": %lu, \"bytes\": %lu, \"bases_mapped\": %lu, \"contigs\": %lu, \"digest\": \"%016lx%016lx\", \"error\": \"%s\"}\n",
+	printf("{\"reads\": %lu, \"records\": %lu, \"primary\": %lu, \"mapped\": %lu, \"unmapped\": %lu, \"secondary\": %lu, \"supplementary\": %lu, \"bytes\": %lu, \"bases_mapped\": %lu, \"contigs\": %lu, \"digest\": \"%016lx%016lx\", \"error\": \"%s\", ",
 		(unsigned long)n_rd, (unsigned long)n_rec, (unsigned long)n_prim, (unsigned long)n_mapped, (unsigned long)n_unmapped, (unsigned long)n_sec, (unsigned long)n_supp, (unsigned long)bytes, (unsigned long)bases_mapped, (unsigned long)n_sq, (unsigned long)d1, (unsigned long)d2, err);
+	parts_print(stdout); printf("}\n");
 	return err[0] ? 1 : 0;
 }
