@@ -176,6 +176,7 @@ typedef struct {
 	/* the same for the first-round sort + chain kernel, and the number of reads whose seed array did not fit the LDS */
 	uint64_t k2_cycles_sort, k2_cycles_chain, k2_cycles_total, k2_reads_hbm;
 	uint64_t pool_grows, batch_splits;          /* batches run again with larger device pools (a pool or a per-read cap overflowed) / batches mapped in halves because no pool size held them */
+	uint64_t pool_regrows;                      /* batches whose sketch launch was repeated because they asked for more seed / rescue / root entries than the run had seen (pools sized to the demand) */
 	uint64_t text_bytes; double reader_ms;      /* the text readers of the streams so far: bytes brought to HBM, time of the uploader threads (summed over devices) */
 } mm_stats_t;
 void mm_stats(mm_align_t *a, mm_stats_t *out, int reset);

@@ -1177,6 +1177,11 @@ struct mm_align_s {
 	/* the other devices of the node: one primary context each (own streams, lanes, pools, DP workspaces, a replica of the index), owned by the first context.  The
 	 * streaming engine deals its batches over all of them; the per-batch entries stay on the first */
 	std::vector<mm_align_s *> peers;
+	/* what the batches of this device have asked of the seed / rescue / chain-root pools so far, in entries per base of batch (primary context; the lanes note it after
+	 * every sketch launch, note_demand): K1 counts a read's hits before it claims room for them (minialign.c:3454-3540 is what a read can emit), so the launch leaves the exact
+	 * demand in the pool cursors -- the pools are sized for what the run has seen (+ a quarter), not for the caps a read could reach, and a batch that asks for more
+	 * has its pools sized to its demand and its sketch launch run again (run_rounds) */
+	std::mutex need_mu; double need_seed = 0.30, need_resc = 0.03, need_root = 0.16; uint64_t batch_bases = 0;
 	/* experiment (MM_K3_CONCURRENT=n): at most n extension launches of this device in flight at a time, the lanes queue for their turn */
 	std::mutex k3_gate_mu; std::condition_variable k3_gate_cv; int k3_in_flight = 0;
 	mm_stats_t st; double t_wall0;
@@ -1248,6 +1253,28 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		hipLaunchKernelGGL(mm_sketch_seed_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k1);
 		CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k1_ms += ms; a->st.k1_launches++;
+		if(!rlen_fixed && a->batch_bases) {
+			/* the first sketch launch of a batch: the pool cursors hold what its reads asked for, exactly (a read counts its hits before it claims room).  Noted for
+			 * the batches to come; and a batch that asked for more than the pools hold gets pools of its size and the launch again -- a few milliseconds, early in a run */
+			unsigned long long t3[3]; CPY(a, t3, tops, sizeof(t3), hipMemcpyDeviceToHost);
+			mm_align_s *NP = a->root ? a->root : a; const double bb = (double)a->batch_bases;
+			{ std::lock_guard<std::mutex> lk(NP->need_mu); NP->need_seed = std::max(NP->need_seed, t3[0] / bb); NP->need_resc = std::max(NP->need_resc, t3[1] / bb); NP->need_root = std::max(NP->need_root, t3[2] / bb); }
+			if(t3[0] > a->seed_pool.n || t3[1] > a->resc_pool.n || t3[2] > a->root_pool.n) {
+				if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   the batch asks for %.1f / %.1f / %.1f M seed / rescue / root entries (%.3f / %.3f / %.3f per base), the pools hold %.1f / %.1f / %.1f M: sized again, sketch launch repeated\n",
+					t3[0] * 1e-6, t3[1] * 1e-6, t3[2] * 1e-6, t3[0] / bb, t3[1] / bb, t3[2] / bb, a->seed_pool.n * 1e-6, a->resc_pool.n * 1e-6, a->root_pool.n * 1e-6);
+				auto grow = [](uint64_t need) -> uint64_t { const uint64_t w = need + need / 8 + (1ull << 20), q = w < (64ull << 20) ? (1ull << 20) : (16ull << 20); return (w + q - 1) / q * q; };
+				if((t3[0] > a->seed_pool.n && !a->seed_pool.ensure(grow(t3[0]))) || (t3[1] > a->resc_pool.n && !a->resc_pool.ensure(grow(t3[1]))) || (t3[2] > a->root_pool.n && !a->root_pool.ensure(grow(t3[2])))) return false;
+				if(!getenv("MM_K2_LDS_CHAIN") && !a->k2w_scratch.ensure(a->seed_pool.n * 8)) return false;
+				a->st.pool_regrows++;
+				if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;          /* (the states as they were before the launch) */
+				CK(hipMemsetAsync(tops, 0, 3 * 8, a->stream)); CK(hipMemsetAsync(tops + 8, 0, 2 * 8, a->stream)); CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
+				k1.seed_pool = a->seed_pool.p; k1.seed_pool_cap = a->seed_pool.n; k1.resc_pool = a->resc_pool.p; k1.resc_pool_cap = a->resc_pool.n; k1.root_pool = a->root_pool.p; k1.root_pool_cap = a->root_pool.n;
+				CK(hipEventRecord(a->ev0, a->stream));
+				hipLaunchKernelGGL(mm_sketch_seed_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k1);
+				CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
+				CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k1_ms += ms; a->st.k1_launches++;
+			}
+		}
 	}
 	for(uint32_t round = 0; round < a->mi->n_occ && !work.empty(); round++) {
 		CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
@@ -1813,6 +1840,9 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 }
 
 bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen);
+/* minimizer records a read gets room for, per base: at most one per position; 2 / (w + 1) per base on average, so 2.6 / (w + 1) is ample (w = 10: 0.24); a read whose
+ * hashes keep falling emits one per position: after an overflow the batch is redone with room for that (scale > 1) */
+inline double min_cap_frac(uint32_t w, uint64_t scale) { return (scale > 1 || getenv("MM_POOLS_BY_CAP")) ? ((w < 4 || scale > 1) ? 1.0 : 0.5) : std::min(1.0, 2.6 / ((double)w + 1.0)); }
 /* DP workspace of a wave for reads up to qlen bases (a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors), qlen in steps of 8 k */
 uint64_t slab_bytes_for(uint32_t qlen) { qlen = (qlen + 8191u) & ~8191u; const uint64_t blocks = 2 * ((2ull * qlen + 8192) / 32 + 64); return (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull; }
 bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_qlen, uint64_t scale)
@@ -1826,12 +1856,21 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	  bases = (bases + bases / 8 + bq - 1) / bq * bq; }
 	ok &= a->d_in.ensure(n_reads); ok &= a->d_st.ensure(n_reads); ok &= a->d_work.ensure(n_reads);
 	ok &= a->q_pk.ensure(bases / 16 + 8); ok &= a->q_nm.ensure(bases / 32 + 8);
-	const uint64_t min_total = ((a->mi->w < 4 || scale > 1) ? bases : bases / 2) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
+	const uint64_t min_total = (uint64_t)((double)bases * min_cap_frac(a->mi->w, scale)) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
 	ok &= a->min_pool.ensure(min_total);
-	ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
-	if(!getenv("MM_K2_LDS_CHAIN")) { ok &= a->k2w_scratch.ensure(a->seed_pool.n * 16 / 3); }          /* (16 B per seed found, K2wArgs.scratch; the pool holds the reads' caps) */
-	ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
-	ok &= a->resc_pool.ensure(min_total * std::min<uint64_t>(scale, 4));
+	if(getenv("MM_POOLS_BY_CAP")) {          /* rounds 1-3: room for what the reads of the batch could emit at most */
+		ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
+		ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
+		ok &= a->resc_pool.ensure(min_total * std::min<uint64_t>(scale, 4));
+	} else {
+		/* room for what the batches of this run have asked for (entries per base, + a quarter; note_demand), in steps of 16 M entries; a batch that asks for more is
+		 * caught right behind its sketch launch (run_rounds) */
+		mm_align_s *NP = a->root ? a->root : a; double ns, nr, nt;
+		{ std::lock_guard<std::mutex> lk(NP->need_mu); ns = NP->need_seed; nr = NP->need_resc; nt = NP->need_root; }
+		auto room = [&](double per_base, uint64_t per_read) -> uint64_t { const uint64_t w = (uint64_t)((double)bases * per_base * 1.25) * scale + per_read * n_reads + (1ull << 20), q = w < (64ull << 20) ? (1ull << 20) : (16ull << 20); return (w + q - 1) / q * q; };
+		ok &= a->seed_pool.ensure(room(ns, 8)); ok &= a->root_pool.ensure(room(nt, 4)); ok &= a->resc_pool.ensure(room(nr, 2));
+	}
+	if(!getenv("MM_K2_LDS_CHAIN")) { ok &= a->k2w_scratch.ensure(a->seed_pool.n * 8); }          /* (16 B per seed found, K2wArgs.scratch; a read claims two pool entries per seed it can find) */
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
 	ok &= a->next_pool.ensure((uint64_t)std::max(a->n_waves, (a->root ? a->root : a)->slab_total) * MM_NEXT_STRIDE(a->next_cap));
 	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap);
@@ -2059,7 +2098,7 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 			out->k3_cycles_fill += q.k3_cycles_fill; out->k3_cycles_leaf += q.k3_cycles_leaf; out->k3_cycles_trace += q.k3_cycles_trace; out->k3_cycles_total += q.k3_cycles_total;
 			out->k3_cycles_next += q.k3_cycles_next; out->k3_cycles_max += q.k3_cycles_max;             /* summed over launches; k3_waves stays the per-launch count */
 			out->k2_cycles_sort += q.k2_cycles_sort; out->k2_cycles_chain += q.k2_cycles_chain; out->k2_cycles_total += q.k2_cycles_total; out->k2_reads_hbm += q.k2_reads_hbm;
-			out->pool_grows += q.pool_grows; out->batch_splits += q.batch_splits; out->text_bytes += q.text_bytes; out->reader_ms += q.reader_ms;
+			out->pool_grows += q.pool_grows; out->pool_regrows += q.pool_regrows; out->batch_splits += q.batch_splits; out->text_bytes += q.text_bytes; out->reader_ms += q.reader_ms;
 		});
 	}
 	if(reset) { a->t_wall0 = now_ms(); each_context(a, [](mm_align_t *ln) { memset(&ln->st, 0, sizeof(ln->st)); }); }
@@ -2093,12 +2132,13 @@ bool batch_upload(mm_align_t *a, Batch &b)
 	if(!ensure_pools(a, b.n, b.total + 64, b.max_qlen, b.scale)) return false;
 	if(verbose) { fprintf(stderr, "[minialign_amd]   pools %.1f ms\n", now_ms() - tv); tv = now_ms(); }
 	b.hst.assign(b.n, ReadState()); b.work.clear();
-	uint64_t moff = 0;
+	uint64_t moff = 0; const double mcf = min_cap_frac(a->mi->w, b.scale);
+	a->batch_bases = b.total;
 	for(uint32_t i = 0; i < b.n; i++) {
 		memset(&b.hst[i], 0, sizeof(ReadState));
 		/* minimizers of a read: at most one per position; 2 / (w + 1) per base on average, so half the length is ample from w = 4 up */
 		/* (a read whose hashes keep falling emits one per position: after a pool overflow the batch is redone with room for that) */
-		b.hst[i].min_off = moff; b.hst[i].min_cap = ((a->mi->w < 4 || b.scale > 1) ? b.lens[i] : b.lens[i] / 2) + 64; moff += b.hst[i].min_cap;
+		b.hst[i].min_off = moff; b.hst[i].min_cap = (uint32_t)((double)b.lens[i] * mcf) + 64; moff += b.hst[i].min_cap;
 		b.hst[i].bin_off = ~0ull; b.hst[i].apos0 = gaba::NIL; b.hst[i].rid_last = gaba::NIL; b.hst[i].pred_rid = gaba::NIL;
 		/* unmappable reads are skipped outright (minialign.c:4434) */
 		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
@@ -3405,7 +3445,7 @@ static int default_lanes();
 /* the largest batch the device memory allows on `lanes` lanes: the pools of a lane take about 52 bytes per base of its batches (seeds and the sweep's scratch are most of it,
  * ensure_pools); what they may take together is what was free when the first stream of the context started, less the DP workspaces at their largest (1.75 x the budget:
  * the ordinary class and a ladder of four above it) and 10 GB for the runtime (kernel scratch) and the text */
-static uint64_t batch_cap_bases(mm_align_t *a, int lanes)
+static uint64_t batch_cap_bases(mm_align_t *a, int lanes)  /* (bytes per base: 52 with the pools sized by caps, about 24 since they follow the demand) */
 {
 	mm_align_s *P = a->root ? a->root : a;
 	if(!P->mem_for_batches) {
@@ -3414,7 +3454,7 @@ static uint64_t batch_cap_bases(mm_align_t *a, int lanes)
 		const uint64_t taken = slab_budget + slab_budget * 3 / 4 + (10ull << 30) - std::min<uint64_t>(P->shared_slabs ? P->slabs.bytes : 0, slab_budget);          /* (workspaces already allocated are no longer in `avail`) */
 		P->mem_for_batches = avail > taken + (8ull << 30) ? avail - taken : (8ull << 30);
 	}
-	return std::max<uint64_t>(128ull << 20, P->mem_for_batches / (uint64_t)std::max(1, lanes) / 52);
+	return std::max<uint64_t>(128ull << 20, P->mem_for_batches / (uint64_t)std::max(1, lanes) / (getenv("MM_POOLS_BY_CAP") ? 52 : 28));
 }
 static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const PieceSink &sink, int lanes)
 {
