@@ -339,6 +339,8 @@ struct K1Args {
 	unsigned long long *stats;     /* [0] minimizers probed, [1] seeds */
 	const uint32_t *work;          /* read indices to process (n_reads entries) */
 	uint64_t *tap;                 /* stage tap (tests): when set, the stream word of every minimizer (hash << 8 | strand << 7 | position mod w, minialign.c:2402) beside its record */
+	unsigned long long *note;      /* pinned HOST memory (or NULL): the last wave of the launch leaves the three pool cursors there -- what the reads of the launch asked for -- so that the host
+	                                * has them when the launch is over without a copy of its own (a 24-byte D2H is a blit kernel that waits for a wave slot beside the extension waves: 17 ms per batch) */
 };
 
 /* code (0..3, 4 = N) of base p of the read */
@@ -515,7 +517,14 @@ __global__ void __launch_bounds__(256, MM_SHORT_KERNEL_WAVES) mm_sketch_seed_ker
 			st->root_off = to; st->root_cap = root_cap; st->n_root = 0; st->n_res = 0;
 		}
 	}
-	if(lane == 0) { atomicAdd(&a.stats[0], n_probe); atomicAdd(&a.stats[1], n_seedtot); }
+	if(lane == 0) {
+		atomicAdd(&a.stats[0], n_probe); atomicAdd(&a.stats[1], n_seedtot);
+		if(a.note) {
+			__threadfence();
+			const uint32_t prev = atomicAdd(a.counter + 1, 1u);          /* waves that are through (the word behind the work counter; zeroed with it) */
+			if(prev + 1 == gridDim.x * (blockDim.x / 64)) { a.note[0] = atomicAdd(a.seed_top, 0ull); a.note[1] = atomicAdd(a.resc_top, 0ull); a.note[2] = atomicAdd(a.root_top, 0ull); }
+		}
+	}
 }
 
 /* =====================================================================================================
@@ -1861,9 +1870,6 @@ __device__ __attribute__((noinline)) uint32_t k3_rescue_round(ReadState *st, uin
 #endif
 #define K3_TAB_WORDS 1536u
 #define K3_LDS_BYTES ((K3_TAB_WORDS + 16u) * 4u)          /* dynamic LDS of a launch with the rounds in the kernel: the tables of k3_rescue_round + their lock */
-#ifdef MM_K3_NUM_VGPR
-__attribute__((amdgpu_num_vgpr(MM_K3_NUM_VGPR)))
-#endif
 /* one thread per heavy read (the first n_heavy entries of the work list): the chains mm_extend will visit -- root order, up to the length test of
  * mm_search_load_root (minialign.c:3849) -- with the positions mm_search_load_pos gives their root seeds; the `apos >= rlen` test sees the length of the
  * reference the chain in front loaded (minialign.c:3864).  Reads with fewer than min_roots such chains are left alone. */
@@ -1905,6 +1911,9 @@ __global__ void __launch_bounds__(64) mm_spec_jobs_kernel(SpecJobsArgs a)
 	st->spec_off = (uint32_t)off; st->spec_n = cnt;
 }
 
+#ifdef MM_K3_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(MM_K3_NUM_VGPR)))
+#endif
 __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Args a)
 {
 	extern __shared__ uint32_t k3_tab[];       /* launched with 4 x 1536 words when the rounds run in the kernel (per wave: tables of k3_rescue_round's sort + chain), else with none:

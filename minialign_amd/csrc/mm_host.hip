@@ -1189,6 +1189,7 @@ struct mm_align_s {
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
 	void *pin_stage = nullptr; size_t pin_stage_cap = 0;      /* pinned staging buffer of the lane: the per-read state records and the packed reads cross PCIe through it (one DMA each instead of a train of staged blits) */
 	bool tap_stop = false;                 /* mm_batch_tap: stop behind the sort + chain stage of the first round */
+	unsigned long long *pin_note = nullptr;    /* 64 bytes of pinned host memory the sketch kernel writes the pool cursors to (K1Args.note) */
 	uint32_t k2_leaf_shift = 2;            /* leaf area of the first chaining attempt: (n + 1) >> shift; lowered when more than 2 % of a batch had to be retried */
 };
 
@@ -1246,7 +1247,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k1.min_pool = a->min_pool.p; k1.seed_pool = a->seed_pool.p; k1.seed_pool_cap = a->seed_pool.n; k1.seed_top = tops + 0;
 		k1.resc_pool = a->resc_pool.p; k1.resc_pool_cap = a->resc_pool.n; k1.resc_top = tops + 1;
 		k1.root_pool = a->root_pool.p; k1.root_pool_cap = a->root_pool.n; k1.root_top = tops + 2;
-		k1.counter = (uint32_t *)(tops + 16); k1.stats = tops + 8; k1.work = a->d_work.p; k1.tap = nullptr;
+		k1.counter = (uint32_t *)(tops + 16); k1.stats = tops + 8; k1.work = a->d_work.p; k1.tap = nullptr; k1.note = a->pin_note;
+		if(a->pin_note) { a->pin_note[0] = a->pin_note[1] = a->pin_note[2] = ~0ull; }
 		if(a->tap_stop) { if(!a->tap_words.ensure(a->min_pool.n)) return false; k1.tap = a->tap_words.p; }
 		uint32_t waves = std::min<uint32_t>(a->n_waves, (uint32_t)((work.size() + 3) & ~3ull));
 		CK(hipEventRecord(a->ev0, a->stream));
@@ -1256,7 +1258,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		if(!rlen_fixed && a->batch_bases) {
 			/* the first sketch launch of a batch: the pool cursors hold what its reads asked for, exactly (a read counts its hits before it claims room).  Noted for
 			 * the batches to come; and a batch that asked for more than the pools hold gets pools of its size and the launch again -- a few milliseconds, early in a run */
-			unsigned long long t3[3]; CPY(a, t3, tops, sizeof(t3), hipMemcpyDeviceToHost);
+			unsigned long long t3[3] = { a->pin_note[0], a->pin_note[1], a->pin_note[2] };          /* (written by the last wave of the launch, which is over) */
+			if(t3[0] == ~0ull) { CPY(a, t3, tops, sizeof(t3), hipMemcpyDeviceToHost); }
 			mm_align_s *NP = a->root ? a->root : a; const double bb = (double)a->batch_bases;
 			{ std::lock_guard<std::mutex> lk(NP->need_mu); NP->need_seed = std::max(NP->need_seed, t3[0] / bb); NP->need_resc = std::max(NP->need_resc, t3[1] / bb); NP->need_root = std::max(NP->need_root, t3[2] / bb); }
 			if(t3[0] > a->seed_pool.n || t3[1] > a->resc_pool.n || t3[2] > a->root_pool.n) {
@@ -1269,6 +1272,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;          /* (the states as they were before the launch) */
 				CK(hipMemsetAsync(tops, 0, 3 * 8, a->stream)); CK(hipMemsetAsync(tops + 8, 0, 2 * 8, a->stream)); CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
 				k1.seed_pool = a->seed_pool.p; k1.seed_pool_cap = a->seed_pool.n; k1.resc_pool = a->resc_pool.p; k1.resc_pool_cap = a->resc_pool.n; k1.root_pool = a->root_pool.p; k1.root_pool_cap = a->root_pool.n;
+				k1.note = nullptr;
 				CK(hipEventRecord(a->ev0, a->stream));
 				hipLaunchKernelGGL(mm_sketch_seed_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k1);
 				CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
@@ -1403,9 +1407,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		}
 		if(a->tap_stop) { return true; }
 		uint32_t k3_work_override = 0, n_heavy = 0; uint32_t seg_beg[8], seg_len[8];
+		std::vector<uint32_t> by_len(work);          /* (lives until the extension launch is over: its upload below is not waited for on its own) */
 		{
 			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
-			std::vector<uint32_t> by_len(work);
 			/* (ordering by the chain count, the best predictor of a read's DP work, was tried and is worse: the heaviest reads then run
 			 * under full contention from the start and become the critical path) */
 			if(qlens.size() == n_reads) { std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return qlens[x] > qlens[y]; }); }
@@ -1446,7 +1450,6 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				}
 			}
 			CK(hipMemcpyAsync(a->d_work.p, by_len.data(), by_len.size() * 4, hipMemcpyHostToDevice, a->stream));
-			CK(hipStreamSynchronize(a->stream));
 		}
 		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
 		K3Args k3; k3.idx = a->dix; k3.gc = a->gctx->hc; k3.roots = a->gctx->droots; k3.ar_ref = gaba::SeqArena{ a->ref_ar->pk, a->ref_ar->nm }; k3.ar_q = gaba::SeqArena{ a->q_pk.p, a->q_nm.p };
@@ -1965,6 +1968,7 @@ static bool make_streams(mm_align_s *a)
 	if(hipStreamCreateWithPriority(&a->stream, hipStreamNonBlocking, greatest) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) return false;
 	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithPriority(&a->k2s[i], hipStreamNonBlocking, greatest) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) return false; }
 	a->k2s_ok = true;
+	if(hipHostMalloc((void **)&a->pin_note, 64, hipHostMallocPortable) != hipSuccess) return false;
 	if(least != greatest) { if(hipStreamCreateWithPriority(&a->k3s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) return false; }
 	return true;
 }
@@ -2071,6 +2075,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
+	if(a->pin_note) (void)hipHostFree(a->pin_note);
 	free_chunk_pool(a->chunk_pool); a->chunk_pool = nullptr;
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
 	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < MM_SIDE) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
