@@ -71,6 +71,10 @@ struct ReadState {
 	uint32_t k3_t0, k3_wait_ticks;                              /* ... when its wave took it (s_memtime >> 8) and the ticks it waited for a DP workspace (profiling build) */
 	uint32_t n_bin; uint64_t bin_off;                 /* bin slot pool (uint64 slots) */
 	uint32_t n_aln; uint64_t aln_off;                 /* alignment record pool */
+	/* room of this read in the result-bin pool, the alignment pool and the position-hash pool, set by the host between chaining and extension from the number of chains
+	 * that pass the length test (n_pass): a read inside a repeat family walks hundreds of chains, each with a bin header, an alignment and a few hash entries, where the
+	 * typical read has one or two (0: the launch's defaults, K3Args.bin_cap_per_read / aln_cap_per_read / kh_cap at the read's number) */
+	uint32_t bin_cap, aln_cap, kh_cap, pad_; uint64_t kh_off;
 };
 enum : uint32_t { ERR_SEED_CAP = 1, ERR_DP_SLAB = 2, ERR_PATH_CAP = 4, ERR_SEG_CAP = 8, ERR_KH_CAP = 16, ERR_BIN_CAP = 32, ERR_ALN_CAP = 64, ERR_NEXT_CAP = 128, ERR_STACK = 256 };
 
@@ -1631,6 +1635,7 @@ struct K3Args {
 	 * fraction of the waves; a wave changes class when the read it takes asks for another one */
 	const K3Class *cls; uint32_t n_cls;
 	KhSlot *kh_pool; uint32_t kh_cap;                    /* per read (work index) */
+	unsigned long long *kh_top; uint64_t kh_base, kh_pool_cap;      /* larger tables for the reads with many chains: handed out behind the fixed regions (from kh_base on) */
 	uint32_t round;
 	uint64_t *next_pool; uint32_t next_cap;              /* per wave: (pdiff, sid) */
 	uint64_t *bin_pool; uint64_t bin_pool_cap; unsigned long long *bin_top; uint32_t bin_cap_per_read;
@@ -1911,6 +1916,59 @@ __global__ void __launch_bounds__(64) mm_spec_jobs_kernel(SpecJobsArgs a)
 	st->spec_off = (uint32_t)off; st->spec_n = cnt;
 }
 
+/* Room of a read in the result-bin pool, the alignment pool and the position-hash pool, by the chains the round at hand will walk (st->n_pass: from the chaining of
+ * this round -- K2 for the first, k3_rescue_round for the later ones): a chain costs a bin header (two words), every alignment it records a bin word, an alignment
+ * record and two position-hash entries.  The typical read walks one or two chains; a read inside a repeat family finds its hundreds of chains only in the later rounds
+ * (the repeat's minimizers pass the second or third occurrence threshold), and with one cap for all reads those few made the whole batch run again with 4 x, 16 x, 64 x
+ * the pools (the hard-repeat set: 250 - 400 chains, 300 alignments, 770 bin words on reads whose first round had three chains).  A read that needs more than it
+ * holds takes a new, larger region from the pool and carries over what it had -- the bins of dropped chains and the alignments they recorded stay readable at their
+ * old indices, as in the reference's vectors (a later alignment that ends where one of them did reads them, minialign.c:4018-4067), and the hash table keeps its
+ * layout (it grows in place, up to the size of its region).  Called by the whole wave at the start of every round of a read; the state goes through *st.
+ * Returns 0, or the error bit of the pool that is used up (the host then runs the batch again with larger pools). */
+__device__ __attribute__((noinline)) uint32_t k3_room(ReadState *st, uint32_t round, uint32_t r, uint64_t *bin_pool, uint64_t bin_pool_cap, unsigned long long *bin_top, uint32_t bin_def,
+	AlnRec *aln_pool, uint64_t aln_pool_cap, unsigned long long *aln_top, uint32_t aln_def, KhSlot *kh_pool, uint64_t kh_pool_cap, unsigned long long *kh_top, uint64_t kh_base, uint32_t kh_def)
+{
+	const int lane = lane_id();
+	const uint32_t np = (uint32_t)rdfirst((int)st->n_pass);
+	const uint64_t bin_off = rdfirst64(st->bin_off), aln_off = rdfirst64(st->aln_off);
+	const uint32_t bin_cap = (uint32_t)rdfirst((int)st->bin_cap), aln_cap = (uint32_t)rdfirst((int)st->aln_cap), n_aln = (uint32_t)rdfirst((int)st->n_aln);
+	const uint32_t want_bin = min(1u << 24, max(bin_def, 5u * np + 64u)), want_aln = min(1u << 22, max(aln_def, 3u * np + 32u));
+	const bool first = bin_off == ~0ull;
+	if(first || want_bin > bin_cap || want_aln > aln_cap) {
+		const uint32_t nb = first ? want_bin : max(want_bin, bin_cap), na = first ? want_aln : max(want_aln, aln_cap);
+		uint32_t bo_lo = 0, bo_hi = 0, ao_lo = 0, ao_hi = 0;
+		if(lane == 0) { const unsigned long long b = atomicAdd(bin_top, (unsigned long long)nb), q = atomicAdd(aln_top, (unsigned long long)na); bo_lo = (uint32_t)b; bo_hi = (uint32_t)(b >> 32); ao_lo = (uint32_t)q; ao_hi = (uint32_t)(q >> 32); }
+		const uint64_t bo = (uint64_t)(uint32_t)rdfirst((int)bo_lo) | ((uint64_t)(uint32_t)rdfirst((int)bo_hi) << 32), ao = (uint64_t)(uint32_t)rdfirst((int)ao_lo) | ((uint64_t)(uint32_t)rdfirst((int)ao_hi) << 32);
+		/* no room in the pools: the read is given up for this pass; it must not touch another read's region */
+		if(bo + nb > bin_pool_cap || ao + na > aln_pool_cap) { return ERR_BIN_CAP; }
+		if(!first) {
+			const uint32_t *ob = (const uint32_t *)(bin_pool + bin_off); uint32_t *nbp = (uint32_t *)(bin_pool + bo);
+			for(uint32_t i = (uint32_t)lane; i < 2u * bin_cap; i += 64) { nbp[i] = ob[i]; }
+			const uint32_t *oa = (const uint32_t *)(aln_pool + aln_off); uint32_t *nap = (uint32_t *)(aln_pool + ao);
+			for(uint32_t i = (uint32_t)lane; i < n_aln * (uint32_t)(sizeof(AlnRec) / 4); i += 64) { nap[i] = oa[i]; }
+		}
+		if(lane == 0) { st->bin_off = bo; st->aln_off = ao; st->bin_cap = nb; st->aln_cap = na; if(first) { st->n_bin = 0; st->n_aln = 0; } }          /* (first round of this read: mm_tbuf_clear, minialign.c:4402) */
+	}
+	/* the position hash: two entries per recorded alignment at a load of 0.4 */
+	uint32_t kcap = (uint32_t)rdfirst((int)st->kh_cap); uint64_t koff = rdfirst64(st->kh_off);
+	if(kcap == 0) { kcap = kh_def; koff = (uint64_t)r * kh_def; if(lane == 0) { st->kh_off = koff; st->kh_cap = kh_def; } }          /* the read's ordinary region */
+	uint32_t want_kh = kh_def; while(want_kh < 32u * np && want_kh < (1u << 22)) { want_kh <<= 1; }
+	if(want_kh > kcap && kh_top != nullptr) {
+		uint32_t ko_lo = 0, ko_hi = 0;
+		if(lane == 0) { const unsigned long long k = atomicAdd(kh_top, (unsigned long long)want_kh) + kh_base; ko_lo = (uint32_t)k; ko_hi = (uint32_t)(k >> 32); }
+		const uint64_t ko = (uint64_t)(uint32_t)rdfirst((int)ko_lo) | ((uint64_t)(uint32_t)rdfirst((int)ko_hi) << 32);
+		if(ko + want_kh > kh_pool_cap) { return ERR_KH_CAP; }
+		if(round != 0) {
+			const uint32_t mask = (uint32_t)rdfirst((int)st->kh_mask);
+			const uint32_t *ok_ = (const uint32_t *)(kh_pool + koff); uint32_t *nk_ = (uint32_t *)(kh_pool + ko);
+			for(uint32_t i = (uint32_t)lane; i < 4u * (mask + 1u); i += 64) { nk_[i] = ok_[i]; }
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if(lane == 0) { st->kh_off = ko; st->kh_cap = want_kh; }
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	return 0;
+}
 #ifdef MM_K3_NUM_VGPR
 __attribute__((amdgpu_num_vgpr(MM_K3_NUM_VGPR)))
 #endif
@@ -2210,22 +2268,20 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		uint32_t apos0 = (uint32_t)rdfirst((int)st->apos0), cond0 = (uint32_t)rdfirst((int)st->cond0);
 
 		/* per-read output regions */
+		/* room by the chains this round will walk (k3_room: a read that needs more than it holds moves to a larger region of the pools) */
+		{
+			const uint32_t e3 = k3_room(st, round, r, a.bin_pool, a.bin_pool_cap, a.bin_top, a.bin_cap_per_read, a.aln_pool, a.aln_pool_cap, a.aln_top, a.aln_cap_per_read, a.kh_pool, a.kh_pool_cap, a.kh_top, a.kh_base, a.kh_cap);
+			if(e3) { if(lane == 0) { st->err |= e3; } break; }
+		}
 		uint64_t bin_off = rdfirst64(st->bin_off), aln_off = rdfirst64(st->aln_off);
 		uint32_t n_bin = (uint32_t)rdfirst((int)st->n_bin), n_aln = (uint32_t)rdfirst((int)st->n_aln);
-		if(bin_off == ~0ull) {
-			unsigned long long bo = 0, ao = 0;
-			if(lane == 0) { bo = atomicAdd(a.bin_top, (unsigned long long)a.bin_cap_per_read); ao = atomicAdd(a.aln_top, (unsigned long long)a.aln_cap_per_read); }
-			bin_off = rdfirst64(bo); aln_off = rdfirst64(ao); n_bin = 0; n_aln = 0;
-			/* no room in the pools: the read is given up for this pass (the host grows the pools and redoes the batch); it must not touch another read's region */
-			if(bin_off + a.bin_cap_per_read > a.bin_pool_cap || aln_off + a.aln_cap_per_read > a.aln_pool_cap) { if(lane == 0) { st->err |= ERR_BIN_CAP; } break; }
-			/* first round of this read: mm_tbuf_clear (minialign.c:4402) */
-		}
+		const uint32_t bin_cap_r = (uint32_t)rdfirst((int)st->bin_cap), aln_cap_r = (uint32_t)rdfirst((int)st->aln_cap);
 		uint64_t *bin = a.bin_pool + bin_off;
 		AlnRec *alns = a.aln_pool + aln_off;
 		/* the hash is cleared once per read (mm_tbuf_clear, minialign.c:4402) and shared by the rounds of that read */
-		kh.a = a.kh_pool + (uint64_t)r * a.kh_cap;
+		kh.a = a.kh_pool + rdfirst64(st->kh_off); kh.cap = (uint32_t)rdfirst((int)st->kh_cap);
+		if(round != 0) { kh.mask = (uint32_t)rdfirst((int)st->kh_mask); kh.cnt = (uint32_t)rdfirst((int)st->kh_cnt); kh.ub = (uint32_t)rdfirst((int)st->kh_ub); }
 		if(round == 0) { if(lane == 0) { kh_clear(kh); } }
-		else { kh.mask = (uint32_t)rdfirst((int)st->kh_mask); kh.cnt = (uint32_t)rdfirst((int)st->kh_cnt); kh.ub = (uint32_t)rdfirst((int)st->kh_ub); }
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		x.err = 0;
 
@@ -2253,7 +2309,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			uint32_t plen = (uint32_t)OFS((int32_t)rdfirst((int)rt.plen));
 			if(plen * a.mcoef < 2.0 * a.min_score) { break; }
 			next_n = 0; dg_chains++;
-			if(n_bin + 2 > a.bin_cap_per_read) { err |= ERR_BIN_CAP; break; }
+			if(n_bin + 2 > bin_cap_r) { err |= ERR_BIN_CAP; break; }
 			uint32_t iid = n_bin;
 			if(lane == 0) { bin[iid] = 0; bin[iid + 1] = 0; }        /* header {n_aln, plen, lb, ub}: all-zero as in the reference *as built*  */
 			n_bin += 2;
@@ -2483,7 +2539,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				if(err & ERR_KH_CAP) { break; }
 				if(skip) { continue; }
 				/* trace into the output pools */
-				if(n_aln >= a.aln_cap_per_read) { err |= ERR_ALN_CAP; break; }
+				if(n_aln >= aln_cap_r) { err |= ERR_ALN_CAP; break; }
 				uint64_t need_words = (tplen + 31) / 32 + 2;
 				unsigned long long po = 0, so_ = 0;
 				if(lane == 0) { po = atomicAdd(a.path_top, (unsigned long long)need_words + 2); so_ = atomicAdd(a.seg_top, 8ull); }
@@ -2534,7 +2590,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					uint64_t ti = kh_put(kh, tk, false, &err);
 					isnew = (uint32_t)(kh.a[hi].v >> 32) == 0xffffffffu;
 					uint32_t nid;
-					if(isnew) { nid = n_bin; if(n_bin < a.bin_cap_per_read) { bin[n_bin] = (uint64_t)ai + 1; } else { err |= ERR_BIN_CAP; } }
+					if(isnew) { nid = n_bin; if(n_bin < bin_cap_r) { bin[n_bin] = (uint64_t)ai + 1; } else { err |= ERR_BIN_CAP; } }
 					else { nid = (uint32_t)(kh.a[hi].v >> 32); }
 					uint32_t *hdr = (uint32_t *)&bin[sr.iid];           /* { n_aln, plen, lb, ub } */
 					uint32_t lb = hdr[2], ubb = hdr[3];
@@ -2542,12 +2598,12 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					Root *rr = &root[sr.eid];
 					rr->plen -= (uint32_t)(ao.score + (int64_t)d2u32((double)(uint32_t)(ovl * 2) * ao.identity));
 					hdr[0] += isnew; hdr[1] += ao.plen; hdr[2] = min(lb, p1); hdr[3] = max(ubb, p3);
-					uint32_t cur = nid < a.bin_cap_per_read ? (uint32_t)bin[nid] - 1 : ai;
+					uint32_t cur = nid < bin_cap_r ? (uint32_t)bin[nid] - 1 : ai;
 					int64_t bscore = alns[cur].score;
 					if(bscore > ao.score) {
 						kh.a[ti].v = (uint64_t)sr.eid | (0xffffffffull << 32);
 					} else {
-						if(cur != ai && nid < a.bin_cap_per_read) { bin[nid] = (uint64_t)ai + 1; }
+						if(cur != ai && nid < bin_cap_r) { bin[nid] = (uint64_t)ai + 1; }
 						uint64_t nv = (uint64_t)sr.eid | ((uint64_t)nid << 32);
 						kh.a[ti].v = nv; kh.a[hi].v = nv;              /* *h = *t = ... (t first, then h, as the chained assignment evaluates) */
 					}

@@ -1459,7 +1459,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.cls = nullptr; k3.n_cls = 0;
 		{ const mm_align_s *P = a->root ? a->root : a; if(P->shared_slabs) { k3.slabs = P->slabs.p; k3.slab_bytes = P->slab_stride; k3.ring = P->slab_ring.p; k3.ring_ctr = P->slab_ring_ctr.p; k3.ring_n = P->slab_ring_n;
 			k3.cls = P->d_cls.p; k3.n_cls = (uint32_t)P->h_cls.size(); } }
-		k3.kh_pool = a->kh_pool.p; k3.kh_cap = a->kh_cap; k3.round = round; k3.next_pool = a->next_pool.p; k3.next_cap = a->next_cap;
+		k3.kh_pool = a->kh_pool.p; k3.kh_cap = a->kh_cap; k3.kh_top = tops + 7; k3.kh_base = (uint64_t)n_reads * a->kh_cap; k3.kh_pool_cap = a->kh_pool.n; k3.round = round; k3.next_pool = a->next_pool.p; k3.next_cap = a->next_cap;
 		k3.bin_pool = a->bin_pool.p; k3.bin_pool_cap = a->bin_pool.n; k3.bin_top = tops + 3; k3.bin_cap_per_read = a->bin_cap;
 		k3.aln_pool = a->aln_pool.p; k3.aln_pool_cap = a->aln_pool.n; k3.aln_top = tops + 4; k3.aln_cap_per_read = a->aln_cap;
 		k3.seg_pool = a->seg_pool.p; k3.seg_pool_cap = a->seg_pool.n; k3.seg_top = tops + 5;
@@ -1843,9 +1843,9 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 }
 
 bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen);
-/* minimizer records a read gets room for, per base: at most one per position; 2 / (w + 1) per base on average, so 2.6 / (w + 1) is ample (w = 10: 0.24); a read whose
+/* minimizer records a read gets room for, per base: at most one per position; 2 / (w + 1) per base on average, so 4 / (w + 1) is ample for all but the reads inside low-complexity sequence (w = 10: 0.36; a run of one repeated k-mer emits a minimizer per base); a read whose
  * hashes keep falling emits one per position: after an overflow the batch is redone with room for that (scale > 1) */
-inline double min_cap_frac(uint32_t w, uint64_t scale) { return (scale > 1 || getenv("MM_POOLS_BY_CAP")) ? ((w < 4 || scale > 1) ? 1.0 : 0.5) : std::min(1.0, 2.6 / ((double)w + 1.0)); }
+inline double min_cap_frac(uint32_t w, uint64_t scale) { return (scale > 1 || getenv("MM_POOLS_BY_CAP")) ? ((w < 4 || scale > 1) ? 1.0 : 0.5) : std::min(1.0, 4.0 / ((double)w + 1.0)); }
 /* DP workspace of a wave for reads up to qlen bases (a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors), qlen in steps of 8 k */
 uint64_t slab_bytes_for(uint32_t qlen) { qlen = (qlen + 8191u) & ~8191u; const uint64_t blocks = 2 * ((2ull * qlen + 8192) / 32 + 64); return (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull; }
 bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_qlen, uint64_t scale)
@@ -1874,11 +1874,13 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 		ok &= a->seed_pool.ensure(room(ns, 8)); ok &= a->root_pool.ensure(room(nt, 4)); ok &= a->resc_pool.ensure(room(nr, 2));
 	}
 	if(!getenv("MM_K2_LDS_CHAIN")) { ok &= a->k2w_scratch.ensure(a->seed_pool.n * 8); }          /* (16 B per seed found, K2wArgs.scratch; a read claims two pool entries per seed it can find) */
-	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap);
+	/* (the result pools carry room beyond the reads' ordinary regions: the few reads with hundreds of chains take larger ones as they go, mm_extend_kernel) */
+	const uint64_t heavy = bases / 64 + (1ull << 16);
+	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap + 8 * heavy);
 	ok &= a->next_pool.ensure((uint64_t)std::max(a->n_waves, (a->root ? a->root : a)->slab_total) * MM_NEXT_STRIDE(a->next_cap));
-	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap);
-	ok &= a->aln_pool.ensure(((uint64_t)n_reads + 2048) * a->aln_cap);
-	ok &= a->seg_pool.ensure((uint64_t)n_reads * a->aln_cap * 2 + 4096);
+	ok &= a->bin_pool.ensure(((uint64_t)n_reads + 2048) * a->bin_cap + 4 * heavy);
+	ok &= a->aln_pool.ensure(((uint64_t)n_reads + 2048) * a->aln_cap + heavy);
+	ok &= a->seg_pool.ensure((uint64_t)n_reads * a->aln_cap * 2 + 4096 + 8 * heavy);
 	ok &= a->path_pool.ensure((bases / 4 + 1024ull * n_reads) * scale + (1ull << 20));
 	/* DP workspace: a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors */
 	/* re-allocating tens of GB costs seconds: size for the longest read of the whole input when the caller knows it (qlen_hint), in steps of 8 k bases */
@@ -2276,7 +2278,17 @@ int batch_run_spec(mm_align_t *a, Batch &b)
 	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return -1;
 	b.used.assign(n_reads, 0);
 	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen(); } }
-	for(uint32_t i = 0; i < n_reads; i++) if(hst[i].err) return 1;
+	{
+		/* which caps gave way, and on how many reads: said once per attempt (the batch is then run again with larger pools) */
+		uint32_t bits = 0, n_bad = 0, first = 0; for(uint32_t i = 0; i < n_reads; i++) if(hst[i].err) { if(!n_bad) first = i; bits |= hst[i].err; n_bad++; }
+		if(n_bad) {
+			static const char *nm[9] = { "seed / minimizer room", "DP workspace", "path pool", "segment pool", "position hash", "result bins", "alignments per read", "next-seed list", "sort stack" };
+			std::string w; for(int k = 0; k < 9; k++) if(bits & (1u << k)) { if(!w.empty()) w += ", "; w += nm[k]; }
+			fprintf(stderr, "[minialign_amd] %u of %u reads of a batch ran out of room (%s); the first: read %u, %u bases, %u seeds, %u chains of which %u pass the length test, err 0x%x; it holds %u of %u bin words, %u of %u alignments, a position hash of %u of %u slots; pools: bins %.1f M words, alignments %.2f M\n", n_bad, n_reads, w.c_str(), first, b.lens[first], hst[first].seed_n0, hst[first].n_root, hst[first].n_pass, hst[first].err,
+				hst[first].n_bin, hst[first].bin_cap, hst[first].n_aln, hst[first].aln_cap, hst[first].kh_cnt, hst[first].kh_cap, a->bin_pool.n * 1e-6, a->aln_pool.n * 1e-6);
+			return 1;
+		}
+	}
 	return 0;
 }
 int batch_run_once(mm_align_t *a, Batch &b)
