@@ -48,6 +48,8 @@ void mm_idx_destroy(mm_idx_t *mi);
 int mm_idx_dump(mm_idx_t const *mi, FILE *fp);
 mm_idx_t *mm_idx_load(FILE *fp, int *at_eof);
 uint32_t mm_idx_n_seq(mm_idx_t const *mi);
+/* test entry: the 2-bit + N-mask reference a device-built index holds in HBM against the host's conversion of the same text; returns the number of differing bases (-1: nothing to compare) */
+int64_t mm_idx_ref_check(mm_idx_t const *mi);
 uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i);
 uint32_t mm_idx_max_len(mm_idx_t const *mi);          /* length of the longest reference sequence */
 /* mm_idx_get (minialign.c:2728) on the host copy: writes up to max values (pos | rid << 32), returns the count */

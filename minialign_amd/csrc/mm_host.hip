@@ -1091,6 +1091,29 @@ extern "C" mm_idx_t *mm_idx_load(FILE *fp, int *at_eof)
 	if(!ok || mi->seq.empty()) { delete mi; return NULL; }
 	return mi;
 }
+/* test entry: the packed reference of a device-built index (K0 over the text in HBM: mm_text_codes_tiled_kernel + mm_codes_pack_kernel) brought back and compared base by
+ * base with the host's conversion of the same text (ref_codes: the table of minialign.c:223-229).  Returns the number of differing bases (the first few go to stderr),
+ * -1 when there is nothing on the device to compare */
+extern "C" int64_t mm_idx_ref_check(mm_idx_t const *mi)
+{
+	if(!mi->on_device || !mi->ref_ar) return -1;
+	(void)hipSetDevice(mi->dev);
+	const uint64_t n = mi->ref_ar->n, nw = (n + 15) / 16 + 4, nn = (n + 31) / 32 + 4;
+	std::vector<uint32_t> pk(nw), nm(nn);
+	if(hipMemcpy(pk.data(), mi->ref_ar->pk, nw * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(nm.data(), mi->ref_ar->nm, nn * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	uint64_t off = 0; std::atomic<int64_t> bad{0}; std::mutex pm;
+	std::vector<uint64_t> offs; for(const HSeq &q : mi->seq) { offs.push_back(off); off += ((uint64_t)q.blen() + 63) & ~63ull; }
+	host_parallel((uint32_t)mi->seq.size(), [&](uint32_t t, uint32_t nth) {
+		for(size_t i = t; i < mi->seq.size(); i += nth) {
+			const std::vector<uint8_t> &c = ref_codes(mi, (uint32_t)i);
+			for(uint64_t j = 0; j < c.size(); j++) {
+				const uint64_t p = offs[i] + j; const uint8_t d = ((nm[p >> 5] >> (p & 31)) & 1) ? 4 : (uint8_t)((pk[p >> 4] >> (2 * (p & 15))) & 3);
+				if(d != c[j]) { if(bad.fetch_add(1) < 8) { std::lock_guard<std::mutex> lk(pm); fprintf(stderr, "[minialign_amd] reference check: sequence %zu (`%s') base %lu: %u on the device, %u from the text\n", i, mi->seq[i].name.c_str(), (unsigned long)j, d, c[j]); } }
+			}
+		}
+	}, 32);
+	return bad.load();
+}
 extern "C" uint32_t mm_idx_n_seq(mm_idx_t const *mi) { return (uint32_t)mi->seq.size(); }
 extern "C" uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i) { return mi->occ[i]; }
 extern "C" uint32_t mm_idx_max_len(mm_idx_t const *mi) { uint32_t m = 0; for(const HSeq &q : mi->seq) m = std::max<uint32_t>(m, q.blen()); return m; }
@@ -1190,6 +1213,7 @@ struct mm_align_s {
 	void *pin_stage = nullptr; size_t pin_stage_cap = 0;      /* pinned staging buffer of the lane: the per-read state records and the packed reads cross PCIe through it (one DMA each instead of a train of staged blits) */
 	bool tap_stop = false;                 /* mm_batch_tap: stop behind the sort + chain stage of the first round */
 	unsigned long long *pin_note = nullptr;    /* 64 bytes of pinned host memory the sketch kernel writes the pool cursors to (K1Args.note) */
+	std::vector<uint32_t> ran_with;            /* the carried reference length every read of the batch at hand was handed before its extension launch (run_rounds) */
 	uint32_t k2_leaf_shift = 2;            /* leaf area of the first chaining attempt: (n + 1) >> shift; lowered when more than 2 % of a batch had to be retried */
 };
 
@@ -1397,8 +1421,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(rlen_fixed) { for(size_t i = 0; i < work.size(); i++) hst[work[i]].rlen = (*rlen_fixed)[i]; }
 			else {
 				uint32_t cur = a->rlen_carry;
+				a->ran_with.resize(n_reads);
 				for(uint32_t i = 0; i < n_reads; i++) {
-					hst[i].rlen = cur;
+					hst[i].rlen = cur; a->ran_with[i] = cur;          /* (what the read runs with, kept as it is handed out: see batch_run_spec) */
 					if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen();
 				}
 			}
@@ -2275,9 +2300,15 @@ int batch_run_spec(mm_align_t *a, Batch &b)
 {
 	const uint32_t n_reads = b.n;
 	std::vector<ReadState> &hst = b.hst;
+	a->ran_with.clear();
 	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return -1;
-	b.used.assign(n_reads, 0);
-	{ uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen(); } }
+	/* what every read ran with: the values handed out BEFORE the extension launch (run_rounds).  They must not be derived again from the reads' states afterwards: a read
+	 * that goes on to the next occurrence threshold is chained again inside the launch (k3_rescue_round) and then carries the prediction of THAT chaining in pred_rid,
+	 * while the reads behind it ran with the prediction of its first one -- derived afterwards, `used` then said what the reads should have run with, the check against
+	 * the true chain of values found nothing to re-run, and a read whose `apos >= rlen` decision the difference flips kept the records of the wrong decision (one read
+	 * of the 266 589 of the ONT-like hg38-size set, found by the whole-set comparison of round 4; rounds 1-3 compared the first 20 000) */
+	if(a->ran_with.size() == n_reads) { b.used = a->ran_with; }
+	else { b.used.assign(n_reads, 0); uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen(); } }
 	{
 		/* which caps gave way, and on how many reads: said once per attempt (the batch is then run again with larger pools) */
 		uint32_t bits = 0, n_bad = 0, first = 0; for(uint32_t i = 0; i < n_reads; i++) if(hst[i].err) { if(!n_bad) first = i; bits |= hst[i].err; n_bad++; }
@@ -3317,6 +3348,16 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 				}
 				else if(ok) {
 					b.ran = true;
+					if(const char *cfn = getenv("MM_DUMP_CARRY")) {          /* diagnostics: what every read ran with and left behind (the carried reference length), in batch order */
+						static std::mutex dmu; std::lock_guard<std::mutex> dl(dmu);
+						if(FILE *fp = fopen(cfn, k == 0 ? "w" : "a")) {
+							for(uint32_t i = 0; i < b.n; i++) {
+								std::string nm; if(b.tsrc) { const char *q = b.tsrc->p + b.trec[i].start + 1, *e = b.tsrc->p + b.tsrc->n; while(q < e && *q != ' ' && *q != '\t' && *q != '\n') nm.push_back(*q++); } else if(i < b.names.size()) nm = b.names[i];
+								fprintf(fp, "%s\t%u\t%u\t%u\t%d\t%u\n", nm.c_str(), b.used[i], b.hst[i].apos0, b.hst[i].cond0, b.hst[i].rid_last == gaba::NIL ? -1 : (int)b.hst[i].rid_last, b.hst[i].n_res);
+							}
+							fclose(fp);
+						}
+					}
 					const uint32_t out = batch_carry_out(c, b, truth);
 					{
 						std::lock_guard<std::mutex> lk(mu); carry = out; verified = k + 1;

@@ -1476,6 +1476,7 @@ int om_main_files(om_opt_t const *op, char const *const *files, int nf, FILE *ou
 			if(om_read_error) { om_seqs_free(&qs); om_align_free(al); om_idx_free(mi); om_seqs_free(&ref); return 4; }
 			for(uint64_t i = 0; i < qs.n; i++) {
 				double t1 = now_s();
+				if(getenv("OM_DEBUG_CARRY")) { fprintf(stderr, "carry\t%s\t%u\n", qs.a[i].name, al->rlen); }          /* what this read starts with: the length of the reference the reads before it loaded last (minialign.c:3864) */
 				om_reg_t *reg = om_align_seq(al, qs.a[i].l_seq, qs.a[i].seq);
 				tmap += now_s() - t1; nb += qs.a[i].l_seq;
 				om_print_record(out, &o, ref.a, &qs.a[i], reg);
