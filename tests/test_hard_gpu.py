@@ -15,11 +15,11 @@ def test_hard_repeats_20000_reads_equal_the_reference():
     d = tempfile.mkdtemp(prefix='mmhard_')
     try:
         ref, rd, parts = H._generate(d, 'hard', (0x5eed0011, 400000000, 12, 0.45), (0x5eed0012, 1.0, 'pacbio'), keep_parts=True, hard=True)
-        bg = H._reference_by_parts('pacbio', ref, parts, os.path.join(d, 'hard_ref'), threads=32)
+        bg = H._reference_by_parts('pacbio', ref, parts, os.path.join(d, 'hard_ref'), threads=32, group=2)          # (a 400 Mb index: 2.5 GB per process)
         s, err, sec = H._map_through_samcheck([H.CLI, '-xpacbio', ref, rd], rd, 0, os.devnull, timeout=300)
         assert s['error'] == '' and s['reads'] == s['primary'] and s['reads'] >= 19000, s
         assert bg.wait(timeout=900) == 0, open(os.path.join(d, 'hard_ref.idx.err')).read()[-2000:]
-        want = H._parts_of(os.path.join(d, 'hard_ref'), H.PARTS); got = [tuple(x) for x in s['parts']]
+        want = H._parts_of(os.path.join(d, 'hard_ref'), H.PARTS, group=2); got = [tuple(x) for x in s['parts']]
         bad = [p for p in range(H.PARTS) if got[p] != want[p]]
         assert not bad, 'hard-repeat set: parts %r differ from the compiled reference (ours %r, reference %r)' % (bad, [got[p] for p in bad], [want[p] for p in bad])
         assert sum(x[0] for x in want) == s['records']

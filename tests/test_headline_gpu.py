@@ -5,8 +5,8 @@ with several threads the reference's own output depends on which thread buffer a
         same set over 2 / 4 device contexts of one process and over 8 ranks of minialign_amd.multi, all on cuda:0, identical to the single stream);
   (ii)  human hg38-size reference (3.1 Gb, 25 contigs) x PBSIM-like x3 (9.3 Gb, the headline set): size-independent properties of the whole 13 GB stream
         (tools/samcheck.c: one primary record per read in input order, every CIGAR adds up to its read and stays inside its contig, ...), EVERY record of it against
-        the compiled reference (all 446 956 reads: the reference maps the 16 parts of the set in 16 -t1 processes side by side, each primed with the last reads of the
-        part in front; a digest per part) (and, with MM_TEST_CONTEXTS_AT_SCALE set, the same set over 2 and 4 device contexts of ONE process identical to the single stream);
+        the compiled reference (all 446 956 reads: the reference maps the 16 parts of the set in four -t1 processes side by side, four consecutive parts each, primed with
+        the last reads of the part in front; a digest per part) (and, with MM_TEST_CONTEXTS_AT_SCALE set, the same set over 2 and 4 device contexts of ONE process identical to the single stream);
   (iii) the hg38-size reference x ONT-like reads (3.1 Gb) with -xont.1dsq: properties of the whole stream, every record of it against the compiled reference likewise.
 
 The reference runs (index files, then the -t1 processes) go on in the background on host cores while the device maps.  Skipped where the compiled reference
@@ -57,28 +57,34 @@ def _last_records(fn, n, window):
     assert len(starts) >= n, 'window too small for %d records' % n
     return tail[starts[-n]:]
 
-def _reference_by_parts(preset, ref, parts, out, threads=32, primer=4, window=8 << 20):
-    """The compiled reference over a WHOLE set, part by part: its index file (with `threads` threads), then one -t1 process per part, side by side, each fed the last
-    `primer` reads of the part in front and then its own part -- so that its thread buffer holds, at the first read of the part, what a single -t1 stream over the whole
-    set would hold there (the carried reference length) -- through tools/samcheck --parts (a digest and a record count per part).  Returns the Popen of the
-    shell that runs it all; part p's line lands in out.<p>.json"""
+def _reference_by_parts(preset, ref, parts, out, threads=32, primer=4, window=8 << 20, group=4, wait_for=None):
+    """The compiled reference over a WHOLE set: its index file (with `threads` threads), then -t1 processes side by side, each over `group` consecutive parts (one
+    stream: its thread buffer carries the state from part to part as a single run over the whole set would) and fed, in front of them, the last `primer` reads of the part
+    before -- so that it holds, at the first read of its first part, what the single run would hold there (the carried reference length) -- through
+    tools/samcheck --parts (a digest and a record count per part).  HOST MEMORY: a reference process with a human-size index takes 18 GB; the first version of this
+    ran one per part for two sets at once (32 x 18 GB beside the index builds) and three gpurun boxes were lost under it.  Four at a time here (72 GB), and the sets
+    one after the other (`wait_for`: the Popen of the set in front).  Returns the Popen of the shell that runs it all; the line of parts [g, g + group) lands in out.<g>.json"""
     mai = out + '.mai'; sc = _samcheck()
-    lines = ['%s -x%s -t%d -d %s %s 2> %s.idx.err || exit 1' % (REFBIN, preset, threads, mai, ref, out)]
-    for p, fn in enumerate(parts):
-        pf = '%s.primer.%02d.fa' % (out, p)
-        with open(pf, 'wb') as g:
-            if p: g.write(_last_records(parts[p - 1], primer, window))
-        lines.append('( cat %s %s | %s -x%s -t1 %s 2> %s.%02d.err | %s --parts > %s.%02d.json ) &' % (pf, fn, REFBIN, preset, mai, out, p, sc, out, p))
+    lines = []
+    if wait_for is not None: lines.append('while kill -0 %d 2>/dev/null; do sleep 1; done' % wait_for.pid)
+    lines.append('%s -x%s -t%d -d %s %s 2> %s.idx.err || exit 1' % (REFBIN, preset, threads, mai, ref, out))
+    for g in range(0, len(parts), group):
+        pf = '%s.primer.%02d.fa' % (out, g)
+        with open(pf, 'wb') as f:
+            if g: f.write(_last_records(parts[g - 1], primer, window))
+        lines.append('( cat %s %s | %s -x%s -t1 %s 2> %s.%02d.err | %s --parts > %s.%02d.json ) &' % (pf, ' '.join(parts[g:g + group]), REFBIN, preset, mai, out, g, sc, out, g))
     lines.append('wait; rm -f %s' % mai)
     return subprocess.Popen(['bash', '-c', '\n'.join(lines)])
 
-def _parts_of(out, n):
-    """[(records, digest)] of parts 0 .. n - 1 as the reference processes left them: part p from the process that mapped part p"""
+def _parts_of(out, n, group=4):
+    """[(records, digest)] of parts 0 .. n - 1 as the reference processes left them: part p from the process that mapped it (the primer reads in front of a process' first
+    part count under the part before and are ignored)"""
     got = []
-    for p in range(n):
-        with open('%s.%02d.json' % (out, p)) as f: d = json.loads(f.read().strip().splitlines()[-1])
-        assert len(d['parts']) > p, ('part %d' % p, d)
-        got.append(tuple(d['parts'][p]))
+    for g in range(0, n, group):
+        with open('%s.%02d.json' % (out, g)) as f: d = json.loads(f.read().strip().splitlines()[-1])
+        for p in range(g, min(n, g + group)):
+            assert len(d['parts']) > p, ('part %d' % p, d)
+            got.append(tuple(d['parts'][p]))
     return got
 
 def _head_fasta(rd, n, out):
@@ -124,7 +130,8 @@ def work():
     yield d
     shutil.rmtree(d, ignore_errors=True)
 
-def test_dm6_size_x20_whole_sam_equals_the_reference(work):
+def test_dm6_size_x20_whole_sam_equals_the_reference(work, hg38):
+    # (hg38: asked for here so that the reference's runs over the two human-size sets are under way in the background while this test runs)
     ref, rd = _generate(work, 'dm6', (0x5eed0001, 143700000, 1870, 0.05), (0x5eed0002, 20.0, 'pacbio'))
     want = os.path.join(work, 'dm6_ref.sam')
     bg = _reference_in_background('pacbio', ref, rd, want)
@@ -161,7 +168,7 @@ def hg38(work):
     ref, rd, pb_parts = _generate(work, 'hg38', genome, (0x5eed0002, 3.0, 'pacbio'), keep_parts=True)
     bg_pb = _reference_by_parts('pacbio', ref, pb_parts, os.path.join(work, 'pb_ref'))
     _, ont_rd, ont_parts = _generate(work, 'hg38', genome, (0x5eed0003, 1.0, 'ont'), rd_tag='ont', keep_parts=True)
-    bg_ont = _reference_by_parts('ont.1dsq', ref, ont_parts, os.path.join(work, 'ont_ref'), window=64 << 20)
+    bg_ont = _reference_by_parts('ont.1dsq', ref, ont_parts, os.path.join(work, 'ont_ref'), window=64 << 20, wait_for=bg_pb)
     yield dict(ref=ref, rd=rd, ont=ont_rd, bg_pb=bg_pb, bg_ont=bg_ont)
     for b in (bg_pb, bg_ont):
         if b.poll() is None: b.kill()
@@ -190,7 +197,7 @@ def test_hg38_size_ont_like_whole_set_equals_the_reference(work, hg38):
     s, err, sec = _map_through_samcheck([CLI, '-xont.1dsq', ref, rd], rd, 0, os.devnull)
     assert s['error'] == '' and s['reads'] == s['primary'] and s['contigs'] == 25, s
     assert s['bases_mapped'] > 2.5e9, s                                             # the whole 3.1 Gb set
-    assert hg38['bg_ont'].wait(timeout=1200) == 0, open(os.path.join(work, 'ont_ref.idx.err')).read()[-2000:]
+    assert hg38['bg_ont'].wait(timeout=1500) == 0, open(os.path.join(work, 'ont_ref.idx.err')).read()[-2000:]
     want = _parts_of(os.path.join(work, 'ont_ref'), PARTS); got = [tuple(x) for x in s['parts']]
     bad = [p for p in range(PARTS) if got[p] != want[p]]
     assert not bad, 'hg38-size ONT-like set: parts %r differ from the compiled reference (ours %r, reference %r)' % (bad, [got[p] for p in bad], [want[p] for p in bad])
