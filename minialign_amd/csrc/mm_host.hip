@@ -1451,6 +1451,25 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				auto mid = std::stable_partition(by_len.begin(), by_len.end(), [&](uint32_t x) { return hst[x].w_pass >= thr && hst[x].n_pass >= 2; });
 				std::stable_sort(by_len.begin(), mid, [&](uint32_t x, uint32_t y) { return hst[x].w_pass > hst[y].w_pass; });
 				n_heavy = (uint32_t)(mid - by_len.begin());
+				/* ... and, in front of those, the reads that found NO chain worth a trial at the first occurrence threshold but have rescue minimizers waiting: they go on to the
+				 * next thresholds inside the launch, and a read inside a repeat family then finds its hundreds of chains there and walks them on its one wave -- seconds, on the
+				 * hard-repeat set (6 M DP vectors on a wave while the rest of the launch has long finished).  Nothing spreads that walk yet; starting it when the
+				 * launch starts at least overlaps it with the bulk.  At most a 64th of the list, the ones with the most rescue hits first; on the sets without such repeats these
+				 * are a handful of reads */
+				if(!getenv("MM_K3_NO_RESCUE_FIRST")) {
+					auto resc_hits = [&](uint32_t x) -> uint32_t { const uint32_t half = hst[x].seed_cap / 2, base = hst[x].seed_n0 + 2; return half > base ? half - base : 0u; };
+					std::vector<uint32_t> front;
+					for(uint32_t x : by_len) { if(hst[x].n_pass == 0 && hst[x].n_resc > 0 && resc_hits(x) >= 64) front.push_back(x); }
+					std::stable_sort(front.begin(), front.end(), [&](uint32_t x, uint32_t y) { return resc_hits(x) > resc_hits(y); });
+					if(front.size() > by_len.size() / 64) front.resize(by_len.size() / 64);
+					if(!front.empty()) {
+						std::vector<uint8_t> is_front(n_reads, 0); for(uint32_t x : front) is_front[x] = 1;
+						std::vector<uint32_t> rest; rest.reserve(by_len.size());
+						for(uint32_t x : by_len) if(!is_front[x]) rest.push_back(x);
+						by_len = front; by_len.insert(by_len.end(), rest.begin(), rest.end());
+						n_heavy += (uint32_t)front.size();          /* (the enumeration of chain jobs skips them: no passing chain) */
+					}
+				}
 			}
 			if(const char *e = getenv("MM_EXPERIMENT_K3_HEAVY")) {          /* timing experiment only (results incomplete): the N reads with the most chains */
 				std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return hst[x].n_root > hst[y].n_root; });
