@@ -135,15 +135,16 @@ def work():
 def test_dm6_size_x20_whole_sam_equals_the_reference(work, hg38):
     # (hg38: asked for here so that the reference's runs over the two human-size sets are under way in the background while this test runs)
     ref, rd = _generate(work, 'dm6', (0x5eed0001, 143700000, 1870, 0.05), (0x5eed0002, 20.0, 'pacbio'))
-    want = os.path.join(work, 'dm6_ref.sam')
-    bg = _reference_in_background('pacbio', ref, rd, want)
-    s, err, sec = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 1 << 30, os.path.join(work, 'dm6_ours.sam'))
+    # the reference: ONE -t1 run over the whole set (1 870 contigs: the carried value changes at nearly every read), its records through tools/samcheck --parts
+    want_fn = os.path.join(work, 'dm6_ref.json')
+    bg = subprocess.Popen(['bash', '-c', '%s -xpacbio -t32 -d %s.mai %s 2> %s.idx.err && %s -xpacbio -t1 %s.mai %s 2> %s.err | %s --parts > %s; rc=${PIPESTATUS[0]}; rm -f %s.mai; exit $rc' % (
+        REFBIN, want_fn, ref, want_fn, REFBIN, want_fn, rd, want_fn, _samcheck(), want_fn, want_fn)])
+    s, err, sec = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull)
     assert s['error'] == '' and s['reads'] == s['primary'] and s['mapped'] > 0.98 * s['reads'], s
     assert s['bases_mapped'] > 2.7e9, s                                             # the full x20 set (2.87 Gb), not a sample
-    assert bg.wait(timeout=900) == 0, open(want + '.err').read()[-2000:]
-    got = _md5_records(os.path.join(work, 'dm6_ours.sam')); ref_md5 = _md5_records(want)
-    assert got == ref_md5, 'dm6-size x20: SAM differs from the compiled reference'
-    assert got[1] == s['records']
+    assert bg.wait(timeout=900) == 0, open(want_fn + '.err').read()[-2000:]
+    with open(want_fn) as f: want = json.loads(f.read().strip().splitlines()[-1])
+    assert [tuple(x) for x in s['parts']] == [tuple(x) for x in want['parts']] and want['records'] == s['records'], 'dm6-size x20: SAM differs from the compiled reference (%r against %r)' % (s['parts'], want['parts'])
     # the same set through the command-line program spanning 2 and 4 device contexts in ONE process (all on the one GPU of the box): pieces of the text dealt to the
     # devices, batches to device x lane, the carried value (which changes at nearly every read of this set) verified in batch order across devices, one writer
     for n, gb, lanes in (((2, 60, 1), (4, 30, 1)) if AT_SCALE_ON_ONE_GPU else ()):
@@ -151,7 +152,7 @@ def test_dm6_size_x20_whole_sam_equals_the_reference(work, hg38):
         assert sn['error'] == '' and sn['digest'] == s['digest'] and sn['records'] == s['records'] and sn['bytes'] == s['bytes'], (n, s, sn, errn.decode()[-1500:])
         sys.stderr.write('[headline] dm6-size x20: one context %.1f s, %d contexts on one GPU %.1f s (index build included)\n' % (sec, n, secn))
     if not AT_SCALE_ON_ONE_GPU:
-        for f in ('dm6_ours.sam', 'dm6_ref.sam', 'dm6_rd.fa', 'dm6_ref.fa'): os.unlink(os.path.join(work, f))
+        for f in ('dm6_rd.fa', 'dm6_ref.fa'): os.unlink(os.path.join(work, f))
         return
     # the same set over EIGHT ranks (all on cuda:0; MM_LANES=1 each): 1 870 contigs, so the carried value differs at nearly every shard boundary -- checks, window re-maps
     # and the rank-after-rank writers all have work -- and the stream must still be the single stream's
@@ -161,7 +162,7 @@ def test_dm6_size_x20_whole_sam_equals_the_reference(work, hg38):
                                             '-m', 'minialign_amd.multi', '-xpacbio', ref, rd], rd, 0, os.devnull, env=env, cwd=M.ROOT, timeout=1200)
     assert s8['error'] == '' and s8['digest'] == s['digest'] and s8['records'] == s['records'] and s8['bytes'] == s['bytes'], (s, s8, err8.decode()[-1500:])
     sys.stderr.write('[headline] dm6-size x20: single stream %.1f s, eight ranks on one GPU %.1f s (index builds included)\n' % (sec, sec8))
-    for f in ('dm6_ours.sam', 'dm6_ref.sam', 'dm6_rd.fa', 'dm6_ref.fa'): os.unlink(os.path.join(work, f))
+    for f in ('dm6_rd.fa', 'dm6_ref.fa'): os.unlink(os.path.join(work, f))
 
 @pytest.fixture(scope='module')
 def hg38(work):
