@@ -108,6 +108,8 @@ int64_t mm_pack_fetch(mm_align_t *a, mm_reads_t const *r, uint8_t *codes, uint64
 /* part `part` of `n_parts` of a read file (one rank's shard of a set): a plain FASTA file is cut by bytes where a '>' starts a line and only that stretch is read;
  * anything else (gzip, FASTQ, stdin) is read whole and the part keeps its share of the records.  The parts, in order, are the file. */
 mm_reads_t *mm_reads_load_part(char const *fn, uint32_t part, uint32_t n_parts);
+/* ... with the reader's options of a parsed command line (-L, -Q, -T CO), as the text entries take them from the context */
+mm_reads_t *mm_reads_load_part_opt(mm_opt_t const *o, char const *fn, uint32_t part, uint32_t n_parts);
 void mm_reads_free(mm_reads_t *r);
 /* the records of a file as the DEVICE reader finds them (mm_device.hpp K0r: record scanning; K0: base conversion + packing), nothing mapped: names / comments / qualities
  * read off the text at the offsets the scan gave, base codes brought back from the packed arena.  *host_scanned = records that went through the host's sequential FASTQ

@@ -2567,6 +2567,9 @@ extern "C" mm_reads_t *mm_reads_load_text(char const *fn) { return reads_load(fn
 /* part `part` of `n_parts` of a read file (one rank's shard, minialign_amd/multi.py): a plain FASTA file is cut by bytes at record starts and only that stretch is read;
  * anything else is read whole and the part keeps its share of the records.  The parts in order are the file. */
 extern "C" mm_reads_t *mm_reads_load_part(char const *fn, uint32_t part, uint32_t n_parts) { return (n_parts == 0 || part >= n_parts) ? NULL : reads_load(fn, 1, false, false, false, part, n_parts); }
+/* the same with the reader's options as the command line has them (-L: shortest read kept, -Q: qualities, -T CO: comments): what the text path (mm_map_text) applies from the
+ * context's options, so that one command line gives one output whatever the format of the read file */
+extern "C" mm_reads_t *mm_reads_load_part_opt(mm_opt_t const *o, char const *fn, uint32_t part, uint32_t n_parts) { return (n_parts == 0 || part >= n_parts) ? NULL : reads_load(fn, o->min_len, o->keep_qual, (o->ptags() >> 1) & 1, false, part, n_parts); }
 static mm_reads_t *reads_load(char const *fn, uint32_t min_len, bool keep_qual, bool keep_comment, bool keep_text, uint32_t part, uint32_t n_parts)
 {
 	mm_reads_t *r = new mm_reads_s();

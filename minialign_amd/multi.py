@@ -34,6 +34,7 @@ def load_library(path=None):
     L.mm_reads_bases.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
     L.mm_reads_count.argtypes = [ctypes.c_void_p]; L.mm_reads_append.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
     L.mm_reads_load_part.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32]; L.mm_reads_load_part.restype = ctypes.c_void_p
+    L.mm_reads_load_part_opt.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32]; L.mm_reads_load_part_opt.restype = ctypes.c_void_p
     L.mm_align_get_carry.argtypes = [ctypes.c_void_p]; L.mm_align_get_carry.restype = ctypes.c_uint32
     L.mm_align_set_carry.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; L.mm_align_set_carry.restype = None
     L.mm_carry_check.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
@@ -254,7 +255,7 @@ def main(argv=None):
     if tp is not None:
         sm = ShardMapper(L, al, None, 0, 0, guess=L.mm_idx_max_len(mi), text=(tp[1], tp[2])).map()
     else:
-        reads = ctypes.c_void_p(L.mm_reads_load_part(files[1], rank, world))
+        reads = ctypes.c_void_p(L.mm_reads_load_part_opt(o, files[1], rank, world))          # (with -L / -Q / -T CO of the command line, as the text path applies them)
         if not reads: raise RuntimeError('cannot read %r' % files[1])
         sm = ShardMapper(L, al, reads, 0, L.mm_reads_count(reads), guess=L.mm_idx_max_len(mi)).map()
     sm.settle(dist if world > 1 else None, rank, world, 0, None)

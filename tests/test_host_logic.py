@@ -390,3 +390,29 @@ def test_batches_are_cut_by_bases_lanes_and_the_longest_read(tmp_path):
     part = spans(first=100, n=500, MM_BATCH_BASES=1000000)
     assert sum(part) == sum(lens[100:600]) and all(x <= 1000000 or x <= max(lens) for x in part)
     L.mm_reads_free(reads)
+
+def test_part_loader_applies_the_readers_options(tmp_path):
+    """mm_reads_load_part_opt: the host parser's part of a FASTQ file with the command line's reader options (-L drops short reads as bseq_read_fasta does, minialign.c:2077;
+    -Q keeps qualities) -- what minialign_amd/multi.py uses for inputs that do not go through the text path, so that one command line gives one output whatever the format"""
+    from minialign_amd import multi
+    L = multi.load_library()
+    L.mm_reads_qual.restype = ctypes.c_char_p; L.mm_reads_qual.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    fq = tmp_path / 'r.fq'; lens = [10, 100, 200, 50, 300, 70]
+    fq.write_text(''.join('@r%d c%d\n%s\n+\n%s\n' % (i, i, 'ACGT' * (n // 4) + 'A' * (n % 4), 'I' * n) for i, n in enumerate(lens)))
+    def load(args, part=0, n_parts=1):
+        o = ctypes.c_void_p(L.mm_opt_init()); av = [b'minialign'] + args + [b'ref.fa', str(fq).encode()]
+        argv = (ctypes.c_char_p * len(av))(*av); files = (ctypes.c_char_p * 8)(); nf = ctypes.c_int(0)
+        assert L.mm_opt_parse(o, len(av), argv, files, 8, ctypes.byref(nf)) == 0
+        r = ctypes.c_void_p(L.mm_reads_load_part_opt(o, str(fq).encode(), part, n_parts)); assert r
+        return r
+    r = load([b'-L60', b'-Q'])
+    assert L.mm_reads_count(r) == 4 and [L.mm_reads_name(r, i) for i in range(4)] == [b'r1', b'r2', b'r4', b'r5']
+    assert L.mm_reads_qual(r, 1) == b'I' * 200
+    L.mm_reads_free(r)
+    r = load([])
+    assert L.mm_reads_count(r) == 6 and L.mm_reads_qual(r, 0) in (b'', None)
+    L.mm_reads_free(r)
+    n = 0
+    for p in range(3):
+        r = load([b'-L60'], p, 3); n += L.mm_reads_count(r); L.mm_reads_free(r)
+    assert n == 4          # the parts, in order, are the file
