@@ -1667,6 +1667,8 @@ struct K3Args {
 	uint32_t rq_early;                   /* helpers are helpers from the start of the launch (they take no reads): the reads that publish retry jobs are at the front of the work list */
 	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = helpers' cursor, [2] = reads done, [3] = results taken */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
+	uint32_t defer_thr;                  /* experiment (MM_K3_DEFER_RESCUE, off = 0): a read left without a result by the first threshold that has this many rescue hits waiting does NOT go on inside
+	                                      * the launch; the host runs its later rounds as launches of their own, where the chains it finds there are spread over the launch as chain jobs */
 };
 
 /* the per-read position hash, kh_t (minialign.c:341-683), literal */
@@ -2291,7 +2293,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		uint32_t next_n = 0;
 		uint32_t rj_base = 0, rj_n = 0, rj_i = 0;          /* retry jobs published for the trials that follow (K3Args.rjobs): first slot, count, next to be used */
 		auto cancel_rjobs = [&]() { if(rj_i < rj_n && lane == 0) { for(uint32_t q = rj_i; q < rj_n; q++) { (void)atomicCAS(&a.rstate[rj_base + q], (uint32_t)RJ_READY, (uint32_t)RJ_CANCELLED); } } rj_n = rj_i = 0; };
-		const uint32_t spec_n = (a.jobs != nullptr && round == 0) ? (uint32_t)rdfirst((int)st->spec_n) : 0u, spec_off = (uint32_t)rdfirst((int)st->spec_off);
+		const uint32_t spec_n = (a.jobs != nullptr && round == a.round) ? (uint32_t)rdfirst((int)st->spec_n) : 0u, spec_off = (uint32_t)rdfirst((int)st->spec_off);          /* (chain jobs are enumerated for the round a launch starts with) */
 		gaba::Sec rsec_f, rsec_r, qsec_f, qsec_r; int rcirc = 0;
 		qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }; qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
 
@@ -2644,6 +2646,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if(!a.inkernel_rounds || n_res > 0 || err != 0 || round + 1 >= ix.n_occ) { break; }
+		if(a.defer_thr) { const uint32_t half = (uint32_t)rdfirst((int)st->seed_cap) / 2u, base = (uint32_t)rdfirst((int)st->seed_n0) + 2u; if(half > base && half - base >= a.defer_thr) { if(lane == 0) { st->done = 2; } break; } }          /* (done = 2: the later rounds are the host's) */
 		}
 		if(rq_on && lane == 0) { atomicAdd(&a.rq_ctl[2], 1u); }          /* (helper waves leave when every read is done) */
 		if(!persistent) { break; }

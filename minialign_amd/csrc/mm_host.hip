@@ -1304,6 +1304,11 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 	}
+	/* experiment (MM_K3_DEFER_RESCUE=n, off by default; not yet run on a GPU): reads that the first threshold leaves without a result and that have n rescue hits or more
+	 * waiting come back to the host, and their later rounds run as launches of their own -- the serial sort + chain kernel, then an extension launch whose waves first take
+	 * the chains those reads now have as chain jobs (the enumeration and the hand-off of round 0, at a later round) -- instead of on the one wave that holds the read */
+	const uint32_t defer_thr = getenv("MM_K3_DEFER_RESCUE") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_DEFER_RESCUE"))) : 0u;
+	bool deferred = false;          /* the rounds from here on are those of deferred reads */
 	for(uint32_t round = 0; round < a->mi->n_occ && !work.empty(); round++) {
 		CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
 		K2Args k2; k2.idx = a->dix; k2.st = a->d_st.p; k2.work = a->d_work.p; k2.n_work = (uint32_t)work.size(); k2.round = round;
@@ -1431,6 +1436,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;
 		}
 		if(a->tap_stop) { return true; }
+		if(deferred) { if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false; }          /* (the chains of this round: n_pass / w_pass for the order and the jobs) */
 		uint32_t k3_work_override = 0, n_heavy = 0; uint32_t seg_beg[8], seg_len[8];
 		std::vector<uint32_t> by_len(work);          /* (lives until the extension launch is over: its upload below is not waited for on its own) */
 		{
@@ -1470,6 +1476,10 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 						n_heavy += (uint32_t)front.size();          /* (the enumeration of chain jobs skips them: no passing chain) */
 					}
 				}
+			}
+			if(deferred) {          /* a launch of deferred reads: all of them are candidates for chain jobs, the ones with the most to walk first */
+				std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return hst[x].w_pass > hst[y].w_pass; });
+				n_heavy = (uint32_t)by_len.size();
 			}
 			if(const char *e = getenv("MM_EXPERIMENT_K3_HEAVY")) {          /* timing experiment only (results incomplete): the N reads with the most chains */
 				std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return hst[x].n_root > hst[y].n_root; });
@@ -1515,8 +1525,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* a read without a result goes on to the next occurrence threshold on the wave that holds it (k3_rescue_round) instead of coming back through the host
 		 * for another round of launches: 2.77 against 3.20 s per step on the headline workload (the latency-bound rescue launches -- a serial sort + chain and
 		 * an extension launch of some eighty waves, twice -- took half of a lane's time per batch).  MM_K3_HOST_ROUNDS: the rounds as separate launches */
-		const bool inkernel = getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL;
+		const bool inkernel = getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL && !deferred;
 		k3.inkernel_rounds = inkernel ? 1u : 0u; k3.resc_pool = a->resc_pool.p; k3.twlen = a->twlen;
+		k3.defer_thr = (inkernel && round == 0 && !rlen_fixed) ? defer_thr : 0u;
 		k3.rjobs = nullptr; k3.rmemo = nullptr; k3.rstate = nullptr; k3.rq_cap = 0; k3.rq_ctl = nullptr;
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
 		k3.rq_early = getenv("MM_K3_LATE_HELPERS") ? 0u : 1u;
@@ -1536,7 +1547,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* chain jobs: the first trials of the chains of the heaviest reads (the front of the work list), taken by all waves of the launch before the reads (K3Args.jobs) */
 		/* (a wave that has claimed a job takes the workspace for it without waiting, K3_TRY_SLAB, and hands the job back undone when none of its class is free: with fewer
 		 * workspaces than waves, or on the class ladder of a long-tailed set, the waves that hold the workspaces may be the ones that wait for the job) */
-		if(round == 0 && n_heavy > 0 && k3.ring && k3.cls && inkernel && !getenv("MM_K3_NO_JOBS")) {
+		if(((round == 0 && inkernel) || deferred) && n_heavy > 0 && k3.ring && k3.cls && !getenv("MM_K3_NO_JOBS")) {
 			const uint64_t job_cap = getenv("MM_K3_JOB_CAP") ? (uint64_t)std::max(1, atoi(getenv("MM_K3_JOB_CAP"))) : (1u << 16), path_cap = 48ull << 20;          /* (MM_K3_JOB_CAP: test hook, a launch with more chain jobs than slots) */
 			if(a->spec_jobs.ensure(job_cap) && a->spec_memo.ensure(job_cap) && a->spec_path.ensure(path_cap) && a->spec_seg.ensure(job_cap * 8) && a->spec_top.ensure(8)) {
 				CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
@@ -1548,6 +1559,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
+		if(deferred && k3.jobs) { uint64_t nj = 0; for(uint32_t wi : work) nj += hst[wi].n_pass; waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((std::max<uint64_t>(work.size(), std::min<uint64_t>(nj, 4096)) + 3) & ~3ull)); }          /* (waves for the jobs, not only for the reads) */
 		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
 		/* several batches in flight (lanes): 5 persistent waves per SIMD keep the integer VALU as busy as 8 do (a wave issues at most every 4th cycle, about two
 		 * thirds of its instructions are VALU) and leave wave slots for the sketch and sort + chain kernels of the other lanes, which otherwise wait for the
@@ -1573,9 +1585,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
 		if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
 		std::vector<uint32_t> nxt;
-		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u)) nxt.push_back(wi);
+		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u) && (k3.defer_thr == 0 || hst[wi].done == 2)) nxt.push_back(wi);          /* (with deferral: only the reads the launch handed back; the others went through every round inside it) */
 		work.swap(nxt);
-		if(inkernel) { break; }          /* every round of every read has run inside that launch */
+		if(inkernel) { if(k3.defer_thr && !work.empty()) { deferred = true; continue; } break; }          /* every round of every read has run inside that launch (but for the deferred ones) */
 		if(getenv("MM_EXPERIMENT_K3_HEAVY")) { break; }
 	}
 	return true;
