@@ -35,3 +35,30 @@ def test_deferred_rescue_rounds_give_the_same_bytes():
             r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='32', MM_BATCH_BASES='3000000', MM_K3_DEFER_RESCUE=thr), timeout=600)
             assert r.returncode == 0, r.stderr.decode()[-2000:]
             assert strip(r.stdout) == want, thr
+
+def test_extension_trials_that_start_at_the_end_of_a_section():
+    """libgaba level: trials that start 1 .. 47 bases in front of the end of the b section (a seed at the very end of a read: the init fetch cannot finish inside the section,
+    the fill goes on into the N tail) with OTHER sequences -- all-A padding, random bases -- standing next to it in the arena: positions, fills and (traced) paths as the oracle's,
+    whatever the neighbours hold.  (Written while chasing the one ONT-like read of round 4 whose records differed; the DP turned out to be innocent -- DESIGN.md 5 -- and this sweep
+    is why that could be said.)"""
+    import numpy as np
+    import gabalib as G
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 4, 6000).astype(np.uint8)
+    rd = a[1500:4500].copy(); flip = rng.random(len(rd)) < 0.1; rd[flip] = (rd[flip] + 1 + rng.integers(0, 3, int(flip.sum()))) % 4          # a read off a[1500:4500], 10 % substitutions
+    rc = G.revcomp(rd)
+    for P in (G.ONT1DSQ, G.PACBIO):
+        hip = G.Hip(**P); ora = G.Oracle(**P)
+        for filler in (np.zeros(64, np.uint8), rng.integers(0, 4, 64).astype(np.uint8)):
+            jobs = []; keep = []
+            for k in range(1, 48):
+                for da in (0, 1, 3, 15):
+                    for tr in (0, 1):
+                        # forward read section ending at len(rd): the trial starts k bases before its end; the same through the reversed section of the reverse complement
+                        jobs.append((a, 100, 0, filler, 0, 0, 0, 0)); keep.append(False)
+                        jobs.append((a, 1500 + len(rd) - k + da, 0, rd, len(rd) - k, 0, 0, tr)); keep.append(True)
+                        jobs.append((a, 100, 0, filler, 0, 0, 0, 0)); keep.append(False)
+                        jobs.append((a, 1500 + len(rd) - k + da, 0, rc, len(rd) - k, 1, 0, tr)); keep.append(True)
+            got = hip.extend_batch(jobs)
+            bad = [(j[2:3] + j[4:8]) for j, g, kp in zip(jobs, got, keep) if kp and g != ora.extend(*j)]
+            assert not bad, bad[:5]
