@@ -14,8 +14,8 @@ def test_hard_repeats_20000_reads_equal_the_reference():
     if not os.path.exists(H.REFBIN): pytest.skip('oracle/_ref not built')
     d = tempfile.mkdtemp(prefix='mmhard_')
     try:
-        ref, rd, parts = H._generate(d, 'hard', (0x5eed0011, 400000000, 12, 0.45), (0x5eed0012, 1.0, 'pacbio'), keep_parts=True, hard=True)
-        bg = H._reference_by_parts('pacbio', ref, parts, os.path.join(d, 'hard_ref'), threads=32, group=2)          # (a 400 Mb index: 2.5 GB per process)
+        ref, rd, spans = H._generate(d, 'hard', (0x5eed0011, 400000000, 12, 0.45), (0x5eed0012, 1.0, 'pacbio'), keep_parts=True, hard=True)
+        bg = H._reference_by_parts('pacbio', ref, rd, spans, os.path.join(d, 'hard_ref'), threads=32, group=2)          # (a 400 Mb index: 2.5 GB per process)
         s, err, sec = H._map_through_samcheck([H.CLI, '-xpacbio', ref, rd], rd, 0, os.devnull, timeout=300)
         assert s['error'] == '' and s['reads'] == s['primary'] and s['reads'] >= 19000, s
         assert bg.wait(timeout=900) == 0, open(os.path.join(d, 'hard_ref.idx.err')).read()[-2000:]

@@ -34,47 +34,53 @@ def _samcheck():
     return exe
 
 def _generate(d, tag, genome, reads, rd_tag='rd', keep_parts=False, hard=False):
-    """reference (made once per tag) + read set (16 parts side by side, then one file); returns (ref.fa, reads.fa) -- and the part files when they are kept"""
+    """reference (made once per tag) + read set (16 parts, eight generators side by side, joined into one file); returns (ref.fa, reads.fa) -- and, keep_parts, the byte spans
+    [(offset, length)] of the parts inside reads.fa (the part files themselves do not stay: 13 GB of scratch space less on the human-size sets)"""
     ref = os.path.join(d, tag + '_ref.fa'); rd = os.path.join(d, '%s_%s.fa' % (tag, rd_tag))
     if not os.path.exists(ref): M.gensim('genomehard' if hard else 'genome', *genome, out=ref)
     seed, depth, kind = reads
-    procs = []
-    for p in range(PARTS):
-        f = open('%s.%02d' % (rd, p), 'wb')
-        procs.append((subprocess.Popen([GENSIM, 'reads', str(seed), ref, str(depth), kind, 'fa', '20000', '2000', str(p), str(PARTS)], stdout=f), f))
-    for pr, f in procs:
-        assert pr.wait() == 0; f.close()
-    parts = ['%s.%02d' % (rd, p) for p in range(PARTS)]
+    for lo in range(0, PARTS, 8):          # (a generator holds the reference: eight at a time)
+        procs = []
+        for p in range(lo, min(PARTS, lo + 8)):
+            f = open('%s.%02d' % (rd, p), 'wb')
+            procs.append((subprocess.Popen([GENSIM, 'reads', str(seed), ref, str(depth), kind, 'fa', '20000', '2000', str(p), str(PARTS)], stdout=f), f))
+        for pr, f in procs:
+            assert pr.wait() == 0; f.close()
+    spans = []; at = 0
     with open(rd, 'wb') as g:
-        for fn in parts:
+        for p in range(PARTS):
+            fn = '%s.%02d' % (rd, p)
             with open(fn, 'rb') as f: shutil.copyfileobj(f, g, 64 << 20)
-            if not keep_parts: os.unlink(fn)
-    return (ref, rd, parts) if keep_parts else (ref, rd)
+            n = os.path.getsize(fn); spans.append((at, n)); at += n
+            os.unlink(fn)
+    return (ref, rd, spans) if keep_parts else (ref, rd)
 
-def _last_records(fn, n, window):
-    """the last n FASTA records of a file (read off its last `window` bytes)"""
+def _last_records(fn, end, n, window):
+    """the last n FASTA records in front of byte offset `end` of a file (read off the `window` bytes in front of it)"""
     with open(fn, 'rb') as f:
-        f.seek(0, 2); size = f.tell(); f.seek(max(0, size - window)); tail = f.read()
+        f.seek(max(0, end - window)); tail = f.read(min(window, end))
     starts = [i + 1 for i in range(len(tail) - 1) if tail[i:i + 2] == b'\n>']
     assert len(starts) >= n, 'window too small for %d records' % n
     return tail[starts[-n]:]
 
-def _reference_by_parts(preset, ref, parts, out, threads=32, primer=4, window=8 << 20, group=4, wait_for=None):
-    """The compiled reference over a WHOLE set: its index file (with `threads` threads), then -t1 processes side by side, each over `group` consecutive parts (one
-    stream: its thread buffer carries the state from part to part as a single run over the whole set would) and fed, in front of them, the last `primer` reads of the part
-    before -- so that it holds, at the first read of its first part, what the single run would hold there (the carried reference length) -- through
-    tools/samcheck --parts (a digest and a record count per part).  HOST MEMORY: a reference process with a human-size index takes 18 GB; the first version of this
-    ran one per part for two sets at once (32 x 18 GB beside the index builds) and three gpurun boxes were lost under it.  Four at a time here (72 GB), and the sets
-    one after the other (`wait_for`: the Popen of the set in front).  Returns the Popen of the shell that runs it all; the line of parts [g, g + group) lands in out.<g>.json"""
+def _reference_by_parts(preset, ref, rd, spans, out, threads=32, primer=4, window=8 << 20, group=4, wait_for=None):
+    """The compiled reference over a WHOLE set (rd: its parts one after the other, spans: their byte extents): its index file (with `threads` threads), then -t1 processes
+    side by side, each over `group` consecutive parts (one stream: its thread buffer carries the state from part to part as a single run over the whole set would) and fed, in
+    front of them, the last `primer` reads of the part before -- so that it holds, at the first read of its first part, what the single run would hold there (the carried
+    reference length) -- through tools/samcheck --parts (a digest and a record count per part).  HOST MEMORY: a reference process with a human-size index takes
+    18 GB; the first version of this ran one per part for two sets at once (32 x 18 GB beside the index builds) and three gpurun boxes were lost under it.  Four at a time
+    here (72 GB), and the sets one after the other (`wait_for`: the Popen of the set in front).  Returns the Popen of the shell that runs it all; the line of parts
+    [g, g + group) lands in out.<g>.json"""
     mai = out + '.mai'; sc = _samcheck()
     lines = []
     if wait_for is not None: lines.append('while kill -0 %d 2>/dev/null; do sleep 1; done' % wait_for.pid)
     lines.append('%s -x%s -t%d -d %s %s 2> %s.idx.err || exit 1' % (REFBIN, preset, threads, mai, ref, out))
-    for g in range(0, len(parts), group):
+    for g in range(0, len(spans), group):
         pf = '%s.primer.%02d.fa' % (out, g)
         with open(pf, 'wb') as f:
-            if g: f.write(_last_records(parts[g - 1], primer, window))
-        lines.append('( cat %s %s | %s -x%s -t1 %s 2> %s.%02d.err | %s --parts > %s.%02d.json ) &' % (pf, ' '.join(parts[g:g + group]), REFBIN, preset, mai, out, g, sc, out, g))
+            if g: f.write(_last_records(rd, spans[g][0], primer, window))
+        lo = spans[g][0]; hi = spans[min(len(spans), g + group) - 1]; n = hi[0] + hi[1] - lo
+        lines.append('( ( cat %s; tail -c +%d %s | head -c %d ) | %s -x%s -t1 %s 2> %s.%02d.err | %s --parts > %s.%02d.json ) &' % (pf, lo + 1, rd, n, REFBIN, preset, mai, out, g, sc, out, g))
     lines.append('wait; rm -f %s' % mai)
     return subprocess.Popen(['bash', '-c', '\n'.join(lines)])
 
@@ -168,10 +174,10 @@ def test_dm6_size_x20_whole_sam_equals_the_reference(work, hg38):
 def hg38(work):
     """the headline set and the ONT-like set in 16 parts each, and -- running in the background on host cores -- the compiled reference over BOTH whole sets, part by part"""
     genome = (0x5eed0001, 3100000000, 25, 0.05)
-    ref, rd, pb_parts = _generate(work, 'hg38', genome, (0x5eed0002, 3.0, 'pacbio'), keep_parts=True)
-    bg_pb = _reference_by_parts('pacbio', ref, pb_parts, os.path.join(work, 'pb_ref'))
-    _, ont_rd, ont_parts = _generate(work, 'hg38', genome, (0x5eed0003, 1.0, 'ont'), rd_tag='ont', keep_parts=True)
-    bg_ont = _reference_by_parts('ont.1dsq', ref, ont_parts, os.path.join(work, 'ont_ref'), window=64 << 20, wait_for=bg_pb)
+    ref, rd, pb_spans = _generate(work, 'hg38', genome, (0x5eed0002, 3.0, 'pacbio'), keep_parts=True)
+    bg_pb = _reference_by_parts('pacbio', ref, rd, pb_spans, os.path.join(work, 'pb_ref'))
+    _, ont_rd, ont_spans = _generate(work, 'hg38', genome, (0x5eed0003, 1.0, 'ont'), rd_tag='ont', keep_parts=True)
+    bg_ont = _reference_by_parts('ont.1dsq', ref, ont_rd, ont_spans, os.path.join(work, 'ont_ref'), window=64 << 20, wait_for=bg_pb)
     yield dict(ref=ref, rd=rd, ont=ont_rd, bg_pb=bg_pb, bg_ont=bg_ont)
     for b in (bg_pb, bg_ont):
         if b.poll() is None: b.kill()

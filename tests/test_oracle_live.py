@@ -29,19 +29,17 @@ def test_primed_part_runs_reproduce_the_single_stream(tmp_path):
 	import mmlib as M, test_headline_gpu as H
 	d = str(tmp_path); ref = os.path.join(d, 'ref.fa'); n_parts = 6
 	M.gensim('genome', 9301, 8000000, 60, 0.1, out=ref)
-	parts = []
-	for p in range(n_parts):
-		fn = os.path.join(d, 'rd.%02d' % p); parts.append(fn)
-		with open(fn, 'wb') as f: subprocess.check_call([H.GENSIM, 'reads', '9302', ref, '1.5', 'pacbio', 'fa', '6000', '2500', str(p), str(n_parts)], stdout=f)
-	whole = os.path.join(d, 'rd.fa')
+	whole = os.path.join(d, 'rd.fa'); spans = []; at = 0
 	with open(whole, 'wb') as g:
-		for fn in parts: g.write(open(fn, 'rb').read())
+		for p in range(n_parts):
+			b = subprocess.run([H.GENSIM, 'reads', '9302', ref, '1.5', 'pacbio', 'fa', '6000', '2500', str(p), str(n_parts)], capture_output=True, check=True).stdout
+			g.write(b); spans.append((at, len(b))); at += len(b)
 	one = subprocess.run('%s -xpacbio -t1 %s %s 2>/dev/null | %s --parts' % (H.REFBIN, ref, whole, H._samcheck()), shell=True, capture_output=True, text=True, check=True)
 	want = [tuple(x) for x in json.loads(one.stdout.strip().splitlines()[-1])['parts']]
 	assert len(want) == n_parts and all(x[0] > 0 for x in want)
 	for group in (1, 2, 3):
 		out = os.path.join(d, 'g%d' % group)
-		assert H._reference_by_parts('pacbio', ref, parts, out, threads=4, primer=4, window=1 << 20, group=group).wait(timeout=300) == 0
+		assert H._reference_by_parts('pacbio', ref, whole, spans, out, threads=4, primer=4, window=1 << 20, group=group).wait(timeout=300) == 0
 		assert H._parts_of(out, n_parts, group=group) == want, group
 
 

@@ -1,7 +1,7 @@
 /*
  * samcheck.c -- test tool: size-independent properties of a SAM stream too large to walk in Python (the 13 GB the hg38-size x3 set maps to), at pipe speed.
  *
- *   minialign ... ref.fa reads.fa | tools/samcheck reads.fa N head.sam
+ *   minialign ... ref.fa reads.fa | tools/samcheck reads.fa[,more.fa,...] N head.sam
  *
  * Reads the names and lengths of the reads from reads.fa (plain FASTA as tools/gensim writes it), then the SAM text from stdin and checks, record by record:
  *   - one primary record (flag without 0x100 / 0x800) per read, in input order; the other records of a read follow its primary record
@@ -69,10 +69,11 @@ int main(int argc, char **argv)
 	}
 	if(argc < 4) { fprintf(stderr, "usage: samcheck reads.fa n_head head.sam < sam\n"); return 2; }
 	const uint64_t n_head = strtoull(argv[2], NULL, 10);
-	/* reads: names and lengths */
-	FILE *fp = fopen(argv[1], "rb"); if(!fp) { perror(argv[1]); return 2; }
+	/* reads: names and lengths (argv[1]: one file, or several separated by commas -- the parts of a set in order) */
 	size_t cap = 1 << 20, n_rd = 0; rd_t *rd = malloc(cap * sizeof(rd_t));
-	{
+	char *flist = strdup(argv[1]);
+	for(char *fn = strtok(flist, ","); fn != NULL; fn = strtok(NULL, ",")) {
+		FILE *fp = fopen(fn, "rb"); if(!fp) { perror(fn); return 2; }
 		size_t bcap = 64u << 20; char *buf = malloc(bcap + 1); size_t have = 0, got; int in_name = 0;
 		char nm[4096]; size_t nl = 0; int name_done = 0; int at_line_start = 1;
 		while((got = fread(buf, 1, bcap, fp)) > 0) {
@@ -95,6 +96,7 @@ int main(int argc, char **argv)
 		}
 		free(buf); fclose(fp);
 	}
+	free(flist);
 	FILE *hf = fopen(argv[3], "wb"); if(!hf) { perror(argv[3]); return 2; }
 	sq_t *sq = NULL; size_t n_sq = 0, sq_cap = 0;
 	char *line = NULL; size_t lcap = 0; ssize_t ln;
