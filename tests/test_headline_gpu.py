@@ -21,9 +21,10 @@ REFBIN = os.path.join(M.ROOT, 'oracle', '_ref', 'minialign')
 GENSIM = os.path.join(M.ROOT, 'tools', 'gensim')
 PARTS = 16
 # Several device contexts (or ranks) on the ONE GPU of a test box at FULL size: off unless asked for (MM_TEST_CONTEXTS_AT_SCALE=1).  Three gpurun boxes were lost in
-# round 4 while this file ran.  What the three runs had in common was the reference's whole-set runs as they were then -- one 18 GB process per part, 32 of them for the
-# two human-size sets, beside the index builds: host memory (see _reference_by_parts; bounded since) -- and two of them also ran 2 / 4 device contexts x 2 lanes on the
-# dm6-size set; the one run of this file that survived had neither.  The several-context runs at full size have therefore never completed on a box and stay opt-in until
+# round 4 while this file ran, 195 - 225 s into it.  What the three runs had in common was the HOST side of the human-size fixture as it was then -- sixteen read generators
+# at once, part files kept beside the joined file, and one 18 GB reference process per part, 32 of them for the two sets, beside the index builds (see _generate and
+# _reference_by_parts; all bounded since) -- and two of them also ran 2 / 4 device contexts x 2 lanes on the dm6-size set.  Nothing comes back from a lost box, so the cause
+# is not established; in the last of the three no GPU process was alive at that moment.  The several-context runs at full size have therefore never completed on a box and stay opt-in until
 # they have; on a node each device has ONE context with the whole workspace budget, which is the single-context path the tests below run at full size, and the
 # several-context engine is covered at small size in tests/test_multi_gpu.py (2 / 3 / 4 contexts, pieces of 64 KB .. 1 MB, through the command line and the C-ABI).
 AT_SCALE_ON_ONE_GPU = os.environ.get('MM_TEST_CONTEXTS_AT_SCALE') is not None
