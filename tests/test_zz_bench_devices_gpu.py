@@ -62,3 +62,33 @@ def test_extension_trials_that_start_at_the_end_of_a_section():
             got = hip.extend_batch(jobs)
             bad = [(j[2:3] + j[4:8]) for j, g, kp in zip(jobs, got, keep) if kp and g != ora.extend(*j)]
             assert not bad, bad[:5]
+
+def test_every_read_runs_with_the_value_the_reference_would_carry():
+    """the carried reference length read by read: what the device handed every read (MM_DUMP_CARRY, after verification and re-runs) against what the oracle's
+    thread buffer holds when it takes the read (OM_DEBUG_CARRY) -- on a many-contig, repeat-rich set with a high seed threshold, where reads go on to the later occurrence
+    thresholds and are chained again (the case in which round 3's bookkeeping went wrong: a read that is chained again changes the prediction behind its neighbours' backs)"""
+    import tempfile
+    CLI = os.path.join(M.ROOT, 'minialign_amd', 'minialign')
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa'); dump = os.path.join(d, 'carry.txt')
+        M.gensim('genomehard', 7701, 16000000, 60, 0.5, out=ref); M.gensim('reads', 7702, ref, 0.4, 'pacbio', 'fa', 5000, 2000, out=rd)
+        opts = ['-xpacbio', '-f0.2,0.05,0.002']
+        o = subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, OM_DEBUG_CARRY='1'), check=True)
+        want = [(f[1], int(f[2])) for f in (l.split('\t') for l in o.stderr.decode().splitlines()) if f[0] == 'carry']
+        lens = [int(l.split(b'len=')[1]) for l in open(ref, 'rb') if l.startswith(b'>')]
+        NIL = 0xffffffff
+        for env in (dict(MM_BATCH_BASES='400000', MM_LANES='3'), dict(MM_BATCH_BASES='3000000', MM_LANES='1')):
+            r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='8', MM_DUMP_CARRY=dump, **env), timeout=600)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            got = [l.split('\t') for l in open(dump).read().splitlines()]          # name, value the read ran with, its first apos, (bpos >= qlen), last reference it loaded, results
+            assert [g[0] for g in got] == [n for n, _ in want]
+            bad = []; flips = 0
+            for i, (g, (n, truth)) in enumerate(zip(got, want)):
+                used, apos0, cond0, rid_last = int(g[1]), int(g[2]), int(g[3]), int(g[4])
+                # the decision the value feeds (minialign.c:3823: apos >= rlen) must be the one the reference's value gives -- the value itself may differ where it decides nothing
+                if apos0 != NIL and not cond0 and (apos0 >= used) != (apos0 >= truth): bad.append((i, n, used, truth, apos0))
+                if apos0 != NIL and not cond0 and apos0 >= truth: flips += 1
+                # ... and what the read leaves behind is what the reference carries on to the next one
+                if i + 1 < len(want): assert want[i + 1][1] == (lens[rid_last] if rid_last >= 0 else truth), (i, n, rid_last, truth, want[i + 1])
+            assert not bad, bad[:5]
+            assert flips > 0, 'no read of the set has its first seed beyond the carried length: the test has no teeth'
