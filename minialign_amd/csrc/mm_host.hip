@@ -2028,6 +2028,17 @@ static bool make_streams(mm_align_s *a)
 	a->k2s_ok = true;
 	if(hipHostMalloc((void **)&a->pin_note, 64, hipHostMallocPortable) != hipSuccess) return false;
 	if(least != greatest) { if(hipStreamCreateWithPriority(&a->k3s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) return false; }
+	else if(const char *e = getenv("MM_K3_CU_RESERVE")) {
+		/* experiment (off by default; not yet run on a GPU): the extension launches go to a stream whose CU mask leaves every (CUs / n)-th compute unit out, so that the short
+		 * operations of the other lanes -- copies, memsets, the sketch and sort launches -- always find free wave slots somewhere instead of waiting 10 - 40 ms for a
+		 * persistent extension launch to end; the extension kernel pays n CUs for it */
+		int dev = 0; hipDeviceProp_t prop; const int n = std::max(1, atoi(e));
+		if(hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > n) {
+			const int cus = prop.multiProcessorCount, step = cus / n; std::vector<uint32_t> mask((cus + 31) / 32, 0);
+			for(int i = 0; i < cus; i++) { if(i % step != step - 1) mask[i >> 5] |= 1u << (i & 31); }
+			if(hipExtStreamCreateWithCUMask(&a->k3s, (uint32_t)mask.size(), mask.data()) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) { a->k3s = nullptr; fprintf(stderr, "[minialign_amd] MM_K3_CU_RESERVE: no stream with a CU mask\n"); }
+		}
+	}
 	return true;
 }
 /* a primary context on the current device */
