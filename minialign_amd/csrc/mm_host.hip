@@ -2225,6 +2225,38 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		if(!a->d_tinfo.ensure(spare(b.n)) || !a->d_codes.ensure(spare(arena + 64)) || !a->d_tn.ensure(spare(b.n))) return false;
 		std::vector<TextRead> tr(b.n);
 		CK(hipMemsetAsync(a->d_codes.p, 0, arena + 64, a->stream));
+		if(!b.dch.empty() && getenv("MM_UPLOAD_ONE_SYNC")) {
+			/* experiment (off by default; not yet run on a GPU): the whole upload of a batch behind ONE wait.  Every wait of a lane for its stream is a wait for a wave slot beside
+			 * the persistent extension waves of the other lanes (10 - 40 ms each under load), and this function has five: the extents, the packed-base count, the
+			 * read table, the states, the cursors.  Here everything the device needs goes through one pinned staging buffer in three copies, the kernels and the memsets follow on
+			 * the stream, the base counts come back into the same buffer, and the host waits once */
+			for(const Batch::Piece &pc : b.dch) for(uint32_t i = pc.first; i < pc.first + pc.n; i++) tr[i] = TextRead{ b.trec[i].t_off - pc.ch->off, b.trec[i].t_len, 0, b.qoff[i] };
+			const size_t s_tr = ((size_t)b.n * sizeof(TextRead) + 255) & ~(size_t)255, s_in = ((size_t)b.n * sizeof(ReadIn) + 255) & ~(size_t)255, s_st = ((size_t)b.n * sizeof(ReadState) + 255) & ~(size_t)255, s_tn = ((size_t)b.n * 4 + 255) & ~(size_t)255;
+			uint8_t *stg = (uint8_t *)lane_stage(a, s_tr + s_in + s_st + s_tn);
+			if(stg) {
+				memcpy(stg, tr.data(), (size_t)b.n * sizeof(TextRead)); memcpy(stg + s_tr, b.in.data(), (size_t)b.n * sizeof(ReadIn)); memcpy(stg + s_tr + s_in, b.hst.data(), (size_t)b.n * sizeof(ReadState));
+				CK(hipMemcpyAsync(a->d_tinfo.p, stg, (size_t)b.n * sizeof(TextRead), hipMemcpyHostToDevice, a->stream));
+				CK(hipMemcpyAsync(a->d_in.p, stg + s_tr, (size_t)b.n * sizeof(ReadIn), hipMemcpyHostToDevice, a->stream));
+				CK(hipMemcpyAsync(a->d_st.p, stg + s_tr + s_in, (size_t)b.n * sizeof(ReadState), hipMemcpyHostToDevice, a->stream));
+				for(const Batch::Piece &pc : b.dch) {
+					if(pc.n == 0) continue;
+					hipLaunchKernelGGL(mm_text_codes_kernel, dim3((pc.n + 3) / 4), dim3(256), 0, a->stream, pc.ch->d, a->d_tinfo.p + pc.first, pc.n, a->d_codes.p, a->d_tn.p + pc.first);
+					CK(hipGetLastError());
+				}
+				const uint64_t nw1 = (b.total + 64 + 31) / 32;
+				hipLaunchKernelGGL(mm_codes_pack_kernel, dim3((uint32_t)((nw1 + 255) / 256)), dim3(256), 0, a->stream, a->d_codes.p, nw1, a->q_pk.p, a->q_nm.p);
+				CK(hipGetLastError());
+				CK(hipMemsetAsync(a->d_tops.p, 0, 32 * 8, a->stream));
+				CK(hipMemcpyAsync(stg + s_tr + s_in + s_st, a->d_tn.p, (size_t)b.n * 4, hipMemcpyDeviceToHost, a->stream));
+				CK(hipStreamSynchronize(a->stream));
+				const uint32_t *tn1 = (const uint32_t *)(stg + s_tr + s_in + s_st);
+				for(uint32_t i = 0; i < b.n; i++) if(tn1[i] != b.lens[i]) { fprintf(stderr, "[minialign_amd] read %u of a batch: %u bases in its text when packed, %u when scanned\n", i, tn1[i], b.lens[i]); return false; }
+				b.dch.clear();
+				if(verbose) { fprintf(stderr, "[minialign_amd]   host state + H2D %.1f ms (one wait)\n", now_ms() - tv); }
+				b.uploaded = true; b.ran = false;
+				return true;
+			}
+		}
 		if(!b.dch.empty()) {
 			for(const Batch::Piece &pc : b.dch) for(uint32_t i = pc.first; i < pc.first + pc.n; i++) tr[i] = TextRead{ b.trec[i].t_off - pc.ch->off, b.trec[i].t_len, 0, b.qoff[i] };
 			if(!lane_h2d(a, a->d_tinfo.p, tr.data(), b.n * sizeof(TextRead))) return false;
