@@ -5,7 +5,7 @@ with several threads the reference's own output depends on which thread buffer a
         same set over 2 / 4 device contexts of one process and over 8 ranks of minialign_amd.multi, all on cuda:0, identical to the single stream);
   (ii)  human hg38-size reference (3.1 Gb, 25 contigs) x PBSIM-like x3 (9.3 Gb, the headline set): size-independent properties of the whole 13 GB stream
         (tools/samcheck.c: one primary record per read in input order, every CIGAR adds up to its read and stays inside its contig, ...), EVERY record of it against
-        the compiled reference (all 446 956 reads: the reference maps the 16 parts of the set in four -t1 processes side by side, four consecutive parts each, primed with
+        the compiled reference (all 446 956 reads: the reference maps the 16 parts of the set in eight -t1 processes side by side, two consecutive parts each, primed with
         the last reads of the part in front; a digest per part) (and, with MM_TEST_CONTEXTS_AT_SCALE set, the same set over 2 and 4 device contexts of ONE process identical to the single stream);
   (iii) the hg38-size reference x ONT-like reads (3.1 Gb) with -xont.1dsq: properties of the whole stream, every record of it against the compiled reference likewise.
 
@@ -64,13 +64,13 @@ def _last_records(fn, end, n, window):
     assert len(starts) >= n, 'window too small for %d records' % n
     return tail[starts[-n]:]
 
-def _reference_by_parts(preset, ref, rd, spans, out, threads=32, primer=4, window=8 << 20, group=4, wait_for=None):
+def _reference_by_parts(preset, ref, rd, spans, out, threads=32, primer=4, window=8 << 20, group=2, wait_for=None):
     """The compiled reference over a WHOLE set (rd: its parts one after the other, spans: their byte extents): its index file (with `threads` threads), then -t1 processes
     side by side, each over `group` consecutive parts (one stream: its thread buffer carries the state from part to part as a single run over the whole set would) and fed, in
     front of them, the last `primer` reads of the part before -- so that it holds, at the first read of its first part, what the single run would hold there (the carried
     reference length) -- through tools/samcheck --parts (a digest and a record count per part).  HOST MEMORY: a reference process with a human-size index takes
-    18 GB; the first version of this ran one per part for two sets at once (32 x 18 GB beside the index builds) and three gpurun boxes were lost under it.  Four at a time
-    here (72 GB), and the sets one after the other (`wait_for`: the Popen of the set in front).  Returns the Popen of the shell that runs it all; the line of parts
+    18 GB; the first version of this ran one per part for two sets at once (32 x 18 GB beside the index builds) and three gpurun boxes were lost under it.  Eight at a time
+    here (143 GB; sixteen at a time -- one set -- is what the one run that survived had for most of its time), and the sets one after the other (`wait_for`: the Popen of the set in front).  Returns the Popen of the shell that runs it all; the line of parts
     [g, g + group) lands in out.<g>.json"""
     mai = out + '.mai'; sc = _samcheck()
     lines = []
@@ -85,7 +85,7 @@ def _reference_by_parts(preset, ref, rd, spans, out, threads=32, primer=4, windo
     lines.append('wait; rm -f %s' % mai)
     return subprocess.Popen(['bash', '-c', '\n'.join(lines)])
 
-def _parts_of(out, n, group=4):
+def _parts_of(out, n, group=2):
     """[(records, digest)] of parts 0 .. n - 1 as the reference processes left them: part p from the process that mapped it (the primer reads in front of a process' first
     part count under the part before and are ignored)"""
     got = []
