@@ -1462,7 +1462,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				 * hard-repeat set (6 M DP vectors on a wave while the rest of the launch has long finished).  Nothing spreads that walk yet; starting it when the
 				 * launch starts at least overlaps it with the bulk.  At most a 64th of the list, the ones with the most rescue hits first; on the sets without such repeats these
 				 * are a handful of reads */
-				if(!getenv("MM_K3_NO_RESCUE_FIRST")) {
+				if(getenv("MM_K3_RESCUE_FIRST")) {          /* (experiment, off by default: not yet run on a GPU) */
 					auto resc_hits = [&](uint32_t x) -> uint32_t { const uint32_t half = hst[x].seed_cap / 2, base = hst[x].seed_n0 + 2; return half > base ? half - base : 0u; };
 					std::vector<uint32_t> front;
 					for(uint32_t x : by_len) { if(hst[x].n_pass == 0 && hst[x].n_resc > 0 && resc_hits(x) >= 64) front.push_back(x); }
