@@ -1,0 +1,58 @@
+#!/bin/bash
+# The first GPU calls of a round, one stage per gpurun call (a lost box then costs one stage, not the lot).  Round 4 ended with GPU access closed: the final tree has not run
+# the whole suite, four tests and four switches have never run on a device.  Usage, from the repo root on the GPU box:
+#   tools/round_start.sh box        what the box is: memory and its cgroup limit, scratch space, devices  (seconds; run it FIRST and keep it in front of every other stage:
+#                                   three boxes were lost in round 4 and nothing is known about their limits)
+#   tools/round_start.sh suite      python -m pytest tests -x -q -m gpu   (as the driver runs it)
+#   tools/round_start.sh unrun      the four GPU tests that have not run yet (MM_TEST_NOT_YET_RUN=1), one by one, no -x
+#   tools/round_start.sh switches   the switches that have not run yet, each against the default on the headline workload (bench.py, 3 steps) and the hard-repeat set
+#   tools/round_start.sh scale      several device contexts at full size on the one GPU (MM_TEST_CONTEXTS_AT_SCALE=1; in two of the three calls that lost their box in round 4)
+#   tools/round_start.sh profiles   tools/round_profiles.sh gpurun_out/round <tag>   (bench line, rocprofv3 stats, PMC passes, lane trace)
+# Everything lands under gpurun_out/start/.
+STAGE=${1:-box}; TAG=${2:-round5}; OUT=gpurun_out/start; mkdir -p "$OUT"; export TMPDIR=/tmp
+
+box() {
+	{
+		echo "== memory"; free -g | head -2
+		echo "== cgroup memory limit"; cat /sys/fs/cgroup/memory.max 2> /dev/null || cat /sys/fs/cgroup/memory/memory.limit_in_bytes 2> /dev/null
+		echo "== cgroup memory in use"; cat /sys/fs/cgroup/memory.current 2> /dev/null || cat /sys/fs/cgroup/memory/memory.usage_in_bytes 2> /dev/null
+		echo "== scratch space"; df -h /tmp /root/repo / /dev/shm 2> /dev/null
+		echo "== cores"; nproc; echo "== pids limit"; cat /sys/fs/cgroup/pids.max 2> /dev/null
+		echo "== devices"; rocm-smi --showmeminfo vram 2> /dev/null | grep -i "total\|used" | head -16
+	} > "$OUT/${TAG}_box.txt" 2>&1
+	cat "$OUT/${TAG}_box.txt"
+}
+
+# a memory / scratch watch beside a stage: one line every 5 s, so that the last lines of a stage that loses its box are at least in the part of the log that was flushed
+watch_box() { while true; do echo "$(date +%T) mem_used_gb=$(free -g | awk 'NR==2{print $3}') cgroup=$(cat /sys/fs/cgroup/memory.current 2> /dev/null) tmp_used=$(df --output=used -BG /tmp | tail -1)"; sleep 5; done; }
+
+case "$STAGE" in
+box) box ;;
+suite)
+	box > /dev/null; watch_box > "$OUT/${TAG}_suite_watch.txt" & W=$!
+	python -m pytest tests -x -q -m gpu --durations=15 > "$OUT/${TAG}_suite.log" 2>&1; echo "rc=$?" >> "$OUT/${TAG}_suite.log"
+	kill $W; tail -25 "$OUT/${TAG}_suite.log" ;;
+unrun)
+	box > /dev/null
+	for t in test_bench_line_with_two_devices_in_one_process test_deferred_rescue_rounds_give_the_same_bytes test_extension_trials_that_start_at_the_end_of_a_section test_every_read_runs_with_the_value_the_reference_would_carry; do
+		MM_TEST_NOT_YET_RUN=1 timeout 900 python -m pytest "tests/test_zz_bench_devices_gpu.py::$t" -q > "$OUT/${TAG}_unrun_$t.log" 2>&1; echo "$t rc=$?" | tee -a "$OUT/${TAG}_unrun.txt"
+	done ;;
+switches)
+	box > /dev/null
+	B="python bench.py --steps 3 --warmup 1 --no-cpu --no-cli --no-packed"
+	for cfg in "" "MM_UPLOAD_ONE_SYNC=1" "MM_K3_CU_RESERVE=16" "MM_K3_CU_RESERVE=32" "MM_K3_CU_RESERVE=16 MM_UPLOAD_ONE_SYNC=1"; do
+		echo "== headline: ${cfg:-default}" >> "$OUT/${TAG}_switches.txt"
+		env $cfg timeout 600 $B 2> /dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms per step', 'identical' if d.get('sam_identical') in (None, True) else 'SAM DIFFERS')" >> "$OUT/${TAG}_switches.txt" 2>&1
+	done
+	for cfg in "" "MM_K3_RESCUE_FIRST=1" "MM_K3_DEFER_RESCUE=64" "MM_K3_DEFER_RESCUE=64 MM_K3_RESCUE_FIRST=1"; do
+		echo "== hard repeats: ${cfg:-default}" >> "$OUT/${TAG}_switches.txt"
+		env $cfg timeout 900 python bench.py --steps 2 --warmup 1 --no-cli --no-packed --workload hg38hard --check-reads 4000 --baseline-reads 4000 2> /dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms per step', 'identical' if d.get('sam_identical') in (None, True) else 'SAM DIFFERS')" >> "$OUT/${TAG}_switches.txt" 2>&1
+	done
+	cat "$OUT/${TAG}_switches.txt" ;;
+scale)
+	box > /dev/null; watch_box > "$OUT/${TAG}_scale_watch.txt" & W=$!
+	MM_TEST_CONTEXTS_AT_SCALE=1 timeout 2400 python -m pytest tests/test_headline_gpu.py -x -q --durations=10 > "$OUT/${TAG}_scale.log" 2>&1; echo "rc=$?" >> "$OUT/${TAG}_scale.log"
+	kill $W; tail -15 "$OUT/${TAG}_scale.log" ;;
+profiles) bash tools/round_profiles.sh gpurun_out/round "$TAG" ;;
+*) echo "unknown stage $STAGE"; exit 2 ;;
+esac
