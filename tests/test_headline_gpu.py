@@ -35,14 +35,14 @@ def _samcheck():
     return exe
 
 def _generate(d, tag, genome, reads, rd_tag='rd', keep_parts=False, hard=False):
-    """reference (made once per tag) + read set (16 parts, eight generators side by side, joined into one file); returns (ref.fa, reads.fa) -- and, keep_parts, the byte spans
+    """reference (made once per tag) + read set (16 parts, their generators side by side, joined into one file); returns (ref.fa, reads.fa) -- and, keep_parts, the byte spans
     [(offset, length)] of the parts inside reads.fa (the part files themselves do not stay: 13 GB of scratch space less on the human-size sets)"""
     ref = os.path.join(d, tag + '_ref.fa'); rd = os.path.join(d, '%s_%s.fa' % (tag, rd_tag))
     if not os.path.exists(ref): M.gensim('genomehard' if hard else 'genome', *genome, out=ref)
     seed, depth, kind = reads
-    for lo in range(0, PARTS, 8):          # (a generator holds the reference: eight at a time)
+    for lo in range(0, PARTS, 16):          # (a generator holds the reference: 16 x 3.1 GB on the human-size sets, as round 3's fixture had it)
         procs = []
-        for p in range(lo, min(PARTS, lo + 8)):
+        for p in range(lo, min(PARTS, lo + 16)):
             f = open('%s.%02d' % (rd, p), 'wb')
             procs.append((subprocess.Popen([GENSIM, 'reads', str(seed), ref, str(depth), kind, 'fa', '20000', '2000', str(p), str(PARTS)], stdout=f), f))
         for pr, f in procs:
@@ -74,8 +74,8 @@ def _reference_by_parts(preset, ref, rd, spans, out, threads=32, primer=4, windo
     [g, g + group) lands in out.<g>.json"""
     mai = out + '.mai'; sc = _samcheck()
     lines = []
-    if wait_for is not None: lines.append('while kill -0 %d 2>/dev/null; do sleep 1; done' % wait_for.pid)
     lines.append('%s -x%s -t%d -d %s %s 2> %s.idx.err || exit 1' % (REFBIN, preset, threads, mai, ref, out))
+    if wait_for is not None: lines.append('while kill -0 %d 2>/dev/null; do sleep 1; done' % wait_for.pid)          # (the index build goes on beside the set in front; the 18 GB processes do not)
     for g in range(0, len(spans), group):
         pf = '%s.primer.%02d.fa' % (out, g)
         with open(pf, 'wb') as f:
@@ -141,17 +141,16 @@ def work():
 
 def test_dm6_size_x20_whole_sam_equals_the_reference(work, hg38):
     # (hg38: asked for here so that the reference's runs over the two human-size sets are under way in the background while this test runs)
-    ref, rd = _generate(work, 'dm6', (0x5eed0001, 143700000, 1870, 0.05), (0x5eed0002, 20.0, 'pacbio'))
-    # the reference: ONE -t1 run over the whole set (1 870 contigs: the carried value changes at nearly every read), its records through tools/samcheck --parts
-    want_fn = os.path.join(work, 'dm6_ref.json')
-    bg = subprocess.Popen(['bash', '-c', '%s -xpacbio -t32 -d %s.mai %s 2> %s.idx.err && %s -xpacbio -t1 %s.mai %s 2> %s.err | %s --parts > %s; rc=${PIPESTATUS[0]}; rm -f %s.mai; exit $rc' % (
-        REFBIN, want_fn, ref, want_fn, REFBIN, want_fn, rd, want_fn, _samcheck(), want_fn, want_fn)])
+    ref, rd, spans = _generate(work, 'dm6', (0x5eed0001, 143700000, 1870, 0.05), (0x5eed0002, 20.0, 'pacbio'), keep_parts=True)
+    # the reference: every part of the set (1 870 contigs: the carried value changes at nearly every read), eight -t1 processes of two consecutive parts, primed with the reads in
+    # front (one -t1 run over the 2.87 Gb takes 107 s of the suite's time; the method is checked against one run in tests/test_oracle_live.py and on this set's like in round 3)
+    bg = _reference_by_parts('pacbio', ref, rd, spans, os.path.join(work, 'dm6_ref'))
     s, err, sec = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull)
     assert s['error'] == '' and s['reads'] == s['primary'] and s['mapped'] > 0.98 * s['reads'], s
     assert s['bases_mapped'] > 2.7e9, s                                             # the full x20 set (2.87 Gb), not a sample
-    assert bg.wait(timeout=900) == 0, open(want_fn + '.err').read()[-2000:]
-    with open(want_fn) as f: want = json.loads(f.read().strip().splitlines()[-1])
-    assert [tuple(x) for x in s['parts']] == [tuple(x) for x in want['parts']] and want['records'] == s['records'], 'dm6-size x20: SAM differs from the compiled reference (%r against %r)' % (s['parts'], want['parts'])
+    assert bg.wait(timeout=600) == 0, open(os.path.join(work, 'dm6_ref.idx.err')).read()[-2000:]
+    want = _parts_of(os.path.join(work, 'dm6_ref'), PARTS); got = [tuple(x) for x in s['parts']]
+    assert len(got) == PARTS and got == want and sum(x[0] for x in want) == s['records'], 'dm6-size x20: SAM differs from the compiled reference (%r against %r)' % (got, want)
     # the same set through the command-line program spanning 2 and 4 device contexts in ONE process (all on the one GPU of the box): pieces of the text dealt to the
     # devices, batches to device x lane, the carried value (which changes at nearly every read of this set) verified in batch order across devices, one writer
     for n, gb, lanes in (((2, 60, 1), (4, 30, 1)) if AT_SCALE_ON_ONE_GPU else ()):

@@ -16,7 +16,7 @@ def test_short_soak_against_the_compiled_reference():
 
 
 def test_a_context_left_idle_maps_the_same_bytes_when_it_resumes():
-    """a device context that has mapped a long-tailed set (the workspace ladder, jobs, helper waves, recycled device buffers all in play), then sits idle for a while (twice twenty seconds) while
+    """a device context that has mapped a long-tailed set (the workspace ladder, jobs, helper waves, recycled device buffers all in play), then sits idle for a while (twice eight seconds) while
     the host churns through memory (page cache and anonymous pages come and go: what a neighbouring CPU job does to a box), then maps again -- twice: same bytes every time,
     and the oracle's.  (Round 3 saw one `Memory access fault by GPU ... address (nil)' in a bench process whose device was idle under heavy host memory pressure.)"""
     from minialign_amd import multi
@@ -42,7 +42,7 @@ def test_a_context_left_idle_maps_the_same_bytes_when_it_resumes():
                     del b; time.sleep(0.2)
             t = threading.Thread(target=churn); t.start()
             for _ in range(2):
-                time.sleep(20)
+                time.sleep(8)
                 assert once() == want
             stop.set(); t.join()
             L.mm_align_destroy(al); L.mm_idx_destroy(mi)
