@@ -14,10 +14,10 @@ def test_hard_repeats_20000_reads_equal_the_reference():
     if not os.path.exists(H.REFBIN): pytest.skip('oracle/_ref not built')
     d = tempfile.mkdtemp(prefix='mmhard_')
     try:
-        ref, rd, spans = H._generate(d, 'hard', (0x5eed0011, 400000000, 12, 0.45), (0x5eed0012, 1.0, 'pacbio'), keep_parts=True, hard=True)
-        bg = H._reference_by_parts('pacbio', ref, rd, spans, os.path.join(d, 'hard_ref'), threads=32, group=2)          # (a 400 Mb index: 2.5 GB per process)
+        ref, rd, spans = H._generate(d, 'hard', H.SIZES['hard_genome'], H.SIZES['hard_reads'], keep_parts=True, hard=True)
+        bg = H._reference_by_parts('pacbio', ref, rd, spans, os.path.join(d, 'hard_ref'), group=2)          # (a 400 Mb index: 2.5 GB per process)
         s, err, sec = H._map_through_samcheck([H.CLI, '-xpacbio', ref, rd], rd, 0, os.devnull, timeout=300)
-        assert s['error'] == '' and s['reads'] == s['primary'] and s['reads'] >= 19000, s
+        assert s['error'] == '' and s['reads'] == s['primary'] and s['reads'] >= H.SIZES['hard_min_reads'], s
         assert bg.wait(timeout=900) == 0, open(os.path.join(d, 'hard_ref.idx.err')).read()[-2000:]
         want = H._parts_of(os.path.join(d, 'hard_ref'), H.PARTS, group=2); got = [tuple(x) for x in s['parts']]
         bad = [p for p in range(H.PARTS) if got[p] != want[p]]

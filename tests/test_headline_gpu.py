@@ -20,6 +20,12 @@ CLI = os.path.join(M.ROOT, 'minialign_amd', 'minialign')
 REFBIN = os.path.join(M.ROOT, 'oracle', '_ref', 'minialign')
 GENSIM = os.path.join(M.ROOT, 'tools', 'gensim')
 PARTS = 16
+# the sizes of the sets and what a run over them must at least show; tests/test_headline_plumbing.py runs this file's tests with small sizes and the oracle's program in place of
+# the device program (no GPU), so that a mistake in the plumbing of these long tests is found before a GPU box is spent on it
+SIZES = dict(dm6_genome=(0x5eed0001, 143700000, 1870, 0.05), dm6_reads=(0x5eed0002, 20.0, 'pacbio'), dm6_min_bases=2.7e9,          # the full x20 set (2.87 Gb), not a sample
+             hg38_genome=(0x5eed0001, 3100000000, 25, 0.05), pb_reads=(0x5eed0002, 3.0, 'pacbio'), pb_min_bases=8.8e9, pb_min_bytes=12e9, pb_min_reads=440000,          # the whole 9.3 Gb set
+             ont_reads=(0x5eed0003, 1.0, 'ont'), ont_min_bases=2.5e9, ont_min_reads=250000,          # the whole 3.1 Gb set
+             hard_genome=(0x5eed0011, 400000000, 12, 0.45), hard_reads=(0x5eed0012, 1.0, 'pacbio'), hard_min_reads=19000, index_threads=32)
 # Several device contexts (or ranks) on the ONE GPU of a test box at FULL size: off unless asked for (MM_TEST_CONTEXTS_AT_SCALE=1).  Three gpurun boxes were lost in
 # round 4 while this file ran, 195 - 225 s into it.  What the three runs had in common was the HOST side of the human-size fixture as it was then -- sixteen read generators
 # at once, part files kept beside the joined file, and one 18 GB reference process per part, 32 of them for the two sets, beside the index builds (see _generate and
@@ -64,7 +70,7 @@ def _last_records(fn, end, n, window):
     assert len(starts) >= n, 'window too small for %d records' % n
     return tail[starts[-n]:]
 
-def _reference_by_parts(preset, ref, rd, spans, out, threads=32, primer=4, window=8 << 20, group=2, wait_for=None):
+def _reference_by_parts(preset, ref, rd, spans, out, threads=None, primer=4, window=8 << 20, group=2, wait_for=None):
     """The compiled reference over a WHOLE set (rd: its parts one after the other, spans: their byte extents): its index file (with `threads` threads), then -t1 processes
     side by side, each over `group` consecutive parts (one stream: its thread buffer carries the state from part to part as a single run over the whole set would) and fed, in
     front of them, the last `primer` reads of the part before -- so that it holds, at the first read of its first part, what the single run would hold there (the carried
@@ -72,7 +78,7 @@ def _reference_by_parts(preset, ref, rd, spans, out, threads=32, primer=4, windo
     18 GB; the first version of this ran one per part for two sets at once (32 x 18 GB beside the index builds) and three gpurun boxes were lost under it.  Eight at a time
     here (143 GB; sixteen at a time -- one set -- is what the one run that survived had for most of its time), and the sets one after the other (`wait_for`: the Popen of the set in front).  Returns the Popen of the shell that runs it all; the line of parts
     [g, g + group) lands in out.<g>.json"""
-    mai = out + '.mai'; sc = _samcheck()
+    mai = out + '.mai'; sc = _samcheck(); threads = threads or SIZES['index_threads']
     lines = []
     lines.append('%s -x%s -t%d -d %s %s 2> %s.idx.err || exit 1' % (REFBIN, preset, threads, mai, ref, out))
     if wait_for is not None: lines.append('while kill -0 %d 2>/dev/null; do sleep 1; done' % wait_for.pid)          # (the index build goes on beside the set in front; the 18 GB processes do not)
@@ -141,13 +147,13 @@ def work():
 
 def test_dm6_size_x20_whole_sam_equals_the_reference(work, hg38):
     # (hg38: asked for here so that the reference's runs over the two human-size sets are under way in the background while this test runs)
-    ref, rd, spans = _generate(work, 'dm6', (0x5eed0001, 143700000, 1870, 0.05), (0x5eed0002, 20.0, 'pacbio'), keep_parts=True)
+    ref, rd, spans = _generate(work, 'dm6', SIZES['dm6_genome'], SIZES['dm6_reads'], keep_parts=True)
     # the reference: every part of the set (1 870 contigs: the carried value changes at nearly every read), eight -t1 processes of two consecutive parts, primed with the reads in
     # front (one -t1 run over the 2.87 Gb takes 107 s of the suite's time; the method is checked against one run in tests/test_oracle_live.py and on this set's like in round 3)
     bg = _reference_by_parts('pacbio', ref, rd, spans, os.path.join(work, 'dm6_ref'))
     s, err, sec = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull)
     assert s['error'] == '' and s['reads'] == s['primary'] and s['mapped'] > 0.98 * s['reads'], s
-    assert s['bases_mapped'] > 2.7e9, s                                             # the full x20 set (2.87 Gb), not a sample
+    assert s['bases_mapped'] > SIZES['dm6_min_bases'], s
     assert bg.wait(timeout=600) == 0, open(os.path.join(work, 'dm6_ref.idx.err')).read()[-2000:]
     want = _parts_of(os.path.join(work, 'dm6_ref'), PARTS); got = [tuple(x) for x in s['parts']]
     assert len(got) == PARTS and got == want and sum(x[0] for x in want) == s['records'], 'dm6-size x20: SAM differs from the compiled reference (%r against %r)' % (got, want)
@@ -172,11 +178,14 @@ def test_dm6_size_x20_whole_sam_equals_the_reference(work, hg38):
 
 @pytest.fixture(scope='module')
 def hg38(work):
+    yield from _hg38_sets(work)
+
+def _hg38_sets(work):
     """the headline set and the ONT-like set in 16 parts each, and -- running in the background on host cores -- the compiled reference over BOTH whole sets, part by part"""
-    genome = (0x5eed0001, 3100000000, 25, 0.05)
-    ref, rd, pb_spans = _generate(work, 'hg38', genome, (0x5eed0002, 3.0, 'pacbio'), keep_parts=True)
+    genome = SIZES['hg38_genome']
+    ref, rd, pb_spans = _generate(work, 'hg38', genome, SIZES['pb_reads'], keep_parts=True)
     bg_pb = _reference_by_parts('pacbio', ref, rd, pb_spans, os.path.join(work, 'pb_ref'))
-    _, ont_rd, ont_spans = _generate(work, 'hg38', genome, (0x5eed0003, 1.0, 'ont'), rd_tag='ont', keep_parts=True)
+    _, ont_rd, ont_spans = _generate(work, 'hg38', genome, SIZES['ont_reads'], rd_tag='ont', keep_parts=True)
     bg_ont = _reference_by_parts('ont.1dsq', ref, ont_rd, ont_spans, os.path.join(work, 'ont_ref'), window=64 << 20, wait_for=bg_pb)
     yield dict(ref=ref, rd=rd, ont=ont_rd, bg_pb=bg_pb, bg_ont=bg_ont)
     for b in (bg_pb, bg_ont):
@@ -187,8 +196,8 @@ def test_hg38_size_x3_whole_set_equals_the_reference_and_device_contexts(work, h
     reads), and the same set over 2 and 4 device contexts in one process"""
     ref, rd = hg38['ref'], hg38['rd']
     s, err, sec = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull)
-    assert s['error'] == '' and s['reads'] == s['primary'] and s['contigs'] == 25, s
-    assert s['bases_mapped'] > 8.8e9 and s['mapped'] > 0.98 * s['reads'] and s['bytes'] > 12e9, s          # the whole 9.3 Gb set
+    assert s['error'] == '' and s['reads'] == s['primary'] and s['contigs'] == SIZES['hg38_genome'][2], s
+    assert s['bases_mapped'] > SIZES['pb_min_bases'] and s['mapped'] > 0.98 * s['reads'] and s['bytes'] > SIZES['pb_min_bytes'], s
     for n, gb, lanes in (((2, 60, 1), (4, 30, 1)) if AT_SCALE_ON_ONE_GPU else ()):
         sn, errn, secn = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull, env=_contexts_env(n, gb, lanes), timeout=300)
         assert sn['error'] == '' and sn['digest'] == s['digest'] and sn['records'] == s['records'] and sn['bytes'] == s['bytes'], (n, s, sn, errn.decode()[-1500:])
@@ -199,15 +208,15 @@ def test_hg38_size_x3_whole_set_equals_the_reference_and_device_contexts(work, h
     assert len(got) == PARTS and sum(x[0] for x in got) == s['records'], s
     bad = [p for p in range(PARTS) if got[p] != want[p]]
     assert not bad, 'hg38-size x3: parts %r differ from the compiled reference (ours %r, reference %r)' % (bad, [got[p] for p in bad], [want[p] for p in bad])
-    assert sum(x[0] for x in want) == s['records'] and s['reads'] > 440000          # all of the set
+    assert sum(x[0] for x in want) == s['records'] and s['reads'] > SIZES['pb_min_reads']          # all of the set
 
 def test_hg38_size_ont_like_whole_set_equals_the_reference(work, hg38):
     ref, rd = hg38['ref'], hg38['ont']
     s, err, sec = _map_through_samcheck([CLI, '-xont.1dsq', ref, rd], rd, 0, os.devnull)
-    assert s['error'] == '' and s['reads'] == s['primary'] and s['contigs'] == 25, s
-    assert s['bases_mapped'] > 2.5e9, s                                             # the whole 3.1 Gb set
+    assert s['error'] == '' and s['reads'] == s['primary'] and s['contigs'] == SIZES['hg38_genome'][2], s
+    assert s['bases_mapped'] > SIZES['ont_min_bases'], s
     assert hg38['bg_ont'].wait(timeout=1500) == 0, open(os.path.join(work, 'ont_ref.idx.err')).read()[-2000:]
     want = _parts_of(os.path.join(work, 'ont_ref'), PARTS); got = [tuple(x) for x in s['parts']]
     bad = [p for p in range(PARTS) if got[p] != want[p]]
     assert not bad, 'hg38-size ONT-like set: parts %r differ from the compiled reference (ours %r, reference %r)' % (bad, [got[p] for p in bad], [want[p] for p in bad])
-    assert sum(x[0] for x in want) == s['records'] and s['reads'] > 250000
+    assert sum(x[0] for x in want) == s['records'] and s['reads'] > SIZES['ont_min_reads']
