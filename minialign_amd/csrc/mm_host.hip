@@ -2457,6 +2457,10 @@ mm_reg_t *build_reg(const OutReg &reg, const AlnRec *alns, const gaba::Segment *
 }
 /* finish, first half (needs the lane's device pools): counters, then the result pools of the batch copied to the host */
 struct Fetched {
+	/* the lane's 32 counters (d_tops), who writes which: [0..7] pool cursors (seed, rescue, root, bin, alignment, segment, path, position-hash regions), [8..15] the sketch and extension
+	 * kernels' statistics, [16] their work counters, [17..23] the extension kernel's profile ([17] longest wave, [19] next, [20] fill, [21] leaf, [22] trace, [23] total), [24..27] + [29] the LDS sort + chain kernel and the chain / scan kernels through
+	 * `prof` = tops + 24 (their prof[0] sort, [1] chain, [2] total, [3] reads beyond the LDS, [5] = tops[29] reads that did not fit: index 4 is used by none of them), [28] the
+	 * HBM sort kernel alone (`prof` = tops + 28, its prof[0] only), [30] the chain sweep's scratch cursor.  The ranges are disjoint as long as nobody starts to use prof[4] */
 	unsigned long long tops[32];
 	Root *root = nullptr; uint64_t *bin = nullptr; AlnRec *aln = nullptr; gaba::Segment *seg = nullptr; uint32_t *path = nullptr;
 	std::unique_ptr<uint8_t[]> own[5];          /* plain host memory when no pinned set is given */
