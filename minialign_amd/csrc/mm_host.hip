@@ -2027,8 +2027,7 @@ static bool make_streams(mm_align_s *a)
 	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithPriority(&a->k2s[i], hipStreamNonBlocking, greatest) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) return false; }
 	a->k2s_ok = true;
 	if(hipHostMalloc((void **)&a->pin_note, 64, hipHostMallocPortable) != hipSuccess) return false;
-	if(least != greatest) { if(hipStreamCreateWithPriority(&a->k3s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) return false; }
-	else if(const char *e = getenv("MM_K3_CU_RESERVE")) {
+	if(const char *e = getenv("MM_K3_CU_RESERVE")) {          /* (instead of the low-priority stream below: a stream with a CU mask comes at the default priority) */
 		/* experiment (off by default; not yet run on a GPU): the extension launches go to a stream whose CU mask leaves every (CUs / n)-th compute unit out, so that the short
 		 * operations of the other lanes -- copies, memsets, the sketch and sort launches -- always find free wave slots somewhere instead of waiting 10 - 40 ms for a
 		 * persistent extension launch to end; the extension kernel pays n CUs for it */
@@ -2039,6 +2038,7 @@ static bool make_streams(mm_align_s *a)
 			if(hipExtStreamCreateWithCUMask(&a->k3s, (uint32_t)mask.size(), mask.data()) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) { a->k3s = nullptr; fprintf(stderr, "[minialign_amd] MM_K3_CU_RESERVE: no stream with a CU mask\n"); }
 		}
 	}
+	if(!a->k3s && least != greatest) { if(hipStreamCreateWithPriority(&a->k3s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) return false; }
 	return true;
 }
 /* a primary context on the current device */
