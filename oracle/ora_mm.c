@@ -735,6 +735,11 @@ static uint64_t mm_seed(om_align_t *self, uint64_t cnt)
 	if(self->seed.n == 0) { return 0; }
 	om_seed_t sentinel = { .rid = INT32_MAX, .upos = (uint32_t)INT32_MIN, .vpos = (uint32_t)INT32_MIN, .lid = INT32_MAX };
 	vec_push(om_seed_t, self->seed, sentinel);
+	{	/* analysis hook (tools/k2s_model.c): the seed arrays as they go into the sort, one record { n, n x 16 bytes } per call */
+		static FILE *dump = NULL; static int asked = 0;
+		if(!asked) { asked = 1; const char *fn = getenv("OM_DUMP_SEEDS"); if(fn) { dump = fopen(fn, "wb"); } }
+		if(dump) { uint64_t n = self->seed.n; fwrite(&n, 8, 1, dump); fwrite(self->seed.a, sizeof(om_seed_t), n, dump); fflush(dump); }
+	}
 	radix_sort_128x((v4u32_t *)self->seed.a, self->seed.n);
 	self->cnt[1] += self->seed.n;
 	return self->seed.n;
