@@ -1054,6 +1054,11 @@ static og_fill_t const *mm_extend_core(om_align_t *self, int bw_idx, og_section_
 	}
 	return m;
 }
+/* analysis hook (tools/trial_stats.py): OM_DUMP_TRIALS=<file> -> one line per extension trial: read ordinal, round, chain, trial of the chain, ns of the downward pass + maximum
+ * search, ns of the upward pass + traceback, outcome (z = maximum 0, d = duplicate, s = score too low / no path, r = recorded, R = recorded and the walk ends) */
+static FILE *om_trial_dump = NULL; static uint64_t om_trial_read = 0, om_trial_round = 0;
+static inline uint64_t om_ns(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
+#define OM_TRIAL(_k, _t, _d, _u, _o) { if(om_trial_dump) { fprintf(om_trial_dump, "%lu\t%lu\t%lu\t%lu\t%lu\t%lu\t%c\n", (unsigned long)om_trial_read, (unsigned long)om_trial_round, (unsigned long)(_k), (unsigned long)(_t), (unsigned long)(_d), (unsigned long)(_u), (_o)); } }
 /* mm_extend, minialign.c:4118-4173 */
 static uint64_t mm_extend(om_align_t *self)
 {
@@ -1061,22 +1066,27 @@ static uint64_t mm_extend(om_align_t *self)
 	for(uint64_t k = 0; k < self->root.n; k++) {
 		if(mm_search_load_root(self, &st, (uint32_t)k)) { if(getenv("OM_DEBUG")) fprintf(stderr, "chain %lu: plen too short, break\n", k); break; }
 		if(getenv("OM_DEBUG")) fprintf(stderr, "chain %lu/%lu: prem %ld aid %u cp(%u,%u) rev %u\n", k, self->root.n, st.prem, st.aid, st.cp.apos, st.cp.bpos, st.rev);
-		for(; st.srem > 0 && st.prem > 0; mm_search_load_next(self, &st)) {
+		uint64_t trial = 0;
+		for(; st.srem > 0 && st.prem > 0; mm_search_load_next(self, &st), trial++) {
+			const uint64_t t0 = om_trial_dump ? om_ns() : 0; uint64_t t1 = 0;
 			og_dp_flush(self->dp);
 			/* QUIRK (minialign.c:4123): _dp(x) ignores its argument, every call uses dp[st.narrow] */
 			og_fill_t const *f = mm_extend_core(self, (int)st.narrow, &self->r[0], self->rtp, &self->q[st.rev], &self->t[0], st.cp);
 			if(getenv("OM_DEBUG")) fprintf(stderr, "  down max %ld\n", f->max);
-			if(f->max == 0) { continue; }
+			if(f->max == 0) { if(om_trial_dump) { OM_TRIAL(k, trial, om_ns() - t0, 0, 'z'); } continue; }
 			og_pos_pair_t const *pp = og_dp_search_max(self->dp, f);
-			if(mm_search_test_dup(self, &st, pp) != 0) { if(getenv("OM_DEBUG")) fprintf(stderr, "  dup\n"); continue; }
+			if(om_trial_dump) { t1 = om_ns(); }
+			if(mm_search_test_dup(self, &st, pp) != 0) { if(getenv("OM_DEBUG")) fprintf(stderr, "  dup\n"); OM_TRIAL(k, trial, t1 - t0, 0, 'd'); continue; }
 			pos_pair_t up = { .apos = self->r[0].len - st.tp.apos, .bpos = self->q[0].len - st.tp.bpos };
 			f = mm_extend_core(self, (int)st.narrow, &self->r[1], self->rtp + 1, &self->q[1 - st.rev], &self->t[0], up);
 			og_alignment_t *a = NULL;
 			if(getenv("OM_DEBUG")) fprintf(stderr, "  up max %ld (from %u,%u)\n", f->max, up.apos, up.bpos);
 			if(getenv("OM_DEBUG_REC")) { fprintf(stderr, "up eid %u max %ld tp %u %u\n", st.eid, (long)f->max, st.tp.apos, st.tp.bpos); }
-			if(f->max < (int64_t)self->min_score || (a = og_dp_trace(self->dp, f)) == NULL) { if(getenv("OM_DEBUG_REC")) { fprintf(stderr, "  rejected (%s)\n", f->max < (int64_t)self->min_score ? "score" : "trace"); } continue; }
+			if(f->max < (int64_t)self->min_score || (a = og_dp_trace(self->dp, f)) == NULL) { if(getenv("OM_DEBUG_REC")) { fprintf(stderr, "  rejected (%s)\n", f->max < (int64_t)self->min_score ? "score" : "trace"); } if(om_trial_dump) { OM_TRIAL(k, trial, t1 - t0, om_ns() - t1, 's'); } continue; }
 			self->cnt[4]++;
-			if(mm_search_record(self, &st, a)) { break; }
+			const uint64_t t2 = om_trial_dump ? om_ns() : 0;
+			if(mm_search_record(self, &st, a)) { OM_TRIAL(k, trial, t1 - t0, t2 - t1, 'R'); break; }
+			OM_TRIAL(k, trial, t1 - t0, t2 - t1, 'r');
 		}
 		if(getenv("OM_DEBUG")) fprintf(stderr, "  finish: n_aln %u score %d min_score %u\n", bin_at(self, st.iid)->n_aln, OFS(self->root.a[st.eid].plen), self->min_score);
 		if(mm_finish_root(self, &st)) { break; }
@@ -1171,7 +1181,10 @@ om_reg_t *om_align_seq(om_align_t *self, uint32_t l_seq, uint8_t const *seq)
 	if(l_seq < self->mi->k || l_seq * self->mcoef < (double)self->min_score) { return NULL; }
 	tbuf_clear(self);
 	init_query(self, l_seq, seq);
+	{ static int asked = 0; if(!asked) { asked = 1; const char *fn = getenv("OM_DUMP_TRIALS"); if(fn) { om_trial_dump = fopen(fn, "w"); } } }
+	om_trial_read++;
 	for(uint64_t i = 0; i < self->mi->n_occ; i++) {
+		om_trial_round = i;
 		if(mm_seed(self, i) == 0) { continue; }
 		if(mm_chain(self) == 0) { continue; }
 		if(mm_extend(self) > 0) { break; }
