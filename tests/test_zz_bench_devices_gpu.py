@@ -1,12 +1,12 @@
-"""GPU, last in the suite and OPT-IN (MM_TEST_NOT_YET_RUN=1): written after GPU access had closed in round 4, none of these has run on a device yet, and a test that has never
-run fails as easily from its own mistakes as from the product's.  They join the default run once they have passed on a box.
+"""GPU, last in the suite.  Written after GPU access had closed in round 4 and opt-in until they had run; all four passed on a box at the start of round 5
+(profiles/round5_unrun_tests.txt) and have been part of the default run since.
 `python bench.py --gpus 2` launched PLAINLY -- no torch.distributed.run, one process -- drives two device contexts through the library's own multi-device engine
 (mm_align_init spans the devices, stream_map deals the batches) and prints ONE JSON line with n_gpus = 2; on a one-GPU box MM_BENCH_SAME_DEVICE puts both contexts on cuda:0."""
 import json, os, subprocess, sys
 import pytest
 import mmlib as M
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get('MM_TEST_NOT_YET_RUN') is None, reason='written after GPU access closed in round 4; has not run on a device yet (MM_TEST_NOT_YET_RUN=1 runs it)')]
+pytestmark = pytest.mark.gpu
 
 def test_bench_line_with_two_devices_in_one_process():
     env = dict(os.environ, MM_BENCH_SAME_DEVICE='1', MM_SLAB_GB='8', PYTHONPATH=M.ROOT)

@@ -40,14 +40,14 @@ unrun)
 switches)
 	box > /dev/null
 	B="python bench.py --steps 3 --warmup 1 --no-cpu --no-cli --no-packed"
-	for cfg in "" "MM_UPLOAD_ONE_SYNC=1" "MM_K3_CU_RESERVE=16" "MM_K3_CU_RESERVE=32" "MM_K3_CU_RESERVE=16 MM_UPLOAD_ONE_SYNC=1" "LANES=6" "LANES=6 MM_K3_CU_RESERVE=16" "LANES=8 MM_K3_CU_RESERVE=16" "LANES=6 MM_K3_CU_RESERVE=32 MM_UPLOAD_ONE_SYNC=1"; do
+	for cfg in "" "MM_UPLOAD_ONE_SYNC=1" "MM_K3_CU_RESERVE=16" "MM_K3_CU_RESERVE=32" "LANES=6" "LANES=6 MM_K3_CU_RESERVE=16" "LANES=8 MM_K3_CU_RESERVE=16" "LANES=6 MM_K3_CU_RESERVE=32 MM_UPLOAD_ONE_SYNC=1"; do
 		echo "== headline: ${cfg:-default}" >> "$OUT/${TAG}_switches.txt"
 		lanes=4; envs=""; for kv in $cfg; do case $kv in LANES=*) lanes=${kv#LANES=} ;; *) envs="$envs $kv" ;; esac; done
 		env $envs timeout 600 $B --lanes $lanes 2> /dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms per step', 'identical' if d.get('sam_identical') in (None, True) else 'SAM DIFFERS')" >> "$OUT/${TAG}_switches.txt" 2>&1
 	done
-	for cfg in "" "MM_K3_RESCUE_FIRST=1" "MM_K3_DEFER_RESCUE=64" "MM_K3_DEFER_RESCUE=64 MM_K3_RESCUE_FIRST=1"; do
+	for cfg in "" "MM_K3_DEFER_RESCUE=64" "MM_K3_DEFER_RESCUE=64 MM_K3_RESCUE_FIRST=1"; do
 		echo "== hard repeats: ${cfg:-default}" >> "$OUT/${TAG}_switches.txt"
-		env $cfg timeout 900 python bench.py --steps 2 --warmup 1 --no-cli --no-packed --workload hg38hard --check-reads 4000 --baseline-reads 4000 2> /dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms per step', 'identical' if d.get('sam_identical') in (None, True) else 'SAM DIFFERS')" >> "$OUT/${TAG}_switches.txt" 2>&1
+		env $cfg timeout 900 python bench.py --steps 1 --warmup 1 --no-cli --no-packed --workload hg38hard --depth 0.3 --check-reads 2000 --baseline-reads 4000 2> /dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms per step', 'identical' if d.get('sam_identical') in (None, True) else 'SAM DIFFERS', 'dp vectors per base', d['config']['dp_vectors_per_base'], 'extend ms summed', d['config']['kernel_ms_per_step (summed over lanes and ranks)']['extend'], 'cpu', (d.get('cpu_baseline') or {}).get('value'))" >> "$OUT/${TAG}_switches.txt" 2>&1
 	done
 	cat "$OUT/${TAG}_switches.txt" ;;
 scale)
