@@ -343,6 +343,10 @@ struct K1Args {
 	unsigned long long *stats;     /* [0] minimizers probed, [1] seeds */
 	const uint32_t *work;          /* read indices to process (n_reads entries) */
 	uint64_t *tap;                 /* stage tap (tests): when set, the stream word of every minimizer (hash << 8 | strand << 7 | position mod w, minialign.c:2402) beside its record */
+	/* room for the minimizer records of the few reads that emit more than their share (a read inside a satellite array or a homopolymer run emits one per position where
+	 * the typical read emits 2 / (w + 1) per base): a region behind the reads' own in min_pool, handed out by a cursor; the records are scratch of this kernel, so a read that
+	 * overflows its share takes min(qlen, ...) records there and runs its first pass again (NULL: no such region, the read reports ERR_SEED_CAP as before) */
+	unsigned long long *min_over_top; uint64_t min_over_base, min_over_cap;
 	unsigned long long *note;      /* pinned HOST memory (or NULL): the last wave of the launch leaves the three pool cursors there -- what the reads of the launch asked for -- so that the host
 	                                * has them when the launch is over without a copy of its own (a 24-byte D2H is a blit kernel that waits for a wave slot beside the extension waves: 17 ms per batch) */
 };
@@ -432,10 +436,13 @@ __global__ void __launch_bounds__(256, MM_SHORT_KERNEL_WAVES) mm_sketch_seed_ker
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		MinRec *rec = a.min_pool + rdfirst64(st->min_off);
-		const uint32_t min_cap = (uint32_t)rdfirst((int)st->min_cap);
+		uint32_t min_cap = (uint32_t)rdfirst((int)st->min_cap);
 		uint32_t n_rec = 0;            /* uniform */
 		uint32_t n_seed = 0, n_resc = 0, n_resc_hits = 0;
+		bool in_share = true;          /* the records are in the read's own share of the pool (the stage tap is parallel to that) */
 
+		pass1_again:
+		n_rec = 0;
 		/* pass 1: minimizers in order, probe the index, keep (qs, n, ref) records */
 		uint64_t h_prev = ~0ull;       /* h of the previous 64 positions (lane i = position base - 64 + i) */
 		uint64_t v_last = 0;           /* v of the last position of the previous chunk: u of the reference, initial cap value 0 (minialign.c:2412) */
@@ -468,12 +475,21 @@ __global__ void __launch_bounds__(256, MM_SHORT_KERNEL_WAVES) mm_sketch_seed_ker
 				}
 				uint32_t pos = (uint32_t)((qpos + (k & (uint32_t)-(int32_t)fr)) ^ (uint32_t)-(int32_t)fr);   /* minialign.c:3482 */
 				uint32_t slot_i = n_rec + my;
-				if(slot_i < min_cap) { rec[slot_i] = MinRec{ pos, n > max_occ ? 0u : n, ref }; if(a.tap) { a.tap[(uint64_t)(rec - a.min_pool) + slot_i] = hh << 8 | fr << 7 | (uint64_t)(qpos % w); } }
+				if(slot_i < min_cap) { rec[slot_i] = MinRec{ pos, n > max_occ ? 0u : n, ref }; if(a.tap && in_share) { a.tap[(uint64_t)(rec - a.min_pool) + slot_i] = hh << 8 | fr << 7 | (uint64_t)(qpos % w); } }
 			}
 			n_rec += (uint32_t)__popcll(em);
 			n_probe += (unsigned long long)__popcll(em);
 		}
-		if(n_rec > min_cap) { n_rec = min_cap; if(lane == 0) { st->err |= ERR_SEED_CAP; } }
+		if(n_rec > min_cap) {
+			if(in_share && a.min_over_top != nullptr) {
+				/* more minimizers than the read's share holds: room for one per position from the overflow region, and the pass again */
+				const uint64_t need = ((uint64_t)qlen + 63u) & ~63ull; unsigned long long off = 0;
+				if(lane == 0) { off = atomicAdd(a.min_over_top, (unsigned long long)need); }
+				off = rdfirst64(off);
+				if(off + need <= a.min_over_cap) { rec = a.min_pool + a.min_over_base + off; min_cap = (uint32_t)need; in_share = false; goto pass1_again; }
+			}
+			n_rec = min_cap; if(lane == 0) { st->err |= ERR_SEED_CAP; }
+		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		/* totals */
 		for(uint32_t i = (uint32_t)lane; i < n_rec + 63 - ((n_rec + 63) % 64); i += 64) {
@@ -1654,7 +1670,7 @@ struct K3Args {
 	 * (reference, cp_a, cp_b, strand) -- is a job any wave of the launch takes BEFORE the waves start on the reads; the wave that later walks the read's chains in order,
 	 * with the real hash and bins, takes a job's result where the inputs of the trial it is about to run are the job's (agent-scope release / acquire between the two
 	 * waves).  Same results by construction.  NULL: no jobs */
-	const struct SpecJob *jobs; struct SpecMemo *memo; unsigned long long *job_top;      /* job_top[0] = jobs enumerated (mm_spec_jobs_kernel), [1] = cursor, [2] staged path words, [3] staged segments, [4] memo hits */
+	const struct SpecJob *jobs; struct SpecMemo *memo; unsigned long long *job_top;      /* job_top[0] = jobs enumerated (mm_spec_jobs_kernel), [1] = cursor, [2] staged path words, [3] staged segments (= stage_top), [4] memo hits */
 	uint64_t job_cap; uint32_t *spath; uint64_t spath_cap; gaba::Segment *sseg; uint64_t sseg_cap;
 	/* retry jobs: after a recorded alignment whose chain has length to spare, mm_search_load_next hands out up to eight more seeds of the chain, one per trial, and nearly every one of
 	 * those trials is a full downward pass that ends in a maximum already in the hash (a duplicate, thrown away, minialign.c:3969) -- the tail of a launch is a read doing that on one
@@ -1665,7 +1681,10 @@ struct K3Args {
 	uint32_t rq_helper_mask;             /* one wave in (mask + 1) is a helper for the retry jobs (one in 128 by default): the first wave of one workgroup in (mask + 1) / 4 of every XCD; every helper holds a wave slot the other lanes' launches wait for */
 	uint32_t full_n;                     /* workspaces per XCD that make a class complete: one for every wave the XCD can hold */
 	uint32_t rq_early;                   /* helpers are helpers from the start of the launch (they take no reads): the reads that publish retry jobs are at the front of the work list */
-	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = helpers' cursor, [2] = reads done, [3] = results taken */
+	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = the takers' cursor, [2] = reads done, [3] = results taken, [4] = reads being walked that have published the chains of a round */
+	unsigned long long *stage_top;       /* cursors of the staging area (spath / sseg) that the traced jobs of either kind write to: [0] path words, [1] segments */
+	uint32_t round_jobs;                 /* 1: a read publishes the chains of a round that was chained inside the launch as jobs (rjobs, JOB_FULL) */
+	uint32_t dyn0_min;                   /* experiment (MM_K3_DYN_ROUND0 = n, off = 0): a read with n or more passing chains in the round the launch starts with that got no chain jobs before the launch publishes them itself when its wave takes it */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 	uint32_t defer_thr;                  /* experiment (MM_K3_DEFER_RESCUE, off = 0): a read left without a result by the first threshold that has this many rescue hits waiting does NOT go on inside
 	                                      * the launch; the host runs its later rounds as launches of their own, where the chains it finds there are spread over the launch as chain jobs */
@@ -1728,11 +1747,12 @@ struct Search {                 /* mm_search_t, minialign.c:3218 */
 	int64_t prem; uint32_t pacc, crem, srem, narrow, min_score;
 };
 constexpr uint32_t MM_CREM = 50000, MM_SREM = 8;
-struct SpecJob { uint32_t r, aid, cp_a, cp_b, rev, rlen, rcirc, pad; };
+struct SpecJob { uint32_t r, aid, cp_a, cp_b, rev, rlen, rcirc, pad; };          /* pad: band width class of the trial (sr.narrow: 0 .. 2) | JOB_FULL */
+constexpr uint32_t JOB_FULL = 0x100u;          /* the whole first trial of a chain (downward pass, max search, upward pass, traceback into the staging area); without it: downward pass + max search only (a retry trial) */
 struct SpecMemo {
 	uint32_t state;                  /* 0: not done yet; bit 31: done, bit 0: downward pass + max search valid, bit 1: upward pass (+ traceback when mmax1 >= min_score) valid */
 	uint32_t aid, cp_a, cp_b, rev;   /* the inputs it was computed for */
-	uint32_t pp_apos, pp_bpos; uint64_t pp_plen; int64_t mmax0;
+	uint32_t pp_apos, pp_bpos, bw; uint64_t pp_plen; int64_t mmax0;
 	int64_t mmax1; uint64_t tplen; uint64_t path_off; uint32_t seg_off;
 	gaba::AlnOut ao;
 };
@@ -1793,6 +1813,81 @@ __device__ __attribute__((noinline)) TraceOut k3_trace(DpIn in, uint32_t tail, g
 	uint32_t *lfw = (uint32_t *)&lf; for(uint32_t i = 0; i < sizeof(gaba::Leaf) / 4; i++) { lfw[i] = (uint32_t)rdfirst((int)lfw[i]); }
 	o.ao = gaba::dp_trace_finish(x, (uint32_t)rdfirst((int)tail), lf, rdfirst64(plen), (uint32_t *)rdfirst64((uint64_t)path), (gaba::Segment *)rdfirst64((uint64_t)seg), 8);
 	o.d = DpOut{ x.top, x.err, x.n_vec, x.n_blk, x.n_tr };
+	return o;
+}
+
+/*
+ * One job: a trial of a chain as a pure function of its inputs (reference, cp_a, cp_b, strand, band width; minialign.c:4134-4166 up to the duplicate test, and with
+ * JOB_FULL on through the upward pass and the traceback, whose path words and segments go to a staging area).  Run by whichever wave of the launch takes the job --
+ * the chain jobs enumerated before the launch (K3Args.jobs), the chains a read finds in a later occurrence-threshold round and the retry trials behind a recorded
+ * alignment (K3Args.rjobs) -- on the workspace that wave holds (flushed by the caller).  The result goes out with plain stores, an agent-scope release, the drain the
+ * compiler may drop, then the flag (MI355X_MICROARCH.md, inter-workgroup visibility: the wave that takes it may sit on another XCD): flag_in_memo -> the memo's own
+ * state word (bit 31 | valid bits; it reads 0 until then), else *flag = flag_val with the valid bits in the memo.
+ */
+struct JobOut { DpOut d; uint32_t n_fill, n_trace; };
+__device__ __attribute__((noinline)) JobOut k3_run_job(DpIn din, SpecJob j, uint32_t qlen, uint64_t q_off, uint64_t roff, uint32_t min_score,
+	SpecMemo *mo_out, uint32_t *flag, uint32_t flag_val, int flag_in_memo, uint32_t *spath, uint64_t spath_cap, gaba::Segment *sseg, uint64_t sseg_cap, unsigned long long *stage_top)
+{
+	const int lane = lane_id();
+	const uint32_t aid = (uint32_t)rdfirst((int)j.aid), cp_a = (uint32_t)rdfirst((int)j.cp_a), cp_b = (uint32_t)rdfirst((int)j.cp_b);
+	const uint32_t rev = (uint32_t)rdfirst((int)j.rev), rlen = (uint32_t)rdfirst((int)j.rlen), kind = (uint32_t)rdfirst((int)j.pad); const int rcirc = rdfirst((int)j.rcirc);
+	const int bw = (int)(kind & 0xffu); const bool full = (kind & JOB_FULL) != 0;
+	qlen = (uint32_t)rdfirst((int)qlen); q_off = rdfirst64(q_off); roff = rdfirst64(roff); min_score = (uint32_t)rdfirst((int)min_score);
+	mo_out = (SpecMemo *)rdfirst64((uint64_t)mo_out); flag = (uint32_t *)rdfirst64((uint64_t)flag); flag_val = (uint32_t)rdfirst((int)flag_val); flag_in_memo = rdfirst(flag_in_memo);
+	spath = (uint32_t *)rdfirst64((uint64_t)spath); spath_cap = rdfirst64(spath_cap); sseg = (gaba::Segment *)rdfirst64((uint64_t)sseg); sseg_cap = rdfirst64(sseg_cap);
+	stage_top = (unsigned long long *)rdfirst64((uint64_t)stage_top);
+	const gaba::Sec rsec_f = gaba::Sec{ aid << 1, rlen, roff, 0, 0 }, rsec_r = gaba::Sec{ (aid << 1) + 1, rlen, roff, 0, 1 };
+	const gaba::Sec qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }, qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
+	SpecMemo mo; mo.state = 0; mo.aid = aid; mo.cp_a = cp_a; mo.cp_b = cp_b; mo.rev = rev; mo.bw = (uint32_t)bw; mo.mmax0 = 0; mo.mmax1 = 0; mo.tplen = 0; mo.path_off = 0; mo.seg_off = 0;
+	mo.pp_apos = mo.pp_bpos = 0; mo.pp_plen = 0;
+	mo.ao.status = 0; mo.ao.score = 0; mo.ao.identity = 0; mo.ao.agcnt = mo.ao.bgcnt = mo.ao.dcnt = mo.ao.slen = mo.ao.plen = 0;
+	JobOut o; o.n_fill = 0; o.n_trace = 0; o.d.n_vec = 0; o.d.n_blk = 0; o.d.n_tr = 0;
+	ExtOut eo = k3_extend_core(din, bw, rsec_f, cp_a, rev ? qsec_r : qsec_f, cp_b, 1, rcirc);
+	uint32_t top = (uint32_t)rdfirst((int)eo.d.top); int err = rdfirst(eo.d.err);
+	o.d.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); o.d.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk); o.n_fill += (uint32_t)rdfirst((int)eo.n_fill);
+	uint32_t m = (uint32_t)rdfirst((int)eo.m); int64_t mmax = (int64_t)rdfirst64((uint64_t)eo.mmax);
+	bool go = err == 0;
+	if(go) { mo.mmax0 = mmax; mo.state = 1; if(mmax == 0) { go = false; } }
+	if(go) {
+		din.top = top;
+		LeafOut lo = k3_leaf_search(din, m, 1);
+		mo.pp_apos = (uint32_t)rdfirst((int)lo.pp.apos); mo.pp_bpos = (uint32_t)rdfirst((int)lo.pp.bpos); mo.pp_plen = rdfirst64(lo.pp.plen);
+	}
+	if(go && full) {
+		const uint32_t tp_a = (uint32_t)max(1, min((int32_t)mo.pp_apos, (int32_t)rlen)), tp_b = (uint32_t)max(1, min((int32_t)mo.pp_bpos, (int32_t)qlen));
+		din.top = top;
+		ExtOut e1 = k3_extend_core(din, bw, rsec_r, rlen - tp_a, rev ? qsec_f : qsec_r, qlen - tp_b, 0, rcirc);
+		top = (uint32_t)rdfirst((int)e1.d.top); err = rdfirst(e1.d.err);
+		o.d.n_vec += (uint32_t)rdfirst((int)e1.d.n_vec); o.d.n_blk += (uint32_t)rdfirst((int)e1.d.n_blk); o.n_fill += (uint32_t)rdfirst((int)e1.n_fill);
+		m = (uint32_t)rdfirst((int)e1.m); mmax = (int64_t)rdfirst64((uint64_t)e1.mmax);
+		if(err == 0) {
+			mo.mmax1 = mmax;
+			if(mmax < (int64_t)min_score) { mo.state |= 2; }
+			else {
+				din.top = top;
+				LeafOut l1 = k3_leaf_search(din, m, 0);
+				const uint64_t tplen = rdfirst64(l1.plen);
+				const uint64_t need_words = (tplen + 31) / 32 + 2;
+				unsigned long long po = 0, so_ = 0;
+				if(lane == 0) { po = atomicAdd(&stage_top[0], (unsigned long long)need_words); so_ = atomicAdd(&stage_top[1], 8ull); }
+				po = rdfirst64(po); so_ = rdfirst64(so_);
+				if(po + need_words <= spath_cap && so_ + 8 <= sseg_cap) {
+					din.top = top;
+					TraceOut to = k3_trace(din, m, l1.lf, tplen, spath + po, sseg + so_);
+					gaba::AlnOut ao = to.ao;
+					ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
+					if(rdfirst(to.d.err) == 0) { mo.ao = ao; mo.tplen = tplen; mo.path_off = po; mo.seg_off = (uint32_t)so_; o.d.n_tr += (uint32_t)rdfirst((int)to.d.n_tr); o.n_trace++; mo.state |= 2; }
+				}
+			}
+		}
+	}
+	const uint32_t bits = mo.state;
+	if(flag_in_memo) { mo.state = 0; flag = &mo_out->state; flag_val = bits | 0x80000000u; }
+	if(lane == 0) { *mo_out = mo; }
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if(lane == 0) { __hip_atomic_store(flag, flag_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	o.d.top = top; o.d.err = 0;
 	return o;
 }
 
@@ -2050,6 +2145,18 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
 			if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[_want].next_base) * MM_NEXT_STRIDE(a.next_cap); next_scratch = (uint32_t *)(next + a.next_cap); } \
 		} }
+	/* a job on the workspace this wave holds (the caller has made sure of its class): counters of the DP work go to this wave */
+	auto run_job = [&](const SpecJob &j, SpecMemo *mo_out, uint32_t *flag, uint32_t flag_val, int flag_in_memo) {
+		const uint32_t jr = (uint32_t)rdfirst((int)j.r), ja = (uint32_t)rdfirst((int)j.aid);
+		gaba::dp_flush(x); x.err = 0;
+		DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
+		const unsigned long long cyj0 = MM_TICK();
+		JobOut jo = k3_run_job(din, j, a.in[jr].qlen, a.in[jr].q_off, a.idx.seq_off[ja], a.min_score, mo_out, flag, flag_val, flag_in_memo, a.spath, a.spath_cap, a.sseg, a.sseg_cap, a.stage_top);
+		x.n_vec += (uint32_t)rdfirst((int)jo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)jo.d.n_blk); x.n_tr += (uint32_t)rdfirst((int)jo.d.n_tr);
+		n_fill += (uint32_t)rdfirst((int)jo.n_fill); n_trace += (uint32_t)rdfirst((int)jo.n_trace);
+		cy_fill += MM_TICK() - cyj0;
+		gaba::dp_flush(x); x.err = 0;
+	};
 	/* jobs first: the first trials of the chains of the heaviest reads, one per wave at a time, by every wave of the launch (K3Args.jobs) */
 	if(a.jobs && a.ring) {
 		const unsigned long long n_jobs = min(rdfirst64(a.job_top[0]), (unsigned long long)a.job_cap);
@@ -2059,11 +2166,9 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			if(lane == 0) { ji = atomicAdd(&a.job_top[1], 1ull); }
 			ji = rdfirst64(ji);
 			if(ji >= n_jobs) { break; }
-			const SpecJob j = a.jobs[ji];
+			SpecJob j = a.jobs[ji];
 			if((uint32_t)rdfirst((int)j.r) == 0xffffffffu) { continue; }          /* a slot of a read whose jobs did not fit (mm_spec_jobs_kernel) */
-			const uint32_t r = (uint32_t)rdfirst((int)j.r), aid = (uint32_t)rdfirst((int)j.aid), cp_a = (uint32_t)rdfirst((int)j.cp_a), cp_b = (uint32_t)rdfirst((int)j.cp_b);
-			const uint32_t rev = (uint32_t)rdfirst((int)j.rev), rlen = (uint32_t)rdfirst((int)j.rlen); const int rcirc = rdfirst((int)j.rcirc);
-			const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen); const uint64_t q_off = rdfirst64(a.in[r].q_off), roff = rdfirst64(a.idx.seq_off[aid]);
+			const uint32_t qlen = (uint32_t)rdfirst((int)a.in[(uint32_t)rdfirst((int)j.r)].qlen);
 			{
 				/* the workspace without waiting: the wave holds a claimed job, and the waves that hold the workspaces of a scarce class may soon be waiting for this very job.
 				 * None free: the job is handed back undone (the read's own wave runs the trial when it gets there, as without jobs) */
@@ -2076,102 +2181,77 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				if(!have) { K3_TRY_SLAB(want, have); }
 				if(!have) { if(lane == 0) { __hip_atomic_store(&a.memo[ji].state, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } continue; }
 			}
-			const gaba::Sec rsec_f = gaba::Sec{ aid << 1, rlen, roff, 0, 0 }, rsec_r = gaba::Sec{ (aid << 1) + 1, rlen, roff, 0, 1 };
-			const gaba::Sec qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }, qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
-			SpecMemo mo; mo.state = 0; mo.aid = aid; mo.cp_a = cp_a; mo.cp_b = cp_b; mo.rev = rev; mo.mmax0 = 0; mo.mmax1 = 0; mo.tplen = 0; mo.path_off = 0; mo.seg_off = 0;
-			mo.pp_apos = mo.pp_bpos = 0; mo.pp_plen = 0;
-			mo.ao.status = 0; mo.ao.score = 0; mo.ao.identity = 0; mo.ao.agcnt = mo.ao.bgcnt = mo.ao.dcnt = mo.ao.slen = mo.ao.plen = 0;
-			gaba::dp_flush(x); x.err = 0;
-			DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
-			const unsigned long long cyj0 = MM_TICK();
-			ExtOut eo = k3_extend_core(din, 0, rsec_f, cp_a, rev ? qsec_r : qsec_f, cp_b, 1, rcirc);
-			x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk); n_fill += (uint32_t)rdfirst((int)eo.n_fill);
-			uint32_t m = (uint32_t)rdfirst((int)eo.m); int64_t mmax = (int64_t)rdfirst64((uint64_t)eo.mmax);
-			bool go = x.err == 0;
-			if(go) { mo.mmax0 = mmax; mo.state = 1; if(mmax == 0) { go = false; } }
-			if(go) {
-				din.top = x.top;
-				LeafOut lo = k3_leaf_search(din, m, 1);
-				gaba::PosPair pp = lo.pp;
-				mo.pp_apos = (uint32_t)rdfirst((int)pp.apos); mo.pp_bpos = (uint32_t)rdfirst((int)pp.bpos); mo.pp_plen = rdfirst64(pp.plen);
-				const uint32_t tp_a = (uint32_t)max(1, min((int32_t)mo.pp_apos, (int32_t)rlen)), tp_b = (uint32_t)max(1, min((int32_t)mo.pp_bpos, (int32_t)qlen));
-				din.top = x.top;
-				ExtOut e1 = k3_extend_core(din, 0, rsec_r, rlen - tp_a, rev ? qsec_f : qsec_r, qlen - tp_b, 0, rcirc);
-				x.top = (uint32_t)rdfirst((int)e1.d.top); x.err = rdfirst(e1.d.err); x.n_vec += (uint32_t)rdfirst((int)e1.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)e1.d.n_blk); n_fill += (uint32_t)rdfirst((int)e1.n_fill);
-				m = (uint32_t)rdfirst((int)e1.m); mmax = (int64_t)rdfirst64((uint64_t)e1.mmax);
-				if(x.err == 0) {
-					mo.mmax1 = mmax;
-					if(mmax < (int64_t)a.min_score) { mo.state |= 2; }
-					else {
-						din.top = x.top;
-						LeafOut l1 = k3_leaf_search(din, m, 0);
-						const uint64_t tplen = rdfirst64(l1.plen);
-						const uint64_t need_words = (tplen + 31) / 32 + 2;
-						unsigned long long po = 0, so_ = 0;
-						if(lane == 0) { po = atomicAdd(&a.job_top[2], (unsigned long long)need_words); so_ = atomicAdd(&a.job_top[3], 8ull); }
-						po = rdfirst64(po); so_ = rdfirst64(so_);
-						if(po + need_words <= a.spath_cap && so_ + 8 <= a.sseg_cap) {
-							DpIn din2; din2.c = x.c; din2.ar0 = ar[0]; din2.ar1 = ar[1]; din2.slab = x.slab; din2.top = x.top; din2.cap = x.cap;
-							TraceOut to = k3_trace(din2, m, l1.lf, tplen, a.spath + po, a.sseg + so_);
-							gaba::AlnOut ao = to.ao;
-							ao.status = rdfirst(ao.status); ao.plen = (uint32_t)rdfirst((int)ao.plen); ao.slen = (uint32_t)rdfirst((int)ao.slen);
-							if(rdfirst(to.d.err) == 0) { mo.ao = ao; mo.tplen = tplen; mo.path_off = po; mo.seg_off = (uint32_t)so_; x.n_tr += (uint32_t)rdfirst((int)to.d.n_tr); n_trace++; mo.state |= 2; }
-						}
-					}
-				}
-			}
-			cy_fill += MM_TICK() - cyj0;
-			x.err = 0;
-			/* publish: the payload with plain stores (the path words and segments came from the traceback, the record from lane 0), an agent-scope release -- the wave
-			 * that takes it may sit on another XCD --, the drain the compiler may drop, then the flag (MI355X_MICROARCH.md, inter-workgroup visibility) */
-			const uint32_t done_state = mo.state | 0x80000000u; mo.state = 0;
-			if(lane == 0) { a.memo[ji] = mo; }
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if(lane == 0) { __hip_atomic_store(&a.memo[ji].state, done_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			j.pad = JOB_FULL;
+			run_job(j, a.memo + ji, nullptr, 0u, 1);
 		}
 		__builtin_amdgcn_s_setprio(0);
 	}
-	/* a retry job (K3Args.rjobs): the downward pass of a trial and its max search, into rmemo[ji]; run by a helper wave, or by the read's own wave ahead of its turn */
+	/* jobs published inside the launch (K3Args.rjobs; SpecJob.pad says which kind): the retry trials behind a recorded alignment (downward pass + max search) and the
+	 * first trials of the chains a read finds in a later occurrence-threshold round (the whole trial), into rmemo[ji]; taken by helper waves, by every wave between two
+	 * reads, by waves that have run out of reads while a read with published chains is still being walked, or by the read's own wave ahead of its turn */
 	enum : uint32_t { RJ_EMPTY = 0, RJ_READY = 1, RJ_CLAIMED = 2, RJ_DONE = 3, RJ_CANCELLED = 4 };
-	auto run_rjob = [&](uint32_t ji) {
-		const SpecJob j = a.rjobs[ji];
-		const uint32_t r = (uint32_t)rdfirst((int)j.r), aid = (uint32_t)rdfirst((int)j.aid), cp_a = (uint32_t)rdfirst((int)j.cp_a), cp_b = (uint32_t)rdfirst((int)j.cp_b);
-		const uint32_t rev = (uint32_t)rdfirst((int)j.rev), rlen = (uint32_t)rdfirst((int)j.rlen); const int rcirc = rdfirst((int)j.rcirc), bw = rdfirst((int)j.pad);
-		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen); const uint64_t q_off = rdfirst64(a.in[r].q_off), roff = rdfirst64(a.idx.seq_off[aid]);
-		K3_NEED_SLAB(qlen);
-		const gaba::Sec rsec_f = gaba::Sec{ aid << 1, rlen, roff, 0, 0 };
-		const gaba::Sec qsec_f = gaba::Sec{ 0, qlen, q_off, 1, 0 }, qsec_r = gaba::Sec{ 1, qlen, q_off, 1, 1 };
-		SpecMemo mo; mo.state = 0; mo.aid = aid; mo.cp_a = cp_a; mo.cp_b = cp_b; mo.rev = rev; mo.mmax0 = 0; mo.mmax1 = 0; mo.tplen = 0; mo.path_off = 0; mo.seg_off = (uint32_t)bw;
-		mo.pp_apos = mo.pp_bpos = 0; mo.pp_plen = 0;
-		mo.ao.status = 0; mo.ao.score = 0; mo.ao.identity = 0; mo.ao.agcnt = mo.ao.bgcnt = mo.ao.dcnt = mo.ao.slen = mo.ao.plen = 0;
-		gaba::dp_flush(x); x.err = 0;
-		DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
-		ExtOut eo = k3_extend_core(din, bw, rsec_f, cp_a, rev ? qsec_r : qsec_f, cp_b, 1, rcirc);
-		x.top = (uint32_t)rdfirst((int)eo.d.top); x.err = rdfirst(eo.d.err); x.n_vec += (uint32_t)rdfirst((int)eo.d.n_vec); x.n_blk += (uint32_t)rdfirst((int)eo.d.n_blk); n_fill += (uint32_t)rdfirst((int)eo.n_fill);
-		const uint32_t m = (uint32_t)rdfirst((int)eo.m); const int64_t mmax = (int64_t)rdfirst64((uint64_t)eo.mmax);
-		if(x.err == 0) {
-			mo.mmax0 = mmax; mo.state = 1;
-			if(mmax != 0) {
-				din.top = x.top;
-				LeafOut lo = k3_leaf_search(din, m, 1);
-				mo.pp_apos = (uint32_t)rdfirst((int)lo.pp.apos); mo.pp_bpos = (uint32_t)rdfirst((int)lo.pp.bpos); mo.pp_plen = rdfirst64(lo.pp.plen);
-			}
-		}
-		x.err = 0;
-		if(lane == 0) { a.rmemo[ji] = mo; }
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		if(lane == 0) { __hip_atomic_store(&a.rstate[ji], (uint32_t)RJ_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-	};
 	const bool rq_on = a.rjobs != nullptr && a.ring != nullptr && persistent;
+	/* the read's own wave, while a job it needs is in another wave's hands: one of its later jobs (slots [q0, q1)), if one is still unclaimed */
+	auto own_job = [&](uint32_t q0, uint32_t q1) -> bool {
+		uint32_t take = 0xffffffffu;
+		if(lane == 0) { for(uint32_t q = q0; q < q1; q++) { if(atomicCAS(&a.rstate[q], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY) { take = q; break; } } }
+		take = (uint32_t)rdfirst((int)take);
+		if(take == 0xffffffffu) { return false; }
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		run_job(a.rjobs[take], a.rmemo + take, a.rstate + take, (uint32_t)RJ_DONE, 0);
+		return true;
+	};
 
 	/* the helpers: the first wave of one workgroup in (mask + 1) / 4, counted within an XCD (workgroup b runs on XCD b % 8: the workspaces a helper can take are its XCD's) */
 	const bool rq_helper = rq_on && (threadIdx.x >> 6) == 0 && ((blockIdx.x >> 3) & (max(a.rq_helper_mask, 3u) >> 2)) == 0;
+	bool no_reads = rq_helper && a.rq_early;          /* this wave takes no (more) reads */
+	uint32_t rq_mine = 0xffffffffu;                   /* a slot number this wave drew that has not been published yet */
 	while(true) {
+		if(rq_on) {
+			/* published jobs come before the next read: a wave with reads left takes what is there and goes on; one without stays -- a helper until the last read is done,
+			 * any other wave while a read that has published the chains of a later round is still being walked (rq_ctl[4]) */
+			uint32_t idle = 0;
+			while(true) {
+				uint32_t ji = rq_mine, stt = 0, fin = 0, wide = 0;
+				if(lane == 0) {
+					if(ji == 0xffffffffu) {
+						const uint32_t cur = __hip_atomic_load(&a.rq_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), top = __hip_atomic_load(&a.rq_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if(cur < top && cur < a.rq_cap) { ji = atomicAdd(&a.rq_ctl[1], 1u); if(ji >= a.rq_cap) { ji = 0xffffffffu; } }
+					}
+					if(ji != 0xffffffffu) { stt = __hip_atomic_load(&a.rstate[ji], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					if(no_reads) { fin = __hip_atomic_load(&a.rq_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.n_work ? 1u : 0u; wide = __hip_atomic_load(&a.rq_ctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				}
+				ji = (uint32_t)rdfirst((int)ji); stt = (uint32_t)rdfirst((int)stt); fin = (uint32_t)rdfirst((int)fin); wide = (uint32_t)rdfirst((int)wide);
+				if(ji != 0xffffffffu && stt == RJ_READY) {
+					/* the workspace the job needs comes BEFORE the claim: a claimed job is one that will be finished, whatever the waves that wait for it hold (with several
+					 * workspace classes a wave that claimed first and then waited for a workspace of a scarce class could wait for the very waves that wait for it) */
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+					const uint32_t jr = (uint32_t)rdfirst((int)a.rjobs[ji].r), jq = (uint32_t)rdfirst((int)a.in[jr].qlen);
+					int want = 0; while(want + 1 < (int)a.n_cls && jq > a.cls[want].qmax) { want++; }
+					bool have = want == slab_cls;
+					if(!have) { K3_TRY_SLAB(want, have); }
+					if(have) { if(lane == 0) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY ? 100u : 99u; } stt = (uint32_t)rdfirst((int)stt); }
+					else { stt = RJ_EMPTY; }          /* no workspace of that class free: the job stays with its owner unless one comes back before the owner gets there */
+				}
+				if(ji != 0xffffffffu && stt == 100u) {
+					/* (at the top priority: the wave that waits for this result is the critical path of the launch) */
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __builtin_amdgcn_s_setprio(3);
+					run_job(a.rjobs[ji], a.rmemo + ji, a.rstate + ji, (uint32_t)RJ_DONE, 0);
+					__builtin_amdgcn_s_setprio(0); rq_mine = 0xffffffffu; idle = 0;
+					/* a workspace of a class above the ordinary one goes back at once: the classes are small, and a wave that sat on one between jobs could be what a read is waiting for */
+					if(slab_cls >= 1) { K3_RING_GIVE(slab_cls, slab_no); slab_cls = -1; }
+					continue;
+				}
+				if(ji != 0xffffffffu && stt != RJ_EMPTY) { rq_mine = 0xffffffffu; idle = 0; continue; }          /* taken by its owner, done or cancelled: the next one */
+				rq_mine = ji;                                                                                 /* drawn but not published yet (or nothing drawn) */
+				if(!no_reads) { if(ji == 0xffffffffu || ++idle > 4u) { break; } __builtin_amdgcn_s_sleep(8); continue; }          /* (reads are waiting: on with them) */
+				if(fin || (!rq_helper && wide == 0u)) { break; }
+				__builtin_amdgcn_s_sleep(64);
+			}
+		}
+		if(no_reads) { break; }
 		uint32_t wi = wave;
-		if(rq_helper && a.rq_early) { wi = 0xffffffffu; }
-		else if(persistent && a.n_cls > 1 && a.ring) {
+		if(persistent && a.n_cls > 1 && a.ring) {
 			/* several workspace classes: a read of the highest class that has reads left AND a workspace at hand (held already, or free on this XCD right now); else one of
 			 * the ordinary class; when that is used up, what is left above it, waiting for a workspace as need be */
 			wi = 0xffffffffu;
@@ -2195,44 +2275,8 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		}
 		else if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
 		if(wi >= a.n_work) {
-			/* no read left for this wave: it takes retry jobs of the reads that are still being walked until the last of them is done */
-			if(rq_helper) {
-				uint32_t mine = 0xffffffffu;          /* a slot number this wave drew that has not been published yet */
-				while(true) {
-					uint32_t ji = mine, stt = 0, fin = 0;
-					if(lane == 0) {
-						if(ji == 0xffffffffu) {
-							const uint32_t cur = __hip_atomic_load(&a.rq_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), top = __hip_atomic_load(&a.rq_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-							if(cur < top && cur < a.rq_cap) { ji = atomicAdd(&a.rq_ctl[1], 1u); if(ji >= a.rq_cap) { ji = 0xffffffffu; } }
-						}
-						if(ji != 0xffffffffu) { stt = __hip_atomic_load(&a.rstate[ji], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-						fin = __hip_atomic_load(&a.rq_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.n_work ? 1u : 0u;
-					}
-					ji = (uint32_t)rdfirst((int)ji); stt = (uint32_t)rdfirst((int)stt); fin = (uint32_t)rdfirst((int)fin);
-					if(ji != 0xffffffffu && stt == RJ_READY) {
-						/* the workspace the job needs comes BEFORE the claim: a claimed job is one that will be finished, whatever the waves that wait for it hold (with several
-						 * workspace classes a helper that claimed first and then waited for a workspace of a scarce class could wait for the very waves that wait for it) */
-						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-						const uint32_t jr = (uint32_t)rdfirst((int)a.rjobs[ji].r), jq = (uint32_t)rdfirst((int)a.in[jr].qlen);
-						int want = 0; while(want + 1 < (int)a.n_cls && jq > a.cls[want].qmax) { want++; }
-						bool have = want == slab_cls;
-						if(!have) { K3_TRY_SLAB(want, have); }
-						if(have) { if(lane == 0) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY ? 100u : 99u; } stt = (uint32_t)rdfirst((int)stt); }
-						else { stt = RJ_EMPTY; }          /* no workspace of that class free: the job stays with its owner unless one comes back before the owner gets there */
-					}
-					if(ji != 0xffffffffu && stt == 100u) {
-						/* (at the top priority: the wave that waits for this result is the critical path of the launch) */
-						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __builtin_amdgcn_s_setprio(3); run_rjob(ji); __builtin_amdgcn_s_setprio(0); mine = 0xffffffffu;
-						/* a workspace of a class above the ordinary one goes back at once: the classes are small, and a helper that sat on one between jobs could be what a read is waiting for */
-						if(slab_cls >= 1) { K3_RING_GIVE(slab_cls, slab_no); slab_cls = -1; }
-						continue;
-					}
-					if(ji != 0xffffffffu && stt != RJ_EMPTY) { mine = 0xffffffffu; continue; }          /* taken by its owner, done or cancelled: the next one */
-					mine = ji;                                                                        /* drawn but not published yet (or nothing drawn) */
-					if(fin) { break; }
-					__builtin_amdgcn_s_sleep(64);
-				}
-			}
+			/* no read left for this wave: it stays for the published jobs of the reads that are still being walked (above), or ends */
+			if(rq_on) { no_reads = true; continue; }
 			break;
 		}
 		const uint32_t r = (uint32_t)rdfirst((int)a.work[wi]);
@@ -2303,6 +2347,38 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			if(first_pos) { apos0 = (_cpa); cond0 = (_cpb) >= qlen; first_pos = false; } \
 			if((_cpa) >= rlen || (_cpb) >= qlen) { (_cpa) -= min((_cpa), ix.k); (_cpb) -= min((_cpb), ix.k); } }
 		bool first_pos = apos0 == gaba::NIL;
+
+		/* The chains of a round that was chained INSIDE the launch (k3_rescue_round above) become jobs here: a read inside a repeat family finds its hundreds of chains only
+		 * when the second or third occurrence threshold admits the family's minimizers, nearly every one of them a full-length alignment that is recorded, and walked them one
+		 * after the other on this one wave -- seconds, while the rest of the launch had long finished (the hard-repeat set: 6 M DP vectors on one wave, 0.05 G bases/s).  The
+		 * first trial of a chain is a pure function of (reference, cp_a, cp_b, strand) -- what mm_search_load_root / load_pos will set up, the carried reference length
+		 * included (the `apos >= rlen` test sees the length of the reference the chain in front loaded, minialign.c:3864) -- so all of them are published at once (the hand-off of
+		 * the retry jobs: slot states, agent-scope release / acquire), any wave takes them, and the walk below, in order and with the real hash and bins, takes the results.
+		 * dyn0_min: the same for the chains of the round the launch starts with, for reads that got no chain jobs before the launch. */
+		uint32_t cj_base = 0, cj_n = 0;
+		if(rq_on && a.round_jobs && (round != a.round || (a.dyn0_min != 0u && spec_n == 0u))) {
+			const uint32_t np = (uint32_t)rdfirst((int)st->n_pass);
+			if(np >= (round != a.round ? 2u : a.dyn0_min) && np <= n_root) {
+				uint32_t base = 0, ok = 0;
+				if(lane == 0) { base = atomicAdd(&a.rq_ctl[0], np); ok = (base + np <= a.rq_cap) ? 1u : 0u; }          /* (a full queue: the slots stay empty, the waves step over them) */
+				base = (uint32_t)rdfirst((int)base); ok = (uint32_t)rdfirst((int)ok);
+				if(ok) {
+					for(uint32_t kj = (uint32_t)lane; kj < np; kj += 64) {
+						const Seed p = s[s[root[kj].lid].upos];
+						const uint32_t rl = kj ? ix.seq_len[s[s[root[kj - 1].lid].upos].rid] : rlen;
+						const int32_t bs = BS(p); const uint32_t jrev = bs < 0;
+						uint32_t cpa = (uint32_t)AS(p), cpb = (uint32_t)(bs + ((bs >> 31) & (int32_t)qlen));
+						if(cpa >= rl || cpb >= qlen) { cpa -= min(cpa, ix.k); cpb -= min(cpb, ix.k); }
+						a.rjobs[base + kj] = SpecJob{ r, p.rid, cpa, cpb, jrev, ix.seq_len[p.rid], ix.seq_circ ? (uint32_t)ix.seq_circ[p.rid] : 0u, JOB_FULL };
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					for(uint32_t kj = (uint32_t)lane; kj < np; kj += 64) { __hip_atomic_store(&a.rstate[base + kj], (uint32_t)RJ_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					if(lane == 0) { atomicAdd(&a.rq_ctl[4], 1u); }
+					cj_base = base; cj_n = np;
+				}
+			}
+		}
 
 		for(uint32_t kq = 0; kq < n_root; kq++) {
 			/* mm_search_load_root (minialign.c:3839-3883) */
@@ -2404,6 +2480,28 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					if(memo0 && lane == 0) { atomicAdd(&a.job_top[4], 1ull); }
 					dg_hits += memo0 ? 1u : 0u;
 				}
+				if(chain_first && kq < cj_n) {
+					/* the first trial of a chain that was published as a job above: taken where it is done, run here where nobody has claimed it, and while another wave is at
+					 * it this one works on a later chain of the read */
+					const uint32_t ji = cj_base + kq;
+					while(true) {
+						uint32_t stt = 0;
+						if(lane == 0) { stt = __hip_atomic_load(&a.rstate[ji], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if(stt == RJ_READY) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CANCELLED) == RJ_READY ? (uint32_t)RJ_CANCELLED : (uint32_t)RJ_CLAIMED; } }
+						stt = (uint32_t)rdfirst((int)stt);
+						if(stt == RJ_CANCELLED) { break; }
+						if(stt == RJ_DONE) {
+							__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+							smp = a.rmemo + ji;
+							const uint32_t bits = (uint32_t)rdfirst((int)smp->state);
+							memo0 = (bits & 1u) != 0 && (uint32_t)rdfirst((int)smp->aid) == sr.aid && (uint32_t)rdfirst((int)smp->cp_a) == sr.cp_a && (uint32_t)rdfirst((int)smp->cp_b) == sr.cp_b
+								&& (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u) && (uint32_t)rdfirst((int)smp->bw) == (uint32_t)bw;
+							memo1 = memo0 && (bits & 2u) != 0;
+							if(memo0) { dg_hits++; if(lane == 0) { atomicAdd(&a.rq_ctl[3], 1u); } }
+							break;
+						}
+						if(!own_job(ji + 1, cj_base + cj_n)) { __builtin_amdgcn_s_sleep(32); }
+					}
+				}
 				if(rq_on && !chain_first) {
 					/* a trial mm_search_load_next set up.  If it was published as a job: taken where it is done, run here where nobody has claimed it, and while another wave is at it this
 					 * one works on a later job of its own */
@@ -2422,15 +2520,12 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 									__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 									smp = a.rmemo + ji; memo1 = false;
 									memo0 = ((uint32_t)rdfirst((int)smp->state) & 1u) != 0 && (uint32_t)rdfirst((int)smp->aid) == sr.aid && (uint32_t)rdfirst((int)smp->cp_a) == sr.cp_a && (uint32_t)rdfirst((int)smp->cp_b) == sr.cp_b
-										&& (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u) && (uint32_t)rdfirst((int)smp->seg_off) == (uint32_t)bw;          /* (computed for exactly this trial: what the job said when it was run) */
+										&& (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u) && (uint32_t)rdfirst((int)smp->bw) == (uint32_t)bw;          /* (computed for exactly this trial: what the job said when it was run) */
 									if(memo0) { dg_hits++; if(lane == 0) { atomicAdd(&a.rq_ctl[3], 1u); } }
 									break;
 								}
 								/* another wave is working on it: one of the later jobs of this read meanwhile */
-								uint32_t take = 0xffffffffu;
-								if(lane == 0) { for(uint32_t q = rj_i; q < rj_n; q++) { if(atomicCAS(&a.rstate[rj_base + q], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY) { take = rj_base + q; break; } } }
-								take = (uint32_t)rdfirst((int)take);
-								if(take != 0xffffffffu) { run_rjob(take); gaba::dp_flush(x); } else { __builtin_amdgcn_s_sleep(32); }
+								if(!own_job(rj_base + rj_i, rj_base + rj_n)) { __builtin_amdgcn_s_sleep(32); }
 							}
 						}
 					}
@@ -2633,6 +2728,11 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			}
 		}
 		#undef LOAD_POS
+		if(cj_n) {
+			/* the walk is over (or gave up): what is left unclaimed of the read's chain jobs is withdrawn, and the waves that stayed for this read may go */
+			for(uint32_t kj = (uint32_t)lane; kj < cj_n; kj += 64) { (void)atomicCAS(&a.rstate[cj_base + kj], (uint32_t)RJ_READY, (uint32_t)RJ_CANCELLED); }
+			if(lane == 0) { atomicSub(&a.rq_ctl[4], 1u); }
+		}
 		if(lane == 0) {
 			st->n_res = n_res; st->rlen = rlen; st->rid_last = rid_last; st->apos0 = apos0; st->cond0 = cond0;
 			st->n_bin = n_bin; st->bin_off = bin_off; st->n_aln = n_aln; st->aln_off = aln_off;

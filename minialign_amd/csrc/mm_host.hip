@@ -18,6 +18,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <deque>
+#include <cerrno>
 #include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
@@ -624,33 +625,69 @@ struct mm_idx_s {
 	double build_ms[8] = { 0 };          /* device build: arena, sketch, partition, sort, thresholds, table */
 	/* copies of a device-built index on the other devices of the node (one per device, made when a context on that device asks: idx_replica; device to device,
 	 * the host never sees the tables) -- "the minimizer index replicated into each GPU's HBM" of north_star */
-	struct Rep { int dev; IdxSlot *d_slot; uint64_t *d_val; gaba_arena_t *ref_ar; };
-	std::vector<Rep> reps; std::mutex rep_mu;
+	/* state: 0 being copied (by the thread that made the entry), 1 ready, -1 failed; serving: copies that read from this holder right now */
+	struct Rep { int key, dev; IdxSlot *d_slot; uint64_t *d_val; gaba_arena_t *ref_ar; int state; int serving; };          /* key: the device, or (test hook) 1000 + the context's number */
+	std::vector<std::unique_ptr<Rep>> reps; std::mutex rep_mu; std::condition_variable rep_cv; int serving0 = 0;          /* serving0: copies reading from the originals */
 	~mm_idx_s()
 	{
 		if(d_slot) (void)hipFree(d_slot); if(d_val) (void)hipFree(d_val); if(ref_ar) gaba_arena_free(ref_ar);
-		for(Rep &r : reps) { if(r.d_slot) (void)hipFree(r.d_slot); if(r.d_val) (void)hipFree(r.d_val); if(r.ref_ar) gaba_arena_free(r.ref_ar); }
+		for(auto &r : reps) { if(r->d_slot) (void)hipFree(r->d_slot); if(r->d_val) (void)hipFree(r->d_val); if(r->ref_ar) gaba_arena_free(r->ref_ar); }
 	}
 };
-/* the tables and the packed reference of a device-built index on device `dev` (the current device of the caller): the originals on the device that built them, a
- * copy anywhere else.  false: out of memory / copy failed */
-static bool idx_replica(const mm_idx_s *cmi, int dev, IdxSlot **slot, uint64_t **val, gaba_arena_t **ar)
+/* the tables and the packed reference of a device-built index on device `dev`: the originals on the device that built them, a copy anywhere else (made once per
+ * device, by the first context that asks; the others of that device wait for it).  The contexts of a node ask side by side (mm_align_init: one thread per device), so
+ * nothing but the bookkeeping is under the index's lock: a copy reads from whichever holder -- the originals or a replica that is complete -- serves the fewest copies
+ * right now, at most MM_REPLICA_FANOUT (default 4) per holder: xGMI is point to point, so copies out of one device to different devices run on different links, and
+ * once the first replicas are complete they serve the rest.  Eight devices, 20 GB (a human-size index + packed reference): four copies out of the builder side by side,
+ * the other three from three of those four -- two link times, 2 x 20 GB / (what one xGMI link sustains) instead of seven in a row behind one lock as in round 4.
+ * forced > 0 (MM_TEST_REPLICA, one-GPU boxes; the number of the context that asks): a context takes the copy path whatever device it is on, and gets a replica
+ * of its own (device-to-device on one device), so that allocation, hipMemcpyPeer, the choice among several holders, adoption and release of replicas run where there
+ * is no second device.  false: out of memory / copy failed */
+static bool idx_replica(const mm_idx_s *cmi, int dev, int forced, IdxSlot **slot, uint64_t **val, gaba_arena_t **ar)
 {
 	mm_idx_s *mi = const_cast<mm_idx_s *>(cmi);
-	if(dev == mi->dev) { *slot = mi->d_slot; *val = mi->d_val; *ar = mi->ref_ar; return true; }
-	std::lock_guard<std::mutex> lk(mi->rep_mu);
-	for(const mm_idx_s::Rep &r : mi->reps) if(r.dev == dev) { *slot = r.d_slot; *val = r.d_val; *ar = r.ref_ar; return true; }
-	mm_idx_s::Rep r{ dev, nullptr, nullptr, nullptr };
+	if(dev == mi->dev && forced <= 0) { *slot = mi->d_slot; *val = mi->d_val; *ar = mi->ref_ar; return true; }
+	const int key = forced > 0 ? 1000 + forced : dev;
+	const int fanout = getenv("MM_REPLICA_FANOUT") ? std::max(1, atoi(getenv("MM_REPLICA_FANOUT"))) : 4;
+	std::unique_lock<std::mutex> lk(mi->rep_mu);
+	for(;;) {
+		mm_idx_s::Rep *have = nullptr;
+		for(auto &r : mi->reps) if(r->key == key) { have = r.get(); break; }
+		if(!have) break;
+		if(have->state == 0) { mi->rep_cv.wait(lk); continue; }          /* another context of this device is making it */
+		if(have->state < 0) return false;
+		*slot = have->d_slot; *val = have->d_val; *ar = have->ref_ar; return true;
+	}
+	mi->reps.emplace_back(new mm_idx_s::Rep{ key, dev, nullptr, nullptr, nullptr, 0, 0 });
+	mm_idx_s::Rep *r = mi->reps.back().get();
+	/* the source: the holder that serves the fewest copies, once one is below the fan-out */
+	mm_idx_s::Rep *src = nullptr; bool from_orig = false;
+	for(;;) {
+		int best = mi->serving0; from_orig = true; src = nullptr;
+		for(auto &q : mi->reps) if(q->state == 1 && q->serving <= best) { best = q->serving; src = q.get(); from_orig = false; }          /* (a tie goes to a replica: the builder's device has the first contexts' work already) */
+		if(best < fanout) break;
+		mi->rep_cv.wait(lk);
+	}
+	if(from_orig) mi->serving0++; else src->serving++;
+	const int sdev = from_orig ? mi->dev : src->dev;
+	const IdxSlot *s_slot = from_orig ? mi->d_slot : src->d_slot; const uint64_t *s_val = from_orig ? mi->d_val : src->d_val; const gaba_arena_t *s_ar = from_orig ? mi->ref_ar : src->ref_ar;
+	lk.unlock();
+	const double t0 = now_ms();
 	const uint64_t n = mi->ref_ar->n, nw = (n + 15) / 16 + 4, nn = (n + 31) / 32 + 4;
 	gaba_arena_t *q = (gaba_arena_t *)calloc(1, sizeof(gaba_arena_t));
-	bool ok = q != nullptr && hipMalloc(&r.d_slot, mi->n_slot * sizeof(IdxSlot)) == hipSuccess && hipMalloc(&r.d_val, (mi->n_val + 64) * 8) == hipSuccess
+	bool ok = q != nullptr && hipSetDevice(dev) == hipSuccess && hipMalloc(&r->d_slot, mi->n_slot * sizeof(IdxSlot)) == hipSuccess && hipMalloc(&r->d_val, (mi->n_val + 64) * 8) == hipSuccess
 		&& hipMalloc(&q->pk, nw * 4) == hipSuccess && hipMalloc(&q->nm, nn * 4) == hipSuccess;
-	ok = ok && hipMemcpyPeer(r.d_slot, dev, mi->d_slot, mi->dev, mi->n_slot * sizeof(IdxSlot)) == hipSuccess && hipMemcpyPeer(r.d_val, dev, mi->d_val, mi->dev, (mi->n_val + 64) * 8) == hipSuccess
-		&& hipMemcpyPeer(q->pk, dev, mi->ref_ar->pk, mi->dev, nw * 4) == hipSuccess && hipMemcpyPeer(q->nm, dev, mi->ref_ar->nm, mi->dev, nn * 4) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-	if(!ok) { if(r.d_slot) (void)hipFree(r.d_slot); if(r.d_val) (void)hipFree(r.d_val); if(q) { if(q->pk) (void)hipFree(q->pk); if(q->nm) (void)hipFree(q->nm); free(q); } return false; }
-	q->n = n; q->host = NULL; r.ref_ar = q;
-	mi->reps.push_back(r);
-	*slot = r.d_slot; *val = r.d_val; *ar = r.ref_ar;
+	ok = ok && hipMemcpyPeer(r->d_slot, dev, s_slot, sdev, mi->n_slot * sizeof(IdxSlot)) == hipSuccess && hipMemcpyPeer(r->d_val, dev, s_val, sdev, (mi->n_val + 64) * 8) == hipSuccess
+		&& hipMemcpyPeer(q->pk, dev, s_ar->pk, sdev, nw * 4) == hipSuccess && hipMemcpyPeer(q->nm, dev, s_ar->nm, sdev, nn * 4) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+	if(!ok) { if(r->d_slot) (void)hipFree(r->d_slot); if(r->d_val) (void)hipFree(r->d_val); if(q) { if(q->pk) (void)hipFree(q->pk); if(q->nm) (void)hipFree(q->nm); free(q); } r->d_slot = nullptr; r->d_val = nullptr; q = nullptr; }
+	if(ok) { q->n = n; q->host = NULL; r->ref_ar = q; }
+	if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd] index replica on device %d from device %d (%s): %.1f MB in %.1f ms%s\n", dev, sdev, from_orig ? "the originals" : "a replica", (mi->n_slot * sizeof(IdxSlot) + (mi->n_val + 64) * 8 + nw * 4 + nn * 4) * 1e-6, now_ms() - t0, ok ? "" : " -- FAILED");
+	lk.lock();
+	if(from_orig) mi->serving0--; else src->serving--;
+	r->state = ok ? 1 : -1;
+	mi->rep_cv.notify_all();
+	if(!ok) return false;
+	*slot = r->d_slot; *val = r->d_val; *ar = r->ref_ar;
 	return true;
 }
 /* host copy of a device-built index (for mm_idx_dump / mm_idx_get) */
@@ -1167,6 +1204,7 @@ struct mm_align_s {
 	/* pools */
 	DBuf<uint32_t> q_pk, q_nm; DBuf<ReadIn> d_in; DBuf<ReadState> d_st; DBuf<uint32_t> d_work;
 	DBuf<MinRec> min_pool; DBuf<Seed> seed_pool; DBuf<Resc> resc_pool; DBuf<Root> root_pool;
+	uint64_t min_over_base = 0, min_over_n = 0;          /* the overflow region of the sketch kernel inside min_pool (ensure_pools) */
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
 	DBuf<uint32_t> d_k2cnt;                /* work-list cursors of the sort + chain launches */
@@ -1185,7 +1223,7 @@ struct mm_align_s {
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
 	/* reusable host buffers of the streaming engine (primary context only): pinned result buffers for the D2H of a batch, text pieces with their capacity */
 	struct PinSet { void *p[5] = { nullptr, nullptr, nullptr, nullptr, nullptr }; size_t cap[5] = { 0, 0, 0, 0, 0 };
-		void *get(int i, size_t bytes) { if(bytes > cap[i]) { if(p[i]) (void)hipHostFree(p[i]); p[i] = nullptr; cap[i] = 0; size_t want = bytes + bytes / 4 + (1u << 20); if(hipHostMalloc(&p[i], want, hipHostMallocDefault) != hipSuccess) return nullptr; cap[i] = want; } return p[i]; }
+		void *get(int i, size_t bytes) { if(bytes > cap[i]) { if(p[i]) (void)hipHostFree(p[i]); p[i] = nullptr; cap[i] = 0; size_t want = bytes + bytes / 4 + (1u << 20); if(hipHostMalloc(&p[i], want, hipHostMallocPortable) != hipSuccess) return nullptr; cap[i] = want; } return p[i]; }          /* (portable: a set is pooled on the first context and handed to lanes of any device) */
 		~PinSet() { for(int i = 0; i < 5; i++) if(p[i]) (void)hipHostFree(p[i]); } };
 	std::vector<PinSet *> pin_free; std::vector<std::vector<std::string>> piece_free; std::mutex pool_mu;
 	/* the head of the last stream mapped through this context (mm_map_*): what decides whether another carried value at its start changes anything */
@@ -1200,6 +1238,7 @@ struct mm_align_s {
 	/* the other devices of the node: one primary context each (own streams, lanes, pools, DP workspaces, a replica of the index), owned by the first context.  The
 	 * streaming engine deals its batches over all of them; the per-batch entries stay on the first */
 	std::vector<mm_align_s *> peers;
+	std::vector<int> span; std::mutex span_mu; bool span_failed = false;          /* the devices this context was made to span (mm_align_init); the peers are made when first needed (ensure_peers) */
 	/* what the batches of this device have asked of the seed / rescue / chain-root pools so far, in entries per base of batch (primary context; the lanes note it after
 	 * every sketch launch, note_demand): K1 counts a read's hits before it claims room for them (minialign.c:3454-3540 is what a read can emit), so the launch leaves the exact
 	 * demand in the pool cursors -- the pools are sized for what the run has seen (+ a quarter), not for the caps a read could reach, and a batch that asks for more
@@ -1240,7 +1279,7 @@ struct BatchOut {                       /* host copies of what post-map / SAM ne
 
 inline void *lane_stage(mm_align_t *a, size_t bytes)
 {
-	if(bytes > a->pin_stage_cap) { if(a->pin_stage) (void)hipHostFree(a->pin_stage); a->pin_stage = nullptr; a->pin_stage_cap = 0; size_t want = bytes + bytes / 4 + (1u << 20); if(hipHostMalloc(&a->pin_stage, want, hipHostMallocDefault) != hipSuccess) return nullptr; a->pin_stage_cap = want; }
+	if(bytes > a->pin_stage_cap) { if(a->pin_stage) (void)hipHostFree(a->pin_stage); a->pin_stage = nullptr; a->pin_stage_cap = 0; size_t want = bytes + bytes / 4 + (1u << 20); if(hipHostMalloc(&a->pin_stage, want, hipHostMallocPortable) != hipSuccess) return nullptr; a->pin_stage_cap = want; }
 	return a->pin_stage;
 }
 /* host <-> device copies of a lane through its pinned staging buffer (falls back to the plain copy when pinning fails) */
@@ -1272,6 +1311,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k1.resc_pool = a->resc_pool.p; k1.resc_pool_cap = a->resc_pool.n; k1.resc_top = tops + 1;
 		k1.root_pool = a->root_pool.p; k1.root_pool_cap = a->root_pool.n; k1.root_top = tops + 2;
 		k1.counter = (uint32_t *)(tops + 16); k1.stats = tops + 8; k1.work = a->d_work.p; k1.tap = nullptr; k1.note = a->pin_note;
+		/* the overflow region for the minimizer records of low-complexity reads: behind the reads' own shares (ensure_pools), its cursor reset with every sketch launch */
+		k1.min_over_top = nullptr; k1.min_over_base = 0; k1.min_over_cap = 0;
+		if(a->min_over_n && a->min_over_base + a->min_over_n <= a->min_pool.n && !getenv("MM_NO_MIN_OVERFLOW")) { k1.min_over_top = tops + 32; k1.min_over_base = a->min_over_base; k1.min_over_cap = a->min_over_n; CK(hipMemsetAsync(tops + 32, 0, 8, a->stream)); }
 		if(a->pin_note) { a->pin_note[0] = a->pin_note[1] = a->pin_note[2] = ~0ull; }
 		if(a->tap_stop) { if(!a->tap_words.ensure(a->min_pool.n)) return false; k1.tap = a->tap_words.p; }
 		uint32_t waves = std::min<uint32_t>(a->n_waves, (uint32_t)((work.size() + 3) & ~3ull));
@@ -1297,6 +1339,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				CK(hipMemsetAsync(tops, 0, 3 * 8, a->stream)); CK(hipMemsetAsync(tops + 8, 0, 2 * 8, a->stream)); CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
 				k1.seed_pool = a->seed_pool.p; k1.seed_pool_cap = a->seed_pool.n; k1.resc_pool = a->resc_pool.p; k1.resc_pool_cap = a->resc_pool.n; k1.root_pool = a->root_pool.p; k1.root_pool_cap = a->root_pool.n;
 				k1.note = nullptr;
+				if(k1.min_over_top) { CK(hipMemsetAsync(tops + 32, 0, 8, a->stream)); }
 				CK(hipEventRecord(a->ev0, a->stream));
 				hipLaunchKernelGGL(mm_sketch_seed_kernel, dim3(waves / 4), dim3(256), 0, a->stream, k1);
 				CK(hipGetLastError()); CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
@@ -1543,19 +1586,30 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				k3.rjobs = a->rq_jobs.p; k3.rmemo = a->rq_memo.p; k3.rstate = a->rq_state.p; k3.rq_cap = rq_cap; k3.rq_ctl = (unsigned int *)(a->rq_state.p + rq_cap);
 			}
 		}
-		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0;
+		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0; k3.stage_top = nullptr; k3.round_jobs = 0;
+		k3.dyn0_min = getenv("MM_K3_DYN_ROUND0") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_DYN_ROUND0"))) : 0u;
+		/* the staging area of the traced jobs (path words, segments) and its cursors: for the chain jobs enumerated before the launch and for the chains a read publishes from
+		 * inside it (K3Args.rjobs, JOB_FULL) alike */
+		const uint64_t stage_job_cap = getenv("MM_K3_JOB_CAP") ? (uint64_t)std::max(1, atoi(getenv("MM_K3_JOB_CAP"))) : (1u << 16), stage_path_cap = 48ull << 20, stage_seg_cap = (stage_job_cap + k3.rq_cap) * 8;          /* (MM_K3_JOB_CAP: test hook, a launch with more chain jobs than slots) */
+		const bool staged = k3.ring && k3.cls && (k3.rjobs || (((round == 0 && inkernel) || deferred) && n_heavy > 0 && !getenv("MM_K3_NO_JOBS")))
+			&& a->spec_path.ensure(stage_path_cap) && a->spec_seg.ensure(stage_seg_cap) && a->spec_top.ensure(8);
+		if(staged) {
+			CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
+			k3.spath = a->spec_path.p; k3.spath_cap = stage_path_cap; k3.sseg = a->spec_seg.p; k3.sseg_cap = stage_seg_cap; k3.job_top = a->spec_top.p;
+			k3.stage_top = a->spec_top.p + 2;
+			k3.round_jobs = (k3.rjobs && !getenv("MM_K3_NO_ROUND_JOBS")) ? 1u : 0u;          /* (MM_K3_NO_ROUND_JOBS: the chains of the later rounds walked by the read's own wave, as before round 5) */
+		}
 		/* chain jobs: the first trials of the chains of the heaviest reads (the front of the work list), taken by all waves of the launch before the reads (K3Args.jobs) */
 		/* (a wave that has claimed a job takes the workspace for it without waiting, K3_TRY_SLAB, and hands the job back undone when none of its class is free: with fewer
 		 * workspaces than waves, or on the class ladder of a long-tailed set, the waves that hold the workspaces may be the ones that wait for the job) */
-		if(((round == 0 && inkernel) || deferred) && n_heavy > 0 && k3.ring && k3.cls && !getenv("MM_K3_NO_JOBS")) {
-			const uint64_t job_cap = getenv("MM_K3_JOB_CAP") ? (uint64_t)std::max(1, atoi(getenv("MM_K3_JOB_CAP"))) : (1u << 16), path_cap = 48ull << 20;          /* (MM_K3_JOB_CAP: test hook, a launch with more chain jobs than slots) */
-			if(a->spec_jobs.ensure(job_cap) && a->spec_memo.ensure(job_cap) && a->spec_path.ensure(path_cap) && a->spec_seg.ensure(job_cap * 8) && a->spec_top.ensure(8)) {
-				CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
+		if(staged && ((round == 0 && inkernel) || deferred) && n_heavy > 0 && !getenv("MM_K3_NO_JOBS")) {
+			const uint64_t job_cap = stage_job_cap;
+			if(a->spec_jobs.ensure(job_cap) && a->spec_memo.ensure(job_cap)) {
 				SpecJobsArgs sj; sj.idx = a->dix; sj.in = a->d_in.p; sj.st = a->d_st.p; sj.work = a->d_work.p; sj.n_heavy = n_heavy; sj.seed_pool = a->seed_pool.p; sj.root_pool = a->root_pool.p;
 				sj.mcoef = a->mcoef; sj.min_score = a->o.min_score; sj.min_roots = 2; sj.jobs = a->spec_jobs.p; sj.memo = a->spec_memo.p; sj.job_cap = job_cap; sj.job_top = a->spec_top.p;
 				hipLaunchKernelGGL(mm_spec_jobs_kernel, dim3((n_heavy + 63) / 64), dim3(64), 0, a->stream, sj);
 				CK(hipGetLastError());
-				k3.jobs = a->spec_jobs.p; k3.memo = a->spec_memo.p; k3.job_top = a->spec_top.p; k3.job_cap = job_cap; k3.spath = a->spec_path.p; k3.spath_cap = path_cap; k3.sseg = a->spec_seg.p; k3.sseg_cap = job_cap * 8;
+				k3.jobs = a->spec_jobs.p; k3.memo = a->spec_memo.p; k3.job_cap = job_cap;
 			}
 		}
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
@@ -1916,7 +1970,12 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	ok &= a->d_in.ensure(n_reads); ok &= a->d_st.ensure(n_reads); ok &= a->d_work.ensure(n_reads);
 	ok &= a->q_pk.ensure(bases / 16 + 8); ok &= a->q_nm.ensure(bases / 32 + 8);
 	const uint64_t min_total = (uint64_t)((double)bases * min_cap_frac(a->mi->w, scale)) + 64ull * n_reads + 1024;        /* as the per-read caps of batch_upload */
-	ok &= a->min_pool.ensure(min_total);
+	/* ... and behind the reads' shares the overflow region of the sketch kernel (K1Args.min_over_*): a read inside low-complexity sequence emits a minimizer per position;
+	 * such reads take room for that there instead of making the whole batch run again with larger pools (the hard-repeat human-size set: 35 - 45 of the 7 500 reads of every
+	 * batch, every batch twice and the extension-side caps of the lane multiplied each time -- round 5) */
+	const uint64_t min_over = bases / 32 + 2ull * max_qlen + 4096;
+	ok &= a->min_pool.ensure(min_total + min_over);
+	a->min_over_base = min_total; a->min_over_n = min_over;
 	if(getenv("MM_POOLS_BY_CAP")) {          /* rounds 1-3: room for what the reads of the batch could emit at most */
 		ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
 		ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
@@ -1958,7 +2017,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	}
 	else if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
 	else { ok &= a->slabs.ensure(slab * kw); if(ok) { a->slab_stride = a->slabs.n / kw; a->k3_waves = kw; } }
-	ok &= a->d_tops.ensure(32); ok &= a->d_k2cnt.ensure(48);
+	ok &= a->d_tops.ensure(40); ok &= a->d_k2cnt.ensure(48);
 	return ok;
 }
 /* one set of DP workspaces for all lanes of a context (the streaming engine calls this before its lane threads start, with the longest read of the input):
@@ -2042,7 +2101,7 @@ static bool make_streams(mm_align_s *a)
 	return true;
 }
 /* a primary context on the current device */
-static mm_align_t *align_init_here(mm_opt_t const *o, mm_idx_t const *mi)
+static mm_align_t *align_init_here(mm_opt_t const *o, mm_idx_t const *mi, int force_replica = 0)
 {
 	mm_align_t *a = new mm_align_s();
 	a->o = *o; a->mi = mi;
@@ -2062,7 +2121,7 @@ static mm_align_t *align_init_here(mm_opt_t const *o, mm_idx_t const *mi)
 	if(mi->on_device) {
 		/* an index built on a device: the packed reference, the table and the value array are there already -- on the device that built them; any other gets a copy, once */
 		int cur = 0; (void)hipGetDevice(&cur);
-		if(!idx_replica(mi, cur, &a->d_slot, &a->d_val, &a->ref_ar)) { fprintf(stderr, "[minialign_amd] mm_align_init: the index was built on device %d and could not be copied to device %d\n", mi->dev, cur); a->d_slot = nullptr; a->d_val = nullptr; a->ref_ar = nullptr; a->own_index = false; delete a; return NULL; }
+		if(!idx_replica(mi, cur, force_replica, &a->d_slot, &a->d_val, &a->ref_ar)) { fprintf(stderr, "[minialign_amd] mm_align_init: the index was built on device %d and could not be copied to device %d\n", mi->dev, cur); a->d_slot = nullptr; a->d_val = nullptr; a->ref_ar = nullptr; a->own_index = false; delete a; return NULL; }
 		uint64_t total = 0; for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back(s.blen()); total += ((uint64_t)s.blen() + 63) & ~63ull; }
 		a->own_index = false;
 	} else {
@@ -2115,18 +2174,36 @@ extern "C" mm_align_t *mm_align_init(mm_opt_t const *o, mm_idx_t const *mi)
 	const std::vector<int> devs = context_devices();
 	if(devs.empty()) { fprintf(stderr, "[minialign_amd] mm_align_init: no HIP device available (the device stages have no CPU path)\n"); return NULL; }
 	mm_align_t *a = align_init_here(o, mi);
-	if(!a || devs.size() == 1) return a;
-	/* the other devices side by side (a replica of a human-size index is 20 GB over xGMI) */
-	std::vector<mm_align_t *> pe(devs.size(), nullptr); std::vector<std::thread> th;
-	for(size_t i = 1; i < devs.size(); i++) th.emplace_back([&, i]() { if(hipSetDevice(devs[i]) == hipSuccess) pe[i] = align_init_here(o, mi); });
-	for(auto &t : th) t.join();
-	bool ok = true; for(size_t i = 1; i < devs.size(); i++) ok &= pe[i] != nullptr;
-	if(!ok) { fprintf(stderr, "[minialign_amd] mm_align_init: a context on one of %d devices could not be made\n", (int)devs.size()); for(size_t i = 1; i < devs.size(); i++) if(pe[i]) mm_align_destroy(pe[i]); mm_align_destroy(a); (void)hipSetDevice(devs[0]); return NULL; }
-	for(size_t i = 1; i < devs.size(); i++) a->peers.push_back(pe[i]);
-	(void)hipSetDevice(devs[0]);
+	if(a) { a->span = devs; }
 	return a;
 }
-extern "C" int mm_align_devices(mm_align_t const *a) { return 1 + (int)a->peers.size(); }
+/* The contexts on the other devices of the span are made when a streaming entry first runs (stream_map) or when somebody asks how many devices there are
+ * (mm_align_devices) -- not by mm_align_init: the per-batch entries (mm_align_seq, mm_align_batch, mm_batch_*) only ever use the first device and should not pay for
+ * streams, DP constants and a 20 GB index replica on seven others.  All of them side by side, one thread per device (idx_replica: what serves which copy).
+ * false: one of them could not be made (the context is then left with its first device only, and says so). */
+static bool ensure_peers(mm_align_t *a)
+{
+	std::lock_guard<std::mutex> lk(a->span_mu);
+	if(a->span.size() <= 1 || !a->peers.empty() || a->span_failed) return !a->span_failed;
+	const std::vector<int> &devs = a->span;
+	int cur = 0; (void)hipGetDevice(&cur);
+	const bool force = getenv("MM_TEST_REPLICA") != NULL;
+	const double t0 = now_ms();
+	std::vector<mm_align_t *> pe(devs.size(), nullptr); std::vector<std::thread> th;
+	for(size_t i = 1; i < devs.size(); i++) th.emplace_back([&, i]() { if(hipSetDevice(devs[i]) == hipSuccess) pe[i] = align_init_here(&a->o, a->mi, force ? (int)i : 0); });
+	for(auto &t : th) t.join();
+	bool ok = true; for(size_t i = 1; i < devs.size(); i++) ok &= pe[i] != nullptr;
+	if(!ok) {
+		fprintf(stderr, "[minialign_amd] a context on one of %d devices could not be made: mapping on the first device only\n", (int)devs.size());
+		for(size_t i = 1; i < devs.size(); i++) if(pe[i]) { (void)hipSetDevice(pe[i]->dev); mm_align_destroy(pe[i]); }
+		a->span_failed = true; (void)hipSetDevice(cur); return false;
+	}
+	for(size_t i = 1; i < devs.size(); i++) a->peers.push_back(pe[i]);
+	(void)hipSetDevice(cur);
+	if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd] %d device contexts (index replicas included) in %.1f ms\n", (int)devs.size(), now_ms() - t0);
+	return true;
+}
+extern "C" int mm_align_devices(mm_align_t const *a) { (void)ensure_peers(const_cast<mm_align_t *>(a)); return 1 + (int)a->peers.size(); }
 static void free_chunk_pool(struct ChunkPool *p);
 extern "C" void mm_align_destroy(mm_align_t *a)
 {
@@ -2769,7 +2846,7 @@ extern "C" int64_t mm_batch_tap_sketch(mm_align_t *a, mm_batch_t *h, uint32_t re
 extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
 
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = false);
-static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const std::function<bool(uint32_t, std::vector<std::string> &)> &sink, int lanes);
+static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const std::function<bool(uint32_t, std::vector<std::string> &)> &sink, int lanes, int pos_fd = -1, uint64_t *pos_at = nullptr);
 static std::shared_ptr<TextSrc> open_text_once(const char *fn);
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
@@ -2778,7 +2855,16 @@ extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 		/* the text of the file goes to the device as it is; records are found there (K0r), bases packed there (K0) */
 		std::shared_ptr<TextSrc> src = open_text_once(reads_fn);
 		if(!src) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
-		return align_text(a, src, [&](uint32_t, std::vector<std::string> &piece) { for(auto &x : piece) { if(fwrite(x.data(), 1, x.size(), out) != x.size()) return false; } return true; }, 0);
+		/* where the output is a regular file (`minialign ... > out.sam`): the batches' text goes to its place in the file from several threads (stream_map, drain workers);
+		 * a pipe, a terminal or a file opened for appending is written in order by the one writer */
+		int pos_fd = -1; uint64_t pos_at = 0;
+		if(!getenv("MM_ONE_WRITER") && fflush(out) == 0) {
+			const int fd = fileno(out); struct stat sb;
+			if(fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) { const int fl = fcntl(fd, F_GETFL); const off_t at = lseek(fd, 0, SEEK_CUR); if(fl >= 0 && !(fl & O_APPEND) && at >= 0) { pos_fd = fd; pos_at = (uint64_t)at; } }
+		}
+		const int rc = align_text(a, src, [&](uint32_t, std::vector<std::string> &piece) { for(auto &x : piece) { if(fwrite(x.data(), 1, x.size(), out) != x.size()) return false; } return true; }, 0, pos_fd, &pos_at);
+		if(pos_fd >= 0 && lseek(pos_fd, (off_t)pos_at, SEEK_SET) < 0) return 1;          /* (the stream goes on behind what was written) */
+		return rc;
 	}
 	mm_reads_t *reads = reads_load(reads_fn, a->o.min_len, a->o.keep_qual, (a->o.ptags() >> 1) & 1, getenv("MM_HOST_PACK") == NULL);
 	if(!reads) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
@@ -3314,11 +3400,11 @@ static BatchSource counted_source(uint32_t n_batches, const std::function<mm_bat
 	};
 }
 /* the primary contexts of the devices `a` spans, in slot order */
-static std::vector<mm_align_t *> device_slots(mm_align_t *a) { std::vector<mm_align_t *> v; v.push_back(a); for(mm_align_t *p : a->peers) v.push_back(p); return v; }
+static std::vector<mm_align_t *> device_slots(mm_align_t *a) { (void)ensure_peers(a); std::vector<mm_align_t *> v; v.push_back(a); for(mm_align_t *p : a->peers) v.push_back(p); return v; }
 /* n_batches: how many the source holds when that is known (the lanes made are no more than that), 0xffffffff otherwise */
 #define MM_OPEN_ENDED 0xffffffffu
 static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &source, const std::function<void(mm_batch_t *)> &release,
-	const PieceSink &sink, int lanes_want)
+	const PieceSink &sink, int lanes_want, int pos_fd = -1, uint64_t *pos_at = nullptr)
 {
 	if(n_batches == 0) { a->head.clear(); a->head_off.assign(1, 0); a->head_off_closed = false; a->head_carry_in = a->rlen_carry; return 0; }
 	const bool verbose = getenv("MM_VERBOSE") != NULL;
@@ -3354,6 +3440,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 	std::vector<Item *> fetched;                       /* waiting for a finisher */
 	std::map<uint32_t, Item *> formatted;              /* waiting for the writer */
 	uint32_t lanes_done = 0, fin_done = 0; bool head_open = true;
+	std::deque<std::pair<Item *, uint64_t>> drain_q; bool writer_done = false;          /* a drain with positions: (batch, where its text goes) waiting for a drain worker */
 	const uint32_t lanes_total = (uint32_t)(lanes * n_dev);
 	a->head.clear(); a->head_txt.clear(); a->head_txt_end = 0; a->head_off.clear(); a->head_off_closed = false; a->head_carry_in = a->rlen_carry;
 	for(auto &D : dv) D->P->streaming = true;
@@ -3506,23 +3593,56 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 				if(it->split || it->roff.size() != it->piece.size()) { a->head_off_closed = true; }
 				else { uint64_t at = written; for(size_t t = 0; t < it->piece.size() && a->head_off.size() <= 4096; t++) { for(uint32_t o : it->roff[t]) { if(a->head_off.size() > 4096) break; a->head_off.push_back(at + o); } at += it->piece[t].size(); } }
 			}
+			const uint64_t at0 = written;
 			written += nb;
 			bool failed; { std::lock_guard<std::mutex> lk(mu); failed = rc != 0; }
+			if(pos_fd >= 0 && !failed) {
+				/* a drain with positions (a regular file): this thread only says where the batch goes -- the sizes of everything in front of it are known -- and the bytes are
+				 * written by the drain workers side by side, so no one thread touches every byte of the output (the reference's drain is one thread: minialign.c:4633-4645; at eight
+				 * devices that thread would have 50 GB/s of text to move) */
+				{ std::lock_guard<std::mutex> lk(mu); next_write++; drain_q.emplace_back(it, *pos_at + at0); }
+				cv.notify_all();
+				continue;
+			}
 			const bool ok = !failed ? sink(it->k, it->piece) : true;
 			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: written %.1f MB in %.1f ms\n", it->k, nb * 1e-6, now_ms() - tv); }
 			release(it->h); drop_item(it);
 			{ std::lock_guard<std::mutex> lk(mu); next_write++; pending--; if(!ok) rc = 1; }
 			cv.notify_all();
 		}
+		{ std::lock_guard<std::mutex> lk(mu); writer_done = true; }
+		cv.notify_all();
 		/* whatever is left after an error */
 		std::lock_guard<std::mutex> lk(mu);
 		for(auto &kv : formatted) { release(kv.second->h); drop_item(kv.second); } formatted.clear();
+	};
+	auto drain_main = [&]() {
+		while(true) {
+			Item *it = nullptr; uint64_t at = 0;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&]() { return !drain_q.empty() || writer_done; });
+				if(drain_q.empty()) break;
+				it = drain_q.front().first; at = drain_q.front().second; drain_q.pop_front();
+			}
+			double tv = now_ms(); size_t nb = 0; bool ok = true;
+			for(auto &x : it->piece) {
+				const char *q = x.data(); size_t left = x.size();
+				while(left && ok) { const ssize_t w = pwrite(pos_fd, q, left, (off_t)at); if(w <= 0) { if(w < 0 && errno == EINTR) continue; ok = false; break; } q += w; left -= (size_t)w; at += (uint64_t)w; nb += (size_t)w; }
+			}
+			if(verbose) { fprintf(stderr, "[minialign_amd] batch %u: written %.1f MB in %.1f ms (at its place in the file)\n", it->k, nb * 1e-6, now_ms() - tv); }
+			release(it->h); drop_item(it);
+			{ std::lock_guard<std::mutex> lk(mu); pending--; if(!ok) rc = 1; }
+			cv.notify_all();
+		}
 	};
 	std::vector<std::thread> th;
 	for(int d = 0; d < n_dev; d++) for(int i = 0; i < lanes; i++) th.emplace_back(lane_main, d, i);
 	for(int i = 0; i < n_fin; i++) th.emplace_back(fin_main);
 	th.emplace_back(writer_main);
+	if(pos_fd >= 0) { for(int i = 0; i < std::min(8, 2 * n_dev); i++) th.emplace_back(drain_main); }
 	for(auto &t : th) t.join();
+	if(pos_fd >= 0 && pos_at) { *pos_at += written; }
 	for(Item *it : fetched) { release(it->h); drop_item(it); }
 	if(rc == 0) { each_context(a, [carry](mm_align_t *q) { q->rlen_carry = carry; }); }
 	if(!a->head_off_closed && a->head_off.size() <= 4096) { a->head_off.push_back(written); }          /* a stream shorter than the head: its end */
@@ -3595,7 +3715,7 @@ static uint64_t batch_cap_bases(mm_align_t *a, int lanes)  /* (bytes per base: 5
 	}
 	return std::max<uint64_t>(128ull << 20, P->mem_for_batches / (uint64_t)std::max(1, lanes) / (getenv("MM_POOLS_BY_CAP") ? 52 : 28));
 }
-static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const PieceSink &sink, int lanes)
+static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const PieceSink &sink, int lanes, int pos_fd, uint64_t *pos_at)
 {
 	if(lanes <= 0) lanes = default_lanes();
 	if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
@@ -3603,7 +3723,7 @@ static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const 
 	rd.cap_bases = std::min<uint64_t>(1000000000ull, batch_cap_bases(a, lanes));
 	if(!rd.start()) { fprintf(stderr, "[minialign_amd] reader: no stream / staging memory\n"); return 1; }
 	bool err = false;
-	int rc = stream_map(a, MM_OPEN_ENDED, [&](int di) { return rd.take(di, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes);
+	int rc = stream_map(a, MM_OPEN_ENDED, [&](int di) { return rd.take(di, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes, pos_fd, pos_at);
 	{ std::lock_guard<std::mutex> lk(rd.mu); if(err || rd.failed) rc = 1; }
 	for(ReaderDev *R : rd.rdev) { a->st.text_bytes += R->bytes_up; a->st.reader_ms += R->t_io; }
 	return rc;

@@ -122,9 +122,13 @@ def test_bench_line_with_two_ranks_on_one_gpu():
     assert d['roofline']['achieved'] > 0 and 'cpu_baseline' not in d
 
 @pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1'),
-                                 dict(MM_K2_LDS_CHAIN='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_HOST_READER='1'), dict(MM_HOST_INDEX='1'), dict(MM_K3_JOB_CAP='7'), dict(MM_DEVICE_CONTEXTS='2', MM_SLAB_GB='14')],
+                                 dict(MM_K2_LDS_CHAIN='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_HOST_READER='1'), dict(MM_HOST_INDEX='1'), dict(MM_K3_JOB_CAP='7'), dict(MM_DEVICE_CONTEXTS='2', MM_SLAB_GB='14'),
+                                 dict(MM_K3_NO_ROUND_JOBS='1'), dict(MM_K3_DYN_ROUND0='2'), dict(MM_K3_DYN_ROUND0='2', MM_K3_NO_JOBS='1'), dict(MM_K3_HELPERS='4'),
+                                 dict(MM_K3_RESCUE_FIRST='1'), dict(MM_K3_DEFER_RESCUE='1'), dict(MM_K3_CU_RESERVE='16'), dict(MM_UPLOAD_ONE_SYNC='1')],
                          ids=['rounds-through-the-host', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain', 'batch-split-on-pool-exhaustion',
-                              'chain-sweep-in-lds', 'no-chain-jobs', 'host-reader', 'host-index', 'more-chain-jobs-than-slots', 'two-device-contexts'])
+                              'chain-sweep-in-lds', 'no-chain-jobs', 'host-reader', 'host-index', 'more-chain-jobs-than-slots', 'two-device-contexts',
+                              'later-round-chains-on-the-own-wave', 'first-round-chains-published-by-the-read', 'first-round-chains-published-only-by-the-read', 'one-wave-in-four-helps',
+                              'rescue-bound-reads-first', 'rescue-rounds-deferred-to-launches-of-their-own', 'cu-reserve', 'upload-behind-one-wait'])
 def test_alternative_schedules_give_the_same_bytes(env):
     """the forms kept behind environment switches -- the occurrence-threshold rounds as separate launches through the host (the default runs them inside the
     extension kernel, k3_rescue_round), one read per wave, per-lane DP
@@ -138,6 +142,24 @@ def test_alternative_schedules_give_the_same_bytes(env):
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert _strip_pg(r.stdout) == want
         assert b're-run' in r.stderr
+
+@pytest.mark.parametrize('fanout', ['1', '4'])
+def test_index_replicas_are_copied_device_to_device(fanout):
+    """the replica path of the N-device engine on a one-GPU box (MM_TEST_REPLICA): the contexts behind the first take their index and packed reference through
+    idx_replica's copy path -- hipMalloc, hipMemcpyPeer from a holder (fan-out 1: a chain, each replica made from the one before; 4: side by side from the originals),
+    adoption by the context, release with the index -- and map through the copies: the records are those of the single stream"""
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
+        M.gensim('genome', 7411, 4000000, 25, 0.3, out=ref); M.gensim('reads', 7412, ref, 2.0, 'pacbio', 'fa', 5000, 2000, out=rd)
+        opts = ['-xpacbio']
+        want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+        r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                           env=dict(os.environ, MM_DEVICE_CONTEXTS='4', MM_TEST_REPLICA='1', MM_REPLICA_FANOUT=fanout, MM_SLAB_GB='8', MM_LANES='2', MM_BATCH_BASES='400000', MM_VERBOSE='1'))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert _strip_pg(r.stdout) == want
+        made = [l for l in r.stderr.decode().splitlines() if 'index replica on device' in l]
+        assert len(made) == 3 and not any('FAILED' in l for l in made), made          # (test hook: a replica per context behind the first)
+        if fanout == '1': assert any('(a replica)' in l for l in made), made          # with one copy per holder at a time the third is served by the first replica
 
 @pytest.fixture(scope='module')
 def long_tailed():

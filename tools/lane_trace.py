@@ -5,7 +5,7 @@ Usage: tools/lane_trace.py <stderr file>"""
 import re, sys, collections
 ev = []
 for l in open(sys.argv[1]):
-    m = re.match(r'\[minialign_amd\] batch (\d+) \(lane (\d+)\): (.*?) ([\d.]+) ms \(at ([\d.]+)\)', l)
+    m = re.match(r'\[minialign_amd\] batch (\d+) \((?:device \d+ )?lane (\d+)\): (.*?) ([\d.]+) ms \(at ([\d.]+)\)', l)
     if m: ev.append((int(m.group(1)), int(m.group(2)), m.group(3), float(m.group(4)), float(m.group(5))))
 idx = max(i for i, e in enumerate(ev) if e[0] == 0 and e[2].startswith('pack'))
 run = ev[idx:]; by = {}
