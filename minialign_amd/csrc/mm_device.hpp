@@ -74,8 +74,14 @@ struct ReadState {
 	/* room of this read in the result-bin pool, the alignment pool and the position-hash pool, set by the host between chaining and extension from the number of chains
 	 * that pass the length test (n_pass): a read inside a repeat family walks hundreds of chains, each with a bin header, an alignment and a few hash entries, where the
 	 * typical read has one or two (0: the launch's defaults, K3Args.bin_cap_per_read / aln_cap_per_read / kh_cap at the read's number) */
-	uint32_t bin_cap, aln_cap, kh_cap, pad_; uint64_t kh_off;
+	uint32_t bin_cap, aln_cap, kh_cap, dep; uint64_t kh_off;
+	/* the carried reference length between reads of one launch.  The host predicts it from the chains (pred_rid); a read that has no chain worth a trial at
+	 * the first occurrence threshold but rescue minimizers waiting leaves something nobody can predict -- whatever its later rounds find.  The reads whose value such a read
+	 * decides (dep = its index; NIL: none) take it from the read itself inside the launch: the source (flags & RS_CARRY_SRC) publishes its final rlen (agent-scope release,
+	 * carry_ready = 1), the dependent read waits for that before its first trial.  rlen_in: the value the read ran with, for the host's check */
+	uint32_t flags, rlen_in, carry_ready, pad2_;
 };
+enum : uint32_t { RS_CARRY_SRC = 1 };
 enum : uint32_t { ERR_SEED_CAP = 1, ERR_DP_SLAB = 2, ERR_PATH_CAP = 4, ERR_SEG_CAP = 8, ERR_KH_CAP = 16, ERR_BIN_CAP = 32, ERR_ALN_CAP = 64, ERR_NEXT_CAP = 128, ERR_STACK = 256 };
 
 /* coordinate transforms, minialign.c:3340-3362 */
@@ -2309,6 +2315,21 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		Seed *s = a.seed_pool + rdfirst64(st->seed_off);
 		Root *root = a.root_pool + rdfirst64(st->root_off);
 		uint32_t rlen = (uint32_t)rdfirst((int)st->rlen);
+		if(round == a.round) {
+			const uint32_t dep = (uint32_t)rdfirst((int)st->dep);
+			if(dep != gaba::NIL) {
+				/* the value this read starts with is what read `dep` ends with, and that read is one whose later rounds decide it: taken from the read itself (it stands at the
+				 * front of the work list, so a wave has it; the wait is bounded all the same -- past it the read runs with the host's prediction and the host's check decides) */
+				uint32_t ok = 0;
+				if(lane == 0) {
+					const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+					while((ok = __hip_atomic_load(&a.st[dep].carry_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) { if(__builtin_amdgcn_s_memtime() - t0 > (1ull << 28)) { break; } __builtin_amdgcn_s_sleep(32); }
+				}
+				ok = (uint32_t)rdfirst((int)ok);
+				if(ok) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); rlen = (uint32_t)rdfirst((int)__hip_atomic_load(&a.st[dep].rlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+			}
+			if(lane == 0) { st->rlen_in = rlen; }
+		}
 		uint32_t err = 0, n_res = (uint32_t)rdfirst((int)st->n_res);
 		uint32_t rid_last = (uint32_t)rdfirst((int)st->rid_last);
 		uint32_t apos0 = (uint32_t)rdfirst((int)st->apos0), cond0 = (uint32_t)rdfirst((int)st->cond0);
@@ -2747,6 +2768,12 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if(!a.inkernel_rounds || n_res > 0 || err != 0 || round + 1 >= ix.n_occ) { break; }
 		if(a.defer_thr) { const uint32_t half = (uint32_t)rdfirst((int)st->seed_cap) / 2u, base = (uint32_t)rdfirst((int)st->seed_n0) + 2u; if(half > base && half - base >= a.defer_thr) { if(lane == 0) { st->done = 2; } break; } }          /* (done = 2: the later rounds are the host's) */
+		}
+		if(((uint32_t)rdfirst((int)st->flags) & RS_CARRY_SRC) != 0u) {
+			/* a read whose end decides what the reads behind it start with: its state is out (st->rlen above), then the flag */
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if(lane == 0) { __hip_atomic_store(&st->carry_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 		}
 		if(rq_on && lane == 0) { atomicAdd(&a.rq_ctl[2], 1u); }          /* (helper waves leave when every read is done) */
 		if(!persistent) { break; }

@@ -1466,13 +1466,24 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			/* seed the carried reference-length state (see ReadIn.rlen_in): either given exactly (re-runs), or predicted from
 			 * the chain lists: read i starts with the length of the last reference read i - 1 loads */
 			if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
-			if(rlen_fixed) { for(size_t i = 0; i < work.size(); i++) hst[work[i]].rlen = (*rlen_fixed)[i]; }
+			if(rlen_fixed) { for(size_t i = 0; i < work.size(); i++) { hst[work[i]].rlen = (*rlen_fixed)[i]; hst[work[i]].dep = gaba::NIL; hst[work[i]].flags = 0; } }
 			else {
-				uint32_t cur = a->rlen_carry;
+				/* ... except behind a read that has no chain worth a trial at this threshold but rescue minimizers waiting: what it leaves is whatever its later rounds find, which
+				 * nobody knows before they have run.  Such a read is a source (RS_CARRY_SRC): the reads whose starting value it decides (the next read, and on through reads that
+				 * load nothing at all) take the value from it inside the launch (ReadState.dep, mm_extend_kernel) instead of running with a guess and being run again from the
+				 * sketch on when the check finds the guess wrong -- 71 such re-runs per step of the headline set, 154 on a tenth of the hard-repeat set, where the re-runs of a batch
+				 * (one read inside a repeat family alone on a launch: a second) were three quarters of the step; MM_NO_CARRY_DEPS: all by prediction as before */
+				static const bool no_deps = getenv("MM_NO_CARRY_DEPS") != NULL;
+				const bool deps = !no_deps && getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL && getenv("MM_K3_DEFER_RESCUE") == NULL && getenv("MM_K3_ONE_READ_PER_WAVE") == NULL;
+				std::vector<uint8_t> in_work(n_reads, 0); for(uint32_t wi : work) in_work[wi] = 1;
+				uint32_t cur = a->rlen_carry, src = gaba::NIL;          /* src: the source read that decides the value at hand */
 				a->ran_with.resize(n_reads);
 				for(uint32_t i = 0; i < n_reads; i++) {
 					hst[i].rlen = cur; a->ran_with[i] = cur;          /* (what the read runs with, kept as it is handed out: see batch_run_spec) */
-					if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen();
+					hst[i].dep = src; hst[i].flags = 0; hst[i].carry_ready = 0; hst[i].rlen_in = cur;
+					if(!in_work[i]) continue;
+					if(hst[i].pred_rid != gaba::NIL) { cur = a->mi->seq[hst[i].pred_rid].blen(); src = gaba::NIL; }
+					else if(deps && hst[i].n_resc > 0 && !hst[i].err) { hst[i].flags = RS_CARRY_SRC; src = i; }
 				}
 			}
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
@@ -1500,24 +1511,22 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				auto mid = std::stable_partition(by_len.begin(), by_len.end(), [&](uint32_t x) { return hst[x].w_pass >= thr && hst[x].n_pass >= 2; });
 				std::stable_sort(by_len.begin(), mid, [&](uint32_t x, uint32_t y) { return hst[x].w_pass > hst[y].w_pass; });
 				n_heavy = (uint32_t)(mid - by_len.begin());
-				/* ... and, in front of those, the reads that found NO chain worth a trial at the first occurrence threshold but have rescue minimizers waiting: they go on to the
-				 * next thresholds inside the launch, and a read inside a repeat family then finds its hundreds of chains there and walks them on its one wave -- seconds, on the
-				 * hard-repeat set (6 M DP vectors on a wave while the rest of the launch has long finished).  Nothing spreads that walk yet; starting it when the
-				 * launch starts at least overlaps it with the bulk.  At most a 64th of the list, the ones with the most rescue hits first; on the sets without such repeats these
-				 * are a handful of reads */
-				if(getenv("MM_K3_RESCUE_FIRST")) {          /* (experiment, off by default: not yet run on a GPU) */
-					auto resc_hits = [&](uint32_t x) -> uint32_t { const uint32_t half = hst[x].seed_cap / 2, base = hst[x].seed_n0 + 2; return half > base ? half - base : 0u; };
-					std::vector<uint32_t> front;
-					for(uint32_t x : by_len) { if(hst[x].n_pass == 0 && hst[x].n_resc > 0 && resc_hits(x) >= 64) front.push_back(x); }
+			}
+			{
+				/* ... and, in front of everything, the reads that found NO chain worth a trial at the first occurrence threshold but have rescue minimizers waiting (the sources
+				 * of the carried value, RS_CARRY_SRC above): they go on to the next thresholds inside the launch -- a read inside a repeat family finds its hundreds of chains
+				 * there (published as jobs since round 5) -- and the reads behind them in the batch wait for what they leave, so a wave must have taken every one of them before
+				 * any wave can be waiting: the most rescue hits first */
+				auto resc_hits = [&](uint32_t x) -> uint32_t { const uint32_t half = hst[x].seed_cap / 2, base = hst[x].seed_n0 + 2; return half > base ? half - base : 0u; };
+				std::vector<uint32_t> front;
+				for(uint32_t x : by_len) { if((hst[x].flags & RS_CARRY_SRC) || (getenv("MM_K3_RESCUE_FIRST") && hst[x].n_pass == 0 && hst[x].n_resc > 0 && resc_hits(x) >= 64)) front.push_back(x); }
+				if(!front.empty() && !deferred && round == 0) {
 					std::stable_sort(front.begin(), front.end(), [&](uint32_t x, uint32_t y) { return resc_hits(x) > resc_hits(y); });
-					if(front.size() > by_len.size() / 64) front.resize(by_len.size() / 64);
-					if(!front.empty()) {
-						std::vector<uint8_t> is_front(n_reads, 0); for(uint32_t x : front) is_front[x] = 1;
-						std::vector<uint32_t> rest; rest.reserve(by_len.size());
-						for(uint32_t x : by_len) if(!is_front[x]) rest.push_back(x);
-						by_len = front; by_len.insert(by_len.end(), rest.begin(), rest.end());
-						n_heavy += (uint32_t)front.size();          /* (the enumeration of chain jobs skips them: no passing chain) */
-					}
+					std::vector<uint8_t> is_front(n_reads, 0); for(uint32_t x : front) is_front[x] = 1;
+					std::vector<uint32_t> rest; rest.reserve(by_len.size());
+					for(uint32_t x : by_len) if(!is_front[x]) rest.push_back(x);
+					by_len = front; by_len.insert(by_len.end(), rest.begin(), rest.end());
+					if(n_heavy) n_heavy += (uint32_t)front.size();          /* (the enumeration of chain jobs skips them: no passing chain) */
 				}
 			}
 			if(deferred) {          /* a launch of deferred reads: all of them are candidates for chain jobs, the ones with the most to walk first */
@@ -1579,7 +1588,11 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* (any number of workspace classes, any number of workspaces: a helper takes the workspace a job needs before it claims the job and without waiting, K3_TRY_SLAB, so the
 		 * wave that waits for a claimed job waits for one that is running; on the ONT-like set the reads that decide the launch are 60 - 160 kb long with 9 - 27 trials for
 		 * one alignment, tools/read_cost.py) */
-		if(round == 0 && k3.ring && k3.cls && inkernel && work.size() >= 256 && !getenv("MM_K3_NO_RETRY_JOBS")) {
+		/* (a launch of a few reads -- the re-runs of the carried-value check -- has them too, with a helper in every workgroup: one read inside a repeat family alone on a launch
+		 * walked its hundreds of chains on one wave for a second while the lanes behind it waited for their turn at the carried value) */
+		const bool small_launch = work.size() < 256;
+		if(small_launch) { k3.rq_helper_mask = 3u; }
+		if(round == 0 && k3.ring && k3.cls && inkernel && !getenv("MM_K3_NO_RETRY_JOBS")) {
 			const uint32_t rq_cap = 1u << 17;
 			if(a->rq_jobs.ensure(rq_cap) && a->rq_memo.ensure(rq_cap) && a->rq_state.ensure(rq_cap + 16)) {
 				CK(hipMemsetAsync(a->rq_state.p, 0, ((size_t)rq_cap + 16) * 4, a->stream));
@@ -1587,7 +1600,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0; k3.stage_top = nullptr; k3.round_jobs = 0;
-		k3.dyn0_min = getenv("MM_K3_DYN_ROUND0") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_DYN_ROUND0"))) : 0u;
+		k3.dyn0_min = getenv("MM_K3_DYN_ROUND0") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_DYN_ROUND0"))) : (small_launch ? 2u : 0u);          /* (a small launch has no chain jobs from before the launch: its reads publish their chains themselves) */
 		/* the staging area of the traced jobs (path words, segments) and its cursors: for the chain jobs enumerated before the launch and for the chains a read publishes from
 		 * inside it (K3Args.rjobs, JOB_FULL) alike */
 		const uint64_t stage_job_cap = getenv("MM_K3_JOB_CAP") ? (uint64_t)std::max(1, atoi(getenv("MM_K3_JOB_CAP"))) : (1u << 16), stage_path_cap = 48ull << 20, stage_seg_cap = (stage_job_cap + k3.rq_cap) * 8;          /* (MM_K3_JOB_CAP: test hook, a launch with more chain jobs than slots) */
@@ -1613,6 +1626,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
+		if(small_launch && k3.rjobs) { waves = std::min<uint32_t>(a->k3_waves, std::max<uint32_t>(waves, 1024u)); }          /* (waves for the jobs of a small launch: 256 workgroups, the first wave of each a helper) */
 		if(deferred && k3.jobs) { uint64_t nj = 0; for(uint32_t wi : work) nj += hst[wi].n_pass; waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((std::max<uint64_t>(work.size(), std::min<uint64_t>(nj, 4096)) + 3) & ~3ull)); }          /* (waves for the jobs, not only for the reads) */
 		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
 		/* several batches in flight (lanes): 5 persistent waves per SIMD keep the integer VALU as busy as 8 do (a wave issues at most every 4th cycle, about two
@@ -2290,7 +2304,7 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		/* minimizers of a read: at most one per position; 2 / (w + 1) per base on average, so half the length is ample from w = 4 up */
 		/* (a read whose hashes keep falling emits one per position: after a pool overflow the batch is redone with room for that) */
 		b.hst[i].min_off = moff; b.hst[i].min_cap = (uint32_t)((double)b.lens[i] * mcf) + 64; moff += b.hst[i].min_cap;
-		b.hst[i].bin_off = ~0ull; b.hst[i].apos0 = gaba::NIL; b.hst[i].rid_last = gaba::NIL; b.hst[i].pred_rid = gaba::NIL;
+		b.hst[i].bin_off = ~0ull; b.hst[i].apos0 = gaba::NIL; b.hst[i].rid_last = gaba::NIL; b.hst[i].pred_rid = gaba::NIL; b.hst[i].dep = gaba::NIL;
 		/* unmappable reads are skipped outright (minialign.c:4434) */
 		if(!(b.lens[i] < a->mi->k || b.lens[i] * a->mcoef < (double)a->o.min_score)) b.work.push_back(i);
 	}
@@ -2437,7 +2451,7 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 		for(size_t j = 0; j < redo.size(); j++) {
 			uint32_t i = redo[j]; uint64_t mo = hst[i].min_off; uint32_t mc = hst[i].min_cap;
 			memset(&hst[i], 0, sizeof(ReadState)); hst[i].min_off = mo; hst[i].min_cap = mc;
-			hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL;
+			hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL; hst[i].dep = gaba::NIL;
 			used[i] = redo_rlen[j];
 		}
 		if(!lane_h2d(a, a->d_st.p, hst.data(), n_reads * sizeof(ReadState))) return -1;
@@ -2458,7 +2472,7 @@ int batch_run_spec(mm_align_t *a, Batch &b)
 	 * while the reads behind it ran with the prediction of its first one -- derived afterwards, `used` then said what the reads should have run with, the check against
 	 * the true chain of values found nothing to re-run, and a read whose `apos >= rlen` decision the difference flips kept the records of the wrong decision (one read
 	 * of the 266 589 of the ONT-like hg38-size set, found by the whole-set comparison of round 4; rounds 1-3 compared the first 20 000) */
-	if(a->ran_with.size() == n_reads) { b.used = a->ran_with; }
+	if(a->ran_with.size() == n_reads) { b.used = a->ran_with; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].dep != gaba::NIL) b.used[i] = hst[i].rlen_in; } }          /* (a read behind a source ran with what the source left: the kernel says what that was) */
 	else { b.used.assign(n_reads, 0); uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen(); } }
 	{
 		/* which caps gave way, and on how many reads: said once per attempt (the batch is then run again with larger pools) */
