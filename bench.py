@@ -185,6 +185,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU legs (baseline and identity check)')
     ap.add_argument('--no-packed', action='store_true', help='skip the value_from_packed leg'); ap.add_argument('--no-cli', action='store_true', help='skip the command-line run')
     ap.add_argument('--keep', action='store_true', help='keep the generated data (prints the directory)')
+    ap.add_argument('--no-hard', action='store_true', help='skip the hard-repeat record (config.hard_repeats: the hg38hard workload in a process of its own behind the timed steps; default workload on one GPU only)')
     args = ap.parse_args()
     os.environ['MM_LANES'] = str(args.lanes)          # the batch rule of the library (one batch per lane for a small set) sees the lanes this run uses
     rank = int(os.environ.get('RANK', '0')); local = int(os.environ.get('LOCAL_RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -354,6 +355,22 @@ def main():
             else:
                 out['sam_identical'] = None; out['sam_check'] = 'not run'
         out['config'].update(cli_info)
+        if args.workload == 'hg38' and not custom and n_gpus == 1 and world == 1 and not args.no_hard and not args.no_cpu:
+            # the same path on a reference with mammalian repeat structure (45 % repeats: the headline set has 5 %), in a process of its own once this one has given the
+            # device back: value, DP vectors per base, records of the first reads against the compiled reference, the reference's own speed beside it
+            L.mm_align_destroy.argtypes = [ctypes.c_void_p]; L.mm_align_destroy.restype = None; L.mm_idx_destroy.argtypes = [ctypes.c_void_p]; L.mm_idx_destroy.restype = None
+            L.mm_align_destroy(al); L.mm_idx_destroy(mi); al = mi = None
+            try:
+                env = dict(os.environ); env.pop('MM_LIB_OVERRIDE', None)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', 'hg38hard', '--steps', '1', '--warmup', '1', '--no-cli', '--no-packed', '--lanes', str(args.lanes)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+                h = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
+                out['config']['hard_repeats'] = {'value': h['value'], 'unit': h['unit'], 'ms_per_step': h['ms_per_step'], 'workload': h['config']['workload'], 'dp_vectors_per_base': h['config']['dp_vectors_per_base'],
+                                                 'reruns_per_step': h['config']['reruns_per_step (rank 0)'], 'extend_wave_balance': h['config']['extend_wave_balance (mean / max lifetime)'],
+                                                 'sam_identical': h.get('sam_identical'), 'sam_check': h.get('sam_check'), 'cpu_baseline': h.get('cpu_baseline'),
+                                                 'note': 'python bench.py --workload hg38hard --steps 1 --warmup 1, run behind the timed steps of the headline workload'}
+            except Exception as e:
+                out['config']['hard_repeats'] = {'error': repr(e)}
+            stage('hard-repeat record done')
         print(json.dumps(out), flush=True)
     if dist: dist.barrier()
     if rank == 0:

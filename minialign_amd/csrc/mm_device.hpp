@@ -1689,6 +1689,7 @@ struct K3Args {
 	uint32_t rq_early;                   /* helpers are helpers from the start of the launch (they take no reads): the reads that publish retry jobs are at the front of the work list */
 	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = the takers' cursor, [2] = reads done, [3] = results taken, [4] = reads being walked that have published the chains of a round */
 	unsigned long long *stage_top;       /* cursors of the staging area (spath / sseg) that the traced jobs of either kind write to: [0] path words, [1] segments */
+	uint32_t rq_between;                 /* 1: a wave with reads left takes published jobs that fit the workspace it holds before its next read (2: of any class; 0: only waves without reads take jobs) */
 	uint32_t round_jobs;                 /* 1: a read publishes the chains of a round that was chained inside the launch as jobs (rjobs, JOB_FULL) */
 	uint32_t dyn0_min;                   /* experiment (MM_K3_DYN_ROUND0 = n, off = 0): a read with n or more passing chains in the round the launch starts with that got no chain jobs before the launch publishes them itself when its wave takes it */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
@@ -2038,12 +2039,14 @@ __device__ __attribute__((noinline)) uint32_t k3_room(ReadState *st, uint32_t ro
 	const uint32_t want_bin = min(1u << 24, max(bin_def, 5u * np + 64u)), want_aln = min(1u << 22, max(aln_def, 3u * np + 32u));
 	const bool first = bin_off == ~0ull;
 	if(first || want_bin > bin_cap || want_aln > aln_cap) {
-		const uint32_t nb = first ? want_bin : max(want_bin, bin_cap), na = first ? want_aln : max(want_aln, aln_cap);
+		/* (a read that moves takes at least twice what it held: the regions it leaves behind are not reclaimed, so the moves of a read are bounded by a logarithm) */
+		const uint32_t nb = first ? want_bin : max(want_bin, 2u * bin_cap), na = first ? want_aln : max(want_aln, 2u * aln_cap);
 		uint32_t bo_lo = 0, bo_hi = 0, ao_lo = 0, ao_hi = 0;
 		if(lane == 0) { const unsigned long long b = atomicAdd(bin_top, (unsigned long long)nb), q = atomicAdd(aln_top, (unsigned long long)na); bo_lo = (uint32_t)b; bo_hi = (uint32_t)(b >> 32); ao_lo = (uint32_t)q; ao_hi = (uint32_t)(q >> 32); }
 		const uint64_t bo = (uint64_t)(uint32_t)rdfirst((int)bo_lo) | ((uint64_t)(uint32_t)rdfirst((int)bo_hi) << 32), ao = (uint64_t)(uint32_t)rdfirst((int)ao_lo) | ((uint64_t)(uint32_t)rdfirst((int)ao_hi) << 32);
 		/* no room in the pools: the read is given up for this pass; it must not touch another read's region */
-		if(bo + nb > bin_pool_cap || ao + na > aln_pool_cap) { return ERR_BIN_CAP; }
+		if(bo + nb > bin_pool_cap) { return ERR_BIN_CAP; }
+		if(ao + na > aln_pool_cap) { return ERR_ALN_CAP; }
 		if(!first) {
 			const uint32_t *ob = (const uint32_t *)(bin_pool + bin_off); uint32_t *nbp = (uint32_t *)(bin_pool + bo);
 			for(uint32_t i = (uint32_t)lane; i < 2u * bin_cap; i += 64) { nbp[i] = ob[i]; }
@@ -2213,7 +2216,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	bool no_reads = rq_helper && a.rq_early;          /* this wave takes no (more) reads */
 	uint32_t rq_mine = 0xffffffffu;                   /* a slot number this wave drew that has not been published yet */
 	while(true) {
-		if(rq_on) {
+		if(rq_on && (no_reads || a.rq_between != 0u)) {
 			/* published jobs come before the next read: a wave with reads left takes what is there and goes on; one without stays -- a helper until the last read is done,
 			 * any other wave while a read that has published the chains of a later round is still being walked (rq_ctl[4]) */
 			uint32_t idle = 0;
@@ -2235,7 +2238,9 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					const uint32_t jr = (uint32_t)rdfirst((int)a.rjobs[ji].r), jq = (uint32_t)rdfirst((int)a.in[jr].qlen);
 					int want = 0; while(want + 1 < (int)a.n_cls && jq > a.cls[want].qmax) { want++; }
 					bool have = want == slab_cls;
-					if(!have) { K3_TRY_SLAB(want, have); }
+					/* (a wave with reads left keeps the workspace it holds: on a ladder of classes it would give a scarce one back for a job of another class and wait for it again for
+					 * its next read -- it takes the jobs that fit what it holds, the waves without reads take any) */
+					if(!have && (no_reads || slab_cls < 0 || a.rq_between >= 2u)) { K3_TRY_SLAB(want, have); }
 					if(have) { if(lane == 0) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY ? 100u : 99u; } stt = (uint32_t)rdfirst((int)stt); }
 					else { stt = RJ_EMPTY; }          /* no workspace of that class free: the job stays with its owner unless one comes back before the owner gets there */
 				}

@@ -1303,6 +1303,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 	if(work.empty()) return true;
 	unsigned long long *tops = a->d_tops.p;
 	float ms;
+	/* a re-run of a few reads with the carried value given (batch_verify_carry): the short way -- one sort + chain launch, no round trip of the states between chaining
+	 * and extension (the caller has put the value and the reset fields in place), the work list as it is */
+	const bool small_rerun = rlen_fixed != nullptr && run_k1 && work.size() < 256 && getenv("MM_SLOW_RERUN") == NULL;
 	if(run_k1) {
 		CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
 		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
@@ -1327,7 +1330,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			unsigned long long t3[3] = { a->pin_note[0], a->pin_note[1], a->pin_note[2] };          /* (written by the last wave of the launch, which is over) */
 			if(t3[0] == ~0ull) { CPY(a, t3, tops, sizeof(t3), hipMemcpyDeviceToHost); }
 			mm_align_s *NP = a->root ? a->root : a; const double bb = (double)a->batch_bases;
-			{ std::lock_guard<std::mutex> lk(NP->need_mu); NP->need_seed = std::max(NP->need_seed, t3[0] / bb); NP->need_resc = std::max(NP->need_resc, t3[1] / bb); NP->need_root = std::max(NP->need_root, t3[2] / bb); }
+			/* (noted from batches of 16 Mb and more only, and clamped: the ratio of one short repeat-family read -- a map_split half, the tail batch of a file, a single read through
+			 * mm_align_seq -- would otherwise size every later 300 Mb batch of the context at tens of GB per lane; a small batch that asks for more than it got is regrown below all the same) */
+			if(a->batch_bases >= (16ull << 20)) { std::lock_guard<std::mutex> lk(NP->need_mu); NP->need_seed = std::min(4.0, std::max(NP->need_seed, t3[0] / bb)); NP->need_resc = std::min(1.0, std::max(NP->need_resc, t3[1] / bb)); NP->need_root = std::min(2.0, std::max(NP->need_root, t3[2] / bb)); }
 			if(t3[0] > a->seed_pool.n || t3[1] > a->resc_pool.n || t3[2] > a->root_pool.n) {
 				if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   the batch asks for %.1f / %.1f / %.1f M seed / rescue / root entries (%.3f / %.3f / %.3f per base), the pools hold %.1f / %.1f / %.1f M: sized again, sketch launch repeated\n",
 					t3[0] * 1e-6, t3[1] * 1e-6, t3[2] * 1e-6, t3[0] / bb, t3[1] / bb, t3[2] / bb, a->seed_pool.n * 1e-6, a->resc_pool.n * 1e-6, a->root_pool.n * 1e-6);
@@ -1376,7 +1381,14 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			CK(hipEventRecord(a->ev0, a->stream));          /* re-recorded behind the memset: the side streams start from here */
 			/* the sort first (mm_sort_kernel: 4 B of LDS per seed, a dozen reads per CU), in size classes by LDS need on the side streams; every stream of the
 			 * chain launches below then waits for all of them (a read's sort class is not its chain class) */
-			const bool presort = getenv("MM_K2_NO_PRESORT") == NULL && getenv("MM_K2_FORCE_HBM") == NULL;
+			/* the few reads of a re-run (the carried-value check): ONE launch, sort + chain in place in HBM (the form the largest reads take) -- the nine launches of the
+			 * size classes each wait 10 - 40 ms for a wave slot beside the extension waves of the other lanes, and every lane behind this one waits for the check */
+			const bool presort = getenv("MM_K2_NO_PRESORT") == NULL && getenv("MM_K2_FORCE_HBM") == NULL && !small_rerun;
+			if(small_rerun) {
+				ka.presorted = 0; ka.leaf_shift = a->k2_leaf_shift ? 1u : 0u; ka.big_only = 0; ka.retry = 0; ka.lds_bytes = 1536 * 4; ka.n_lo = 0; ka.n_hi = 0xffffffffu; ka.counter = a->d_k2cnt.p + 12;
+				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3((uint32_t)work.size()), dim3(64), 1536 * 4, a->stream, ka);
+				CK(hipGetLastError());
+			}
 			if(presort) {
 				static const uint32_t s_kb[] = { 10, 14, 20, 32, 64, 104 };          /* k2s_bytes(K2S_MAX_N) <= 104 KB */
 				const int n_s = (int)(sizeof(s_kb) / sizeof(s_kb[0]));
@@ -1436,7 +1448,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				CK(hipGetLastError());
 			}
 			auto bytes_of = [](uint32_t div) -> uint32_t { return div ? ((160u * 1024u / div) & ~255u) : 0u; };
-			for(int ci = 0; ci <= n_cls && !presort; ci++) {
+			for(int ci = 0; ci <= n_cls && !presort && !small_rerun; ci++) {
 				/* (the one-kernel form, kept behind MM_K2_NO_PRESORT / MM_K2_FORCE_HBM) ci < n_cls: size classes, largest first; ci == n_cls: retry of the reads whose leaf area overflowed, at 160 KB */
 				const uint32_t div = ci == n_cls ? 1u : cls_div[ci];
 				const uint32_t bytes = bytes_of(div);
@@ -1465,6 +1477,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		if(round == 0) {
 			/* seed the carried reference-length state (see ReadIn.rlen_in): either given exactly (re-runs), or predicted from
 			 * the chain lists: read i starts with the length of the last reference read i - 1 loads */
+			if(small_rerun) { /* nothing comes back here, nothing goes up: rlen, apos0, rid_last, bin_off and the counters of the reads are as batch_verify_carry put them */ }
+			else {
 			if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
 			if(rlen_fixed) { for(size_t i = 0; i < work.size(); i++) { hst[work[i]].rlen = (*rlen_fixed)[i]; hst[work[i]].dep = gaba::NIL; hst[work[i]].flags = 0; } }
 			else {
@@ -1488,6 +1502,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
 			if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;
+			}
 		}
 		if(a->tap_stop) { return true; }
 		if(deferred) { if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false; }          /* (the chains of this round: n_pass / w_pass for the order and the jobs) */
@@ -1497,7 +1512,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
 			/* (ordering by the chain count, the best predictor of a read's DP work, was tried and is worse: the heaviest reads then run
 			 * under full contention from the start and become the critical path) */
-			if(qlens.size() == n_reads) { std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return qlens[x] > qlens[y]; }); }
+			if(qlens.size() == n_reads && !small_rerun) { std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return qlens[x] > qlens[y]; }); }
 			/* ... except the few reads with by far the most chains (repeats: dozens of extension trials, several times a wave's
 			 * fair share of the DP work): one of them is the critical path of the launch, so they start first.  Moving *all* reads
 			 * into chain-count order is worse (measured): the bulk of moderately heavy reads then crowds the start. */
@@ -1555,7 +1570,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 					uint32_t at = 0; for(int c = n_cls - 1; c >= 0; c--) { seg_beg[c] = at; at += seg_len[c]; }
 				}
 			}
-			CK(hipMemcpyAsync(a->d_work.p, by_len.data(), by_len.size() * 4, hipMemcpyHostToDevice, a->stream));
+			if(!small_rerun || round != 0) { CK(hipMemcpyAsync(a->d_work.p, by_len.data(), by_len.size() * 4, hipMemcpyHostToDevice, a->stream)); }          /* (a small re-run: the list K1 and K2 used) */
 		}
 		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
 		K3Args k3; k3.idx = a->dix; k3.gc = a->gctx->hc; k3.roots = a->gctx->droots; k3.ar_ref = gaba::SeqArena{ a->ref_ar->pk, a->ref_ar->nm }; k3.ar_q = gaba::SeqArena{ a->q_pk.p, a->q_nm.p };
@@ -1583,6 +1598,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.rjobs = nullptr; k3.rmemo = nullptr; k3.rstate = nullptr; k3.rq_cap = 0; k3.rq_ctl = nullptr;
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
 		k3.rq_early = getenv("MM_K3_LATE_HELPERS") ? 0u : 1u;
+		k3.rq_between = getenv("MM_K3_JOBS_BETWEEN_READS") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_JOBS_BETWEEN_READS"))) : 1u;
 		k3.full_n = a->n_waves / 8;
 		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 is a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) when helpers were the waves that had run out of reads -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for; as helpers from the start, one in 8 / 16 / 32 on the ONT-like set: 2.37 / 2.34 / 2.46 against 2.7 - 2.9 */
 		/* (any number of workspace classes, any number of workspaces: a helper takes the workspace a job needs before it claims the job and without waiting, K3_TRY_SLAB, so the
@@ -2452,6 +2468,7 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 			uint32_t i = redo[j]; uint64_t mo = hst[i].min_off; uint32_t mc = hst[i].min_cap;
 			memset(&hst[i], 0, sizeof(ReadState)); hst[i].min_off = mo; hst[i].min_cap = mc;
 			hst[i].bin_off = ~0ull; hst[i].apos0 = gaba::NIL; hst[i].rid_last = gaba::NIL; hst[i].pred_rid = gaba::NIL; hst[i].dep = gaba::NIL;
+			hst[i].rlen = redo_rlen[j];          /* (run_rounds' short way for a few reads takes it from here) */
 			used[i] = redo_rlen[j];
 		}
 		if(!lane_h2d(a, a->d_st.p, hst.data(), n_reads * sizeof(ReadState))) return -1;
@@ -3504,7 +3521,9 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 				/* run ahead with the predicted carry; pools that overflow are grown here, before anybody waits for this batch */
 				bool split = false; const double k1_0 = c->st.k1_ms, k2_0 = c->st.k2_ms, k3_0 = c->st.k3_ms;
 				if(getenv("MM_TEST_SPLIT") && b.n >= 8) { split = true; }          /* test hook: take the path of a batch the pools cannot hold */
-				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) ok = false; }
+				/* a batch whose pools the device cannot hold (at its size, or after they were grown): not the end of the stream -- its reads go in halves (map_split) */
+				if(!ok && b.n >= 2) { fprintf(stderr, "[minialign_amd] batch %u: its pools do not fit the device, mapped in halves\n", k); ok = true; split = true; }
+				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) { if(b.n >= 2) { split = true; } else { ok = false; } } }
 				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): run %.1f ms (at %.1f): sketch %.1f, sort + chain %.1f, extension %.1f ms on the device, the rest the host's turns in between\n", k, di, li, now_ms() - tv, now_ms() - t_engine0, c->st.k1_ms - k1_0, c->st.k2_ms - k2_0, c->st.k3_ms - k3_0); tv = now_ms(); }
 				uint32_t truth = 0;
 				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return verified == k || rc != 0; }); if(rc) ok = false; truth = carry; }

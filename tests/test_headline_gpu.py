@@ -80,6 +80,10 @@ def _reference_by_parts(preset, ref, rd, spans, out, threads=None, primer=4, win
     [g, g + group) lands in out.<g>.json"""
     mai = out + '.mai'; sc = _samcheck(); threads = threads or SIZES['index_threads']
     lines = []
+    # (round 5: a gpurun box has 3 TB of memory but a cgroup limit of 300 GiB -- profiles/round5_box.txt: what the 32 x 18 GB of round 4 ran into.  Every 18 GB process
+    # waits until 60 GB are left under that limit (or of MemAvailable, whichever is less), and the processes start 5 s apart so that each one's pages are counted before the next asks)
+    lines.append('room() { while true; do lim=$(cat /sys/fs/cgroup/memory.max 2>/dev/null); cur=$(cat /sys/fs/cgroup/memory.current 2>/dev/null); av=$(awk \'/MemAvailable/{printf "%.0f", $2*1024}\' /proc/meminfo); '
+                 'if [ -n "$lim" ] && [ "$lim" != max ] && [ -n "$cur" ]; then left=$((lim-cur)); [ "$left" -lt "$av" ] && av=$left; fi; [ "$av" -gt "$1" ] && return; sleep 2; done; }')
     lines.append('%s -x%s -t%d -d %s %s 2> %s.idx.err || exit 1' % (REFBIN, preset, threads, mai, ref, out))
     if wait_for is not None: lines.append('while kill -0 %d 2>/dev/null; do sleep 1; done' % wait_for.pid)          # (the index build goes on beside the set in front; the 18 GB processes do not)
     for g in range(0, len(spans), group):
@@ -87,7 +91,7 @@ def _reference_by_parts(preset, ref, rd, spans, out, threads=None, primer=4, win
         with open(pf, 'wb') as f:
             if g: f.write(_last_records(rd, spans[g][0], primer, window))
         lo = spans[g][0]; hi = spans[min(len(spans), g + group) - 1]; n = hi[0] + hi[1] - lo
-        lines.append('( ( cat %s; tail -c +%d %s | head -c %d ) | %s -x%s -t1 %s 2> %s.%02d.err | %s --parts > %s.%02d.json ) &' % (pf, lo + 1, rd, n, REFBIN, preset, mai, out, g, sc, out, g))
+        lines.append('room 64424509440; ( ( cat %s; tail -c +%d %s | head -c %d ) | %s -x%s -t1 %s 2> %s.%02d.err | %s --parts > %s.%02d.json ) & sleep 5' % (pf, lo + 1, rd, n, REFBIN, preset, mai, out, g, sc, out, g))
     lines.append('wait; rm -f %s' % mai)
     return subprocess.Popen(['bash', '-c', '\n'.join(lines)])
 
