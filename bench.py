@@ -145,7 +145,7 @@ def pmc_traffic(wname, world, alg_bytes_per_launch):
     """HBM bytes per mm_extend_kernel launch from the committed rocprofv3 PMC passes of the same workload (tools/pmc_traffic.sh; this round's, else the last round's), else None.  The PMC run maps
     a tenth of the set on one lane; its traffic per launch is scaled by the algorithmic bytes per launch of this run over those of that run (same kernel, same reads:
     traffic per vector is what the counters measured)."""
-    fn = next((f for f in (os.path.join(ROOT, 'profiles', t + '_pmc.json') for t in ('round4', 'round3', 'round2')) if os.path.exists(f)), None)
+    fn = next((f for f in (os.path.join(ROOT, 'profiles', t + '_pmc.json') for t in ('round5', 'round4', 'round3', 'round2')) if os.path.exists(f)), None)
     if world != 1 or fn is None: return None
     try:
         with open(fn) as f: d = json.load(f)
@@ -158,7 +158,7 @@ def pmc_traffic(wname, world, alg_bytes_per_launch):
 def valu_position(vectors, wall_s, world):
     """Where the run sits against the integer-VALU issue limit of the chip (the real bound of mm_extend_kernel): the VALU cycles per DP vector that the SQ
     counters measured (tools/pmc_sq.sh -> profiles/round2_pmc_sq.json, SQ_ACTIVE_INST_VALU) x the vectors of this run, over SIMDs x clock x wall time."""
-    fn = next((f for f in (os.path.join(ROOT, 'profiles', t + '_pmc_sq.json') for t in ('round4', 'round3', 'round2')) if os.path.exists(f)), '')
+    fn = next((f for f in (os.path.join(ROOT, 'profiles', t + '_pmc_sq.json') for t in ('round5', 'round4', 'round3', 'round2')) if os.path.exists(f)), '')
     try:
         with open(fn) as f: per = json.load(f)['mm_extend_kernel_per_dp_vector']
         simds, clock = 256 * 4, 2.4e9          # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz maximum engine clock (MI355X_MICROARCH.md)

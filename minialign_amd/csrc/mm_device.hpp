@@ -1687,10 +1687,11 @@ struct K3Args {
 	uint32_t rq_helper_mask;             /* one wave in (mask + 1) is a helper for the retry jobs (one in 128 by default): the first wave of one workgroup in (mask + 1) / 4 of every XCD; every helper holds a wave slot the other lanes' launches wait for */
 	uint32_t full_n;                     /* workspaces per XCD that make a class complete: one for every wave the XCD can hold */
 	uint32_t rq_early;                   /* helpers are helpers from the start of the launch (they take no reads): the reads that publish retry jobs are at the front of the work list */
-	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = the takers' cursor, [2] = reads done, [3] = results taken, [4] = reads being walked that have published the chains of a round */
+	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = the takers' cursor, [2] = reads done, [3] = results taken, [4] = reads being walked that have published the chains of a round, [5] = the cursor of the waves that take chain jobs between their reads */
 	unsigned long long *stage_top;       /* cursors of the staging area (spath / sseg) that the traced jobs of either kind write to: [0] path words, [1] segments */
-	uint32_t rq_between;                 /* 1: a wave with reads left takes published jobs that fit the workspace it holds before its next read (2: of any class; 0: only waves without reads take jobs) */
-	uint32_t round_jobs;                 /* 1: a read publishes the chains of a round that was chained inside the launch as jobs (rjobs, JOB_FULL) */
+	uint32_t rq_stay;                    /* experiment (MM_K3_STAY): waves without reads stay while a read that has published the chains of a round is being walked */
+	uint32_t rq_between;                 /* 1: a wave with reads left takes published jobs that fit the workspace it holds before its next read (2: of any class; 3: retry jobs too; 0: only waves without reads take jobs) */
+	uint32_t round_jobs;                 /* n > 0: a read publishes the chains of a round that was chained inside the launch as jobs (rjobs, JOB_FULL) when it has n or more of them (at least 2) */
 	uint32_t dyn0_min;                   /* experiment (MM_K3_DYN_ROUND0 = n, off = 0): a read with n or more passing chains in the round the launch starts with that got no chain jobs before the launch publishes them itself when its wave takes it */
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 	uint32_t defer_thr;                  /* experiment (MM_K3_DEFER_RESCUE, off = 0): a read left without a result by the first threshold that has this many rescue hits waiting does NOT go on inside
@@ -2222,10 +2223,14 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			uint32_t idle = 0;
 			while(true) {
 				uint32_t ji = rq_mine, stt = 0, fin = 0, wide = 0;
+				/* two cursors over the one queue: the waves without reads (helpers among them) take whatever is published; a wave with reads left walks the queue on a cursor of
+				 * its own and takes the chain jobs only (JOB_FULL) -- the retry trials stay with the helpers as in round 3: taken between reads they cost the ONT-like set 7 %
+				 * (a retry trial of a 100 kb read in front of a wave's own next read).  A slot one cursor steps over is still in front of the other; the claim is by state */
+				const uint32_t cix = no_reads ? 1u : 5u;
 				if(lane == 0) {
 					if(ji == 0xffffffffu) {
-						const uint32_t cur = __hip_atomic_load(&a.rq_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), top = __hip_atomic_load(&a.rq_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						if(cur < top && cur < a.rq_cap) { ji = atomicAdd(&a.rq_ctl[1], 1u); if(ji >= a.rq_cap) { ji = 0xffffffffu; } }
+						const uint32_t cur = __hip_atomic_load(&a.rq_ctl[cix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), top = __hip_atomic_load(&a.rq_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if(cur < top && cur < a.rq_cap) { ji = atomicAdd(&a.rq_ctl[cix], 1u); if(ji >= a.rq_cap) { ji = 0xffffffffu; } }
 					}
 					if(ji != 0xffffffffu) { stt = __hip_atomic_load(&a.rstate[ji], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 					if(no_reads) { fin = __hip_atomic_load(&a.rq_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.n_work ? 1u : 0u; wide = __hip_atomic_load(&a.rq_ctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2235,6 +2240,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					/* the workspace the job needs comes BEFORE the claim: a claimed job is one that will be finished, whatever the waves that wait for it hold (with several
 					 * workspace classes a wave that claimed first and then waited for a workspace of a scarce class could wait for the very waves that wait for it) */
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+					if(!no_reads && a.rq_between < 3u && ((uint32_t)rdfirst((int)a.rjobs[ji].pad) & JOB_FULL) == 0u) { rq_mine = 0xffffffffu; idle = 0; continue; }          /* (a retry job: the helpers') */
 					const uint32_t jr = (uint32_t)rdfirst((int)a.rjobs[ji].r), jq = (uint32_t)rdfirst((int)a.in[jr].qlen);
 					int want = 0; while(want + 1 < (int)a.n_cls && jq > a.cls[want].qmax) { want++; }
 					bool have = want == slab_cls;
@@ -2256,7 +2262,11 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				if(ji != 0xffffffffu && stt != RJ_EMPTY) { rq_mine = 0xffffffffu; idle = 0; continue; }          /* taken by its owner, done or cancelled: the next one */
 				rq_mine = ji;                                                                                 /* drawn but not published yet (or nothing drawn) */
 				if(!no_reads) { if(ji == 0xffffffffu || ++idle > 4u) { break; } __builtin_amdgcn_s_sleep(8); continue; }          /* (reads are waiting: on with them) */
-				if(fin || (!rq_helper && wide == 0u)) { break; }
+				if(fin) { break; }
+				/* a wave that is not a helper leaves as soon as nothing is on offer: staying for what the reads still being walked MIGHT publish (the first form: while
+				 * rq_ctl[4] != 0) held thousands of wave slots through the tail of every launch -- the waves of the other lanes' launches wait for exactly those slots; on the
+				 * ONT-like set, where a launch lasts as long as its longest read, 2.1 against 2.8 G bases/s.  a.rq_stay (MM_K3_STAY): the first form */
+				if(!rq_helper) { if(a.rq_stay ? wide == 0u : (ji == 0xffffffffu || ++idle > 16u)) { break; } }
 				__builtin_amdgcn_s_sleep(64);
 			}
 		}
@@ -2384,7 +2394,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		uint32_t cj_base = 0, cj_n = 0;
 		if(rq_on && a.round_jobs && (round != a.round || (a.dyn0_min != 0u && spec_n == 0u))) {
 			const uint32_t np = (uint32_t)rdfirst((int)st->n_pass);
-			if(np >= (round != a.round ? 2u : a.dyn0_min) && np <= n_root) {
+			if(np >= (round != a.round ? max(2u, a.round_jobs) : a.dyn0_min) && np <= n_root) {
 				uint32_t base = 0, ok = 0;
 				if(lane == 0) { base = atomicAdd(&a.rq_ctl[0], np); ok = (base + np <= a.rq_cap) ? 1u : 0u; }          /* (a full queue: the slots stay empty, the waves step over them) */
 				base = (uint32_t)rdfirst((int)base); ok = (uint32_t)rdfirst((int)ok);

@@ -1204,6 +1204,7 @@ struct mm_align_s {
 	/* pools */
 	DBuf<uint32_t> q_pk, q_nm; DBuf<ReadIn> d_in; DBuf<ReadState> d_st; DBuf<uint32_t> d_work;
 	DBuf<MinRec> min_pool; DBuf<Seed> seed_pool; DBuf<Resc> resc_pool; DBuf<Root> root_pool;
+	bool rerun_heavy = false;              /* the re-run at hand has a read that walked many chains the last time (batch_verify_carry -> run_rounds) */
 	uint64_t min_over_base = 0, min_over_n = 0;          /* the overflow region of the sketch kernel inside min_pool (ensure_pools) */
 	DBuf<uint32_t> rs_scratch; DBuf<uint8_t> slabs; DBuf<KhSlot> kh_pool; DBuf<uint64_t> next_pool;
 	DBuf<uint64_t> bin_pool; DBuf<AlnRec> aln_pool; DBuf<gaba::Segment> seg_pool; DBuf<uint32_t> path_pool;
@@ -1540,8 +1541,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 					std::vector<uint8_t> is_front(n_reads, 0); for(uint32_t x : front) is_front[x] = 1;
 					std::vector<uint32_t> rest; rest.reserve(by_len.size());
 					for(uint32_t x : by_len) if(!is_front[x]) rest.push_back(x);
-					by_len = front; by_len.insert(by_len.end(), rest.begin(), rest.end());
-					if(n_heavy) n_heavy += (uint32_t)front.size();          /* (the enumeration of chain jobs skips them: no passing chain) */
+					/* behind the heavy reads, which keep the front of the list and with it the top issue priority (the first 64th, mm_extend_kernel): with the sources in front of
+					 * them the headline set lost 3 % -- every read in the first few thousand entries is taken by a wave the moment the launch starts, which is all the waiting needs */
+					by_len.assign(rest.begin(), rest.begin() + std::min<size_t>(n_heavy, rest.size())); by_len.insert(by_len.end(), front.begin(), front.end()); by_len.insert(by_len.end(), rest.begin() + std::min<size_t>(n_heavy, rest.size()), rest.end());
 				}
 			}
 			if(deferred) {          /* a launch of deferred reads: all of them are candidates for chain jobs, the ones with the most to walk first */
@@ -1598,6 +1600,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.rjobs = nullptr; k3.rmemo = nullptr; k3.rstate = nullptr; k3.rq_cap = 0; k3.rq_ctl = nullptr;
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
 		k3.rq_early = getenv("MM_K3_LATE_HELPERS") ? 0u : 1u;
+		k3.rq_stay = getenv("MM_K3_STAY") ? 1u : 0u;
 		k3.rq_between = getenv("MM_K3_JOBS_BETWEEN_READS") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_JOBS_BETWEEN_READS"))) : 1u;
 		k3.full_n = a->n_waves / 8;
 		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 is a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) when helpers were the waves that had run out of reads -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for; as helpers from the start, one in 8 / 16 / 32 on the ONT-like set: 2.37 / 2.34 / 2.46 against 2.7 - 2.9 */
@@ -1606,9 +1609,11 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * one alignment, tools/read_cost.py) */
 		/* (a launch of a few reads -- the re-runs of the carried-value check -- has them too, with a helper in every workgroup: one read inside a repeat family alone on a launch
 		 * walked its hundreds of chains on one wave for a second while the lanes behind it waited for their turn at the carried value) */
-		const bool small_launch = work.size() < 256;
-		if(small_launch) { k3.rq_helper_mask = 3u; }
-		if(round == 0 && k3.ring && k3.cls && inkernel && !getenv("MM_K3_NO_RETRY_JOBS")) {
+		/* (... when one of its reads walked many chains the last time: a launch of 256 workgroups ends when the last of them has had its turn at a wave slot, and the lanes
+		 * behind a re-run wait for it -- the ordinary re-run of two or three reads stays a launch of one workgroup) */
+		const bool small_launch = work.size() < 256, small_heavy = small_launch && (a->rerun_heavy || !rlen_fixed);
+		if(small_heavy) { k3.rq_helper_mask = 3u; }
+		if(round == 0 && k3.ring && k3.cls && inkernel && (!small_launch || small_heavy) && !getenv("MM_K3_NO_RETRY_JOBS")) {
 			const uint32_t rq_cap = 1u << 17;
 			if(a->rq_jobs.ensure(rq_cap) && a->rq_memo.ensure(rq_cap) && a->rq_state.ensure(rq_cap + 16)) {
 				CK(hipMemsetAsync(a->rq_state.p, 0, ((size_t)rq_cap + 16) * 4, a->stream));
@@ -1616,7 +1621,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0; k3.stage_top = nullptr; k3.round_jobs = 0;
-		k3.dyn0_min = getenv("MM_K3_DYN_ROUND0") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_DYN_ROUND0"))) : (small_launch ? 2u : 0u);          /* (a small launch has no chain jobs from before the launch: its reads publish their chains themselves) */
+		k3.dyn0_min = getenv("MM_K3_DYN_ROUND0") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_DYN_ROUND0"))) : (small_heavy ? 2u : 0u);          /* (a small launch has no chain jobs from before the launch: its reads publish their chains themselves) */
 		/* the staging area of the traced jobs (path words, segments) and its cursors: for the chain jobs enumerated before the launch and for the chains a read publishes from
 		 * inside it (K3Args.rjobs, JOB_FULL) alike */
 		const uint64_t stage_job_cap = getenv("MM_K3_JOB_CAP") ? (uint64_t)std::max(1, atoi(getenv("MM_K3_JOB_CAP"))) : (1u << 16), stage_path_cap = 48ull << 20, stage_seg_cap = (stage_job_cap + k3.rq_cap) * 8;          /* (MM_K3_JOB_CAP: test hook, a launch with more chain jobs than slots) */
@@ -1626,7 +1631,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
 			k3.spath = a->spec_path.p; k3.spath_cap = stage_path_cap; k3.sseg = a->spec_seg.p; k3.sseg_cap = stage_seg_cap; k3.job_top = a->spec_top.p;
 			k3.stage_top = a->spec_top.p + 2;
-			k3.round_jobs = (k3.rjobs && !getenv("MM_K3_NO_ROUND_JOBS")) ? 1u : 0u;          /* (MM_K3_NO_ROUND_JOBS: the chains of the later rounds walked by the read's own wave, as before round 5) */
+			/* (from four chains on: the ordinary rescued read has one to three, and publishing those cost the headline set 3 % for nothing; MM_K3_ROUND_JOBS_MIN: another number;
+			 * MM_K3_NO_ROUND_JOBS: the chains of the later rounds walked by the read's own wave, as before round 5) */
+			k3.round_jobs = (k3.rjobs && !getenv("MM_K3_NO_ROUND_JOBS")) ? (getenv("MM_K3_ROUND_JOBS_MIN") ? (uint32_t)std::max(2, atoi(getenv("MM_K3_ROUND_JOBS_MIN"))) : 4u) : 0u;
 		}
 		/* chain jobs: the first trials of the chains of the heaviest reads (the front of the work list), taken by all waves of the launch before the reads (K3Args.jobs) */
 		/* (a wave that has claimed a job takes the workspace for it without waiting, K3_TRY_SLAB, and hands the job back undone when none of its class is free: with fewer
@@ -1642,7 +1649,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
-		if(small_launch && k3.rjobs) { waves = std::min<uint32_t>(a->k3_waves, std::max<uint32_t>(waves, 1024u)); }          /* (waves for the jobs of a small launch: 256 workgroups, the first wave of each a helper) */
+		if(small_heavy && k3.rjobs) { waves = std::min<uint32_t>(a->k3_waves, std::max<uint32_t>(waves, 1024u)); }          /* (waves for the jobs of a small launch: 256 workgroups, the first wave of each a helper) */
 		if(deferred && k3.jobs) { uint64_t nj = 0; for(uint32_t wi : work) nj += hst[wi].n_pass; waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((std::max<uint64_t>(work.size(), std::min<uint64_t>(nj, 4096)) + 3) & ~3ull)); }          /* (waves for the jobs, not only for the reads) */
 		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
 		/* several batches in flight (lanes): 5 persistent waves per SIMD keep the integer VALU as busy as 8 do (a wave issues at most every 4th cycle, about two
@@ -2464,6 +2471,8 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 		}
 		if(redo.empty() || overflow) break;
 		a->st.reruns += redo.size();
+		a->rerun_heavy = false;
+		for(size_t j = 0; j < redo.size(); j++) { if(hst[redo[j]].k3_chains >= 8u || hst[redo[j]].presc != 0u) a->rerun_heavy = true; }          /* (a read that walked many chains, or went on to the later thresholds: its re-run gets helpers, run_rounds) */
 		for(size_t j = 0; j < redo.size(); j++) {
 			uint32_t i = redo[j]; uint64_t mo = hst[i].min_off; uint32_t mc = hst[i].min_cap;
 			memset(&hst[i], 0, sizeof(ReadState)); hst[i].min_off = mo; hst[i].min_cap = mc;
