@@ -161,6 +161,25 @@ def test_index_replicas_are_copied_device_to_device(fanout):
         assert len(made) == 3 and not any('FAILED' in l for l in made), made          # (test hook: a replica per context behind the first)
         if fanout == '1': assert any('(a replica)' in l for l in made), made          # with one copy per holder at a time the third is served by the first replica
 
+def test_output_to_a_regular_file_is_written_at_its_offsets():
+    """`minialign ... > out.sam`: where the standard output is a regular file the batches' text is written by several drain threads, each batch at the offset the sizes of the
+    batches in front of it give (stream_map, pos_fd) -- the file must be what a pipe receives from the one ordered writer; many small batches over two device contexts, a header in
+    front of the records (the stream's position when mapping starts), and a file opened for appending (which takes the ordered writer: pwrite ignores offsets there)"""
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa'); out = os.path.join(d, 'out.sam'); app = os.path.join(d, 'app.sam')
+        M.gensim('genome', 7421, 3000000, 12, 0.2, out=ref); M.gensim('reads', 7422, ref, 3.0, 'pacbio', 'fa', 4000, 1500, out=rd)
+        env = dict(os.environ, MM_DEVICE_CONTEXTS='2', MM_SLAB_GB='8', MM_LANES='2', MM_BATCH_BASES='300000')
+        pipe = subprocess.run([CLI, '-xpacbio', ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+        assert pipe.returncode == 0, pipe.stderr.decode()[-2000:]
+        with open(out, 'wb') as f: r = subprocess.run([CLI, '-xpacbio', ref, rd], stdout=f, stderr=subprocess.PIPE, env=dict(env, MM_VERBOSE='1'), timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert b'at its place in the file' in r.stderr          # the drain threads ran
+        assert _strip_pg(open(out, 'rb').read()) == _strip_pg(pipe.stdout)
+        with open(app, 'wb') as f: f.write(b'@CO\tin front\n')
+        with open(app, 'ab') as f: r = subprocess.run([CLI, '-xpacbio', ref, rd], stdout=f, stderr=subprocess.PIPE, env=dict(env, MM_VERBOSE='1'), timeout=600)
+        assert r.returncode == 0 and b'at its place in the file' not in r.stderr
+        assert _strip_pg(open(app, 'rb').read()) == b'@CO\tin front\n' + _strip_pg(pipe.stdout)
+
 @pytest.fixture(scope='module')
 def long_tailed():
     with tempfile.TemporaryDirectory() as d:
