@@ -2307,12 +2307,13 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			/* the next occurrence threshold for this read, here and now */
 			/* ONE set of tables per workgroup, taken in turn by its four waves: the rounds are rare (a few per cent of the reads), and 24 KB of LDS per workgroup held
 			 * six workgroups' worth of a CU's LDS for the whole launch -- the sort and chain kernels of the other lanes, which live on LDS, ran 2.3 x slower beside it */
+			const unsigned long long cy_resc0 = MM_TICK();
 			if(lane == 0) { while(atomicCAS((unsigned int *)&k3_tab[K3_TAB_WORDS], 0u, 1u) != 0u) { __builtin_amdgcn_s_sleep(32); } }
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			const uint32_t e2 = k3_rescue_round(st, round, a.seed_pool + rdfirst64(st->seed_off), a.root_pool + rdfirst64(st->root_off), a.resc_pool + rdfirst64(st->resc_off),
 				a.idx, a.twlen, a.mcoef, a.min_score, (LU32 *)&k3_tab[0]);
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-			if(lane == 0) { atomicExch((unsigned int *)&k3_tab[K3_TAB_WORDS], 0u); }
+			if(lane == 0) { atomicExch((unsigned int *)&k3_tab[K3_TAB_WORDS], 0u); st->k3_ticks += (uint32_t)(MM_TICK() - cy_resc0); st->k3_wait_ticks += (uint32_t)(MM_TICK() - cy_resc0); }          /* (profiling build: the round's sort + chain counts as time of the read; reported with the workspace wait) */
 			if(e2) { if(lane == 0) { st->err |= e2; } break; }
 		}
 		const unsigned long long cy_read0 = MM_TICK(); const uint32_t vec_read0 = x.n_vec; const unsigned long long cyf_read0 = cy_fill, cyt_read0 = cy_trace;

@@ -1601,6 +1601,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
 		k3.rq_early = getenv("MM_K3_LATE_HELPERS") ? 0u : 1u;
 		k3.rq_stay = getenv("MM_K3_STAY") ? 1u : 0u;
+		/* (1: chain jobs of the workspace class held.  Retry jobs as well (3) cost the ONT-like set 7 % -- the retry trial of a 100 kb read in front of a wave's own next read -- and
+		 * give the hard-repeat set nothing: there the long pole of a launch is the SECOND trial of each of a read's 150 - 270 chains, which its owner runs itself, one after the
+		 * other, 0.5 - 1 M DP vectors on one wave -- profiles/round5_hard_read_cost.txt) */
 		k3.rq_between = getenv("MM_K3_JOBS_BETWEEN_READS") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_JOBS_BETWEEN_READS"))) : 1u;
 		k3.full_n = a->n_waves / 8;
 		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 is a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) when helpers were the waves that had run out of reads -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for; as helpers from the start, one in 8 / 16 / 32 on the ONT-like set: 2.37 / 2.34 / 2.46 against 2.7 - 2.9 */
