@@ -27,12 +27,11 @@ SIZES = dict(dm6_genome=(0x5eed0001, 143700000, 1870, 0.05), dm6_reads=(0x5eed00
              ont_reads=(0x5eed0003, 1.0, 'ont'), ont_min_bases=2.5e9, ont_min_reads=250000,          # the whole 3.1 Gb set
              hard_genome=(0x5eed0011, 400000000, 12, 0.45), hard_reads=(0x5eed0012, 1.0, 'pacbio'), hard_min_reads=19000, index_threads=32)
 # Several device contexts (or ranks) on the ONE GPU of a test box at FULL size: off unless asked for (MM_TEST_CONTEXTS_AT_SCALE=1).  Three gpurun boxes were lost in
-# round 4 while this file ran, 195 - 225 s into it.  What the three runs had in common was the HOST side of the human-size fixture as it was then -- sixteen read generators
-# at once, part files kept beside the joined file, and one 18 GB reference process per part, 32 of them for the two sets, beside the index builds (see _generate and
-# _reference_by_parts; all bounded since) -- and two of them also ran 2 / 4 device contexts x 2 lanes on the dm6-size set.  Nothing comes back from a lost box, so the cause
-# is not established; in the last of the three no GPU process was alive at that moment.  The several-context runs at full size have therefore never completed on a box and stay opt-in until
-# they have; on a node each device has ONE context with the whole workspace budget, which is the single-context path the tests below run at full size, and the
-# several-context engine is covered at small size in tests/test_multi_gpu.py (2 / 3 / 4 contexts, pieces of 64 KB .. 1 MB, through the command line and the C-ABI).
+# round 4 while this file ran, 195 - 225 s into it: the fixture of the two human-size sets then started one 18 GB reference process per part for both sets at once, 32 of them,
+# and a gpurun box has a cgroup memory limit of 300 GiB (profiles/round5_box.txt; the fixture is bounded and guarded since, see _reference_by_parts).  With the fixture as it is now
+# these runs completed in round 5 (profiles/round5_contexts_at_scale.log: identical, 203 GB of host memory at the peak); they stay opt-in for their 45 s -- on a node each device
+# has ONE context with the whole workspace budget, which is the single-context path the tests below run at full size, and the several-context engine is covered at small size in
+# tests/test_multi_gpu.py (2 / 3 / 4 contexts, pieces of 64 KB .. 1 MB, through the command line and the C-ABI).
 AT_SCALE_ON_ONE_GPU = os.environ.get('MM_TEST_CONTEXTS_AT_SCALE') is not None
 
 def _samcheck():
