@@ -1253,6 +1253,7 @@ struct mm_align_s {
 	void *pin_stage = nullptr; size_t pin_stage_cap = 0;      /* pinned staging buffer of the lane: the per-read state records and the packed reads cross PCIe through it (one DMA each instead of a train of staged blits) */
 	bool tap_stop = false;                 /* mm_batch_tap: stop behind the sort + chain stage of the first round */
 	unsigned long long *pin_note = nullptr;    /* 64 bytes of pinned host memory the sketch kernel writes the pool cursors to (K1Args.note) */
+	std::vector<uint32_t> np0, wp0;            /* diagnostics (MM_VERBOSE): passing chains and their summed length of every read as the first chaining left them (run_rounds -> batch_run_spec) */
 	std::vector<uint32_t> ran_with;            /* the carried reference length every read of the batch at hand was handed before its extension launch (run_rounds) */
 	uint32_t k2_leaf_shift = 2;            /* leaf area of the first chaining attempt: (n + 1) >> shift; lowered when more than 2 % of a batch had to be retried */
 };
@@ -1491,13 +1492,21 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				static const bool no_deps = getenv("MM_NO_CARRY_DEPS") != NULL;
 				const bool deps = !no_deps && getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL && getenv("MM_K3_DEFER_RESCUE") == NULL && getenv("MM_K3_ONE_READ_PER_WAVE") == NULL;
 				std::vector<uint8_t> in_work(n_reads, 0); for(uint32_t wi : work) in_work[wi] = 1;
+				const double weak_unit = (getenv("MM_CARRY_WEAK") ? std::max(0, atoi(getenv("MM_CARRY_WEAK"))) : 128) * 2.0 * (double)a->o.min_score / a->mcoef;
 				uint32_t cur = a->rlen_carry, src = gaba::NIL;          /* src: the source read that decides the value at hand */
 				a->ran_with.resize(n_reads);
+				if(getenv("MM_VERBOSE")) { a->np0.resize(n_reads); a->wp0.resize(n_reads); for(uint32_t i = 0; i < n_reads; i++) { a->np0[i] = hst[i].n_pass; a->wp0[i] = hst[i].w_pass; } }
 				for(uint32_t i = 0; i < n_reads; i++) {
 					hst[i].rlen = cur; a->ran_with[i] = cur;          /* (what the read runs with, kept as it is handed out: see batch_run_spec) */
 					hst[i].dep = src; hst[i].flags = 0; hst[i].carry_ready = 0; hst[i].rlen_in = cur;
 					if(!in_work[i]) continue;
-					if(hst[i].pred_rid != gaba::NIL) { cur = a->mi->seq[hst[i].pred_rid].blen(); src = gaba::NIL; }
+					if(hst[i].pred_rid != gaba::NIL) {
+						cur = a->mi->seq[hst[i].pred_rid].blen(); src = gaba::NIL;
+						/* ... and a read whose passing chains are weak -- together less than 128 times the length a chain needs to be tried: 110 of the 14 400 reads of a headline
+						 * batch, and 13 of the 16 whose trials all fail and that go on to the next threshold, where the rescued minimizers change what they leave -- is a source too:
+						 * the reads behind it wait for what it really leaves (the prediction stays the guess for the reads further on).  MM_CARRY_WEAK=n: another factor, 0: none */
+						if(deps && weak_unit > 0.0 && hst[i].n_resc > 0 && !hst[i].err && (double)hst[i].w_pass < weak_unit) { hst[i].flags = RS_CARRY_SRC; src = i; }
+					}
 					else if(deps && hst[i].n_resc > 0 && !hst[i].err) { hst[i].flags = RS_CARRY_SRC; src = i; }
 				}
 			}
@@ -2501,6 +2510,14 @@ int batch_run_spec(mm_align_t *a, Batch &b)
 	 * while the reads behind it ran with the prediction of its first one -- derived afterwards, `used` then said what the reads should have run with, the check against
 	 * the true chain of values found nothing to re-run, and a read whose `apos >= rlen` decision the difference flips kept the records of the wrong decision (one read
 	 * of the 266 589 of the ONT-like hg38-size set, found by the whole-set comparison of round 4; rounds 1-3 compared the first 20 000) */
+	if(getenv("MM_VERBOSE") && a->np0.size() == n_reads) {
+		/* which reads with a chain worth a trial at the first threshold ended that round without a result (and went on to the next: what they leave is then not what was predicted):
+		 * by the summed length of their passing chains in units of the length a chain needs to be tried (2 x min_score / mcoef) */
+		const double unit = 2.0 * a->o.min_score / a->mcoef; uint32_t h_all[8] = { 0 }, h_fail[8] = { 0 }, n_all = 0, n_fail = 0;
+		for(uint32_t i = 0; i < n_reads; i++) { if(a->np0[i] == 0) continue; const int q = (int)std::min(7.0, a->wp0[i] / unit / 1.0 - 1.0 < 0 ? 0.0 : std::floor(std::log2(std::max(1.0, a->wp0[i] / unit)) )); const bool fail = hst[i].presc != 0 || (hst[i].n_res == 0 && hst[i].n_resc == 0); h_all[q]++; n_all++; if(hst[i].presc != 0) { h_fail[q]++; n_fail++; } (void)fail; }
+		fprintf(stderr, "[minialign_amd]   reads with a passing chain: %u, of which on to the later thresholds: %u; by log2 of (summed passing length / trial length): all", n_all, n_fail);
+		for(int q = 0; q < 8; q++) fprintf(stderr, " %u", h_all[q]); fprintf(stderr, "; on to the later thresholds"); for(int q = 0; q < 8; q++) fprintf(stderr, " %u", h_fail[q]); fprintf(stderr, "\n");
+	}
 	if(a->ran_with.size() == n_reads) { b.used = a->ran_with; for(uint32_t i = 0; i < n_reads; i++) { if(hst[i].dep != gaba::NIL) b.used[i] = hst[i].rlen_in; } }          /* (a read behind a source ran with what the source left: the kernel says what that was) */
 	else { b.used.assign(n_reads, 0); uint32_t cur = a->rlen_carry; for(uint32_t i = 0; i < n_reads; i++) { b.used[i] = cur; if(hst[i].pred_rid != gaba::NIL) cur = a->mi->seq[hst[i].pred_rid].blen(); } }
 	{
