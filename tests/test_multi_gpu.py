@@ -121,6 +121,16 @@ def test_bench_line_with_two_ranks_on_one_gpu():
     assert d['sam_identical'] is True, d.get('sam_check')
     assert d['roofline']['achieved'] > 0 and 'cpu_baseline' not in d
 
+@pytest.fixture(scope='module')
+def repeat_rich():
+    """750 reads, many with dozens of chains (the chain jobs of the default run have work), on a repeat-rich reference; the records the oracle gives (made once for all the schedules)"""
+    with tempfile.TemporaryDirectory() as d:
+        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
+        M.gensim('genome', 7401, 1500000, 6, 0.45, out=ref); M.gensim('reads', 7402, ref, 3.0, 'pacbio', 'fa', 6000, 2500, out=rd)
+        opts = ['-xpacbio', '-f0.2,0.05,0.002']
+        want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
+        yield ref, rd, opts, want
+
 @pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1'),
                                  dict(MM_K2_LDS_CHAIN='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_HOST_READER='1'), dict(MM_HOST_INDEX='1'), dict(MM_K3_JOB_CAP='7'), dict(MM_DEVICE_CONTEXTS='2', MM_SLAB_GB='14'),
                                  dict(MM_K3_NO_ROUND_JOBS='1'), dict(MM_K3_DYN_ROUND0='2'), dict(MM_K3_DYN_ROUND0='2', MM_K3_NO_JOBS='1'), dict(MM_K3_HELPERS='4'),
@@ -129,19 +139,16 @@ def test_bench_line_with_two_ranks_on_one_gpu():
                               'chain-sweep-in-lds', 'no-chain-jobs', 'host-reader', 'host-index', 'more-chain-jobs-than-slots', 'two-device-contexts',
                               'later-round-chains-on-the-own-wave', 'first-round-chains-published-by-the-read', 'first-round-chains-published-only-by-the-read', 'one-wave-in-four-helps',
                               'rescue-bound-reads-first', 'rescue-rounds-deferred-to-launches-of-their-own', 'cu-reserve', 'upload-behind-one-wait', 'carried-value-by-prediction-only', 'no-minimizer-overflow-region', 'round-jobs-from-two-chains-and-retry-jobs-between-reads', 'waves-stay-and-change-class', 'long-way-re-runs', 'no-weak-sources', 'every-read-with-rescue-minimizers-a-source'])
-def test_alternative_schedules_give_the_same_bytes(env):
+def test_alternative_schedules_give_the_same_bytes(env, repeat_rich):
     """the forms kept behind environment switches -- the occurrence-threshold rounds as separate launches through the host (the default runs them inside the
     extension kernel, k3_rescue_round), one read per wave, per-lane DP
-    workspaces, the one-kernel sort + chain, and the fallback for a batch the device pools cannot hold (its reads in halves, down to fewer than 8) -- on a repeat-rich set with a high seed threshold, where many reads need the rescue rounds"""
-    with tempfile.TemporaryDirectory() as d:
-        ref = os.path.join(d, 'ref.fa'); rd = os.path.join(d, 'rd.fa')
-        M.gensim('genome', 7401, 1500000, 6, 0.45, out=ref); M.gensim('reads', 7402, ref, 3.0, 'pacbio', 'fa', 6000, 2500, out=rd)          # 750 reads, many with dozens of chains: the chain jobs of the default run have work
-        opts = ['-xpacbio', '-f0.2,0.05,0.002']
-        want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
-        r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **dict(dict(MM_SLAB_GB='32', MM_BATCH_BASES='3000000'), **env)), timeout=600)          # (32 GB: a workspace for every resident wave at this read length, so that the chain and retry jobs of the default schedule run)
-        assert r.returncode == 0, r.stderr.decode()[-2000:]
-        assert _strip_pg(r.stdout) == want
-        assert b're-run' in r.stderr
+    workspaces, the one-kernel sort + chain, the fallback for a batch the device pools cannot hold (its reads in halves, down to fewer than 8), and the switches of rounds 4
+    and 5 (jobs, sources of the carried value, re-runs) -- on a repeat-rich set with a high seed threshold, where many reads need the rescue rounds"""
+    ref, rd, opts, want = repeat_rich
+    r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **dict(dict(MM_SLAB_GB='32', MM_BATCH_BASES='3000000'), **env)), timeout=600)          # (32 GB: a workspace for every resident wave at this read length, so that the chain and retry jobs of the default schedule run)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert _strip_pg(r.stdout) == want
+    assert b're-run' in r.stderr
 
 @pytest.mark.parametrize('fanout', ['1', '4'])
 def test_index_replicas_are_copied_device_to_device(fanout):
