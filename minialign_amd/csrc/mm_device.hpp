@@ -1022,6 +1022,26 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_sort_kernel(K2sA
 	if(lane == 0) { atomicAdd(&a.prof[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
 }
 
+/* K2s, lane per read (experiment, MM_K2_LANE_SORT; round 5): the literal radix_sort_128 of the rounds through the host, one LANE per read on the seed array in HBM, every read
+ * of the batch in flight in one launch without LDS -- the form that took the chain sweep from 992 to 153 cycles per seed (K2w).  Reads of more than K2S_MAX_N seeds stay with K2a. */
+struct K2lArgs { ReadState *st; const uint32_t *work; uint32_t n_work; Seed *seed_pool; uint32_t *scratch; uint32_t stride; unsigned long long *prof; };
+__global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_sort_lane_kernel(K2lArgs a)
+{
+	__builtin_amdgcn_s_setprio(2);
+	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if(t < a.n_work) {
+		ReadState *st = &a.st[a.work[t]];
+		const uint32_t n = st->seed_n0, n_all = n + 1;
+		if(n != 0 && n_all <= K2S_MAX_N) {
+			Seed *gs = a.seed_pool + st->seed_off;
+			gs[n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu };          /* sentinel, minialign.c:3531 */
+			if(!radix_sort_128((U128 *)gs, n_all, a.scratch + (uint64_t)t * a.stride, a.stride)) { st->err |= ERR_STACK; }
+		}
+	}
+	if(lane_id() == 0) { atomicAdd(&a.prof[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
+}
+
 /* -----------------------------------------------------------------------------------------------------
  * K2p + K2c: mm_chain_seeds (minialign.c:3547-3625) over the sorted seed array, in two launches.
  *

@@ -1391,7 +1391,17 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3((uint32_t)work.size()), dim3(64), 1536 * 4, a->stream, ka);
 				CK(hipGetLastError());
 			}
-			if(presort) {
+			if(presort && getenv("MM_K2_LANE_SORT")) {
+				/* experiment: the sort with one lane per read in HBM (mm_sort_lane_kernel) instead of the size classes in LDS */
+				if(!a->rs_scratch.ensure((uint64_t)work.size() * a->rs_stride)) return false;
+				K2lArgs kl; kl.st = a->d_st.p; kl.work = a->d_work.p; kl.n_work = (uint32_t)work.size(); kl.seed_pool = a->seed_pool.p; kl.scratch = a->rs_scratch.p; kl.stride = a->rs_stride; kl.prof = tops + 28;
+				CK(hipStreamWaitEvent(a->k2s[0], a->ev0, 0));
+				hipLaunchKernelGGL(mm_sort_lane_kernel, dim3(((uint32_t)work.size() + 63) / 64), dim3(64), 0, a->k2s[0], kl);
+				CK(hipGetLastError());
+				CK(hipEventRecord(a->k2e[12], a->k2s[0]));
+				for(int j = 1; j < MM_SIDE; j++) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[12], 0)); }
+			}
+			else if(presort) {
 				static const uint32_t s_kb[] = { 10, 14, 20, 32, 64, 104 };          /* k2s_bytes(K2S_MAX_N) <= 104 KB */
 				const int n_s = (int)(sizeof(s_kb) / sizeof(s_kb[0]));
 				K2sArgs ks; ks.st = a->d_st.p; ks.work = a->d_work.p; ks.n_work = (uint32_t)work.size(); ks.seed_pool = a->seed_pool.p; ks.prof = tops + 28;
