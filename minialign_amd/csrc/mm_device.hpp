@@ -832,6 +832,8 @@ struct K2sArgs {
 	uint32_t lds_bytes, n_lo, n_hi;   /* this launch takes the reads with n_lo < k2s_bytes(n + 1) <= n_hi */
 	uint32_t *counter;
 	unsigned long long *prof;         /* [0] wave cycles */
+	uint32_t start_shift;             /* the first radix level at which two seeds of a read can differ (56: none skipped): with fewer than 2^8 (2^16) reference sequences the levels of bits 56, 48, 40 (56, 48)
+	                                   * see one digit on every seed -- a counting pass, a scan and a walk over the whole array each, which move nothing and hand the same range on */
 };
 __device__ __forceinline__ uint64_t k2s_key(const Seed *gs, uint32_t src, uint32_t n)
 {
@@ -896,7 +898,9 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_sort_kernel(K2sA
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			k2s_small_buckets(e, bb, be, 0, n_all, gs, n, lane);
 		} else {
-			if(lane == 0) { stk[0] = 0u | (n_all << 16); stsh[0] = 56; }
+			/* (a level whose digit is the same on every seed leaves the range as it is -- the sentinel, the one element with another digit, already stands behind the others --
+			 * and passes it on to the next level because it holds more than 64 elements: starting at start_shift on the range without the sentinel is the same walk) */
+			if(lane == 0) { if(a.start_shift < 56u && n > 64u) { stk[0] = 0u | (n << 16); stsh[0] = a.start_shift; } else { stk[0] = 0u | (n_all << 16); stsh[0] = 56; } }
 			sp = 1;
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		}

@@ -1405,6 +1405,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				static const uint32_t s_kb[] = { 10, 14, 20, 32, 64, 104 };          /* k2s_bytes(K2S_MAX_N) <= 104 KB */
 				const int n_s = (int)(sizeof(s_kb) / sizeof(s_kb[0]));
 				K2sArgs ks; ks.st = a->d_st.p; ks.work = a->d_work.p; ks.n_work = (uint32_t)work.size(); ks.seed_pool = a->seed_pool.p; ks.prof = tops + 28;
+				{ const size_t ns = a->mi->seq.size(); ks.start_shift = getenv("MM_K2_ALL_LEVELS") ? 56u : (ns <= 1 ? 24u : (ns <= 256 ? 32u : (ns <= 65536 ? 40u : 56u))); }
 				const uint32_t n_cu = a->n_waves / (4 * MM_K3_WAVES_PER_SIMD);
 				for(int si = 0; si < n_s; si++) {
 					ks.lds_bytes = s_kb[si] * 1024u; ks.n_lo = si ? s_kb[si - 1] * 1024u : 0u; ks.n_hi = ks.lds_bytes; ks.counter = a->d_k2cnt.p + 16 + si;
