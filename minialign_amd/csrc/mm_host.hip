@@ -2362,9 +2362,9 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		if(!a->d_tinfo.ensure(spare(b.n)) || !a->d_codes.ensure(spare(arena + 64)) || !a->d_tn.ensure(spare(b.n))) return false;
 		std::vector<TextRead> tr(b.n);
 		CK(hipMemsetAsync(a->d_codes.p, 0, arena + 64, a->stream));
-		if(!b.dch.empty() && !getenv("MM_UPLOAD_FIVE_SYNCS")) {
-			/* (round 4's experiment, the default since round 5: three pairs of headline runs, 4.22 / 4.42 / 4.29 against 4.06 / 4.24 / 4.21 G bases/s; MM_UPLOAD_FIVE_SYNCS: the
-			 * earlier form below) the whole upload of a batch behind ONE wait.  Every wait of a lane for its stream is a wait for a wave slot beside
+		if(!b.dch.empty() && getenv("MM_UPLOAD_ONE_SYNC")) {
+			/* experiment (off by default.  Round 5: +3 % in three pairs of headline runs, 4.22 / 4.42 / 4.29 against 4.06 / 4.24 / 4.21 G bases/s, and the whole suite passes with it --
+			 * but the hard-repeat human-size workload did not finish in 900 s with it as the default, not understood, so it stays a switch): the whole upload of a batch behind ONE wait.  Every wait of a lane for its stream is a wait for a wave slot beside
 			 * the persistent extension waves of the other lanes (10 - 40 ms each under load), and this function has five: the extents, the packed-base count, the
 			 * read table, the states, the cursors.  Here everything the device needs goes through one pinned staging buffer in three copies, the kernels and the memsets follow on
 			 * the stream, the base counts come back into the same buffer, and the host waits once */

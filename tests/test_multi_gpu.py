@@ -134,11 +134,11 @@ def repeat_rich():
 @pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1'),
                                  dict(MM_K2_LDS_CHAIN='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_HOST_READER='1'), dict(MM_HOST_INDEX='1'), dict(MM_K3_JOB_CAP='7'), dict(MM_DEVICE_CONTEXTS='2', MM_SLAB_GB='14'),
                                  dict(MM_K3_NO_ROUND_JOBS='1'), dict(MM_K3_DYN_ROUND0='2'), dict(MM_K3_DYN_ROUND0='2', MM_K3_NO_JOBS='1'), dict(MM_K3_HELPERS='4'),
-                                 dict(MM_K3_RESCUE_FIRST='1'), dict(MM_K3_DEFER_RESCUE='1'), dict(MM_K3_CU_RESERVE='16'), dict(MM_UPLOAD_FIVE_SYNCS='1'), dict(MM_NO_CARRY_DEPS='1'), dict(MM_NO_MIN_OVERFLOW='1'), dict(MM_K3_ROUND_JOBS_MIN='2', MM_K3_JOBS_BETWEEN_READS='3'), dict(MM_K3_STAY='1', MM_K3_JOBS_BETWEEN_READS='2'), dict(MM_SLOW_RERUN='1'), dict(MM_CARRY_WEAK='0'), dict(MM_CARRY_WEAK='1000000'), dict(MM_K2_LANE_SORT='1'), dict(MM_K2_ALL_LEVELS='1')],
+                                 dict(MM_K3_RESCUE_FIRST='1'), dict(MM_K3_DEFER_RESCUE='1'), dict(MM_K3_CU_RESERVE='16'), dict(MM_UPLOAD_ONE_SYNC='1'), dict(MM_NO_CARRY_DEPS='1'), dict(MM_NO_MIN_OVERFLOW='1'), dict(MM_K3_ROUND_JOBS_MIN='2', MM_K3_JOBS_BETWEEN_READS='3'), dict(MM_K3_STAY='1', MM_K3_JOBS_BETWEEN_READS='2'), dict(MM_SLOW_RERUN='1'), dict(MM_CARRY_WEAK='0'), dict(MM_CARRY_WEAK='1000000'), dict(MM_K2_LANE_SORT='1'), dict(MM_K2_ALL_LEVELS='1')],
                          ids=['rounds-through-the-host', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain', 'batch-split-on-pool-exhaustion',
                               'chain-sweep-in-lds', 'no-chain-jobs', 'host-reader', 'host-index', 'more-chain-jobs-than-slots', 'two-device-contexts',
                               'later-round-chains-on-the-own-wave', 'first-round-chains-published-by-the-read', 'first-round-chains-published-only-by-the-read', 'one-wave-in-four-helps',
-                              'rescue-bound-reads-first', 'rescue-rounds-deferred-to-launches-of-their-own', 'cu-reserve', 'upload-behind-five-waits', 'carried-value-by-prediction-only', 'no-minimizer-overflow-region', 'round-jobs-from-two-chains-and-retry-jobs-between-reads', 'waves-stay-and-change-class', 'long-way-re-runs', 'no-weak-sources', 'every-read-with-rescue-minimizers-a-source', 'sort-with-a-lane-per-read', 'sort-from-the-top-level'])
+                              'rescue-bound-reads-first', 'rescue-rounds-deferred-to-launches-of-their-own', 'cu-reserve', 'upload-behind-one-wait', 'carried-value-by-prediction-only', 'no-minimizer-overflow-region', 'round-jobs-from-two-chains-and-retry-jobs-between-reads', 'waves-stay-and-change-class', 'long-way-re-runs', 'no-weak-sources', 'every-read-with-rescue-minimizers-a-source', 'sort-with-a-lane-per-read', 'sort-from-the-top-level'])
 def test_alternative_schedules_give_the_same_bytes(env, repeat_rich):
     """the forms kept behind environment switches -- the occurrence-threshold rounds as separate launches through the host (the default runs them inside the
     extension kernel, k3_rescue_round), one read per wave, per-lane DP
