@@ -362,12 +362,12 @@ def main():
             L.mm_align_destroy(al); L.mm_idx_destroy(mi); al = mi = None
             try:
                 env = dict(os.environ); env.pop('MM_LIB_OVERRIDE', None)
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', 'hg38hard', '--steps', '1', '--warmup', '1', '--no-cli', '--no-packed', '--lanes', str(args.lanes)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=480)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', 'hg38hard', '--steps', '2', '--warmup', '1', '--no-cli', '--no-packed', '--lanes', str(args.lanes)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=480)
                 h = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
                 out['config']['hard_repeats'] = {'value': h['value'], 'unit': h['unit'], 'ms_per_step': h['ms_per_step'], 'workload': h['config']['workload'], 'dp_vectors_per_base': h['config']['dp_vectors_per_base'],
                                                  'reruns_per_step': h['config']['reruns_per_step (rank 0)'], 'extend_wave_balance': h['config']['extend_wave_balance (mean / max lifetime)'],
                                                  'sam_identical': h.get('sam_identical'), 'sam_check': h.get('sam_check'), 'cpu_baseline': h.get('cpu_baseline'),
-                                                 'note': 'python bench.py --workload hg38hard --steps 1 --warmup 1, run behind the timed steps of the headline workload'}
+                                                 'note': 'python bench.py --workload hg38hard --steps 2 --warmup 1, run behind the timed steps of the headline workload'}
             except Exception as e:
                 tail = getattr(e, 'stderr', None)
                 out['config']['hard_repeats'] = {'error': repr(e)[:300], 'stderr_tail': (tail.decode(errors='replace')[-600:] if tail else None)}
