@@ -1,6 +1,6 @@
 #!/bin/bash
-# The first GPU calls of a round, one stage per gpurun call (a lost box then costs one stage, not the lot).  Round 4 ended with GPU access closed: the final tree has not run
-# the whole suite, four tests and four switches have never run on a device.  Usage, from the repo root on the GPU box:
+# The GPU calls of a round, one stage per gpurun call (a lost box then costs one stage, not the lot).  A gpurun box: 256 cores, 3 TB of memory under a cgroup limit of 300 GiB,
+# 79 GB of scratch space, one MI355X (profiles/round5_box.txt).  Round 5 ran every stage (profiles/round5_*); `unrun` is kept for tests that are written without a device at hand.
 #   tools/round_start.sh box        what the box is: memory and its cgroup limit, scratch space, devices  (seconds; run it FIRST and keep it in front of every other stage:
 #                                   three boxes were lost in round 4 and nothing is known about their limits)
 #   tools/round_start.sh suite      python -m pytest tests -x -q -m gpu   (as the driver runs it)
