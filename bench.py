@@ -52,7 +52,7 @@ class Stats(ctypes.Structure):
                 ('k3_cycles_fill', ctypes.c_uint64), ('k3_cycles_leaf', ctypes.c_uint64), ('k3_cycles_trace', ctypes.c_uint64),
                 ('k3_cycles_total', ctypes.c_uint64), ('k3_cycles_next', ctypes.c_uint64), ('k3_cycles_max', ctypes.c_uint64), ('k3_waves', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
                 ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64), ('pool_grows', ctypes.c_uint64), ('batch_splits', ctypes.c_uint64), ('pool_regrows', ctypes.c_uint64),
-                ('text_bytes', ctypes.c_uint64), ('reader_ms', ctypes.c_double)]
+                ('text_bytes', ctypes.c_uint64), ('reader_ms', ctypes.c_double), ('k3_aborts', ctypes.c_uint64)]
 
 def gensim_exe():
     exe = os.path.join(ROOT, 'tools', 'gensim')
@@ -331,6 +331,7 @@ def main():
                        'sort_chain_wave_time_split': {'sort_cycles_per_seed': st.k2_cycles_sort / max(1, st.seeds), 'chain_cycles_per_seed': st.k2_cycles_chain / max(1, st.seeds), 'seeds_per_read': st.seeds / max(1, st.reads), 'reads_not_in_lds': st.k2_reads_hbm},
                        'dp_vectors_per_base': vec / max(1.0, total_bases * K), 'trace_steps_per_base': trs / max(1.0, total_bases * K), 'reruns_per_step (rank 0)': st.reruns / K,
                        'pool_overflows (batches run again with larger device pools, rank 0, timed steps)': int(st.pool_grows), 'batch_splits (rank 0, timed steps)': int(st.batch_splits), 'sketch_launches_repeated_with_pools_sized_to_the_demand (rank 0, timed steps)': int(st.pool_regrows),
+                       'extension_launches_called_off_by_the_watchdog (rank 0, timed steps)': int(st.k3_aborts),
                        'reader_gb_per_s (text to HBM, per uploader thread while it copies; one uploader per device)': (st.text_bytes * 1e-6 / st.reader_ms) if st.reader_ms > 0 else None,
                        'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
                        'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'text_load_s (outside)': t_load, 'host_parse_and_pack_s (value_from_packed only)': t_pack},
@@ -367,6 +368,8 @@ def main():
                 out['config']['hard_repeats'] = {'value': h['value'], 'unit': h['unit'], 'ms_per_step': h['ms_per_step'], 'workload': h['config']['workload'], 'dp_vectors_per_base': h['config']['dp_vectors_per_base'],
                                                  'reruns_per_step': h['config']['reruns_per_step (rank 0)'], 'extend_wave_balance': h['config']['extend_wave_balance (mean / max lifetime)'],
                                                  'sam_identical': h.get('sam_identical'), 'sam_check': h.get('sam_check'), 'cpu_baseline': h.get('cpu_baseline'),
+                                                 'extension_launches_called_off_by_the_watchdog': h['config'].get('extension_launches_called_off_by_the_watchdog (rank 0, timed steps)'),
+                                                 'watchdog_log': [l for l in r.stderr.decode(errors='replace').splitlines() if 'watchdog' in l][:40] or None,
                                                  'note': 'python bench.py --workload hg38hard --steps 2 --warmup 1, run behind the timed steps of the headline workload'}
             except Exception as e:
                 tail = getattr(e, 'stderr', None)

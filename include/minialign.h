@@ -182,6 +182,7 @@ typedef struct {
 	uint64_t pool_grows, batch_splits;          /* batches run again with larger device pools (a pool or a per-read cap overflowed) / batches mapped in halves because no pool size held them */
 	uint64_t pool_regrows;                      /* batches whose sketch launch was repeated because they asked for more seed / rescue / root entries than the run had seen (pools sized to the demand) */
 	uint64_t text_bytes; double reader_ms;      /* the text readers of the streams so far: bytes brought to HBM, time of the uploader threads (summed over devices) */
+	uint64_t k3_aborts;                         /* times the watchdog called extension launches off because one did not end (the batches then ran again in the safe mode) */
 } mm_stats_t;
 void mm_stats(mm_align_t *a, mm_stats_t *out, int reset);
 

@@ -82,7 +82,7 @@ struct ReadState {
 	uint32_t flags, rlen_in, carry_ready, pad2_;
 };
 enum : uint32_t { RS_CARRY_SRC = 1 };
-enum : uint32_t { ERR_SEED_CAP = 1, ERR_DP_SLAB = 2, ERR_PATH_CAP = 4, ERR_SEG_CAP = 8, ERR_KH_CAP = 16, ERR_BIN_CAP = 32, ERR_ALN_CAP = 64, ERR_NEXT_CAP = 128, ERR_STACK = 256 };
+enum : uint32_t { ERR_SEED_CAP = 1, ERR_DP_SLAB = 2, ERR_PATH_CAP = 4, ERR_SEG_CAP = 8, ERR_KH_CAP = 16, ERR_BIN_CAP = 32, ERR_ALN_CAP = 64, ERR_NEXT_CAP = 128, ERR_STACK = 256, ERR_ABORT = 512 };          /* ERR_ABORT: the host's watchdog called the extension launch off while the read's wave was waiting (mm_extend_kernel, K3Args.wd): the batch runs again */
 
 /* coordinate transforms, minialign.c:3340-3362 */
 __device__ __forceinline__ int32_t OFS(int32_t x) { return (int32_t)0x40000000 - x; }
@@ -1720,7 +1720,37 @@ struct K3Args {
 	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
 	uint32_t defer_thr;                  /* experiment (MM_K3_DEFER_RESCUE, off = 0): a read left without a result by the first threshold that has this many rescue hits waiting does NOT go on inside
 	                                      * the launch; the host runs its later rounds as launches of their own, where the chains it finds there are spread over the launch as chain jobs */
+	/* the watchdog's window into the launch (pinned host memory the device writes to while the kernel runs; NULL: none): wd[0] != 0 = the host has called the launch off --
+	 * every wave that is waiting for something leaves, its read marked ERR_ABORT; wd[K3_WD_HEAD + wave] = where that wave is (K3_WD_* << 28 | detail), written when a read
+	 * is taken and from inside every wait that lasts (k3_wd_tick).  No wait of the kernel is without this way out */
+	uint32_t *wd; uint32_t wd_n;
+	uint32_t test_hang;                  /* test hook (MM_TEST_K3_HANG): the wave that takes entry test_hang - 1 of the work list waits for something that never comes */
 };
+enum : uint32_t { K3_WD_HEAD = 16,
+	K3_WD_TAKE = 1,          /* waiting for a DP workspace of its XCD's ring (detail: class << 24 | ticket) */
+	K3_WD_GIVE = 2,          /* giving a workspace back: the slot of its give ticket still holds the number of the turn before */
+	K3_WD_TRY = 3,           /* the take without waiting: the number of its ticket is on its way into the slot */
+	K3_WD_LDS = 4,           /* the tables of the rescue round (one set per workgroup) */
+	K3_WD_CARRY = 5,         /* the carried value of the read in front (detail: that read) */
+	K3_WD_MEMO = 6,          /* a chain job enumerated before the launch that another wave is running (detail: memo index) */
+	K3_WD_CJOB = 7,          /* a chain job published inside the launch that another wave has claimed (detail: slot) */
+	K3_WD_RJOB = 8,          /* a retry job another wave has claimed (detail: slot) */
+	K3_WD_IDLE = 9,          /* a wave without reads looking for published jobs (detail: reads done) */
+	K3_WD_TEST = 10,         /* the test hook */
+	K3_WD_JOB = 13,          /* running a job (detail: slot) */
+	K3_WD_RAN = 14,          /* back at work after a wait that lasted */
+	K3_WD_READ = 15 };       /* took a read (detail: its place in the work list) */
+/* called by the polling lane from inside a wait loop: every 1 024th turn it says where the wave is and looks whether the host has called the launch off (true) */
+__device__ __forceinline__ bool k3_wd_tick(uint32_t *w, uint32_t wave, uint32_t &st, uint32_t site, uint32_t detail)
+{
+	st++;
+	if((st & 0x3ffu) != 0u || w == nullptr) { return false; }
+	__hip_atomic_store(&w[K3_WD_HEAD + wave], (site << 28) | (detail & 0x0fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	st |= 0x40000000u;
+	return __hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+}
+__device__ __forceinline__ void k3_wd_mark(uint32_t *w, uint32_t wave, uint32_t site, uint32_t detail) { if(w != nullptr) { __hip_atomic_store(&w[K3_WD_HEAD + wave], (site << 28) | (detail & 0x0fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } }
+__device__ __forceinline__ void k3_wd_ran(uint32_t *w, uint32_t wave, uint32_t &st) { if(st & 0x40000000u) { k3_wd_mark(w, wave, K3_WD_RAN, 0); } st = 0; }
 
 /* the per-read position hash, kh_t (minialign.c:341-683), literal */
 struct Kh { KhSlot *a; uint32_t mask, cnt, ub, cap; };
@@ -2100,6 +2130,62 @@ __device__ __attribute__((noinline)) uint32_t k3_room(ReadState *st, uint32_t ro
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	return 0;
 }
+/*
+ * The rings of free DP workspaces (K3Args.cls: one ring of numbers per class and XCD; slot value ~0 = taken).  A take ticket t is served by give ticket t -- the ring starts
+ * with its n numbers given --, so a waiting take waits for a wave that holds a workspace of the class to be done with it, and a give waits at most for the taker of its
+ * slot's turn before to pick its number up.  Every wait ticks the watchdog (k3_wd_tick) and ends when the host calls the launch off.
+ */
+/* a workspace of class c, waiting for one (NIL: the launch was called off) */
+__device__ __forceinline__ uint32_t k3_ring_take(const K3Class *cls, int c, uint32_t xcc, int lane, uint32_t *wdw, uint32_t wave, uint32_t &wst)
+{
+	uint32_t v = 0xffffffffu;
+	if(lane == 0) {
+		unsigned long long *ctr = cls[c].ctr; uint32_t *rg = cls[c].ring; const uint32_t n = cls[c].n;
+		const unsigned long long t = atomicAdd(&ctr[2 * xcc], 1ull); uint32_t *slot = &rg[(uint64_t)xcc * n + (uint32_t)(t % n)];
+		while((v = atomicExch(slot, 0xffffffffu)) == 0xffffffffu) {          /* every workspace of this XCD in use: one comes back when a wave is done with it */
+			__builtin_amdgcn_s_sleep(16);
+			if(k3_wd_tick(wdw, wave, wst, K3_WD_TAKE, ((uint32_t)c << 24) | ((uint32_t)t & 0xffffffu))) { break; }
+		}
+		k3_wd_ran(wdw, wave, wst);
+	}
+	return (uint32_t)rdfirst((int)v);
+}
+/* workspace `no` of class c goes back */
+__device__ __forceinline__ void k3_ring_give(const K3Class *cls, int c, uint32_t xcc, uint32_t no, int lane, uint32_t *wdw, uint32_t wave, uint32_t &wst)
+{
+	if(lane == 0) {
+		unsigned long long *ctr = cls[c].ctr; uint32_t *rg = cls[c].ring; const uint32_t n = cls[c].n;
+		const unsigned long long t = atomicAdd(&ctr[2 * xcc + 1], 1ull); uint32_t *slot = &rg[(uint64_t)xcc * n + (uint32_t)(t % n)];
+		while(atomicCAS(slot, 0xffffffffu, no) != 0xffffffffu) {          /* (the taker of this slot's previous turn has not picked its number up yet) */
+			__builtin_amdgcn_s_sleep(4);
+			if(k3_wd_tick(wdw, wave, wst, K3_WD_GIVE, ((uint32_t)c << 24) | ((uint32_t)t & 0xffffffu))) { break; }
+		}
+		k3_wd_ran(wdw, wave, wst);
+	}
+}
+/* the same without waiting, for a wave that holds or is about to take somebody else's work: a workspace of class c if one is free on this XCD right now, else NIL.  A
+ * ticket is drawn only while a give ticket is outstanding -- the number may still be on its way into the slot, which is a short wait, never one for a workspace that a
+ * waiting wave holds (a failed compare-and-swap means another wave drew a ticket: somebody always gets on) */
+__device__ __forceinline__ uint32_t k3_ring_try(const K3Class *cls, int c, uint32_t xcc, int lane, uint32_t *wdw, uint32_t wave, uint32_t &wst)
+{
+	uint32_t v = 0xffffffffu;
+	if(lane == 0) {
+		unsigned long long *ctr = cls[c].ctr; uint32_t *rg = cls[c].ring; const uint32_t n = cls[c].n;
+		for(;;) {
+			const unsigned long long t = __hip_atomic_load(&ctr[2 * xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), g = __hip_atomic_load(&ctr[2 * xcc + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if(t >= g) { break; }
+			if(atomicCAS(&ctr[2 * xcc], t, t + 1ull) != t) { continue; }
+			uint32_t *slot = &rg[(uint64_t)xcc * n + (uint32_t)(t % n)];
+			while((v = atomicExch(slot, 0xffffffffu)) == 0xffffffffu) {
+				__builtin_amdgcn_s_sleep(4);
+				if(k3_wd_tick(wdw, wave, wst, K3_WD_TRY, ((uint32_t)c << 24) | ((uint32_t)t & 0xffffffu))) { break; }
+			}
+			k3_wd_ran(wdw, wave, wst);
+			break;
+		}
+	}
+	return (uint32_t)rdfirst((int)v);
+}
 #ifdef MM_K3_NUM_VGPR
 __attribute__((amdgpu_num_vgpr(MM_K3_NUM_VGPR)))
 #endif
@@ -2119,16 +2205,10 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	}
-	/* take / return a workspace of class c on this XCD's ring */
-	#define K3_RING_TAKE(_c, _out) { uint32_t _v = 0; if(lane == 0) { \
-		unsigned long long *_ctr = a.cls[_c].ctr; uint32_t *_rg = a.cls[_c].ring; const uint32_t _n = a.cls[_c].n; \
-		const unsigned long long _t = atomicAdd(&_ctr[2 * xcc], 1ull); uint32_t *_slot = &_rg[(uint64_t)xcc * _n + (uint32_t)(_t % _n)]; \
-		while((_v = atomicExch(_slot, 0xffffffffu)) == 0xffffffffu) { __builtin_amdgcn_s_sleep(16); } }          /* every workspace of this XCD in use: one comes back when a wave is done with it */ \
-		(_out) = (uint32_t)rdfirst((int)_v); }
-	#define K3_RING_GIVE(_c, _no) { if(lane == 0) { \
-		unsigned long long *_ctr = a.cls[_c].ctr; uint32_t *_rg = a.cls[_c].ring; const uint32_t _n = a.cls[_c].n; \
-		const unsigned long long _t = atomicAdd(&_ctr[2 * xcc + 1], 1ull); uint32_t *_slot = &_rg[(uint64_t)xcc * _n + (uint32_t)(_t % _n)]; \
-		while(atomicCAS(_slot, 0xffffffffu, (_no)) != 0xffffffffu) { __builtin_amdgcn_s_sleep(4); } } }          /* (the taker of this slot's previous turn has not picked its number up yet) */
+	/* the watchdog's window (K3Args.wd): where this wave is, and the way out of every wait */
+	uint32_t *const wdw = (a.wd != nullptr && wave < a.wd_n) ? a.wd : nullptr; uint32_t wst = 0;
+	ReadState *cur_st = nullptr;          /* the read this wave holds (marked ERR_ABORT when the wave leaves a wait because the launch was called off) */
+	#define K3_LEAVE() { if(lane == 0 && cur_st != nullptr) { cur_st->err |= ERR_ABORT; } return; }
 	Kh kh; kh.cap = a.kh_cap;
 	/* with shared workspaces a wave maps ONE read and ends (grid = reads / 4): wave slots then come free read by read, and the launches of the other lanes --
 	 * sketch, sort, chain, copies, the next extension launch -- get theirs within a read's time instead of waiting for a whole persistent launch to drain;
@@ -2143,46 +2223,36 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
 	if(a.inkernel_rounds) { if(threadIdx.x == 0) { k3_tab[K3_TAB_WORDS] = 0; } __syncthreads(); }          /* the lock of the tables */
 
-	/* the workspace a read of qlen bases needs: the smallest class that holds it; kept from read to read while the class stays */
-	#define K3_NEED_SLAB(_qlen) { \
-		int _want = 0; while(_want + 1 < (int)a.n_cls && (_qlen) > a.cls[_want].qmax) { _want++; } \
-		if(_want != slab_cls) { \
-			if(slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); } \
-			K3_RING_TAKE(_want, slab_no); slab_cls = _want; \
-			x.slab = a.cls[_want].slabs + (uint64_t)slab_no * a.cls[_want].bytes; x.cap = (uint32_t)a.cls[_want].bytes; x.top = gaba::SLAB_HEAD; \
-			for(uint32_t _i = (uint32_t)lane; _i < gaba::SLAB_HEAD / 4; _i += 64) { ((uint32_t *)x.slab)[_i] = ((const uint32_t *)a.roots)[_i]; } \
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
-			if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[_want].next_base) * MM_NEXT_STRIDE(a.next_cap); next_scratch = (uint32_t *)(next + a.next_cap); } \
-		} }
-	/* the same without waiting, for a wave that is about to take somebody else's work (a retry job): a workspace of class _want if one is free on this XCD right now.  A take
-	 * ticket t is served by give ticket t (the ring starts with its n numbers given), so a ticket is drawn only while one is outstanding -- the number may still be on its way
-	 * into the slot, which is a short wait, never one for a workspace that a waiting wave holds.  The old workspace goes back after the new one is in hand. */
-	#define K3_TRY_SLAB(_want, _ok) { \
-		uint32_t _v = 0xffffffffu; \
-		if(lane == 0) { \
-			unsigned long long *_ctr = a.cls[_want].ctr; uint32_t *_rg = a.cls[_want].ring; const uint32_t _n = a.cls[_want].n; \
-			for(;;) {          /* (a failed compare-and-swap means another wave drew a ticket: somebody always gets on) */ \
-				const unsigned long long _t = __hip_atomic_load(&_ctr[2 * xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), _g = __hip_atomic_load(&_ctr[2 * xcc + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-				if(_t >= _g) { break; } \
-				if(atomicCAS(&_ctr[2 * xcc], _t, _t + 1ull) != _t) { continue; } \
-				uint32_t *_slot = &_rg[(uint64_t)xcc * _n + (uint32_t)(_t % _n)]; \
-				while((_v = atomicExch(_slot, 0xffffffffu)) == 0xffffffffu) { __builtin_amdgcn_s_sleep(4); } \
-				break; \
-			} \
-		} \
-		_v = (uint32_t)rdfirst((int)_v); (_ok) = _v != 0xffffffffu; \
-		if(_ok) { \
-			if(slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); } \
-			slab_no = _v; slab_cls = (_want); \
-			x.slab = a.cls[_want].slabs + (uint64_t)slab_no * a.cls[_want].bytes; x.cap = (uint32_t)a.cls[_want].bytes; x.top = gaba::SLAB_HEAD; \
-			for(uint32_t _i = (uint32_t)lane; _i < gaba::SLAB_HEAD / 4; _i += 64) { ((uint32_t *)x.slab)[_i] = ((const uint32_t *)a.roots)[_i]; } \
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); \
-			if(!persistent) { next = a.next_pool + (uint64_t)(slab_no + a.cls[_want].next_base) * MM_NEXT_STRIDE(a.next_cap); next_scratch = (uint32_t *)(next + a.next_cap); } \
-		} }
+	/* workspace `no` of class c is this wave's from here on */
+	auto bind_slab = [&](int c, uint32_t no) {
+		slab_no = no; slab_cls = c;
+		x.slab = a.cls[c].slabs + (uint64_t)no * a.cls[c].bytes; x.cap = (uint32_t)a.cls[c].bytes; x.top = gaba::SLAB_HEAD;
+		for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		if(!persistent) { next = a.next_pool + (uint64_t)(no + a.cls[c].next_base) * MM_NEXT_STRIDE(a.next_cap); next_scratch = (uint32_t *)(next + a.next_cap); }
+	};
+	auto class_of = [&](uint32_t qlen) -> int { int want = 0; while(want + 1 < (int)a.n_cls && qlen > a.cls[want].qmax) { want++; } return want; };
+	/* the workspace a read of qlen bases needs: the smallest class that holds it; kept from read to read while the class stays.  false: the launch was called off */
+	auto need_slab = [&](uint32_t qlen) -> bool {
+		const int want = class_of(qlen);
+		if(want == slab_cls) { return true; }
+		if(slab_cls >= 0) { k3_ring_give(a.cls, slab_cls, xcc, slab_no, lane, wdw, wave, wst); slab_cls = -1; }
+		const uint32_t no = k3_ring_take(a.cls, want, xcc, lane, wdw, wave, wst);
+		if(no == 0xffffffffu) { return false; }
+		bind_slab(want, no); return true;
+	};
+	/* the same without waiting (k3_ring_try), for a wave that is about to take somebody else's work; the old workspace goes back after the new one is in hand */
+	auto try_slab = [&](int want) -> bool {
+		const uint32_t no = k3_ring_try(a.cls, want, xcc, lane, wdw, wave, wst);
+		if(no == 0xffffffffu) { return false; }
+		if(slab_cls >= 0) { k3_ring_give(a.cls, slab_cls, xcc, slab_no, lane, wdw, wave, wst); }
+		bind_slab(want, no); return true;
+	};
 	/* a job on the workspace this wave holds (the caller has made sure of its class): counters of the DP work go to this wave */
 	auto run_job = [&](const SpecJob &j, SpecMemo *mo_out, uint32_t *flag, uint32_t flag_val, int flag_in_memo) {
 		const uint32_t jr = (uint32_t)rdfirst((int)j.r), ja = (uint32_t)rdfirst((int)j.aid);
 		gaba::dp_flush(x); x.err = 0;
+		if(lane == 0) { k3_wd_mark(wdw, wave, K3_WD_JOB, jr); }
 		DpIn din; din.c = x.c; din.ar0 = ar[0]; din.ar1 = ar[1]; din.slab = x.slab; din.top = x.top; din.cap = x.cap;
 		const unsigned long long cyj0 = MM_TICK();
 		JobOut jo = k3_run_job(din, j, a.in[jr].qlen, a.in[jr].q_off, a.idx.seq_off[ja], a.min_score, mo_out, flag, flag_val, flag_in_memo, a.spath, a.spath_cap, a.sseg, a.sseg_cap, a.stage_top);
@@ -2190,6 +2260,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		n_fill += (uint32_t)rdfirst((int)jo.n_fill); n_trace += (uint32_t)rdfirst((int)jo.n_trace);
 		cy_fill += MM_TICK() - cyj0;
 		gaba::dp_flush(x); x.err = 0;
+		if(lane == 0) { k3_wd_mark(wdw, wave, K3_WD_RAN, 1); }
 	};
 	/* jobs first: the first trials of the chains of the heaviest reads, one per wave at a time, by every wave of the launch (K3Args.jobs) */
 	if(a.jobs && a.ring) {
@@ -2206,13 +2277,13 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			{
 				/* the workspace without waiting: the wave holds a claimed job, and the waves that hold the workspaces of a scarce class may soon be waiting for this very job.
 				 * None free: the job is handed back undone (the read's own wave runs the trial when it gets there, as without jobs) */
-				int want = 0; while(want + 1 < (int)a.n_cls && qlen > a.cls[want].qmax) { want++; }
+				const int want = class_of(qlen);
 				bool have = want == slab_cls;
 				/* (a class with a workspace for every wave an XCD can hold never makes anybody wait: the plain ticket, one atomic add -- the compare-and-swap of the other form,
 				 * with a thousand waves of an XCD at the same counter when the launch starts, is what a first version with a bounded number of attempts failed on: nearly every
 				 * job of an E.coli-size set was handed back, 182 -> 211 ms per step) */
-				if(!have && a.cls[want].n >= a.full_n) { K3_NEED_SLAB(qlen); have = true; }
-				if(!have) { K3_TRY_SLAB(want, have); }
+				if(!have && a.cls[want].n >= a.full_n) { if(!need_slab(qlen)) { K3_LEAVE(); } have = true; }
+				if(!have) { have = try_slab(want); }
 				if(!have) { if(lane == 0) { __hip_atomic_store(&a.memo[ji].state, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } continue; }
 			}
 			j.pad = JOB_FULL;
@@ -2266,11 +2337,11 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 					if(!no_reads && a.rq_between < 3u && ((uint32_t)rdfirst((int)a.rjobs[ji].pad) & JOB_FULL) == 0u) { rq_mine = 0xffffffffu; idle = 0; continue; }          /* (a retry job: the helpers') */
 					const uint32_t jr = (uint32_t)rdfirst((int)a.rjobs[ji].r), jq = (uint32_t)rdfirst((int)a.in[jr].qlen);
-					int want = 0; while(want + 1 < (int)a.n_cls && jq > a.cls[want].qmax) { want++; }
+					const int want = class_of(jq);
 					bool have = want == slab_cls;
 					/* (a wave with reads left keeps the workspace it holds: on a ladder of classes it would give a scarce one back for a job of another class and wait for it again for
 					 * its next read -- it takes the jobs that fit what it holds, the waves without reads take any) */
-					if(!have && (no_reads || slab_cls < 0 || a.rq_between >= 2u)) { K3_TRY_SLAB(want, have); }
+					if(!have && (no_reads || slab_cls < 0 || a.rq_between >= 2u)) { have = try_slab(want); }
 					if(have) { if(lane == 0) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY ? 100u : 99u; } stt = (uint32_t)rdfirst((int)stt); }
 					else { stt = RJ_EMPTY; }          /* no workspace of that class free: the job stays with its owner unless one comes back before the owner gets there */
 				}
@@ -2280,7 +2351,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					run_job(a.rjobs[ji], a.rmemo + ji, a.rstate + ji, (uint32_t)RJ_DONE, 0);
 					__builtin_amdgcn_s_setprio(0); rq_mine = 0xffffffffu; idle = 0;
 					/* a workspace of a class above the ordinary one goes back at once: the classes are small, and a wave that sat on one between jobs could be what a read is waiting for */
-					if(slab_cls >= 1) { K3_RING_GIVE(slab_cls, slab_no); slab_cls = -1; }
+					if(slab_cls >= 1) { k3_ring_give(a.cls, slab_cls, xcc, slab_no, lane, wdw, wave, wst); slab_cls = -1; }
 					continue;
 				}
 				if(ji != 0xffffffffu && stt != RJ_EMPTY) { rq_mine = 0xffffffffu; idle = 0; continue; }          /* taken by its owner, done or cancelled: the next one */
@@ -2292,9 +2363,12 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				 * ONT-like set, where a launch lasts as long as its longest read, 2.1 against 2.8 G bases/s.  a.rq_stay (MM_K3_STAY): the first form */
 				if(!rq_helper) { if(a.rq_stay ? wide == 0u : (ji == 0xffffffffu || ++idle > 16u)) { break; } }
 				__builtin_amdgcn_s_sleep(64);
+				{ uint32_t off = 0; if(lane == 0) { off = k3_wd_tick(wdw, wave, wst, K3_WD_IDLE, ji) ? 1u : 0u; } if(rdfirst((int)off)) { K3_LEAVE(); } }
 			}
 		}
 		if(no_reads) { break; }
+		cur_st = nullptr;
+		if(wdw != nullptr) { uint32_t off = 0; if(lane == 0) { off = __hip_atomic_load(&wdw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } if(rdfirst((int)off)) { return; } }          /* (called off: no more reads) */
 		uint32_t wi = wave;
 		if(persistent && a.n_cls > 1 && a.ring) {
 			/* several workspace classes: a read of the highest class that has reads left AND a workspace at hand (held already, or free on this XCD right now); else one of
@@ -2306,7 +2380,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				uint32_t cur = 0; if(lane == 0) { cur = __hip_atomic_load(&a.seg_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } cur = (uint32_t)rdfirst((int)cur);
 				if(cur >= len) { continue; }
 				bool have = slab_cls == c;
-				if(!have) { K3_TRY_SLAB(c, have); }
+				if(!have) { have = try_slab(c); }
 				if(!have) { continue; }
 				uint32_t i = 0; if(lane == 0) { i = atomicAdd(&a.seg_cnt[c], 1u); } i = (uint32_t)rdfirst((int)i);
 				if(i < len) { wi = a.seg_beg[c] + i; }
@@ -2326,13 +2400,22 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		}
 		const uint32_t r = (uint32_t)rdfirst((int)a.work[wi]);
 		ReadState *st = &a.st[r];
+		cur_st = st; if(lane == 0) { k3_wd_mark(wdw, wave, K3_WD_READ, wi); }
+		if(a.test_hang != 0u && wi + 1u == a.test_hang) {          /* test hook: this wave waits for something that never comes, until the watchdog calls the launch off */
+			uint32_t off = 0; if(lane == 0) { while(!k3_wd_tick(wdw, wave, wst, K3_WD_TEST, wi)) { __builtin_amdgcn_s_sleep(32); if(wdw == nullptr && wst > (1u << 16)) { break; } } off = 1; }
+			if(rdfirst((int)off) && wdw != nullptr) { K3_LEAVE(); }
+		}
 		for(uint32_t round = a.round; ; round++) {
 		if(round != a.round) {
 			/* the next occurrence threshold for this read, here and now */
 			/* ONE set of tables per workgroup, taken in turn by its four waves: the rounds are rare (a few per cent of the reads), and 24 KB of LDS per workgroup held
 			 * six workgroups' worth of a CU's LDS for the whole launch -- the sort and chain kernels of the other lanes, which live on LDS, ran 2.3 x slower beside it */
 			const unsigned long long cy_resc0 = MM_TICK();
-			if(lane == 0) { while(atomicCAS((unsigned int *)&k3_tab[K3_TAB_WORDS], 0u, 1u) != 0u) { __builtin_amdgcn_s_sleep(32); } }
+			{
+				uint32_t off = 0;
+				if(lane == 0) { while(atomicCAS((unsigned int *)&k3_tab[K3_TAB_WORDS], 0u, 1u) != 0u) { __builtin_amdgcn_s_sleep(32); if(k3_wd_tick(wdw, wave, wst, K3_WD_LDS, r)) { off = 1; break; } } k3_wd_ran(wdw, wave, wst); }
+				if(rdfirst((int)off)) { K3_LEAVE(); }
+			}
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 			const uint32_t e2 = k3_rescue_round(st, round, a.seed_pool + rdfirst64(st->seed_off), a.root_pool + rdfirst64(st->root_off), a.resc_pool + rdfirst64(st->resc_off),
 				a.idx, a.twlen, a.mcoef, a.min_score, (LU32 *)&k3_tab[0]);
@@ -2350,7 +2433,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		if(wi < (a.n_work >> 6) || a.n_work < 64) { __builtin_amdgcn_s_setprio(3); }          /* (a launch of a few reads is a re-run for the carried value: its lane, and the lanes behind it, wait for it) */ else if(n_root >= 5) { __builtin_amdgcn_s_setprio(1); } else { __builtin_amdgcn_s_setprio(0); }
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
-		if(a.ring) { K3_NEED_SLAB(qlen); }
+		if(a.ring) { if(!need_slab(qlen)) { K3_LEAVE(); } }
 		const unsigned long long cy_slab = MM_TICK();
 		Seed *s = a.seed_pool + rdfirst64(st->seed_off);
 		Root *root = a.root_pool + rdfirst64(st->root_off);
@@ -2363,7 +2446,8 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				uint32_t ok = 0;
 				if(lane == 0) {
 					const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-					while((ok = __hip_atomic_load(&a.st[dep].carry_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) { if(__builtin_amdgcn_s_memtime() - t0 > (1ull << 28)) { break; } __builtin_amdgcn_s_sleep(32); }
+					while((ok = __hip_atomic_load(&a.st[dep].carry_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) { if(__builtin_amdgcn_s_memtime() - t0 > (1ull << 28)) { break; } __builtin_amdgcn_s_sleep(32); if(k3_wd_tick(wdw, wave, wst, K3_WD_CARRY, dep)) { break; } }
+					k3_wd_ran(wdw, wave, wst);
 				}
 				ok = (uint32_t)rdfirst((int)ok);
 				if(ok) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); rlen = (uint32_t)rdfirst((int)__hip_atomic_load(&a.st[dep].rlen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -2534,8 +2618,9 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				const SpecMemo *smp = a.memo + (spec_off + kq); bool memo0 = false, memo1 = false, memo_trace = false;
 				if(chain_first && bw == 0 && kq < spec_n) {
 					uint32_t stt = 0;
-					if(lane == 0) { while((stt = __hip_atomic_load(&smp->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) { __builtin_amdgcn_s_sleep(32); } }
+					if(lane == 0) { while((stt = __hip_atomic_load(&smp->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) { __builtin_amdgcn_s_sleep(32); if(k3_wd_tick(wdw, wave, wst, K3_WD_MEMO, spec_off + kq)) { break; } } k3_wd_ran(wdw, wave, wst); }
 					stt = (uint32_t)rdfirst((int)stt);
+					if(stt == 0u) { K3_LEAVE(); }          /* (called off while the job was in another wave's hands) */
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 					if((stt & 1u) && (uint32_t)rdfirst((int)smp->aid) == sr.aid && (uint32_t)rdfirst((int)smp->cp_a) == sr.cp_a && (uint32_t)rdfirst((int)smp->cp_b) == sr.cp_b && (uint32_t)rdfirst((int)smp->rev) == (sr.rev ? 1u : 0u)) { memo0 = true; memo1 = (stt & 2u) != 0; }
 					if(memo0 && lane == 0) { atomicAdd(&a.job_top[4], 1ull); }
@@ -2560,7 +2645,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 							if(memo0) { dg_hits++; if(lane == 0) { atomicAdd(&a.rq_ctl[3], 1u); } }
 							break;
 						}
-						if(!own_job(ji + 1, cj_base + cj_n)) { __builtin_amdgcn_s_sleep(32); }
+						if(!own_job(ji + 1, cj_base + cj_n)) { __builtin_amdgcn_s_sleep(32); uint32_t off = 0; if(lane == 0) { off = k3_wd_tick(wdw, wave, wst, K3_WD_CJOB, ji) ? 1u : 0u; } if(rdfirst((int)off)) { K3_LEAVE(); } }
 					}
 				}
 				if(rq_on && !chain_first) {
@@ -2586,7 +2671,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 									break;
 								}
 								/* another wave is working on it: one of the later jobs of this read meanwhile */
-								if(!own_job(rj_base + rj_i, rj_base + rj_n)) { __builtin_amdgcn_s_sleep(32); }
+								if(!own_job(rj_base + rj_i, rj_base + rj_n)) { __builtin_amdgcn_s_sleep(32); uint32_t off = 0; if(lane == 0) { off = k3_wd_tick(wdw, wave, wst, K3_WD_RJOB, ji) ? 1u : 0u; } if(rdfirst((int)off)) { K3_LEAVE(); } }
 							}
 						}
 					}
@@ -2644,6 +2729,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 						}
 					}
 				}
+				if(lane == 0) { k3_wd_ran(wdw, wave, wst); }
 				chain_first = false; dg_trials++;
 				for(int pass = 0; pass < 2 && !skip; pass++) {
 					gaba::Sec ca = pass == 0 ? rsec_f : rsec_r;
@@ -2825,10 +2911,8 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		atomicAdd(&a.stats[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
 		atomicMax(&a.stats[9], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));      /* longest-living wave: load balance */
 	}
-	if(a.ring && slab_cls >= 0) { K3_RING_GIVE(slab_cls, slab_no); }
-	#undef K3_NEED_SLAB
-	#undef K3_RING_TAKE
-	#undef K3_RING_GIVE
+	if(a.ring && slab_cls >= 0) { k3_ring_give(a.cls, slab_cls, xcc, slab_no, lane, wdw, wave, wst); }
+	#undef K3_LEAVE
 }
 
 } /* namespace mm */

@@ -1247,6 +1247,12 @@ struct mm_align_s {
 	std::mutex need_mu; double need_seed = 0.30, need_resc = 0.03, need_root = 0.16; uint64_t batch_bases = 0;
 	/* experiment (MM_K3_CONCURRENT=n): at most n extension launches of this device in flight at a time, the lanes queue for their turn */
 	std::mutex k3_gate_mu; std::condition_variable k3_gate_cv; int k3_in_flight = 0;
+	/* the watchdog of the extension launches (primary context; k3_watchdog): every launch of a device goes through the gate above; a launch that lasts longer than the
+	 * deadline gets the census of its waves printed (wd: the lane's window into its launch, K3Args.wd) and is called off with every other launch of the device in flight,
+	 * the workspace rings are set up again, and the batches run again in the safe mode (no jobs, no waiting for carried values inside a launch, one extension launch at a
+	 * time: nothing left in the kernel that waits for another wave but the ring of a scarce workspace class, whose holders then wait for nobody) until the stream ends */
+	std::thread wd_thread; bool wd_running = false, wd_stop = false, wd_recovering = false; std::atomic<bool> safe_mode{false}; double wd_longest_ms = 0;
+	uint32_t *wd = nullptr; std::atomic<double> k3_t0{0.0}; std::atomic<bool> k3_called_off{false}; uint32_t k3_wd_waves = 0, k3_wd_work = 0;          /* per lane: the pinned window, when its launch in flight began (0: none), whether it was called off, its shape */
 	mm_stats_t st; double t_wall0;
 	/* knobs (grown on overflow) */
 	uint32_t bin_cap = 192, aln_cap = 96, kh_cap = 1024, next_cap = 256, rs_stride = 512 + 3 * 1024;
@@ -1297,6 +1303,7 @@ bool lane_h2d(mm_align_t *a, void *dst, const void *src, size_t n)
 	if(!st) { CPY(a, dst, src, n, hipMemcpyHostToDevice); return true; }
 	memcpy(st, src, n); CPY(a, dst, st, n, hipMemcpyHostToDevice); return true;
 }
+void k3_watchdog_start(mm_align_s *GP);
 /* run K1..K3 over `work` (indices into the batch) with rlen_in already stored in d_st[].rlen */
 bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &work_in, bool run_k1, std::vector<ReadState> &hst,
 	const std::vector<uint32_t> *rlen_fixed, const std::vector<uint32_t> &qlens)
@@ -1305,6 +1312,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 	if(work.empty()) return true;
 	unsigned long long *tops = a->d_tops.p;
 	float ms;
+	mm_align_s *const GPw = a->root ? a->root : a;
+	const bool safe = GPw->safe_mode.load();          /* the watchdog has called a launch of this device off (k3_watchdog_main): nothing in the extension launches that waits for another wave */
+	a->k3_called_off.store(false);
 	/* a re-run of a few reads with the carried value given (batch_verify_carry): the short way -- one sort + chain launch, no round trip of the states between chaining
 	 * and extension (the caller has put the value and the reset fields in place), the work list as it is */
 	const bool small_rerun = rlen_fixed != nullptr && run_k1 && work.size() < 256 && getenv("MM_SLOW_RERUN") == NULL;
@@ -1501,7 +1511,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				 * sketch on when the check finds the guess wrong -- 71 such re-runs per step of the headline set, 154 on a tenth of the hard-repeat set, where the re-runs of a batch
 				 * (one read inside a repeat family alone on a launch: a second) were three quarters of the step; MM_NO_CARRY_DEPS: all by prediction as before */
 				static const bool no_deps = getenv("MM_NO_CARRY_DEPS") != NULL;
-				const bool deps = !no_deps && getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL && getenv("MM_K3_DEFER_RESCUE") == NULL && getenv("MM_K3_ONE_READ_PER_WAVE") == NULL;
+				const bool deps = !no_deps && !safe && getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL && getenv("MM_K3_DEFER_RESCUE") == NULL && getenv("MM_K3_ONE_READ_PER_WAVE") == NULL;
 				std::vector<uint8_t> in_work(n_reads, 0); for(uint32_t wi : work) in_work[wi] = 1;
 				const double weak_unit = (getenv("MM_CARRY_WEAK") ? std::max(0, atoi(getenv("MM_CARRY_WEAK"))) : 128) * 2.0 * (double)a->o.min_score / a->mcoef;
 				uint32_t cur = a->rlen_carry, src = gaba::NIL;          /* src: the source read that decides the value at hand */
@@ -1636,7 +1646,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * behind a re-run wait for it -- the ordinary re-run of two or three reads stays a launch of one workgroup) */
 		const bool small_launch = work.size() < 256, small_heavy = small_launch && (a->rerun_heavy || !rlen_fixed);
 		if(small_heavy) { k3.rq_helper_mask = 3u; }
-		if(round == 0 && k3.ring && k3.cls && inkernel && (!small_launch || small_heavy) && !getenv("MM_K3_NO_RETRY_JOBS")) {
+		if(round == 0 && k3.ring && k3.cls && inkernel && !safe && (!small_launch || small_heavy) && !getenv("MM_K3_NO_RETRY_JOBS")) {
 			const uint32_t rq_cap = 1u << 17;
 			if(a->rq_jobs.ensure(rq_cap) && a->rq_memo.ensure(rq_cap) && a->rq_state.ensure(rq_cap + 16)) {
 				CK(hipMemsetAsync(a->rq_state.p, 0, ((size_t)rq_cap + 16) * 4, a->stream));
@@ -1648,7 +1658,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* the staging area of the traced jobs (path words, segments) and its cursors: for the chain jobs enumerated before the launch and for the chains a read publishes from
 		 * inside it (K3Args.rjobs, JOB_FULL) alike */
 		const uint64_t stage_job_cap = getenv("MM_K3_JOB_CAP") ? (uint64_t)std::max(1, atoi(getenv("MM_K3_JOB_CAP"))) : (1u << 16), stage_path_cap = 48ull << 20, stage_seg_cap = (stage_job_cap + k3.rq_cap) * 8;          /* (MM_K3_JOB_CAP: test hook, a launch with more chain jobs than slots) */
-		const bool staged = k3.ring && k3.cls && (k3.rjobs || (((round == 0 && inkernel) || deferred) && n_heavy > 0 && !getenv("MM_K3_NO_JOBS")))
+		const bool staged = k3.ring && k3.cls && !safe && (k3.rjobs || (((round == 0 && inkernel) || deferred) && n_heavy > 0 && !getenv("MM_K3_NO_JOBS")))
 			&& a->spec_path.ensure(stage_path_cap) && a->spec_seg.ensure(stage_seg_cap) && a->spec_top.ensure(8);
 		if(staged) {
 			CK(hipMemsetAsync(a->spec_top.p, 0, 64, a->stream));
@@ -1688,13 +1698,27 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * no faster on the headline workload (2.86 against 2.77 s per step with the rounds in the kernel, 3.7 against 3.2 without), kept as an experiment */
 		k3.persistent = 1;
 		if(k3.ring) { if((uint64_t)k3.ring_n * 8 >= a->n_waves && getenv("MM_K3_ONE_READ_PER_WAVE")) { k3.persistent = 0; waves = (uint32_t)((k3.n_work + 3) & ~3u); } else { waves = std::min<uint32_t>(waves, (k3.ring_n * 8u) & ~3u); } }
-		const int k3_conc = getenv("MM_K3_CONCURRENT") ? std::max(1, atoi(getenv("MM_K3_CONCURRENT"))) : 0;
-		mm_align_s *GP = a->root ? a->root : a;
-		if(k3_conc) { std::unique_lock<std::mutex> lk(GP->k3_gate_mu); GP->k3_gate_cv.wait(lk, [&]() { return GP->k3_in_flight < k3_conc; }); GP->k3_in_flight++; CK(hipEventRecord(a->ev0, xs)); }
+		const int k3_conc = safe ? 1 : (getenv("MM_K3_CONCURRENT") ? std::max(1, atoi(getenv("MM_K3_CONCURRENT"))) : 0);
+		mm_align_s *GP = GPw;
+		/* the watchdog's window into this launch (k3_watchdog_main): where every wave is, and the word that calls the launch off */
+		if(!a->wd) { if(hipHostMalloc((void **)&a->wd, (K3_WD_HEAD + (size_t)GP->n_waves) * 4, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { a->wd = nullptr; } }
+		if(a->wd) { memset(a->wd, 0, (K3_WD_HEAD + (size_t)GP->n_waves) * 4); k3_watchdog_start(GP); }
+		k3.wd = a->wd; k3.wd_n = GP->n_waves; k3.test_hang = 0;
+		if(const char *e = getenv("MM_TEST_K3_HANG")) { static std::atomic<int> once{0}; if(round == 0 && !rlen_fixed && k3.n_work > (uint32_t)atoi(e) && once.fetch_add(1) == 0) { k3.test_hang = (uint32_t)atoi(e) + 1u; } }          /* test hook: one wave of the first launch of the process waits for nothing */
+		{
+			/* the gate of the device's extension launches: closed while the watchdog recovers; in the safe mode (and with MM_K3_CONCURRENT) one launch at a time */
+			std::unique_lock<std::mutex> lk(GP->k3_gate_mu);
+			GP->k3_gate_cv.wait(lk, [&]() { return !GP->wd_recovering && (k3_conc == 0 || GP->k3_in_flight < k3_conc); });
+			if(GP->safe_mode.load() != safe) { a->k3_called_off.store(true); return false; }          /* (the mode changed while this launch was being set up: the batch again, as if it had been called off) */
+			GP->k3_in_flight++; a->k3_wd_waves = waves; a->k3_wd_work = k3.n_work; a->k3_t0.store(now_ms());
+			if(k3_conc) { (void)hipEventRecord(a->ev0, xs); }
+		}
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), inkernel ? K3_LDS_BYTES : 0, xs, k3);
 		{ const hipError_t le = hipGetLastError(); hipError_t se = le == hipSuccess ? hipEventRecord(a->ev1, xs) : le; if(se == hipSuccess) se = hipEventSynchronize(a->ev1);
-		  if(k3_conc) { { std::lock_guard<std::mutex> lk(GP->k3_gate_mu); GP->k3_in_flight--; } GP->k3_gate_cv.notify_all(); }
+		  { std::lock_guard<std::mutex> lk(GP->k3_gate_mu); GP->k3_in_flight--; if(!a->k3_called_off.load()) { GP->wd_longest_ms = std::max(GP->wd_longest_ms, now_ms() - a->k3_t0.load()); } a->k3_t0.store(0.0); }
+		  GP->k3_gate_cv.notify_all();
 		  CK(se); }
+		if(a->k3_called_off.load()) { return false; }          /* called off by the watchdog: the caller runs the batch again (batch_run_spec) */
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k3_ms += ms; a->st.k3_launches++;
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
 		if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
@@ -2082,14 +2106,19 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 }
 /* one set of DP workspaces for all lanes of a context (the streaming engine calls this before its lane threads start, with the longest read of the input):
  * as many as waves can be resident (n_waves), fewer when MM_SLAB_GB (default 64) says so -- waves then wait for one to come back */
+/* a ring of free workspace numbers as it stands before anything has been taken: every number in its slot, take tickets at 0, give tickets at `per` (K3Args.ring) */
+static bool ring_fill(uint32_t *ring, unsigned long long *ctr, uint32_t per, uint32_t n_xcd)
+{
+	std::vector<uint32_t> r((size_t)per * n_xcd); for(size_t i = 0; i < r.size(); i++) r[i] = (uint32_t)i;
+	std::vector<unsigned long long> c(2 * n_xcd); for(uint32_t x = 0; x < n_xcd; x++) { c[2 * x] = 0; c[2 * x + 1] = per; }
+	return hipMemcpy(ring, r.data(), r.size() * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(ctr, c.data(), c.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+}
 bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
 {
 	auto slab_of = [](uint32_t qlen) -> uint64_t { const uint64_t blocks = 2 * ((2ull * qlen + 8192) / 32 + 64); return (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull; };
 	auto fill_ring = [](DBuf<uint32_t> &ring, DBuf<unsigned long long> &ctr, uint32_t per, uint32_t n_xcd) -> bool {
 		if(!ring.ensure((uint64_t)per * n_xcd) || !ctr.ensure(2 * n_xcd)) return false;
-		std::vector<uint32_t> r((size_t)per * n_xcd); for(size_t i = 0; i < r.size(); i++) r[i] = (uint32_t)i;
-		std::vector<unsigned long long> c(2 * n_xcd); for(uint32_t x = 0; x < n_xcd; x++) { c[2 * x] = 0; c[2 * x + 1] = per; }
-		return hipMemcpy(ring.p, r.data(), r.size() * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(ctr.p, c.data(), c.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+		return ring_fill(ring.p, ctr.p, per, n_xcd);
 	};
 	max_qlen = (std::max(max_qlen, P->qlen_hint) + 8191u) & ~8191u;
 	const uint64_t budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
@@ -2130,6 +2159,99 @@ bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
 	if(getenv("MM_VERBOSE_SLABS")) { for(auto &k : P->h_cls) fprintf(stderr, "[minialign_amd] workspace class: reads up to %u bases, %u x %.1f MB\n", k.qmax, k.n * n_xcd, k.bytes / 1048576.0); }
 	P->shared_slabs = true;
 	return true;
+}
+
+/*
+ * The watchdog of the extension launches.  mm_extend_kernel is the one kernel whose waves wait for each other (workspace rings, published jobs, carried values, the tables
+ * of a workgroup); every such wait ticks into a window of pinned host memory (K3Args.wd) and ends when the word at its head is set.  This thread looks at the launches of
+ * its device every 50 ms.  One that has been in flight longer than the deadline (MM_K3_WATCHDOG_MS, default: 20 s or 40 x the longest launch that has ended, whichever is
+ * more) is not slow, it is stuck: the thread prints where every wave of every launch in flight is, calls all of them off (the waves that wait leave, the others finish
+ * the read they hold and take no more), waits for the launches to end, sets the rings up again (a wave that left a wait may have drawn a ticket it never used), and
+ * switches the device to the safe mode for the rest of the stream.  The lanes run their batches again from the upload on: same bytes, later.  A launch that does not end
+ * within 60 s of being called off is a wave that spins outside every wait -- nothing the host can recover from: the process says so and ends with status 86 instead of
+ * spinning with the device for ever.
+ */
+static const char *k3_wd_site(uint32_t s)
+{
+	static const char *nm[16] = { "not started / ended", "waits for a DP workspace (take)", "gives a DP workspace back (slot busy)", "takes a DP workspace without waiting (number on its way)", "waits for the tables of its workgroup (rescue round)",
+		"waits for the carried value of the read in front", "waits for a chain job of before the launch", "waits for a chain job another wave claimed", "waits for a retry job another wave claimed", "without reads, looking for jobs",
+		"TEST HOOK: waits for nothing", "?", "?", "runs a job", "at work again after a wait", "at work on a read" };
+	return nm[s & 15];
+}
+static void k3_wd_census(mm_align_s *GP, double now)
+{
+	int li = 0;
+	for(mm_align_s *q = GP; q; q = q->sib, li++) {
+		const double t0 = q->k3_t0.load();
+		if(t0 == 0.0 || !q->wd) { fprintf(stderr, "[minialign_amd] watchdog: device %d lane %d: no extension launch in flight\n", GP->dev, li); continue; }
+		const uint32_t nw = std::min<uint32_t>(q->k3_wd_waves, GP->n_waves);
+		uint32_t cnt[16] = { 0 }; std::vector<uint32_t> ex[16];
+		for(uint32_t w = 0; w < nw; w++) { const uint32_t v = q->wd[K3_WD_HEAD + w], sidx = v >> 28; cnt[sidx]++; if(ex[sidx].size() < 12) { ex[sidx].push_back(w); ex[sidx].push_back(v & 0x0fffffffu); } }
+		fprintf(stderr, "[minialign_amd] watchdog: device %d lane %d: extension launch in flight for %.1f s, %u waves, %u reads\n", GP->dev, li, (now - t0) * 1e-3, nw, q->k3_wd_work);
+		for(int sidx = 0; sidx < 16; sidx++) {
+			if(!cnt[sidx]) continue;
+			fprintf(stderr, "[minialign_amd] watchdog:   %5u wave(s): %s", cnt[sidx], k3_wd_site((uint32_t)sidx));
+			if(sidx != 0) { fprintf(stderr, "; e.g."); for(size_t i = 0; i + 1 < ex[sidx].size(); i += 2) { const uint32_t d = ex[sidx][i + 1]; if(sidx >= 1 && sidx <= 3) fprintf(stderr, " wave %u (class %u, ticket ..%u)", ex[sidx][i], d >> 24, d & 0xffffffu); else fprintf(stderr, " wave %u (%u)", ex[sidx][i], d); } }
+			fprintf(stderr, "\n");
+		}
+	}
+}
+static void k3_wd_rings_dump_and_reset(mm_align_s *GP)
+{
+	const uint32_t n_xcd = 8;
+	for(size_t c = 0; c < GP->h_cls.size(); c++) {
+		const K3Class &k = GP->h_cls[c];
+		std::vector<unsigned long long> ctr(2 * n_xcd);
+		if(hipMemcpy(ctr.data(), k.ctr, ctr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+			fprintf(stderr, "[minialign_amd] watchdog: workspace class %zu (reads up to %u bases, %u per XCD): takes / gives beyond the first %u, per XCD:", c, k.qmax, k.n, k.n);
+			for(uint32_t x = 0; x < n_xcd; x++) fprintf(stderr, " %llu/%llu", ctr[2 * x], ctr[2 * x + 1] - k.n);
+			fprintf(stderr, "\n");
+		}
+		if(!ring_fill(k.ring, k.ctr, k.n, n_xcd)) fprintf(stderr, "[minialign_amd] watchdog: the ring of workspace class %zu could not be set up again\n", c);
+	}
+}
+static void k3_watchdog_main(mm_align_s *GP)
+{
+	(void)hipSetDevice(GP->dev);
+	const double fixed_ms = getenv("MM_K3_WATCHDOG_MS") ? atof(getenv("MM_K3_WATCHDOG_MS")) : 0.0;
+	std::unique_lock<std::mutex> lk(GP->k3_gate_mu);
+	while(!GP->wd_stop) {
+		GP->k3_gate_cv.wait_for(lk, std::chrono::milliseconds(50));
+		if(GP->wd_stop) break;
+		if(GP->k3_in_flight == 0) continue;
+		const double now = now_ms(), deadline = fixed_ms > 0.0 ? fixed_ms : std::max(20000.0, 40.0 * GP->wd_longest_ms);
+		bool late = false;
+		for(mm_align_s *q = GP; q; q = q->sib) { const double t0 = q->k3_t0.load(); if(t0 != 0.0 && now - t0 > deadline) late = true; }
+		if(!late) continue;
+		GP->wd_recovering = true;          /* (no new launch gets through the gate from here on) */
+		fprintf(stderr, "[minialign_amd] watchdog: an extension launch on device %d has not ended within %.1f s: it is called off with every other one in flight, and the batches run again in the safe mode\n", GP->dev, deadline * 1e-3);
+		k3_wd_census(GP, now);
+		for(mm_align_s *q = GP; q; q = q->sib) { if(q->k3_t0.load() != 0.0 && q->wd) { q->k3_called_off.store(true); __atomic_store_n(&q->wd[0], 1u, __ATOMIC_SEQ_CST); } }
+		const bool ended = GP->k3_gate_cv.wait_for(lk, std::chrono::seconds(60), [&]() { return GP->k3_in_flight == 0; });
+		if(!ended) {
+			k3_wd_census(GP, now_ms());
+			fprintf(stderr, "[minialign_amd] watchdog: the launch does not end after it was called off (a wave spins outside every wait): giving up\n");
+			fflush(stderr); _exit(86);
+		}
+		k3_wd_rings_dump_and_reset(GP);
+		for(mm_align_s *q = GP; q; q = q->sib) { if(q->wd) { memset(q->wd, 0, (K3_WD_HEAD + (size_t)GP->n_waves) * 4); } }
+		GP->safe_mode.store(true); GP->st.k3_aborts++;
+		GP->wd_recovering = false;
+		GP->k3_gate_cv.notify_all();
+	}
+}
+void k3_watchdog_start(mm_align_s *GP)
+{
+	std::lock_guard<std::mutex> lk(GP->k3_gate_mu);
+	if(GP->wd_running || getenv("MM_NO_K3_WATCHDOG")) return;
+	GP->wd_running = true; GP->wd_stop = false;
+	GP->wd_thread = std::thread(k3_watchdog_main, GP);
+}
+static void k3_watchdog_stop(mm_align_s *GP)
+{
+	{ std::lock_guard<std::mutex> lk(GP->k3_gate_mu); if(!GP->wd_running) return; GP->wd_stop = true; }
+	GP->k3_gate_cv.notify_all();
+	GP->wd_thread.join(); GP->wd_running = false;
 }
 
 } /* anonymous */
@@ -2282,6 +2404,8 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	if(a->pin_note) (void)hipHostFree(a->pin_note);
+	if(!a->is_sib) { k3_watchdog_stop(a); }
+	if(a->wd) { (void)hipHostFree(a->wd); a->wd = nullptr; }
 	free_chunk_pool(a->chunk_pool); a->chunk_pool = nullptr;
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
 	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < MM_SIDE) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
@@ -2309,7 +2433,7 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 			out->k3_cycles_fill += q.k3_cycles_fill; out->k3_cycles_leaf += q.k3_cycles_leaf; out->k3_cycles_trace += q.k3_cycles_trace; out->k3_cycles_total += q.k3_cycles_total;
 			out->k3_cycles_next += q.k3_cycles_next; out->k3_cycles_max += q.k3_cycles_max;             /* summed over launches; k3_waves stays the per-launch count */
 			out->k2_cycles_sort += q.k2_cycles_sort; out->k2_cycles_chain += q.k2_cycles_chain; out->k2_cycles_total += q.k2_cycles_total; out->k2_reads_hbm += q.k2_reads_hbm;
-			out->pool_grows += q.pool_grows; out->pool_regrows += q.pool_regrows; out->batch_splits += q.batch_splits; out->text_bytes += q.text_bytes; out->reader_ms += q.reader_ms;
+			out->pool_grows += q.pool_grows; out->pool_regrows += q.pool_regrows; out->batch_splits += q.batch_splits; out->text_bytes += q.text_bytes; out->reader_ms += q.reader_ms; out->k3_aborts += q.k3_aborts;
 		});
 	}
 	if(reset) { a->t_wall0 = now_ms(); each_context(a, [](mm_align_t *ln) { memset(&ln->st, 0, sizeof(ln->st)); }); }
@@ -2476,7 +2600,8 @@ bool batch_prepare(mm_align_t *a, Batch &b)
 	if(!b.packed) batch_pack(b);
 	return batch_upload(a, b);
 }
-/* the hot path over the uploaded batch; returns 0 ok, 1 device pools overflowed (caller grows and retries), -1 error */
+/* the hot path over the uploaded batch; returns 0 ok, 1 device pools overflowed (caller grows and retries), 2 an extension launch was called off by the watchdog (caller
+ * uploads the batch again and runs it again: batch_again), -1 error */
 /* the carried reference length: check what each read ran with (b.used) against the chain of values the reads actually
  * produce, starting from a->rlen_carry, and re-run the reads it changes until nothing moves.  0 ok, 1 overflow, -1 error */
 int batch_verify_carry(mm_align_t *a, Batch &b)
@@ -2505,7 +2630,7 @@ int batch_verify_carry(mm_align_t *a, Batch &b)
 			used[i] = redo_rlen[j];
 		}
 		if(!lane_h2d(a, a->d_st.p, hst.data(), n_reads * sizeof(ReadState))) return -1;
-		if(!run_rounds(a, n_reads, redo, true, hst, &redo_rlen, b.lens)) return -1;
+		if(!run_rounds(a, n_reads, redo, true, hst, &redo_rlen, b.lens)) return a->k3_called_off.load() ? 2 : -1;
 	}
 	return overflow ? 1 : 0;
 }
@@ -2516,7 +2641,7 @@ int batch_run_spec(mm_align_t *a, Batch &b)
 	const uint32_t n_reads = b.n;
 	std::vector<ReadState> &hst = b.hst;
 	a->ran_with.clear();
-	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return -1;
+	if(!run_rounds(a, n_reads, b.work, true, hst, nullptr, b.lens)) return a->k3_called_off.load() ? 2 : -1;
 	/* what every read ran with: the values handed out BEFORE the extension launch (run_rounds).  They must not be derived again from the reads' states afterwards: a read
 	 * that goes on to the next occurrence threshold is chained again inside the launch (k3_rescue_round) and then carries the prediction of THAT chaining in pred_rid,
 	 * while the reads behind it ran with the prediction of its first one -- derived afterwards, `used` then said what the reads should have run with, the check against
@@ -2574,6 +2699,7 @@ bool batch_run(mm_align_t *a, Batch &b)
 		int rc = batch_run_once(a, b);
 		if(rc < 0) return false;
 		if(rc == 0) return true;
+		if(rc == 2) { if(!batch_upload(a, b)) return false; continue; }          /* called off by the watchdog: again from the upload on */
 		/* a pool or a per-read cap overflowed: grow and redo the batch */
 		if(!batch_grow(a, b) || !batch_upload(a, b)) return false;
 	}
@@ -3564,7 +3690,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 				if(getenv("MM_TEST_SPLIT") && b.n >= 8) { split = true; }          /* test hook: take the path of a batch the pools cannot hold */
 				/* a batch whose pools the device cannot hold (at its size, or after they were grown): not the end of the stream -- its reads go in halves (map_split) */
 				if(!ok && b.n >= 2) { fprintf(stderr, "[minialign_amd] batch %u: its pools do not fit the device, mapped in halves\n", k); ok = true; split = true; }
-				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) { if(b.n >= 2) { split = true; } else { ok = false; } } }
+				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(r == 2) { if(!batch_upload(c, b)) ok = false; } else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) { if(b.n >= 2) { split = true; } else { ok = false; } } }
 				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): run %.1f ms (at %.1f): sketch %.1f, sort + chain %.1f, extension %.1f ms on the device, the rest the host's turns in between\n", k, di, li, now_ms() - tv, now_ms() - t_engine0, c->st.k1_ms - k1_0, c->st.k2_ms - k2_0, c->st.k3_ms - k3_0); tv = now_ms(); }
 				uint32_t truth = 0;
 				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return verified == k || rc != 0; }); if(rc) ok = false; truth = carry; }
@@ -3574,9 +3700,10 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 					if(r == 0) break;
 					/* an overflow among the re-runs: the whole batch again with larger pools, now with the true value from the start */
 					if(r < 0) { ok = false; break; }
-					if(!batch_grow(c, b)) { split = true; break; }
+					if(r != 2 && !batch_grow(c, b)) { split = true; break; }          /* (2: a re-run was called off by the watchdog -- the whole batch again as it is) */
 					if(!batch_upload(c, b)) { ok = false; break; }
 					r = batch_run_spec(c, b); if(r < 0) { ok = false; }
+					while(ok && r == 2) { if(!batch_upload(c, b)) { ok = false; break; } r = batch_run_spec(c, b); if(r < 0) { ok = false; } }
 				}
 				if(ok && split) {
 					/* the pools cannot hold this batch: its reads in halves on this lane, in order, with the true carried value; the text goes straight to the writer */
@@ -3720,7 +3847,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 	for(Item *it : fetched) { release(it->h); drop_item(it); }
 	if(rc == 0) { each_context(a, [carry](mm_align_t *q) { q->rlen_carry = carry; }); }
 	if(!a->head_off_closed && a->head_off.size() <= 4096) { a->head_off.push_back(written); }          /* a stream shorter than the head: its end */
-	for(auto &D : dv) D->P->streaming = false;
+	for(auto &D : dv) { D->P->streaming = false; D->P->safe_mode.store(false); }          /* (the safe mode the watchdog switched on lasts to the end of the stream) */
 	if(getenv("MM_VERBOSE")) { for(auto &D : dv) { (void)hipSetDevice(D->P->dev); size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot); fprintf(stderr, "[minialign_amd] device %d memory at the end of the stream: %.1f of %.1f GB free; %.1f GB held in recycled buffers\n", D->P->dev, fr / 1073741824.0, tot / 1073741824.0, dev_cache().held_on(D->P->dev) / 1073741824.0); } }
 	(void)hipSetDevice(cur_dev);
 	return rc;

@@ -7,7 +7,10 @@ with several threads the reference's own output depends on which thread buffer a
         (tools/samcheck.c: one primary record per read in input order, every CIGAR adds up to its read and stays inside its contig, ...), EVERY record of it against
         the compiled reference (all 446 956 reads: the reference maps the 16 parts of the set in eight -t1 processes side by side, two consecutive parts each, primed with
         the last reads of the part in front; a digest per part) (and, with MM_TEST_CONTEXTS_AT_SCALE set, the same set over 2 and 4 device contexts of ONE process identical to the single stream);
-  (iii) the hg38-size reference x ONT-like reads (3.1 Gb) with -xont.1dsq: properties of the whole stream, every record of it against the compiled reference likewise.
+  (iii) the hg38-size reference x ONT-like reads (3.1 Gb) with -xont.1dsq: properties of the whole stream, every record of it against the compiled reference likewise;
+  (iv)  a human-size reference with mammalian repeat structure (tools/gensim.c genomehard: 3.1 Gb, 25 contigs, 45 % repeats -- bench.py's `hg38hard` workload, the one whose
+        extension launch did not end in the driver's run of round 5) x PBSIM-like x1 (3.1 Gb, 148 967 reads): properties of the whole stream, every record of it against
+        the compiled reference likewise, and no word from the watchdog of the extension launches.
 
 The reference runs (index files, then the -t1 processes) go on in the background on host cores while the device maps.  Skipped where the compiled reference
 did not travel with the snapshot (it does with gpurun; /root/reference itself is never read here)."""
@@ -25,6 +28,7 @@ PARTS = 16
 SIZES = dict(dm6_genome=(0x5eed0001, 143700000, 1870, 0.05), dm6_reads=(0x5eed0002, 20.0, 'pacbio'), dm6_min_bases=2.7e9,          # the full x20 set (2.87 Gb), not a sample
              hg38_genome=(0x5eed0001, 3100000000, 25, 0.05), pb_reads=(0x5eed0002, 3.0, 'pacbio'), pb_min_bases=8.8e9, pb_min_bytes=12e9, pb_min_reads=440000,          # the whole 9.3 Gb set
              ont_reads=(0x5eed0003, 1.0, 'ont'), ont_min_bases=2.5e9, ont_min_reads=250000,          # the whole 3.1 Gb set
+             hg38hard_genome=(0x5eed0001, 3100000000, 25, 0.45), hg38hard_reads=(0x5eed0002, 1.0, 'pacbio'), hg38hard_min_bases=2.7e9, hg38hard_min_reads=140000,          # bench.py's hg38hard workload, whole
              hard_genome=(0x5eed0011, 400000000, 12, 0.45), hard_reads=(0x5eed0012, 1.0, 'pacbio'), hard_min_reads=19000, index_threads=32)
 # Several device contexts (or ranks) on the ONE GPU of a test box at FULL size: off unless asked for (MM_TEST_CONTEXTS_AT_SCALE=1).  Three gpurun boxes were lost in
 # round 4 while this file ran, 195 - 225 s into it: the fixture of the two human-size sets then started one 18 GB reference process per part for both sets at once, 32 of them,
@@ -190,8 +194,11 @@ def _hg38_sets(work):
     bg_pb = _reference_by_parts('pacbio', ref, rd, pb_spans, os.path.join(work, 'pb_ref'))
     _, ont_rd, ont_spans = _generate(work, 'hg38', genome, SIZES['ont_reads'], rd_tag='ont', keep_parts=True)
     bg_ont = _reference_by_parts('ont.1dsq', ref, ont_rd, ont_spans, os.path.join(work, 'ont_ref'), window=64 << 20, wait_for=bg_pb)
-    yield dict(ref=ref, rd=rd, ont=ont_rd, bg_pb=bg_pb, bg_ont=bg_ont)
-    for b in (bg_pb, bg_ont):
+    # (the hard-repeat human-size set: another reference, so another index file of the compiled reference -- built beside the sets in front, its 18 GB processes after them)
+    hard_ref, hard_rd, hard_spans = _generate(work, 'hg38hard', SIZES['hg38hard_genome'], SIZES['hg38hard_reads'], keep_parts=True, hard=True)
+    bg_hard = _reference_by_parts('pacbio', hard_ref, hard_rd, hard_spans, os.path.join(work, 'hard_ref'), wait_for=bg_ont)
+    yield dict(ref=ref, rd=rd, ont=ont_rd, bg_pb=bg_pb, bg_ont=bg_ont, hard_ref=hard_ref, hard_rd=hard_rd, bg_hard=bg_hard)
+    for b in (bg_pb, bg_ont, bg_hard):
         if b.poll() is None: b.kill()
 
 def test_hg38_size_x3_whole_set_equals_the_reference_and_device_contexts(work, hg38):
@@ -223,3 +230,18 @@ def test_hg38_size_ont_like_whole_set_equals_the_reference(work, hg38):
     bad = [p for p in range(PARTS) if got[p] != want[p]]
     assert not bad, 'hg38-size ONT-like set: parts %r differ from the compiled reference (ours %r, reference %r)' % (bad, [got[p] for p in bad], [want[p] for p in bad])
     assert sum(x[0] for x in want) == s['records'] and s['reads'] > SIZES['ont_min_reads']
+
+def test_hg38_size_hard_repeat_whole_set_equals_the_reference(work, hg38):
+    """bench.py's hg38hard workload (config.hard_repeats of the bench line), every read of it: 45 % repeats, reads that find 150 - 400 chains in their later
+    occurrence-threshold rounds (published as jobs inside the extension launch), 2.5 records per read"""
+    ref, rd = hg38['hard_ref'], hg38['hard_rd']
+    s, err, sec = _map_through_samcheck([CLI, '-xpacbio', ref, rd], rd, 0, os.devnull)
+    assert s['error'] == '' and s['reads'] == s['primary'] and s['contigs'] == SIZES['hg38hard_genome'][2], s
+    assert s['bases_mapped'] > SIZES['hg38hard_min_bases'] and s['reads'] > SIZES['hg38hard_min_reads'], s
+    assert b'watchdog' not in err, err.decode()[-3000:]          # (an extension launch that had to be called off would have been mapped again correctly -- but it must not happen)
+    assert hg38['bg_hard'].wait(timeout=1500) == 0, open(os.path.join(work, 'hard_ref.idx.err')).read()[-2000:]
+    want = _parts_of(os.path.join(work, 'hard_ref'), PARTS); got = [tuple(x) for x in s['parts']]
+    bad = [p for p in range(PARTS) if got[p] != want[p]]
+    assert not bad, 'hard-repeat human-size set: parts %r differ from the compiled reference (ours %r, reference %r)' % (bad, [got[p] for p in bad], [want[p] for p in bad])
+    assert sum(x[0] for x in want) == s['records']
+    sys.stderr.write('[headline] hard-repeat human-size set: %d reads, %d records (%.2f per read), %.1f s with the index build\n' % (s['reads'], s['records'], s['records'] / max(1, s['reads']), sec))
