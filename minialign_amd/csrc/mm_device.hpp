@@ -1666,7 +1666,11 @@ struct AlnRec {                /* what the host needs of a gaba_alignment_t (gab
 	uint32_t seg_off;          /* index into the segment pool */
 	uint64_t path_off;         /* word offset into the path pool; two header words {plen, 0x40000000} precede it (gaba.h:217) */
 };
-struct K3Class { uint8_t *slabs; uint64_t bytes; unsigned long long *ctr; uint32_t *ring; uint32_t n; uint32_t qmax; uint32_t next_base; uint32_t pad; };      /* ctr / ring as K3Args.ring_ctr / ring; next_base: first per-wave scratch number of the class */
+/* one class of DP workspaces as a launch sees it: `slabs` = every workspace of the class, numbered; two rings of free numbers per XCD (k3_ring_try / k3_ring_give) --
+ * the SHARED ring of the device (ctr / ring, n numbers per XCD: 0 .. 8 n - 1) that the launches of all lanes take from, and the PRIVATE ring of the lane that launches
+ * (pctr / pring, pn numbers per XCD: from 8 n on, the lane's own stretch).  A wave only ever WAITS for a number of its own launch's private ring: the waves of another
+ * launch sit on another hardware queue, and a queue can be switched out with everything its waves hold (the hang of round 5) */
+struct K3Class { uint8_t *slabs; uint64_t bytes; unsigned long long *ctr; uint32_t *ring; uint32_t n; uint32_t qmax; uint32_t pn; uint32_t pad; unsigned long long *pctr; uint32_t *pring; };
 struct K3Args {
 	DevIndex idx; gaba::Consts gc; const uint8_t *roots; gaba::SeqArena ar_ref, ar_q;
 	const ReadIn *in; ReadState *st; const uint32_t *work; uint32_t n_work;
@@ -1727,7 +1731,7 @@ struct K3Args {
 	uint32_t test_hang;                  /* test hook (MM_TEST_K3_HANG): the wave that takes entry test_hang - 1 of the work list waits for something that never comes */
 };
 enum : uint32_t { K3_WD_HEAD = 16,
-	K3_WD_TAKE = 1,          /* waiting for a DP workspace of its XCD's ring (detail: class << 24 | ticket) */
+	K3_WD_TAKE = 1,          /* looking for a DP workspace: none on offer on its XCD (detail: the class, for a wave that holds a read; bit 24 | the cursor of the work list for one that holds none) */
 	K3_WD_GIVE = 2,          /* giving a workspace back: the slot of its give ticket still holds the number of the turn before */
 	K3_WD_TRY = 3,           /* the take without waiting: the number of its ticket is on its way into the slot */
 	K3_WD_LDS = 4,           /* the tables of the rescue round (one set per workgroup) */
@@ -2131,60 +2135,42 @@ __device__ __attribute__((noinline)) uint32_t k3_room(ReadState *st, uint32_t ro
 	return 0;
 }
 /*
- * The rings of free DP workspaces (K3Args.cls: one ring of numbers per class and XCD; slot value ~0 = taken).  A take ticket t is served by give ticket t -- the ring starts
- * with its n numbers given --, so a waiting take waits for a wave that holds a workspace of the class to be done with it, and a give waits at most for the taker of its
- * slot's turn before to pick its number up.  Every wait ticks the watchdog (k3_wd_tick) and ends when the host calls the launch off.
+ * A ring of free DP workspace numbers (K3Class: a shared one per class, a private one per class and lane), one per XCD: ring[x * n ..] = numbers (~0 = taken),
+ * ctr[4 x + 0] = take tickets drawn, [4 x + 1] = give tickets drawn (the ring starts with its n numbers given), [4 x + 2] = numbers on offer.  Taking never waits for
+ * a workspace: a number is promised first (the counter of numbers on offer, a semaphore) and the ticket drawn only then, so that the one wait left is the short one for
+ * the number of that ticket to land in its slot (its giver has drawn the give ticket and is about to store).  A wave that finds nothing on offer goes on without, or
+ * looks again later (mm_extend_kernel: acquire) -- it holds no ticket and no place in any line, and can leave whenever it likes.  The L2s of different XCDs are not
+ * coherent inside a launch, so a workspace never wanders between them: a wave takes from and gives to the rings of the XCD it runs on.
  */
-/* a workspace of class c, waiting for one (NIL: the launch was called off) */
-__device__ __forceinline__ uint32_t k3_ring_take(const K3Class *cls, int c, uint32_t xcc, int lane, uint32_t *wdw, uint32_t wave, uint32_t &wst)
+__device__ __forceinline__ uint32_t k3_ring_try(unsigned long long *ctr, uint32_t *ring, uint32_t n, uint32_t xcc, int lane, uint32_t *wdw, uint32_t wave, uint32_t &wst)
 {
 	uint32_t v = 0xffffffffu;
-	if(lane == 0) {
-		unsigned long long *ctr = cls[c].ctr; uint32_t *rg = cls[c].ring; const uint32_t n = cls[c].n;
-		const unsigned long long t = atomicAdd(&ctr[2 * xcc], 1ull); uint32_t *slot = &rg[(uint64_t)xcc * n + (uint32_t)(t % n)];
-		while((v = atomicExch(slot, 0xffffffffu)) == 0xffffffffu) {          /* every workspace of this XCD in use: one comes back when a wave is done with it */
-			__builtin_amdgcn_s_sleep(16);
-			if(k3_wd_tick(wdw, wave, wst, K3_WD_TAKE, ((uint32_t)c << 24) | ((uint32_t)t & 0xffffffu))) { break; }
-		}
-		k3_wd_ran(wdw, wave, wst);
-	}
-	return (uint32_t)rdfirst((int)v);
-}
-/* workspace `no` of class c goes back */
-__device__ __forceinline__ void k3_ring_give(const K3Class *cls, int c, uint32_t xcc, uint32_t no, int lane, uint32_t *wdw, uint32_t wave, uint32_t &wst)
-{
-	if(lane == 0) {
-		unsigned long long *ctr = cls[c].ctr; uint32_t *rg = cls[c].ring; const uint32_t n = cls[c].n;
-		const unsigned long long t = atomicAdd(&ctr[2 * xcc + 1], 1ull); uint32_t *slot = &rg[(uint64_t)xcc * n + (uint32_t)(t % n)];
-		while(atomicCAS(slot, 0xffffffffu, no) != 0xffffffffu) {          /* (the taker of this slot's previous turn has not picked its number up yet) */
-			__builtin_amdgcn_s_sleep(4);
-			if(k3_wd_tick(wdw, wave, wst, K3_WD_GIVE, ((uint32_t)c << 24) | ((uint32_t)t & 0xffffffu))) { break; }
-		}
-		k3_wd_ran(wdw, wave, wst);
-	}
-}
-/* the same without waiting, for a wave that holds or is about to take somebody else's work: a workspace of class c if one is free on this XCD right now, else NIL.  A
- * ticket is drawn only while a give ticket is outstanding -- the number may still be on its way into the slot, which is a short wait, never one for a workspace that a
- * waiting wave holds (a failed compare-and-swap means another wave drew a ticket: somebody always gets on) */
-__device__ __forceinline__ uint32_t k3_ring_try(const K3Class *cls, int c, uint32_t xcc, int lane, uint32_t *wdw, uint32_t wave, uint32_t &wst)
-{
-	uint32_t v = 0xffffffffu;
-	if(lane == 0) {
-		unsigned long long *ctr = cls[c].ctr; uint32_t *rg = cls[c].ring; const uint32_t n = cls[c].n;
-		for(;;) {
-			const unsigned long long t = __hip_atomic_load(&ctr[2 * xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), g = __hip_atomic_load(&ctr[2 * xcc + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if(t >= g) { break; }
-			if(atomicCAS(&ctr[2 * xcc], t, t + 1ull) != t) { continue; }
-			uint32_t *slot = &rg[(uint64_t)xcc * n + (uint32_t)(t % n)];
-			while((v = atomicExch(slot, 0xffffffffu)) == 0xffffffffu) {
-				__builtin_amdgcn_s_sleep(4);
-				if(k3_wd_tick(wdw, wave, wst, K3_WD_TRY, ((uint32_t)c << 24) | ((uint32_t)t & 0xffffffu))) { break; }
+	if(lane == 0 && n != 0u) {
+		unsigned long long *c = ctr + 4u * xcc;
+		if((long long)atomicAdd(&c[2], ~0ull) <= 0ll) { atomicAdd(&c[2], 1ull); }          /* nothing on offer (the promise is handed back) */
+		else {
+			const unsigned long long t = atomicAdd(&c[0], 1ull); uint32_t *slot = &ring[(uint64_t)xcc * n + (uint32_t)(t % n)];
+			while((v = atomicExch(slot, 0xffffffffu)) == 0xffffffffu) {          /* (the number is on its way into the slot) */
+				__builtin_amdgcn_s_sleep(2);
+				if(k3_wd_tick(wdw, wave, wst, K3_WD_TRY, (uint32_t)t & 0xffffffu)) { break; }
 			}
 			k3_wd_ran(wdw, wave, wst);
-			break;
 		}
 	}
 	return (uint32_t)rdfirst((int)v);
+}
+__device__ __forceinline__ void k3_ring_give(unsigned long long *ctr, uint32_t *ring, uint32_t n, uint32_t xcc, uint32_t no, int lane, uint32_t *wdw, uint32_t wave, uint32_t &wst)
+{
+	if(lane == 0) {
+		unsigned long long *c = ctr + 4u * xcc;
+		const unsigned long long t = atomicAdd(&c[1], 1ull); uint32_t *slot = &ring[(uint64_t)xcc * n + (uint32_t)(t % n)];
+		while(atomicCAS(slot, 0xffffffffu, no) != 0xffffffffu) {          /* (the taker of this slot's previous turn has not picked its number up yet) */
+			__builtin_amdgcn_s_sleep(2);
+			if(k3_wd_tick(wdw, wave, wst, K3_WD_GIVE, (uint32_t)t & 0xffffffu)) { break; }
+		}
+		k3_wd_ran(wdw, wave, wst);
+		atomicAdd(&c[2], 1ull);
+	}
 }
 #ifdef MM_K3_NUM_VGPR
 __attribute__((amdgpu_num_vgpr(MM_K3_NUM_VGPR)))
@@ -2208,7 +2194,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	/* the watchdog's window (K3Args.wd): where this wave is, and the way out of every wait */
 	uint32_t *const wdw = (a.wd != nullptr && wave < a.wd_n) ? a.wd : nullptr; uint32_t wst = 0;
 	ReadState *cur_st = nullptr;          /* the read this wave holds (marked ERR_ABORT when the wave leaves a wait because the launch was called off) */
-	#define K3_LEAVE() { if(lane == 0 && cur_st != nullptr) { cur_st->err |= ERR_ABORT; } return; }
+	#define K3_LEAVE() { if(lane == 0) { if(cur_st != nullptr) { cur_st->err |= ERR_ABORT; } k3_wd_mark(wdw, wave, 0, 2); } return; }
 	Kh kh; kh.cap = a.kh_cap;
 	/* with shared workspaces a wave maps ONE read and ends (grid = reads / 4): wave slots then come free read by read, and the launches of the other lanes --
 	 * sketch, sort, chain, copies, the next extension launch -- get theirs within a read's time instead of waiting for a whole persistent launch to drain;
@@ -2229,25 +2215,38 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		x.slab = a.cls[c].slabs + (uint64_t)no * a.cls[c].bytes; x.cap = (uint32_t)a.cls[c].bytes; x.top = gaba::SLAB_HEAD;
 		for(uint32_t i = (uint32_t)lane; i < gaba::SLAB_HEAD / 4; i += 64) { ((uint32_t *)x.slab)[i] = ((const uint32_t *)a.roots)[i]; }
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		if(!persistent) { next = a.next_pool + (uint64_t)(no + a.cls[c].next_base) * MM_NEXT_STRIDE(a.next_cap); next_scratch = (uint32_t *)(next + a.next_cap); }
 	};
 	auto class_of = [&](uint32_t qlen) -> int { int want = 0; while(want + 1 < (int)a.n_cls && qlen > a.cls[want].qmax) { want++; } return want; };
-	/* the workspace a read of qlen bases needs: the smallest class that holds it; kept from read to read while the class stays.  false: the launch was called off */
-	auto need_slab = [&](uint32_t qlen) -> bool {
-		const int want = class_of(qlen);
+	/* the workspace this wave holds goes back to the ring it came from (numbers below 8 n: the shared one) */
+	auto give_slab = [&]() {
+		if(slab_cls < 0) { return; }
+		const K3Class &k = a.cls[slab_cls];
+		if(slab_no < 8u * k.n) { k3_ring_give(k.ctr, k.ring, k.n, xcc, slab_no, lane, wdw, wave, wst); }
+		else { k3_ring_give(k.pctr, k.pring, k.pn, xcc, slab_no, lane, wdw, wave, wst); }
+		slab_cls = -1;
+	};
+	/* A workspace of class `want`: one of the launch's own if there is one on offer, else one of the shared ones.  must = false: if there is none right now the wave goes on
+	 * with what it holds (a wave without a read, or about to take somebody else's work: it looks again later or does without -- never a line to stand in).  must = true: the
+	 * wave holds a read that needs the class; what it holds goes back first and it looks again until there is one -- the launch's own ring has at least one workspace of
+	 * every class per XCD, held by waves of this very launch, which are on this hardware queue and give theirs back when they change class or run out of reads.
+	 * false with called_off set: the watchdog ended the wait */
+	bool called_off = false;
+	auto acquire = [&](int want, bool must) -> bool {
 		if(want == slab_cls) { return true; }
-		if(slab_cls >= 0) { k3_ring_give(a.cls, slab_cls, xcc, slab_no, lane, wdw, wave, wst); slab_cls = -1; }
-		const uint32_t no = k3_ring_take(a.cls, want, xcc, lane, wdw, wave, wst);
-		if(no == 0xffffffffu) { return false; }
-		bind_slab(want, no); return true;
+		if(must) { give_slab(); }
+		const K3Class &k = a.cls[want];
+		for(;;) {
+			uint32_t no = k3_ring_try(k.pctr, k.pring, k.pn, xcc, lane, wdw, wave, wst);
+			if(no == 0xffffffffu) { no = k3_ring_try(k.ctr, k.ring, k.n, xcc, lane, wdw, wave, wst); }
+			if(no != 0xffffffffu) { give_slab(); bind_slab(want, no); return true; }
+			if(!must) { return false; }
+			__builtin_amdgcn_s_sleep(32);
+			uint32_t off = 0; if(lane == 0) { off = k3_wd_tick(wdw, wave, wst, K3_WD_TAKE, (uint32_t)want) ? 1u : 0u; }
+			if(rdfirst((int)off)) { called_off = true; return false; }
+		}
 	};
-	/* the same without waiting (k3_ring_try), for a wave that is about to take somebody else's work; the old workspace goes back after the new one is in hand */
-	auto try_slab = [&](int want) -> bool {
-		const uint32_t no = k3_ring_try(a.cls, want, xcc, lane, wdw, wave, wst);
-		if(no == 0xffffffffu) { return false; }
-		if(slab_cls >= 0) { k3_ring_give(a.cls, slab_cls, xcc, slab_no, lane, wdw, wave, wst); }
-		bind_slab(want, no); return true;
-	};
+	auto need_slab = [&](uint32_t qlen) -> bool { return acquire(class_of(qlen), true); };
+	auto try_slab = [&](int want) -> bool { return acquire(want, false); };
 	/* a job on the workspace this wave holds (the caller has made sure of its class): counters of the DP work go to this wave */
 	auto run_job = [&](const SpecJob &j, SpecMemo *mo_out, uint32_t *flag, uint32_t flag_val, int flag_in_memo) {
 		const uint32_t jr = (uint32_t)rdfirst((int)j.r), ja = (uint32_t)rdfirst((int)j.aid);
@@ -2282,7 +2281,6 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				/* (a class with a workspace for every wave an XCD can hold never makes anybody wait: the plain ticket, one atomic add -- the compare-and-swap of the other form,
 				 * with a thousand waves of an XCD at the same counter when the launch starts, is what a first version with a bounded number of attempts failed on: nearly every
 				 * job of an E.coli-size set was handed back, 182 -> 211 ms per step) */
-				if(!have && a.cls[want].n >= a.full_n) { if(!need_slab(qlen)) { K3_LEAVE(); } have = true; }
 				if(!have) { have = try_slab(want); }
 				if(!have) { if(lane == 0) { __hip_atomic_store(&a.memo[ji].state, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } continue; }
 			}
@@ -2351,7 +2349,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					run_job(a.rjobs[ji], a.rmemo + ji, a.rstate + ji, (uint32_t)RJ_DONE, 0);
 					__builtin_amdgcn_s_setprio(0); rq_mine = 0xffffffffu; idle = 0;
 					/* a workspace of a class above the ordinary one goes back at once: the classes are small, and a wave that sat on one between jobs could be what a read is waiting for */
-					if(slab_cls >= 1) { k3_ring_give(a.cls, slab_cls, xcc, slab_no, lane, wdw, wave, wst); slab_cls = -1; }
+					if(slab_cls >= 1) { give_slab(); }
 					continue;
 				}
 				if(ji != 0xffffffffu && stt != RJ_EMPTY) { rq_mine = 0xffffffffu; idle = 0; continue; }          /* taken by its owner, done or cancelled: the next one */
@@ -2370,22 +2368,36 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		cur_st = nullptr;
 		if(wdw != nullptr) { uint32_t off = 0; if(lane == 0) { off = __hip_atomic_load(&wdw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } if(rdfirst((int)off)) { return; } }          /* (called off: no more reads) */
 		uint32_t wi = wave;
-		if(persistent && a.n_cls > 1 && a.ring) {
-			/* several workspace classes: a read of the highest class that has reads left AND a workspace at hand (held already, or free on this XCD right now); else one of
-			 * the ordinary class; when that is used up, what is left above it, waiting for a workspace as need be */
+		if(a.ring) {
+			/* The work list by workspace class (K3Args.seg_*; one class: everything in [0]).  A read of the highest class above the ordinary one that has reads left AND a
+			 * workspace at hand (held already, or on offer on this XCD right now); else one of the ordinary class -- the workspace FIRST, then the read: a wave that finds no
+			 * workspace on offer holds nothing anybody could wait for, looks again while reads of the class are left, and ends when they are gone (the waves of the launch
+			 * that hold its own workspaces work the list off whatever the rest of the device does); when the ordinary class is used up, what is left above it: the read
+			 * first, then its workspace, waiting for one of the launch's own as need be */
 			wi = 0xffffffffu;
 			for(int c = (int)a.n_cls - 1; c >= 1 && wi == 0xffffffffu; c--) {
 				const uint32_t len = a.seg_len[c];
 				if(len == 0) { continue; }
 				uint32_t cur = 0; if(lane == 0) { cur = __hip_atomic_load(&a.seg_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } cur = (uint32_t)rdfirst((int)cur);
 				if(cur >= len) { continue; }
-				bool have = slab_cls == c;
-				if(!have) { have = try_slab(c); }
-				if(!have) { continue; }
+				if(!try_slab(c)) { continue; }
 				uint32_t i = 0; if(lane == 0) { i = atomicAdd(&a.seg_cnt[c], 1u); } i = (uint32_t)rdfirst((int)i);
 				if(i < len) { wi = a.seg_beg[c] + i; }
 			}
-			if(wi == 0xffffffffu) { uint32_t i = 0; if(lane == 0) { i = atomicAdd(&a.seg_cnt[0], 1u); } i = (uint32_t)rdfirst((int)i); if(i < a.seg_len[0]) { wi = a.seg_beg[0] + i; } }
+			if(wi == 0xffffffffu && a.seg_len[0] != 0u) {
+				bool have0 = slab_cls == 0;
+				while(!have0) {
+					uint32_t cur = 0; if(lane == 0) { cur = __hip_atomic_load(&a.seg_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } cur = (uint32_t)rdfirst((int)cur);
+					if(cur >= a.seg_len[0]) { break; }
+					have0 = try_slab(0);
+					if(have0) { break; }
+					__builtin_amdgcn_s_sleep(64);
+					uint32_t off = 0; if(lane == 0) { off = k3_wd_tick(wdw, wave, wst, K3_WD_TAKE, 0x1000000u | (cur & 0xffffffu)) ? 1u : 0u; }
+					if(rdfirst((int)off)) { K3_LEAVE(); }
+				}
+				if(lane == 0) { k3_wd_ran(wdw, wave, wst); }
+				if(have0) { uint32_t i = 0; if(lane == 0) { i = atomicAdd(&a.seg_cnt[0], 1u); } i = (uint32_t)rdfirst((int)i); if(i < a.seg_len[0]) { wi = a.seg_beg[0] + i; } }
+			}
 			for(int c = (int)a.n_cls - 1; c >= 1 && wi == 0xffffffffu; c--) {
 				if(a.seg_len[c] == 0) { continue; }
 				uint32_t i = 0; if(lane == 0) { i = atomicAdd(&a.seg_cnt[c], 1u); } i = (uint32_t)rdfirst((int)i);
@@ -2433,7 +2445,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		if(wi < (a.n_work >> 6) || a.n_work < 64) { __builtin_amdgcn_s_setprio(3); }          /* (a launch of a few reads is a re-run for the carried value: its lane, and the lanes behind it, wait for it) */ else if(n_root >= 5) { __builtin_amdgcn_s_setprio(1); } else { __builtin_amdgcn_s_setprio(0); }
 		const uint32_t qlen = (uint32_t)rdfirst((int)a.in[r].qlen);
 		const uint64_t q_off = rdfirst64(a.in[r].q_off);
-		if(a.ring) { if(!need_slab(qlen)) { K3_LEAVE(); } }
+		if(a.ring) { if(!need_slab(qlen)) { K3_LEAVE(); } }          /* (false only when the launch was called off; the class the read needs: held already unless the read came from what was left above the ordinary class) */
 		const unsigned long long cy_slab = MM_TICK();
 		Seed *s = a.seed_pool + rdfirst64(st->seed_off);
 		Root *root = a.root_pool + rdfirst64(st->root_off);
@@ -2911,7 +2923,8 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		atomicAdd(&a.stats[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));
 		atomicMax(&a.stats[9], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin));      /* longest-living wave: load balance */
 	}
-	if(a.ring && slab_cls >= 0) { k3_ring_give(a.cls, slab_cls, xcc, slab_no, lane, wdw, wave, wst); }
+	if(a.ring) { give_slab(); }
+	if(lane == 0) { k3_wd_mark(wdw, wave, 0, 1); }
 	#undef K3_LEAVE
 }
 

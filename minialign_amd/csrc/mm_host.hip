@@ -1219,7 +1219,8 @@ struct mm_align_s {
 	bool shared_slabs = false; DBuf<uint32_t> slab_ring; DBuf<unsigned long long> slab_ring_ctr; uint32_t slab_ring_n = 0;
 	/* the classes above the ordinary one (reads of more than 32 k bases), when the input has a long tail of lengths; h_cls[0] describes slabs / slab_ring */
 	static const uint32_t MAX_CLS = 8;
-	DBuf<uint8_t> xslabs[MAX_CLS]; DBuf<uint32_t> xring[MAX_CLS]; DBuf<unsigned long long> xctr[MAX_CLS]; std::vector<K3Class> h_cls; DBuf<K3Class> d_cls; uint32_t slab_total = 0; uint64_t slab_max = 0;
+	DBuf<uint8_t> xslabs[MAX_CLS]; DBuf<uint32_t> xring[MAX_CLS]; DBuf<unsigned long long> xctr[MAX_CLS]; std::vector<K3Class> h_cls; DBuf<K3Class> d_cls;          /* h_cls: the classes as lane 0 sees them; d_cls: slab_lanes tables of h_cls.size() entries, one per lane (its own rings) */
+	DBuf<uint32_t> pring[MAX_CLS]; DBuf<unsigned long long> pctr[MAX_CLS]; uint32_t slab_lanes = 0; int lane_ix = 0;          /* the lanes' own rings of every class (K3Class.pring / pctr: lane-major); lanes the workspaces were made for; this context's place among the lanes of its device */ uint32_t slab_total = 0; uint64_t slab_max = 0;
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
 	/* reusable host buffers of the streaming engine (primary context only): pinned result buffers for the D2H of a batch, text pieces with their capacity */
@@ -1611,7 +1612,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.ring = nullptr; k3.ring_ctr = nullptr; k3.ring_n = 0;
 		k3.cls = nullptr; k3.n_cls = 0;
 		{ const mm_align_s *P = a->root ? a->root : a; if(P->shared_slabs) { k3.slabs = P->slabs.p; k3.slab_bytes = P->slab_stride; k3.ring = P->slab_ring.p; k3.ring_ctr = P->slab_ring_ctr.p; k3.ring_n = P->slab_ring_n;
-			k3.cls = P->d_cls.p; k3.n_cls = (uint32_t)P->h_cls.size(); } }
+			k3.n_cls = (uint32_t)P->h_cls.size(); k3.cls = P->d_cls.p + (size_t)std::min<uint32_t>((uint32_t)a->lane_ix, P->slab_lanes - 1) * k3.n_cls; } }
 		k3.kh_pool = a->kh_pool.p; k3.kh_cap = a->kh_cap; k3.kh_top = tops + 7; k3.kh_base = (uint64_t)n_reads * a->kh_cap; k3.kh_pool_cap = a->kh_pool.n; k3.round = round; k3.next_pool = a->next_pool.p; k3.next_cap = a->next_cap;
 		k3.bin_pool = a->bin_pool.p; k3.bin_pool_cap = a->bin_pool.n; k3.bin_top = tops + 3; k3.bin_cap_per_read = a->bin_cap;
 		k3.aln_pool = a->aln_pool.p; k3.aln_pool_cap = a->aln_pool.n; k3.aln_top = tops + 4; k3.aln_cap_per_read = a->aln_cap;
@@ -1697,7 +1698,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		 * the device can hold): grid = reads / 4, a wave maps one read and ends -- wave slots then come free read by read for the other lanes' launches; measured
 		 * no faster on the headline workload (2.86 against 2.77 s per step with the rounds in the kernel, 3.7 against 3.2 without), kept as an experiment */
 		k3.persistent = 1;
-		if(k3.ring) { if((uint64_t)k3.ring_n * 8 >= a->n_waves && getenv("MM_K3_ONE_READ_PER_WAVE")) { k3.persistent = 0; waves = (uint32_t)((k3.n_work + 3) & ~3u); } else { waves = std::min<uint32_t>(waves, (k3.ring_n * 8u) & ~3u); } }
+		if(k3.ring) { waves = std::min<uint32_t>(waves, (k3.ring_n * 8u) & ~3u); }          /* (never more waves than the shared ring and the lane's own hold workspaces of the ordinary class) */
 		const int k3_conc = safe ? 1 : (getenv("MM_K3_CONCURRENT") ? std::max(1, atoi(getenv("MM_K3_CONCURRENT"))) : 0);
 		mm_align_s *GP = GPw;
 		/* the watchdog's window into this launch (k3_watchdog_main): where every wave is, and the word that calls the launch off */
@@ -2036,7 +2037,7 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 	}
 }
 
-bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen);
+bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen, uint32_t lanes);
 /* minimizer records a read gets room for, per base: at most one per position; 2 / (w + 1) per base on average, so 4 / (w + 1) is ample for all but the reads inside low-complexity sequence (w = 10: 0.36; a run of one repeated k-mer emits a minimizer per base); a read whose
  * hashes keep falling emits one per position: after an overflow the batch is redone with room for that (scale > 1) */
 inline double min_cap_frac(uint32_t w, uint64_t scale) { return (scale > 1 || getenv("MM_POOLS_BY_CAP")) ? ((w < 4 || scale > 1) ? 1.0 : 0.5) : std::min(1.0, 4.0 / ((double)w + 1.0)); }
@@ -2095,7 +2096,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	if(P->shared_slabs) {
 		/* the engine sized the shared workspaces for the longest read of the input before the lanes started */
 		/* outside the streaming engine nothing is in flight on the context (the per-call entries after a stream): the workspaces are simply sized again */
-		if(P->slab_max < slab && !P->streaming) { ok &= ensure_shared_slabs(P, max_qlen); }
+		if(P->slab_max < slab && !P->streaming) { ok &= ensure_shared_slabs(P, max_qlen, P->slab_lanes); }
 		if(P->slab_max < slab) { fprintf(stderr, "[minialign_amd] a read longer than announced (%u bases) does not fit the shared DP workspaces\n", max_qlen); ok = false; }
 		a->k3_waves = lane_waves & ~3u;
 	}
@@ -2104,59 +2105,84 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	ok &= a->d_tops.ensure(40); ok &= a->d_k2cnt.ensure(48);
 	return ok;
 }
-/* one set of DP workspaces for all lanes of a context (the streaming engine calls this before its lane threads start, with the longest read of the input):
- * as many as waves can be resident (n_waves), fewer when MM_SLAB_GB (default 64) says so -- waves then wait for one to come back */
-/* a ring of free workspace numbers as it stands before anything has been taken: every number in its slot, take tickets at 0, give tickets at `per` (K3Args.ring) */
-static bool ring_fill(uint32_t *ring, unsigned long long *ctr, uint32_t per, uint32_t n_xcd)
+/* A ring of free workspace numbers as it stands before anything has been taken (k3_ring_try / k3_ring_give): per XCD x the numbers base + x * per .. in their slots,
+ * take tickets at 0, give tickets and numbers on offer at `per` */
+static bool ring_fill(uint32_t *ring, unsigned long long *ctr, uint32_t per, uint32_t n_xcd, uint32_t base)
 {
-	std::vector<uint32_t> r((size_t)per * n_xcd); for(size_t i = 0; i < r.size(); i++) r[i] = (uint32_t)i;
-	std::vector<unsigned long long> c(2 * n_xcd); for(uint32_t x = 0; x < n_xcd; x++) { c[2 * x] = 0; c[2 * x + 1] = per; }
+	if(per == 0) return true;
+	std::vector<uint32_t> r((size_t)per * n_xcd); for(size_t i = 0; i < r.size(); i++) r[i] = base + (uint32_t)i;
+	std::vector<unsigned long long> c(4 * n_xcd, 0ull); for(uint32_t x = 0; x < n_xcd; x++) { c[4 * x + 1] = per; c[4 * x + 2] = per; }
 	return hipMemcpy(ring, r.data(), r.size() * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(ctr, c.data(), c.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
 }
-bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
+/* every ring of the context as new (after the workspaces were made, and after the watchdog has called launches off: a wave that left a wait may have drawn a ticket) */
+static bool rings_reset(mm_align_s *P)
+{
+	const uint32_t n_xcd = 8; bool ok = true;
+	for(size_t c = 0; c < P->h_cls.size(); c++) {
+		const K3Class &k = P->h_cls[c];
+		ok &= ring_fill(k.ring, k.ctr, k.n, n_xcd, 0);
+		for(uint32_t l = 0; l < P->slab_lanes; l++) ok &= ring_fill(k.pring + (size_t)l * n_xcd * k.pn, k.pctr + (size_t)l * n_xcd * 4, k.pn, n_xcd, n_xcd * k.n + l * n_xcd * k.pn);
+	}
+	return ok;
+}
+/*
+ * The DP workspaces of a context, for `lanes` lanes (the streaming engine calls this before its lane threads start, with the longest read of the input).  Per class of
+ * read lengths one allocation and, per XCD, a SHARED ring of free numbers that the launches of all lanes take from plus one PRIVATE ring per lane (K3Class).  The
+ * ordinary class (reads up to 32 k bases): 3/4 of a workspace per wave the device can hold in the shared ring and one wave per SIMD's worth in every lane's own -- a
+ * launch alone reaches its five waves per SIMD, two launches fill the device, as when all of them were shared (rounds 2-5) --, fewer when MM_SLAB_GB (default 64) says
+ * so.  What the private rings are for: a wave may only WAIT for a workspace that waves of its own launch hold.
+ */
+bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen, uint32_t lanes)
 {
 	auto slab_of = [](uint32_t qlen) -> uint64_t { const uint64_t blocks = 2 * ((2ull * qlen + 8192) / 32 + 64); return (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull; };
-	auto fill_ring = [](DBuf<uint32_t> &ring, DBuf<unsigned long long> &ctr, uint32_t per, uint32_t n_xcd) -> bool {
-		if(!ring.ensure((uint64_t)per * n_xcd) || !ctr.ensure(2 * n_xcd)) return false;
-		return ring_fill(ring.p, ctr.p, per, n_xcd);
-	};
 	max_qlen = (std::max(max_qlen, P->qlen_hint) + 8191u) & ~8191u;
+	lanes = std::max<uint32_t>(1, std::max(lanes, P->slab_lanes));
 	const uint64_t budget = (getenv("MM_SLAB_GB") ? (uint64_t)atoll(getenv("MM_SLAB_GB")) : 64ull) << 30;
 	const uint32_t n_xcd = 8;
-	/* reads up to 32 k bases (the PacBio-like sets whole, nine tenths of an ONT-like one) take the ordinary class, one workspace for every wave the device can hold if
-	 * the budget allows (MM_SLAB_GB, default 64); a longer maximum adds classes of 64 k, 128 k, ... bases up to it, each with a share of the budget of its own (below) */
+	/* reads up to 32 k bases (the PacBio-like sets whole, nine tenths of an ONT-like one) take the ordinary class; a longer maximum adds classes of 64 k, 128 k, ... bases
+	 * up to it, each with a share of the budget of its own (below) */
 	const uint32_t q_small = 32768;
 	std::vector<uint32_t> qmax;
 	if(max_qlen > q_small && !getenv("MM_ONE_SLAB_CLASS")) {
 		for(uint32_t q = q_small; ; q *= 2) { if(q >= max_qlen || qmax.size() + 1 == mm_align_s::MAX_CLS) { qmax.push_back(max_qlen); break; } qmax.push_back(q); }
-		if(getenv("MM_TWO_SLAB_CLASSES")) { qmax.resize(1); qmax.push_back(max_qlen); }
 	} else { qmax.push_back(max_qlen); }
-	std::vector<uint64_t> bytes(qmax.size()); std::vector<uint32_t> per(qmax.size());
+	std::vector<uint64_t> bytes(qmax.size()); std::vector<uint32_t> per(qmax.size()), pn(qmax.size()), sn(qmax.size());
 	for(size_t c = 0; c < qmax.size(); c++) {
 		bytes[c] = slab_of(qmax[c]);
-		if(c == 0) { per[c] = (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(32, budget / bytes[c] / n_xcd)); continue; }
-		/* a quarter of the budget each for the two classes above the ordinary one, an eighth for every class above those.  The waves a class needs go with the share of the
-		 * DP work in its reads -- on the ONT-like set 17 % in 32 - 64 kb, 7 % in 64 - 128 kb, 1 % above -- and more at the start of a launch, where the long reads are; with
-		 * 8 GB for the 64 - 128 kb class (320 workspaces for the 2 164 such reads of a step on four lanes) its reads spent four fifths of their wave time waiting for one */
-		const uint64_t share = c <= 2 ? budget / 4 : budget / 8;
-		per[c] = (uint32_t)std::min<uint64_t>(P->n_waves / n_xcd, std::max<uint64_t>(4, share / bytes[c] / n_xcd));
+		const uint32_t full = P->n_waves / n_xcd;          /* a workspace for every wave an XCD can hold */
+		if(c == 0) { per[c] = (uint32_t)std::min<uint64_t>(full + full / 4, std::max<uint64_t>(32, budget / bytes[c] / n_xcd)); }
+		else {
+			/* a quarter of the budget each for the two classes above the ordinary one, an eighth for every class above those.  The waves a class needs go with the share of the
+			 * DP work in its reads -- on the ONT-like set 17 % in 32 - 64 kb, 7 % in 64 - 128 kb, 1 % above -- and more at the start of a launch, where the long reads are; with
+			 * 8 GB for the 64 - 128 kb class (320 workspaces for the 2 164 such reads of a step on four lanes) its reads spent four fifths of their wave time waiting for one */
+			const uint64_t share = c <= 2 ? budget / 4 : budget / 8;
+			per[c] = (uint32_t)std::min<uint64_t>(full, std::max<uint64_t>(4, share / bytes[c] / n_xcd));
+		}
+		/* half of a class in the lanes' own rings (the ordinary class: at most a wave per SIMD per lane), the rest shared */
+		pn[c] = std::max<uint32_t>(1, per[c] / (2 * lanes)); if(c == 0) pn[c] = std::min<uint32_t>(pn[c], std::max<uint32_t>(1, full / 8));
+		sn[c] = per[c] > lanes * pn[c] ? per[c] - lanes * pn[c] : 0;
 	}
-	bool same = P->shared_slabs && P->h_cls.size() == qmax.size();
-	for(size_t c = 0; same && c < qmax.size(); c++) same = P->h_cls[c].bytes >= bytes[c] && P->h_cls[c].n >= per[c] && (c + 1 == qmax.size() || P->h_cls[c].qmax == qmax[c]);
+	bool same = P->shared_slabs && P->h_cls.size() == qmax.size() && P->slab_lanes >= lanes;
+	for(size_t c = 0; same && c < qmax.size(); c++) same = P->h_cls[c].bytes >= bytes[c] && P->h_cls[c].n >= sn[c] && P->h_cls[c].pn >= pn[c] && (c + 1 == qmax.size() || P->h_cls[c].qmax == qmax[c]);
 	if(same) return true;
 	/* (re)allocation: only between runs -- nothing is in flight when the engine calls */
 	if(hipDeviceSynchronize() != hipSuccess) return false;
-	P->h_cls.clear(); P->slab_total = 0; P->slab_max = 0;
+	P->h_cls.clear(); P->slab_total = 0; P->slab_max = 0; P->slab_lanes = lanes;
 	for(size_t c = 0; c < qmax.size(); c++) {
 		DBuf<uint8_t> &sl = c ? P->xslabs[c] : P->slabs; DBuf<uint32_t> &rg = c ? P->xring[c] : P->slab_ring; DBuf<unsigned long long> &ct = c ? P->xctr[c] : P->slab_ring_ctr;
-		if(!sl.ensure(bytes[c] * per[c] * n_xcd) || !fill_ring(rg, ct, per[c], n_xcd)) return false;
-		K3Class k; k.slabs = sl.p; k.bytes = bytes[c]; k.ctr = ct.p; k.ring = rg.p; k.n = per[c]; k.qmax = qmax[c]; k.next_base = P->slab_total; k.pad = 0;
-		P->h_cls.push_back(k); P->slab_total += per[c] * n_xcd; P->slab_max = bytes[c];
+		const uint64_t total = (uint64_t)(sn[c] + lanes * pn[c]) * n_xcd;
+		if(!sl.ensure(bytes[c] * total) || !rg.ensure(std::max<uint64_t>(1, (uint64_t)sn[c] * n_xcd)) || !ct.ensure(4 * n_xcd) || !P->pring[c].ensure((uint64_t)lanes * pn[c] * n_xcd) || !P->pctr[c].ensure((uint64_t)lanes * 4 * n_xcd)) return false;
+		K3Class k; k.slabs = sl.p; k.bytes = bytes[c]; k.ctr = ct.p; k.ring = rg.p; k.n = sn[c]; k.qmax = qmax[c]; k.pn = pn[c]; k.pad = 0; k.pctr = P->pctr[c].p; k.pring = P->pring[c].p;
+		P->h_cls.push_back(k); P->slab_total += (uint32_t)total; P->slab_max = bytes[c];
 	}
-	for(size_t c = qmax.size(); c < mm_align_s::MAX_CLS; c++) { if(c) { P->xslabs[c].release(); P->xring[c].release(); P->xctr[c].release(); } }
-	if(!P->d_cls.ensure(P->h_cls.size()) || hipMemcpy(P->d_cls.p, P->h_cls.data(), P->h_cls.size() * sizeof(K3Class), hipMemcpyHostToDevice) != hipSuccess) return false;
-	P->slab_stride = bytes[0]; P->slab_ring_n = per[0]; P->k3_waves = P->n_waves;
-	if(getenv("MM_VERBOSE_SLABS")) { for(auto &k : P->h_cls) fprintf(stderr, "[minialign_amd] workspace class: reads up to %u bases, %u x %.1f MB\n", k.qmax, k.n * n_xcd, k.bytes / 1048576.0); }
+	for(size_t c = qmax.size(); c < mm_align_s::MAX_CLS; c++) { if(c) { P->xslabs[c].release(); P->xring[c].release(); P->xctr[c].release(); } P->pring[c].release(); P->pctr[c].release(); }
+	if(!rings_reset(P)) return false;
+	/* the table of classes as each lane's launches see it: the lane's own rings */
+	std::vector<K3Class> tab;
+	for(uint32_t l = 0; l < lanes; l++) for(size_t c = 0; c < P->h_cls.size(); c++) { K3Class k = P->h_cls[c]; k.pring += (size_t)l * n_xcd * k.pn; k.pctr += (size_t)l * n_xcd * 4; tab.push_back(k); }
+	if(!P->d_cls.ensure(tab.size()) || hipMemcpy(P->d_cls.p, tab.data(), tab.size() * sizeof(K3Class), hipMemcpyHostToDevice) != hipSuccess) return false;
+	P->slab_stride = bytes[0]; P->slab_ring_n = sn[0] + pn[0]; P->k3_waves = P->n_waves;
+	if(getenv("MM_VERBOSE_SLABS")) { for(auto &k : P->h_cls) fprintf(stderr, "[minialign_amd] workspace class: reads up to %u bases, %u shared + %u x %u of the lanes' own, %.1f MB each\n", k.qmax, k.n * n_xcd, lanes, k.pn * n_xcd, k.bytes / 1048576.0); }
 	P->shared_slabs = true;
 	return true;
 }
@@ -2173,7 +2199,7 @@ bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen)
  */
 static const char *k3_wd_site(uint32_t s)
 {
-	static const char *nm[16] = { "not started / ended", "waits for a DP workspace (take)", "gives a DP workspace back (slot busy)", "takes a DP workspace without waiting (number on its way)", "waits for the tables of its workgroup (rescue round)",
+	static const char *nm[16] = { "not started / ended", "looks for a DP workspace (none on offer on its XCD)", "gives a DP workspace back (slot busy)", "takes a DP workspace without waiting (number on its way)", "waits for the tables of its workgroup (rescue round)",
 		"waits for the carried value of the read in front", "waits for a chain job of before the launch", "waits for a chain job another wave claimed", "waits for a retry job another wave claimed", "without reads, looking for jobs",
 		"TEST HOOK: waits for nothing", "?", "?", "runs a job", "at work again after a wait", "at work on a read" };
 	return nm[s & 15];
@@ -2191,7 +2217,7 @@ static void k3_wd_census(mm_align_s *GP, double now)
 		for(int sidx = 0; sidx < 16; sidx++) {
 			if(!cnt[sidx]) continue;
 			fprintf(stderr, "[minialign_amd] watchdog:   %5u wave(s): %s", cnt[sidx], k3_wd_site((uint32_t)sidx));
-			if(sidx != 0) { fprintf(stderr, "; e.g."); for(size_t i = 0; i + 1 < ex[sidx].size(); i += 2) { const uint32_t d = ex[sidx][i + 1]; if(sidx >= 1 && sidx <= 3) fprintf(stderr, " wave %u (class %u, ticket ..%u)", ex[sidx][i], d >> 24, d & 0xffffffu); else fprintf(stderr, " wave %u (%u)", ex[sidx][i], d); } }
+			if(sidx != 0) { fprintf(stderr, "; e.g."); for(size_t i = 0; i + 1 < ex[sidx].size(); i += 2) { const uint32_t d = ex[sidx][i + 1]; if(sidx == 1 && (d & 0x1000000u)) fprintf(stderr, " wave %u (holds no read; work list at %u)", ex[sidx][i], d & 0xffffffu); else if(sidx == 1) fprintf(stderr, " wave %u (holds a read of class %u)", ex[sidx][i], d); else fprintf(stderr, " wave %u (%u)", ex[sidx][i], d); } }
 			fprintf(stderr, "\n");
 		}
 	}
@@ -2201,14 +2227,20 @@ static void k3_wd_rings_dump_and_reset(mm_align_s *GP)
 	const uint32_t n_xcd = 8;
 	for(size_t c = 0; c < GP->h_cls.size(); c++) {
 		const K3Class &k = GP->h_cls[c];
-		std::vector<unsigned long long> ctr(2 * n_xcd);
+		std::vector<unsigned long long> ctr(4 * n_xcd);
 		if(hipMemcpy(ctr.data(), k.ctr, ctr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-			fprintf(stderr, "[minialign_amd] watchdog: workspace class %zu (reads up to %u bases, %u per XCD): takes / gives beyond the first %u, per XCD:", c, k.qmax, k.n, k.n);
-			for(uint32_t x = 0; x < n_xcd; x++) fprintf(stderr, " %llu/%llu", ctr[2 * x], ctr[2 * x + 1] - k.n);
+			fprintf(stderr, "[minialign_amd] watchdog: workspace class %zu (reads up to %u bases), shared ring of %u per XCD: taken / given back / on offer, per XCD:", c, k.qmax, k.n);
+			for(uint32_t x = 0; x < n_xcd; x++) fprintf(stderr, " %llu/%llu/%lld", ctr[4 * x], ctr[4 * x + 1] - k.n, (long long)ctr[4 * x + 2]);
 			fprintf(stderr, "\n");
 		}
-		if(!ring_fill(k.ring, k.ctr, k.n, n_xcd)) fprintf(stderr, "[minialign_amd] watchdog: the ring of workspace class %zu could not be set up again\n", c);
+		for(uint32_t l = 0; l < GP->slab_lanes; l++) {
+			if(hipMemcpy(ctr.data(), k.pctr + (size_t)l * n_xcd * 4, ctr.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) continue;
+			fprintf(stderr, "[minialign_amd] watchdog:   lane %u's own ring of %u per XCD:", l, k.pn);
+			for(uint32_t x = 0; x < n_xcd; x++) fprintf(stderr, " %llu/%llu/%lld", ctr[4 * x], ctr[4 * x + 1] - k.pn, (long long)ctr[4 * x + 2]);
+			fprintf(stderr, "\n");
+		}
 	}
+	if(!rings_reset(GP)) fprintf(stderr, "[minialign_amd] watchdog: the workspace rings could not be set up again\n");
 }
 static void k3_watchdog_main(mm_align_s *GP)
 {
@@ -2400,7 +2432,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 		gaba_clean(a->gctx);
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
-	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
+	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); a->pring[c].release(); a->pctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
 	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	if(a->pin_note) (void)hipHostFree(a->pin_note);
@@ -2940,6 +2972,7 @@ static mm_align_t *align_lane(mm_align_t *a)
 	q->qlen_hint = a->qlen_hint; q->k2_leaf_shift = a->k2_leaf_shift; q->bin_cap = a->bin_cap; q->aln_cap = a->aln_cap; q->kh_cap = a->kh_cap; q->next_cap = a->next_cap; q->rs_stride = a->rs_stride;
 	if(!make_streams(q)) { delete q; return NULL; }
 	memset(&q->st, 0, sizeof(q->st)); q->t_wall0 = now_ms();
+	q->lane_ix = a->lane_ix + 1;
 	a->sib = q;
 	return q;
 }
@@ -3623,7 +3656,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 	if(!getenv("MM_NO_SHARED_SLABS")) {
 		/* the shared DP workspaces of every device, side by side (tens of GB each: seconds on memory nobody has touched yet) */
 		std::vector<int> okv(n_dev, 1); std::vector<std::thread> st;
-		for(int d = 0; d < n_dev; d++) st.emplace_back([&, d]() { okv[d] = hipSetDevice(dv[d]->P->dev) == hipSuccess && ensure_shared_slabs(dv[d]->P, dv[d]->P->qlen_hint); });
+		for(int d = 0; d < n_dev; d++) st.emplace_back([&, d]() { okv[d] = hipSetDevice(dv[d]->P->dev) == hipSuccess && ensure_shared_slabs(dv[d]->P, dv[d]->P->qlen_hint, (uint32_t)lanes); });
 		for(auto &t : st) t.join();
 		for(int d = 0; d < n_dev; d++) if(!okv[d]) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); (void)hipSetDevice(cur_dev); return 1; }
 	}
@@ -3671,7 +3704,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 				if(P->shared_slabs && slab_bytes_for(std::max(h->b.max_qlen, P->qlen_hint)) > P->slab_max) {
 					std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return D.active == 0 || rc != 0; });
 					const uint32_t want = h->b.max_qlen;
-					if(rc == 0 && !ensure_shared_slabs(P, want)) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); rc = 1; }
+					if(rc == 0 && !ensure_shared_slabs(P, want, (uint32_t)lanes)) { fprintf(stderr, "[minialign_amd] shared DP workspaces: allocation failed\n"); rc = 1; }
 					for(mm_align_t *ln = P; ln; ln = ln->sib) ln->qlen_hint = std::max(ln->qlen_hint, want);
 					if(verbose) fprintf(stderr, "[minialign_amd] batch %u: a read of %u bases, DP workspaces of device %d sized again\n", k, h->b.max_qlen, di);
 				}
