@@ -52,7 +52,7 @@ class Stats(ctypes.Structure):
                 ('k3_cycles_fill', ctypes.c_uint64), ('k3_cycles_leaf', ctypes.c_uint64), ('k3_cycles_trace', ctypes.c_uint64),
                 ('k3_cycles_total', ctypes.c_uint64), ('k3_cycles_next', ctypes.c_uint64), ('k3_cycles_max', ctypes.c_uint64), ('k3_waves', ctypes.c_uint64), ('k2_cycles_sort', ctypes.c_uint64), ('k2_cycles_chain', ctypes.c_uint64),
                 ('k2_cycles_total', ctypes.c_uint64), ('k2_reads_hbm', ctypes.c_uint64), ('pool_grows', ctypes.c_uint64), ('batch_splits', ctypes.c_uint64), ('pool_regrows', ctypes.c_uint64),
-                ('text_bytes', ctypes.c_uint64), ('reader_ms', ctypes.c_double), ('k3_aborts', ctypes.c_uint64)]
+                ('text_bytes', ctypes.c_uint64), ('reader_ms', ctypes.c_double), ('d2h_bytes', ctypes.c_uint64), ('cigar_bytes_device', ctypes.c_uint64), ('k3_aborts', ctypes.c_uint64)]
 
 def gensim_exe():
     exe = os.path.join(ROOT, 'tools', 'gensim')
@@ -185,6 +185,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU legs (baseline and identity check)')
     ap.add_argument('--no-packed', action='store_true', help='skip the value_from_packed leg'); ap.add_argument('--no-cli', action='store_true', help='skip the command-line run')
     ap.add_argument('--keep', action='store_true', help='keep the generated data (prints the directory)')
+    ap.add_argument('--early-line', action='store_true', help='print the JSON line once the timed steps are over, and again with the CPU legs in it (the hard-repeat record: the measurement is not lost when the CPU legs outlast the budget)')
     ap.add_argument('--no-hard', action='store_true', help='skip the hard-repeat record (config.hard_repeats: the hg38hard workload in a process of its own behind the timed steps; default workload on one GPU only)')
     args = ap.parse_args()
     os.environ['MM_LANES'] = str(args.lanes)          # the batch rule of the library (one batch per lane for a small set) sees the lanes this run uses
@@ -332,6 +333,7 @@ def main():
                        'dp_vectors_per_base': vec / max(1.0, total_bases * K), 'trace_steps_per_base': trs / max(1.0, total_bases * K), 'reruns_per_step (rank 0)': st.reruns / K,
                        'pool_overflows (batches run again with larger device pools, rank 0, timed steps)': int(st.pool_grows), 'batch_splits (rank 0, timed steps)': int(st.batch_splits), 'sketch_launches_repeated_with_pools_sized_to_the_demand (rank 0, timed steps)': int(st.pool_regrows),
                        'extension_launches_called_off_by_the_watchdog (rank 0, timed steps)': int(st.k3_aborts),
+                       'd2h_bytes_per_step (result pools + CIGAR text made on the device, rank 0)': st.d2h_bytes / K, 'cigar_text_bytes_per_step (made on the device, rank 0)': st.cigar_bytes_device / K,
                        'reader_gb_per_s (text to HBM, per uploader thread while it copies; one uploader per device)': (st.text_bytes * 1e-6 / st.reader_ms) if st.reader_ms > 0 else None,
                        'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
                        'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'text_load_s (outside)': t_load, 'host_parse_and_pack_s (value_from_packed only)': t_pack},
@@ -343,6 +345,7 @@ def main():
                          'note': 'the kernel is integer-VALU-issue bound, not HBM bound (DESIGN.md 4); achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch streams, this run), achieved_all_lanes = per GPU over the wall time; traffic is NOT measured in this run: it is the HBM bytes per launch of the committed rocprofv3 PMC passes of the same workload (profiles/roundN_pmc.json, FETCH_SIZE / WRITE_SIZE in separate runs) scaled by the algorithmic bytes per launch of this run over those of that one',
                          'valu_issue': valu_position(vec / K, dt / K, n_gpus)},
         }
+        if args.early_line: print(json.dumps(out), flush=True)
         if (n_gpus == 1 or args.check) and not args.no_cpu:
             cpu = reference_runs(w, ref_fa, parts, work, args.check_reads, args.baseline_reads, True)
             stage('CPU legs done')
@@ -361,16 +364,26 @@ def main():
             # device back: value, DP vectors per base, records of the first reads against the compiled reference, the reference's own speed beside it
             L.mm_align_destroy.argtypes = [ctypes.c_void_p]; L.mm_align_destroy.restype = None; L.mm_idx_destroy.argtypes = [ctypes.c_void_p]; L.mm_idx_destroy.restype = None
             L.mm_align_destroy(al); L.mm_idx_destroy(mi); al = mi = None
+            env = dict(os.environ); env.pop('MM_LIB_OVERRIDE', None)
+            cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'hg38hard', '--steps', '2', '--warmup', '1', '--no-cli', '--no-packed', '--early-line', '--check-reads', '1000', '--baseline-reads', '8000', '--lanes', str(args.lanes)]
             try:
-                env = dict(os.environ); env.pop('MM_LIB_OVERRIDE', None)
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--workload', 'hg38hard', '--steps', '2', '--warmup', '1', '--no-cli', '--no-packed', '--lanes', str(args.lanes)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=480)
+                # (the mapping itself is over within half a minute -- generation 10 s, index 3 s, three steps of 2 s; the line it prints then is kept whatever becomes of the CPU
+                # legs behind it, which build the reference's own index of another 3.1 Gb genome on the host cores: 300 s for all of it.  An extension launch that does not
+                # end is called off by the library's watchdog after 20 s and mapped again: the record then says so, extension_launches_called_off_by_the_watchdog)
+                class R: pass
+                r = R()
+                try:
+                    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300); r.stdout, r.stderr, r.note = p.stdout, p.stderr, None
+                except subprocess.TimeoutExpired as e:
+                    r.stdout, r.stderr, r.note = e.stdout or b'', e.stderr or b'', 'the CPU legs of the record did not finish within 300 s: the line printed behind the timed steps'
+                    if not any(l.startswith('{') for l in r.stdout.decode(errors='replace').splitlines()): raise
                 h = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith('{')][-1])
                 out['config']['hard_repeats'] = {'value': h['value'], 'unit': h['unit'], 'ms_per_step': h['ms_per_step'], 'workload': h['config']['workload'], 'dp_vectors_per_base': h['config']['dp_vectors_per_base'],
                                                  'reruns_per_step': h['config']['reruns_per_step (rank 0)'], 'extend_wave_balance': h['config']['extend_wave_balance (mean / max lifetime)'],
                                                  'sam_identical': h.get('sam_identical'), 'sam_check': h.get('sam_check'), 'cpu_baseline': h.get('cpu_baseline'),
                                                  'extension_launches_called_off_by_the_watchdog': h['config'].get('extension_launches_called_off_by_the_watchdog (rank 0, timed steps)'),
                                                  'watchdog_log': [l for l in r.stderr.decode(errors='replace').splitlines() if 'watchdog' in l][:40] or None,
-                                                 'note': 'python bench.py --workload hg38hard --steps 2 --warmup 1, run behind the timed steps of the headline workload'}
+                                                 'note': 'python bench.py --workload hg38hard --steps 2 --warmup 1, run behind the timed steps of the headline workload' + ('; ' + r.note if r.note else '')}
             except Exception as e:
                 tail = getattr(e, 'stderr', None)
                 out['config']['hard_repeats'] = {'error': repr(e)[:300], 'stderr_tail': (tail.decode(errors='replace')[-600:] if tail else None)}

@@ -182,9 +182,13 @@ typedef struct {
 	uint64_t pool_grows, batch_splits;          /* batches run again with larger device pools (a pool or a per-read cap overflowed) / batches mapped in halves because no pool size held them */
 	uint64_t pool_regrows;                      /* batches whose sketch launch was repeated because they asked for more seed / rescue / root entries than the run had seen (pools sized to the demand) */
 	uint64_t text_bytes; double reader_ms;      /* the text readers of the streams so far: bytes brought to HBM, time of the uploader threads (summed over devices) */
+	uint64_t d2h_bytes, cigar_bytes_device;     /* result bytes brought back from the devices (result pools + either path words or the CIGAR text made on the device, K4); bytes of that text */
 	uint64_t k3_aborts;                         /* times the watchdog called extension launches off because one did not end (the batches then ran again in the safe mode) */
 } mm_stats_t;
 void mm_stats(mm_align_t *a, mm_stats_t *out, int reset);
+/* test entry: the CIGAR run lengths of path bits [ppos, ppos + len) of the path that starts at pool[path_word] (header words { plen, 0x40000000 } in front, gaba.h:217) by the
+ * code the device kernel runs (K4, csrc/mm_cigar.hpp), on the host: what gaba_dp_print_cigar_reverse prints (gaba_parse.h:168-221); returns the characters (out NULL: counts) */
+uint64_t mm_cigar_walk(uint32_t const *pool, uint64_t path_word, uint64_t ppos, uint64_t len, char *out);
 
 /* the command-line program: `minialign [-x preset] [opts] ref.fa reads.{fa,fq} > out.sam` */
 int mm_main(int argc, char **argv);

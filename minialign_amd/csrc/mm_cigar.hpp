@@ -1,0 +1,108 @@
+/*
+ * K4: CIGAR strings on the device (second half).
+ *
+ * When the extension launch of a batch is over, the path words, the segments and the alignment records of every alignment it recorded are in HBM.  The printer of the
+ * reference turns the path bits of a segment into run lengths with gaba_dp_print_cigar_reverse (gaba_parse.h:168-221, called from minialign.c:5147-5200 for the CIGAR
+ * column and :5390-5426 for the SA tag): from the END of the segment's stretch of path bits downwards, a run of 0 bits is a deletion, a run of 1 bits an insertion, a run
+ * of 01 pairs a match -- each test on the 64 bits BELOW the cursor, counted with a leading-zero count, the deletion run one short when it is followed by anything
+ * (that 0 is the first half of a 01 pair).  That parser is restated here bit for bit (cig_next), one lane per segment: a first walk counts the characters, the lane
+ * takes that many bytes of the batch's text buffer (one atomic add), a second walk writes them.  What crosses PCIe for a default SAM run is then this text and a
+ * (offset, length) pair per segment instead of the path words; the host splices names, flags, positions, mapping qualities (libm's log10: host), SEQ / QUAL
+ * and the clips around the string (sam_record).  Runs that print MD tags, the other output formats and the mm_reg_t entries walk the path on the host as before.
+ *
+ * Bound: HBM latency of a lane's dependent 8-byte reads (one per run) and its byte stores -- a few milliseconds per 300 Mb batch beside the extension launches of the
+ * other lanes; algorithmic bytes: path bits / 8 read twice + text written once.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mm_device.hpp"
+
+namespace mm {
+
+struct CigItem { uint32_t seg; uint32_t pad; uint64_t path_word; };          /* one segment of a recorded alignment: its slot in the segment pool, the first path word of its alignment in the path pool */
+struct CigEnt { uint32_t off, len; };                                        /* where its string stands in the text buffer (len = ~0: it did not fit) */
+
+struct CigListArgs { const ReadState *st; uint32_t n_reads; const AlnRec *aln_pool; CigItem *items; unsigned long long *ctl; uint64_t item_cap; };          /* ctl[0] = items, [1] = text bytes, [2] = overflow flag */
+/* every segment of every alignment the reads of the batch recorded (thread per read) */
+__global__ void __launch_bounds__(256) mm_cigar_list_kernel(CigListArgs a)
+{
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+	if(r >= a.n_reads) { return; }
+	const ReadState &rs = a.st[r];
+	if(rs.n_aln == 0 || rs.bin_off == ~0ull) { return; }
+	const AlnRec *al = a.aln_pool + rs.aln_off;
+	uint32_t n = 0; for(uint32_t i = 0; i < rs.n_aln; i++) { n += al[i].slen; }
+	if(n == 0) { return; }
+	unsigned long long at = atomicAdd(&a.ctl[0], (unsigned long long)n);
+	if(at + n > a.item_cap) { atomicExch(&a.ctl[2], 1ull); return; }
+	for(uint32_t i = 0; i < rs.n_aln; i++) { for(uint32_t j = 0; j < al[i].slen; j++) { a.items[at++] = CigItem{ al[i].seg_off + j, 0u, al[i].path_off }; } }
+}
+
+/* 64 path bits from absolute bit position p of the pool on (p >= 0: two header words stand in front of every path, gaba.h:217) */
+__host__ __device__ __forceinline__ uint64_t cig_bits(const uint32_t *pool, uint64_t p)
+{
+	const uint64_t w = p >> 5; const uint32_t r = (uint32_t)p & 31u;
+	const uint64_t lo = (uint64_t)pool[w] | ((uint64_t)pool[w + 1] << 32);
+	return r ? (lo >> r) | ((uint64_t)pool[w + 2] << (64u - r)) : lo;
+}
+__host__ __device__ __forceinline__ uint64_t cig_lzc(uint64_t x) { return x ? (uint64_t)__builtin_clzll(x) : 64ull; }
+/* the next run of the reverse parser (gaba_parse.h:183-216): base = absolute bit position of the segment's first path bit minus 64, idx = bits left; returns the run's
+ * length and its letter ('D', 'I', 'M'; 0 when the step printed nothing), idx moved down */
+struct CigWalk { const uint32_t *pool; uint64_t base; uint64_t idx; int phase; };
+__host__ __device__ __forceinline__ uint64_t cig_next(CigWalk &w, char &op)
+{
+	if(w.phase == 0) {
+		w.phase = 1;
+		const uint64_t m = cig_lzc(cig_bits(w.pool, w.base + w.idx)), d = m - (m > 0 ? 1ull : 0ull), c = w.idx < d ? w.idx : d;
+		w.idx -= c; op = 'D'; return c;
+	}
+	if(w.phase == 1) {
+		w.phase = 2;
+		const uint64_t m = cig_lzc(~cig_bits(w.pool, w.base + w.idx)), c = w.idx < m ? w.idx : m;
+		w.idx -= c; op = 'I'; return c;
+	}
+	w.phase = 0;
+	const uint64_t sidx = w.idx; uint64_t c;
+	do { const uint64_t m = cig_lzc(cig_bits(w.pool, w.base + w.idx) ^ 0x5555555555555555ull); c = (w.idx < m ? w.idx : m) & ~1ull; w.idx -= c; } while(c == 64);
+	op = 'M'; return (sidx - w.idx) >> 1;
+}
+__host__ __device__ __forceinline__ uint32_t cig_digits(uint64_t v) { uint32_t n = 1; while(v >= 10) { v /= 10; n++; } return n; }
+
+/* one string, by the code of the kernel below (host side: tests pin the restated parser on the reference's own without a device, mm_cigar_walk) */
+__host__ __device__ __forceinline__ uint64_t cig_write(const uint32_t *pool, uint64_t base, uint64_t len, char *o)
+{
+	uint64_t chars = 0;
+	CigWalk w{ pool, base, len, 0 };
+	while(w.idx != 0) {          /* (gaba_parse.h:183: all three tests per turn, also when the first one used the bits up) */
+		const uint64_t before = w.idx;
+		for(int ph = 0; ph < 3; ph++) {
+			char op; uint64_t c = cig_next(w, op);
+			if(!c) { continue; }
+			const uint32_t d = cig_digits(c);
+			if(o) { for(uint32_t i = d; i > 0; i--) { o[chars + i - 1] = (char)('0' + c % 10); c /= 10; } o[chars + d] = op; }
+			chars += d + 1;
+		}
+		if(w.idx == before) { break; }          /* (bits that are no path -- a lone 0 above a 1 at the bottom of the stretch: the reference's loop would turn for ever; never seen on what the traceback writes) */
+	}
+	return chars;
+}
+struct CigArgs { const CigItem *items; const gaba::Segment *seg_pool; const uint32_t *path_pool; CigEnt *ent; char *text; uint64_t text_cap; unsigned long long *ctl; };
+/* lane per segment: count, take room, write */
+__global__ void __launch_bounds__(256) mm_cigar_kernel(CigArgs a)
+{
+	const unsigned long long n = a.ctl[0];
+	const unsigned long long k = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+	if(k >= n) { return; }
+	const CigItem it = a.items[k];
+	const gaba::Segment sg = a.seg_pool[it.seg];
+	const uint64_t len = (uint64_t)sg.alen + sg.blen;
+	/* (the host's parser aligns its pointer down to 8 bytes and adds 32 to the offset when it had to, gaba_parse.h:176-177: the same absolute bit either way) */
+	const uint64_t base = it.path_word * 32ull + sg.ppos - 64ull;
+	const uint64_t chars = cig_write(a.path_pool, base, len, nullptr);
+	const unsigned long long at = atomicAdd(&a.ctl[1], (unsigned long long)chars);
+	if(at + chars > a.text_cap || chars > 0xfffffff0ull) { a.ent[it.seg] = CigEnt{ 0u, 0xffffffffu }; atomicExch(&a.ctl[2], 1ull); return; }
+	a.ent[it.seg] = CigEnt{ (uint32_t)at, (uint32_t)chars };
+	(void)cig_write(a.path_pool, base, len, a.text + at);
+}
+
+} /* namespace mm */

@@ -37,6 +37,7 @@
 #include "gaba_host.hpp"
 #include "mm_device.hpp"
 #include "mm_index.hpp"
+#include "mm_cigar.hpp"
 #include "../../include/minialign.h"
 
 using namespace mm;
@@ -1212,6 +1213,7 @@ struct mm_align_s {
 	DBuf<uint8_t> k2w_scratch;          /* lane-per-read chain sweep: leaf / chain scratch, 16 B per seed found (a third of 16 B per element of the seed pool) */
 	DBuf<SpecJob> rq_jobs; DBuf<SpecMemo> rq_memo; DBuf<uint32_t> rq_state;          /* retry jobs of a launch (K3Args.rjobs); rq_state: one word per slot, then the four control words */
 	DBuf<SpecJob> spec_jobs; DBuf<SpecMemo> spec_memo; DBuf<uint32_t> spec_path; DBuf<gaba::Segment> spec_seg; DBuf<unsigned long long> spec_top;      /* chain jobs of the heaviest reads of a launch (K3Args.jobs) */
+	DBuf<CigItem> cig_items; DBuf<CigEnt> cig_ent; DBuf<char> cig_text; DBuf<unsigned long long> cig_ctl;          /* K4 (mm_cigar.hpp): the CIGAR strings of a batch made on the device */
 	DBuf<uint64_t> tap_words;              /* mm_batch_tap: the minimizer stream words of the batch, parallel to min_pool */
 	DBuf<uint8_t> d_text, d_codes; DBuf<TextRead> d_tinfo; DBuf<uint32_t> d_tn;      /* packing on the device: text range of the batch, per-read extents, code bytes of the arena, bases found per read */
 	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
@@ -1224,9 +1226,9 @@ struct mm_align_s {
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
 	/* reusable host buffers of the streaming engine (primary context only): pinned result buffers for the D2H of a batch, text pieces with their capacity */
-	struct PinSet { void *p[5] = { nullptr, nullptr, nullptr, nullptr, nullptr }; size_t cap[5] = { 0, 0, 0, 0, 0 };
+	struct PinSet { void *p[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; size_t cap[7] = { 0, 0, 0, 0, 0, 0, 0 };
 		void *get(int i, size_t bytes) { if(bytes > cap[i]) { if(p[i]) (void)hipHostFree(p[i]); p[i] = nullptr; cap[i] = 0; size_t want = bytes + bytes / 4 + (1u << 20); if(hipHostMalloc(&p[i], want, hipHostMallocPortable) != hipSuccess) return nullptr; cap[i] = want; } return p[i]; }          /* (portable: a set is pooled on the first context and handed to lanes of any device) */
-		~PinSet() { for(int i = 0; i < 5; i++) if(p[i]) (void)hipHostFree(p[i]); } };
+		~PinSet() { for(int i = 0; i < 7; i++) if(p[i]) (void)hipHostFree(p[i]); } };
 	std::vector<PinSet *> pin_free; std::vector<std::vector<std::string>> piece_free; std::mutex pool_mu;
 	/* the head of the last stream mapped through this context (mm_map_*): what decides whether another carried value at its start changes anything */
 	struct HeadRec { uint32_t apos0, cond0, used, rid_last; };
@@ -1880,8 +1882,13 @@ inline void put_int(std::string &s, int64_t v) { if(v < 0) { s.push_back('-'); p
  * secondaries); the SA entries name the first reference sequence whatever they hit and carry the raw 16x fixed-point mapping quality; RG:Z prints
  * the whole "ID:..." token. */
 void sam_record(const mm_align_t *a, std::string &s, const char *qname, const uint8_t *qseq, uint32_t qlen, const OutReg &reg,
-	const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths, const HSeq *rec)
+	const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths, const HSeq *rec, const CigEnt *cig_ent = nullptr, const char *cig_text = nullptr)
 {
+	/* the run lengths of a segment: the string the device made for its slot (K4, mm_cigar.hpp) or, without one, the walk over the path words (gaba_parse.h:168-221) */
+	auto put_cigar = [&](const AlnRec &al, uint32_t slot, const gaba::Segment &g) {
+		if(cig_ent) { s.append(cig_text + cig_ent[slot].off, cig_ent[slot].len); }
+		else { cigar_reverse(s, paths + al.path_off, g.ppos, (uint64_t)g.alen + g.blen); }
+	};
 	const uint64_t f = a->o.ptags();
 	auto tag = [f](int x) { return ((f >> x) & 1) != 0; };
 	const bool has_qual = rec && !rec->qual.empty(), has_co = rec && rec->has_comment;
@@ -1908,7 +1915,7 @@ void sam_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 			s += r.name; s.push_back('\t'); put_num(s, rs + 1); s.push_back('\t'); put_num(s, reg.aln[i].mapq >> 4); s.push_back('\t');
 			char clip = (flag & 0x900) ? 'H' : 'S';
 			if(hl) { put_num(s, hl); s.push_back(clip); }
-			cigar_reverse(s, paths + al.path_off, sg.ppos, (uint64_t)sg.alen + sg.blen);
+			put_cigar(al, al.seg_off + j - 1, sg);
 			if(tl) { put_num(s, tl); s.push_back(clip); }
 			s += "\t*\t0\t0\t";
 			if(sg.bid & 1) sam_seq(s, qseq + qs, qe - qs, false); else sam_seq(s, qseq + (qlen - qe), qe - qs, true);
@@ -1941,7 +1948,7 @@ void sam_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 							s.push_back((sh.bid & 1) ? '+' : '-'); s.push_back(',');
 							uint32_t h2 = qlen - sh.bpos - sh.blen, t2 = sh.bpos;
 							if(h2) { put_num(s, h2); s.push_back('H'); }
-							cigar_reverse(s, paths + bl.path_off, sh.ppos, (uint64_t)sh.alen + sh.blen);
+							put_cigar(bl, bl.seg_off + y - 1, sh);
 							if(t2) { put_num(s, t2); s.push_back('H'); }
 							s.push_back(','); put_num(s, reg.aln[x].mapq); s.push_back(','); put_num(s, edit(bl)); s.push_back(';');
 						}
@@ -2433,7 +2440,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); a->pring[c].release(); a->pctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
-	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release(); a->cig_items.release(); a->cig_ent.release(); a->cig_text.release(); a->cig_ctl.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	if(a->pin_note) (void)hipHostFree(a->pin_note);
 	if(!a->is_sib) { k3_watchdog_stop(a); }
@@ -2465,7 +2472,7 @@ extern "C" void mm_stats(mm_align_t *a, mm_stats_t *out, int reset)
 			out->k3_cycles_fill += q.k3_cycles_fill; out->k3_cycles_leaf += q.k3_cycles_leaf; out->k3_cycles_trace += q.k3_cycles_trace; out->k3_cycles_total += q.k3_cycles_total;
 			out->k3_cycles_next += q.k3_cycles_next; out->k3_cycles_max += q.k3_cycles_max;             /* summed over launches; k3_waves stays the per-launch count */
 			out->k2_cycles_sort += q.k2_cycles_sort; out->k2_cycles_chain += q.k2_cycles_chain; out->k2_cycles_total += q.k2_cycles_total; out->k2_reads_hbm += q.k2_reads_hbm;
-			out->pool_grows += q.pool_grows; out->pool_regrows += q.pool_regrows; out->batch_splits += q.batch_splits; out->text_bytes += q.text_bytes; out->reader_ms += q.reader_ms; out->k3_aborts += q.k3_aborts;
+			out->pool_grows += q.pool_grows; out->pool_regrows += q.pool_regrows; out->batch_splits += q.batch_splits; out->text_bytes += q.text_bytes; out->reader_ms += q.reader_ms; out->k3_aborts += q.k3_aborts; out->d2h_bytes += q.d2h_bytes; out->cigar_bytes_device += q.cigar_bytes_device;
 		});
 	}
 	if(reset) { a->t_wall0 = now_ms(); each_context(a, [](mm_align_t *ln) { memset(&ln->st, 0, sizeof(ln->st)); }); }
@@ -2770,7 +2777,9 @@ struct Fetched {
 	 * HBM sort kernel alone (`prof` = tops + 28, its prof[0] only), [30] the chain sweep's scratch cursor.  The ranges are disjoint as long as nobody starts to use prof[4] */
 	unsigned long long tops[32];
 	Root *root = nullptr; uint64_t *bin = nullptr; AlnRec *aln = nullptr; gaba::Segment *seg = nullptr; uint32_t *path = nullptr;
-	std::unique_ptr<uint8_t[]> own[5];          /* plain host memory when no pinned set is given */
+	const CigEnt *cig_ent = nullptr; const char *cig_text = nullptr;          /* the CIGAR strings of the batch as the device made them (K4), indexed by segment slot; NULL: the printers walk the path words (which are then what was fetched) */
+	uint64_t d2h_bytes = 0;
+	std::unique_ptr<uint8_t[]> own[7];          /* plain host memory when no pinned set is given */
 	mm_align_s::PinSet *pin = nullptr;          /* pinned set the pointers live in (returned to the pool by the caller) */
 };
 bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
@@ -2791,23 +2800,55 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
 	/* host copies of the result pools (uninitialised storage: the copies fill them); pinned when the caller lends a set */
+	/* K4: the CIGAR strings on the device (mm_cigar.hpp) for a run that prints SAM without MD tags -- the text and an (offset, length) pair per segment come back instead
+	 * of the path words.  The strings of a batch that do not fit 0.5 characters per path bit (three times what PacBio-CLR-like reads make) are made by the host as
+	 * before, from the path words; MM_HOST_CIGAR: always (the form of rounds 1-5: test, and the other side of the measurement) */
+	static const bool host_cigar = getenv("MM_HOST_CIGAR") != NULL;
+	const uint64_t n_seg = std::min<uint64_t>(tops[5], a->seg_pool.n), n_path = std::min<uint64_t>(tops[6], a->path_pool.n);
+	bool dev_cigar = a->o.format == 0 && !((a->o.ptags() >> 8) & 1) && !b.regs && !host_cigar && n_seg > 0 && n_path * 16 < 0xf0000000ull;
+	unsigned long long cig_ctl[4] = { 0, 0, 0, 0 };
+	if(dev_cigar) {
+		const uint64_t text_cap = ((n_path * 16 + (1ull << 20)) + (32ull << 20) - 1) & ~((32ull << 20) - 1);
+		if(a->cig_items.ensure(n_seg) && a->cig_ent.ensure(n_seg) && a->cig_text.ensure(text_cap) && a->cig_ctl.ensure(4)) {
+			CK(hipMemsetAsync(a->cig_ctl.p, 0, 32, a->stream));
+			CigListArgs la; la.st = a->d_st.p; la.n_reads = n_reads; la.aln_pool = a->aln_pool.p; la.items = a->cig_items.p; la.ctl = a->cig_ctl.p; la.item_cap = n_seg;
+			hipLaunchKernelGGL(mm_cigar_list_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, a->stream, la);
+			CigArgs ca; ca.items = a->cig_items.p; ca.seg_pool = a->seg_pool.p; ca.path_pool = a->path_pool.p; ca.ent = a->cig_ent.p; ca.text = a->cig_text.p; ca.text_cap = std::min<uint64_t>(a->cig_text.n, 0xf0000000ull); ca.ctl = a->cig_ctl.p;
+			hipLaunchKernelGGL(mm_cigar_kernel, dim3((uint32_t)((n_seg + 255) / 256)), dim3(256), 0, a->stream, ca);
+			CK(hipGetLastError());
+			CK(hipMemcpyAsync(cig_ctl, a->cig_ctl.p, 32, hipMemcpyDeviceToHost, a->stream)); CK(hipStreamSynchronize(a->stream));
+			if(cig_ctl[2] != 0) { dev_cigar = false; if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   CIGAR strings of a batch beyond %.1f MB of text: made by the host\n", text_cap / 1e6); }
+		} else { dev_cigar = false; }
+	}
 	{
-		const size_t need[5] = { (size_t)std::max<uint64_t>(tops[2], 1) * sizeof(Root), (size_t)std::max<uint64_t>(tops[3], 1) * 8, (size_t)std::max<uint64_t>(tops[4], 1) * sizeof(AlnRec),
-			(size_t)std::max<uint64_t>(tops[5], 1) * sizeof(gaba::Segment), (size_t)(std::max<uint64_t>(tops[6], 2) + 8) * 4 };
-		void *ptr[5];
-		for(int i = 0; i < 5; i++) {
+		const size_t need[7] = { (size_t)std::max<uint64_t>(tops[2], 1) * sizeof(Root), (size_t)std::max<uint64_t>(tops[3], 1) * 8, (size_t)std::max<uint64_t>(tops[4], 1) * sizeof(AlnRec),
+			(size_t)std::max<uint64_t>(tops[5], 1) * sizeof(gaba::Segment), dev_cigar ? 64 : (size_t)(std::max<uint64_t>(tops[6], 2) + 8) * 4,
+			dev_cigar ? (size_t)n_seg * sizeof(CigEnt) : 0, dev_cigar ? (size_t)cig_ctl[1] + 16 : 0 };
+		void *ptr[7];
+		for(int i = 0; i < 7; i++) {
+			if(need[i] == 0) { ptr[i] = nullptr; continue; }
 			ptr[i] = f.pin ? f.pin->get(i, need[i]) : nullptr;
 			if(!ptr[i]) { f.own[i].reset(new uint8_t[need[i] + 16]); ptr[i] = f.own[i].get(); }
 		}
 		f.root = (Root *)ptr[0]; f.bin = (uint64_t *)ptr[1]; f.aln = (AlnRec *)ptr[2]; f.seg = (gaba::Segment *)ptr[3]; f.path = (uint32_t *)ptr[4];
+		f.cig_ent = (const CigEnt *)ptr[5]; f.cig_text = (const char *)ptr[6];
 	}
+	f.d2h_bytes = std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root) + std::min<uint64_t>(tops[3], a->bin_pool.n) * 8 + std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec) + n_seg * sizeof(gaba::Segment);
 	CK(hipMemcpyAsync(f.root, a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost, a->stream));
 	CK(hipMemcpyAsync(f.bin, a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost, a->stream));
 	CK(hipMemcpyAsync(f.aln, a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(f.seg, a->seg_pool.p, std::min<uint64_t>(tops[5], a->seg_pool.n) * sizeof(gaba::Segment), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(f.path, a->path_pool.p, std::min<uint64_t>(tops[6], a->path_pool.n) * 4, hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.seg, a->seg_pool.p, n_seg * sizeof(gaba::Segment), hipMemcpyDeviceToHost, a->stream));
+	if(dev_cigar) {
+		CK(hipMemcpyAsync((void *)f.cig_ent, a->cig_ent.p, n_seg * sizeof(CigEnt), hipMemcpyDeviceToHost, a->stream));
+		if(cig_ctl[1]) { CK(hipMemcpyAsync((void *)f.cig_text, a->cig_text.p, cig_ctl[1], hipMemcpyDeviceToHost, a->stream)); }
+		f.d2h_bytes += n_seg * sizeof(CigEnt) + cig_ctl[1];
+	} else {
+		CK(hipMemcpyAsync(f.path, a->path_pool.p, n_path * 4, hipMemcpyDeviceToHost, a->stream));
+		f.d2h_bytes += n_path * 4; f.cig_ent = nullptr; f.cig_text = nullptr;
+	}
 	CK(hipStreamSynchronize(a->stream));
-	a->st.host_post_ms += now_ms() - t0;
+	a->st.host_post_ms += now_ms() - t0; a->st.d2h_bytes += f.d2h_bytes; if(dev_cigar) { a->st.cigar_bytes_device += cig_ctl[1]; }
+	if(getenv("MM_VERBOSE") && dev_cigar) fprintf(stderr, "[minialign_amd]   CIGAR text made on the device: %llu segments, %.1f MB (the path words it stands for: %.1f MB); %.1f MB back in all\n", cig_ctl[0], cig_ctl[1] / 1e6, n_path * 4 / 1e6, f.d2h_bytes / 1e6);
 	return true;
 }
 /* a read of a scanned text as the printers want it: name, comment, base codes and qualities read off the text, as bseq_read_fasta leaves them (minialign.c:1996-2090) */
@@ -2854,7 +2895,7 @@ void batch_format(const mm_align_t *a, Batch &b, const Fetched &f, std::vector<s
 			const char *qname; const uint8_t *qseq; const HSeq *qrec;
 			if(b.tsrc) { materialize(b, i, tmp, a->o.keep_qual, (a->o.ptags() >> 1) & 1); qname = tmp.name.c_str(); qseq = tmp.seq.data(); qrec = &tmp; }
 			else { qname = b.names[i].c_str(); qseq = b.seq[i]; qrec = i < b.rec.size() ? b.rec[i] : nullptr; }
-			if(a->o.format == 0) sam_record(a, out, qname, qseq, b.lens[i], reg, alns, seg, path, qrec);
+			if(a->o.format == 0) sam_record(a, out, qname, qseq, b.lens[i], reg, alns, seg, path, qrec, f.cig_ent, f.cig_text);
 			else alt_record(a, out, qname, qseq, b.lens[i], reg, alns, seg, path);
 		}
 	};
@@ -3074,6 +3115,9 @@ extern "C" int64_t mm_batch_tap_sketch(mm_align_t *a, mm_batch_t *h, uint32_t re
 	if(n && hipMemcpy(words, c->tap_words.p + rs.min_off, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return rs.n_min;
 }
+/* test entry: the run lengths of path bits [ppos, ppos + len) of a path whose first word is pool[path_word] (two header words in front of it), by the very code the
+ * device runs (mm_cigar.hpp: cig_write), on the host; returns the characters written (out may be NULL: the count) */
+extern "C" uint64_t mm_cigar_walk(uint32_t const *pool, uint64_t path_word, uint64_t ppos, uint64_t len, char *out) { return cig_write(pool, path_word * 32ull + ppos - 64ull, len, out); }
 extern "C" int mm_set_device(int dev) { return hipSetDevice(dev) == hipSuccess ? 0 : -1; }
 
 static int align_reads(mm_align_t *a, mm_reads_t *reads, FILE *out, bool keep = false);

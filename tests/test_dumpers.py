@@ -65,3 +65,47 @@ def test_calc_score_matches_the_reference():
         assert got == v['score'], (v['model'], v['seg'])
         assert np.float64(s.identity).tobytes().hex() == v['identity']
         L.gaba_dp_flush(dps[v['model']])
+
+def test_the_device_side_cigar_walker_prints_what_the_reverse_dumper_prints():
+    """K4 (csrc/mm_cigar.hpp) restates gaba_dp_print_cigar_reverse for one lane per segment; the same code compiled for the host (mm_cigar_walk) against the library's
+    dumper (gaba_dump_cigar_reverse, the function the SAM goldens and the vectors above pin) on the golden paths and on random bit strings -- runs of every length,
+    stretches that start and end anywhere in a word, paths at odd and even word offsets of a pool (the dumper aligns its pointer down to 8 bytes, the walker counts bits
+    from the start of the pool)"""
+    L = G.load_product()
+    L.mm_cigar_walk.restype = ctypes.c_uint64; L.gaba_dump_cigar_reverse.restype = ctypes.c_uint64
+    rng = np.random.default_rng(20260929)
+    cases = []
+    for v in _vectors()[:60]:
+        cases.append((np.array(v['path'], dtype=np.uint32), v['plen'], 0, v['plen']))
+    for _ in range(300):
+        # alignment-like bit strings: 01 pairs (a match: the 1 in the lower bit) with runs of 0s (deletions) and 1s (insertions) of many lengths in between -- never a
+        # deletion right above an insertion, which IS a match pair; stretches are cut right above a run of pairs (a lone 0 above a 1 at the bottom of a stretch is not a path)
+        ops = []; n_bits = 0; target = int(rng.integers(40, 4000)); last = 'M'
+        while n_bits < target:
+            r = rng.random()
+            if r < 0.6 or (last == 'I'): k = int(rng.integers(1, 90)); ops.append(('M', k)); n_bits += 2 * k; last = 'M'
+            elif r < 0.8: k = int(rng.integers(1, 140)); ops.append(('D', k)); n_bits += k; last = 'D'
+            else: k = int(rng.integers(1, 140)); ops.append(('I', k)); n_bits += k; last = 'I'
+        bits = []; cuts = [0]
+        for op, k in ops:
+            if op == 'M': bits += [1, 0] * k; cuts.append(len(bits))
+            elif op == 'D': bits += [0] * k
+            else: bits += [1] * k
+        words = np.zeros(len(bits) // 32 + 2, dtype=np.uint32)
+        for i, b in enumerate(bits):
+            if b: words[i >> 5] |= np.uint32(1 << (i & 31))
+        lo = int(cuts[int(rng.integers(0, len(cuts)))]) if rng.random() < 0.7 else 0
+        if lo >= len(bits): lo = 0
+        ln = int(rng.integers(1, len(bits) - lo + 1))
+        cases.append((words, len(bits), lo, ln))
+    buf = ctypes.create_string_buffer(1 << 16); out = ctypes.create_string_buffer(1 << 16)
+    for words, plen, ppos, ln in cases:
+        for lead in (2, 3):          # the path starts at an even / odd word of the pool (header words right in front of it, filler in front of those)
+            pool = np.zeros(lead + len(words) + 8, dtype=np.uint32)
+            pool[:lead - 2] = 0xdeadbeef; pool[lead - 2] = plen & 0xffffffff; pool[lead - 1] = 0x40000000; pool[lead:lead + len(words)] = words
+            path = ctypes.c_void_p(pool.ctypes.data + 4 * lead)
+            n = L.gaba_dump_cigar_reverse(buf, ctypes.c_uint64(len(buf)), path, ctypes.c_uint64(ppos), ctypes.c_uint64(ln))
+            want = buf.raw[:n]
+            cnt = L.mm_cigar_walk(pool.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(lead), ctypes.c_uint64(ppos), ctypes.c_uint64(ln), None)
+            m = L.mm_cigar_walk(pool.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(lead), ctypes.c_uint64(ppos), ctypes.c_uint64(ln), out)
+            assert cnt == m == n and out.raw[:m] == want, (plen, ppos, ln, lead, want[:80], out.raw[:80])

@@ -203,3 +203,23 @@ def test_traceback_that_leaves_the_band_is_dropped_like_the_reference(workdir):
     got = _run(CLI, 'ava', ref, one)
     want = _run(os.path.join(M.ROOT, 'oracle', 'ora_minialign'), 'ava', ref, one)
     assert got == want, _first_diff(got, want)
+
+
+@pytest.mark.parametrize('opts', [[], ['-TSA,AS,NM'], ['-P']], ids=['default-tags', 'SA-tag', 'omit-secondaries'])
+def test_cigar_strings_made_on_the_device_are_the_hosts(opts, workdir):
+    """K4 (csrc/mm_cigar.hpp): for SAM without MD tags the run lengths of every segment are made on the device and only their text comes back; MM_HOST_CIGAR takes the
+    form of rounds 1-5 (path words back, the host walks them).  Same bytes -- on a repeat-rich multi-contig set (secondary and supplementary records, SA entries) and on
+    the oracle's records; with -T MD the host walks the paths whatever the switch says (the third run)"""
+    s = dict(name='g_cig', preset='pacbio', genome=(361, 2000000, 8, 0.40), reads=(362, 1.5, 'pacbio', 'fa', 7000, 2000))
+    ref, rd = make_inputs(s, workdir)
+    def run(env, extra=[]):
+        r = subprocess.run([CLI, '-x' + s['preset']] + opts + extra + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_BATCH_BASES='1500000', MM_VERBOSE='1', **env))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        return _strip_pg(r.stdout), r.stderr
+    dev, err_d = run({}); host, err_h = run(dict(MM_HOST_CIGAR='1'))
+    assert dev == host, _first_diff(dev, host)
+    assert b'CIGAR text made on the device' in err_d and b'CIGAR text made on the device' not in err_h
+    if not opts:
+        r = subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign'), '-x' + s['preset'], ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE); assert r.returncode == 0
+        want = _strip_pg(r.stdout); assert dev == want, _first_diff(dev, want)
+        md, err_m = run({}, ['-TMD']); assert b'CIGAR text made on the device' not in err_m and md.count(b'MD:Z:') > 100
