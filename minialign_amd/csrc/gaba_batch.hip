@@ -206,7 +206,6 @@ gaba_t *gaba_init(gaba_params_t const *params)
 	{
 		const int8_t *sb = (const int8_t *)c.sb;
 		c.fast_score = sb[2] == sb[3] && sb[2] == sb[6];
-		if(getenv("MM_NO_FAST_SCORE")) { c.fast_score = 0; }           /* test hook: force the general lookup */
 		c.score_n = sb[2];
 		for(int a = 0; a < 5; a++) {
 			uint32_t row = 0;
@@ -297,8 +296,7 @@ int gaba_dp_extend_batch(gaba_t *ctx, gaba_arena_t const *a, gaba_arena_t const 
 	need = (need + 255) & ~255ull;
 	int dev = 0; hipDeviceProp_t prop;
 	HIP_OK(hipGetDevice(&dev), -1); HIP_OK(hipGetDeviceProperties(&prop, dev), -1);
-	const char *wenv = getenv("MM_WAVES_PER_CU");
-	uint32_t max_waves = (uint32_t)prop.multiProcessorCount * (wenv ? (uint32_t)atoi(wenv) : 4u * GABA_WAVES_PER_SIMD);          /* default: as many 4-wave workgroups per CU as the launch bound allows */
+	uint32_t max_waves = (uint32_t)prop.multiProcessorCount * 4u * GABA_WAVES_PER_SIMD;          /* default: as many 4-wave workgroups per CU as the launch bound allows */
 	uint32_t waves = n < max_waves ? ((n + 3) & ~3u) : max_waves;
 	if(ctx->slab_bytes < need || ctx->n_waves < waves) {
 		if(ctx->slabs) hipFree(ctx->slabs);

@@ -38,32 +38,40 @@ __global__ void __launch_bounds__(256) mm_cigar_list_kernel(CigListArgs a)
 	for(uint32_t i = 0; i < rs.n_aln; i++) { for(uint32_t j = 0; j < al[i].slen; j++) { a.items[at++] = CigItem{ al[i].seg_off + j, 0u, al[i].path_off }; } }
 }
 
-/* 64 path bits from absolute bit position p of the pool on (p >= 0: two header words stand in front of every path, gaba.h:217) */
-__host__ __device__ __forceinline__ uint64_t cig_bits(const uint32_t *pool, uint64_t p)
+/* 64 path bits from absolute bit position p of the pool on (p >= 0: two header words stand in front of every path, gaba.h:217).  The parser asks for a fresh window per
+ * test and moves down a few bits per run, so the lane keeps 256 bits of the pool in registers (four 8-byte words from word cq on) and goes to memory once per ~190 bits it
+ * has walked instead of once per test: the walk is a chain of dependent reads, and a dependent read is a round trip to L2 / HBM */
+struct CigWalk { const uint32_t *pool; uint64_t base; uint64_t idx; int phase; uint64_t cq; uint64_t c0, c1, c2, c3; };
+__host__ __device__ __forceinline__ uint64_t cig_bits(CigWalk &w, uint64_t p)
 {
-	const uint64_t w = p >> 5; const uint32_t r = (uint32_t)p & 31u;
-	const uint64_t lo = (uint64_t)pool[w] | ((uint64_t)pool[w + 1] << 32);
-	return r ? (lo >> r) | ((uint64_t)pool[w + 2] << (64u - r)) : lo;
+	const uint64_t q = p >> 6; const uint32_t r = (uint32_t)p & 63u;
+	if(q < w.cq || q > w.cq + 2) {
+		w.cq = q >= 2 ? q - 2 : 0;
+		const uint64_t *m = (const uint64_t *)w.pool + w.cq;
+		w.c0 = m[0]; w.c1 = m[1]; w.c2 = m[2]; w.c3 = m[3];
+	}
+	const uint64_t k = q - w.cq;
+	const uint64_t lo = k == 0 ? w.c0 : (k == 1 ? w.c1 : w.c2), hi = k == 0 ? w.c1 : (k == 1 ? w.c2 : w.c3);
+	return r ? (lo >> r) | (hi << (64u - r)) : lo;
 }
 __host__ __device__ __forceinline__ uint64_t cig_lzc(uint64_t x) { return x ? (uint64_t)__builtin_clzll(x) : 64ull; }
 /* the next run of the reverse parser (gaba_parse.h:183-216): base = absolute bit position of the segment's first path bit minus 64, idx = bits left; returns the run's
  * length and its letter ('D', 'I', 'M'; 0 when the step printed nothing), idx moved down */
-struct CigWalk { const uint32_t *pool; uint64_t base; uint64_t idx; int phase; };
 __host__ __device__ __forceinline__ uint64_t cig_next(CigWalk &w, char &op)
 {
 	if(w.phase == 0) {
 		w.phase = 1;
-		const uint64_t m = cig_lzc(cig_bits(w.pool, w.base + w.idx)), d = m - (m > 0 ? 1ull : 0ull), c = w.idx < d ? w.idx : d;
+		const uint64_t m = cig_lzc(cig_bits(w, w.base + w.idx)), d = m - (m > 0 ? 1ull : 0ull), c = w.idx < d ? w.idx : d;
 		w.idx -= c; op = 'D'; return c;
 	}
 	if(w.phase == 1) {
 		w.phase = 2;
-		const uint64_t m = cig_lzc(~cig_bits(w.pool, w.base + w.idx)), c = w.idx < m ? w.idx : m;
+		const uint64_t m = cig_lzc(~cig_bits(w, w.base + w.idx)), c = w.idx < m ? w.idx : m;
 		w.idx -= c; op = 'I'; return c;
 	}
 	w.phase = 0;
 	const uint64_t sidx = w.idx; uint64_t c;
-	do { const uint64_t m = cig_lzc(cig_bits(w.pool, w.base + w.idx) ^ 0x5555555555555555ull); c = (w.idx < m ? w.idx : m) & ~1ull; w.idx -= c; } while(c == 64);
+	do { const uint64_t m = cig_lzc(cig_bits(w, w.base + w.idx) ^ 0x5555555555555555ull); c = (w.idx < m ? w.idx : m) & ~1ull; w.idx -= c; } while(c == 64);
 	op = 'M'; return (sidx - w.idx) >> 1;
 }
 __host__ __device__ __forceinline__ uint32_t cig_digits(uint64_t v) { uint32_t n = 1; while(v >= 10) { v /= 10; n++; } return n; }
@@ -72,7 +80,7 @@ __host__ __device__ __forceinline__ uint32_t cig_digits(uint64_t v) { uint32_t n
 __host__ __device__ __forceinline__ uint64_t cig_write(const uint32_t *pool, uint64_t base, uint64_t len, char *o)
 {
 	uint64_t chars = 0;
-	CigWalk w{ pool, base, len, 0 };
+	CigWalk w{ pool, base, len, 0, ~0ull >> 1, 0, 0, 0, 0 };
 	while(w.idx != 0) {          /* (gaba_parse.h:183: all three tests per turn, also when the first one used the bits up) */
 		const uint64_t before = w.idx;
 		for(int ph = 0; ph < 3; ph++) {

@@ -591,14 +591,6 @@ __device__ inline void circularize(Seed *s, Root *c, uint32_t n_seed, uint32_t t
 		s[rlid].upos = s[llid].upos;
 	}
 }
-struct K2Args {
-	DevIndex idx;
-	ReadState *st; const uint32_t *work; uint32_t n_work;     /* indices of the reads taking part in this round */
-	uint32_t round;
-	Seed *seed_pool; Resc *resc_pool; Root *root_pool;
-	uint32_t *rs_scratch; uint32_t rs_stride;                 /* per-lane scratch: 512 bucket words + range stack */
-	uint32_t twlen; double mcoef; uint32_t min_score;
-};
 
 /* ---- ksort.h:84-131 restated over 16-byte records with a 64-bit key (first 8 bytes) ---- */
 struct U128 { uint64_t k, v; };
@@ -717,97 +709,6 @@ __device__ __forceinline__ int32_t pdiff(const V4 &w, const V4 &f) { return (int
 __device__ __forceinline__ uint32_t d2u32(double d) { if(!(d > -9.2e18 && d < 9.2e18)) { return 0; } return (uint32_t)(long long)d; }
 __device__ __forceinline__ uint32_t f2u32(float f) { if(!(f > -9.2e18f && f < 9.2e18f)) { return 0; } return (uint32_t)(long long)f; }
 
-__global__ void __launch_bounds__(64) mm_sort_chain_kernel(K2Args a)
-{
-	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if(t >= a.n_work) { return; }
-	ReadState *st = &a.st[a.work[t]];
-	uint32_t *scratch = a.rs_scratch + (uint64_t)t * a.rs_stride;
-	Seed *s = a.seed_pool + st->seed_off;
-	Root *c = a.root_pool + st->root_off;
-	const DevIndex &ix = a.idx;
-
-	/* mm_seed for round >= 1 (minialign.c:3509-3526): rescued minimizers join the (already sorted) seed array */
-	uint32_t seed_n = st->seed_n;
-	if(a.round > 0) {
-		Resc *resc = a.resc_pool + st->resc_off;
-		if(a.round == 1) { if(!radix_sort_128((U128 *)resc, st->n_resc, scratch, a.rs_stride)) { st->err |= ERR_STACK; } }    /* key = qs | n << 32 */
-		seed_n = st->n_seed;
-		for(uint32_t i = 0; i < seed_n; i++) { s[i].lid = 0x7fffffffu; }
-		uint32_t p = st->presc, e = st->n_resc;
-		while(p < e && resc[p].n <= ix.occ[a.round]) {
-			Resc m = resc[p];
-			for(uint32_t j = 0; j < m.n; j++) {
-				uint64_t hit = (int64_t)m.ref >= 0 ? m.ref : ix.val[((m.ref & 0x7fffffffffffffffull) >> 24) + j];
-				uint32_t rid = (uint32_t)(hit >> 32), rs = (uint32_t)hit;
-				uint32_t rmask = (uint32_t)-(int32_t)(rid & 1);
-				int32_t _rs = (int32_t)(rs + (ix.k & rmask)), _qs = (int32_t)(m.qs ^ rmask);
-				if(seed_n + 2 < st->seed_cap / 2) { s[seed_n++] = Seed{ U_(_rs, _qs), rid >> 1, V_(_rs, _qs), 0x7fffffffu }; } else { st->err |= ERR_SEED_CAP; }
-			}
-			p++;
-		}
-		st->presc = p;
-	}
-	st->n_seed = seed_n; st->n_root = 0; st->pred_rid = gaba::NIL;
-	if(seed_n == 0) { st->seed_n = 0; return; }
-	/* sentinel + sort (minialign.c:3531-3535) */
-	s[seed_n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu };
-	uint32_t n_all = seed_n + 1;
-	if(!radix_sort_128((U128 *)s, n_all, scratch, a.rs_stride)) { st->err |= ERR_STACK; }
-
-	/* mm_chain_seeds (minialign.c:3547-3625) */
-	Seed *ls = s;                                   /* leaf view of the same array */
-	uint32_t ncid = 0, nlid = seed_n + 1, nlsid = 0, tsid = seed_n;
-	const int32_t tw = (int32_t)a.twlen;
-	while(nlsid < tsid) {
-		uint32_t lid = nlid++;
-		ls[lid] = Seed{ nlsid, s[nlsid].rid, nlsid, 0xffffffffu };        /* { rsid, rid, lsid, cid } */
-		uint32_t plen = s[nlsid].upos + s[nlsid].vpos, scnt = 1;
-		uint64_t nrsid = nlsid; nlsid = 0xffffffffu;
-		while(true) {
-			uint32_t rsid = (uint32_t)nrsid; nrsid = 0;
-			V4 wv = add_win(load_pv(s[rsid]), tw);
-			for(uint32_t sid = rsid + 1; ; sid++) {
-				V4 fv = load_pv(s[sid]);
-				if(!inside_wv(wv, fv)) {
-					nlsid = nlsid < sid ? nlsid : sid;
-					if(inside_uub(wv, fv)) { continue; }
-					break;
-				}
-				wv = update_wv(wv, fv);
-				int64_t di = (int64_t)(((uint64_t)(int64_t)pdiff(wv, fv) << 32) | sid);
-				nrsid = (uint64_t)((int64_t)nrsid > di ? (int64_t)nrsid : di);
-			}
-			if(nrsid == 0) { nrsid = rsid; break; }
-			if(s[(uint32_t)nrsid].lid != 0x7fffffffu) { nrsid = (uint32_t)nrsid; break; }
-			s[(uint32_t)nrsid].lid = lid; scnt++;
-			if((uint64_t)nlsid <= nrsid) { nlsid = 0xffffffffu; }     /* the reference compares with the full (pdiff << 32 | sid) value */
-		}
-		if(nrsid == ls[lid].vpos /* lsid */) { continue; }
-		uint32_t cid = 0xffffffffu;
-		if(s[nrsid].lid < lid) {
-			nrsid = ls[s[nrsid].lid].upos /* rsid */;
-			cid = ls[s[nrsid].lid].lid /* cid */;
-		}
-		if(cid == 0xffffffffu) { cid = ncid++; c[cid] = Root{ (uint32_t)OFS(0), lid }; }
-		ls[lid].lid = cid; ls[lid].upos = (uint32_t)nrsid;
-		plen = (uint32_t)OFS((int32_t)d2u32((1.0 - 1.0 / (double)scnt) * (double)(uint32_t)((s[nrsid].upos + s[nrsid].vpos) - plen)));
-		if(plen < c[cid].plen) { c[cid] = Root{ plen, lid }; }
-	}
-	st->seed_n = nlid; st->n_root = ncid;
-	if(ncid == 0) { return; }
-	if(a.idx.seq_circ) { circularize(s, c, seed_n, nlid, ncid, a.idx.seq_len, a.idx.seq_circ, a.twlen); }
-	if(!radix_sort_64((U64R *)c, ncid, scratch, a.rs_stride)) { st->err |= ERR_STACK; }      /* longest first (minialign.c:3719) */
-	/* prediction for the carried reference-length state: the last chain that passes the length test of
-	 * mm_search_load_root (minialign.c:3849) is the last one mm_init_ref sees, unless the extension loop stops early */
-	uint32_t pred = gaba::NIL, n_pass = 0, w_pass = 0;          /* chains that pass the length test of mm_search_load_root and their summed lengths: what the extension will cost */
-	for(uint32_t kq = 0; kq < ncid; kq++) {
-		uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
-		if(pl * a.mcoef < 2.0 * a.min_score) { break; }
-		pred = s[ls[c[kq].lid].upos].rid; n_pass++; w_pass += pl;
-	}
-	st->pred_rid = pred; st->n_pass = n_pass; st->w_pass = w_pass;
-}
 
 typedef __attribute__((address_space(3))) Seed LSeed;
 typedef __attribute__((address_space(3))) uint32_t LU32;
@@ -1026,25 +927,6 @@ __global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_sort_kernel(K2sA
 	if(lane == 0) { atomicAdd(&a.prof[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
 }
 
-/* K2s, lane per read (experiment, MM_K2_LANE_SORT; round 5): the literal radix_sort_128 of the rounds through the host, one LANE per read on the seed array in HBM, every read
- * of the batch in flight in one launch without LDS -- the form that took the chain sweep from 992 to 153 cycles per seed (K2w).  Reads of more than K2S_MAX_N seeds stay with K2a. */
-struct K2lArgs { ReadState *st; const uint32_t *work; uint32_t n_work; Seed *seed_pool; uint32_t *scratch; uint32_t stride; unsigned long long *prof; };
-__global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_sort_lane_kernel(K2lArgs a)
-{
-	__builtin_amdgcn_s_setprio(2);
-	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
-	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if(t < a.n_work) {
-		ReadState *st = &a.st[a.work[t]];
-		const uint32_t n = st->seed_n0, n_all = n + 1;
-		if(n != 0 && n_all <= K2S_MAX_N) {
-			Seed *gs = a.seed_pool + st->seed_off;
-			gs[n] = Seed{ 0x80000000u, 0x7fffffffu, 0x80000000u, 0x7fffffffu };          /* sentinel, minialign.c:3531 */
-			if(!radix_sort_128((U128 *)gs, n_all, a.scratch + (uint64_t)t * a.stride, a.stride)) { st->err |= ERR_STACK; }
-		}
-	}
-	if(lane_id() == 0) { atomicAdd(&a.prof[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
-}
 
 /* -----------------------------------------------------------------------------------------------------
  * K2p + K2c: mm_chain_seeds (minialign.c:3547-3625) over the sorted seed array, in two launches.
@@ -1096,16 +978,6 @@ __global__ void __launch_bounds__(64) mm_chain_scan_kernel(K2pArgs a)
 	}
 	if(lane == 0) { atomicAdd(&a.prof[1], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
 }
-struct K2cArgs {
-	ReadState *st; const uint32_t *work; uint32_t n_work;
-	Seed *seed_pool; Root *root_pool;
-	uint32_t lds_bytes, n_lo, n_hi;   /* this launch takes the reads with n_lo < k2c_bytes(...) <= n_hi */
-	uint32_t retry, leaf_shift;       /* first attempt: room for (n + 1) >> leaf_shift leaves; retry = 1: the reads whose leaves did not fit (n_root = ~0), with room for n + 1 */
-	uint32_t *counter;
-	double mcoef; uint32_t min_score, twlen;
-	const uint32_t *seq_len; const uint8_t *seq_circ;
-	unsigned long long *prof;         /* [1] wave cycles, [5] reads whose leaf area overflowed */
-};
 /* the largest LDS image mm_chain_kernel takes: what a CU has left beside eight workgroups of the extension kernel (K3_LDS_BYTES each) -- a launch that asks for all
  * 160 KB finds no CU to start on until an extension launch of another lane ends, whether it has a read to sweep or not; larger reads go the in-HBM way of K2a */
 #ifndef K2C_MAX_LDS_KB
@@ -1113,119 +985,6 @@ struct K2cArgs {
 #endif
 __host__ __device__ inline uint32_t k2c_leafcap(uint32_t n_all, uint32_t shift) { return (n_all >> shift) + 64; }
 __host__ __device__ inline uint32_t k2c_bytes(uint32_t n_all, uint32_t leafcap) { return 12u * ((n_all + 63u) & ~63u) + 12u * ((leafcap + 63u) & ~63u) + 1536u * 4u; }
-__global__ void __launch_bounds__(64, MM_SHORT_KERNEL_WAVES) mm_chain_kernel(K2cArgs a)
-{
-	__builtin_amdgcn_s_setprio(2);          /* short and latency bound beside the extension waves of the other lanes (which run at 0 or 1, the few heaviest reads of a launch at 3) */
-	extern __shared__ uint8_t lds_raw[];
-	const int lane = lane_id();
-	const unsigned long long cy_begin = __builtin_amdgcn_s_memtime();
-	LU32 *tab = (LU32 *)(lds_raw + a.lds_bytes - 1536 * 4);       /* scratch of the root sort */
-	while(true) {
-		uint32_t wi = 0;
-		if(lane == 0) { wi = atomicAdd(a.counter, 1u); }
-		wi = (uint32_t)rdfirst((int)wi);
-		if(wi >= a.n_work) { break; }
-		ReadState *st = &a.st[a.work[wi]];
-		const uint32_t n = (uint32_t)rdfirst((int)st->seed_n0), n_all = n + 1;
-		if(n == 0) { if(a.n_lo == 0 && !a.retry && lane == 0) { st->n_seed = 0; st->n_root = 0; st->pred_rid = gaba::NIL; } continue; }
-		if(n_all > K2S_MAX_N) { continue; }                               /* the in-HBM path of K2a takes these */
-		if(a.retry && (uint32_t)rdfirst((int)st->n_root) != 0xffffffffu) { continue; }
-		const uint32_t lcap = a.retry ? n_all : k2c_leafcap(n_all, a.leaf_shift);
-		const uint32_t need = k2c_bytes(n_all, lcap);
-		if(need <= a.n_lo || need > a.n_hi) { continue; }                /* another size class */
-		const uint32_t N = (n_all + 63u) & ~63u, C = (lcap + 63u) & ~63u;
-		/* per seed: ent = { succ | seen << 16, mark } (one 8-byte read gives everything the sweep wants to know about a seed), uv = upos + vpos;
-		 * per leaf: rsid, lsid, cid; per chain: lid, plen */
-		typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-		typedef __attribute__((address_space(3))) u32x2 LU64;
-		LU64 *ent = (LU64 *)lds_raw; LU32 *uv = (LU32 *)(ent + N);
-		LU16 *lrs = (LU16 *)(uv + N), *lls = lrs + C, *lcid = lls + C, *rlid = lcid + C;
-		LU32 *rplen = (LU32 *)(rlid + C);
-		Seed *gs = a.seed_pool + rdfirst64(st->seed_off);
-		Root *c = a.root_pool + rdfirst64(st->root_off);
-		const uint2 *ss = (const uint2 *)(gs + n_all);
-		for(uint32_t i = (uint32_t)lane; i < n; i += 64) {
-			const uint2 x = ss[i]; const Seed sd = gs[i];
-			u32x2 ev; ev.x = (x.x & 0xffffu) | ((x.y == 0xffffffffu ? 0xffffu : (x.y & 0xffffu)) << 16); ev.y = 0xffffffffu; ent[i] = ev;
-			uv[i] = sd.upos + sd.vpos;
-		}
-		if(lane == 0) { st->n_seed = n; st->n_root = 0; st->pred_rid = gaba::NIL; }
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		/* ---- the sweep (minialign.c:3560-3622): one lane, everything it touches is in LDS, one dependent read per chained seed ---- */
-		uint32_t ncid = 0, nleaf = 0; uint32_t over = 0;
-		if(lane == 0) {
-			uint32_t nlsid = 0; const uint32_t tsid = n;
-			while(nlsid < tsid) {
-				const uint32_t lf = nleaf++;                     /* leaf number; its id in the array is n_all + lf */
-				if(lf >= lcap) { over = 1; break; }
-				const uint32_t lsid0 = nlsid;
-				const u32x2 e0 = ent[lsid0]; const uint32_t plen0 = uv[lsid0]; uint32_t scnt = 1;
-				lrs[lf] = (uint16_t)lsid0; lls[lf] = (uint16_t)lsid0; lcid[lf] = 0xffffu;
-				uint32_t nrsid = lsid0, x = e0.x, hl = e0.y;    /* hl: the mark of the seed the chain stands on when it stops */
-				nlsid = 0xffffffffu;
-				while(true) {
-					const uint32_t nx = x & 0xffffu; uint32_t sm = x >> 16; if(sm == 0xffffu) { sm = 0xffffffffu; }
-					nlsid = nlsid < sm ? nlsid : sm;
-					if(nx == 0) { break; }                        /* nothing inside the window: the chain ends on the seed it stands on */
-					const u32x2 en = ent[nx];
-					nrsid = nx; hl = en.y;
-					if(en.y != 0xffffffffu) { break; }            /* marked by an earlier leaf: the chain runs into that one */
-					((LU32 *)&ent[nx])[1] = lf; hl = lf;
-					scnt++;
-					if(nlsid <= nx) { nlsid = 0xffffffffu; }
-					x = en.x;
-				}
-				if(nrsid == lsid0) { continue; }
-				uint32_t cid = 0xffffu;
-				if(hl != 0xffffffffu && hl < lf) {
-					nrsid = lrs[hl];                              /* leaf.rsid */
-					cid = lcid[ent[nrsid].y & 0x7fffu];           /* leaf.cid of the leaf that marks it */
-				}
-				bool fresh = false;
-				if(cid == 0xffffu) { cid = ncid++; fresh = true; }
-				const uint32_t eu = uv[nrsid];
-				const uint32_t plen = (uint32_t)OFS((int32_t)d2u32((1.0 - 1.0 / (double)scnt) * (double)(uint32_t)(eu - plen0)));
-				uint32_t best = fresh ? (uint32_t)OFS(0) : rplen[cid];
-				if(fresh) { rlid[cid] = (uint16_t)lf; }
-				lcid[lf] = (uint16_t)cid; lrs[lf] = (uint16_t)nrsid;
-				if(plen < best) { best = plen; rlid[cid] = (uint16_t)lf; }
-				if(fresh || plen == best) { rplen[cid] = best; }
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		over = (uint32_t)rdfirst((int)over); ncid = (uint32_t)rdfirst((int)ncid); nleaf = (uint32_t)rdfirst((int)nleaf);
-		if(over) {
-			/* leaf area exhausted: nothing has been written, the retry launch redoes the read with room for one leaf per seed */
-			if(lane == 0) { if(!a.retry) { st->n_root = k2c_bytes(n_all, n_all) <= K2C_MAX_LDS_KB * 1024u ? 0xffffffffu : 0xfffffffeu; atomicAdd(&a.prof[5], 1ull); } else { st->err |= ERR_SEED_CAP; } }
-			continue;
-		}
-		/* write out: the seeds' marks, the sentinel, the leaves { rsid, rid, lsid, cid }, the chain roots */
-		for(uint32_t i = (uint32_t)lane; i < n; i += 64) { const uint32_t mk = ent[i].y; gs[i].lid = mk == 0xffffffffu ? 0x7fffffffu : n_all + mk; }
-		for(uint32_t lf = (uint32_t)lane; lf < nleaf; lf += 64) {
-			const uint32_t ls = lls[lf], ci = lcid[lf];
-			gs[n_all + lf] = Seed{ (uint32_t)lrs[lf], gs[ls].rid, ls, ci == 0xffffu ? 0xffffffffu : ci };
-		}
-		for(uint32_t ci = (uint32_t)lane; ci < ncid; ci += 64) { c[ci] = Root{ rplen[ci], n_all + (uint32_t)rlid[ci] }; }
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-		if(lane == 0) {
-			const uint32_t nlid = n_all + nleaf;
-			st->seed_n = nlid; st->n_root = ncid;
-			if(ncid) {
-				if(a.seq_circ) { circularize(gs, c, n, nlid, ncid, a.seq_len, a.seq_circ, a.twlen); }
-				if(!radix_sort_64((U64R *)c, ncid, (uint32_t *)tab, 1536)) { st->err |= ERR_STACK; }              /* longest first (minialign.c:3719) */
-				uint32_t pred = gaba::NIL, n_pass = 0, w_pass = 0;          /* chains that pass the length test of mm_search_load_root and their summed lengths: what the extension will cost */
-				for(uint32_t kq = 0; kq < ncid; kq++) {
-					uint32_t pl = (uint32_t)OFS((int32_t)c[kq].plen);
-					if(pl * a.mcoef < 2.0 * a.min_score) { break; }
-					pred = gs[gs[c[kq].lid].upos].rid; n_pass++; w_pass += pl;
-				}
-				st->pred_rid = pred; st->n_pass = n_pass; st->w_pass = w_pass;
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	}
-	if(lane == 0) { atomicAdd(&a.prof[1], (unsigned long long)(__builtin_amdgcn_s_memtime() - cy_begin)); }
-}
 
 /* -----------------------------------------------------------------------------------------------------
  * K2w: the same sweep, one LANE per read, everything in HBM / L2.  The sweep is a chain of dependent look-ups (one round trip per chained seed) whichever memory
@@ -1713,17 +1472,10 @@ struct K3Args {
 	 * (they stay in the launch until the last read is done: reads_done).  The owner takes a result where its inputs are the trial's, runs a job itself where nobody has claimed it, and
 	 * works on a later job of its own while one it needs is in another wave's hands.  NULL: none */
 	uint32_t rq_helper_mask;             /* one wave in (mask + 1) is a helper for the retry jobs (one in 128 by default): the first wave of one workgroup in (mask + 1) / 4 of every XCD; every helper holds a wave slot the other lanes' launches wait for */
-	uint32_t full_n;                     /* workspaces per XCD that make a class complete: one for every wave the XCD can hold */
-	uint32_t rq_early;                   /* helpers are helpers from the start of the launch (they take no reads): the reads that publish retry jobs are at the front of the work list */
 	struct SpecJob *rjobs; struct SpecMemo *rmemo; uint32_t *rstate; uint32_t rq_cap; unsigned int *rq_ctl;      /* rq_ctl[0] = published, [1] = the takers' cursor, [2] = reads done, [3] = results taken, [4] = reads being walked that have published the chains of a round, [5] = the cursor of the waves that take chain jobs between their reads */
 	unsigned long long *stage_top;       /* cursors of the staging area (spath / sseg) that the traced jobs of either kind write to: [0] path words, [1] segments */
-	uint32_t rq_stay;                    /* experiment (MM_K3_STAY): waves without reads stay while a read that has published the chains of a round is being walked */
-	uint32_t rq_between;                 /* 1: a wave with reads left takes published jobs that fit the workspace it holds before its next read (2: of any class; 3: retry jobs too; 0: only waves without reads take jobs) */
 	uint32_t round_jobs;                 /* n > 0: a read publishes the chains of a round that was chained inside the launch as jobs (rjobs, JOB_FULL) when it has n or more of them (at least 2) */
 	uint32_t dyn0_min;                   /* experiment (MM_K3_DYN_ROUND0 = n, off = 0): a read with n or more passing chains in the round the launch starts with that got no chain jobs before the launch publishes them itself when its wave takes it */
-	uint32_t persistent;                 /* 1: waves steal reads from the counter until none is left; 0: one read per wave (grid = reads / 4; needs the shared workspaces) */
-	uint32_t defer_thr;                  /* experiment (MM_K3_DEFER_RESCUE, off = 0): a read left without a result by the first threshold that has this many rescue hits waiting does NOT go on inside
-	                                      * the launch; the host runs its later rounds as launches of their own, where the chains it finds there are spread over the launch as chain jobs */
 	/* the watchdog's window into the launch (pinned host memory the device writes to while the kernel runs; NULL: none): wd[0] != 0 = the host has called the launch off --
 	 * every wave that is waiting for something leaves, its read marked ERR_ABORT; wd[K3_WD_HEAD + wave] = where that wave is (K3_WD_* << 28 | detail), written when a read
 	 * is taken and from inside every wait that lasts (k3_wd_tick).  No wait of the kernel is without this way out */
@@ -2199,7 +1951,6 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	/* with shared workspaces a wave maps ONE read and ends (grid = reads / 4): wave slots then come free read by read, and the launches of the other lanes --
 	 * sketch, sort, chain, copies, the next extension launch -- get theirs within a read's time instead of waiting for a whole persistent launch to drain;
 	 * the per-wave scratch is numbered like the workspace.  Without the ring (per-call entries): persistent waves stealing reads from a counter, as before. */
-	const bool persistent = a.persistent != 0 || a.ring == nullptr;
 	uint64_t *next = a.next_pool + (uint64_t)wave * MM_NEXT_STRIDE(a.next_cap);      /* [next_cap entries][radix-sort scratch]; one-read-per-wave launches: re-pointed below by workspace number */
 	uint32_t *next_scratch = (uint32_t *)(next + a.next_cap);
 	const DevIndex &ix = a.idx;
@@ -2293,7 +2044,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 	 * first trials of the chains a read finds in a later occurrence-threshold round (the whole trial), into rmemo[ji]; taken by helper waves, by every wave between two
 	 * reads, by waves that have run out of reads while a read with published chains is still being walked, or by the read's own wave ahead of its turn */
 	enum : uint32_t { RJ_EMPTY = 0, RJ_READY = 1, RJ_CLAIMED = 2, RJ_DONE = 3, RJ_CANCELLED = 4 };
-	const bool rq_on = a.rjobs != nullptr && a.ring != nullptr && persistent;
+	const bool rq_on = a.rjobs != nullptr && a.ring != nullptr;
 	/* the read's own wave, while a job it needs is in another wave's hands: one of its later jobs (slots [q0, q1)), if one is still unclaimed */
 	auto own_job = [&](uint32_t q0, uint32_t q1) -> bool {
 		uint32_t take = 0xffffffffu;
@@ -2307,10 +2058,10 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 
 	/* the helpers: the first wave of one workgroup in (mask + 1) / 4, counted within an XCD (workgroup b runs on XCD b % 8: the workspaces a helper can take are its XCD's) */
 	const bool rq_helper = rq_on && (threadIdx.x >> 6) == 0 && ((blockIdx.x >> 3) & (max(a.rq_helper_mask, 3u) >> 2)) == 0;
-	bool no_reads = rq_helper && a.rq_early;          /* this wave takes no (more) reads */
+	bool no_reads = rq_helper;          /* this wave takes no (more) reads: the helpers are helpers from the start of the launch (the reads that publish retry jobs are at the front of the work list) */
 	uint32_t rq_mine = 0xffffffffu;                   /* a slot number this wave drew that has not been published yet */
 	while(true) {
-		if(rq_on && (no_reads || a.rq_between != 0u)) {
+		if(rq_on) {
 			/* published jobs come before the next read: a wave with reads left takes what is there and goes on; one without stays -- a helper until the last read is done,
 			 * any other wave while a read that has published the chains of a later round is still being walked (rq_ctl[4]) */
 			uint32_t idle = 0;
@@ -2333,13 +2084,13 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 					/* the workspace the job needs comes BEFORE the claim: a claimed job is one that will be finished, whatever the waves that wait for it hold (with several
 					 * workspace classes a wave that claimed first and then waited for a workspace of a scarce class could wait for the very waves that wait for it) */
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-					if(!no_reads && a.rq_between < 3u && ((uint32_t)rdfirst((int)a.rjobs[ji].pad) & JOB_FULL) == 0u) { rq_mine = 0xffffffffu; idle = 0; continue; }          /* (a retry job: the helpers') */
+					if(!no_reads && ((uint32_t)rdfirst((int)a.rjobs[ji].pad) & JOB_FULL) == 0u) { rq_mine = 0xffffffffu; idle = 0; continue; }          /* (a retry job: the helpers') */
 					const uint32_t jr = (uint32_t)rdfirst((int)a.rjobs[ji].r), jq = (uint32_t)rdfirst((int)a.in[jr].qlen);
 					const int want = class_of(jq);
 					bool have = want == slab_cls;
 					/* (a wave with reads left keeps the workspace it holds: on a ladder of classes it would give a scarce one back for a job of another class and wait for it again for
 					 * its next read -- it takes the jobs that fit what it holds, the waves without reads take any) */
-					if(!have && (no_reads || slab_cls < 0 || a.rq_between >= 2u)) { have = try_slab(want); }
+					if(!have && (no_reads || slab_cls < 0)) { have = try_slab(want); }
 					if(have) { if(lane == 0) { stt = atomicCAS(&a.rstate[ji], (uint32_t)RJ_READY, (uint32_t)RJ_CLAIMED) == RJ_READY ? 100u : 99u; } stt = (uint32_t)rdfirst((int)stt); }
 					else { stt = RJ_EMPTY; }          /* no workspace of that class free: the job stays with its owner unless one comes back before the owner gets there */
 				}
@@ -2359,7 +2110,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				/* a wave that is not a helper leaves as soon as nothing is on offer: staying for what the reads still being walked MIGHT publish (the first form: while
 				 * rq_ctl[4] != 0) held thousands of wave slots through the tail of every launch -- the waves of the other lanes' launches wait for exactly those slots; on the
 				 * ONT-like set, where a launch lasts as long as its longest read, 2.1 against 2.8 G bases/s.  a.rq_stay (MM_K3_STAY): the first form */
-				if(!rq_helper) { if(a.rq_stay ? wide == 0u : (ji == 0xffffffffu || ++idle > 16u)) { break; } }
+				if(!rq_helper) { if(ji == 0xffffffffu || ++idle > 16u) { break; } }
 				__builtin_amdgcn_s_sleep(64);
 				{ uint32_t off = 0; if(lane == 0) { off = k3_wd_tick(wdw, wave, wst, K3_WD_IDLE, ji) ? 1u : 0u; } if(rdfirst((int)off)) { K3_LEAVE(); } }
 			}
@@ -2404,7 +2155,7 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 				if(i < a.seg_len[c]) { wi = a.seg_beg[c] + i; }
 			}
 		}
-		else if(persistent) { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
+		else { if(lane == 0) { wi = atomicAdd(a.counter, 1u); } wi = (uint32_t)rdfirst((int)wi); }
 		if(wi >= a.n_work) {
 			/* no read left for this wave: it stays for the published jobs of the reads that are still being walked (above), or ends */
 			if(rq_on) { no_reads = true; continue; }
@@ -2905,7 +2656,6 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if(!a.inkernel_rounds || n_res > 0 || err != 0 || round + 1 >= ix.n_occ) { break; }
-		if(a.defer_thr) { const uint32_t half = (uint32_t)rdfirst((int)st->seed_cap) / 2u, base = (uint32_t)rdfirst((int)st->seed_n0) + 2u; if(half > base && half - base >= a.defer_thr) { if(lane == 0) { st->done = 2; } break; } }          /* (done = 2: the later rounds are the host's) */
 		}
 		if(((uint32_t)rdfirst((int)st->flags) & RS_CARRY_SRC) != 0u) {
 			/* a read whose end decides what the reads behind it start with: its state is out (st->rlen above), then the flag */
@@ -2914,7 +2664,6 @@ __global__ void __launch_bounds__(256, MM_K3_LAUNCH_BOUND) mm_extend_kernel(K3Ar
 			if(lane == 0) { __hip_atomic_store(&st->carry_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 		}
 		if(rq_on && lane == 0) { atomicAdd(&a.rq_ctl[2], 1u); }          /* (helper waves leave when every read is done) */
-		if(!persistent) { break; }
 	}
 	if(lane == 0) {
 		atomicAdd(&a.stats[2], n_fill); atomicAdd(&a.stats[3], (unsigned long long)x.n_vec); atomicAdd(&a.stats[4], (unsigned long long)x.n_blk);

@@ -725,11 +725,7 @@ struct DevCache {
 	 * being replaced: nothing is in flight then) -- an ONT-like run that re-sized its workspace ladder a few times had 150 GB of them waiting here and the runtime ran out of memory */
 	void give(int dev, size_t bytes, void *p)
 	{
-		/* MM_POISON_CACHE (diagnostics): a block that comes back is overwritten, so that anything still reading it -- a kernel of another lane, a copy in flight, a pointer
-		 * kept in a descriptor -- computes garbage instead of the right bytes by luck */
-		static const bool poison = getenv("MM_POISON_CACHE") != NULL;
-		if(poison) { (void)hipMemset(p, 0xab, bytes); (void)hipDeviceSynchronize(); }
-		/* ... and nothing is kept while the device is short of memory (the runtime allocates the kernels' scratch memory on demand and aborts the process when it cannot).
+		/* nothing is kept while the device is short of memory (the runtime allocates the kernels' scratch memory on demand and aborts the process when it cannot).
 		 * `tight` is what the last fresh allocation found: hipMemGetInfo costs about 2 ms, and a stream gives a dozen buffers back when it ends -- asked here, it made every
 		 * stream 20 ms longer, 12 % of one over an E.coli-size set */
 		{ std::lock_guard<std::mutex> lk(mu); const int d = dslot(dev); if(!tight[d].load() && bytes <= (16ull << 30) && held[d] + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held[d] += bytes; return; } }
@@ -1196,7 +1192,6 @@ struct mm_align_s {
 	gaba_arena_t *ref_ar = nullptr;
 	uint32_t twlen, tglen; double mcoef, xcoef;
 	hipStream_t stream; hipEvent_t ev0, ev1;
-	hipStream_t k3s = nullptr; hipEvent_t k3e = nullptr;      /* the extension launches' own stream (lowest priority; the others are created with the highest), see make_streams */
 	hipStream_t k2s[12]; hipEvent_t k2e[16]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
 	uint64_t mem_for_batches = 0;                              /* device memory the lanes' pools may take together (measured when the first text stream starts: batch_cap_bases) */
@@ -1320,7 +1315,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 	a->k3_called_off.store(false);
 	/* a re-run of a few reads with the carried value given (batch_verify_carry): the short way -- one sort + chain launch, no round trip of the states between chaining
 	 * and extension (the caller has put the value and the reset fields in place), the work list as it is */
-	const bool small_rerun = rlen_fixed != nullptr && run_k1 && work.size() < 256 && getenv("MM_SLOW_RERUN") == NULL;
+	const bool small_rerun = rlen_fixed != nullptr && run_k1 && work.size() < 256;
 	if(run_k1) {
 		CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
 		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
@@ -1331,7 +1326,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k1.counter = (uint32_t *)(tops + 16); k1.stats = tops + 8; k1.work = a->d_work.p; k1.tap = nullptr; k1.note = a->pin_note;
 		/* the overflow region for the minimizer records of low-complexity reads: behind the reads' own shares (ensure_pools), its cursor reset with every sketch launch */
 		k1.min_over_top = nullptr; k1.min_over_base = 0; k1.min_over_cap = 0;
-		if(a->min_over_n && a->min_over_base + a->min_over_n <= a->min_pool.n && !getenv("MM_NO_MIN_OVERFLOW")) { k1.min_over_top = tops + 32; k1.min_over_base = a->min_over_base; k1.min_over_cap = a->min_over_n; CK(hipMemsetAsync(tops + 32, 0, 8, a->stream)); }
+		if(a->min_over_n && a->min_over_base + a->min_over_n <= a->min_pool.n) { k1.min_over_top = tops + 32; k1.min_over_base = a->min_over_base; k1.min_over_cap = a->min_over_n; CK(hipMemsetAsync(tops + 32, 0, 8, a->stream)); }
 		if(a->pin_note) { a->pin_note[0] = a->pin_note[1] = a->pin_note[2] = ~0ull; }
 		if(a->tap_stop) { if(!a->tap_words.ensure(a->min_pool.n)) return false; k1.tap = a->tap_words.p; }
 		uint32_t waves = std::min<uint32_t>(a->n_waves, (uint32_t)((work.size() + 3) & ~3ull));
@@ -1353,7 +1348,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 					t3[0] * 1e-6, t3[1] * 1e-6, t3[2] * 1e-6, t3[0] / bb, t3[1] / bb, t3[2] / bb, a->seed_pool.n * 1e-6, a->resc_pool.n * 1e-6, a->root_pool.n * 1e-6);
 				auto grow = [](uint64_t need) -> uint64_t { const uint64_t w = need + need / 8 + (1ull << 20), q = w < (64ull << 20) ? (1ull << 20) : (16ull << 20); return (w + q - 1) / q * q; };
 				if((t3[0] > a->seed_pool.n && !a->seed_pool.ensure(grow(t3[0]))) || (t3[1] > a->resc_pool.n && !a->resc_pool.ensure(grow(t3[1]))) || (t3[2] > a->root_pool.n && !a->root_pool.ensure(grow(t3[2])))) return false;
-				if(!getenv("MM_K2_LDS_CHAIN") && !a->k2w_scratch.ensure(a->seed_pool.n * 8)) return false;
+				if(!a->k2w_scratch.ensure(a->seed_pool.n * 8)) return false;
 				a->st.pool_regrows++;
 				if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;          /* (the states as they were before the launch) */
 				CK(hipMemsetAsync(tops, 0, 3 * 8, a->stream)); CK(hipMemsetAsync(tops + 8, 0, 2 * 8, a->stream)); CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
@@ -1367,22 +1362,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 	}
-	/* experiment (MM_K3_DEFER_RESCUE=n, off by default; not yet run on a GPU): reads that the first threshold leaves without a result and that have n rescue hits or more
-	 * waiting come back to the host, and their later rounds run as launches of their own -- the serial sort + chain kernel, then an extension launch whose waves first take
-	 * the chains those reads now have as chain jobs (the enumeration and the hand-off of round 0, at a later round) -- instead of on the one wave that holds the read */
-	const uint32_t defer_thr = getenv("MM_K3_DEFER_RESCUE") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_DEFER_RESCUE"))) : 0u;
-	bool deferred = false;          /* the rounds from here on are those of deferred reads */
+	const bool deferred = false;          /* (round 4's experiment -- the later rounds of rescue-heavy reads as launches of their own -- lost to the round jobs of round 5: HISTORY.md) */
 	for(uint32_t round = 0; round < a->mi->n_occ && !work.empty(); round++) {
 		CK(hipMemcpyAsync(a->d_work.p, work.data(), work.size() * 4, hipMemcpyHostToDevice, a->stream));
-		K2Args k2; k2.idx = a->dix; k2.st = a->d_st.p; k2.work = a->d_work.p; k2.n_work = (uint32_t)work.size(); k2.round = round;
-		k2.seed_pool = a->seed_pool.p; k2.resc_pool = a->resc_pool.p; k2.root_pool = a->root_pool.p;
-		k2.twlen = a->twlen; k2.mcoef = a->mcoef; k2.min_score = a->o.min_score;
-		auto launch_serial_k2 = [&](uint32_t n) -> bool {
-			if(!a->rs_scratch.ensure((uint64_t)n * a->rs_stride)) return false;
-			k2.rs_scratch = a->rs_scratch.p; k2.rs_stride = a->rs_stride; k2.n_work = n;
-			hipLaunchKernelGGL(mm_sort_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, a->stream, k2);
-			return hipGetLastError() == hipSuccess;
-		};
 		CK(hipEventRecord(a->ev0, a->stream));
 		if(round == 0) {
 			/* wave-per-read kernel with the seed array in LDS.  Reads are split into size classes by the LDS they need, one launch
@@ -1398,27 +1380,17 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			 * chain launches below then waits for all of them (a read's sort class is not its chain class) */
 			/* the few reads of a re-run (the carried-value check): ONE launch, sort + chain in place in HBM (the form the largest reads take) -- the nine launches of the
 			 * size classes each wait 10 - 40 ms for a wave slot beside the extension waves of the other lanes, and every lane behind this one waits for the check */
-			const bool presort = getenv("MM_K2_NO_PRESORT") == NULL && getenv("MM_K2_FORCE_HBM") == NULL && !small_rerun;
+			const bool presort = !small_rerun;
 			if(small_rerun) {
 				ka.presorted = 0; ka.leaf_shift = a->k2_leaf_shift ? 1u : 0u; ka.big_only = 0; ka.retry = 0; ka.lds_bytes = 1536 * 4; ka.n_lo = 0; ka.n_hi = 0xffffffffu; ka.counter = a->d_k2cnt.p + 12;
 				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3((uint32_t)work.size()), dim3(64), 1536 * 4, a->stream, ka);
 				CK(hipGetLastError());
 			}
-			if(presort && getenv("MM_K2_LANE_SORT")) {
-				/* experiment: the sort with one lane per read in HBM (mm_sort_lane_kernel) instead of the size classes in LDS */
-				if(!a->rs_scratch.ensure((uint64_t)work.size() * a->rs_stride)) return false;
-				K2lArgs kl; kl.st = a->d_st.p; kl.work = a->d_work.p; kl.n_work = (uint32_t)work.size(); kl.seed_pool = a->seed_pool.p; kl.scratch = a->rs_scratch.p; kl.stride = a->rs_stride; kl.prof = tops + 28;
-				CK(hipStreamWaitEvent(a->k2s[0], a->ev0, 0));
-				hipLaunchKernelGGL(mm_sort_lane_kernel, dim3(((uint32_t)work.size() + 63) / 64), dim3(64), 0, a->k2s[0], kl);
-				CK(hipGetLastError());
-				CK(hipEventRecord(a->k2e[12], a->k2s[0]));
-				for(int j = 1; j < MM_SIDE; j++) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[12], 0)); }
-			}
-			else if(presort) {
+			if(presort) {
 				static const uint32_t s_kb[] = { 10, 14, 20, 32, 64, 104 };          /* k2s_bytes(K2S_MAX_N) <= 104 KB */
 				const int n_s = (int)(sizeof(s_kb) / sizeof(s_kb[0]));
 				K2sArgs ks; ks.st = a->d_st.p; ks.work = a->d_work.p; ks.n_work = (uint32_t)work.size(); ks.seed_pool = a->seed_pool.p; ks.prof = tops + 28;
-				{ const size_t ns = a->mi->seq.size(); ks.start_shift = getenv("MM_K2_ALL_LEVELS") ? 56u : (ns <= 1 ? 24u : (ns <= 256 ? 32u : (ns <= 65536 ? 40u : 56u))); }
+				{ const size_t ns = a->mi->seq.size(); ks.start_shift = (ns <= 1 ? 24u : (ns <= 256 ? 32u : (ns <= 65536 ? 40u : 56u))); }
 				const uint32_t n_cu = a->n_waves / (4 * MM_K3_WAVES_PER_SIMD);
 				for(int si = 0; si < n_s; si++) {
 					ks.lds_bytes = s_kb[si] * 1024u; ks.n_lo = si ? s_kb[si - 1] * 1024u : 0u; ks.n_hi = ks.lds_bytes; ks.counter = a->d_k2cnt.p + 16 + si;
@@ -1442,7 +1414,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				CK(hipGetLastError());
 				CK(hipEventRecord(a->k2e[14], a->k2s[0]));
 				for(int j = 1; j < MM_SIDE; j++) { CK(hipStreamWaitEvent(a->k2s[j], a->k2e[14], 0)); }
-				if(!getenv("MM_K2_LDS_CHAIN")) {
+				{
 					/* the sweep with one lane per read in HBM (mm_chain_sweep_kernel): every read of the batch in flight at once, no LDS, a few hundred waves */
 					K2wArgs kw; kw.st = a->d_st.p; kw.work = a->d_work.p; kw.n_work = (uint32_t)work.size(); kw.seed_pool = a->seed_pool.p; kw.root_pool = a->root_pool.p; kw.scratch = a->k2w_scratch.p; kw.scratch_top = tops + 30; kw.scratch_bytes = a->k2w_scratch.bytes;
 					CK(hipMemsetAsync(tops + 30, 0, 8, a->k2s[0]));
@@ -1450,53 +1422,14 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 					hipLaunchKernelGGL(mm_chain_sweep_kernel, dim3(((uint32_t)work.size() + 63) / 64), dim3(64), 0, a->k2s[0], kw);
 					CK(hipGetLastError());
 					CK(hipEventRecord(a->k2e[0], a->k2s[0])); CK(hipStreamWaitEvent(a->stream, a->k2e[0], 0));
-				} else {
-				static const uint32_t c_kb[] = { 12, 16, 24, 32, 48, 64, 84, K2C_MAX_LDS_KB };
-				const int n_c = (int)(sizeof(c_kb) / sizeof(c_kb[0]));
-				K2cArgs kc; kc.st = a->d_st.p; kc.work = a->d_work.p; kc.n_work = (uint32_t)work.size(); kc.seed_pool = a->seed_pool.p; kc.root_pool = a->root_pool.p;
-				kc.leaf_shift = a->k2_leaf_shift ? 1u : 0u; kc.mcoef = a->mcoef; kc.min_score = a->o.min_score; kc.twlen = a->twlen; kc.seq_len = a->dix.seq_len; kc.seq_circ = a->dix.seq_circ; kc.prof = tops + 24;
-				for(int ci = 0; ci <= n_c; ci++) {
-					/* ci < n_c: size classes; ci == n_c: the reads whose leaves did not fit, with room for one leaf per seed, any size */
-					kc.retry = ci == n_c;
-					kc.lds_bytes = (ci == n_c ? K2C_MAX_LDS_KB : c_kb[ci]) * 1024u; kc.n_lo = (ci == n_c || ci == 0) ? 0u : c_kb[ci - 1] * 1024u; kc.n_hi = kc.lds_bytes; kc.counter = a->d_k2cnt.p + ci;
-					const uint32_t per_cu = std::min<uint32_t>(16u, 160u * 1024u / kc.lds_bytes);
-					const uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), n_cu * per_cu);
-					hipStream_t sq = ci == n_c ? a->stream : a->k2s[ci % MM_SIDE];
-					if(ci == n_c) { for(int j = 0; j < MM_SIDE; j++) { CK(hipStreamWaitEvent(a->stream, a->k2e[j], 0)); } }
-					hipLaunchKernelGGL(mm_chain_kernel, dim3(grid), dim3(64), kc.lds_bytes, sq, kc);
-					CK(hipGetLastError());
-					if(ci == n_c - 1 || ci == n_c - 2) { CK(hipEventRecord(a->k2e[ci % MM_SIDE], sq)); }          /* the last launch on each side stream */
-				}
 				}
 				/* reads with more than K2S_MAX_N seeds: the old kernel's in-HBM form, behind everything else on the main stream */
-				ka.big_only = getenv("MM_K2_LDS_CHAIN") ? 1 : 2; ka.retry = 0; ka.leaf_shift = a->k2_leaf_shift ? 1u : 0u; ka.lds_bytes = 1536 * 4; ka.n_lo = 0; ka.n_hi = 0xffffffffu; ka.counter = a->d_k2cnt.p + 12;
+				ka.big_only = 2; ka.retry = 0; ka.leaf_shift = a->k2_leaf_shift ? 1u : 0u; ka.lds_bytes = 1536 * 4; ka.n_lo = 0; ka.n_hi = 0xffffffffu; ka.counter = a->d_k2cnt.p + 12;
 				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(std::min<uint32_t>((uint32_t)work.size(), n_cu)), dim3(64), 1536 * 4, a->stream, ka);
 				CK(hipGetLastError());
 			}
-			auto bytes_of = [](uint32_t div) -> uint32_t { return div ? ((160u * 1024u / div) & ~255u) : 0u; };
-			for(int ci = 0; ci <= n_cls && !presort && !small_rerun; ci++) {
-				/* (the one-kernel form, kept behind MM_K2_NO_PRESORT / MM_K2_FORCE_HBM) ci < n_cls: size classes, largest first; ci == n_cls: retry of the reads whose leaf area overflowed, at 160 KB */
-				const uint32_t div = ci == n_cls ? 1u : cls_div[ci];
-				const uint32_t bytes = bytes_of(div);
-				ka.retry = ci == n_cls;
-				ka.lds_bytes = bytes ? bytes : 1536 * 4;
-				ka.n_hi = ci == 0 ? 0xffffffffu : bytes;                    /* classes are cut by k2a_bytes() of the read */
-				ka.n_lo = ci == 0 ? bytes_of(1) : (ci >= n_cls - 1 ? 0u : bytes_of(cls_div[ci + 1]));
-				if(getenv("MM_K2_FORCE_HBM")) { if(ci == 0) { ka.n_lo = 0; } else if(ci < n_cls) { ka.n_hi = 0; ka.n_lo = 0; } }       /* test hook: every read through the in-HBM path */
-				ka.counter = a->d_k2cnt.p + ci;
-				const uint32_t per_cu = div ? div : 8;
-				uint32_t grid = std::min<uint32_t>((uint32_t)work.size(), (a->n_waves / (4 * MM_K3_WAVES_PER_SIMD)) * per_cu);
-				/* the classes are independent: each goes to its own stream behind ev0 so that their tails overlap; the retry waits for all */
-				hipStream_t sq = ci == n_cls ? a->stream : a->k2s[ci % MM_SIDE];
-				if(ci < n_cls && ci < MM_SIDE) { CK(hipStreamWaitEvent(sq, a->ev0, 0)); }
-				else { for(int j = 0; j < n_cls; j++) { CK(hipStreamWaitEvent(a->stream, a->k2e[j], 0)); } }
-				hipLaunchKernelGGL(mm_sort_chain_lds_kernel, dim3(grid), dim3(64), bytes ? bytes : 1536 * 4, sq, ka);
-				CK(hipGetLastError());
-				if(ci < n_cls) { CK(hipEventRecord(a->k2e[ci], sq)); }
-			}
-		} else {
-			if(!launch_serial_k2((uint32_t)work.size())) return false;
 		}
+
 		CK(hipEventRecord(a->ev1, a->stream)); CK(hipEventSynchronize(a->ev1));
 		CK(hipEventElapsedTime(&ms, a->ev0, a->ev1)); a->st.k2_ms += ms; a->st.k2_launches++;
 
@@ -1514,9 +1447,9 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				 * sketch on when the check finds the guess wrong -- 71 such re-runs per step of the headline set, 154 on a tenth of the hard-repeat set, where the re-runs of a batch
 				 * (one read inside a repeat family alone on a launch: a second) were three quarters of the step; MM_NO_CARRY_DEPS: all by prediction as before */
 				static const bool no_deps = getenv("MM_NO_CARRY_DEPS") != NULL;
-				const bool deps = !no_deps && !safe && getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL && getenv("MM_K3_DEFER_RESCUE") == NULL && getenv("MM_K3_ONE_READ_PER_WAVE") == NULL;
+				const bool deps = !no_deps && !safe;
 				std::vector<uint8_t> in_work(n_reads, 0); for(uint32_t wi : work) in_work[wi] = 1;
-				const double weak_unit = (getenv("MM_CARRY_WEAK") ? std::max(0, atoi(getenv("MM_CARRY_WEAK"))) : 128) * 2.0 * (double)a->o.min_score / a->mcoef;
+				const double weak_unit = 128 * 2.0 * (double)a->o.min_score / a->mcoef;          /* (the factor measured at 0 / 128 / 256 / 384 / 1 024 in round 5: HISTORY.md) */
 				uint32_t cur = a->rlen_carry, src = gaba::NIL;          /* src: the source read that decides the value at hand */
 				a->ran_with.resize(n_reads);
 				if(getenv("MM_VERBOSE")) { a->np0.resize(n_reads); a->wp0.resize(n_reads); for(uint32_t i = 0; i < n_reads; i++) { a->np0[i] = hst[i].n_pass; a->wp0[i] = hst[i].w_pass; } }
@@ -1539,8 +1472,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 		if(a->tap_stop) { return true; }
-		if(deferred) { if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false; }          /* (the chains of this round: n_pass / w_pass for the order and the jobs) */
-		uint32_t k3_work_override = 0, n_heavy = 0; uint32_t seg_beg[8], seg_len[8];
+		uint32_t n_heavy = 0; uint32_t seg_beg[8], seg_len[8];
 		std::vector<uint32_t> by_len(work);          /* (lives until the extension launch is over: its upload below is not waited for on its own) */
 		{
 			/* longest read first: with ~5 reads per wave the tail of the launch is one read long, so the short ones go last */
@@ -1568,7 +1500,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				 * any wave can be waiting: the most rescue hits first */
 				auto resc_hits = [&](uint32_t x) -> uint32_t { const uint32_t half = hst[x].seed_cap / 2, base = hst[x].seed_n0 + 2; return half > base ? half - base : 0u; };
 				std::vector<uint32_t> front;
-				for(uint32_t x : by_len) { if((hst[x].flags & RS_CARRY_SRC) || (getenv("MM_K3_RESCUE_FIRST") && hst[x].n_pass == 0 && hst[x].n_resc > 0 && resc_hits(x) >= 64)) front.push_back(x); }
+				for(uint32_t x : by_len) { if(hst[x].flags & RS_CARRY_SRC) front.push_back(x); }
 				if(!front.empty() && !deferred && round == 0) {
 					std::stable_sort(front.begin(), front.end(), [&](uint32_t x, uint32_t y) { return resc_hits(x) > resc_hits(y); });
 					std::vector<uint8_t> is_front(n_reads, 0); for(uint32_t x : front) is_front[x] = 1;
@@ -1579,15 +1511,6 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 					by_len.assign(rest.begin(), rest.begin() + std::min<size_t>(n_heavy, rest.size())); by_len.insert(by_len.end(), front.begin(), front.end()); by_len.insert(by_len.end(), rest.begin() + std::min<size_t>(n_heavy, rest.size()), rest.end());
 				}
 			}
-			if(deferred) {          /* a launch of deferred reads: all of them are candidates for chain jobs, the ones with the most to walk first */
-				std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return hst[x].w_pass > hst[y].w_pass; });
-				n_heavy = (uint32_t)by_len.size();
-			}
-			if(const char *e = getenv("MM_EXPERIMENT_K3_HEAVY")) {          /* timing experiment only (results incomplete): the N reads with the most chains */
-				std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return hst[x].n_root > hst[y].n_root; });
-				by_len.resize(std::min<size_t>(by_len.size(), (size_t)atoi(e)));
-				k3_work_override = (uint32_t)by_len.size();
-			}
 			{
 				/* with several workspace classes: the reads of a class together, the highest class first (within a class the order made above).  A wave takes reads of
 				 * the highest class that has a workspace free and falls through to the ordinary class otherwise (mm_extend_kernel), instead of waiting at the front of
@@ -1596,7 +1519,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				const mm_align_s *P = a->root ? a->root : a;
 				for(int c = 0; c < 8; c++) { seg_beg[c] = 0; seg_len[c] = 0; }
 				seg_len[0] = (uint32_t)by_len.size();
-				if(P->shared_slabs && P->h_cls.size() > 1 && qlens.size() == n_reads && !k3_work_override && !getenv("MM_K3_ONE_WORK_LIST")) {
+				if(P->shared_slabs && P->h_cls.size() > 1 && qlens.size() == n_reads) {
 					const int n_cls = (int)P->h_cls.size();
 					auto cls_of = [&](uint32_t r) { int c = 0; while(c + 1 < n_cls && qlens[r] > P->h_cls[c].qmax) { c++; } return c; };
 					std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t x, uint32_t y) { return cls_of(x) > cls_of(y); });
@@ -1609,7 +1532,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		}
 		CK(hipMemsetAsync(tops + 16, 0, 8, a->stream));
 		K3Args k3; k3.idx = a->dix; k3.gc = a->gctx->hc; k3.roots = a->gctx->droots; k3.ar_ref = gaba::SeqArena{ a->ref_ar->pk, a->ref_ar->nm }; k3.ar_q = gaba::SeqArena{ a->q_pk.p, a->q_nm.p };
-		k3.in = a->d_in.p; k3.st = a->d_st.p; k3.work = a->d_work.p; k3.n_work = k3_work_override ? k3_work_override : (uint32_t)work.size();
+		k3.in = a->d_in.p; k3.st = a->d_st.p; k3.work = a->d_work.p; k3.n_work = (uint32_t)work.size();
 		k3.seed_pool = a->seed_pool.p; k3.root_pool = a->root_pool.p; k3.slabs = a->slabs.p; k3.slab_bytes = a->slab_stride;
 		k3.ring = nullptr; k3.ring_ctr = nullptr; k3.ring_n = 0;
 		k3.cls = nullptr; k3.n_cls = 0;
@@ -1627,19 +1550,14 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* a read without a result goes on to the next occurrence threshold on the wave that holds it (k3_rescue_round) instead of coming back through the host
 		 * for another round of launches: 2.77 against 3.20 s per step on the headline workload (the latency-bound rescue launches -- a serial sort + chain and
 		 * an extension launch of some eighty waves, twice -- took half of a lane's time per batch).  MM_K3_HOST_ROUNDS: the rounds as separate launches */
-		const bool inkernel = getenv("MM_K3_HOST_ROUNDS") == NULL && getenv("MM_EXPERIMENT_K3_HEAVY") == NULL && !deferred;
+		const bool inkernel = true;          /* (the rounds as launches of their own through the host, rounds 1-2: 3.20 against 2.77 s per headline step -- HISTORY.md) */
 		k3.inkernel_rounds = inkernel ? 1u : 0u; k3.resc_pool = a->resc_pool.p; k3.twlen = a->twlen;
-		k3.defer_thr = (inkernel && round == 0 && !rlen_fixed) ? defer_thr : 0u;
 		k3.rjobs = nullptr; k3.rmemo = nullptr; k3.rstate = nullptr; k3.rq_cap = 0; k3.rq_ctl = nullptr;
 		/* retry jobs: the look-ahead of the reads that try seed after seed of a chain, taken by waves that have run out of reads (K3Args.rjobs) */
-		k3.rq_early = getenv("MM_K3_LATE_HELPERS") ? 0u : 1u;
-		k3.rq_stay = getenv("MM_K3_STAY") ? 1u : 0u;
 		/* (1: chain jobs of the workspace class held.  Retry jobs as well (3) cost the ONT-like set 7 % -- the retry trial of a 100 kb read in front of a wave's own next read -- and
 		 * give the hard-repeat set nothing: there the long pole of a launch is the SECOND trial of each of a read's 150 - 270 chains, which its owner runs itself, one after the
 		 * other, 0.5 - 1 M DP vectors on one wave -- profiles/round5_hard_read_cost.txt) */
-		k3.rq_between = getenv("MM_K3_JOBS_BETWEEN_READS") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_JOBS_BETWEEN_READS"))) : 1u;
-		k3.full_n = a->n_waves / 8;
-		k3.rq_helper_mask = getenv("MM_K3_HELPERS") ? (uint32_t)std::max(1, atoi(getenv("MM_K3_HELPERS"))) - 1u : 127u;          /* one wave in 128 is a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) when helpers were the waves that had run out of reads -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for; as helpers from the start, one in 8 / 16 / 32 on the ONT-like set: 2.37 / 2.34 / 2.46 against 2.7 - 2.9 */
+		k3.rq_helper_mask = 127u;          /* one wave in 128 is a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) when helpers were the waves that had run out of reads -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for; as helpers from the start, one in 8 / 16 / 32 on the ONT-like set: 2.37 / 2.34 / 2.46 against 2.7 - 2.9 */
 		/* (any number of workspace classes, any number of workspaces: a helper takes the workspace a job needs before it claims the job and without waiting, K3_TRY_SLAB, so the
 		 * wave that waits for a claimed job waits for one that is running; on the ONT-like set the reads that decide the launch are 60 - 160 kb long with 9 - 27 trials for
 		 * one alignment, tools/read_cost.py) */
@@ -1657,7 +1575,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			}
 		}
 		k3.jobs = nullptr; k3.memo = nullptr; k3.job_top = nullptr; k3.job_cap = 0; k3.spath = nullptr; k3.spath_cap = 0; k3.sseg = nullptr; k3.sseg_cap = 0; k3.stage_top = nullptr; k3.round_jobs = 0;
-		k3.dyn0_min = getenv("MM_K3_DYN_ROUND0") ? (uint32_t)std::max(0, atoi(getenv("MM_K3_DYN_ROUND0"))) : (small_heavy ? 2u : 0u);          /* (a small launch has no chain jobs from before the launch: its reads publish their chains themselves) */
+		k3.dyn0_min = small_heavy ? 2u : 0u;          /* (a small launch has no chain jobs from before the launch: its reads publish their chains themselves) */
 		/* the staging area of the traced jobs (path words, segments) and its cursors: for the chain jobs enumerated before the launch and for the chains a read publishes from
 		 * inside it (K3Args.rjobs, JOB_FULL) alike */
 		const uint64_t stage_job_cap = getenv("MM_K3_JOB_CAP") ? (uint64_t)std::max(1, atoi(getenv("MM_K3_JOB_CAP"))) : (1u << 16), stage_path_cap = 48ull << 20, stage_seg_cap = (stage_job_cap + k3.rq_cap) * 8;          /* (MM_K3_JOB_CAP: test hook, a launch with more chain jobs than slots) */
@@ -1669,7 +1587,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			k3.stage_top = a->spec_top.p + 2;
 			/* (from four chains on: the ordinary rescued read has one to three, and publishing those cost the headline set 3 % for nothing; MM_K3_ROUND_JOBS_MIN: another number;
 			 * MM_K3_NO_ROUND_JOBS: the chains of the later rounds walked by the read's own wave, as before round 5) */
-			k3.round_jobs = (k3.rjobs && !getenv("MM_K3_NO_ROUND_JOBS")) ? (getenv("MM_K3_ROUND_JOBS_MIN") ? (uint32_t)std::max(2, atoi(getenv("MM_K3_ROUND_JOBS_MIN"))) : 4u) : 0u;
+			k3.round_jobs = (k3.rjobs && !getenv("MM_K3_NO_ROUND_JOBS")) ? 4u : 0u;
 		}
 		/* chain jobs: the first trials of the chains of the heaviest reads (the front of the work list), taken by all waves of the launch before the reads (K3Args.jobs) */
 		/* (a wave that has claimed a job takes the workspace for it without waiting, K3_TRY_SLAB, and hands the job back undone when none of its class is free: with fewer
@@ -1686,22 +1604,18 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		}
 		uint32_t waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((work.size() + 3) & ~3ull));
 		if(small_heavy && k3.rjobs) { waves = std::min<uint32_t>(a->k3_waves, std::max<uint32_t>(waves, 1024u)); }          /* (waves for the jobs of a small launch: 256 workgroups, the first wave of each a helper) */
-		if(deferred && k3.jobs) { uint64_t nj = 0; for(uint32_t wi : work) nj += hst[wi].n_pass; waves = std::min<uint32_t>(a->k3_waves, (uint32_t)((std::max<uint64_t>(work.size(), std::min<uint64_t>(nj, 4096)) + 3) & ~3ull)); }          /* (waves for the jobs, not only for the reads) */
-		if(const char *e = getenv("MM_K3_WAVES_PER_SIMD")) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * (uint32_t)atoi(e)); }     /* test hook */
 		/* several batches in flight (lanes): 5 persistent waves per SIMD keep the integer VALU as busy as 8 do (a wave issues at most every 4th cycle, about two
 		 * thirds of its instructions are VALU) and leave wave slots for the sketch and sort + chain kernels of the other lanes, which otherwise wait for the
 		 * tail of this launch: +4 % on round 1's bench workload with 3 in flight, -10 % for a launch running alone; 2 / 3 / 4 / 6 measure the same on the headline workload of
 		 * round 2 */
-		else if(a->is_sib || a->sib) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u); }
+		if(a->is_sib || a->sib) { waves = std::min<uint32_t>(waves, (a->n_waves / MM_K3_WAVES_PER_SIMD) * 5u); }
 		hipStream_t xs = a->stream;
-		if(a->k3s && (a->is_sib || a->sib)) { xs = a->k3s; CK(hipEventRecord(a->k3e, a->stream)); CK(hipStreamWaitEvent(xs, a->k3e, 0)); }      /* (the host waits for the launch below before it queues anything else) */
 		CK(hipEventRecord(a->ev0, xs));
 		/* persistent waves stealing reads from a counter, never more of them than there are workspaces.  MM_K3_ONE_READ_PER_WAVE (with a workspace for every wave
 		 * the device can hold): grid = reads / 4, a wave maps one read and ends -- wave slots then come free read by read for the other lanes' launches; measured
 		 * no faster on the headline workload (2.86 against 2.77 s per step with the rounds in the kernel, 3.7 against 3.2 without), kept as an experiment */
-		k3.persistent = 1;
 		if(k3.ring) { waves = std::min<uint32_t>(waves, (k3.ring_n * 8u) & ~3u); }          /* (never more waves than the shared ring and the lane's own hold workspaces of the ordinary class) */
-		const int k3_conc = safe ? 1 : (getenv("MM_K3_CONCURRENT") ? std::max(1, atoi(getenv("MM_K3_CONCURRENT"))) : 0);
+		const int k3_conc = safe ? 1 : 0;          /* (a cap on the extension launches in flight measured flat or worse with 4 / 6 / 8 lanes: profiles/round5_sweep_lanes_batches_registers.txt) */
 		mm_align_s *GP = GPw;
 		/* the watchdog's window into this launch (k3_watchdog_main): where every wave is, and the word that calls the launch off */
 		if(!a->wd) { if(hipHostMalloc((void **)&a->wd, (K3_WD_HEAD + (size_t)GP->n_waves) * 4, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { a->wd = nullptr; } }
@@ -1726,10 +1640,8 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		/* next round: reads that still have no result (minialign.c:4444-4448) */
 		if(!lane_d2h(a, hst.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState))) return false;
 		std::vector<uint32_t> nxt;
-		for(uint32_t wi : work) if(hst[wi].n_res == 0 && !(hst[wi].err & ~0u) && (k3.defer_thr == 0 || hst[wi].done == 2)) nxt.push_back(wi);          /* (with deferral: only the reads the launch handed back; the others went through every round inside it) */
-		work.swap(nxt);
-		if(inkernel) { if(k3.defer_thr && !work.empty()) { deferred = true; continue; } break; }          /* every round of every read has run inside that launch (but for the deferred ones) */
-		if(getenv("MM_EXPERIMENT_K3_HEAVY")) { break; }
+		(void)nxt;
+		break;          /* every round of every read has run inside that launch */
 	}
 	return true;
 }
@@ -2047,7 +1959,7 @@ void alt_record(const mm_align_t *a, std::string &s, const char *qname, const ui
 bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen, uint32_t lanes);
 /* minimizer records a read gets room for, per base: at most one per position; 2 / (w + 1) per base on average, so 4 / (w + 1) is ample for all but the reads inside low-complexity sequence (w = 10: 0.36; a run of one repeated k-mer emits a minimizer per base); a read whose
  * hashes keep falling emits one per position: after an overflow the batch is redone with room for that (scale > 1) */
-inline double min_cap_frac(uint32_t w, uint64_t scale) { return (scale > 1 || getenv("MM_POOLS_BY_CAP")) ? ((w < 4 || scale > 1) ? 1.0 : 0.5) : std::min(1.0, 4.0 / ((double)w + 1.0)); }
+inline double min_cap_frac(uint32_t w, uint64_t scale) { return scale > 1 ? 1.0 : std::min(1.0, 4.0 / ((double)w + 1.0)); }
 /* DP workspace of a wave for reads up to qlen bases (a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors), qlen in steps of 8 k */
 uint64_t slab_bytes_for(uint32_t qlen) { qlen = (qlen + 8191u) & ~8191u; const uint64_t blocks = 2 * ((2ull * qlen + 8192) / 32 + 64); return (gaba::SLAB_HEAD + blocks * sizeof(gaba::Blk) + 32 * sizeof(gaba::Tail) + 4095) & ~4095ull; }
 bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_qlen, uint64_t scale)
@@ -2068,11 +1980,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	const uint64_t min_over = bases / 32 + 2ull * max_qlen + 4096;
 	ok &= a->min_pool.ensure(min_total + min_over);
 	a->min_over_base = min_total; a->min_over_n = min_over;
-	if(getenv("MM_POOLS_BY_CAP")) {          /* rounds 1-3: room for what the reads of the batch could emit at most */
-		ok &= a->seed_pool.ensure((bases / 2 + 4096ull * n_reads) * scale + (4ull << 20));
-		ok &= a->root_pool.ensure((bases / 4 + 2048ull * n_reads) * scale + (2ull << 20));
-		ok &= a->resc_pool.ensure(min_total * std::min<uint64_t>(scale, 4));
-	} else {
+	{
 		/* room for what the batches of this run have asked for (entries per base, + a quarter; note_demand), in steps of 16 M entries; a batch that asks for more is
 		 * caught right behind its sketch launch (run_rounds) */
 		mm_align_s *NP = a->root ? a->root : a; double ns, nr, nt;
@@ -2080,7 +1988,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 		auto room = [&](double per_base, uint64_t per_read) -> uint64_t { const uint64_t w = (uint64_t)((double)bases * per_base * 1.25) * scale + per_read * n_reads + (1ull << 20), q = w < (64ull << 20) ? (1ull << 20) : (16ull << 20); return (w + q - 1) / q * q; };
 		ok &= a->seed_pool.ensure(room(ns, 8)); ok &= a->root_pool.ensure(room(nt, 4)); ok &= a->resc_pool.ensure(room(nr, 2));
 	}
-	if(!getenv("MM_K2_LDS_CHAIN")) { ok &= a->k2w_scratch.ensure(a->seed_pool.n * 8); }          /* (16 B per seed found, K2wArgs.scratch; a read claims two pool entries per seed it can find) */
+	ok &= a->k2w_scratch.ensure(a->seed_pool.n * 8);          /* (16 B per seed found, K2wArgs.scratch; a read claims two pool entries per seed it can find) */
 	/* (the result pools carry room beyond the reads' ordinary regions: the few reads with hundreds of chains take larger ones as they go, mm_extend_kernel) */
 	const uint64_t heavy = bases / 64 + (1ull << 16);
 	ok &= a->kh_pool.ensure((uint64_t)n_reads * a->kh_cap + 8 * heavy);
@@ -2189,7 +2097,7 @@ bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen, uint32_t lanes)
 	for(uint32_t l = 0; l < lanes; l++) for(size_t c = 0; c < P->h_cls.size(); c++) { K3Class k = P->h_cls[c]; k.pring += (size_t)l * n_xcd * k.pn; k.pctr += (size_t)l * n_xcd * 4; tab.push_back(k); }
 	if(!P->d_cls.ensure(tab.size()) || hipMemcpy(P->d_cls.p, tab.data(), tab.size() * sizeof(K3Class), hipMemcpyHostToDevice) != hipSuccess) return false;
 	P->slab_stride = bytes[0]; P->slab_ring_n = sn[0] + pn[0]; P->k3_waves = P->n_waves;
-	if(getenv("MM_VERBOSE_SLABS")) { for(auto &k : P->h_cls) fprintf(stderr, "[minialign_amd] workspace class: reads up to %u bases, %u shared + %u x %u of the lanes' own, %.1f MB each\n", k.qmax, k.n * n_xcd, lanes, k.pn * n_xcd, k.bytes / 1048576.0); }
+	if(getenv("MM_VERBOSE")) { for(auto &k : P->h_cls) fprintf(stderr, "[minialign_amd] workspace class: reads up to %u bases, %u shared + %u x %u of the lanes' own, %.1f MB each\n", k.qmax, k.n * n_xcd, lanes, k.pn * n_xcd, k.bytes / 1048576.0); }
 	P->shared_slabs = true;
 	return true;
 }
@@ -2282,7 +2190,7 @@ static void k3_watchdog_main(mm_align_s *GP)
 void k3_watchdog_start(mm_align_s *GP)
 {
 	std::lock_guard<std::mutex> lk(GP->k3_gate_mu);
-	if(GP->wd_running || getenv("MM_NO_K3_WATCHDOG")) return;
+	if(GP->wd_running) return;
 	GP->wd_running = true; GP->wd_stop = false;
 	GP->wd_thread = std::thread(k3_watchdog_main, GP);
 }
@@ -2295,30 +2203,15 @@ static void k3_watchdog_stop(mm_align_s *GP)
 
 } /* anonymous */
 
-/* the streams of a context.  MM_STREAM_PRIO (experiment, off by default): everything but the extension launch on streams of the highest priority and the extension on one
- * of the lowest, so that the dispatcher hands a wave slot that comes free to the short, latency-bound kernels of the other lanes first.  Measured on the headline
- * workload: nothing at 4 lanes (2.74 / 2.81 against 2.74 / 2.72 s per step), worse at 6 (3.15 against 2.84: 6 x 4 streams no longer get a hardware queue each) --
- * the extension launch runs persistent waves, which give their slots back at its end only, and with one read per wave (MM_K3_ONE_READ_PER_WAVE) the lanes fall into step */
+/* the streams of a context: the lane's own and its side streams (every stream wants a hardware queue of its own: MM_SIDE).  Stream priorities and a CU mask for the
+ * extension launches were tried in rounds 2 and 5 and measured nothing (HISTORY.md) */
 static bool make_streams(mm_align_s *a)
 {
-	int least = 0, greatest = 0;
-	if(getenv("MM_STREAM_PRIO") == NULL || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+	const int greatest = 0;
 	if(hipStreamCreateWithPriority(&a->stream, hipStreamNonBlocking, greatest) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) return false;
 	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithPriority(&a->k2s[i], hipStreamNonBlocking, greatest) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) return false; }
 	a->k2s_ok = true;
 	if(hipHostMalloc((void **)&a->pin_note, 64, hipHostMallocPortable) != hipSuccess) return false;
-	if(const char *e = getenv("MM_K3_CU_RESERVE")) {          /* (instead of the low-priority stream below: a stream with a CU mask comes at the default priority) */
-		/* experiment (off by default; not yet run on a GPU): the extension launches go to a stream whose CU mask leaves every (CUs / n)-th compute unit out, so that the short
-		 * operations of the other lanes -- copies, memsets, the sketch and sort launches -- always find free wave slots somewhere instead of waiting 10 - 40 ms for a
-		 * persistent extension launch to end; the extension kernel pays n CUs for it */
-		int dev = 0; hipDeviceProp_t prop; const int n = std::max(1, atoi(e));
-		if(hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > n) {
-			const int cus = prop.multiProcessorCount, step = cus / n; std::vector<uint32_t> mask((cus + 31) / 32, 0);
-			for(int i = 0; i < cus; i++) { if(i % step != step - 1) mask[i >> 5] |= 1u << (i & 31); }
-			if(hipExtStreamCreateWithCUMask(&a->k3s, (uint32_t)mask.size(), mask.data()) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) { a->k3s = nullptr; fprintf(stderr, "[minialign_amd] MM_K3_CU_RESERVE: no stream with a CU mask\n"); }
-		}
-	}
-	if(!a->k3s && least != greatest) { if(hipStreamCreateWithPriority(&a->k3s, hipStreamNonBlocking, least) != hipSuccess || hipEventCreateWithFlags(&a->k3e, hipEventDisableTiming) != hipSuccess) return false; }
 	return true;
 }
 /* a primary context on the current device */
@@ -2334,8 +2227,7 @@ static mm_align_t *align_init_here(mm_opt_t const *o, mm_idx_t const *mi, int fo
 	a->mcoef = mc / 4.0; a->xcoef = xc / 12.0;
 	if(!make_streams(a)) { delete a; return NULL; }
 	/* dynamic LDS limits of the sort / chain kernels: per device, set with every context (lane threads only launch) */
-	if(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess || hipFuncSetAttribute((const void *)mm_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess
-		|| hipFuncSetAttribute((const void *)mm_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K2C_MAX_LDS_KB * 1024) != hipSuccess) { fprintf(stderr, "[minialign_amd] mm_align_init: kernel attributes rejected\n"); delete a; return NULL; }
+	if(hipFuncSetAttribute((const void *)mm_sort_chain_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess || hipFuncSetAttribute((const void *)mm_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { fprintf(stderr, "[minialign_amd] mm_align_init: kernel attributes rejected\n"); delete a; return NULL; }
 	/* reference: one arena, per-sequence offsets */
 	std::vector<uint64_t> off; std::vector<uint32_t> len;
 	bool ok = true;
@@ -2446,7 +2338,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	if(!a->is_sib) { k3_watchdog_stop(a); }
 	if(a->wd) { (void)hipHostFree(a->wd); a->wd = nullptr; }
 	free_chunk_pool(a->chunk_pool); a->chunk_pool = nullptr;
-	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream); if(a->k3s) { (void)hipStreamDestroy(a->k3s); } if(a->k3e) { (void)hipEventDestroy(a->k3e); }
+	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
 	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < MM_SIDE) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
 	delete a;
 }
@@ -2525,12 +2417,12 @@ bool batch_upload(mm_align_t *a, Batch &b)
 		if(!a->d_tinfo.ensure(spare(b.n)) || !a->d_codes.ensure(spare(arena + 64)) || !a->d_tn.ensure(spare(b.n))) return false;
 		std::vector<TextRead> tr(b.n);
 		CK(hipMemsetAsync(a->d_codes.p, 0, arena + 64, a->stream));
-		if(!b.dch.empty() && getenv("MM_UPLOAD_ONE_SYNC")) {
-			/* experiment (off by default.  Round 5: +3 % in three pairs of headline runs, 4.22 / 4.42 / 4.29 against 4.06 / 4.24 / 4.21 G bases/s, and the whole suite passes with it --
-			 * but the hard-repeat human-size workload did not finish in 900 s with it as the default, not understood, so it stays a switch): the whole upload of a batch behind ONE wait.  Every wait of a lane for its stream is a wait for a wave slot beside
-			 * the persistent extension waves of the other lanes (10 - 40 ms each under load), and this function has five: the extents, the packed-base count, the
-			 * read table, the states, the cursors.  Here everything the device needs goes through one pinned staging buffer in three copies, the kernels and the memsets follow on
-			 * the stream, the base counts come back into the same buffer, and the host waits once */
+		if(!b.dch.empty()) {
+			/* The whole upload of a batch behind ONE wait.  Every wait of a lane for its stream is a wait for a wave slot beside the persistent extension waves of the other
+			 * lanes (10 - 40 ms each under load), and this function had five: the extents, the packed-base count, the read table, the states, the cursors.  Everything the
+			 * device needs goes through one pinned staging buffer in three copies, the kernels and the memsets follow on the stream, the base counts come back into the same
+			 * buffer, and the host waits once: +3 % in three pairs of headline runs of round 5 (4.22 / 4.42 / 4.29 against 4.06 / 4.24 / 4.21 G bases/s), whole suite green.  It
+			 * was taken back then because the hard-repeat record did not finish with it -- which was the oversubscribed runlist of DESIGN.md 4b, not this */
 			for(const Batch::Piece &pc : b.dch) for(uint32_t i = pc.first; i < pc.first + pc.n; i++) tr[i] = TextRead{ b.trec[i].t_off - pc.ch->off, b.trec[i].t_len, 0, b.qoff[i] };
 			const size_t s_tr = ((size_t)b.n * sizeof(TextRead) + 255) & ~(size_t)255, s_in = ((size_t)b.n * sizeof(ReadIn) + 255) & ~(size_t)255, s_st = ((size_t)b.n * sizeof(ReadState) + 255) & ~(size_t)255, s_tn = ((size_t)b.n * 4 + 255) & ~(size_t)255;
 			uint8_t *stg = (uint8_t *)lane_stage(a, s_tr + s_in + s_st + s_tn);
@@ -2621,7 +2513,7 @@ void batch_pack(Batch &b, bool on_host = true)
 	/* the reads of a batch that come from one file whose text was kept are packed on the device, from that text (batch_upload) */
 	b.text.reset();
 	if(b.tsrc) { b.scale = 1; b.packed = true; return; }          /* reads in a scanned text: packed on the device (batch_upload) */
-	if(!on_host && !b.rec.empty() && b.rec.size() == b.n && b.text_src && !getenv("MM_HOST_PACK")) {
+	if(!on_host && !b.rec.empty() && b.rec.size() == b.n && b.text_src) {
 		bool all = true; for(uint32_t i = 0; i < b.n && all; i++) all = b.rec[i]->t_id == b.rec[0]->t_id && b.rec[i]->t_id >= 0 && (size_t)b.rec[i]->t_id < b.text_src->size();
 		if(all && b.n) b.text = (*b.text_src)[b.rec[0]->t_id];
 	}
@@ -2786,12 +2678,6 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 {
 	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
 	a->rlen_carry = batch_carry_out(a, b, a->rlen_carry);
-	if(const char *fn = getenv("MM_DUMP_READ_COST")) {          /* diagnostics: per-read cost of the extension kernel */
-		std::vector<ReadState> d(n_reads); CPY(a, d.data(), a->d_st.p, (uint64_t)n_reads * sizeof(ReadState), hipMemcpyDeviceToHost);
-		static std::atomic<unsigned> dump_no{0};          /* one file per batch, in the order the batches are fetched (batch order): <name>, <name>.1, <name>.2 ... */
-		const unsigned dn = dump_no++; const std::string dfn = dn ? std::string(fn) + "." + std::to_string(dn) : std::string(fn);
-		if(FILE *fp = fopen(dfn.c_str(), "w")) { for(uint32_t i = 0; i < n_reads; i++) fprintf(fp, "%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", i, b.lens[i], d[i].seed_n0, d[i].n_root, d[i].k3_ticks, d[i].k3_vec, d[i].k3_fill_ticks, d[i].k3_trace_ticks, d[i].n_pass, d[i].w_pass, d[i].k3_chains, d[i].k3_trials, d[i].k3_hits, d[i].n_aln, d[i].spec_n, d[i].k3_t0, d[i].k3_wait_ticks); fclose(fp); }
-	}
 	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
 	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->k3_waves; a->st.k3_cycles_next += tops[19];
@@ -3126,25 +3012,22 @@ static std::shared_ptr<TextSrc> open_text_once(const char *fn);
 extern "C" int mm_align_file(mm_align_t *a, char const *reads_fn, FILE *out)
 {
 	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
-	if(!getenv("MM_HOST_READER") && !getenv("MM_HOST_PACK")) {
+	{
 		/* the text of the file goes to the device as it is; records are found there (K0r), bases packed there (K0) */
 		std::shared_ptr<TextSrc> src = open_text_once(reads_fn);
 		if(!src) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
 		/* where the output is a regular file (`minialign ... > out.sam`): the batches' text goes to its place in the file from several threads (stream_map, drain workers);
 		 * a pipe, a terminal or a file opened for appending is written in order by the one writer */
 		int pos_fd = -1; uint64_t pos_at = 0;
-		if(!getenv("MM_ONE_WRITER") && fflush(out) == 0) {
+		if(fflush(out) == 0) {
 			const int fd = fileno(out); struct stat sb;
 			if(fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) { const int fl = fcntl(fd, F_GETFL); const off_t at = lseek(fd, 0, SEEK_CUR); if(fl >= 0 && !(fl & O_APPEND) && at >= 0) { pos_fd = fd; pos_at = (uint64_t)at; } }
 		}
 		const int rc = align_text(a, src, [&](uint32_t, std::vector<std::string> &piece) { for(auto &x : piece) { if(fwrite(x.data(), 1, x.size(), out) != x.size()) return false; } return true; }, 0, pos_fd, &pos_at);
 		if(pos_fd >= 0 && lseek(pos_fd, (off_t)pos_at, SEEK_SET) < 0) return 1;          /* (the stream goes on behind what was written) */
+		(void)verbose; (void)tv;
 		return rc;
 	}
-	mm_reads_t *reads = reads_load(reads_fn, a->o.min_len, a->o.keep_qual, (a->o.ptags() >> 1) & 1, getenv("MM_HOST_PACK") == NULL);
-	if(!reads) { fprintf(stderr, "[minialign_amd] cannot read `%s'\n", reads_fn); return 1; }
-	if(verbose) { fprintf(stderr, "[minialign_amd] parse %.1f ms\n", now_ms() - tv); }
-	return align_reads(a, reads, out);
 }
 /*
  * The streaming engine.  Batches 0 .. n - 1 of a read set go through `lanes` lanes of the device context (each lane: own streams, pools and host thread; index,
@@ -3370,7 +3253,7 @@ struct ReaderDev {
 		hipLaunchKernelGGL(mm_text_emit_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
 		uint32_t tot[2], flag[4];
 		CK(hipMemcpyAsync(tot, d_blk.p + 2 * (uint64_t)n_blk, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(flag, d_flag.p, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-		bool on_host = fastq && (flag[1] != 0 || getenv("MM_HOST_SCAN") != NULL);
+		bool on_host = fastq && flag[1] != 0;
 		uint32_t n_rec = 0;
 		if(!fastq) {
 			if(flag[1]) { fprintf(stderr, "[minialign_amd] reader: more record starts than one per 8 bytes in a stretch of `>' records\n"); return false; }
@@ -3550,11 +3433,10 @@ struct TextReader {
 		if(dctx.empty()) return false;
 		if(const char *e = getenv("MM_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) & ~63ull;          /* test hook: small stretches */
 		prefix = std::min<uint64_t>(1ull << 20, chunk_bytes);
-		if(const char *e = getenv("MM_CHUNK_PREFIX")) prefix = std::max<uint64_t>(64, (uint64_t)atoll(e)) & ~63ull;          /* test hook: the slow way for records longer than this */
 		const uint32_t nd = (uint32_t)dctx.size();
 		/* copy threads per device: the staging copy wants a handful of cores (a core copies 5 - 10 GB/s; PCIe takes 50) */
 		const uint32_t hw = std::max<uint32_t>(1, std::thread::hardware_concurrency());
-		const uint32_t cpt = getenv("MM_COPY_THREADS") ? (uint32_t)std::max(0, atoi(getenv("MM_COPY_THREADS"))) : std::max<uint32_t>(2, std::min<uint32_t>(12, hw / (4 * nd)));
+		const uint32_t cpt = std::max<uint32_t>(2, std::min<uint32_t>(12, hw / (4 * nd)));
 		int cur_dev = 0; (void)hipGetDevice(&cur_dev);
 		for(uint32_t d = 0; d < nd; d++) {
 			mm_align_t *P = dctx[d];
@@ -3697,7 +3579,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 		mm_align_t *q = D.P; for(int i = 0; i < lanes && q; i++) { D.ctx.push_back(q); if(i + 1 < lanes) q = align_lane(q); }
 		if((int)D.ctx.size() < lanes || !D.ctx.back()) { (void)hipSetDevice(cur_dev); return 1; }
 	}
-	if(!getenv("MM_NO_SHARED_SLABS")) {
+	{
 		/* the shared DP workspaces of every device, side by side (tens of GB each: seconds on memory nobody has touched yet) */
 		std::vector<int> okv(n_dev, 1); std::vector<std::thread> st;
 		for(int d = 0; d < n_dev; d++) st.emplace_back([&, d]() { okv[d] = hipSetDevice(dv[d]->P->dev) == hipSuccess && ensure_shared_slabs(dv[d]->P, dv[d]->P->qlen_hint, (uint32_t)lanes); });
@@ -3991,7 +3873,7 @@ static uint64_t batch_cap_bases(mm_align_t *a, int lanes)  /* (bytes per base: 5
 		const uint64_t taken = slab_budget + slab_budget * 3 / 4 + (10ull << 30) - std::min<uint64_t>(P->shared_slabs ? P->slabs.bytes : 0, slab_budget);          /* (workspaces already allocated are no longer in `avail`) */
 		P->mem_for_batches = avail > taken + (8ull << 30) ? avail - taken : (8ull << 30);
 	}
-	return std::max<uint64_t>(128ull << 20, P->mem_for_batches / (uint64_t)std::max(1, lanes) / (getenv("MM_POOLS_BY_CAP") ? 52 : 28));
+	return std::max<uint64_t>(128ull << 20, P->mem_for_batches / (uint64_t)std::max(1, lanes) / 28);
 }
 static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const PieceSink &sink, int lanes, int pos_fd, uint64_t *pos_at)
 {
@@ -4230,8 +4112,7 @@ extern "C" int mm_main(int argc, char **argv)
 	if(qh == nf) { fprintf(stderr, "[M::main_align] query-side input redirected to stdin.\n"); files[nf++] = "-"; }     /* minialign.c:6380-6384 */
 	/* the first query file is parsed on a thread of its own while the index is built or loaded */
 	mm_reads_t *first_reads = NULL;
-	const bool host_reader = getenv("MM_HOST_READER") != NULL || getenv("MM_HOST_PACK") != NULL;          /* the host's parser instead of the device reader (kept for comparison) */
-	std::thread rt([&]() { if(host_reader && strcmp(files[qh], "-") != 0) first_reads = reads_load(files[qh], o->min_len, o->keep_qual, (o->ptags() >> 1) & 1, getenv("MM_HOST_PACK") == NULL); });
+	std::thread rt([]() {});
 	std::thread hw([]() { int n = 0; if(hipGetDeviceCount(&n) == hipSuccess && n > 0) { (void)hipFree(0); } });      /* bring the HIP runtime up meanwhile */
 	const bool keep_first = prebuilt || n_ref > 1;      /* the parsed first query file serves every index */
 	FILE *pg = prebuilt ? fopen(files[0], "rb") : NULL;

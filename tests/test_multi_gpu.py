@@ -131,19 +131,17 @@ def repeat_rich():
         want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
         yield ref, rd, opts, want
 
-@pytest.mark.parametrize('env', [dict(MM_K3_HOST_ROUNDS='1'), dict(MM_K3_ONE_READ_PER_WAVE='1'), dict(MM_NO_SHARED_SLABS='1'), dict(MM_K2_NO_PRESORT='1'), dict(MM_TEST_SPLIT='1'),
-                                 dict(MM_K2_LDS_CHAIN='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_HOST_READER='1'), dict(MM_HOST_INDEX='1'), dict(MM_K3_JOB_CAP='7'), dict(MM_DEVICE_CONTEXTS='2', MM_SLAB_GB='14'),
-                                 dict(MM_K3_NO_ROUND_JOBS='1'), dict(MM_K3_DYN_ROUND0='2'), dict(MM_K3_DYN_ROUND0='2', MM_K3_NO_JOBS='1'), dict(MM_K3_HELPERS='4'),
-                                 dict(MM_K3_RESCUE_FIRST='1'), dict(MM_K3_DEFER_RESCUE='1'), dict(MM_K3_CU_RESERVE='16'), dict(MM_UPLOAD_ONE_SYNC='1'), dict(MM_NO_CARRY_DEPS='1'), dict(MM_NO_MIN_OVERFLOW='1'), dict(MM_K3_ROUND_JOBS_MIN='2', MM_K3_JOBS_BETWEEN_READS='3'), dict(MM_K3_STAY='1', MM_K3_JOBS_BETWEEN_READS='2'), dict(MM_SLOW_RERUN='1'), dict(MM_CARRY_WEAK='0'), dict(MM_CARRY_WEAK='1000000'), dict(MM_K2_LANE_SORT='1'), dict(MM_K2_ALL_LEVELS='1')],
-                         ids=['rounds-through-the-host', 'one-read-per-wave', 'own-workspaces', 'one-kernel-sort-chain', 'batch-split-on-pool-exhaustion',
-                              'chain-sweep-in-lds', 'no-chain-jobs', 'host-reader', 'host-index', 'more-chain-jobs-than-slots', 'two-device-contexts',
-                              'later-round-chains-on-the-own-wave', 'first-round-chains-published-by-the-read', 'first-round-chains-published-only-by-the-read', 'one-wave-in-four-helps',
-                              'rescue-bound-reads-first', 'rescue-rounds-deferred-to-launches-of-their-own', 'cu-reserve', 'upload-behind-one-wait', 'carried-value-by-prediction-only', 'no-minimizer-overflow-region', 'round-jobs-from-two-chains-and-retry-jobs-between-reads', 'waves-stay-and-change-class', 'long-way-re-runs', 'no-weak-sources', 'every-read-with-rescue-minimizers-a-source', 'sort-with-a-lane-per-read', 'sort-from-the-top-level'])
+@pytest.mark.parametrize('env', [dict(MM_TEST_SPLIT='1'), dict(MM_K3_NO_JOBS='1'), dict(MM_K3_NO_RETRY_JOBS='1'), dict(MM_K3_NO_ROUND_JOBS='1'), dict(MM_K3_NO_JOBS='1', MM_K3_NO_RETRY_JOBS='1', MM_K3_NO_ROUND_JOBS='1'),
+                                 dict(MM_HOST_INDEX='1'), dict(MM_K3_JOB_CAP='7'), dict(MM_DEVICE_CONTEXTS='2', MM_SLAB_GB='14'), dict(MM_NO_CARRY_DEPS='1'), dict(MM_HOST_CIGAR='1'), dict(MM_SLAB_GB='1', MM_LANES='3'),
+                                 dict(MM_TEST_K3_HANG='40', MM_K3_WATCHDOG_MS='1500')],
+                         ids=['batch-split-on-pool-exhaustion', 'no-chain-jobs', 'no-retry-jobs', 'later-round-chains-on-the-own-wave', 'no-jobs-of-any-kind',
+                              'host-index', 'more-chain-jobs-than-slots', 'two-device-contexts', 'carried-value-by-prediction-only', 'cigar-strings-by-the-host', 'few-workspaces-three-lanes',
+                              'a-launch-called-off-by-the-watchdog'])
 def test_alternative_schedules_give_the_same_bytes(env, repeat_rich):
-    """the forms kept behind environment switches -- the occurrence-threshold rounds as separate launches through the host (the default runs them inside the
-    extension kernel, k3_rescue_round), one read per wave, per-lane DP
-    workspaces, the one-kernel sort + chain, the fallback for a batch the device pools cannot hold (its reads in halves, down to fewer than 8), and the switches of rounds 4
-    and 5 (jobs, sources of the carried value, re-runs) -- on a repeat-rich set with a high seed threshold, where many reads need the rescue rounds"""
+    """the forms kept behind environment switches -- the fallback for a batch the device pools cannot hold (its reads in halves, down to fewer than 8), the extension
+    launch without its chain / retry / round jobs, without the carried value taken from its source inside the launch, the host's index build and CIGAR walk, several device
+    contexts, a workspace budget so small that waves find none on offer, a launch that the watchdog has to call off -- on a repeat-rich set with a high seed threshold, where
+    many reads need the rescue rounds (what round 5 still kept behind switches and measured slower is in HISTORY.md, not in the library)"""
     ref, rd, opts, want = repeat_rich
     r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **dict(dict(MM_SLAB_GB='32', MM_BATCH_BASES='3000000'), **env)), timeout=600)          # (32 GB: a workspace for every resident wave at this read length, so that the chain and retry jobs of the default schedule run)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
@@ -196,11 +194,11 @@ def long_tailed():
         want = _strip_pg(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
         yield ref, rd, opts, want
 
-@pytest.mark.parametrize('env', [dict(), dict(MM_SLAB_GB='64'), dict(MM_K3_ONE_WORK_LIST='1'), dict(MM_K3_LATE_HELPERS='1'), dict(MM_K3_HELPERS='4'), dict(MM_K3_NO_RETRY_JOBS='1', MM_K3_NO_JOBS='1'), dict(MM_ONE_SLAB_CLASS='1')],
-                         ids=['four-workspaces-per-class-and-xcd', 'full-ladder', 'one-work-list', 'late-helpers', 'one-wave-in-four-helps', 'no-jobs', 'one-class'])
+@pytest.mark.parametrize('env', [dict(), dict(MM_SLAB_GB='64'), dict(MM_LANES='4', MM_BATCH_BASES='2500000'), dict(MM_K3_NO_RETRY_JOBS='1', MM_K3_NO_JOBS='1'), dict(MM_ONE_SLAB_CLASS='1')],
+                         ids=['four-workspaces-per-class-and-xcd', 'full-ladder', 'four-lanes-one-workspace-each', 'no-jobs', 'one-class'])
 def test_workspace_ladder_with_jobs_gives_the_same_bytes(long_tailed, env):
     """a long-tailed read set on the ladder of DP workspace classes (32 k / 64 k / 128 k / longest), with so small a budget that the classes above the ordinary one have four
-    workspaces per XCD: chain jobs and retry jobs take their workspaces without waiting (K3_TRY_SLAB), the work list is by class -- and the forms kept behind switches; a
+    workspaces per XCD, shared and the lanes' own: chain jobs and retry jobs take their workspaces without waiting (acquire), the work list is by class -- and the forms kept behind switches; a
     hang here is the failure the first version had (helpers waiting for workspaces held by the waves that waited for them)"""
     ref, rd, opts, want = long_tailed
     r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **dict(dict(MM_SLAB_GB='2', MM_LANES='2', MM_BATCH_BASES='6000000'), **env)), timeout=300)

@@ -21,9 +21,9 @@ def test_bench_line_with_two_devices_in_one_process():
     assert d['sam_identical'] is True, d.get('sam_check')
     assert d['roofline']['achieved'] > 0 and 'cpu_baseline' not in d
 
-def test_deferred_rescue_rounds_give_the_same_bytes():
-    """MM_K3_DEFER_RESCUE (experiment, off by default): reads the first occurrence threshold leaves without a result come back to the host and run their later rounds as
-    launches of their own, their chains spread over the launch as chain jobs -- on a repeat-rich set with a high seed threshold, where many reads need those rounds"""
+def test_rescue_rounds_on_a_hard_repeat_set_give_the_oracles_bytes():
+    """a reference with mammalian repeat structure and a high seed threshold: many reads find their chains only in the later occurrence-threshold rounds, which run inside the
+    extension launch on the wave that holds the read, the chains they find spread over the launch as jobs (default) or walked by that wave (MM_K3_NO_ROUND_JOBS)"""
     import tempfile
     CLI = os.path.join(M.ROOT, 'minialign_amd', 'minialign')
     strip = lambda sam: b''.join(l for l in sam.splitlines(True) if not l.startswith(b'@PG'))
@@ -32,8 +32,8 @@ def test_deferred_rescue_rounds_give_the_same_bytes():
         M.gensim('genomehard', 7601, 12000000, 4, 0.5, out=ref); M.gensim('reads', 7602, ref, 0.5, 'pacbio', 'fa', 6000, 2500, out=rd)
         opts = ['-xpacbio', '-f0.2,0.05,0.002']
         want = strip(subprocess.run([os.path.join(M.ROOT, 'oracle', 'ora_minialign')] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout)
-        for thr in ('1', '64'):
-            r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='32', MM_BATCH_BASES='3000000', MM_K3_DEFER_RESCUE=thr), timeout=600)
+        for thr in ({}, dict(MM_K3_NO_ROUND_JOBS='1')):
+            r = subprocess.run([CLI] + opts + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_SLAB_GB='32', MM_BATCH_BASES='3000000', **thr), timeout=600)
             assert r.returncode == 0, r.stderr.decode()[-2000:]
             assert strip(r.stdout) == want, thr
 

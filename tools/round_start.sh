@@ -5,7 +5,6 @@
 #                                   three boxes were lost in round 4 and nothing is known about their limits)
 #   tools/round_start.sh suite      python -m pytest tests -x -q -m gpu   (as the driver runs it)
 #   tools/round_start.sh unrun      the four GPU tests that have not run yet (MM_TEST_NOT_YET_RUN=1), one by one, no -x
-#   tools/round_start.sh switches   the switches that have not run yet, each against the default on the headline workload (bench.py, 3 steps) and the hard-repeat set
 #   tools/round_start.sh scale      several device contexts at full size on the one GPU (MM_TEST_CONTEXTS_AT_SCALE=1; in two of the three calls that lost their box in round 4)
 #   tools/round_start.sh profiles   tools/round_profiles.sh gpurun_out/round <tag>   (bench line, rocprofv3 stats, PMC passes, lane trace)
 # Everything lands under gpurun_out/start/.
@@ -37,19 +36,6 @@ unrun)
 	for t in test_bench_line_with_two_devices_in_one_process test_deferred_rescue_rounds_give_the_same_bytes test_extension_trials_that_start_at_the_end_of_a_section test_every_read_runs_with_the_value_the_reference_would_carry; do
 		MM_TEST_NOT_YET_RUN=1 timeout 900 python -m pytest "tests/test_zz_bench_devices_gpu.py::$t" -q > "$OUT/${TAG}_unrun_$t.log" 2>&1; echo "$t rc=$?" | tee -a "$OUT/${TAG}_unrun.txt"
 	done ;;
-switches)
-	box > /dev/null
-	B="python bench.py --steps 3 --warmup 1 --no-cpu --no-cli --no-packed"
-	for cfg in "" "MM_UPLOAD_ONE_SYNC=1" "MM_K3_CU_RESERVE=16" "MM_K3_CU_RESERVE=32" "LANES=6" "LANES=6 MM_K3_CU_RESERVE=16" "LANES=8 MM_K3_CU_RESERVE=16" "LANES=6 MM_K3_CU_RESERVE=32 MM_UPLOAD_ONE_SYNC=1"; do
-		echo "== headline: ${cfg:-default}" >> "$OUT/${TAG}_switches.txt"
-		lanes=4; envs=""; for kv in $cfg; do case $kv in LANES=*) lanes=${kv#LANES=} ;; *) envs="$envs $kv" ;; esac; done
-		env $envs timeout 600 $B --lanes $lanes 2> /dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms per step', 'identical' if d.get('sam_identical') in (None, True) else 'SAM DIFFERS')" >> "$OUT/${TAG}_switches.txt" 2>&1
-	done
-	for cfg in "" "MM_K3_DEFER_RESCUE=64" "MM_K3_DEFER_RESCUE=64 MM_K3_RESCUE_FIRST=1"; do
-		echo "== hard repeats: ${cfg:-default}" >> "$OUT/${TAG}_switches.txt"
-		env $cfg timeout 900 python bench.py --steps 1 --warmup 1 --no-cli --no-packed --workload hg38hard --depth 0.3 --check-reads 2000 --baseline-reads 4000 2> /dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['unit'], d['ms_per_step'], 'ms per step', 'identical' if d.get('sam_identical') in (None, True) else 'SAM DIFFERS', 'dp vectors per base', d['config']['dp_vectors_per_base'], 'extend ms summed', d['config']['kernel_ms_per_step (summed over lanes and ranks)']['extend'], 'cpu', (d.get('cpu_baseline') or {}).get('value'))" >> "$OUT/${TAG}_switches.txt" 2>&1
-	done
-	cat "$OUT/${TAG}_switches.txt" ;;
 scale)
 	box > /dev/null; watch_box > "$OUT/${TAG}_scale_watch.txt" & W=$!
 	MM_TEST_CONTEXTS_AT_SCALE=1 timeout 2400 python -m pytest tests/test_headline_gpu.py -x -q --durations=10 > "$OUT/${TAG}_scale.log" 2>&1; echo "rc=$?" >> "$OUT/${TAG}_scale.log"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """sweep_env.py -- the headline workload once (data, index, context), then a list of environment settings, each timed over a few steps of mm_map_text.
-usage: sweep_env.py [--workload hg38] [--steps 2] 'LANES=4' 'LANES=6 MM_K3_CONCURRENT=2 MM_K3_WAVES_PER_SIMD=3' ...   (LANES is the lanes argument, the rest environment)"""
+usage: sweep_env.py [--workload hg38] [--steps 2] 'LANES=4' 'LANES=6 MM_SLAB_GB=96' ...   (LANES is the lanes argument, the rest environment)"""
 import argparse, ctypes, os, sys, tempfile, time, shutil
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
