@@ -5,8 +5,10 @@
  * reference turns the path bits of a segment into run lengths with gaba_dp_print_cigar_reverse (gaba_parse.h:168-221, called from minialign.c:5147-5200 for the CIGAR
  * column and :5390-5426 for the SA tag): from the END of the segment's stretch of path bits downwards, a run of 0 bits is a deletion, a run of 1 bits an insertion, a run
  * of 01 pairs a match -- each test on the 64 bits BELOW the cursor, counted with a leading-zero count, the deletion run one short when it is followed by anything
- * (that 0 is the first half of a 01 pair).  That parser is restated here bit for bit (cig_next), one lane per segment: a first walk counts the characters, the lane
- * takes that many bytes of the batch's text buffer (one atomic add), a second walk writes them.  What crosses PCIe for a default SAM run is then this text and a
+ * (that 0 is the first half of a 01 pair).  That parser is restated here bit for bit (cig_next), one lane per read (its segments one after the other): a first walk counts the
+ * characters, the lane takes that many bytes of the batch's text buffer (one atomic add), a second walk writes them, eight characters per store.  The kernel is queued on the
+ * lane's stream right behind every extension launch (run_rounds), over the reads of that launch's work list: it starts when the launch ends, needs no turn of the host, and
+ * the reads a carried-value re-run maps again simply get new strings.  What crosses PCIe for a default SAM run is then this text and a
  * (offset, length) pair per segment instead of the path words; the host splices names, flags, positions, mapping qualities (libm's log10: host), SEQ / QUAL
  * and the clips around the string (sam_record).  Runs that print MD tags, the other output formats and the mm_reg_t entries walk the path on the host as before.
  *
@@ -19,24 +21,7 @@
 
 namespace mm {
 
-struct CigItem { uint32_t seg; uint32_t pad; uint64_t path_word; };          /* one segment of a recorded alignment: its slot in the segment pool, the first path word of its alignment in the path pool */
-struct CigEnt { uint32_t off, len; };                                        /* where its string stands in the text buffer (len = ~0: it did not fit) */
-
-struct CigListArgs { const ReadState *st; uint32_t n_reads; const AlnRec *aln_pool; CigItem *items; unsigned long long *ctl; uint64_t item_cap; };          /* ctl[0] = items, [1] = text bytes, [2] = overflow flag */
-/* every segment of every alignment the reads of the batch recorded (thread per read) */
-__global__ void __launch_bounds__(256) mm_cigar_list_kernel(CigListArgs a)
-{
-	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-	if(r >= a.n_reads) { return; }
-	const ReadState &rs = a.st[r];
-	if(rs.n_aln == 0 || rs.bin_off == ~0ull) { return; }
-	const AlnRec *al = a.aln_pool + rs.aln_off;
-	uint32_t n = 0; for(uint32_t i = 0; i < rs.n_aln; i++) { n += al[i].slen; }
-	if(n == 0) { return; }
-	unsigned long long at = atomicAdd(&a.ctl[0], (unsigned long long)n);
-	if(at + n > a.item_cap) { atomicExch(&a.ctl[2], 1ull); return; }
-	for(uint32_t i = 0; i < rs.n_aln; i++) { for(uint32_t j = 0; j < al[i].slen; j++) { a.items[at++] = CigItem{ al[i].seg_off + j, 0u, al[i].path_off }; } }
-}
+struct CigEnt { uint32_t off, len; };                                        /* where the string of a segment slot stands in the text buffer (len = ~0: it did not fit) */
 
 /* 64 path bits from absolute bit position p of the pool on (p >= 0: two header words stand in front of every path, gaba.h:217).  The parser asks for a fresh window per
  * test and moves down a few bits per run, so the lane keeps 256 bits of the pool in registers (four 8-byte words from word cq on) and goes to memory once per ~190 bits it
@@ -110,23 +95,35 @@ __host__ __device__ __forceinline__ uint64_t cig_write(const uint32_t *pool, uin
 	}
 	return cig_flush(out);
 }
-struct CigArgs { const CigItem *items; const gaba::Segment *seg_pool; const uint32_t *path_pool; CigEnt *ent; char *text; uint64_t text_cap; unsigned long long *ctl; };
-/* lane per segment: count, take room, write */
+struct CigArgs { const ReadState *st; const uint32_t *work; uint32_t n_work; const AlnRec *aln_pool; const gaba::Segment *seg_pool; const uint32_t *path_pool;
+	CigEnt *ent; uint64_t ent_cap; char *text; uint64_t text_cap; unsigned long long *ctl; };          /* ctl[0] = segments done, [1] = text bytes taken, [2] = something did not fit */
+/* lane per read of the work list of the extension launch in front (the launch's stream: this kernel starts when that one ends): every segment of every alignment the read
+ * recorded -- count, take room, write */
 __global__ void __launch_bounds__(256) mm_cigar_kernel(CigArgs a)
 {
-	const unsigned long long n = a.ctl[0];
-	const unsigned long long k = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
-	if(k >= n) { return; }
-	const CigItem it = a.items[k];
-	const gaba::Segment sg = a.seg_pool[it.seg];
-	const uint64_t len = (uint64_t)sg.alen + sg.blen;
-	/* (the host's parser aligns its pointer down to 8 bytes and adds 32 to the offset when it had to, gaba_parse.h:176-177: the same absolute bit either way) */
-	const uint64_t base = it.path_word * 32ull + sg.ppos - 64ull;
-	const uint64_t chars = cig_write(a.path_pool, base, len, nullptr);
-	const unsigned long long at = atomicAdd(&a.ctl[1], (unsigned long long)chars);
-	if(at + chars > a.text_cap || chars > 0xfffffff0ull) { a.ent[it.seg] = CigEnt{ 0u, 0xffffffffu }; atomicExch(&a.ctl[2], 1ull); return; }
-	a.ent[it.seg] = CigEnt{ (uint32_t)at, (uint32_t)chars };
-	(void)cig_write(a.path_pool, base, len, a.text + at);
+	const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+	if(k >= a.n_work) { return; }
+	const ReadState &rs = a.st[a.work[k]];
+	if(rs.n_aln == 0 || rs.bin_off == ~0ull) { return; }
+	const AlnRec *al = a.aln_pool + rs.aln_off;
+	uint32_t done = 0;
+	for(uint32_t i = 0; i < rs.n_aln; i++) {
+		for(uint32_t j = 0; j < al[i].slen; j++) {
+			const uint32_t slot = al[i].seg_off + j;
+			if(slot >= a.ent_cap) { atomicExch(&a.ctl[2], 1ull); continue; }
+			const gaba::Segment sg = a.seg_pool[slot];
+			const uint64_t len = (uint64_t)sg.alen + sg.blen;
+			/* (the host's parser aligns its pointer down to 8 bytes and adds 32 to the offset when it had to, gaba_parse.h:176-177: the same absolute bit either way) */
+			const uint64_t base = al[i].path_off * 32ull + sg.ppos - 64ull;
+			const uint64_t chars = cig_write(a.path_pool, base, len, nullptr);
+			const unsigned long long at = atomicAdd(&a.ctl[1], (unsigned long long)chars);
+			if(at + chars > a.text_cap || chars > 0xfffffff0ull) { a.ent[slot] = CigEnt{ 0u, 0xffffffffu }; atomicExch(&a.ctl[2], 1ull); continue; }
+			a.ent[slot] = CigEnt{ (uint32_t)at, (uint32_t)chars };
+			(void)cig_write(a.path_pool, base, len, a.text + at);
+			done++;
+		}
+	}
+	if(done) { atomicAdd(&a.ctl[0], (unsigned long long)done); }
 }
 
 } /* namespace mm */

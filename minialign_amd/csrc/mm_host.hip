@@ -1208,7 +1208,7 @@ struct mm_align_s {
 	DBuf<uint8_t> k2w_scratch;          /* lane-per-read chain sweep: leaf / chain scratch, 16 B per seed found (a third of 16 B per element of the seed pool) */
 	DBuf<SpecJob> rq_jobs; DBuf<SpecMemo> rq_memo; DBuf<uint32_t> rq_state;          /* retry jobs of a launch (K3Args.rjobs); rq_state: one word per slot, then the four control words */
 	DBuf<SpecJob> spec_jobs; DBuf<SpecMemo> spec_memo; DBuf<uint32_t> spec_path; DBuf<gaba::Segment> spec_seg; DBuf<unsigned long long> spec_top;      /* chain jobs of the heaviest reads of a launch (K3Args.jobs) */
-	DBuf<CigItem> cig_items; DBuf<CigEnt> cig_ent; DBuf<char> cig_text; DBuf<unsigned long long> cig_ctl;          /* K4 (mm_cigar.hpp): the CIGAR strings of a batch made on the device */
+	DBuf<CigEnt> cig_ent; DBuf<char> cig_text;          /* K4 (mm_cigar.hpp): the CIGAR strings of a batch made on the device: where the string of a segment slot stands, the text (cursors: d_tops[36 ..]) */
 	DBuf<uint64_t> tap_words;              /* mm_batch_tap: the minimizer stream words of the batch, parallel to min_pool */
 	DBuf<uint8_t> d_text, d_codes; DBuf<TextRead> d_tinfo; DBuf<uint32_t> d_tn;      /* packing on the device: text range of the batch, per-read extents, code bytes of the arena, bases found per read */
 	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
@@ -1302,6 +1302,8 @@ bool lane_h2d(mm_align_t *a, void *dst, const void *src, size_t n)
 	memcpy(st, src, n); CPY(a, dst, st, n, hipMemcpyHostToDevice); return true;
 }
 void k3_watchdog_start(mm_align_s *GP);
+/* the CIGAR strings of this context's output are made on the device (K4): SAM without MD tags; MM_HOST_CIGAR: the host walks the path words as in rounds 1-5 */
+static bool device_cigar(const mm_align_s *a) { static const bool host_cigar = getenv("MM_HOST_CIGAR") != NULL; return a->o.format == 0 && !((a->o.ptags() >> 8) & 1) && !host_cigar; }
 /* run K1..K3 over `work` (indices into the batch) with rlen_in already stored in d_st[].rlen */
 bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &work_in, bool run_k1, std::vector<ReadState> &hst,
 	const std::vector<uint32_t> *rlen_fixed, const std::vector<uint32_t> &qlens)
@@ -1631,7 +1633,16 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 			if(k3_conc) { (void)hipEventRecord(a->ev0, xs); }
 		}
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), inkernel ? K3_LDS_BYTES : 0, xs, k3);
-		{ const hipError_t le = hipGetLastError(); hipError_t se = le == hipSuccess ? hipEventRecord(a->ev1, xs) : le; if(se == hipSuccess) se = hipEventSynchronize(a->ev1);
+		{ const hipError_t le = hipGetLastError(); hipError_t se = le == hipSuccess ? hipEventRecord(a->ev1, xs) : le;
+		  /* K4 right behind it on the same stream: the CIGAR strings of what this launch records (mm_cigar.hpp); a run that prints them from the path words on the host
+		   * (MD tags, the other formats, MM_HOST_CIGAR) does without */
+		  if(se == hipSuccess && device_cigar(a) && a->cig_ent.p && a->cig_text.p) {
+			CigArgs ca; ca.st = a->d_st.p; ca.work = a->d_work.p; ca.n_work = k3.n_work; ca.aln_pool = a->aln_pool.p; ca.seg_pool = a->seg_pool.p; ca.path_pool = a->path_pool.p;
+			ca.ent = a->cig_ent.p; ca.ent_cap = a->cig_ent.n; ca.text = a->cig_text.p; ca.text_cap = std::min<uint64_t>(a->cig_text.n, 0xf0000000ull); ca.ctl = tops + 36;
+			hipLaunchKernelGGL(mm_cigar_kernel, dim3((k3.n_work + 255) / 256), dim3(256), 0, xs, ca);
+			se = hipGetLastError();
+		  }
+		  if(se == hipSuccess) se = hipEventSynchronize(a->ev1);
 		  { std::lock_guard<std::mutex> lk(GP->k3_gate_mu); GP->k3_in_flight--; if(!a->k3_called_off.load()) { GP->wd_longest_ms = std::max(GP->wd_longest_ms, now_ms() - a->k3_t0.load()); } a->k3_t0.store(0.0); }
 		  GP->k3_gate_cv.notify_all();
 		  CK(se); }
@@ -1997,6 +2008,9 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	ok &= a->aln_pool.ensure(((uint64_t)n_reads + 2048) * a->aln_cap + heavy);
 	ok &= a->seg_pool.ensure((uint64_t)n_reads * a->aln_cap * 2 + 4096 + 8 * heavy);
 	ok &= a->path_pool.ensure((bases / 4 + 1024ull * n_reads) * scale + (1ull << 20));
+	/* K4's text: two characters per base of batch (PacBio-CLR-like reads make 0.38 per base and record; a read inside a repeat family has a few records) -- a batch that needs
+	 * more has its strings made by the host (batch_fetch) */
+	if(device_cigar(a)) { ok &= a->cig_ent.ensure(a->seg_pool.n) && a->cig_text.ensure(std::min<uint64_t>(0xf0000000ull, (2 * bases + (32ull << 20)) & ~((32ull << 20) - 1))); }
 	/* DP workspace: a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors */
 	/* re-allocating tens of GB costs seconds: size for the longest read of the whole input when the caller knows it (qlen_hint), in steps of 8 k bases */
 	max_qlen = (std::max(max_qlen, a->qlen_hint) + 8191u) & ~8191u;
@@ -2017,7 +2031,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	}
 	else if(a->slab_stride >= slab && a->k3_waves >= kw) { /* the current allocation already serves */ }
 	else { ok &= a->slabs.ensure(slab * kw); if(ok) { a->slab_stride = a->slabs.n / kw; a->k3_waves = kw; } }
-	ok &= a->d_tops.ensure(40); ok &= a->d_k2cnt.ensure(48);
+	ok &= a->d_tops.ensure(48); ok &= a->d_k2cnt.ensure(48);
 	return ok;
 }
 /* A ring of free workspace numbers as it stands before anything has been taken (k3_ring_try / k3_ring_give): per XCD x the numbers base + x * per .. in their slots,
@@ -2332,7 +2346,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); a->pring[c].release(); a->pctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
-	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release(); a->cig_items.release(); a->cig_ent.release(); a->cig_text.release(); a->cig_ctl.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release(); a->cig_ent.release(); a->cig_text.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	if(a->pin_note) (void)hipHostFree(a->pin_note);
 	if(!a->is_sib) { k3_watchdog_stop(a); }
@@ -2439,7 +2453,7 @@ bool batch_upload(mm_align_t *a, Batch &b)
 				const uint64_t nw1 = (b.total + 64 + 31) / 32;
 				hipLaunchKernelGGL(mm_codes_pack_kernel, dim3((uint32_t)((nw1 + 255) / 256)), dim3(256), 0, a->stream, a->d_codes.p, nw1, a->q_pk.p, a->q_nm.p);
 				CK(hipGetLastError());
-				CK(hipMemsetAsync(a->d_tops.p, 0, 32 * 8, a->stream));
+				CK(hipMemsetAsync(a->d_tops.p, 0, 40 * 8, a->stream));
 				CK(hipMemcpyAsync(stg + s_tr + s_in + s_st, a->d_tn.p, (size_t)b.n * 4, hipMemcpyDeviceToHost, a->stream));
 				CK(hipStreamSynchronize(a->stream));
 				const uint32_t *tn1 = (const uint32_t *)(stg + s_tr + s_in + s_st);
@@ -2500,7 +2514,7 @@ bool batch_upload(mm_align_t *a, Batch &b)
 	else if(!lane_h2d(a, a->q_pk.p, b.pk.data(), b.pk.size() * 4) || !lane_h2d(a, a->q_nm.p, b.nm.data(), b.nm.size() * 4)) return false;
 	if(!lane_h2d(a, a->d_in.p, b.in.data(), b.n * sizeof(ReadIn))) return false;
 	if(!lane_h2d(a, a->d_st.p, b.hst.data(), b.n * sizeof(ReadState))) return false;
-	CK(hipMemsetAsync(a->d_tops.p, 0, 32 * 8, a->stream)); CK(hipStreamSynchronize(a->stream));
+	CK(hipMemsetAsync(a->d_tops.p, 0, 40 * 8, a->stream)); CK(hipStreamSynchronize(a->stream));
 	if(verbose) { fprintf(stderr, "[minialign_amd]   host state + H2D %.1f ms\n", now_ms() - tv); }
 	b.uploaded = true; b.ran = false;
 	return true;
@@ -2667,7 +2681,7 @@ struct Fetched {
 	 * kernels' statistics, [16] their work counters, [17..23] the extension kernel's profile ([17] longest wave, [19] next, [20] fill, [21] leaf, [22] trace, [23] total), [24..27] + [29] the LDS sort + chain kernel and the chain / scan kernels through
 	 * `prof` = tops + 24 (their prof[0] sort, [1] chain, [2] total, [3] reads beyond the LDS, [5] = tops[29] reads that did not fit: index 4 is used by none of them), [28] the
 	 * HBM sort kernel alone (`prof` = tops + 28, its prof[0] only), [30] the chain sweep's scratch cursor.  The ranges are disjoint as long as nobody starts to use prof[4] */
-	unsigned long long tops[32];
+	unsigned long long tops[40];          /* ([36 .. 38]: K4's cursors -- segments done, text bytes, overflow) */
 	Root *root = nullptr; uint64_t *bin = nullptr; AlnRec *aln = nullptr; gaba::Segment *seg = nullptr; uint32_t *path = nullptr;
 	const CigEnt *cig_ent = nullptr; const char *cig_text = nullptr;          /* the CIGAR strings of the batch as the device made them (K4), indexed by segment slot; NULL: the printers walk the path words (which are then what was fetched) */
 	uint64_t d2h_bytes = 0;
@@ -2686,26 +2700,12 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
 	/* host copies of the result pools (uninitialised storage: the copies fill them); pinned when the caller lends a set */
-	/* K4: the CIGAR strings on the device (mm_cigar.hpp) for a run that prints SAM without MD tags -- the text and an (offset, length) pair per segment come back instead
-	 * of the path words.  The strings of a batch that do not fit 0.5 characters per path bit (three times what PacBio-CLR-like reads make) are made by the host as
-	 * before, from the path words; MM_HOST_CIGAR: always (the form of rounds 1-5: test, and the other side of the measurement) */
-	static const bool host_cigar = getenv("MM_HOST_CIGAR") != NULL;
+	/* K4 made the CIGAR strings of every alignment right behind the launch that recorded it (run_rounds): the text and an (offset, length) pair per segment come back
+	 * instead of the path words.  The strings of a batch that did not fit its text buffer are made by the host as before, from the path words */
 	const uint64_t n_seg = std::min<uint64_t>(tops[5], a->seg_pool.n), n_path = std::min<uint64_t>(tops[6], a->path_pool.n);
-	bool dev_cigar = a->o.format == 0 && !((a->o.ptags() >> 8) & 1) && !b.regs && !host_cigar && n_seg > 0 && n_path * 16 < 0xf0000000ull;
-	unsigned long long cig_ctl[4] = { 0, 0, 0, 0 };
-	if(dev_cigar) {
-		const uint64_t text_cap = ((n_path * 16 + (1ull << 20)) + (32ull << 20) - 1) & ~((32ull << 20) - 1);
-		if(a->cig_items.ensure(n_seg) && a->cig_ent.ensure(n_seg) && a->cig_text.ensure(text_cap) && a->cig_ctl.ensure(4)) {
-			CK(hipMemsetAsync(a->cig_ctl.p, 0, 32, a->stream));
-			CigListArgs la; la.st = a->d_st.p; la.n_reads = n_reads; la.aln_pool = a->aln_pool.p; la.items = a->cig_items.p; la.ctl = a->cig_ctl.p; la.item_cap = n_seg;
-			hipLaunchKernelGGL(mm_cigar_list_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, a->stream, la);
-			CigArgs ca; ca.items = a->cig_items.p; ca.seg_pool = a->seg_pool.p; ca.path_pool = a->path_pool.p; ca.ent = a->cig_ent.p; ca.text = a->cig_text.p; ca.text_cap = std::min<uint64_t>(a->cig_text.n, 0xf0000000ull); ca.ctl = a->cig_ctl.p;
-			hipLaunchKernelGGL(mm_cigar_kernel, dim3((uint32_t)((n_seg + 255) / 256)), dim3(256), 0, a->stream, ca);
-			CK(hipGetLastError());
-			CK(hipMemcpyAsync(cig_ctl, a->cig_ctl.p, 32, hipMemcpyDeviceToHost, a->stream)); CK(hipStreamSynchronize(a->stream));
-			if(cig_ctl[2] != 0) { dev_cigar = false; if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   CIGAR strings of a batch beyond %.1f MB of text: made by the host\n", text_cap / 1e6); }
-		} else { dev_cigar = false; }
-	}
+	const unsigned long long cig_ctl[3] = { tops[36], tops[37], tops[38] };
+	bool dev_cigar = device_cigar(a) && !b.regs && a->cig_ent.p && a->cig_text.p && n_seg > 0 && n_seg <= a->cig_ent.n;
+	if(dev_cigar && cig_ctl[2] != 0) { dev_cigar = false; if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   CIGAR strings of a batch beyond %.1f MB of text: made by the host\n", a->cig_text.n / 1e6); }
 	{
 		const size_t need[7] = { (size_t)std::max<uint64_t>(tops[2], 1) * sizeof(Root), (size_t)std::max<uint64_t>(tops[3], 1) * 8, (size_t)std::max<uint64_t>(tops[4], 1) * sizeof(AlnRec),
 			(size_t)std::max<uint64_t>(tops[5], 1) * sizeof(gaba::Segment), dev_cigar ? 64 : (size_t)(std::max<uint64_t>(tops[6], 2) + 8) * 4,
