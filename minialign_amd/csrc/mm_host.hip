@@ -1192,6 +1192,7 @@ struct mm_align_s {
 	gaba_arena_t *ref_ar = nullptr;
 	uint32_t twlen, tglen; double mcoef, xcoef;
 	hipStream_t stream; hipEvent_t ev0, ev1;
+	hipEvent_t k4e = nullptr; bool k4_pending = false;          /* K4 (mm_cigar.hpp) runs on the last side stream behind every extension launch: recorded behind the last one queued */
 	hipStream_t k2s[12]; hipEvent_t k2e[16]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
 	uint64_t mem_for_batches = 0;                              /* device memory the lanes' pools may take together (measured when the first text stream starts: batch_cap_bases) */
@@ -1315,6 +1316,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 	mm_align_s *const GPw = a->root ? a->root : a;
 	const bool safe = GPw->safe_mode.load();          /* the watchdog has called a launch of this device off (k3_watchdog_main): nothing in the extension launches that waits for another wave */
 	a->k3_called_off.store(false);
+	if(a->k4_pending) { CK(hipStreamWaitEvent(a->stream, a->k4e, 0)); }          /* (K4 of the launch in front still reads the states and pools this one is about to change) */
 	/* a re-run of a few reads with the carried value given (batch_verify_carry): the short way -- one sort + chain launch, no round trip of the states between chaining
 	 * and extension (the caller has put the value and the reset fields in place), the work list as it is */
 	const bool small_rerun = rlen_fixed != nullptr && run_k1 && work.size() < 256;
@@ -1634,13 +1636,16 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		}
 		hipLaunchKernelGGL(mm_extend_kernel, dim3(waves / 4), dim3(256), inkernel ? K3_LDS_BYTES : 0, xs, k3);
 		{ const hipError_t le = hipGetLastError(); hipError_t se = le == hipSuccess ? hipEventRecord(a->ev1, xs) : le;
-		  /* K4 right behind it on the same stream: the CIGAR strings of what this launch records (mm_cigar.hpp); a run that prints them from the path words on the host
-		   * (MD tags, the other formats, MM_HOST_CIGAR) does without */
+		  /* K4 behind it, on a side stream that waits for the launch: the CIGAR strings of what this launch records (mm_cigar.hpp) are made while the host checks the carried
+		   * value of the batch and waits for its turn -- a lane per read walking its paths is a few milliseconds of dependent steps alone and several times that beside the
+		   * extension waves of the other lanes: on the lane's own stream it stood in front of the check (3.7 against 4.2 G bases/s); batch_fetch waits for it (k4e).  A run
+		   * that prints the strings from the path words on the host (MD tags, the other formats, MM_HOST_CIGAR) does without */
 		  if(se == hipSuccess && device_cigar(a) && a->cig_ent.p && a->cig_text.p) {
+			se = hipEventRecord(a->k2e[15], xs); if(se == hipSuccess) se = hipStreamWaitEvent(a->k2s[MM_SIDE - 1], a->k2e[15], 0);
 			CigArgs ca; ca.st = a->d_st.p; ca.work = a->d_work.p; ca.n_work = k3.n_work; ca.aln_pool = a->aln_pool.p; ca.seg_pool = a->seg_pool.p; ca.path_pool = a->path_pool.p;
 			ca.ent = a->cig_ent.p; ca.ent_cap = a->cig_ent.n; ca.text = a->cig_text.p; ca.text_cap = std::min<uint64_t>(a->cig_text.n, 0xf0000000ull); ca.ctl = tops + 36;
-			hipLaunchKernelGGL(mm_cigar_kernel, dim3((k3.n_work + 255) / 256), dim3(256), 0, xs, ca);
-			se = hipGetLastError();
+			if(se == hipSuccess) { hipLaunchKernelGGL(mm_cigar_kernel, dim3((k3.n_work + 255) / 256), dim3(256), 0, a->k2s[MM_SIDE - 1], ca); se = hipGetLastError(); }
+			if(se == hipSuccess) { se = hipEventRecord(a->k4e, a->k2s[MM_SIDE - 1]); a->k4_pending = true; }
 		  }
 		  if(se == hipSuccess) se = hipEventSynchronize(a->ev1);
 		  { std::lock_guard<std::mutex> lk(GP->k3_gate_mu); GP->k3_in_flight--; if(!a->k3_called_off.load()) { GP->wd_longest_ms = std::max(GP->wd_longest_ms, now_ms() - a->k3_t0.load()); } a->k3_t0.store(0.0); }
@@ -2225,6 +2230,7 @@ static bool make_streams(mm_align_s *a)
 	if(hipStreamCreateWithPriority(&a->stream, hipStreamNonBlocking, greatest) != hipSuccess || hipEventCreate(&a->ev0) != hipSuccess || hipEventCreate(&a->ev1) != hipSuccess) return false;
 	for(int i = 0; i < 16; i++) { if((i < MM_SIDE && hipStreamCreateWithPriority(&a->k2s[i], hipStreamNonBlocking, greatest) != hipSuccess) || hipEventCreateWithFlags(&a->k2e[i], hipEventDisableTiming) != hipSuccess) return false; }
 	a->k2s_ok = true;
+	if(hipEventCreateWithFlags(&a->k4e, hipEventDisableTiming) != hipSuccess) return false;
 	if(hipHostMalloc((void **)&a->pin_note, 64, hipHostMallocPortable) != hipSuccess) return false;
 	return true;
 }
@@ -2353,6 +2359,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	if(a->wd) { (void)hipHostFree(a->wd); a->wd = nullptr; }
 	free_chunk_pool(a->chunk_pool); a->chunk_pool = nullptr;
 	(void)hipEventDestroy(a->ev0); (void)hipEventDestroy(a->ev1); (void)hipStreamDestroy(a->stream);
+	if(a->k4e) (void)hipEventDestroy(a->k4e);
 	if(a->k2s_ok) { for(int i = 0; i < 16; i++) { if(i < MM_SIDE) { (void)hipStreamDestroy(a->k2s[i]); } (void)hipEventDestroy(a->k2e[i]); } }
 	delete a;
 }
@@ -2409,6 +2416,7 @@ namespace {
 bool batch_upload(mm_align_t *a, Batch &b)
 {
 	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
+	if(a->k4_pending) { CK(hipStreamSynchronize(a->k2s[MM_SIDE - 1])); a->k4_pending = false; }          /* (a batch that goes up again -- pools grown, a launch called off -- while K4 still walks what the last attempt recorded: the pools may move) */
 	if(!ensure_pools(a, b.n, b.total + 64, b.max_qlen, b.scale)) return false;
 	if(verbose) { fprintf(stderr, "[minialign_amd]   pools %.1f ms\n", now_ms() - tv); tv = now_ms(); }
 	b.hst.assign(b.n, ReadState()); b.work.clear();
@@ -2692,6 +2700,7 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 {
 	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
 	a->rlen_carry = batch_carry_out(a, b, a->rlen_carry);
+	if(a->k4_pending) { CK(hipStreamWaitEvent(a->stream, a->k4e, 0)); a->k4_pending = false; }          /* (the strings of the last extension launch of the batch: K4 on its side stream) */
 	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
 	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->k3_waves; a->st.k3_cycles_next += tops[19];
