@@ -1192,6 +1192,7 @@ struct mm_align_s {
 	gaba_arena_t *ref_ar = nullptr;
 	uint32_t twlen, tglen; double mcoef, xcoef;
 	hipStream_t stream; hipEvent_t ev0, ev1;
+	bool k4_off = false;          /* a text stream of fewer than two batches per lane: K4's walk (5 - 15 ms of dependent steps behind a batch's extension launch) has nothing to hide behind, the host's threads are idle anyway -- the strings are made there (align_text) */
 	hipEvent_t k4e = nullptr; bool k4_pending = false;          /* K4 (mm_cigar.hpp) runs on the last side stream behind every extension launch: recorded behind the last one queued */
 	hipStream_t k2s[12]; hipEvent_t k2e[16]; bool k2s_ok = false;    /* side streams: the size classes of the sort + chain stage run concurrently */
 	uint32_t n_waves = 0;
@@ -1209,7 +1210,7 @@ struct mm_align_s {
 	DBuf<uint8_t> k2w_scratch;          /* lane-per-read chain sweep: leaf / chain scratch, 16 B per seed found (a third of 16 B per element of the seed pool) */
 	DBuf<SpecJob> rq_jobs; DBuf<SpecMemo> rq_memo; DBuf<uint32_t> rq_state;          /* retry jobs of a launch (K3Args.rjobs); rq_state: one word per slot, then the four control words */
 	DBuf<SpecJob> spec_jobs; DBuf<SpecMemo> spec_memo; DBuf<uint32_t> spec_path; DBuf<gaba::Segment> spec_seg; DBuf<unsigned long long> spec_top;      /* chain jobs of the heaviest reads of a launch (K3Args.jobs) */
-	DBuf<CigEnt> cig_ent; DBuf<char> cig_text;          /* K4 (mm_cigar.hpp): the CIGAR strings of a batch made on the device: where the string of a segment slot stands, the text (cursors: d_tops[36 ..]) */
+	DBuf<CigItem> cig_items; DBuf<CigEnt> cig_ent; DBuf<char> cig_text;          /* K4 (mm_cigar.hpp): the CIGAR strings of a batch made on the device: where the string of a segment slot stands, the text (cursors: d_tops[36 ..]) */
 	DBuf<uint64_t> tap_words;              /* mm_batch_tap: the minimizer stream words of the batch, parallel to min_pool */
 	DBuf<uint8_t> d_text, d_codes; DBuf<TextRead> d_tinfo; DBuf<uint32_t> d_tn;      /* packing on the device: text range of the batch, per-read extents, code bytes of the arena, bases found per read */
 	/* shared DP workspaces (streaming engine): owned by the primary context, used by every lane; see K3Args.ring */
@@ -1304,7 +1305,7 @@ bool lane_h2d(mm_align_t *a, void *dst, const void *src, size_t n)
 }
 void k3_watchdog_start(mm_align_s *GP);
 /* the CIGAR strings of this context's output are made on the device (K4): SAM without MD tags; MM_HOST_CIGAR: the host walks the path words as in rounds 1-5 */
-static bool device_cigar(const mm_align_s *a) { static const bool host_cigar = getenv("MM_HOST_CIGAR") != NULL; return a->o.format == 0 && !((a->o.ptags() >> 8) & 1) && !host_cigar; }
+static bool device_cigar(const mm_align_s *a) { static const bool host_cigar = getenv("MM_HOST_CIGAR") != NULL; return a->o.format == 0 && !((a->o.ptags() >> 8) & 1) && !host_cigar && !a->k4_off; }
 /* run K1..K3 over `work` (indices into the batch) with rlen_in already stored in d_st[].rlen */
 bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &work_in, bool run_k1, std::vector<ReadState> &hst,
 	const std::vector<uint32_t> *rlen_fixed, const std::vector<uint32_t> &qlens)
@@ -1640,11 +1641,13 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		   * value of the batch and waits for its turn -- a lane per read walking its paths is a few milliseconds of dependent steps alone and several times that beside the
 		   * extension waves of the other lanes: on the lane's own stream it stood in front of the check (3.7 against 4.2 G bases/s); batch_fetch waits for it (k4e).  A run
 		   * that prints the strings from the path words on the host (MD tags, the other formats, MM_HOST_CIGAR) does without */
-		  if(se == hipSuccess && device_cigar(a) && a->cig_ent.p && a->cig_text.p) {
+		  if(se == hipSuccess && device_cigar(a) && a->cig_items.p && a->cig_ent.p && a->cig_text.p) {
 			se = hipEventRecord(a->k2e[15], xs); if(se == hipSuccess) se = hipStreamWaitEvent(a->k2s[MM_SIDE - 1], a->k2e[15], 0);
 			CigArgs ca; ca.st = a->d_st.p; ca.work = a->d_work.p; ca.n_work = k3.n_work; ca.aln_pool = a->aln_pool.p; ca.seg_pool = a->seg_pool.p; ca.path_pool = a->path_pool.p;
-			ca.ent = a->cig_ent.p; ca.ent_cap = a->cig_ent.n; ca.text = a->cig_text.p; ca.text_cap = std::min<uint64_t>(a->cig_text.n, 0xf0000000ull); ca.ctl = tops + 36;
-			if(se == hipSuccess) { hipLaunchKernelGGL(mm_cigar_kernel, dim3((k3.n_work + 255) / 256), dim3(256), 0, a->k2s[MM_SIDE - 1], ca); se = hipGetLastError(); }
+			ca.items = a->cig_items.p; ca.item_cap = a->cig_items.n; ca.ent = a->cig_ent.p; ca.ent_cap = a->cig_ent.n; ca.text = a->cig_text.p; ca.text_cap = std::min<uint64_t>(a->cig_text.n, 0xf0000000ull); ca.ctl = tops + 36;
+			if(se == hipSuccess) se = hipMemsetAsync(tops + 39, 0, 8, a->k2s[MM_SIDE - 1]);
+			if(se == hipSuccess) { hipLaunchKernelGGL(mm_cigar_list_kernel, dim3((k3.n_work + 255) / 256), dim3(256), 0, a->k2s[MM_SIDE - 1], ca); se = hipGetLastError(); }
+			if(se == hipSuccess) { hipLaunchKernelGGL(mm_cigar_kernel, dim3(std::min<uint32_t>(2048u, std::max<uint32_t>(1u, (k3.n_work * 4u + 255u) / 256u))), dim3(256), 0, a->k2s[MM_SIDE - 1], ca); se = hipGetLastError(); }
 			if(se == hipSuccess) { se = hipEventRecord(a->k4e, a->k2s[MM_SIDE - 1]); a->k4_pending = true; }
 		  }
 		  if(se == hipSuccess) se = hipEventSynchronize(a->ev1);
@@ -2015,7 +2018,7 @@ bool ensure_pools(mm_align_t *a, uint32_t n_reads, uint64_t bases, uint32_t max_
 	ok &= a->path_pool.ensure((bases / 4 + 1024ull * n_reads) * scale + (1ull << 20));
 	/* K4's text: two characters per base of batch (PacBio-CLR-like reads make 0.38 per base and record; a read inside a repeat family has a few records) -- a batch that needs
 	 * more has its strings made by the host (batch_fetch) */
-	if(device_cigar(a)) { ok &= a->cig_ent.ensure(a->seg_pool.n) && a->cig_text.ensure(std::min<uint64_t>(0xf0000000ull, (2 * bases + (32ull << 20)) & ~((32ull << 20) - 1))); }
+	if(device_cigar(a)) { ok &= a->cig_items.ensure(a->seg_pool.n) && a->cig_ent.ensure(a->seg_pool.n) && a->cig_text.ensure(std::min<uint64_t>(0xf0000000ull, (2 * bases + (32ull << 20)) & ~((32ull << 20) - 1))); }
 	/* DP workspace: a DOWN and an UP fill chain coexist; each runs at most about 2 x (qlen + 96) + drift vectors */
 	/* re-allocating tens of GB costs seconds: size for the longest read of the whole input when the caller knows it (qlen_hint), in steps of 8 k bases */
 	max_qlen = (std::max(max_qlen, a->qlen_hint) + 8191u) & ~8191u;
@@ -2352,7 +2355,7 @@ extern "C" void mm_align_destroy(mm_align_t *a)
 	}
 	a->q_pk.release(); a->q_nm.release(); a->d_in.release(); a->d_st.release(); a->d_work.release(); a->min_pool.release(); a->seed_pool.release();
 	a->d_text.release(); a->d_codes.release(); a->d_tinfo.release(); a->d_tn.release(); for(uint32_t c = 0; c < mm_align_s::MAX_CLS; c++) { a->xslabs[c].release(); a->xring[c].release(); a->xctr[c].release(); a->pring[c].release(); a->pctr[c].release(); } a->d_cls.release(); a->slab_ring.release(); a->slab_ring_ctr.release(); a->resc_pool.release(); a->root_pool.release(); a->rs_scratch.release(); a->slabs.release(); a->kh_pool.release(); a->next_pool.release();
-	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release(); a->cig_ent.release(); a->cig_text.release();
+	a->bin_pool.release(); a->aln_pool.release(); a->seg_pool.release(); a->path_pool.release(); a->d_tops.release(); a->d_k2cnt.release(); a->tap_words.release(); a->k2w_scratch.release(); a->rq_jobs.release(); a->rq_memo.release(); a->rq_state.release(); a->spec_jobs.release(); a->spec_memo.release(); a->spec_path.release(); a->spec_seg.release(); a->spec_top.release(); a->cig_items.release(); a->cig_ent.release(); a->cig_text.release();
 	if(a->pin_stage) (void)hipHostFree(a->pin_stage);
 	if(a->pin_note) (void)hipHostFree(a->pin_note);
 	if(!a->is_sib) { k3_watchdog_stop(a); }
@@ -2700,7 +2703,6 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 {
 	const uint32_t n_reads = b.n; std::vector<ReadState> &hst = b.hst;
 	a->rlen_carry = batch_carry_out(a, b, a->rlen_carry);
-	if(a->k4_pending) { CK(hipStreamWaitEvent(a->stream, a->k4e, 0)); a->k4_pending = false; }          /* (the strings of the last extension launch of the batch: K4 on its side stream) */
 	unsigned long long *tops = f.tops; CPY(a, tops, a->d_tops.p, sizeof(f.tops), hipMemcpyDeviceToHost);
 	a->st.minimizers += tops[8]; a->st.seeds += tops[9]; a->st.fills += tops[10]; a->st.vectors += tops[11]; a->st.blocks += tops[12]; a->st.traces += tops[13]; a->st.trace_steps += tops[14];
 	a->st.k3_cycles_fill += tops[20]; a->st.k3_cycles_leaf += tops[21]; a->st.k3_cycles_trace += tops[22]; a->st.k3_cycles_total += tops[23]; a->st.k3_cycles_max += tops[17]; a->st.k3_waves = a->k3_waves; a->st.k3_cycles_next += tops[19];
@@ -2708,38 +2710,38 @@ bool batch_fetch(mm_align_t *a, Batch &b, Fetched &f)
 	a->st.k2_cycles_sort += tops[24] + tops[28]; a->st.k2_cycles_chain += tops[25]; a->st.k2_cycles_total += tops[26] + tops[28]; a->st.k2_reads_hbm += tops[27];
 	a->st.reads += n_reads; for(uint32_t i = 0; i < n_reads; i++) a->st.bases += b.lens[i];
 	double t0 = now_ms();
-	/* host copies of the result pools (uninitialised storage: the copies fill them); pinned when the caller lends a set */
-	/* K4 made the CIGAR strings of every alignment right behind the launch that recorded it (run_rounds): the text and an (offset, length) pair per segment come back
-	 * instead of the path words.  The strings of a batch that did not fit its text buffer are made by the host as before, from the path words */
+	/* Host copies of the result pools (uninitialised storage: the copies fill them); pinned when the caller lends a set.  K4 made the CIGAR strings of every alignment
+	 * behind the launch that recorded it (run_rounds, on a side stream): the text and an (offset, length) pair per segment come back instead of the path words.  The pools
+	 * start on their way first; K4's counters, the pairs and the text follow when K4 is through (k4e).  A batch whose strings did not fit the text buffer, a run with MD
+	 * tags, the other formats and the mm_reg_t entries take the path words, and the host walks them as before */
+	const uint64_t n_root = std::min<uint64_t>(tops[2], a->root_pool.n), n_bin = std::min<uint64_t>(tops[3], a->bin_pool.n), n_aln = std::min<uint64_t>(tops[4], a->aln_pool.n);
 	const uint64_t n_seg = std::min<uint64_t>(tops[5], a->seg_pool.n), n_path = std::min<uint64_t>(tops[6], a->path_pool.n);
-	const unsigned long long cig_ctl[3] = { tops[36], tops[37], tops[38] };
-	bool dev_cigar = device_cigar(a) && !b.regs && a->cig_ent.p && a->cig_text.p && n_seg > 0 && n_seg <= a->cig_ent.n;
-	if(dev_cigar && cig_ctl[2] != 0) { dev_cigar = false; if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   CIGAR strings of a batch beyond %.1f MB of text: made by the host\n", a->cig_text.n / 1e6); }
-	{
-		const size_t need[7] = { (size_t)std::max<uint64_t>(tops[2], 1) * sizeof(Root), (size_t)std::max<uint64_t>(tops[3], 1) * 8, (size_t)std::max<uint64_t>(tops[4], 1) * sizeof(AlnRec),
-			(size_t)std::max<uint64_t>(tops[5], 1) * sizeof(gaba::Segment), dev_cigar ? 64 : (size_t)(std::max<uint64_t>(tops[6], 2) + 8) * 4,
-			dev_cigar ? (size_t)n_seg * sizeof(CigEnt) : 0, dev_cigar ? (size_t)cig_ctl[1] + 16 : 0 };
-		void *ptr[7];
-		for(int i = 0; i < 7; i++) {
-			if(need[i] == 0) { ptr[i] = nullptr; continue; }
-			ptr[i] = f.pin ? f.pin->get(i, need[i]) : nullptr;
-			if(!ptr[i]) { f.own[i].reset(new uint8_t[need[i] + 16]); ptr[i] = f.own[i].get(); }
-		}
-		f.root = (Root *)ptr[0]; f.bin = (uint64_t *)ptr[1]; f.aln = (AlnRec *)ptr[2]; f.seg = (gaba::Segment *)ptr[3]; f.path = (uint32_t *)ptr[4];
-		f.cig_ent = (const CigEnt *)ptr[5]; f.cig_text = (const char *)ptr[6];
-	}
-	f.d2h_bytes = std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root) + std::min<uint64_t>(tops[3], a->bin_pool.n) * 8 + std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec) + n_seg * sizeof(gaba::Segment);
-	CK(hipMemcpyAsync(f.root, a->root_pool.p, std::min<uint64_t>(tops[2], a->root_pool.n) * sizeof(Root), hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(f.bin, a->bin_pool.p, std::min<uint64_t>(tops[3], a->bin_pool.n) * 8, hipMemcpyDeviceToHost, a->stream));
-	CK(hipMemcpyAsync(f.aln, a->aln_pool.p, std::min<uint64_t>(tops[4], a->aln_pool.n) * sizeof(AlnRec), hipMemcpyDeviceToHost, a->stream));
+	bool dev_cigar = device_cigar(a) && !b.regs && a->k4_pending && a->cig_ent.p && a->cig_text.p && n_seg > 0 && n_seg <= a->cig_ent.n;
+	auto pinned = [&](int i, size_t need) -> void * { void *q = f.pin ? f.pin->get(i, need) : nullptr; if(!q) { f.own[i].reset(new uint8_t[need + 16]); q = f.own[i].get(); } return q; };
+	f.root = (Root *)pinned(0, (size_t)std::max<uint64_t>(n_root, 1) * sizeof(Root)); f.bin = (uint64_t *)pinned(1, (size_t)std::max<uint64_t>(n_bin, 1) * 8);
+	f.aln = (AlnRec *)pinned(2, (size_t)std::max<uint64_t>(n_aln, 1) * sizeof(AlnRec)); f.seg = (gaba::Segment *)pinned(3, (size_t)std::max<uint64_t>(n_seg, 1) * sizeof(gaba::Segment));
+	f.path = nullptr; f.cig_ent = nullptr; f.cig_text = nullptr;
+	f.d2h_bytes = n_root * sizeof(Root) + n_bin * 8 + n_aln * sizeof(AlnRec) + n_seg * sizeof(gaba::Segment);
+	CK(hipMemcpyAsync(f.root, a->root_pool.p, n_root * sizeof(Root), hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.bin, a->bin_pool.p, n_bin * 8, hipMemcpyDeviceToHost, a->stream));
+	CK(hipMemcpyAsync(f.aln, a->aln_pool.p, n_aln * sizeof(AlnRec), hipMemcpyDeviceToHost, a->stream));
 	CK(hipMemcpyAsync(f.seg, a->seg_pool.p, n_seg * sizeof(gaba::Segment), hipMemcpyDeviceToHost, a->stream));
+	unsigned long long cig_ctl[4] = { 0, 0, 0, 0 };
+	if(a->k4_pending) {
+		CK(hipStreamWaitEvent(a->stream, a->k4e, 0)); a->k4_pending = false;
+		if(dev_cigar) { CK(hipMemcpyAsync(cig_ctl, a->d_tops.p + 36, sizeof(cig_ctl), hipMemcpyDeviceToHost, a->stream)); CK(hipStreamSynchronize(a->stream)); }
+	}
+	if(dev_cigar && cig_ctl[2] != 0) { dev_cigar = false; if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd]   CIGAR strings of a batch beyond %.1f MB of text: made by the host\n", a->cig_text.n / 1e6); }
 	if(dev_cigar) {
+		f.cig_ent = (const CigEnt *)pinned(5, (size_t)n_seg * sizeof(CigEnt)); f.cig_text = (const char *)pinned(6, (size_t)cig_ctl[1] + 16);
+		f.path = (uint32_t *)pinned(4, 64);
 		CK(hipMemcpyAsync((void *)f.cig_ent, a->cig_ent.p, n_seg * sizeof(CigEnt), hipMemcpyDeviceToHost, a->stream));
 		if(cig_ctl[1]) { CK(hipMemcpyAsync((void *)f.cig_text, a->cig_text.p, cig_ctl[1], hipMemcpyDeviceToHost, a->stream)); }
 		f.d2h_bytes += n_seg * sizeof(CigEnt) + cig_ctl[1];
 	} else {
+		f.path = (uint32_t *)pinned(4, (size_t)(std::max<uint64_t>(n_path, 2) + 8) * 4);
 		CK(hipMemcpyAsync(f.path, a->path_pool.p, n_path * 4, hipMemcpyDeviceToHost, a->stream));
-		f.d2h_bytes += n_path * 4; f.cig_ent = nullptr; f.cig_text = nullptr;
+		f.d2h_bytes += n_path * 4;
 	}
 	CK(hipStreamSynchronize(a->stream));
 	a->st.host_post_ms += now_ms() - t0; a->st.d2h_bytes += f.d2h_bytes; if(dev_cigar) { a->st.cigar_bytes_device += cig_ctl[1]; }
@@ -3892,7 +3894,15 @@ static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const 
 	rd.cap_bases = std::min<uint64_t>(1000000000ull, batch_cap_bases(a, lanes));
 	if(!rd.start()) { fprintf(stderr, "[minialign_amd] reader: no stream / staging memory\n"); return 1; }
 	bool err = false;
+	{
+		/* K4 (the CIGAR strings on the device) for streams of two batches per lane and more: E.coli-size x100 (0.46 Gb, a batch and a half per lane) maps at 2.25 G bases/s with
+		 * the strings made by the host and at 1.93 with K4, whose walk ends every batch; from the dm6-size x20 set on (2.9 Gb) it is hidden behind the other lanes' work */
+		const uint64_t bb = getenv("MM_BATCH_BASES") ? (uint64_t)atoll(getenv("MM_BATCH_BASES")) : 300000000ull;
+		const bool small = src->n < 2ull * (uint64_t)lanes * rd.dctx.size() * bb;
+		each_context(a, [small](mm_align_t *q) { q->k4_off = small; });
+	}
 	int rc = stream_map(a, MM_OPEN_ENDED, [&](int di) { return rd.take(di, &err); }, [](mm_batch_t *h) { mm_batch_free(h); }, sink, lanes, pos_fd, pos_at);
+	each_context(a, [](mm_align_t *q) { q->k4_off = false; });
 	{ std::lock_guard<std::mutex> lk(rd.mu); if(err || rd.failed) rc = 1; }
 	for(ReaderDev *R : rd.rdev) { a->st.text_bytes += R->bytes_up; a->st.reader_ms += R->t_io; }
 	return rc;

@@ -213,7 +213,7 @@ def test_cigar_strings_made_on_the_device_are_the_hosts(opts, workdir):
     s = dict(name='g_cig', preset='pacbio', genome=(361, 2000000, 8, 0.40), reads=(362, 1.5, 'pacbio', 'fa', 7000, 2000))
     ref, rd = make_inputs(s, workdir)
     def run(env, extra=[]):
-        r = subprocess.run([CLI, '-x' + s['preset']] + opts + extra + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_BATCH_BASES='1500000', MM_VERBOSE='1', **env))
+        r = subprocess.run([CLI, '-x' + s['preset']] + opts + extra + [ref, rd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, MM_BATCH_BASES='250000', MM_VERBOSE='1', **env))          # (K4 runs for streams of two batches per lane and more)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         return _strip_pg(r.stdout), r.stderr
     dev, err_d = run({}); host, err_h = run(dict(MM_HOST_CIGAR='1'))
