@@ -404,783 +404,8 @@ void sketch_host_circular(const uint8_t *seq, uint32_t len, uint32_t k_, uint32_
 
 } /* anonymous */
 
-/* =============================================================================================
- * options
- * ============================================================================================= */
-struct mm_opt_s {
-	uint32_t k = 15, w = 32, b = 14, n_frq = 3; float frq[8] = { 0.05f, 0.01f, 0.001f, 0 };     /* up to MAX_FRQ_CNT = 7 thresholds, minialign.c:29 */
-	uint32_t min_len = 1, help = 0;
-	/* output (minialign.c:5880-5967): flag = -P 0x08 and bit 0 when -R is given; tags = bits 1 << MM_xx of -T.  The reference's printer ORs the two
-	 * into one word (minialign.c:5677), so -P also switches IH on and -T IH also omits the secondary records: kept */
-	uint64_t flag = 0, tags = 0; std::string rg_line, rg_id; bool keep_qual = false;
-	uint32_t format = 0;             /* -O: 0 sam, 1 maf, 2 blast6, 5 paf (minialign.c:2543-2549, 5940) */
-	bool ava = false;                /* -X (MM_AVA in the mapper's flag word, minialign.c:5965, 6377) */
-	bool circ_set = false; std::vector<std::string> circ_names;     /* -c: given at all / names of the circular reference sequences (none: all), minialign.c:2457, 5986 */
-	uint64_t ptags() const { return flag | tags; }
-	uint32_t wlen = 7000, glen = 7000, min_score = 50; float min_ratio = 0.3f;
-	gaba_params_t p;
-	uint32_t nth = 1;
-	std::string arg_line, fnw;       /* fnw: -d, file the index is dumped to (minialign.c:5979 mm_opt_fnw) */
-	mm_opt_s() { memset(&p, 0, sizeof(p)); for(int i = 0; i < 16; i++) p.score_matrix[i] = (i & 3) == (i >> 2) ? 1 : -1; p.gi = 1; p.ge = 1; p.xdrop = 50; }
-};
-namespace {
-int opt_one(mm_opt_t *o, char c, const char *arg);
-int opt_line(mm_opt_t *o, const char *s)
-{
-	while(*s) {
-		while(*s == ' ') s++;
-		if(*s != '-') break;
-		char c = s[1]; s += 2; std::string a; while(*s && *s != ' ') a.push_back(*s++);
-		if(opt_one(o, c, a.c_str())) return 1;
-	}
-	return 0;
-}
-template<typename F> void split_each(const char *arg, const char *delims, F fn)          /* mm_split_foreach */
-{
-	int i = 0;
-	for(const char *p = arg; ; ) { const char *e = p; while(*e && !strchr(delims, *e)) e++; if(e > p) fn(i++, std::string(p, e)); if(!*e) break; p = e + 1; }
-}
-/* the preset tree of minialign.c:5853-5878 as data: each name applies its option line, then the next name is looked up among its children
- * (mm_opt_preset, minialign.c:5880-5889); a name that is not there is an error (the reference then tries to read it as a configuration file) */
-struct PresetNode { const char *key, *val; const PresetNode *kids; };
-#define PN_END { nullptr, nullptr, nullptr }
-const PresetNode pn_leaf_r7[] = { { "1d", "", nullptr }, { "2d", "", nullptr }, PN_END };
-const PresetNode pn_leaf_1[] = { { "1d", "", nullptr }, { "1dsq", "-b6 -r4,4", nullptr }, { "2d", "-b6 -r4,4", nullptr }, PN_END };
-const PresetNode pn_r9_45[] = { { "1", "", pn_leaf_1 }, { "1d", "", nullptr }, { "1dsq", "-b6 -r4,4", nullptr }, { "2d", "-b6 -r4,4", nullptr }, PN_END };
-const PresetNode pn_r9[] = { { "4", "-a2", pn_r9_45 }, { "5", "-a2", pn_r9_45 }, { "1d", "", nullptr }, { "1dsq", "-b6 -r4,4", nullptr }, { "2d", "-b6 -r4,4", nullptr }, PN_END };
-const PresetNode pn_ont[] = { { "r7", "-b4", pn_leaf_r7 }, { "r9", "", pn_r9 }, { "1d", "-a2", nullptr }, { "1dsq", "-a2 -b6 -r4,4", nullptr }, { "2d", "-a2 -b6 -r4,4", nullptr }, PN_END };
-const PresetNode pn_pacbio[] = { { "clr", "", nullptr }, { "ccs", "-b5 -p6 -p2", nullptr }, PN_END };
-const PresetNode pn_root[] = { { "pacbio", "-k15 -w10 -a2 -b4 -p4 -q2 -r3,3 -Y50 -s50 -m0.3", pn_pacbio }, { "ont", "-k15 -w10 -a3 -b5 -p6 -q2 -r3,3 -Y50 -s50 -m0.3", pn_ont },
-	{ "ava", "-k15 -w5 -a2 -b3 -p0 -q2 -Y50 -s30 -m0.05", nullptr }, PN_END };
-int opt_preset(mm_opt_t *o, const char *name)
-{
-	const PresetNode *c = pn_root; int rc = 0; bool any = false;
-	split_each(name, ".:", [&](int, const std::string &t) {
-		if(rc) return;
-		const PresetNode *q = c; while(q && q->key && t != q->key) q++;
-		if(!q || !q->key) { rc = 1; return; }
-		if(opt_line(o, q->val)) { rc = 1; return; }
-		c = q->kids; any = true;
-	});
-	return rc || !any;
-}
-/* the option handlers of minialign.c:5990-6099 with their range checks; a failed check is an error (the reference counts it and exits 1) */
-bool opt_fail(const char *msg) { fprintf(stderr, "[E::mm_opt_parse] %s\n", msg); return true; }
-int opt_one(mm_opt_t *o, char c, const char *arg)
-{
-	auto base_of = [](char ch) -> int { switch(ch) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': case 'U': return 4; default: return 0; } };     /* idxaf, minialign.c:232 */
-	/* mm_opt_atoi / mm_opt_atof (minialign.c:5745-5768): digits only for the integer options, [0-9-.,eE] for the real ones; anything else is "unparsable number" */
-	auto digits = [](const char *t, size_t n) { for(size_t i = 0; i < n && t[i]; i++) if(!isdigit((unsigned char)t[i])) return false; return true; };
-	if(strchr("kwBLabpqYstWG12", c) && !digits(arg, strlen(arg))) return opt_fail("unparsable number.");
-	if(strchr("rC", c)) { bool bad = false; split_each(arg, ",;:/", [&](int, const std::string &t) { if(!digits(t.c_str(), t.size())) bad = true; }); if(bad) return opt_fail("unparsable number."); }
-	if(strchr("fm", c)) { for(const char *t = arg; *t; t++) if(!strchr("0123456789-.,eE", *t) && !(c == 'f' && strchr(";:/", *t))) return opt_fail("unparsable number."); }
-	switch(c) {
-		case 'x': return opt_preset(o, arg);
-		case 'k': o->k = atoi(arg); return !(o->k > 1 && o->k < 32) && opt_fail("k must be inside [1,32).");
-		case 'w': o->w = atoi(arg); return !(o->w > 1 && o->w < 32) && opt_fail("w must be inside [1,32).");
-		case 'B': o->b = atoi(arg); return !(o->b > 1 && o->b < 32) && opt_fail("b must be inside [1,32).");
-		case 'f': {
-			bool bad = false; o->n_frq = 0;
-			split_each(arg, ",;:/", [&](int i, const std::string &t) {
-				if(i >= 7) { bad = true; return; }
-				float f = o->frq[o->n_frq++] = (float)atof(t.c_str());
-				if(!(f >= 0.0 && f < 1.0) || (i > 0 && !(o->frq[i - 1] > o->frq[i]))) bad = true;
-			});
-			return (bad || o->n_frq == 0) && opt_fail("frequency thresholds (-f) must be inside [0,1), descending, at most 7.");
-		}
-		case 'L': o->min_len = atoi(arg); return !(o->min_len > 0) && opt_fail("minimum sequence length must be > 0.");
-		case 'a': { int m = atoi(arg); for(int i = 0; i < 16; i++) if((i & 3) == (i >> 2)) o->p.score_matrix[i] = (int8_t)m; return !(m > 0 && m < 7) && opt_fail("match award (-a) must be inside [1,7]."); }
-		case 'b': { int x = atoi(arg); for(int i = 0; i < 16; i++) if((i & 3) != (i >> 2)) o->p.score_matrix[i] = (int8_t)-x; return !(x > 0 && x < 7) && opt_fail("mismatch penalty (-b) must be inside [1,7]."); }
-		case 'e': {
-			bool bad = false;
-			split_each(arg, ",;:/", [&](int, const std::string &t) {
-				if(t.size() < 3 || !base_of(t[0]) || !base_of(t[1])) { bad = true; return; }
-				o->p.score_matrix[(base_of(t[1]) - 1) * 4 + (base_of(t[0]) - 1)] += (int8_t)atoi(t.c_str() + 2);
-			});
-			return bad && opt_fail("unknown base in score modifier (-e).");
-		}
-		case 'p': { int gi = atoi(arg); o->p.gi = (int8_t)gi; return !(gi < 32) && opt_fail("gap open penalty (-p) must be inside [0,32]."); }
-		case 'q': { int ge = atoi(arg); o->p.ge = (int8_t)ge; return !(ge > 0 && ge < 32) && opt_fail("gap extension penalty (-q) must be inside [1,32]."); }
-		case 'r': {
-			int g[2] = { 0, 0 };
-			split_each(arg, ",;:/", [&](int i, const std::string &t) { if(i == 0) g[0] = g[1] = atoi(t.c_str()); else if(i == 1) g[1] = atoi(t.c_str()); });
-			o->p.gfa = (int8_t)g[0]; o->p.gfb = (int8_t)g[1];
-			return !(g[0] >= 0 && g[0] < 32 && g[1] >= 0 && g[1] < 32) && opt_fail("short-gap extension penalty (-r) must be inside [0,32].");
-		}
-		case 'Y': { int x = atoi(arg); o->p.xdrop = (int8_t)x; return !(x > 10 && x < 128) && opt_fail("X-drop cutoff must be inside [10,128]."); }
-		case 's': o->min_score = atoi(arg); return !(o->min_score > 0) && opt_fail("minimum alignment score must be > 0.");
-		case 'm': o->min_ratio = (float)atof(arg); return !(o->min_ratio > 0.0 && o->min_ratio < 1.0) && opt_fail("minimum alignment score ratio must be inside [0.0,1.0].");
-		case 't': o->nth = atoi(arg); return 0;             /* host threads of the reference; the device path sizes its own */
-		case 'W': o->wlen = atoi(arg); return 0;
-		case 'G': o->glen = atoi(arg); return 0;
-		case 'd': o->fnw = arg; return o->fnw.empty();
-		case '1': case '2': return 0;                      /* input batch / output buffer sizes of the reference's host pipeline: accepted, no meaning here */
-		case 'v': return 0;
-		case 'h': o->help = 1; return 0;
-		case 'O': {
-			static const struct { const char *k; uint32_t v; } t[] = { { "sam", 0 }, { "maf", 1 }, { "blast6", 2 }, { "paf", 5 } };
-			for(auto &e : t) if(strcmp(arg, e.k) == 0) { o->format = e.v; return 0; }
-			return opt_fail("unknown output format (-O).");
-		}
-		case 'c': {                      /* mm_opt_circular, minialign.c:5986-5997: no name, `*' or `-' marks every sequence */
-			o->circ_set = true;
-			split_each(arg, ",;:/", [&](int, const std::string &t) { if(t == "*" || t == "-") o->circ_names.clear(); else o->circ_names.push_back(t); });
-			return 0;
-		}
-		case 'X': o->flag |= 0x01; o->ava = true; return 0;      /* MM_AVA: every file is mapped onto every file (minialign.c:6377); QUIRK kept: the bit is also the RG tag's */
-		case 'A': o->flag |= 0x10; return 0;      /* MM_COMP: no effect on the mapping; QUIRK kept: the bit is also the AS tag's */
-		case 'C': return 0;                       /* base ids: parsed, unused (minialign.c:3768 pins qid to 0) */
-		case 'P': o->flag |= 0x08; return 0;
-		case 'Q': o->keep_qual = true; return 0;
-		case 'T': {                      /* mm_opt_tags + mm_print_tag2flag, minialign.c:5928, 5631 */
-			static const char *const names[] = { "RG", "CO", "NH", "IH", "AS", "XS", "NM", "SA", "MD", "CG", "ID", "SQ" };
-			bool bad = false;
-			split_each(arg, ",;:/", [&](int, const std::string &t) { if(t.size() != 2) { bad = true; return; } for(int i = 0; i < 12; i++) if(t == names[i]) o->tags |= 1ull << i; });
-			return bad && opt_fail("unknown tag (-T).");
-		}
-		case 'R': {                      /* mm_opt_rg, minialign.c:5890-5921: a backslash turns the next character into a tab */
-			o->rg_line.clear(); o->rg_id.clear(); o->flag &= ~1ull;
-			std::string line; for(const char *q = arg; *q; q++) { if(*q == '\\') { q++; line.push_back('\t'); if(!*q) break; } else line.push_back(*q); }
-			bool found = false;
-			split_each(line.c_str(), "\t\r\n", [&](int, const std::string &t) { if(!found && t.compare(0, 3, "ID:") == 0) { o->rg_id = t; found = true; } });
-			if(!found) return opt_fail("RG line must start with @RG and contains ID, like `@RG\\tID:1'.");
-			o->rg_line = line; o->flag |= 1ull; return 0;
-		}
-		default: fprintf(stderr, "[E::mm_opt_parse] unsupported option -%c\n", c); return 1;
-	}
-}
-/* mm_opt_check_sanity, minialign.c:6097-6112 */
-int opt_check(mm_opt_t *o)
-{
-	int x = 0; for(int i = 0; i < 16; i++) x = std::max(x, -(int)o->p.score_matrix[i]);
-	const int gfa = o->p.gfa, gfb = o->p.gfb, ge = o->p.ge;
-	if(!(gfa == 0 || gfa > ge) || !(gfb == 0 || gfb > ge)) return opt_fail("short-gap extension penalty (-r) must be larger than gap extension penalty.");
-	if((gfa == 0) != (gfb == 0)) return opt_fail("short-gap extension penalty (-r) must be set for both sides.");
-	if(!(gfa == 0 || gfb == 0 || gfa + gfb > x)) return opt_fail("short-gap extension penalty (-r) must not be greater than mismatch penalty.");
-	return 0;
-}
-} /* anonymous */
-
-extern "C" mm_opt_t *mm_opt_init(void) { return new mm_opt_s(); }
-extern "C" void mm_opt_destroy(mm_opt_t *o) { delete o; }
-extern "C" int mm_opt_parse(mm_opt_t *o, int argc, char const *const *argv, char const **files, int max_files, int *n_files)
-{
-	int nf = 0;
-	o->arg_line.clear();
-	for(int i = 0; i < argc; i++) { if(i) o->arg_line += ' '; o->arg_line += argv[i]; }    /* mm_join(argv, ' '), minialign.c:6163 */
-	/* the walk of mm_opt_parse_argv (minialign.c:5786-5812): a word that does not start with '-' (or is "-" alone) is positional; behind the dash the boolean
-	 * letters (X A P Q h) are eaten one by one, the first other letter is the option, its argument is the rest of the word or -- when the word ends there -- the
-	 * next word unless that one looks like an option; a required argument that is missing and an unknown letter are errors */
-	auto isarg = [](const char *w) { return w[0] != '-' || w[1] == 0; };
-	for(int i = 1; i < argc; i++) {
-		const char *q = argv[i];
-		if(isarg(q)) { if(nf < max_files) files[nf++] = q; continue; }
-		while(*++q && strchr("XAPQh", *q)) { if(opt_one(o, *q, "")) return 1; }
-		if(*q == 0) continue;
-		const bool req = strchr("xRTOdtkwfBLWGabepqrYsm12", *q) != NULL, optl = strchr("cvC", *q) != NULL;
-		if(!req && !optl) { fprintf(stderr, "[E::mm_opt_parse] unknown option `-%c'.\n", *q); return 1; }
-		const char *r = q[1] ? q + 1 : ((i + 1 < argc && isarg(argv[i + 1])) ? argv[++i] : NULL);
-		if(req && !r) { fprintf(stderr, "[E::mm_opt_parse] missing argument for option `-%c'.\n", *q); return 1; }
-		if(opt_one(o, *q, r ? r : "")) return 1;
-	}
-	if(n_files) *n_files = nf;
-	if(opt_check(o)) return 1;
-	if(o->w >= 32) o->w = (uint32_t)(int)(2.0 / 3.0 * o->k + .499);       /* minialign.c:6111 */
-	return 0;
-}
-
-/* =============================================================================================
- * index (host): mm_idx_gen, minialign.c:2951-3040
- * ============================================================================================= */
-/* ---- the text of an input file in host memory (a mapping of the file, or what stdin / gzip gave) and its records as the device reader finds them ---- */
-struct TextSrc {
-	const char *p = nullptr; uint64_t n = 0; char delim = 0; uint64_t first = 0;      /* delim / first: the record delimiter and where the first record starts (minialign.c:1784-1792) */
-	void *map = nullptr; uint64_t map_len = 0; std::vector<char> own;
-	~TextSrc() { if(map) munmap(map, map_len); }
-};
-struct RRec { uint64_t start, hdr_end, t_off; uint32_t t_len, n_bases; uint64_t q_off; uint32_t q_len; };      /* absolute offsets in the text: delimiter, end of the header line, sequence extent, quality extent */
-struct DevChunk { uint8_t *d = nullptr; uint64_t cap = 0; uint64_t off = 0; uint32_t n = 0; };                  /* a stretch of the text in HBM: text[off, off + n) */
-struct ChunkPool {          /* device buffers for stretches of text, reused while a context lives (a hipFree in mid-run would stall every stream of the device) */
-	std::mutex mu; std::vector<DevChunk *> idle, all;
-	DevChunk *get(uint64_t bytes)
-	{
-		{ std::lock_guard<std::mutex> lk(mu); for(size_t i = 0; i < idle.size(); i++) { if(idle[i]->cap >= bytes) { DevChunk *c = idle[i]; idle.erase(idle.begin() + i); return c; } } }
-		DevChunk *c = new DevChunk(); if(hipMalloc(&c->d, bytes) != hipSuccess) { delete c; return nullptr; } c->cap = bytes;
-		std::lock_guard<std::mutex> lk(mu); all.push_back(c); return c;
-	}
-	void put(DevChunk *c) { std::lock_guard<std::mutex> lk(mu); idle.push_back(c); }
-	~ChunkPool() { for(DevChunk *c : all) { (void)hipFree(c->d); delete c; } }
-};
-struct mm_idx_s {
-	uint32_t b, w, k, n_occ; uint32_t occ[8];
-	std::vector<HSeq> seq;
-	/* flattened table, also what the device gets */
-	std::vector<IdxSlot> slot; uint64_t mask;
-	std::vector<uint64_t> val;
-	uint64_t n_keys = 0;
-	/* an index built on the device (idx_gen_device) lives there: the table, the value array (the sorted (pos | rid << 32) of every minimizer; a list is a run inside it)
-	 * and the packed reference; mm_align_init adopts them, the host copy above is fetched only when somebody asks (mm_idx_dump, mm_idx_get) */
-	std::shared_ptr<TextSrc> rtext; std::vector<RRec> rrec;          /* the reference's text and records when the device reader scanned it (the sequences' base codes are then made on demand, ref_codes) */
-	bool on_device = false; int dev = 0; IdxSlot *d_slot = nullptr; uint64_t *d_val = nullptr; uint64_t n_slot = 0, n_val = 0; gaba_arena_t *ref_ar = nullptr;
-	mutable std::mutex fetch_mu;
-	double build_ms[8] = { 0 };          /* device build: arena, sketch, partition, sort, thresholds, table */
-	/* copies of a device-built index on the other devices of the node (one per device, made when a context on that device asks: idx_replica; device to device,
-	 * the host never sees the tables) -- "the minimizer index replicated into each GPU's HBM" of north_star */
-	/* state: 0 being copied (by the thread that made the entry), 1 ready, -1 failed; serving: copies that read from this holder right now */
-	struct Rep { int key, dev; IdxSlot *d_slot; uint64_t *d_val; gaba_arena_t *ref_ar; int state; int serving; };          /* key: the device, or (test hook) 1000 + the context's number */
-	std::vector<std::unique_ptr<Rep>> reps; std::mutex rep_mu; std::condition_variable rep_cv; int serving0 = 0;          /* serving0: copies reading from the originals */
-	~mm_idx_s()
-	{
-		if(d_slot) (void)hipFree(d_slot); if(d_val) (void)hipFree(d_val); if(ref_ar) gaba_arena_free(ref_ar);
-		for(auto &r : reps) { if(r->d_slot) (void)hipFree(r->d_slot); if(r->d_val) (void)hipFree(r->d_val); if(r->ref_ar) gaba_arena_free(r->ref_ar); }
-	}
-};
-/* the tables and the packed reference of a device-built index on device `dev`: the originals on the device that built them, a copy anywhere else (made once per
- * device, by the first context that asks; the others of that device wait for it).  The contexts of a node ask side by side (mm_align_init: one thread per device), so
- * nothing but the bookkeeping is under the index's lock: a copy reads from whichever holder -- the originals or a replica that is complete -- serves the fewest copies
- * right now, at most MM_REPLICA_FANOUT (default 4) per holder: xGMI is point to point, so copies out of one device to different devices run on different links, and
- * once the first replicas are complete they serve the rest.  Eight devices, 20 GB (a human-size index + packed reference): four copies out of the builder side by side,
- * the other three from three of those four -- two link times, 2 x 20 GB / (what one xGMI link sustains) instead of seven in a row behind one lock as in round 4.
- * forced > 0 (MM_TEST_REPLICA, one-GPU boxes; the number of the context that asks): a context takes the copy path whatever device it is on, and gets a replica
- * of its own (device-to-device on one device), so that allocation, hipMemcpyPeer, the choice among several holders, adoption and release of replicas run where there
- * is no second device.  false: out of memory / copy failed */
-static bool idx_replica(const mm_idx_s *cmi, int dev, int forced, IdxSlot **slot, uint64_t **val, gaba_arena_t **ar)
-{
-	mm_idx_s *mi = const_cast<mm_idx_s *>(cmi);
-	if(dev == mi->dev && forced <= 0) { *slot = mi->d_slot; *val = mi->d_val; *ar = mi->ref_ar; return true; }
-	const int key = forced > 0 ? 1000 + forced : dev;
-	const int fanout = getenv("MM_REPLICA_FANOUT") ? std::max(1, atoi(getenv("MM_REPLICA_FANOUT"))) : 4;
-	std::unique_lock<std::mutex> lk(mi->rep_mu);
-	for(;;) {
-		mm_idx_s::Rep *have = nullptr;
-		for(auto &r : mi->reps) if(r->key == key) { have = r.get(); break; }
-		if(!have) break;
-		if(have->state == 0) { mi->rep_cv.wait(lk); continue; }          /* another context of this device is making it */
-		if(have->state < 0) return false;
-		*slot = have->d_slot; *val = have->d_val; *ar = have->ref_ar; return true;
-	}
-	mi->reps.emplace_back(new mm_idx_s::Rep{ key, dev, nullptr, nullptr, nullptr, 0, 0 });
-	mm_idx_s::Rep *r = mi->reps.back().get();
-	/* the source: the holder that serves the fewest copies, once one is below the fan-out */
-	mm_idx_s::Rep *src = nullptr; bool from_orig = false;
-	for(;;) {
-		int best = mi->serving0; from_orig = true; src = nullptr;
-		for(auto &q : mi->reps) if(q->state == 1 && q->serving <= best) { best = q->serving; src = q.get(); from_orig = false; }          /* (a tie goes to a replica: the builder's device has the first contexts' work already) */
-		if(best < fanout) break;
-		mi->rep_cv.wait(lk);
-	}
-	if(from_orig) mi->serving0++; else src->serving++;
-	const int sdev = from_orig ? mi->dev : src->dev;
-	const IdxSlot *s_slot = from_orig ? mi->d_slot : src->d_slot; const uint64_t *s_val = from_orig ? mi->d_val : src->d_val; const gaba_arena_t *s_ar = from_orig ? mi->ref_ar : src->ref_ar;
-	lk.unlock();
-	const double t0 = now_ms();
-	const uint64_t n = mi->ref_ar->n, nw = (n + 15) / 16 + 4, nn = (n + 31) / 32 + 4;
-	gaba_arena_t *q = (gaba_arena_t *)calloc(1, sizeof(gaba_arena_t));
-	bool ok = q != nullptr && hipSetDevice(dev) == hipSuccess && hipMalloc(&r->d_slot, mi->n_slot * sizeof(IdxSlot)) == hipSuccess && hipMalloc(&r->d_val, (mi->n_val + 64) * 8) == hipSuccess
-		&& hipMalloc(&q->pk, nw * 4) == hipSuccess && hipMalloc(&q->nm, nn * 4) == hipSuccess;
-	ok = ok && hipMemcpyPeer(r->d_slot, dev, s_slot, sdev, mi->n_slot * sizeof(IdxSlot)) == hipSuccess && hipMemcpyPeer(r->d_val, dev, s_val, sdev, (mi->n_val + 64) * 8) == hipSuccess
-		&& hipMemcpyPeer(q->pk, dev, s_ar->pk, sdev, nw * 4) == hipSuccess && hipMemcpyPeer(q->nm, dev, s_ar->nm, sdev, nn * 4) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-	if(!ok) { if(r->d_slot) (void)hipFree(r->d_slot); if(r->d_val) (void)hipFree(r->d_val); if(q) { if(q->pk) (void)hipFree(q->pk); if(q->nm) (void)hipFree(q->nm); free(q); } r->d_slot = nullptr; r->d_val = nullptr; q = nullptr; }
-	if(ok) { q->n = n; q->host = NULL; r->ref_ar = q; }
-	if(getenv("MM_VERBOSE")) fprintf(stderr, "[minialign_amd] index replica on device %d from device %d (%s): %.1f MB in %.1f ms%s\n", dev, sdev, from_orig ? "the originals" : "a replica", (mi->n_slot * sizeof(IdxSlot) + (mi->n_val + 64) * 8 + nw * 4 + nn * 4) * 1e-6, now_ms() - t0, ok ? "" : " -- FAILED");
-	lk.lock();
-	if(from_orig) mi->serving0--; else src->serving--;
-	r->state = ok ? 1 : -1;
-	mi->rep_cv.notify_all();
-	if(!ok) return false;
-	*slot = r->d_slot; *val = r->d_val; *ar = r->ref_ar;
-	return true;
-}
-/* host copy of a device-built index (for mm_idx_dump / mm_idx_get) */
-static bool idx_fetch_host(const mm_idx_s *cmi)
-{
-	mm_idx_s *mi = const_cast<mm_idx_s *>(cmi);
-	std::lock_guard<std::mutex> lk(mi->fetch_mu);
-	if(!mi->on_device || !mi->slot.empty()) return true;
-	(void)hipSetDevice(mi->dev);
-	mi->slot.resize(mi->n_slot); mi->val.resize(std::max<uint64_t>(mi->n_val, 1));
-	return hipMemcpy(mi->slot.data(), mi->d_slot, mi->n_slot * sizeof(IdxSlot), hipMemcpyDeviceToHost) == hipSuccess && (mi->n_val == 0 || hipMemcpy(mi->val.data(), mi->d_val, mi->n_val * 8, hipMemcpyDeviceToHost) == hipSuccess);
-}
-
-
-/* device memory of the library's buffers is recycled, not handed back: a hipFree waits for every stream of the device (a lane's pool that grew used to stall all
- * lanes for 100 - 450 ms), and pages the driver has taken back are wiped before they are handed out again -- the 43 GB of DP workspaces allocated right after the
- * index build's 45 GB of temporaries had been freed took 3.7 s to arrive (1.35 s behind 20 GB), against a few milliseconds on untouched memory.  A released block
- * waits here for the next request it fits (at most four times the size asked for), per device; what is held is bounded by what the library once used. */
-#define MM_BATCH_PER_LONGEST 1700ull          /* bases of batch per base of the longest read of the input (batch_spans) */
-struct DevCache {
-	std::mutex mu; std::multimap<std::pair<int, size_t>, void *> blocks;
-	void *take(int dev, size_t want, size_t *got)
-	{
-		std::lock_guard<std::mutex> lk(mu);
-		auto it = blocks.lower_bound(std::make_pair(dev, want));
-		if(it == blocks.end() || it->first.first != dev || it->first.second > 4 * want + (64u << 20)) return nullptr;
-		void *p = it->second; *got = it->first.second; held[dslot(dev)] -= *got; blocks.erase(it); return p;
-	}
-	static const int MAX_DEV = 16;
-	static int dslot(int dev) { return dev >= 0 && dev < MAX_DEV ? dev : MAX_DEV - 1; }
-	size_t held[MAX_DEV] = { 0 };          /* bytes waiting here, per device (read and written under mu) */
-	size_t held_on(int dev) { std::lock_guard<std::mutex> lk(mu); return held[dslot(dev)]; }
-	/* what is held is bounded (32 GB): a block that would take it beyond that goes back to the driver after all, as do blocks of more than 16 GB (the DP workspaces of a size that is
-	 * being replaced: nothing is in flight then) -- an ONT-like run that re-sized its workspace ladder a few times had 150 GB of them waiting here and the runtime ran out of memory */
-	void give(int dev, size_t bytes, void *p)
-	{
-		/* nothing is kept while the device is short of memory (the runtime allocates the kernels' scratch memory on demand and aborts the process when it cannot).
-		 * `tight` is what the last fresh allocation found: hipMemGetInfo costs about 2 ms, and a stream gives a dozen buffers back when it ends -- asked here, it made every
-		 * stream 20 ms longer, 12 % of one over an E.coli-size set */
-		{ std::lock_guard<std::mutex> lk(mu); const int d = dslot(dev); if(!tight[d].load() && bytes <= (16ull << 30) && held[d] + bytes <= (32ull << 30)) { blocks.emplace(std::make_pair(dev, bytes), p); held[d] += bytes; return; } }
-		(void)hipFree(p);
-	}
-	std::atomic<bool> tight[MAX_DEV];          /* per device: one device running short of memory does not stop the others from recycling */
-	DevCache() { for(int i = 0; i < MAX_DEV; i++) tight[i].store(false); }
-	static size_t reserve() { return 24ull << 30; }
-	/* may `bytes` more be taken?  Not when less than 8 GB would be left after giving back what is held here: the runtime allocates the scratch memory of a kernel when it is first
-	 * launched on a queue (1.7 GB for the extension kernel) and aborts the process when it cannot -- an allocation that fails cleanly is the better end */
-	bool room(int dev, size_t bytes)
-	{
-		size_t fr = 0, tot = 0; if(hipMemGetInfo(&fr, &tot) != hipSuccess) return true;
-		if(fr >= bytes + (8ull << 30)) return true;
-		flush(dev); if(hipMemGetInfo(&fr, &tot) != hipSuccess) return true;
-		return fr >= bytes + (8ull << 30);
-	}
-	/* after a fresh allocation: what is held goes back to the driver when less than the reserve is left */
-	void relieve(int dev) { size_t fr = 0, tot = 0; const bool t = hipMemGetInfo(&fr, &tot) != hipSuccess || fr < reserve(); tight[dslot(dev)].store(t); if(t && held_on(dev)) flush(dev); }
-	void flush(int dev) { std::lock_guard<std::mutex> lk(mu); for(auto it = blocks.begin(); it != blocks.end();) { if(it->first.first == dev) { (void)hipFree(it->second); held[dslot(dev)] -= it->first.second; it = blocks.erase(it); } else ++it; } }          /* out of memory: everything held goes back to the driver */
-};
-static DevCache &dev_cache() { static DevCache *c = new DevCache(); return *c; }          /* (never destroyed: blocks may come back while the process winds down) */
-template<typename T> struct DBuf {
-	T *p = nullptr; uint64_t n = 0; size_t bytes = 0; int dev = 0;
-	DBuf() {}
-	DBuf(const DBuf &) = delete; DBuf &operator=(const DBuf &) = delete;
-	~DBuf() { release(); }          /* temporaries (index build, reference reader) go back to the cache on every way out of their function */
-	bool ensure(uint64_t want)
-	{
-		if(want <= n) return true;
-		release();
-		(void)hipGetDevice(&dev);
-		size_t got = 0; void *q = dev_cache().take(dev, want * sizeof(T), &got);
-		const bool fresh = q == nullptr;
-		if(!q && !dev_cache().room(dev, want * sizeof(T))) { fprintf(stderr, "[minialign_amd] %.1f MB more would leave the device without the memory its runtime needs (kernel scratch): fewer lanes (MM_LANES) or smaller batches (MM_BATCH_BASES) fit\n", want * sizeof(T) / 1048576.0); return false; }
-		if(!q) { got = want * sizeof(T); if(hipMalloc(&q, got) != hipSuccess) { q = nullptr; dev_cache().flush(dev); if(hipMalloc(&q, got) != hipSuccess) { fprintf(stderr, "[minialign_amd] hipMalloc of %.1f MB failed\n", got / 1e6); return false; } } }
-		p = (T *)q; bytes = got; n = got / sizeof(T); if(fresh) dev_cache().relieve(dev); return true;
-	}
-	void release() { if(p) dev_cache().give(dev, bytes, p); p = nullptr; n = 0; bytes = 0; }
-};
-
-/* base codes (0..3, 4 = N) of reference sequence i.  A reference the device reader scanned keeps its bases in the text; the few consumers on the host (MD:Z, MAF rows,
- * index files, the wrap-around sketch of a circular sequence) have them made here, once */
-static const std::vector<uint8_t> &ref_codes(const mm_idx_s *cmi, uint32_t i)
-{
-	mm_idx_s *mi = const_cast<mm_idx_s *>(cmi); HSeq &q = mi->seq[i];
-	if(!mi->rtext || q.len == 0) return q.seq;
-	std::lock_guard<std::mutex> lk(mi->fetch_mu);
-	if(q.seq.empty()) {
-		static const uint8_t enc[16] = { 0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 4, 0 };
-		const RRec &r = mi->rrec[i]; std::vector<uint8_t> c(r.n_bases);
-		const char *p = mi->rtext->p + r.t_off, *e = p + r.t_len; uint32_t k = 0;
-		for(; p < e && k < r.n_bases; p++) { if(*p != '\n') c[k++] = enc[*p & 15]; }
-		q.seq.swap(c);
-	}
-	return q.seq;
-}
-static bool ref_to_device(const mm_opt_s *o, mm_idx_s *mi, const char *fn, std::vector<uint64_t> &off, std::vector<uint32_t> &len);
-/* the packed reference in HBM: one arena, every sequence on a multiple of 64 bases */
-static gaba_arena_t *upload_reference(const mm_idx_s *mi, std::vector<uint64_t> *off_out, std::vector<uint32_t> *len_out)
-{
-	uint64_t total = 0; std::vector<uint64_t> off; std::vector<uint32_t> len;
-	for(const HSeq &s : mi->seq) { off.push_back(total); len.push_back(s.blen()); total += ((uint64_t)s.blen() + 63) & ~63ull; }
-	std::vector<uint8_t> all(total + 64, 4);
-	host_parallel((uint32_t)mi->seq.size(), [&](uint32_t t, uint32_t nth) { for(size_t i = t; i < mi->seq.size(); i += nth) { const std::vector<uint8_t> &c = ref_codes(mi, (uint32_t)i); memcpy(all.data() + off[i], c.data(), c.size()); } }, 32);
-	gaba_arena_t *ar = gaba_arena_upload(all.data(), total + 64);
-	if(ar) gaba_arena_unregister(ar);                 /* `all` is a temporary: keep it out of the per-call API's section lookup */
-	if(off_out) off_out->swap(off);
-	if(len_out) len_out->swap(len);
-	return ar;
-}
-/* mm_idx_gen on the device (mm_index.hpp): sketch of the reference, stable partition into the 2^b buckets in reference order, the unstable per-bucket sort replayed,
- * occurrence thresholds from the histogram of key counts, table fill.  The sequences are parsed by the host (mi->seq); circular ones (-c) are sketched there too
- * (their wrap-around pass is a serial special case, mm_sketch_cap :2437) and take their place in reference order.  false: no device / out of memory / a bucket beyond
- * what the sort's entries address -- the caller reports it (no silent host build). */
-static bool idx_gen_device(const mm_opt_s *o, mm_idx_s *mi, const char *ref_fasta, bool verbose)
-{
-	double tv = now_ms(); int lapi = 0;
-	int ndev = 0; if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "[minialign_amd] mm_idx_gen: no HIP device (MM_HOST_INDEX=1 builds the index on the host)\n"); return false; }
-	(void)hipGetDevice(&mi->dev); (void)hipFree(0);
-	if(verbose) { fprintf(stderr, "[minialign_amd] index (device): HIP runtime up after %.1f ms\n", now_ms() - tv); } tv = now_ms();
-	auto lap = [&](const char *what) { (void)hipDeviceSynchronize(); const double t = now_ms(); if(lapi < 8) mi->build_ms[lapi++] = t - tv; if(verbose) fprintf(stderr, "[minialign_amd] index (device): %s %.1f ms\n", what, t - tv); tv = t; };
-#define IK(_e) do { hipError_t _r = (_e); if(_r != hipSuccess) { fprintf(stderr, "[minialign_amd] index (device): HIP error %s at line %d\n", hipGetErrorString(_r), __LINE__); return false; } } while(0)
-	std::vector<uint64_t> off; std::vector<uint32_t> len;
-	/* the reference goes the way the reads go: its text to HBM, records found (K0r) and bases packed (K0) there, straight into the arena */
-	if(!ref_to_device(o, mi, ref_fasta, off, len) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); return false; }
-	if(o->circ_set) for(HSeq &q : mi->seq) q.circular = o->circ_names.empty() || std::find(o->circ_names.begin(), o->circ_names.end(), q.name) != o->circ_names.end();
-	lap("reference: text to HBM, records, packed arena");
-	const uint32_t bbits = mi->b, nb = 1u << bbits, k = mi->k, w = mi->w;
-	/* stretches: 2^18 positions each; a circular sequence is one stretch, sketched on the host */
-	std::vector<RefStretch> st; std::vector<std::vector<HMin>> hostmin;
-	const uint32_t chunk = 1u << 18;
-	for(uint32_t i = 0; i < mi->seq.size(); i++) {
-		const uint32_t L = len[i];
-		if(mi->seq[i].circular) { st.push_back(RefStretch{ off[i], L, 0, L, i, 0, 1, (uint32_t)hostmin.size() }); hostmin.emplace_back(); continue; }
-		for(uint32_t bg = 0; bg < L; bg += chunk) st.push_back(RefStretch{ off[i], L, bg, std::min(L, bg + chunk), i, 0, 0, 0 });
-	}
-	if(!hostmin.empty()) {
-		std::vector<uint32_t> which; for(uint32_t t = 0; t < st.size(); t++) if(st[t].host) which.push_back(t);
-		host_parallel((uint32_t)which.size(), [&](uint32_t t, uint32_t nth) { for(size_t j = t; j < which.size(); j += nth) { const RefStretch &q = st[which[j]]; const std::vector<uint8_t> &sq = ref_codes(mi, q.seq); sketch_host_circular(sq.data(), (uint32_t)sq.size(), k, w, hostmin[q.pad]); } }, 32);
-	}
-	const uint32_t n_st = (uint32_t)st.size();
-	DBuf<RefStretch> d_st; DBuf<uint32_t> d_cnt, d_ctr; DBuf<IdxMini> d_min, d_flat;
-	if(!d_st.ensure(std::max<uint32_t>(n_st, 1)) || !d_cnt.ensure(std::max<uint32_t>(n_st, 1)) || !d_ctr.ensure(16)) return false;
-	IK(hipMemcpy(d_st.p, st.data(), (size_t)n_st * sizeof(RefStretch), hipMemcpyHostToDevice)); IK(hipMemset(d_ctr.p, 0, 64)); IK(hipMemset(d_cnt.p, 0, (size_t)std::max<uint32_t>(n_st, 1) * 4));
-	hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, mi->dev);
-	const uint32_t waves = (uint32_t)prop.multiProcessorCount * 32u;
-	I1Args i1; i1.ar = gaba::SeqArena{ mi->ref_ar->pk, mi->ref_ar->nm }; i1.st = d_st.p; i1.n = n_st; i1.k = k; i1.w = w; i1.out = nullptr; i1.count = d_cnt.p; i1.emit = 0; i1.counter = d_ctr.p;
-	if(n_st) { hipLaunchKernelGGL(mm_ref_sketch_kernel, dim3(std::min<uint32_t>((n_st + 3) / 4, waves / 4)), dim3(256), 0, 0, i1); IK(hipGetLastError()); }
-	std::vector<uint32_t> cnt(n_st);
-	if(n_st) IK(hipMemcpy(cnt.data(), d_cnt.p, (size_t)n_st * 4, hipMemcpyDeviceToHost));
-	uint64_t N = 0;
-	for(uint32_t t = 0; t < n_st; t++) { if(st[t].host) cnt[t] = (uint32_t)hostmin[st[t].pad].size(); st[t].out = N; N += cnt[t]; }
-	if(!d_min.ensure(N + 64) || !d_flat.ensure(N + 64)) return false;
-	if(n_st) {
-		IK(hipMemcpy(d_st.p, st.data(), (size_t)n_st * sizeof(RefStretch), hipMemcpyHostToDevice)); IK(hipMemset(d_ctr.p, 0, 64));
-		i1.out = d_min.p; i1.emit = 1;
-		hipLaunchKernelGGL(mm_ref_sketch_kernel, dim3(std::min<uint32_t>((n_st + 3) / 4, waves / 4)), dim3(256), 0, 0, i1); IK(hipGetLastError());
-		for(uint32_t t = 0; t < n_st; t++) {
-			if(!st[t].host || cnt[t] == 0) continue;
-			std::vector<IdxMini> tmp(cnt[t]); const std::vector<HMin> &hm = hostmin[st[t].pad];
-			for(uint32_t j = 0; j < cnt[t]; j++) tmp[j] = IdxMini{ hm[j].hash, hm[j].pos, (st[t].seq << 1) + hm[j].strand };
-			IK(hipMemcpy(d_min.p + st[t].out, tmp.data(), (size_t)cnt[t] * sizeof(IdxMini), hipMemcpyHostToDevice));
-		}
-	}
-	lap("sketch");
-	/* stable partition into buckets */
-	const uint32_t tile = 1u << 16, n_tiles = (uint32_t)((N + tile - 1) / tile);
-	DBuf<uint32_t> d_hist; DBuf<uint64_t> d_bofs;
-	if(!d_hist.ensure((uint64_t)std::max<uint32_t>(n_tiles, 1) * nb) || !d_bofs.ensure(nb + 2)) return false;
-	I2Args i2; i2.in = d_min.p; i2.n = N; i2.tile = tile; i2.n_tiles = n_tiles; i2.bbits = bbits; i2.hist = d_hist.p; i2.bofs = d_bofs.p; i2.out = d_flat.p;
-	std::vector<uint64_t> bofs(nb + 1, 0);
-	if(n_tiles) { hipLaunchKernelGGL(mm_idx_hist_kernel, dim3(n_tiles), dim3(64), 0, 0, i2); IK(hipGetLastError()); }
-	hipLaunchKernelGGL(mm_idx_colscan_kernel, dim3((nb + 255) / 256), dim3(256), 0, 0, i2); IK(hipGetLastError());
-	IK(hipMemcpy(bofs.data(), d_bofs.p, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost));
-	bofs[0] = 0; for(uint32_t bi = 0; bi < nb; bi++) bofs[bi + 1] += bofs[bi];
-	IK(hipMemcpy(d_bofs.p, bofs.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice));
-	if(n_tiles) { hipLaunchKernelGGL(mm_idx_scatter_kernel, dim3(n_tiles), dim3(64), 0, 0, i2); IK(hipGetLastError()); }
-	lap("bucket partition");
-	d_hist.release(); d_min.release();
-	/* per-bucket sort, records moved into (hrem, val) */
-	DBuf<uint32_t> d_ent, d_err; DBuf<uint64_t> d_hrem;
-	uint64_t *d_val = nullptr;
-	if(!d_ent.ensure(N + 64) || !d_hrem.ensure(N + 64) || !d_err.ensure(4) || hipMalloc(&d_val, (N + 64) * 8) != hipSuccess) return false;
-	mi->d_val = d_val; mi->n_val = N;
-	IK(hipMemset(d_ctr.p, 0, 64)); IK(hipMemset(d_err.p, 0, 16));
-	I3Args i3; i3.in = d_flat.p; i3.bofs = d_bofs.p; i3.n_buckets = nb; i3.key_bits = 64; i3.ent = d_ent.p; i3.hrem = d_hrem.p; i3.val = d_val; i3.counter = d_ctr.p; i3.err = d_err.p;
-	hipLaunchKernelGGL(mm_idx_sort_kernel, dim3(std::min<uint32_t>(nb, waves)), dim3(64), 0, 0, i3); IK(hipGetLastError());
-	uint32_t serr = 0; IK(hipMemcpy(&serr, d_err.p, 4, hipMemcpyDeviceToHost));
-	if(serr) { fprintf(stderr, "[minialign_amd] index (device): a bucket beyond what the sort addresses (flags %u)\n", serr); return false; }
-	lap("bucket sort");
-	d_flat.release(); d_ent.release();
-	/* key counts -> thresholds (minialign.c:2981-2986) */
-	DBuf<uint32_t> d_run, d_big; DBuf<unsigned long long> d_h; DBuf<uint64_t> d_cut;
-	const uint32_t big_cap = 1u << 20;
-	if(!d_run.ensure(N + 64) || !d_big.ensure(big_cap + 4) || !d_h.ensure(IDX_HB + 4) || !d_cut.ensure(nb + 1)) return false;
-	IK(hipMemset(d_h.p, 0, (size_t)(IDX_HB + 4) * 8)); IK(hipMemset(d_big.p + big_cap, 0, 16));
-	I4Args i4; memset(&i4, 0, sizeof(i4));
-	i4.hrem = d_hrem.p; i4.val = d_val; i4.n = N; i4.bofs = d_bofs.p; i4.n_buckets = nb; i4.bbits = bbits; i4.runlen = d_run.p; i4.hist = d_h.p; i4.big = d_big.p; i4.big_cap = big_cap; i4.n_big = d_big.p + big_cap;
-	i4.cut = d_cut.p; i4.n_keys = d_h.p + IDX_HB + 2;
-	const uint32_t grid_n = (uint32_t)((N + 255) / 256);
-	if(N) { hipLaunchKernelGGL(mm_idx_runs_kernel, dim3(grid_n), dim3(256), 0, 0, i4); IK(hipGetLastError()); }
-	std::vector<unsigned long long> ch(IDX_HB + 1); uint32_t n_big = 0;
-	IK(hipMemcpy(ch.data(), d_h.p, (size_t)(IDX_HB + 1) * 8, hipMemcpyDeviceToHost)); IK(hipMemcpy(&n_big, d_big.p + big_cap, 4, hipMemcpyDeviceToHost));
-	if(n_big > big_cap) { fprintf(stderr, "[minialign_amd] index (device): more than %u keys with %u occurrences and more\n", big_cap, IDX_HB); return false; }
-	std::vector<uint32_t> big(n_big); if(n_big) IK(hipMemcpy(big.data(), d_big.p, (size_t)n_big * 4, hipMemcpyDeviceToHost));
-	uint64_t n_cnt = 0; for(uint32_t c = 0; c <= IDX_HB; c++) n_cnt += ch[c];
-	for(uint32_t i = 0; i < o->n_frq; i++) {
-		if(o->frq[i] <= 0.0) { mi->occ[i] = UINT32_MAX; continue; }
-		if(n_cnt == 0) { mi->occ[i] = 1; continue; }
-		const uint32_t kk = (uint32_t)((1.0 - o->frq[i]) * n_cnt);
-		const uint64_t kth = std::min<uint64_t>(kk, n_cnt - 1);
-		uint64_t acc = 0; uint32_t v = 0; bool found = false;
-		for(uint32_t c = 0; c < IDX_HB; c++) { acc += ch[c]; if(acc > kth) { v = c; found = true; break; } }
-		if(!found) { auto it = big.begin() + (kth - acc); std::nth_element(big.begin(), it, big.end()); v = *it; }
-		mi->occ[i] = v + 1;
-	}
-	lap("key counts + thresholds");
-	/* cut (the reference's fill cursor stops at the first over-frequent key of a bucket), number of keys, table */
-	i4.max_cnt = mi->occ[mi->n_occ - 1];
-	IK(hipMemcpy(d_cut.p, bofs.data() + 1, (size_t)nb * 8, hipMemcpyHostToDevice));          /* cut[b] = end of the bucket unless a key exceeds the threshold */
-	if(N) { hipLaunchKernelGGL(mm_idx_cut_kernel, dim3(grid_n), dim3(256), 0, 0, i4); IK(hipGetLastError()); }
-	i4.slot = nullptr;
-	if(N) { hipLaunchKernelGGL(mm_idx_fill_kernel, dim3(grid_n), dim3(256), 0, 0, i4); IK(hipGetLastError()); }
-	unsigned long long n_keys = 0; IK(hipMemcpy(&n_keys, i4.n_keys, 8, hipMemcpyDeviceToHost));
-	uint64_t tsize = 1024; while(tsize < n_keys * 2) tsize <<= 1;
-	if(hipMalloc(&mi->d_slot, tsize * sizeof(IdxSlot)) != hipSuccess) return false;
-	IK(hipMemset(mi->d_slot, 0, tsize * sizeof(IdxSlot)));
-	mi->n_slot = tsize; mi->mask = tsize - 1; mi->n_keys = n_keys;
-	i4.slot = mi->d_slot; i4.mask = mi->mask;
-	if(N) { hipLaunchKernelGGL(mm_idx_fill_kernel, dim3(grid_n), dim3(256), 0, 0, i4); IK(hipGetLastError()); }
-	lap("table");
-#undef IK
-	mi->on_device = true;
-	return true;
-}
-
-extern "C" mm_idx_t *mm_idx_gen(mm_opt_t const *o, char const *ref_fasta)
-{
-	mm_idx_t *mi = new mm_idx_s();
-	const bool verbose = getenv("MM_VERBOSE") != NULL; double tv = now_ms();
-	auto lap = [&](const char *what) { if(verbose) { double t = now_ms(); fprintf(stderr, "[minialign_amd] index: %s %.1f ms\n", what, t - tv); tv = t; } };
-	uint32_t b = std::min(o->k * 2, o->b);
-	mi->b = b; mi->w = o->w; mi->k = o->k; mi->n_occ = o->n_frq;
-	if(!getenv("MM_HOST_INDEX")) {
-		/* the build runs on the device (mm_index.hpp), reference parsing included; MM_HOST_INDEX=1 keeps all of it on the host threads below (machines without a GPU
-		 * that only write index files; comparison) */
-		if(!idx_gen_device(o, mi, ref_fasta, verbose)) { fprintf(stderr, "[minialign_amd] mm_idx_gen: the device build failed\n"); delete mi; return NULL; }
-		return mi;
-	}
-	if(!read_seq_file(ref_fasta, mi->seq, o->min_len) || mi->seq.empty()) { fprintf(stderr, "[minialign_amd] cannot read reference `%s'\n", ref_fasta); delete mi; return NULL; }
-	lap("read + parse");
-	if(o->circ_set) for(HSeq &q : mi->seq) q.circular = o->circ_names.empty() || std::find(o->circ_names.begin(), o->circ_names.end(), q.name) != o->circ_names.end();
-	const uint64_t nb = 1ull << b, bmask = nb - 1;
-	/* sketch every sequence and put (hrem, pos, rid) into its bucket in reference order (minialign.c:2790-2860): stretches of the sequences are
-	 * sketched on host threads, a histogram per stretch turns into write positions (stretch order inside a bucket = reference order), and the
-	 * stretches scatter their minimizers in parallel into one flat array */
-	std::vector<Mini> flat; std::vector<uint64_t> bofs(nb + 1, 0);
-	{
-		struct Task { uint32_t seq, begin, end; std::vector<HMin> mins; };
-		uint64_t total_bases = 0; for(const HSeq &q : mi->seq) total_bases += q.seq.size();
-		std::vector<Task> task; const uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 18, total_bases / 2048), 1u << 24);
-		for(uint32_t i = 0; i < mi->seq.size(); i++) { const uint32_t L = (uint32_t)mi->seq[i].seq.size(); if(mi->seq[i].circular) { task.push_back(Task{ i, 0, L, {} }); continue; } for(uint32_t bgn = 0; bgn < L || bgn == 0; bgn += chunk) { task.push_back(Task{ i, bgn, std::min(L, bgn + chunk), {} }); if(L == 0) break; } }
-		std::vector<uint32_t> hist((size_t)task.size() * nb, 0);
-		host_parallel((uint32_t)task.size(), [&](uint32_t t, uint32_t nth) {
-			for(size_t j = t; j < task.size(); j += nth) {
-				Task &q = task[j]; const HSeq &sq = mi->seq[q.seq];
-				if(sq.circular) sketch_host_circular(sq.seq.data(), (uint32_t)sq.seq.size(), o->k, o->w, q.mins);
-				else sketch_host(sq.seq.data(), (uint32_t)sq.seq.size(), o->k, o->w, q.mins, q.begin, q.end);
-				uint32_t *h = &hist[j * nb]; for(const HMin &m : q.mins) h[m.hash & bmask]++;
-			}
-		}, 64);
-		lap("sketch");
-		/* hist[j][bi] -> first write position of stretch j in bucket bi (row by row: the rows are contiguous) */
-		/* (columns of the stretch x bucket histogram, a range of buckets per thread) */
-		host_parallel(64, [&](uint32_t t, uint32_t nth) { for(uint64_t bi = nb * t / nth, be_ = nb * (t + 1) / nth; bi < be_; bi++) { uint64_t acc = 0; for(size_t j = 0; j < task.size(); j++) acc += hist[j * nb + bi]; bofs[bi + 1] = acc; } }, 64);
-		for(uint64_t bi = 0; bi < nb; bi++) bofs[bi + 1] += bofs[bi];
-		flat.resize(bofs[nb]);
-		std::vector<uint64_t> wpos((size_t)task.size() * nb);
-		host_parallel(64, [&](uint32_t t, uint32_t nth) { for(uint64_t bi = nb * t / nth, be_ = nb * (t + 1) / nth; bi < be_; bi++) { uint64_t run = bofs[bi]; for(size_t j = 0; j < task.size(); j++) { wpos[j * nb + bi] = run; run += hist[j * nb + bi]; } } }, 64);
-		lap("bucket offsets");
-		host_parallel((uint32_t)task.size(), [&](uint32_t t, uint32_t nth) {
-			for(size_t j = t; j < task.size(); j += nth) {
-				Task &q = task[j]; uint64_t *w = &wpos[j * nb];
-				for(const HMin &m : q.mins) flat[w[m.hash & bmask]++] = Mini{ m.hash >> b, m.pos, (q.seq << 1) + m.strand };
-				std::vector<HMin>().swap(q.mins);
-			}
-		}, 64);
-	}
-	lap("bucket scatter");
-	/* per-bucket sort on hrem + occurrence histogram (minialign.c:2867-2900); buckets are independent */
-	std::vector<uint32_t> cnt;
-	{
-		std::vector<std::vector<uint32_t>> pc(64);
-		host_parallel(64, [&](uint32_t t, uint32_t nth) {
-			std::vector<uint32_t> &c = pc[t];
-			for(uint64_t bi = t; bi < nb; bi += nth) {
-				Mini *v = flat.data() + bofs[bi]; const size_t vn = bofs[bi + 1] - bofs[bi];
-				if(vn == 0) continue;
-				sort_minis(v, vn);
-				uint32_t n = 1;
-				for(size_t j = 1; j < vn; j++) { if(v[j - 1].hrem != v[j].hrem) { c.push_back(n); n = 0; } n++; }
-				c.push_back(n);
-			}
-		}, 64);
-		for(auto &c : pc) cnt.insert(cnt.end(), c.begin(), c.end());
-	}
-	lap("bucket sort");
-	/* thresholds: (1 - frq)-quantile of the per-key counts, + 1 (minialign.c:2981-2986) */
-	{
-		/* the k-th smallest count from a histogram of the counts (nearly all are small; the few above the table fall back to selection among themselves) */
-		const uint32_t HB = 1u << 16; std::vector<uint64_t> ch(HB + 1, 0); std::vector<uint32_t> big;
-		{
-			std::vector<std::vector<uint64_t>> ph(32, std::vector<uint64_t>(HB + 1, 0)); std::vector<std::vector<uint32_t>> pb(32);
-			host_parallel(32, [&](uint32_t t, uint32_t nth) { for(size_t i = cnt.size() * t / nth, e = cnt.size() * (t + 1) / nth; i < e; i++) { const uint32_t c = cnt[i]; if(c < HB) ph[t][c]++; else { ph[t][HB]++; pb[t].push_back(c); } } }, 32);
-			for(auto &h : ph) for(uint32_t c = 0; c <= HB; c++) ch[c] += h[c];
-			for(auto &b2 : pb) big.insert(big.end(), b2.begin(), b2.end());
-		}
-		for(uint32_t i = 0; i < o->n_frq; i++) {
-			if(o->frq[i] <= 0.0) { mi->occ[i] = UINT32_MAX; continue; }
-			uint32_t kk = (uint32_t)((1.0 - o->frq[i]) * cnt.size());
-			if(cnt.empty()) { mi->occ[i] = 1; continue; }
-			const size_t kth = std::min<size_t>(kk, cnt.size() - 1);
-			uint64_t acc = 0; uint32_t v = 0; bool found = false;
-			for(uint32_t c = 0; c < HB; c++) { acc += ch[c]; if(acc > kth) { v = c; found = true; break; } }
-			if(!found) { auto it = big.begin() + (kth - acc); std::nth_element(big.begin(), it, big.end()); v = *it; }
-			mi->occ[i] = v + 1;
-		}
-	}
-	/* key -> value-list map (minialign.c:2905-2944).  The reference stops advancing its fill cursor at the first key of a
-	 * bucket that exceeds the last threshold, which silently drops every later key of that bucket: kept.  Buckets are independent: keys and list
-	 * lengths are counted per bucket, a prefix sum gives every bucket its stretch of the value array, and the table is filled by threads that each
-	 * own a range of home slots (a key whose probe sequence would leave its owner's range waits for a serial pass), so the layout does not depend
-	 * on the number of threads or their timing. */
-	const uint64_t max_cnt = mi->occ[mi->n_occ - 1];
-	std::vector<uint64_t> bkeys(nb + 1, 0), bvals(nb + 1, 0);
-	host_parallel(64, [&](uint32_t t, uint32_t nth) {
-		for(uint64_t bi = t; bi < nb; bi += nth) {
-			const Mini *v = flat.data() + bofs[bi]; const size_t vn = bofs[bi + 1] - bofs[bi]; uint64_t nk = 0, nv = 0;
-			for(size_t j = 0; j < vn;) { size_t e = j + 1; while(e < vn && v[e].hrem == v[j].hrem) e++; if(e - j > max_cnt) break; nk++; if(e - j > 1) nv += e - j; j = e; }
-			bkeys[bi + 1] = nk; bvals[bi + 1] = nv;
-		}
-	}, 64);
-	for(uint64_t bi = 0; bi < nb; bi++) { bkeys[bi + 1] += bkeys[bi]; bvals[bi + 1] += bvals[bi]; }
-	const uint64_t n_keys = bkeys[nb], n_multi_vals = bvals[nb];
-	uint64_t tsize = 1024; while(tsize < n_keys * 2) tsize <<= 1;
-	mi->slot.assign(tsize, IdxSlot{ 0, 0 }); mi->mask = tsize - 1; mi->val.assign(std::max<uint64_t>(n_multi_vals, 1), 0); mi->n_keys = n_keys;
-	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
-	/* (key, value) records in bucket order, value lists written in place */
-	std::vector<IdxSlot> kv(n_keys);
-	host_parallel(64, [&](uint32_t t, uint32_t nth) {
-		for(uint64_t bi = t; bi < nb; bi += nth) {
-			const Mini *v = flat.data() + bofs[bi]; const size_t vn = bofs[bi + 1] - bofs[bi]; uint64_t ko = bkeys[bi], vo = bvals[bi];
-			for(size_t j = 0; j < vn;) {
-				size_t e = j + 1; while(e < vn && v[e].hrem == v[j].hrem) e++;
-				if(e - j > max_cnt) break;
-				uint64_t minier = (v[j].hrem << b) | bi, value;
-				if(e - j == 1) value = (uint64_t)v[j].pos | ((uint64_t)v[j].rid << 32);
-				else { value = (1ull << 63) | (vo << 24) | (uint64_t)(e - j); for(size_t x = j; x < e; x++) mi->val[vo++] = (uint64_t)v[x].pos | ((uint64_t)v[x].rid << 32); }
-				kv[ko++] = IdxSlot{ minier + 1, value };
-				j = e;
-			}
-		}
-	}, 64);
-	std::vector<Mini>().swap(flat);
-	{
-		const uint32_t parts = 64; const uint64_t span = tsize / parts;            /* tsize >= 1024: a power of two, divisible */
-		std::vector<std::vector<uint64_t>> late(parts);
-		/* home slot of every key once (parallel over the keys); the owner of a slot range then walks the one-byte owner column */
-		std::vector<uint64_t> home(n_keys); std::vector<uint8_t> owner(n_keys);
-		host_parallel(64, [&](uint32_t t, uint32_t nth) { for(uint64_t i = (uint64_t)n_keys * t / nth, e = (uint64_t)n_keys * (t + 1) / nth; i < e; i++) { home[i] = hash(kv[i].key - 1) & mi->mask; owner[i] = (uint8_t)(home[i] / span); } }, 64);
-		host_parallel(parts, [&](uint32_t t, uint32_t nth) {
-			for(uint32_t pt = t; pt < parts; pt += nth) {
-				const uint64_t hi = ((uint64_t)pt + 1) * span;
-				for(uint64_t i = 0; i < n_keys; i++) {
-					if(owner[i] != pt) continue;
-					uint64_t sl = home[i]; while(sl < hi && mi->slot[sl].key != 0) sl++;
-					if(sl < hi) mi->slot[sl] = kv[i]; else late[pt].push_back(i);
-				}
-			}
-		}, 64);
-		for(auto &l : late) for(uint64_t i : l) { uint64_t sl = hash(kv[i].key - 1) & mi->mask; while(mi->slot[sl].key != 0) sl = (sl + 1) & mi->mask; mi->slot[sl] = kv[i]; }
-	}
-	if(mi->val.empty()) mi->val.push_back(0);
-	lap("thresholds + table");
-	return mi;
-}
-extern "C" void mm_idx_destroy(mm_idx_t *mi) { delete mi; }
-
-/* index files (-d idx.mai, then `minialign idx.mai reads.fa`; mm_idx_dump / mm_idx_load, minialign.c:3070-3167).  The reference's file is a
- * memory image of its own tables with pointers turned into offsets, declared unstable across its releases (README.md:198); this one holds the
- * flattened table the device uses: magic, the parameters, the sequences (name + one byte per base), the slots and the value array.  A file
- * may hold several such blocks back to back (one per reference file given to -d), as the reference's does. */
-namespace {
-const uint32_t MAI_MAGIC = 0x0341414du;        /* "MAA\x03" */
-struct MaiHead { uint32_t b, w, k, n_occ, occ[8]; uint64_t n_seq, n_slot, n_val, n_keys; };
-}
-extern "C" int mm_idx_dump(mm_idx_t const *mi, FILE *fp)
-{
-	if(!idx_fetch_host(mi)) return 1;
-	bool ok = true;
-	auto put = [&](const void *p, size_t n) { ok = ok && (n == 0 || fwrite(p, 1, n, fp) == n); };
-	MaiHead h; memset(&h, 0, sizeof(h));
-	h.b = mi->b; h.w = mi->w; h.k = mi->k; h.n_occ = mi->n_occ; memcpy(h.occ, mi->occ, sizeof(h.occ)); h.n_seq = mi->seq.size(); h.n_slot = mi->slot.size(); h.n_val = mi->val.size(); h.n_keys = mi->n_keys;
-	put(&MAI_MAGIC, 4); put(&h, sizeof(h));
-	for(uint32_t i = 0; i < mi->seq.size(); i++) {
-		const HSeq &q = mi->seq[i]; const std::vector<uint8_t> &codes = ref_codes(mi, i);
-		uint64_t l[3] = { q.name.size(), codes.size(), q.circular ? 1u : 0u };
-		put(l, sizeof(l)); put(q.name.data(), l[0]); put(codes.data(), l[1]);
-	}
-	put(mi->slot.data(), mi->slot.size() * sizeof(IdxSlot)); put(mi->val.data(), mi->val.size() * sizeof(uint64_t));
-	return ok && fflush(fp) == 0 ? 0 : 1;
-}
-/* next block of an index file; NULL at the end of the file (*at_eof = 1) or when the block is damaged / of another version (*at_eof = 0) */
-extern "C" mm_idx_t *mm_idx_load(FILE *fp, int *at_eof)
-{
-	if(at_eof) *at_eof = 0;
-	uint32_t magic = 0; size_t got = fread(&magic, 1, 4, fp);
-	if(got == 0) { if(at_eof) *at_eof = 1; return NULL; }
-	MaiHead h;
-	if(got != 4 || magic != MAI_MAGIC || fread(&h, 1, sizeof(h), fp) != sizeof(h)) return NULL;
-	if(h.n_occ == 0 || h.n_occ > 7 || h.k < 2 || h.k > 31 || h.w < 1 || h.w > 31 || h.n_slot == 0 || (h.n_slot & (h.n_slot - 1)) || h.n_val == 0) return NULL;
-	mm_idx_t *mi = new mm_idx_s();
-	mi->b = h.b; mi->w = h.w; mi->k = h.k; mi->n_occ = h.n_occ; memcpy(mi->occ, h.occ, sizeof(h.occ)); mi->n_keys = h.n_keys; mi->mask = h.n_slot - 1;
-	bool ok = true;
-	auto get = [&](void *p, size_t n) { ok = ok && (n == 0 || fread(p, 1, n, fp) == n); };
-	try {
-		for(uint64_t i = 0; ok && i < h.n_seq; i++) {
-			uint64_t l[3] = { 0, 0, 0 }; get(l, sizeof(l));
-			if(!ok || l[0] > (1u << 20) || l[1] > 0xffffffffull) { ok = false; break; }
-			mi->seq.emplace_back(); HSeq &q = mi->seq.back();
-			q.name.resize(l[0]); q.seq.resize(l[1]); q.circular = l[2] != 0; get(&q.name[0], l[0]); get(q.seq.data(), l[1]);
-		}
-		if(ok) { mi->slot.resize(h.n_slot); get(mi->slot.data(), h.n_slot * sizeof(IdxSlot)); }
-		if(ok) { mi->val.resize(h.n_val); get(mi->val.data(), h.n_val * sizeof(uint64_t)); }
-	} catch(std::bad_alloc &) { ok = false; }
-	if(!ok || mi->seq.empty()) { delete mi; return NULL; }
-	return mi;
-}
-/* test entry: the packed reference of a device-built index (K0 over the text in HBM: mm_text_codes_tiled_kernel + mm_codes_pack_kernel) brought back and compared base by
- * base with the host's conversion of the same text (ref_codes: the table of minialign.c:223-229).  Returns the number of differing bases (the first few go to stderr),
- * -1 when there is nothing on the device to compare */
-extern "C" int64_t mm_idx_ref_check(mm_idx_t const *mi)
-{
-	if(!mi->on_device || !mi->ref_ar) return -1;
-	(void)hipSetDevice(mi->dev);
-	const uint64_t n = mi->ref_ar->n, nw = (n + 15) / 16 + 4, nn = (n + 31) / 32 + 4;
-	std::vector<uint32_t> pk(nw), nm(nn);
-	if(hipMemcpy(pk.data(), mi->ref_ar->pk, nw * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(nm.data(), mi->ref_ar->nm, nn * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-	uint64_t off = 0; std::atomic<int64_t> bad{0}; std::mutex pm;
-	std::vector<uint64_t> offs; for(const HSeq &q : mi->seq) { offs.push_back(off); off += ((uint64_t)q.blen() + 63) & ~63ull; }
-	host_parallel((uint32_t)mi->seq.size(), [&](uint32_t t, uint32_t nth) {
-		for(size_t i = t; i < mi->seq.size(); i += nth) {
-			const std::vector<uint8_t> &c = ref_codes(mi, (uint32_t)i);
-			for(uint64_t j = 0; j < c.size(); j++) {
-				const uint64_t p = offs[i] + j; const uint8_t d = ((nm[p >> 5] >> (p & 31)) & 1) ? 4 : (uint8_t)((pk[p >> 4] >> (2 * (p & 15))) & 3);
-				if(d != c[j]) { if(bad.fetch_add(1) < 8) { std::lock_guard<std::mutex> lk(pm); fprintf(stderr, "[minialign_amd] reference check: sequence %zu (`%s') base %lu: %u on the device, %u from the text\n", i, mi->seq[i].name.c_str(), (unsigned long)j, d, c[j]); } }
-			}
-		}
-	}, 32);
-	return bad.load();
-}
-extern "C" uint32_t mm_idx_n_seq(mm_idx_t const *mi) { return (uint32_t)mi->seq.size(); }
-extern "C" uint32_t mm_idx_occ(mm_idx_t const *mi, uint32_t i) { return mi->occ[i]; }
-extern "C" uint32_t mm_idx_max_len(mm_idx_t const *mi) { uint32_t m = 0; for(const HSeq &q : mi->seq) m = std::max<uint32_t>(m, q.blen()); return m; }
-extern "C" uint32_t mm_idx_get(mm_idx_t const *mi, uint64_t minier, uint64_t *out, uint32_t max)
-{
-	auto hash = [](uint64_t x) { x ^= x >> 31; x *= 0x9e3779b97f4a7c15ull; x ^= x >> 29; return x; };
-	if(!idx_fetch_host(mi)) return 0;
-	uint64_t s = hash(minier) & mi->mask;
-	while(mi->slot[s].key != 0) {
-		if(mi->slot[s].key == minier + 1) {
-			uint64_t v = mi->slot[s].val;
-			if((int64_t)v >= 0) { if(max) out[0] = v; return 1; }
-			uint32_t n = (uint32_t)(v & 0xffffff); uint64_t off = (v & 0x7fffffffffffffffull) >> 24;
-			for(uint32_t i = 0; i < n && i < max; i++) out[i] = mi->val[off + i];
-			return n;
-		}
-		s = (s + 1) & mi->mask;
-	}
-	return 0;
-}
-
-/* mm_sketch (minialign.c:2410-2435) on the host: the (w,k)-minimizer stream of a sequence given one byte per base (0..3, 4 = N), as the words the
- * reference's stream holds -- hash << 8 | strand << 7 | index inside its block of w (minialign.c:2402) -- plus, when pos != NULL, the k-mer start position
- * the stream decoder (minialign.c:2831-2835) gives each word.  Returns the count (at most max are written).  Reads are sketched on the device by K1;
- * this is the entry the index construction uses. */
-extern "C" uint32_t mm_sketch(uint8_t const *seq, uint32_t len, uint32_t w, uint32_t k, uint64_t *words, uint32_t *pos, uint32_t max)
-{
-	if(!seq || k < 2 || k > 31 || w < 1 || w > 31) return 0;
-	std::vector<HMin> m; sketch_host(seq, len, k, w, m);
-	for(size_t i = 0; i < m.size() && i < max; i++) { if(words) words[i] = m[i].hash << 8 | (uint64_t)m[i].strand << 7 | (m[i].pos % w); if(pos) pos[i] = m[i].pos; }
-	return (uint32_t)m.size();
-}
-
+#include "host_options.hpp"
+#include "host_index.hpp"
 /* =============================================================================================
  * device context + batch pipeline
  * ============================================================================================= */
@@ -1665,317 +890,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 	return true;
 }
 
-/* ---- post-map on the host (minialign.c:4185-4398) ---- */
-struct OutAln { uint32_t aln; uint32_t mapq; };
-struct OutReg { uint32_t n_all = 0, n_uniq = 0; std::vector<OutAln> aln; bool mapped = false; };
-inline uint32_t clip_mapq(double x) { uint32_t v = h_d2u32(x); return std::min<uint32_t>(v, 60 * 16); }
-
-void post_map(const mm_align_t *a, const ReadState &rs, Root *res, uint64_t *bin, const AlnRec *alns, OutReg &out)
-{
-	uint32_t n_res = rs.n_res;
-	out.mapped = n_res > 0;
-	if(!n_res) return;
-	sort_res((ResEnt *)res, n_res);                                       /* radix_sort_64x, minialign.c:4452 */
-	/* mm_prune_regs */
-	uint64_t q = n_res;
-	uint32_t minv = (uint32_t)h_ofs((int32_t)h_f2u32((float)h_ofs((int32_t)res[0].plen) * a->o.min_ratio));
-	while(res[--q].plen > minv) {}
-	n_res = (uint32_t)(q + 1);
-	uint32_t n_all = n_res;
-	auto hdr = [&](uint32_t iid) { return (uint32_t *)&bin[iid]; };        /* { n_aln, plen, lb, ub } */
-	/* mm_collect_supp */
-	uint64_t p, qq;
-	for(p = 1, qq = n_res; p < qq; p++) {
-		uint64_t mx = 0;
-		for(uint64_t i = p; i < qq; i++) {
-			uint32_t *s = hdr(res[i].lid);
-			int64_t lb = s[2], ub = s[3], span = ub - lb; bool covered = false;
-			for(uint64_t j = 0; j < p; j++) {
-				uint32_t *t = hdr(res[j].lid);
-				if((int64_t)t[3] < ub) lb = std::max<int64_t>(lb, t[3]); else ub = std::min<int64_t>(ub, t[2]);
-				if(1.2 * (double)(ub - lb) < (double)span) { qq--; std::swap(res[i], res[qq]); i--; covered = true; break; }
-			}
-			if(covered) continue;
-			mx = std::max<uint64_t>(mx, ((uint64_t)(2 * (ub - lb) - span) << 32) | i);
-		}
-		if(mx & 0xffffffff) std::swap(res[p], res[mx & 0xffffffff]);
-	}
-	p = std::min(p, qq);
-	/* mm_post_map */
-	int64_t usc = 0, lsc = INT64_MAX, tsc = 0;
-	for(uint64_t i = p; i < n_res; i++) { int64_t sc = h_ofs((int32_t)res[i].plen); usc = std::max(usc, sc); lsc = std::min(lsc, sc); tsc += sc; }
-	lsc = (lsc == INT32_MAX) ? 0 : lsc;
-	double tpc = 1.0, x = a->xcoef, mxc = a->mcoef + a->xcoef;
-	for(uint64_t i = 0; i < p; i++) {
-		uint32_t score = (uint32_t)h_ofs((int32_t)res[i].plen);
-		uint32_t *b = hdr(res[i].lid);
-		double pid = 0.0; uint64_t len = 0;
-		for(uint32_t j = 0; j < b[0]; j++) { const AlnRec &al = alns[bin[res[i].lid + 2 + j] - 1]; len += al.plen; pid += (double)al.plen * al.identity; }
-		pid /= (double)len;
-		double ec = 2.0 / (pid * mxc - x);
-		double ulen = ec * (double)std::max<int64_t>((int64_t)score - usc, 0), pe = 1.0 / (ulen * ulen + 1);
-		b[1] = clip_mapq(-10.0 * 16 * log10(pe));
-		tpc *= 1.0 - pe;
-	}
-	double tpe = std::min(1.0 - tpc, 1.0);
-	for(uint64_t i = p; i < n_res; i++) {
-		uint32_t *b = hdr(res[i].lid);
-		b[1] = clip_mapq(-10.0 * 16 * log10(1.0 - tpe * (double)(int64_t)((int64_t)res[i].plen - lsc + 1) / (double)tsc));
-	}
-	/* mm_pack_reg */
-	for(uint64_t i = 0; i < n_all; i++) {
-		uint32_t *b = hdr(res[i].lid);
-		for(uint32_t j = 0; j < b[0]; j++) out.aln.push_back(OutAln{ (uint32_t)(bin[res[i].lid + 2 + j] - 1), b[1] });
-		if(i == p - 1) out.n_uniq = (uint32_t)out.aln.size();
-	}
-	out.n_all = (uint32_t)out.aln.size();
-}
-
-/* ---- CIGAR from path bits (gaba_parse.h:168-221, reverse parser) ---- */
-inline uint64_t path_u64(const uint64_t *ptr, int64_t pos) { int64_t rem = pos & 63; return (ptr[pos >> 6] >> rem) | ((ptr[(pos >> 6) + 1] << (63 - rem)) << 1); }
-inline uint64_t lzc(uint64_t x) { return x ? (uint64_t)__builtin_clzll(x) : 64; }
-inline void put_num(std::string &s, uint64_t v) { char b[24]; int n = 0; if(!v) b[n++] = '0'; while(v) { b[n++] = (char)('0' + v % 10); v /= 10; } while(n) s.push_back(b[--n]); }
-/* the same into a raw buffer (most run lengths have one or two digits) */
-inline char *put_num_p(char *p, uint64_t v)
-{
-	if(v < 10) { *p++ = (char)('0' + v); return p; }
-	if(v < 100) { *p++ = (char)('0' + v / 10); *p++ = (char)('0' + v % 10); return p; }
-	char b[24]; int n = 0; while(v) { b[n++] = (char)('0' + v % 10); v /= 10; } while(n) *p++ = b[--n];
-	return p;
-}
-void cigar_reverse(std::string &out, const uint32_t *path, uint64_t offset, uint64_t len)
-{
-	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
-	uint64_t ofs = (uint64_t)((int64_t)offset + (((uintptr_t)path & 4) ? 32 : 0) - 64), idx = len;
-	/* written through a raw pointer into room reserved for the worst case (every path bit its own run: 2 characters per bit and change) */
-	const size_t o = out.size(); out.resize(o + 2 * len + 64);
-	char *w = &out[o];
-	while((int64_t)idx > 0) {
-		uint64_t m = lzc(path_u64(p, (int64_t)(ofs + idx))), c = std::min(idx, m - (m > 0));
-		idx -= c; if(c) { w = put_num_p(w, c); *w++ = 'D'; }
-		m = lzc(~path_u64(p, (int64_t)(ofs + idx))); c = std::min(idx, m);
-		idx -= c; if(c) { w = put_num_p(w, c); *w++ = 'I'; }
-		uint64_t sidx = idx;
-		do { m = lzc(path_u64(p, (int64_t)(ofs + idx)) ^ 0x5555555555555555ull); c = std::min(idx, m) & ~1ull; idx -= c; } while(c == 64);
-		if((sidx - idx) >> 1) { w = put_num_p(w, (sidx - idx) >> 1); *w++ = 'M'; }
-	}
-	out.resize((size_t)(w - out.data()));
-}
-
-/* ---- SAM (minialign.c:5127-5198, 5390-5426), default tag set ---- */
-void sam_seq(std::string &s, const uint8_t *q, uint32_t n, bool rev)
-{
-	static const char fw[] = "ACGTN\0\0\0\0\0\0\0\0\0\0\0", rv[] = "TGCAN\0\0\0\0\0\0\0\0\0\0\0";
-	size_t o = s.size(); s.resize(o + n);
-	char *d = &s[o];
-	if(!rev) for(uint32_t i = 0; i < n; i++) d[i] = fw[q[i] & 15];
-	else { const uint8_t *e = q + n - 1; for(uint32_t i = 0; i < n; i++) d[i] = rv[e[-(int64_t)i] & 15]; }
-}
-/* walks the path bits in the order of _parser_loop_rv (gaba_parse.h:168-188); fn(op, count) sees every nonzero run ('D', 'I', 'M') */
-template<typename F> void path_walk_reverse(const uint32_t *path, uint64_t offset, uint64_t len, F fn)
-{
-	const uint64_t *p = (const uint64_t *)((uintptr_t)path & ~(uintptr_t)7);
-	uint64_t ofs = (uint64_t)((int64_t)offset + (((uintptr_t)path & 4) ? 32 : 0) - 64), idx = len;
-	while((int64_t)idx > 0) {
-		uint64_t m = lzc(path_u64(p, (int64_t)(ofs + idx))), c = std::min(idx, m - (m > 0));
-		idx -= c; if(c) fn('D', c);
-		m = lzc(~path_u64(p, (int64_t)(ofs + idx))); c = std::min(idx, m);
-		idx -= c; if(c) fn('I', c);
-		uint64_t sidx = idx;
-		do { m = lzc(path_u64(p, (int64_t)(ofs + idx)) ^ 0x5555555555555555ull); c = std::min(idx, m) & ~1ull; idx -= c; } while(c == 64);
-		if((sidx - idx) >> 1) fn('M', (sidx - idx) >> 1);
-	}
-}
-/* MD:Z (mm_print_sam_md, minialign.c:5243-5301): match counts, the reference base at a mismatch, ^ + reference bases at a deletion.  On the
- * reverse strand the query base is complemented by xor 3, so an N there never equals the reference's N. */
-void sam_md(std::string &s, const std::vector<uint8_t> &rcodes, const uint8_t *qseq, uint32_t qlen, const gaba::Segment &sg, const uint32_t *path)
-{
-	static const char dec[] = "ACGTN\0\0\0\0\0\0\0\0\0\0\0";
-	s += "\tMD:Z:";
-	const bool rev = (~sg.bid & 1) != 0;
-	const uint8_t *rp = rcodes.data() + (rcodes.size() - sg.apos - sg.alen), *rb = rp;
-	const uint8_t *qp = rev ? qseq + (qlen - sg.bpos) : qseq + (qlen - sg.bpos - sg.blen);
-	path_walk_reverse(path, sg.ppos, (uint64_t)sg.alen + sg.blen, [&](char op, uint64_t c) {
-		if(op == 'D') { put_num(s, (uint64_t)(rp - rb)); s.push_back('^'); rb = rp + c; for(uint64_t i = 0; i < c; i++) s.push_back(dec[*rp++ & 15]); }
-		else if(op == 'I') { if(rev) qp -= c; else qp += c; }
-		else {
-			for(uint64_t t = 0; t < c; t++) {
-				const uint8_t rc = rp[t], qc = rev ? (uint8_t)(3 ^ qp[-1 - (int64_t)t]) : qp[t];
-				if(rc != qc) { put_num(s, (uint64_t)(rp + t - rb)); s.push_back(dec[rc & 15]); rb = rp + t + 1; }
-			}
-			rp += c; if(rev) qp -= c; else qp += c;
-		}
-	});
-	put_num(s, (uint64_t)(rp - rb));
-}
-inline void put_int(std::string &s, int64_t v) { if(v < 0) { s.push_back('-'); put_num(s, (uint64_t)-v); } else put_num(s, (uint64_t)v); }
-/* mm_print_sam_mapped with its tag printers (minialign.c:5127-5426).  QUIRKS kept: flags and tag bits share one word (-P switches IH on, -T IH omits
- * secondaries); the SA entries name the first reference sequence whatever they hit and carry the raw 16x fixed-point mapping quality; RG:Z prints
- * the whole "ID:..." token. */
-void sam_record(const mm_align_t *a, std::string &s, const char *qname, const uint8_t *qseq, uint32_t qlen, const OutReg &reg,
-	const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths, const HSeq *rec, const CigEnt *cig_ent = nullptr, const char *cig_text = nullptr)
-{
-	/* the run lengths of a segment: the string the device made for its slot (K4, mm_cigar.hpp) or, without one, the walk over the path words (gaba_parse.h:168-221) */
-	auto put_cigar = [&](const AlnRec &al, uint32_t slot, const gaba::Segment &g) {
-		if(cig_ent) { s.append(cig_text + cig_ent[slot].off, cig_ent[slot].len); }
-		else { cigar_reverse(s, paths + al.path_off, g.ppos, (uint64_t)g.alen + g.blen); }
-	};
-	const uint64_t f = a->o.ptags();
-	auto tag = [f](int x) { return ((f >> x) & 1) != 0; };
-	const bool has_qual = rec && !rec->qual.empty(), has_co = rec && rec->has_comment;
-	if(!reg.mapped || reg.n_all == 0) {
-		s += qname; s += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; sam_seq(s, qseq, qlen, false); s.push_back('\t');
-		if(has_qual) s.append(rec->qual, 0, qlen); else s.push_back('*');
-		if(has_co) { s += "\tCO:Z:"; s += rec->comment; }
-		s.push_back('\n');
-		return;
-	}
-	auto edit = [&](const AlnRec &al) { return (uint32_t)((double)al.dcnt * (1.0 - al.identity)) + al.agcnt + al.bgcnt; };
-	uint32_t flag = 0;
-	const uint32_t n = (f & 0x08) ? reg.n_uniq : reg.n_all;           /* MM_OMIT_REP */
-	for(uint32_t i = 0; i < n; i++) {
-		if(i >= reg.n_uniq) flag = 0x100;
-		const AlnRec &al = alns[reg.aln[i].aln];
-		for(uint32_t j = al.slen; j > 0; j--) {
-			const gaba::Segment &sg = segs[al.seg_off + j - 1];
-			const HSeq &r = a->mi->seq[sg.aid >> 1];
-			uint32_t rs = r.blen() - sg.apos - sg.alen;
-			uint32_t hl = qlen - sg.bpos - sg.blen, tl = sg.bpos;
-			uint32_t qs = (flag & 0x900) ? hl : 0, qe = qlen - ((flag & 0x900) ? tl : 0);
-			s += qname; s.push_back('\t'); put_num(s, flag | ((~sg.bid & 1) << 4)); s.push_back('\t');
-			s += r.name; s.push_back('\t'); put_num(s, rs + 1); s.push_back('\t'); put_num(s, reg.aln[i].mapq >> 4); s.push_back('\t');
-			char clip = (flag & 0x900) ? 'H' : 'S';
-			if(hl) { put_num(s, hl); s.push_back(clip); }
-			put_cigar(al, al.seg_off + j - 1, sg);
-			if(tl) { put_num(s, tl); s.push_back(clip); }
-			s += "\t*\t0\t0\t";
-			if(sg.bid & 1) sam_seq(s, qseq + qs, qe - qs, false); else sam_seq(s, qseq + (qlen - qe), qe - qs, true);
-			s.push_back('\t');
-			if(has_qual) {
-				if(sg.bid & 1) s.append(rec->qual, qs, qe - qs);
-				else { const char *qq = rec->qual.data() + (qlen - qe); for(uint32_t x = qe - qs; x > 0; x--) s.push_back(qq[x - 1]); }
-			} else s.push_back('*');
-			if(f) {
-				if(tag(0)) { s += "\tRG:Z:"; s += a->o.rg_id; }
-				if(tag(2)) { s += "\tNH:i:"; put_num(s, reg.n_all); }
-				if(tag(3)) { s += "\tIH:i:"; put_num(s, i); }
-				if(tag(4)) { s += "\tAS:i:"; put_int(s, al.score); }
-				if(tag(6)) { s += "\tNM:i:"; put_num(s, edit(al)); }
-				if(tag(8)) sam_md(s, ref_codes(a->mi, sg.aid >> 1), qseq, qlen, sg, paths + al.path_off);
-			}
-			if(i == 0 && j == al.slen) {
-				flag = 0x800;
-				bool stop = false;
-				if(tag(5)) { s += "\tXS:i:"; put_int(s, reg.n_all > 1 ? alns[reg.aln[1].aln].score : 0); }
-				if(tag(7) && (reg.n_uniq > 1 || alns[reg.aln[0].aln].slen > 1)) {
-					s += "\tSA:Z:";
-					for(uint32_t x = 0; x < reg.n_uniq; x++) {
-						const AlnRec &bl = alns[reg.aln[x].aln];
-						for(uint32_t y = bl.slen; y > 0; y--) {
-							if(x == 0 && y == bl.slen) continue;
-							const gaba::Segment &sh = segs[bl.seg_off + y - 1];
-							const HSeq &rr = a->mi->seq[sh.aid >> 1];
-							s += a->mi->seq[0].name; s.push_back(','); put_num(s, rr.blen() - sh.apos - sh.alen + 1); s.push_back(',');
-							s.push_back((sh.bid & 1) ? '+' : '-'); s.push_back(',');
-							uint32_t h2 = qlen - sh.bpos - sh.blen, t2 = sh.bpos;
-							if(h2) { put_num(s, h2); s.push_back('H'); }
-							put_cigar(bl, bl.seg_off + y - 1, sh);
-							if(t2) { put_num(s, t2); s.push_back('H'); }
-							s.push_back(','); put_num(s, reg.aln[x].mapq); s.push_back(','); put_num(s, edit(bl)); s.push_back(';');
-						}
-					}
-					stop = true;
-				}
-				if(has_co) { s += "\tCO:Z:"; s += rec->comment; }
-				if(stop) { s.push_back('\n'); return; }                 /* the other records are in the SA tag (minialign.c:5418-5420) */
-			}
-			s.push_back('\n');
-		}
-		flag = 0x800;
-	}
-}
-
-/* ---- the other output formats: MAF, BLAST6 (tabular), PAF (minialign.c:5427-5625); nothing is printed for unmapped reads ---- */
-void put_fixed(std::string &s, uint32_t n, int c)           /* _putfi, minialign.c:4812: n with a decimal point in front of its last c digits */
-{
-	char d[24]; int i = 0;
-	while(n || i <= c) { d[i++] = (char)('0' + n % 10); n /= 10; }
-	for(int j = i; j > c; j--) s.push_back(d[j - 1]);
-	s.push_back('.');
-	for(int j = c; j > 0; j--) s.push_back(d[j - 1]);
-}
-void put_pair(std::string &s1, std::string &s2, uint32_t n1, uint32_t n2)       /* _putpi, minialign.c:4847: two numbers right-aligned to one width */
-{
-	char d1[16], d2[16]; int i = 0;
-	while(n1 | n2) { d1[i] = (char)(n1 % 10); d2[i] = (char)(n2 % 10); n1 /= 10; n2 /= 10; i++; }
-	if(i == 0) { d1[0] = d2[0] = 0; i = 1; }
-	int z1 = 0, z2 = 0;
-	for(int j = i; j > 0; j--) {
-		z1 |= d1[j - 1] | (j == 1); z2 |= d2[j - 1] | (j == 1);
-		s1.push_back((char)(d1[j - 1] + '0' - (z1 ? 0 : 0x10))); s2.push_back((char)(d2[j - 1] + '0' - (z2 ? 0 : 0x10)));
-	}
-}
-void alt_record(const mm_align_t *a, std::string &s, const char *qname, const uint8_t *qseq, uint32_t qlen, const OutReg &reg,
-	const AlnRec *alns, const gaba::Segment *segs, const uint32_t *paths)
-{
-	if(!reg.mapped || reg.n_all == 0) return;
-	const uint64_t f = a->o.ptags();
-	const uint32_t n = (f & 0x08) ? reg.n_uniq : reg.n_all;
-	const size_t l_qname = strlen(qname);
-	std::vector<char> buf;
-	for(uint32_t i = 0; i < n; i++) {
-		const AlnRec &al = alns[reg.aln[i].aln];
-		const gaba::Segment &sg = segs[al.seg_off + al.slen - 1], &eg = segs[al.seg_off];
-		const HSeq &r = a->mi->seq[sg.aid >> 1]; const uint32_t rl = r.blen();
-		const uint32_t dcnt = al.dcnt, mcnt = h_d2u32((double)dcnt * al.identity), gcnt = al.agcnt + al.bgcnt;
-		if(a->o.format == 1) {                 /* mm_print_maf_mapped, :5476 */
-			for(uint32_t j = al.slen; j > 0; j--) {
-				const gaba::Segment &g = segs[al.seg_off + j - 1];
-				const HSeq &rr = a->mi->seq[g.aid >> 1]; const uint32_t rrl = rr.blen();
-				const uint32_t rs = rrl - g.apos - g.alen, qs = qlen - g.bpos - g.blen;
-				const uint64_t plen = (uint64_t)g.alen + g.blen;
-				s += "a score="; put_num(s, (uint32_t)al.score); s.push_back('\n');
-				const size_t w = std::max(rr.name.size(), l_qname) + 1;
-				std::string q2 = "s "; q2 += qname; q2.append(w - l_qname, ' ');
-				s += "s "; s += rr.name; s.append(w - rr.name.size(), ' ');
-				put_pair(s, q2, rs, qs); s.push_back(' '); q2.push_back(' ');
-				put_pair(s, q2, g.alen, g.blen); s.push_back(' '); q2.push_back(' ');
-				s += "+ "; q2.push_back((g.bid & 1) ? '+' : '-'); q2.push_back(' ');
-				put_pair(s, q2, rrl, qlen); s.push_back(' '); q2.push_back(' ');
-				buf.resize(plen + 64);
-				uint64_t m = gaba_dump_seq_reverse(buf.data(), buf.size(), GABA_SEQ_A, paths + al.path_off, g.ppos, plen, ref_codes(a->mi, g.aid >> 1).data() + rs, '-');
-				s.append(buf.data(), m); s.push_back('\n');
-				s += q2;
-				m = gaba_dump_seq_reverse(buf.data(), buf.size(), GABA_SEQ_B | ((g.bid & 1) ? GABA_SEQ_FW : GABA_SEQ_RV), paths + al.path_off, g.ppos, plen,
-					(g.bid & 1) ? qseq + qs : qseq + (qlen - qs), '-');
-				s.append(buf.data(), m); s += "\n\n";
-			}
-		} else if(a->o.format == 2) {          /* mm_print_blast6_mapped, :5497: qname rname idt len #x #gap qs qe rs re e-value bitscore */
-			const uint32_t rs = (sg.bid & 1) ? rl - sg.apos - sg.alen + 1 : rl - eg.apos, re = (sg.bid & 1) ? rl - eg.apos : rl - sg.apos - sg.alen + 1;
-			const uint32_t qs = qlen - sg.bpos - sg.blen + 1, qe = qlen - eg.bpos;
-			s += qname; s.push_back('\t'); s += r.name; s.push_back('\t');
-			put_fixed(s, h_d2u32(1000.0 * al.identity), 3);
-			for(uint32_t v : { dcnt + gcnt, dcnt - mcnt, gcnt, qs, qe, rs, re }) { s.push_back('\t'); put_num(s, v); }
-			s.push_back('\t');
-			const double bit = 1.85 * (double)al.score - 0.02;
-			put_fixed(s, h_d2u32(1000.0 * (double)rl * (double)qlen * pow(2.0, -bit)), 3);
-			s.push_back('\t'); put_num(s, h_d2u32(bit)); s.push_back('\n');
-		} else {                                /* mm_print_paf_mapped, :5549: qname ql qs qe strand rname rl rs re #match block_len mapq [tags] */
-			const uint32_t rs = rl - sg.apos - sg.alen, re = rl - eg.apos, qs = qlen - sg.bpos - sg.blen, qe = qlen - eg.bpos;
-			s += qname; for(uint32_t v : { qlen, qs, qe }) { s.push_back('\t'); put_num(s, v); }
-			s.push_back('\t'); s.push_back((sg.bid & 1) ? '+' : '-'); s.push_back('\t'); s += r.name;
-			for(uint32_t v : { rl, rs, re, mcnt, dcnt + gcnt, reg.aln[i].mapq >> 4 }) { s.push_back('\t'); put_num(s, v); }
-			if((f >> 4) & 1) { s += "\tAS:i:"; put_num(s, (uint32_t)al.score); }
-			if((f >> 10) & 1) { s += "\tID:f:"; put_fixed(s, h_d2u32(al.identity * 10000.0), 4); }
-			if((f >> 6) & 1) { s += "\tNM:i:"; put_num(s, (dcnt - mcnt) + gcnt); }
-			if((f >> 11) & 1) { s += "\tSQ:i:"; sam_seq(s, qseq, qlen, false); }
-			if((f >> 9) & 1) { s += "\tCG:Z:"; cigar_reverse(s, paths + al.path_off, 0, al.plen); }
-			s.push_back('\n');
-		}
-	}
-}
-
-bool ensure_shared_slabs(mm_align_t *P, uint32_t max_qlen, uint32_t lanes);
+#include "host_print.hpp"
 /* minimizer records a read gets room for, per base: at most one per position; 2 / (w + 1) per base on average, so 4 / (w + 1) is ample for all but the reads inside low-complexity sequence (w = 10: 0.36; a run of one repeated k-mer emits a minimizer per base); a read whose
  * hashes keep falling emits one per position: after an overflow the batch is redone with room for that (scale > 1) */
 inline double min_cap_frac(uint32_t w, uint64_t scale) { return scale > 1 ? 1.0 : std::min(1.0, 4.0 / ((double)w + 1.0)); }
@@ -3077,416 +1992,7 @@ static bool map_split(mm_align_t *c, const Batch &b, uint32_t lo, uint32_t hi, s
 	return map_split(c, b, lo, mid, pieces) && map_split(c, b, mid, hi, pieces);
 }
 
-/* =============================================================================================
- * the reader: the text of a query file -> records -> batches, with the record scanning on the device (K0r, mm_device.hpp).
- * The host maps the file (or holds what stdin / gzip gave) and brings its bytes to HBM in stretches of 256 MB through pinned staging buffers; a stretch starts
- * where a record starts and is scanned by the kernels, which leave a table of records (delimiter, end of the header line, sequence extent, number of bases);
- * the last, possibly incomplete record of a stretch opens the next one.  The stretches stay in HBM until the batches cut from them have been packed (K0 reads
- * the bases from there), and no base of a read is touched by the host until its record is printed.  FASTQ in any shape other than four lines per record is
- * scanned by the host's sequential reader (host_find_fastq): that grammar -- the number of quality lines depends on the number of bases -- is sequential.
- * ============================================================================================= */
-static void free_chunk_pool(struct ChunkPool *p) { delete p; }
-namespace {
-/* text of a file: a read-only mapping of a plain file (page cache, nothing copied), or memory for stdin and gzip input */
-std::shared_ptr<TextSrc> open_text(const char *fn)
-{
-	auto t = std::make_shared<TextSrc>();
-	bool mapped = false;
-	if(strcmp(fn, "-") != 0) {
-		const int fd = open(fn, O_RDONLY);
-		if(fd < 0) return nullptr;
-		struct stat sb; uint8_t mg[2] = { 0, 0 };
-		if(fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && pread(fd, mg, 2, 0) == 2 && !(mg[0] == 0x1f && mg[1] == 0x8b)) {
-			void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-			if(m != MAP_FAILED) { (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL); t->map = m; t->map_len = (uint64_t)sb.st_size; t->p = (const char *)m; t->n = (uint64_t)sb.st_size; mapped = true; }
-		}
-		close(fd);
-	}
-	if(!mapped) {
-		FILE *fp = strcmp(fn, "-") == 0 ? stdin : fopen(fn, "rb");
-		if(!fp) return nullptr;
-		std::vector<char> data(1 << 22); size_t len = 0, got;
-		while((got = fread(data.data() + len, 1, data.size() - len, fp)) > 0) { len += got; if(len == data.size()) data.resize(data.size() * 2); }
-		data.resize(len);
-		if(fp != stdin) fclose(fp);
-		if(data.size() >= 2 && (uint8_t)data[0] == 0x1f && (uint8_t)data[1] == 0x8b) {          /* gzip members back to back (the reference reads through gzread) */
-			std::vector<char> raw(std::max<size_t>(data.size() * 4, 1 << 16));
-			z_stream zs; memset(&zs, 0, sizeof(zs));
-			if(inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return nullptr;
-			zs.next_in = (Bytef *)data.data(); size_t in_left = data.size(), out_len = 0; bool ok = true;
-			while(ok) {
-				zs.avail_in = (uInt)std::min<size_t>(in_left, 1u << 30); const size_t in_before = zs.avail_in;
-				if(raw.size() - out_len < (1u << 16)) raw.resize(raw.size() * 2);
-				zs.next_out = (Bytef *)raw.data() + out_len; zs.avail_out = (uInt)std::min<size_t>(raw.size() - out_len, 1u << 30); const size_t out_before = zs.avail_out;
-				const int rc = inflate(&zs, Z_NO_FLUSH);
-				in_left -= in_before - zs.avail_in; out_len += out_before - zs.avail_out;
-				if(rc == Z_STREAM_END) { if(in_left < 2 || (uint8_t)zs.next_in[0] != 0x1f || (uint8_t)zs.next_in[1] != 0x8b) break; if(inflateReset(&zs) != Z_OK) ok = false; }
-				else if(rc != Z_OK && !(rc == Z_BUF_ERROR && zs.avail_out == 0)) ok = false;
-				else if(in_left == 0 && zs.avail_out != 0) ok = false;
-			}
-			inflateEnd(&zs);
-			if(!ok) { fprintf(stderr, "[minialign_amd] broken gzip stream in `%s'\n", fn); return nullptr; }
-			raw.resize(out_len); data.swap(raw);
-		}
-		t->own.swap(data); t->p = t->own.data(); t->n = t->own.size();
-	}
-	/* the file type is the first '>' or '@' among the first four bytes; what stands in front of it is dropped (minialign.c:1784-1792) */
-	for(int i = 0; i < 4 && t->first < t->n; i++) { if(t->p[t->first] == '>' || t->p[t->first] == '@') { t->delim = t->p[t->first]; break; } t->first++; }
-	if(!t->delim) { fprintf(stderr, "[minialign_amd] `%s' is neither FASTA nor FASTQ\n", fn); return nullptr; }
-	return t;
-}
-/* FASTQ records of text[0, n) one after the other, as parse_fastq reads them, offsets only (relative to t).  A record the text ends in (last == false: the next
- * stretch brings the rest) is left out and *consumed stops in front of it.  false when a record does not start with '@' where one must (the reference gives up). */
-bool host_find_fastq(const char *t, uint64_t n, bool last, bool keep_qual, std::vector<RRec> &out, uint64_t &consumed)
-{
-	const char *p = t, *end = t + n;
-	consumed = 0;
-	while(p < end) {
-		const char *rs = p;
-		if(*p++ != '@') return false;
-		RRec r; memset(&r, 0, sizeof(r)); r.start = (uint64_t)(rs - t);
-		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-		if(!nl) { if(!last) break; r.hdr_end = n; r.t_off = n; out.push_back(r); p = end; consumed = n; break; }
-		r.hdr_end = (uint64_t)(nl - t); p = nl + 1;
-		r.t_off = (uint64_t)(p - t); const char *t_end = p; uint64_t nb = 0; bool at = false;
-		while(p < end) {
-			nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end;
-			const char *dl = (const char *)memchr(p, '+', (size_t)(le - p)); const char *stop = dl ? dl : le;
-			if(stop > p) { nb += (uint64_t)(stop - p); t_end = stop; }
-			if(dl) { at = true; p = dl; break; }
-			p = nl ? nl + 1 : end;
-		}
-		r.t_len = (uint32_t)((uint64_t)(t_end - t) - r.t_off); r.n_bases = (uint32_t)nb;
-		if(!at) { if(!last) break; out.push_back(r); consumed = n; p = end; break; }
-		nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-		if(!nl && !last) break;
-		p = nl ? nl + 1 : end;
-		r.q_off = (uint64_t)(p - t); uint64_t acc = 0;
-		while(p < end) {
-			nl = (const char *)memchr(p, '\n', (size_t)(end - p)); const char *le = nl ? nl : end; size_t ll = (size_t)(le - p);
-			if(keep_qual) { if(ll > 0 && p[ll - 1] == '\r') ll--; }
-			acc += ll; p = le;
-			if(p >= end || acc >= nb) break;
-			p++;
-		}
-		r.q_len = (uint32_t)((uint64_t)(p - t) - r.q_off);
-		if(!last && p >= end) break;          /* the quality line may go on in the next stretch */
-		out.push_back(r);
-		while(p < end && *p == '\n') p++;
-		consumed = (uint64_t)(p - t);
-	}
-	return true;
-}
-/* host threads that stay for the life of a reader: a piece of text is copied into a pinned staging buffer by all of them, a slice each (threads made per 32 MB piece
- * cost more than the copy) */
-struct CopyPool {
-	std::vector<std::thread> th; std::mutex mu; std::condition_variable cv, dcv;
-	const char *src = nullptr; char *dst = nullptr; size_t n = 0; uint64_t gen = 0; uint32_t left = 0, nth = 0; bool stop = false;
-	void start(uint32_t want) { nth = want; for(uint32_t t = 0; t < nth; t++) th.emplace_back([this, t]() { run(t); }); }
-	void run(uint32_t t)
-	{
-		uint64_t seen = 0;
-		while(true) {
-			std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || gen != seen; }); if(stop) return;
-			seen = gen; const char *sp = src; char *dp = dst; const size_t bytes = n; lk.unlock();
-			const size_t lo = (bytes * t / nth) & ~(size_t)63, hi = t + 1 == nth ? bytes : ((bytes * (t + 1) / nth) & ~(size_t)63);
-			if(hi > lo) memcpy(dp + lo, sp + lo, hi - lo);
-			lk.lock(); if(--left == 0) dcv.notify_all();
-		}
-	}
-	void copy(char *d, const char *sp, size_t bytes)
-	{
-		if(nth == 0 || bytes < (1u << 20)) { memcpy(d, sp, bytes); return; }
-		std::unique_lock<std::mutex> lk(mu); src = sp; dst = d; n = bytes; left = nth; gen++; cv.notify_all();
-		dcv.wait(lk, [&]() { return left == 0; });
-	}
-	~CopyPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for(auto &t : th) t.join(); }
-};
-/* the reader's side of ONE device: the way of the text into its HBM (pinned staging ring + copy threads + an upload stream) and the record scan of a stretch there */
-struct ReaderDev {
-	int dev = 0; ChunkPool *pool = nullptr; bool fastq = false, keep_qual = false;
-	hipStream_t st = nullptr, up = nullptr;          /* scan stream; upload stream */
-	static const int RING = 4; void *pin[RING] = { nullptr, nullptr, nullptr, nullptr }; hipEvent_t pev[RING] = { nullptr, nullptr, nullptr, nullptr }; size_t pin_cap = 32u << 20; uint64_t pin_k = 0;
-	CopyPool cp;
-	DBuf<uint64_t> d_ma, d_mb; DBuf<uint32_t> d_blk, d_pos, d_cum, d_flag; DBuf<TextRec> d_rec;
-	uint64_t chunk_bytes = 256ull << 20;          /* what the scan's scratch arrays are sized for from the start */
-	uint64_t n_host_scanned = 0, bytes_up = 0; double t_io = 0, t_scan = 0;
-	~ReaderDev()
-	{
-		if(st || up) (void)hipSetDevice(dev);
-		if(st) (void)hipStreamDestroy(st); if(up) (void)hipStreamDestroy(up);
-		for(int i = 0; i < RING; i++) { if(pin[i]) (void)hipHostFree(pin[i]); if(pev[i]) (void)hipEventDestroy(pev[i]); }
-		d_ma.release(); d_mb.release(); d_blk.release(); d_pos.release(); d_cum.release(); d_flag.release(); d_rec.release();
-	}
-	/* streams, staging ring, copy threads; the calling thread is on the device */
-	bool init(uint32_t copy_threads)
-	{
-		if(hipGetDevice(&dev) != hipSuccess) return false;
-		if(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess) return false;
-		for(int i = 0; i < RING; i++) { if(hipHostMalloc(&pin[i], pin_cap, hipHostMallocPortable) != hipSuccess || hipEventCreateWithFlags(&pev[i], hipEventDisableTiming) != hipSuccess) return false; }
-		cp.start(copy_threads);
-		return true;
-	}
-	/* host text -> pinned staging (the copy threads) -> HBM, 32 MB at a time on stream q; returns when the last piece has been queued (the caller waits for q) */
-	std::mutex up_mu;          /* (the uploader thread and the scan's slow way share the ring) */
-	bool upload(uint8_t *dst, const char *sp, uint64_t len, hipStream_t q)
-	{
-		const double t0 = now_ms();
-		for(uint64_t o = 0; o < len; o += pin_cap) {
-			std::lock_guard<std::mutex> lk(up_mu);
-			const size_t nb = (size_t)std::min<uint64_t>(pin_cap, len - o); const int pi = (int)(pin_k++ % RING);
-			CK(hipEventSynchronize(pev[pi]));
-			cp.copy((char *)pin[pi], sp + o, nb);
-			CK(hipMemcpyAsync(dst + o, pin[pi], nb, hipMemcpyHostToDevice, q));
-			CK(hipEventRecord(pev[pi], q));
-		}
-		bytes_up += len; t_io += now_ms() - t0;
-		return true;
-	}
-	/* records of the stretch text[at, at + len) (host copy: tx), which stands in HBM at base + skip (base 64-byte aligned, skip < 64).  Offsets come back absolute;
-	 * consumed: bytes of the stretch up to where the next one starts (all of them at the end of the text); grow: not one complete record in it */
-	bool scan(const char *tx, const uint8_t *base, uint32_t skip, uint64_t at, uint64_t len, bool last, std::vector<RRec> &recs, uint64_t &consumed, bool &grow)
-	{
-		grow = false; consumed = 0; recs.clear();
-		const double t1 = now_ms();
-		const uint32_t n = (uint32_t)(len + skip), n_words = (n + 63) / 64, n_blk = (n_words + 255) / 256;
-		/* the scratch arrays are sized for a whole stretch from the start: a buffer that grows in mid-run costs a hipFree, which waits for every stream of the device */
-		const uint64_t cap_n = std::max<uint64_t>(len + 64, chunk_bytes + 64), cap_words = (cap_n + 63) / 64, cap_blk = (cap_words + 255) / 256;
-		const uint32_t pos_cap = (uint32_t)(cap_n / 8 + 1024);
-		if(!d_ma.ensure(cap_words) || !d_mb.ensure(cap_words) || !d_cum.ensure(cap_words) || !d_blk.ensure(2 * cap_blk + 2) || !d_pos.ensure(pos_cap) || !d_flag.ensure(4)) return false;
-		ScanArgs sa; memset(&sa, 0, sizeof(sa));
-		sa.text = base; sa.n = n; sa.skip = skip; sa.fastq = fastq ? 1u : 0u; sa.ma = d_ma.p; sa.mb = d_mb.p; sa.blk = d_blk.p; sa.n_blk = n_blk; sa.pos = d_pos.p; sa.pos_cap = pos_cap; sa.cum = d_cum.p;
-		sa.last = last ? 1u : 0u; sa.keep_qual = keep_qual ? 1u : 0u; sa.flag = d_flag.p;
-		CK(hipMemsetAsync(d_flag.p, 0, 16, st));
-		if(fastq) { CK(hipMemcpyAsync(d_pos.p, &skip, 4, hipMemcpyHostToDevice, st)); CK(hipStreamSynchronize(st)); }          /* the first line starts where the stretch starts */
-		hipLaunchKernelGGL(mm_text_marks_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
-		hipLaunchKernelGGL(mm_text_blocks_kernel, dim3(1), dim3(256), 0, st, sa); CK(hipGetLastError());
-		hipLaunchKernelGGL(mm_text_emit_kernel, dim3(n_blk), dim3(256), 0, st, sa); CK(hipGetLastError());
-		uint32_t tot[2], flag[4];
-		CK(hipMemcpyAsync(tot, d_blk.p + 2 * (uint64_t)n_blk, 8, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(flag, d_flag.p, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-		bool on_host = fastq && flag[1] != 0;
-		uint32_t n_rec = 0;
-		if(!fastq) {
-			if(flag[1]) { fprintf(stderr, "[minialign_amd] reader: more record starts than one per 8 bytes in a stretch of `>' records\n"); return false; }
-			const uint32_t n_starts = tot[1];
-			n_rec = last ? n_starts : (n_starts ? n_starts - 1 : 0);
-			if(!last && n_rec == 0) { grow = true; t_scan += now_ms() - t1; return true; }
-			if(!last) { uint32_t q = 0; CK(hipMemcpyAsync(&q, d_pos.p + (n_starts - 1), 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); consumed = q - skip; } else consumed = len;
-		} else if(!on_host) {
-			/* complete lines; at the end of the text a last line without '\n' counts, and lines left over behind the last record must be empty (the reference skips them) */
-			uint64_t lines = tot[0] + ((last && len > 0 && tx[len - 1] != '\n') ? 1u : 0u);
-			n_rec = (uint32_t)(lines / 4);
-			if(!last && n_rec == 0) { grow = true; t_scan += now_ms() - t1; return true; }
-			if(!last) { uint32_t q = 0; CK(hipMemcpyAsync(&q, d_pos.p + 4 * (uint64_t)n_rec, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); consumed = q - skip; }
-			else {
-				consumed = len;
-				if(lines % 4) { std::vector<uint32_t> ls(lines % 4 + 1, (uint32_t)(len + skip)); CK(hipMemcpyAsync(ls.data(), d_pos.p + 4 * (uint64_t)n_rec, (lines % 4) * 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-					for(uint64_t q = ls[0] - skip; q < len; q++) if(tx[q] != '\n') { on_host = true; break; } }
-			}
-		}
-		if(!on_host && n_rec) {
-			if(!d_rec.ensure(std::max<uint64_t>(n_rec, d_rec.n ? 0 : chunk_bytes / 4096))) return false;          /* (room for reads of 4 kb and more from the start) */
-			sa.rec = d_rec.p; sa.n_rec = n_rec;
-			if(fastq) hipLaunchKernelGGL(mm_text_fastq_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, st, sa); else hipLaunchKernelGGL(mm_text_fasta_kernel, dim3((n_rec + 255) / 256), dim3(256), 0, st, sa);
-			CK(hipGetLastError());
-			std::vector<TextRec> tr(n_rec);
-			CK(hipMemcpyAsync(tr.data(), d_rec.p, (size_t)n_rec * sizeof(TextRec), hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(flag, d_flag.p, 16, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
-			if(fastq && flag[0]) on_host = true;
-			else { const uint64_t o = at - skip; recs.resize(n_rec); for(uint32_t i = 0; i < n_rec; i++) { const TextRec &q = tr[i]; recs[i] = RRec{ o + q.start, o + q.hdr_end, o + q.t_off, q.t_len, q.n_bases, o + q.q_off, q.q_len }; } }
-		}
-		if(on_host) {
-			/* a FASTQ stretch in another shape than four lines per record: the sequential reader, over the host's copy of the same bytes */
-			recs.clear(); uint64_t used = 0;
-			if(!host_find_fastq(tx, len, last, keep_qual, recs, used)) { fprintf(stderr, "[minialign_amd] broken FASTQ record\n"); return false; }          /* the reference gives up on the run (exit 1) */
-			if(!last && recs.empty()) { grow = true; t_scan += now_ms() - t1; return true; }
-			for(RRec &q : recs) { q.start += at; q.hdr_end += at; q.t_off += at; q.q_off += at; }
-			consumed = last ? len : used; n_host_scanned += recs.size();
-		}
-		t_scan += now_ms() - t1;
-		return true;
-	}
-};
-/* The reader of a query text over the devices of a context.  The text is cut into PIECES at fixed byte offsets (the first ones 64 MB, then 256 MB; piece s goes to device
- * s mod N), so every device's uploader thread brings its pieces to HBM without waiting for anybody -- record boundaries are found afterwards, by the scan, in order:
- * the stretch that piece s closes starts where the scan of the stretch before it stopped (the record that was cut by the boundary), and those few bytes -- the tail
- * of piece s - 1 -- are put in FRONT of piece s in its buffer (every buffer keeps `prefix` bytes of room there), so that the stretch is contiguous in the HBM of the
- * device that scans and packs it.  The sequential part of the reader is thereby the scan alone (four short launches and a few words of D2H per stretch); the uploads
- * run side by side, one PCIe link each.  A record longer than the room in front (or than a piece) takes the slow way: its stretch goes up again as a whole.
- * Batches are cut from the records as before; with several devices a batch never holds reads of two stretches on different devices. */
-struct TextReader {
-	std::shared_ptr<TextSrc> src; uint32_t min_len = 1; bool keep_qual = false; int lanes = 4;
-	std::vector<mm_align_t *> dctx;          /* the device slots of the engine: one primary context each (set by the caller) */
-	std::vector<ReaderDev *> rdev;
-	uint64_t chunk_bytes = 256ull << 20, prefix = 1ull << 20;
-	std::vector<uint64_t> B;          /* piece s = text[B[s], B[s + 1]) */
-	struct PieceSt { DevChunk *c = nullptr; int state = 0; };          /* 0 untouched, 1 in HBM, 2 failed, 3 not wanted (its stretch went the slow way), 4 on its way */
-	std::vector<PieceSt> pieces;
-	std::mutex mu; std::condition_variable cv;
-	uint32_t scanned = 0;          /* pieces the scan is done with: the uploaders stay at most `ahead` pieces per device in front of it */
-	static const uint32_t ahead = 2;
-	std::vector<std::deque<mm_batch_t *>> ready; uint32_t n_cut = 0; bool done = false, failed = false, stop = false;
-	uint64_t max_bases = 300000000ull, cap_bases = 1000000000ull; uint32_t longest = 0;          /* cap_bases: what the device memory allows (batch_cap_bases) */
-	std::vector<std::thread> th;
-	mm_batch_t *cur = nullptr; uint64_t cur_bases = 0; int cur_slot = 0;
-	uint64_t n_records = 0, n_host_scanned = 0, n_stretches = 0, n_slow = 0; double t_start = 0;
-
-	~TextReader()
-	{
-		{ std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all();
-		for(auto &t : th) if(t.joinable()) t.join();
-		for(auto &q : ready) for(mm_batch_t *h : q) delete h;
-		delete cur;
-		for(size_t i = 0; i < pieces.size(); i++) if(pieces[i].c) { rdev[i % rdev.size()]->pool->put(pieces[i].c); pieces[i].c = nullptr; }
-		for(ReaderDev *r : rdev) delete r;
-	}
-	void push_batch()
-	{
-		if(!cur) return;
-		mm_batch_t *h = cur; cur = nullptr; cur_bases = 0;
-		std::unique_lock<std::mutex> lk(mu);
-		cv.wait(lk, [&]() { return stop || ready[cur_slot].size() < (size_t)lanes + 2; });          /* not further ahead of the lanes of that device than this */
-		if(stop) { delete h; return; }
-		h->k = n_cut++; ready[cur_slot].push_back(h); lk.unlock(); cv.notify_all();
-	}
-	void add(const RRec &r, const std::shared_ptr<DevChunk> &ch, int slot)
-	{
-		if(r.n_bases < min_len) return;          /* -L (minialign.c:2077) */
-		if(r.n_bases > longest) { longest = r.n_bases; if(!getenv("MM_BATCH_BASES")) max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(cap_bases, (uint64_t)longest * MM_BATCH_PER_LONGEST)); }
-		if(cur && (slot != cur_slot || cur->b.lens.size() >= (1u << 17) || (cur_bases && cur_bases + r.n_bases > max_bases))) push_batch();
-		if(!cur) { cur = new mm_batch_s(); cur->b.tsrc = src; cur_slot = slot; }
-		Batch &b = cur->b;
-		if(b.dch.empty() || b.dch.back().ch != ch) b.dch.push_back(Batch::Piece{ ch, (uint32_t)b.lens.size(), 0 });
-		b.dch.back().n++; b.lens.push_back(r.n_bases); b.trec.push_back(r); cur_bases += r.n_bases;
-	}
-	/* the uploader of device slot di: its pieces in order, each into a buffer with `prefix` bytes of room in front */
-	void upload_main(int di)
-	{
-		ReaderDev *R = rdev[di]; const uint32_t nd = (uint32_t)rdev.size();
-		bool ok = hipSetDevice(R->dev) == hipSuccess;
-		for(uint32_t s = (uint32_t)di; s + 1 < B.size(); s += nd) {
-			{
-				std::unique_lock<std::mutex> lk(mu);
-				cv.wait(lk, [&]() { return stop || s < scanned + ahead * nd; });
-				if(stop) return;
-				if(pieces[s].state == 3) continue;
-				pieces[s].state = 4;
-			}
-			const uint64_t len = B[s + 1] - B[s];
-			DevChunk *c = ok ? R->pool->get(prefix + std::max<uint64_t>(chunk_bytes, (len + 63) & ~63ull) + 128) : nullptr;
-			bool up = c != nullptr;
-			if(up) { c->off = B[s] - prefix; c->n = 0; up = R->upload(c->d + prefix, src->p + B[s], len, R->up) && hipStreamSynchronize(R->up) == hipSuccess; }
-			{ std::lock_guard<std::mutex> lk(mu); pieces[s].c = c; pieces[s].state = up ? 1 : 2; }
-			cv.notify_all();
-		}
-	}
-	/* waits for piece s to be in HBM (or settled otherwise); its state */
-	int piece_wait(uint32_t s) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return stop || (pieces[s].state != 0 && pieces[s].state != 4); }); return stop ? 2 : pieces[s].state; }
-	void run()
-	{
-		const uint32_t nd = (uint32_t)rdev.size(), n_pieces = (uint32_t)B.size() - 1;
-		bool ok = true; uint64_t at = src->first; uint32_t s = 0;
-		while(ok && at < src->n && s < n_pieces) {
-			{ std::lock_guard<std::mutex> lk(mu); if(stop) break; }
-			uint32_t e = s + 1, span = 1; int slot = 0;
-			std::vector<RRec> recs; uint64_t consumed = 0; std::shared_ptr<DevChunk> ch;
-			while(ok) {
-				const uint64_t end = B[e], len = end - at; const bool last = end == src->n; bool grow = false;
-				if(len + 64 > 0x7fff0000ull) { fprintf(stderr, "[minialign_amd] reader: a record of more than 2 GB\n"); ok = false; break; }
-				if(e == s + 1 && B[s] - at <= prefix) {
-					/* the common way: piece s is (being) brought up by its device's uploader; the bytes of the record its boundary cut go in front of it */
-					slot = (int)(s % nd); ReaderDev *R = rdev[slot];
-					if(piece_wait(s) != 1 || hipSetDevice(R->dev) != hipSuccess) { ok = false; break; }
-					DevChunk *c = pieces[s].c; const uint64_t tail = B[s] - at;
-					if(tail && (hipMemcpyAsync(c->d + prefix - tail, src->p + at, tail, hipMemcpyHostToDevice, R->st) != hipSuccess || hipStreamSynchronize(R->st) != hipSuccess)) { ok = false; break; }
-					const uint64_t o = prefix - tail;
-					ok = R->scan(src->p + at, c->d + (o & ~63ull), (uint32_t)(o & 63), at, len, last, recs, consumed, grow);
-					if(ok && !grow) { pieces[s].c = nullptr; ChunkPool *pl = R->pool; ch = std::shared_ptr<DevChunk>(c, [pl](DevChunk *q) { pl->put(q); }); }
-				} else {
-					/* the slow way (a record longer than the room in front of a piece, or than a piece): what the uploaders brought or will bring of pieces s .. e - 1 is not
-					 * wanted, the stretch goes up as a whole on the device of its last piece */
-					for(uint32_t j = s; j < e; j++) {
-						{ std::lock_guard<std::mutex> lk(mu); if(pieces[j].state == 0) { pieces[j].state = 3; continue; } if(pieces[j].state == 3) continue; }
-						(void)piece_wait(j);
-						if(pieces[j].c) { rdev[j % nd]->pool->put(pieces[j].c); pieces[j].c = nullptr; }
-					}
-					slot = (int)((e - 1) % nd); ReaderDev *R = rdev[slot]; n_slow++;
-					if(hipSetDevice(R->dev) != hipSuccess) { ok = false; break; }
-					DevChunk *c = R->pool->get(((len + 63) & ~63ull) + 128);
-					if(!c) { ok = false; break; }
-					c->off = at; c->n = 0;
-					ok = R->upload(c->d, src->p + at, len, R->st) && hipStreamSynchronize(R->st) == hipSuccess && R->scan(src->p + at, c->d, 0, at, len, last, recs, consumed, grow);
-					if(ok && !grow) { ChunkPool *pl = R->pool; ch = std::shared_ptr<DevChunk>(c, [pl](DevChunk *q) { pl->put(q); }); } else { R->pool->put(c); }
-				}
-				if(!ok || !grow) break;
-				if(e == n_pieces) { ok = false; break; }          /* (cannot happen: the stretch that ends the text is complete by definition) */
-				e = std::min<uint32_t>(n_pieces, e + span); span *= 2;          /* a record longer than the stretch: more pieces */
-			}
-			if(!ok) break;
-			n_stretches++; n_records += recs.size();
-			for(const RRec &r : recs) add(r, ch, slot);
-			if(consumed == 0) { ok = false; break; }
-			at += consumed; s = e;
-			{ std::lock_guard<std::mutex> lk(mu); scanned = s; } cv.notify_all();
-			if(nd > 1) push_batch();          /* several devices: the next stretch is another device's */
-		}
-		if(ok) push_batch();
-		{ std::lock_guard<std::mutex> lk(mu); done = true; failed = !ok; }
-		cv.notify_all();
-		for(ReaderDev *R : rdev) n_host_scanned += R->n_host_scanned;
-		if(getenv("MM_VERBOSE")) {
-			double io = 0, sc = 0; uint64_t up = 0; for(ReaderDev *R : rdev) { io += R->t_io; sc += R->t_scan; up += R->bytes_up; }
-			fprintf(stderr, "[minialign_amd] reader: %lu records in %lu stretches on %u device(s) (%lu the slow way; %lu records through the host's sequential FASTQ reader), %.2f GB of text to HBM in %.1f ms of uploader time (%.1f GB/s per uploader), scans %.1f ms, done %.1f ms after the start\n",
-				(unsigned long)n_records, (unsigned long)n_stretches, nd, (unsigned long)n_slow, (unsigned long)n_host_scanned, up * 1e-9, io, io > 0 ? up * 1e-6 / io : 0.0, sc, now_ms() - t_start);
-		}
-	}
-	bool start()
-	{
-		if(dctx.empty()) return false;
-		if(const char *e = getenv("MM_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) & ~63ull;          /* test hook: small stretches */
-		prefix = std::min<uint64_t>(1ull << 20, chunk_bytes);
-		const uint32_t nd = (uint32_t)dctx.size();
-		/* copy threads per device: the staging copy wants a handful of cores (a core copies 5 - 10 GB/s; PCIe takes 50) */
-		const uint32_t hw = std::max<uint32_t>(1, std::thread::hardware_concurrency());
-		const uint32_t cpt = std::max<uint32_t>(2, std::min<uint32_t>(12, hw / (4 * nd)));
-		int cur_dev = 0; (void)hipGetDevice(&cur_dev);
-		for(uint32_t d = 0; d < nd; d++) {
-			mm_align_t *P = dctx[d];
-			if(!P->chunk_pool) P->chunk_pool = new ChunkPool();
-			ReaderDev *R = new ReaderDev(); rdev.push_back(R);
-			R->pool = P->chunk_pool; R->fastq = src->delim == '@'; R->keep_qual = keep_qual; R->chunk_bytes = chunk_bytes + prefix;
-			if(hipSetDevice(P->dev) != hipSuccess || !R->init(cpt)) { (void)hipSetDevice(cur_dev); return false; }
-		}
-		(void)hipSetDevice(cur_dev);
-		ready.resize(nd);
-		/* batch size as batch_spans: 300 Mb; a text smaller than lanes x that (per device) is cut into one and a half batches per lane (its bases are a little fewer than its bytes) */
-		const uint64_t all_lanes = (uint64_t)lanes * nd;
-		if(getenv("MM_BATCH_BASES")) max_bases = (uint64_t)atoll(getenv("MM_BATCH_BASES"));
-		else if(src->n < all_lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, src->n / (all_lanes + all_lanes / 2) + (1ull << 20));          /* (an eighth of the headline set maps in 313 ms in six batches, 366 in four) */
-		/* pieces: the first three per device short (64 MB), so that the first lanes have a batch to work on early; several devices: no longer than a batch */
-		uint64_t first_len = std::min<uint64_t>(chunk_bytes, 64ull << 20), later_len = chunk_bytes;
-		if(nd > 1 && !getenv("MM_CHUNK_BYTES")) { later_len = std::min<uint64_t>(later_len, std::max<uint64_t>(1ull << 20, max_bases)); first_len = std::min(first_len, later_len); }
-		B.push_back(src->first);
-		while(B.back() < src->n) { const uint64_t ln = (B.size() - 1 < 3ull * nd) ? first_len : later_len; B.push_back(std::min<uint64_t>(src->n, B.back() + ln)); }
-		pieces.assign(B.size() - 1, PieceSt());
-		t_start = now_ms();
-		for(uint32_t d = 0; d < nd; d++) th.emplace_back([this, d]() { upload_main((int)d); });
-		th.emplace_back([this]() { run(); });
-		return true;
-	}
-	/* the next batch of device slot di (lanes of a device ask in order); its number in the order of the text in h->k; NULL when the text has no more for this device,
-	 * *err when the reader failed */
-	mm_batch_t *take(int di, bool *err)
-	{
-		std::unique_lock<std::mutex> lk(mu);
-		cv.wait(lk, [&]() { return done || !ready[di].empty(); });
-		if(ready[di].empty()) { if(failed && err) *err = true; return nullptr; }
-		mm_batch_t *h = ready[di].front(); ready[di].pop_front();
-		lk.unlock(); cv.notify_all();
-		batch_pack(h->b, false);
-		return h;
-	}
-};
-} /* anonymous */
+#include "host_reader.hpp"
 /* the reference through the device reader: its text in stretches of 1 GB to HBM, records found there, bases converted and packed there into ONE arena (every sequence
  * on a multiple of 64 bases, N in between); names from the header lines; nothing of a sequence's bases is touched by the host (ref_codes makes codes for the few host
  * consumers on demand) */
