@@ -205,7 +205,7 @@ gaba_t *gaba_init(gaba_params_t const *params)
 	/* single-v_perm lookup (gaba_device.hpp:step): rows of the table per a code, one score for a b side N */
 	{
 		const int8_t *sb = (const int8_t *)c.sb;
-		c.fast_score = sb[2] == sb[3] && sb[2] == sb[6];
+		c.fast_score = (sb[2] == sb[3] && sb[2] == sb[6]) ? 1 : 2;          /* (2: the entries a b side N reads -- sb[a | 2] -- differ: blocks with such an N take the general lookup, fill_block) */
 		c.score_n = sb[2];
 		for(int a = 0; a < 5; a++) {
 			uint32_t row = 0;

@@ -87,8 +87,9 @@ struct Consts {
 	int32_t tx;
 	int32_t gi, ge, gfa, gfb;
 	double imx, xmx;
-	/* single-v_perm score lookup (see step()): usable when sb[a | 2] (the score against a b side N) is one value for all a */
-	int32_t fast_score;  /* 0 / 1 */
+	/* single-v_perm score lookup (see step()): 1 = sb[a | 2] (the score against a b side N) is one value for all a: every block; 2 = it is not: every block that sees
+	 * no N on the b side (fill_block) */
+	int32_t fast_score;
 	int32_t score_n;     /* sb[a | 2] (selector 4 reads its byte 0) */
 	uint32_t arow[5];    /* arow[a] = { sb[a | 0], sb[a | 4], sb[a | 8], sb[a | 12] } for a = 0..3, N */
 };
@@ -206,7 +207,7 @@ __device__ __forceinline__ uint32_t slab_alloc(Ctx &x, uint32_t bytes)
  *    the wrapping int8 add and v_sub_i32 + clamp is the saturating int8 subtract (_subs_n), and t is produced in the same
  *    position by an SDWA `dst_sel:BYTE_3` subtract;
  *  - score lookup, general form: the 16-entry byte table sits in four VGPRs, two v_perm_b32 + a select on bit 3.  Fast form
- *    (Consts.fast_score: all entries of one sign and one common score against a `b` side N): the `a` window carries, per
+ *    (Consts.fast_score; blocks that see a `b` side N take the general form unless the table has one score for that case): the `a` window carries, per
  *    lane, the four scores of its base against b = A, C, G, T as one dword, the `b` window carries a v_perm selector, and
  *    the lookup is a single v_perm_b32;
  *  - compares write SGPR pairs, the mask algebra of the COMBINED model runs on the scalar unit, and each of the four
@@ -522,10 +523,7 @@ template<int MODEL, bool WIDE, bool FAST, bool bounded, bool TRACE>
 __device__ __forceinline__ uint32_t fill_block_t(Ctx &x, Work &w, FillState &f, uint32_t prev_off, uint32_t blk_off, bool cont)
 {
 	const Consts &c = x.c;
-	const StepK sk = step_consts(c, w.W);
-	uint32_t alen = BLK, blen = BLK;
-	if(bounded) { alen = min(w.rem[0], (uint32_t)BLK); blen = min(w.rem[1], (uint32_t)BLK); }
-	fetch_look(x, w, f, alen, blen);
+	const StepK sk = step_consts(c, w.W);          /* (the look-ahead of the block is in f.look: fill_block fetched it) */
 	if(cont) {
 		/* the previous block was filled by this wave a moment ago and its diff vectors are still in the registers: what
 		 * _fill_load_context (gaba.c:1527) would read back is what is here (acc went through its int8 slot) -- no HBM round trip */
@@ -579,7 +577,13 @@ __device__ __forceinline__ uint32_t fill_block(Ctx &x, Work &w, FillState &f, ui
 	 * 32-vector loop once per block */
 	/* the root windows hold two special codes (a = 0x0c, b = 0x03: gaba.c:3739 phantom block) that the row / selector
 	 * encoding cannot express: blocks that still see them take the general lookup (the first one or two after a root) */
-	const bool special = __ballot(x.lane < w.W && (f.b.ach > 4 || ((f.b.bch & 3) != 0 && f.b.bch != 2))) != 0;
+	uint32_t alen = BLK, blen = BLK;
+	if(bounded) { alen = min(w.rem[0], (uint32_t)BLK); blen = min(w.rem[1], (uint32_t)BLK); }
+	fetch_look(x, w, f, alen, blen);
+	bool special = __ballot(x.lane < w.W && (f.b.ach > 4 || ((f.b.bch & 3) != 0 && f.b.bch != 2))) != 0;
+	/* a score table whose entries against a b side N differ by a (Consts.fast_score == 2: the ONT presets' 4 x 4 matrices): the single-v_perm lookup has ONE score for
+	 * that case, so a block that sees an N on the b side -- in the window, or among the 32 bases it may take in -- goes the general way; reads carry Ns rarely */
+	if(x.c.fast_score == 2) { special = special || __ballot((x.lane < w.W && f.b.bch == 2) || (x.lane >= 32 && f.look == 2)) != 0; }
 	const bool wide = w.W == 64, fast = x.c.fast_score != 0 && !special;
 	#define GABA_PICK2(_m, _tr) \
 		( wide ? (fast ? fill_block_t<_m, true, true, bounded, _tr>(x, w, f, prev_off, blk_off, cont) : fill_block_t<_m, true, false, bounded, _tr>(x, w, f, prev_off, blk_off, cont)) \
