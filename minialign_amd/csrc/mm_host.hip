@@ -524,6 +524,9 @@ bool lane_d2h(mm_align_t *a, void *dst, const void *src, size_t n)
 }
 bool lane_h2d(mm_align_t *a, void *dst, const void *src, size_t n)
 {
+	/* (K4 of the extension launch in front may still be walking the states and pools on its side stream: whatever goes up -- the states of the reads a carried-value
+	 * re-run maps again, batch_verify_carry -- goes up behind it) */
+	if(a->k4_pending) { CK(hipStreamWaitEvent(a->stream, a->k4e, 0)); }
 	void *st = lane_stage(a, n);
 	if(!st) { CPY(a, dst, src, n, hipMemcpyHostToDevice); return true; }
 	memcpy(st, src, n); CPY(a, dst, st, n, hipMemcpyHostToDevice); return true;
