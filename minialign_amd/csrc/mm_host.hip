@@ -793,7 +793,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 		k3.rq_helper_mask = 127u;          /* one wave in 128 is a helper: 4.17 / 4.40 / 4.56 G bases/s with one in 8 / 32 / 128 (4.45 without) when helpers were the waves that had run out of reads -- the launch is 13 % shorter with any of them, but a helper holds a wave slot the other lanes' short kernels wait for; as helpers from the start, one in 8 / 16 / 32 on the ONT-like set: 2.37 / 2.34 / 2.46 against 2.7 - 2.9 */
 		/* (any number of workspace classes, any number of workspaces: a helper takes the workspace a job needs before it claims the job and without waiting, K3_TRY_SLAB, so the
 		 * wave that waits for a claimed job waits for one that is running; on the ONT-like set the reads that decide the launch are 60 - 160 kb long with 9 - 27 trials for
-		 * one alignment, tools/read_cost.py) */
+		 * one alignment, profiles/round3_ont_read_cost.txt) */
 		/* (a launch of a few reads -- the re-runs of the carried-value check -- has them too, with a helper in every workgroup: one read inside a repeat family alone on a launch
 		 * walked its hundreds of chains on one wave for a second while the lanes behind it waited for their turn at the carried value) */
 		/* (... when one of its reads walked many chains the last time: a launch of 256 workgroups ends when the last of them has had its turn at a wave slot, and the lanes
