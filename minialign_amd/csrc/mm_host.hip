@@ -410,6 +410,21 @@ void sketch_host_circular(const uint8_t *seq, uint32_t len, uint32_t k_, uint32_
  * device context + batch pipeline
  * ============================================================================================= */
 
+/* What a batch will leave as the carried reference length, as far as its chains tell (the prediction run_rounds hands from read to read inside a batch), posted by the lane
+ * that has the batch as soon as its chaining is through, for the lane with the NEXT batch: that one's first read otherwise starts with the value the stream had when the batch
+ * was taken -- three or four batches back, the wrong contig's length 24 times out of 25 -- and whenever that flips its `apos >= rlen` test the read is mapped again in a launch
+ * of its own behind the check, with every lane behind waiting (12 of the 43 batches of a headline step, 55 - 120 ms each).  A guess like any other: batch_verify_carry checks it. */
+struct PredBoard {
+	std::mutex mu; std::condition_variable cv; std::unordered_map<uint32_t, uint32_t> out; uint32_t gone_below = 0; std::unordered_map<uint32_t, bool> gone;
+	void post(uint32_t k, uint32_t v) { { std::lock_guard<std::mutex> lk(mu); out[k] = v; } cv.notify_all(); }
+	void leave(uint32_t k) { { std::lock_guard<std::mutex> lk(mu); gone[k] = true; } cv.notify_all(); }          /* batch k will post nothing (split, failed) */
+	/* the value batch k posted; false when it has not within `ms` (or never will): the caller keeps its own guess */
+	bool get(uint32_t k, uint32_t *v, int ms) {
+		std::unique_lock<std::mutex> lk(mu);
+		cv.wait_for(lk, std::chrono::milliseconds(ms), [&]() { return out.count(k) != 0 || gone.count(k) != 0; });
+		auto it = out.find(k); if(it == out.end()) return false; *v = it->second; return true;
+	}
+};
 struct mm_align_s {
 	mm_opt_s o; const mm_idx_s *mi;
 	gaba_t *gctx;
@@ -447,6 +462,7 @@ struct mm_align_s {
 	DBuf<uint32_t> pring[MAX_CLS]; DBuf<unsigned long long> pctr[MAX_CLS]; uint32_t slab_lanes = 0; int lane_ix = 0;          /* the lanes' own rings of every class (K3Class.pring / pctr: lane-major); lanes the workspaces were made for; this context's place among the lanes of its device */ uint32_t slab_total = 0; uint64_t slab_max = 0;
 	DBuf<unsigned long long> d_tops;       /* [0] seed [1] resc [2] root [3] bin [4] aln [5] seg [6] path [8..16) stats [16] counter */
 	uint32_t rlen_carry = 0;               /* self->rlen of the reference's thread buffer, carried across reads (and batches) */
+	struct PredBoard *pred = nullptr; uint32_t pred_k = 0;          /* the streaming engine's board of predicted carried values and the number of the batch this lane has in hand (stream_map; NULL: none) */
 	/* reusable host buffers of the streaming engine (primary context only): pinned result buffers for the D2H of a batch, text pieces with their capacity */
 	struct PinSet { void *p[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; size_t cap[7] = { 0, 0, 0, 0, 0, 0, 0 };
 		void *get(int i, size_t bytes) { if(bytes > cap[i]) { if(p[i]) (void)hipHostFree(p[i]); p[i] = nullptr; cap[i] = 0; size_t want = bytes + bytes / 4 + (1u << 20); if(hipHostMalloc(&p[i], want, hipHostMallocPortable) != hipSuccess) return nullptr; cap[i] = want; } return p[i]; }          /* (portable: a set is pooled on the first context and handed to lanes of any device) */
@@ -684,6 +700,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 				std::vector<uint8_t> in_work(n_reads, 0); for(uint32_t wi : work) in_work[wi] = 1;
 				const double weak_unit = 128 * 2.0 * (double)a->o.min_score / a->mcoef;          /* (the factor measured at 0 / 128 / 256 / 384 / 1 024 in round 5: HISTORY.md) */
 				uint32_t cur = a->rlen_carry, src = gaba::NIL;          /* src: the source read that decides the value at hand */
+				if(a->pred && a->pred_k > 0) { uint32_t pv; if(a->pred->get(a->pred_k - 1, &pv, 100)) { cur = pv; } }          /* (what the batch in front expects to leave: PredBoard) */
 				a->ran_with.resize(n_reads);
 				if(getenv("MM_VERBOSE")) { a->np0.resize(n_reads); a->wp0.resize(n_reads); for(uint32_t i = 0; i < n_reads; i++) { a->np0[i] = hst[i].n_pass; a->wp0[i] = hst[i].w_pass; } }
 				for(uint32_t i = 0; i < n_reads; i++) {
@@ -699,6 +716,7 @@ bool run_rounds(mm_align_t *a, uint32_t n_reads, const std::vector<uint32_t> &wo
 					}
 					else if(deps && hst[i].n_resc > 0 && !hst[i].err) { hst[i].flags = RS_CARRY_SRC; src = i; }
 				}
+				if(a->pred) { a->pred->post(a->pred_k, cur); }
 			}
 			for(uint32_t wi : work) { hst[wi].apos0 = gaba::NIL; hst[wi].cond0 = 0; hst[wi].rid_last = gaba::NIL; hst[wi].bin_off = ~0ull; hst[wi].n_bin = 0; hst[wi].n_aln = 0; hst[wi].n_res = 0; }
 			if(!lane_h2d(a, a->d_st.p, hst.data(), (uint64_t)n_reads * sizeof(ReadState))) return false;
@@ -2114,6 +2132,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 	struct Item { mm_batch_t *h = nullptr; Fetched f; std::vector<std::string> piece; std::vector<std::vector<uint32_t>> roff; bool split = false; uint32_t k = 0; };
 	std::mutex mu; std::condition_variable cv;
 	uint32_t verified = 0, next_write = 0, pending = 0; uint32_t carry = a->rlen_carry; int rc = 0;
+	PredBoard board;          /* what each batch expects to leave as the carried value, for the first read of the batch behind it */
 	std::vector<Item *> fetched;                       /* waiting for a finisher */
 	std::map<uint32_t, Item *> formatted;              /* waiting for the writer */
 	uint32_t lanes_done = 0, fin_done = 0; bool head_open = true;
@@ -2161,7 +2180,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 			{
 				h->ctx = c; Batch &b = h->b;
 				if(!b.packed) batch_pack(b, false);
-				c->rlen_carry = guess;
+				c->rlen_carry = guess; c->pred = &board; c->pred_k = k;
 				ok = batch_upload(c, b);
 				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): pack + upload %.1f ms (at %.1f)\n", k, di, li, now_ms() - tv, now_ms() - t_engine0); tv = now_ms(); }
 				/* run ahead with the predicted carry; pools that overflow are grown here, before anybody waits for this batch */
@@ -2171,6 +2190,7 @@ static int stream_map(mm_align_t *a, uint32_t n_batches, const BatchSource &sour
 				if(!ok && b.n >= 2) { fprintf(stderr, "[minialign_amd] batch %u: its pools do not fit the device, mapped in halves\n", k); ok = true; split = true; }
 				while(ok && !split) { int r = batch_run_spec(c, b); if(r == 0) break; if(r < 0) ok = false; else if(r == 2) { if(!batch_upload(c, b)) ok = false; } else if(!batch_grow(c, b)) split = true; else if(!batch_upload(c, b)) { if(b.n >= 2) { split = true; } else { ok = false; } } }
 				if(verbose) { fprintf(stderr, "[minialign_amd] batch %u (device %d lane %d): run %.1f ms (at %.1f): sketch %.1f, sort + chain %.1f, extension %.1f ms on the device, the rest the host's turns in between\n", k, di, li, now_ms() - tv, now_ms() - t_engine0, c->st.k1_ms - k1_0, c->st.k2_ms - k2_0, c->st.k3_ms - k3_0); tv = now_ms(); }
+				c->pred = nullptr; board.leave(k);          /* (from here on the lane runs with the true value; a batch that has posted nothing by now -- one that goes in halves -- will not) */
 				uint32_t truth = 0;
 				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return verified == k || rc != 0; }); if(rc) ok = false; truth = carry; }
 				while(ok && !split) {
