@@ -384,6 +384,10 @@ struct TextReader {
 		const uint64_t all_lanes = (uint64_t)lanes * nd;
 		if(getenv("MM_BATCH_BASES")) max_bases = (uint64_t)atoll(getenv("MM_BATCH_BASES"));
 		else if(src->n < all_lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, src->n / (all_lanes + all_lanes / 2) + (1ull << 20));          /* (an eighth of the headline set maps in 313 ms in six batches, 366 in four) */
+		/* ... and a text of more than five batches per lane gets larger ones, up to 500 Mb: every batch ends in the tail of its extension launch, and since the first read of a batch
+		 * starts from the value the batch in front predicts (PredBoard) nothing is gained from many small ones -- the headline set: 4.44 / 4.54 G bases/s at 300 Mb, 4.59 / 4.60 at
+		 * 400, 4.65 / 4.68 at 500, 4.59 at 600 (profiles/round6_batch_size.txt) */
+		else { const uint64_t est_bases = src->delim == '@' ? src->n / 2 : src->n; max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(std::min<uint64_t>(500000000ull, std::max<uint64_t>(max_bases, cap_bases)), est_bases / (all_lanes * 5))); }
 		/* pieces: the first three per device short (64 MB), so that the first lanes have a batch to work on early; several devices: no longer than a batch */
 		uint64_t first_len = std::min<uint64_t>(chunk_bytes, 64ull << 20), later_len = chunk_bytes;
 		if(nd > 1 && !getenv("MM_CHUNK_BYTES")) { later_len = std::min<uint64_t>(later_len, std::max<uint64_t>(1ull << 20, max_bases)); first_len = std::min(first_len, later_len); }

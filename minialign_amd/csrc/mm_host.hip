@@ -2362,7 +2362,7 @@ static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *
 {
 	const uint32_t max_reads = 1u << 17;
 	const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)first + n, reads->r.size());
-	/* 300 Mb per batch: on the whole hg38-size x3 set anything between 250 and 512 Mb measures the same, on an eighth or a quarter of it (one rank's shard of
+	/* 300 Mb per batch (up to 500 Mb for sets of more than five batches per lane): on the whole hg38-size x3 set anything between 250 and 512 Mb measured the same until round 6, on an eighth or a quarter of it (one rank's shard of
 	 * the multi-GPU job) the smaller batches give every lane one and are 8 - 13 % faster; a set smaller than lanes x 300 Mb is cut into one batch per lane, not
 	 * below 64 Mb.  A set with very long reads wants larger batches: an extension launch lasts at least as long as its longest read (one wave, ~0.8 us per base), and
 	 * every batch pays that tail again -- 1 700 bases of batch per base of the longest read (ONT-like set, longest read 385 kb: round 2 measured 2.40 s per step at 300 Mb,
@@ -2375,6 +2375,7 @@ static std::vector<std::pair<uint32_t, uint32_t>> batch_spans(mm_reads_t const *
 		max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(700000000ull, longest * MM_BATCH_PER_LONGEST));
 		const uint64_t lanes = (uint64_t)default_lanes();
 		if(total < lanes * max_bases) max_bases = std::max<uint64_t>(64ull << 20, total / (lanes + lanes / 2) + (1ull << 20));
+		else max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(500000000ull, total / (lanes * 5)));          /* (more than five batches per lane: larger ones, as the text reader cuts them -- TextReader::start) */
 	}
 	std::vector<std::pair<uint32_t, uint32_t>> sp;
 	for(uint32_t i = first; i < end;) {
