@@ -275,6 +275,7 @@ def main():
     mi = ctypes.c_void_p(L.mm_idx_gen(o, ref_fa.encode())); assert mi
     al = ctypes.c_void_p(L.mm_align_init(o, mi)); assert al, 'mm_align_init failed (no GPU?)'
     t_index = time.time() - t0
+    L.mm_idx_occ.restype = ctypes.c_uint32; L.mm_idx_occ.argtypes = [ctypes.c_void_p, ctypes.c_uint32]; idx_occ = [int(L.mm_idx_occ(mi, i)) for i in range(3)]
     assert L.mm_align_devices(al) == n_inproc, 'the context spans %d device(s), %d were asked for' % (L.mm_align_devices(al), n_inproc)
     # this rank's shard: parts [p0, p1) of the set (PARTS is a multiple of every N the driver uses; otherwise the split is by parts, as even as it gets)
     p0, p1 = multi.shard_bounds(PARTS, rank, world)
@@ -368,7 +369,7 @@ def main():
                        'd2h_bytes_per_step (result pools + CIGAR text made on the device, rank 0)': st.d2h_bytes / K, 'cigar_text_bytes_per_step (made on the device, rank 0)': st.cigar_bytes_device / K,
                        'reader_gb_per_s (text to HBM, per uploader thread while it copies; one uploader per device)': (st.text_bytes * 1e-6 / st.reader_ms) if st.reader_ms > 0 else None,
                        'carried_value': {'checks': n_checks, 'remapped_reads': n_remap, 'full_remaps': n_full},
-                       'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'text_load_s (outside)': t_load, 'host_parse_and_pack_s (value_from_packed only)': t_pack},
+                       'sam_bytes_per_step': total_sam, 'generate_s': t_gen, 'index_build_s': t_index, 'index_occurrence_thresholds (minialign.c:2951: what -f makes of the reference)': idx_occ, 'text_load_s (outside)': t_load, 'host_parse_and_pack_s (value_from_packed only)': t_pack},
             'roofline': {'bound': 'hbm', 'kernel': 'mm_extend_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': pmc_traffic(args.workload if not custom else 'custom', n_gpus, alg_bytes / max(1.0, k3_launches)),
                          'alg_bytes_per_launch': alg_bytes / max(1.0, k3_launches), 'avg_launch_ms': k3_launch_ms, 'launches': k3_launches,

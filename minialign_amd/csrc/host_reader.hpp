@@ -247,7 +247,7 @@ struct TextReader {
 	uint32_t scanned = 0;          /* pieces the scan is done with: the uploaders stay at most `ahead` pieces per device in front of it */
 	static const uint32_t ahead = 2;
 	std::vector<std::deque<mm_batch_t *>> ready; uint32_t n_cut = 0; bool done = false, failed = false, stop = false;
-	uint64_t max_bases = 300000000ull, cap_bases = 1000000000ull; uint32_t longest = 0;          /* cap_bases: what the device memory allows (batch_cap_bases) */
+	uint64_t max_bases = 300000000ull, cap_bases = 1000000000ull; uint32_t longest = 0; bool repeat_rich = false;          /* cap_bases: what the device memory allows (batch_cap_bases); repeat_rich: see start() */
 	std::vector<std::thread> th;
 	mm_batch_t *cur = nullptr; uint64_t cur_bases = 0; int cur_slot = 0;
 	uint64_t n_records = 0, n_host_scanned = 0, n_stretches = 0, n_slow = 0; double t_start = 0;
@@ -387,7 +387,14 @@ struct TextReader {
 		/* ... and a text of more than five batches per lane gets larger ones, up to 500 Mb: every batch ends in the tail of its extension launch, and since the first read of a batch
 		 * starts from the value the batch in front predicts (PredBoard) nothing is gained from many small ones -- the headline set: 4.44 / 4.54 G bases/s at 300 Mb, 4.59 / 4.60 at
 		 * 400, 4.65 / 4.68 at 500, 4.59 at 600 (profiles/round6_batch_size.txt) */
-		else { const uint64_t est_bases = src->delim == '@' ? src->n / 2 : src->n; max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(std::min<uint64_t>(500000000ull, std::max<uint64_t>(max_bases, cap_bases)), est_bases / (all_lanes * 5))); }
+		else {
+			/* ... sooner on a repeat-rich reference (`repeat_rich`: the last occurrence threshold of the index, what -f 0.001 makes of the minimizer counts, at 64 and more -- 113 on the
+			 * hard-repeat human-size reference, 24 on the headline one with its 5 % of repeats, 12 and 10 on the dm6- and E.coli-size ones): there a launch lasts as long as the
+			 * read with the most chains, every batch pays that tail once, and seven batches of 443 Mb map the 3.1 Gb of the hard-repeat set at 2.03 - 2.10 G bases/s where eleven
+			 * of 300 Mb make 1.72 (600 Mb: 1.91, 150 Mb: 1.26); the dm6-size set, whose launches have no such tail, loses 4 % with seven batches instead of ten */
+			const uint64_t est_bases = src->delim == '@' ? src->n / 2 : src->n, per = repeat_rich ? 2 * all_lanes - 1 : all_lanes * 5;
+			max_bases = std::max<uint64_t>(max_bases, std::min<uint64_t>(std::min<uint64_t>(500000000ull, std::max<uint64_t>(max_bases, cap_bases)), est_bases / per));
+		}
 		/* pieces: the first three per device short (64 MB), so that the first lanes have a batch to work on early; several devices: no longer than a batch */
 		uint64_t first_len = std::min<uint64_t>(chunk_bytes, 64ull << 20), later_len = chunk_bytes;
 		if(nd > 1 && !getenv("MM_CHUNK_BYTES")) { later_len = std::min<uint64_t>(later_len, std::max<uint64_t>(1ull << 20, max_bases)); first_len = std::min(first_len, later_len); }

@@ -2421,7 +2421,7 @@ static int align_text(mm_align_t *a, const std::shared_ptr<TextSrc> &src, const 
 	if(lanes <= 0) lanes = default_lanes();
 	if(!a->chunk_pool) a->chunk_pool = new ChunkPool();
 	TextReader rd; rd.dctx = device_slots(a); rd.src = src; rd.min_len = a->o.min_len; rd.keep_qual = a->o.keep_qual; rd.lanes = lanes;
-	rd.cap_bases = std::min<uint64_t>(1000000000ull, batch_cap_bases(a, lanes));
+	rd.cap_bases = std::min<uint64_t>(1000000000ull, batch_cap_bases(a, lanes)); rd.repeat_rich = a->mi->n_occ > 0 && a->mi->occ[a->mi->n_occ - 1] >= 64;
 	if(!rd.start()) { fprintf(stderr, "[minialign_amd] reader: no stream / staging memory\n"); return 1; }
 	bool err = false;
 	{
